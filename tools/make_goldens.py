@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""Generate the committed golden vectors under tests/golden/ by running the REAL reference.
+
+Runs only in the build container (needs /root/reference, which never travels to the GPU box):
+  * imports /root/reference/pyani/tetra.py unmodified via importlib, with tools/bio_shim standing in for
+    Biopython's FASTA reader (the shim holds no hot-path arithmetic);
+  * records the reference's internal k-mer count dicts by handing it a recording ``collections`` namespace;
+  * writes inputs (gzipped copies of the data files the reference's own tests hold, plus small hand-made
+    edge-case FASTA files and the repo's seeded synthetic genomes) and expected outputs (integer counts,
+    Z-scores and correlation matrices as C99 hex floats => exact) as JSON fixtures.
+
+Fixtures are DATA only — no reference source text is written anywhere.
+
+Usage: python tools/make_goldens.py [--skip-large]
+"""
+import argparse
+import gzip
+import importlib.util
+import json
+import random
+import shutil
+import sys
+import tarfile
+import types
+from collections import defaultdict
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+REF = Path("/root/reference")
+GOLD = ROOT / "tests" / "golden"
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tools" / "bio_shim"))
+
+KMERS = {k: ["".join(p) for p in __import__("itertools").product("ACGT", repeat=k)] for k in (2, 3, 4)}
+
+
+def load_reference_tetra():
+    spec = importlib.util.spec_from_file_location("ref_tetra", REF / "pyani" / "tetra.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    # recording stand-in for the `collections` name inside the reference module
+    created = []
+
+    def recording_defaultdict(factory):
+        d = defaultdict(factory)
+        created.append(d)
+        return d
+
+    mod.collections = types.SimpleNamespace(defaultdict=recording_defaultdict)
+    return mod, created
+
+
+def gz_copy(src: Path, dst: Path):
+    dst.parent.mkdir(parents=True, exist_ok=True)
+    with open(src, "rb") as fi, open(dst, "wb") as raw:
+        with gzip.GzipFile(filename="", mode="wb", fileobj=raw, mtime=0, compresslevel=9) as fo:
+            shutil.copyfileobj(fi, fo)
+
+
+def gunzip_to(src: Path, dst: Path):
+    with gzip.open(src, "rb") as fi, open(dst, "wb") as fo:
+        shutil.copyfileobj(fi, fo)
+
+
+def run_reference(ref, created, fasta: Path):
+    del created[:]
+    z = ref.calculate_tetra_zscore(fasta)
+    mono, di, tri, tet = created[:4]
+    return {
+        "c2": [int(di.get(k, 0)) for k in KMERS[2]],
+        "c3": [int(tri.get(k, 0)) for k in KMERS[3]],
+        "c4": [int(tet.get(k, 0)) for k in KMERS[4]],
+        "order": list(z.keys()),
+        "z": {k: float(v).hex() for k, v in z.items()},
+    }, z
+
+
+def write_edge_cases(edge: Path):
+    edge.mkdir(parents=True, exist_ok=True)
+    rnd = random.Random(20250228)
+
+    def rs(n, alphabet="ACGT"):
+        return "".join(rnd.choice(alphabet) for _ in range(n))
+
+    def fasta(path, recs, width=60):
+        with open(path, "w") as fh:
+            for title, s in recs:
+                fh.write(f">{title}\n")
+                for i in range(0, len(s), width):
+                    fh.write(s[i:i + width] + "\n")
+
+    fasta(edge / "e01_tiny_records.fna",
+          [("r_empty", ""), ("r1", "A"), ("r2", "CG"), ("r3", "TGA"), ("r4", "ACGT"), ("r5", "GATTA"),
+           ("r6", "CAAGT"), ("r_long", rs(3000))])
+    body = rs(4000)
+    mixed = "".join(c.lower() if rnd.random() < 0.4 else c for c in body)
+    amb = list(mixed)
+    for _ in range(60):
+        amb[rnd.randrange(len(amb))] = rnd.choice("NRYKMSWBDHVnryk-*")
+    fasta(edge / "e02_lower_iupac.fna", [("mixedcase iupac", "".join(amb)), ("second", rs(2500).lower())], width=61)
+    fasta(edge / "e03_n_runs.fna",
+          [("allN", "N" * 137), ("runs", rs(900) + "N" * 50 + rs(3) + "N" + rs(2) + "NN" + rs(1) + "N" + rs(2200)),
+           ("edgeN", "N" + rs(1500) + "N")])
+    # two genomes over a 3-letter alphabet: identical (incomplete) key sets -> correlation over < 256 keys
+    fasta(edge / "e04_acg_only_a.fna", [("acg_a", rs(6000, "ACG"))])
+    fasta(edge / "e05_acg_only_b.fna", [("acg_b1", rs(3500, "ACG")), ("acg_b2", rs(3100, "ACG"))])
+    # homopolymer + the sd == 0 branch (CAAGT alone: exp=1, sd=0 -> z = 1/(den*den))
+    fasta(edge / "e06_sd_zero.fna", [("only", "CAAGT")])
+    fasta(edge / "e07_homopolymer.fna", [("polyA", "A" * 333), ("polyGC", "GC" * 200)])
+    # whitespace inside sequence lines, CRLF, blank lines, leading junk before the first header
+    with open(edge / "e08_whitespace.fna", "w", newline="") as fh:
+        fh.write("junk before header is ignored\n")
+        s = rs(2600)
+        fh.write(">ws record one\r\n")
+        for i in range(0, 1300, 50):
+            fh.write(s[i:i + 25] + " " + s[i + 25:i + 50] + "\r\n")
+        fh.write("\n>ws2\n" + s[1300:] + "\n\n")
+
+
+def corr_json(ref, zs):
+    df = ref.calculate_correlations(zs)
+    labels = list(df.index)
+    return {"labels": labels, "matrix": [[float(df.loc[a, b]).hex() for b in labels] for a in labels]}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--skip-large", action="store_true", help="skip the 2.4-4 Mb genomes (faster)")
+    args = ap.parse_args()
+    ref, created = load_reference_tetra()
+    tmp = ROOT / "gpurun_out" / "_goldens_tmp"
+    tmp.mkdir(parents=True, exist_ok=True)
+    out = {}
+
+    # ---- (1) data files held by the reference's own tests ------------------------------------------------
+    groups = {
+        "caulobacter": [REF / "tests/fixtures/sequences/NC_002696.fna", REF / "tests/fixtures/sequences/NC_011916.fna"],
+        "blochmannia": sorted((REF / "tests/fixtures/legacy/ANI_input").glob("*.fna")),
+        "concordance": sorted((REF / "tests/fixtures/concordance").glob("*.fna")),
+    }
+    if args.skip_large:
+        groups.pop("caulobacter"), groups.pop("concordance")
+    for grp, files in groups.items():
+        zs = {}
+        for f in files:
+            gz_copy(f, GOLD / "genomes" / grp / (f.name + ".gz"))
+            rec, z = run_reference(ref, created, f)
+            out[f"{grp}/{f.stem}"] = rec
+            zs[f.stem] = z
+            print("ref tetra", grp, f.stem, len(z), flush=True)
+        out[f"{grp}/__corr__"] = corr_json(ref, zs)
+
+    # reference's own committed targets for this path (data)
+    tgt = GOLD / "ref_targets"
+    tgt.mkdir(parents=True, exist_ok=True)
+    shutil.copyfile(REF / "tests/fixtures/targets/tetra/zscore.json", tgt / "tetra_zscore_NC_002696.json")
+    shutil.copyfile(REF / "tests/fixtures/targets/tetra/correlation.tab", tgt / "tetra_correlation_2x2.tab")
+    shutil.copyfile(REF / "tests/target_TETRA_output/TETRA_correlations.tab", tgt / "TETRA_correlations_caulobacter_4x4.tab")
+    shutil.copyfile(REF / "tests/test_targets/legacy_scripts/TETRA_mpl/TETRA_correlations.tab",
+                    tgt / "TETRA_correlations_blochmannia_6x6.tab")
+    shutil.copyfile(REF / "tests/fixtures/concordance/jspecies_output.tab", tgt / "jspecies_output.tab")
+
+    # ---- (2) hand-made edge cases ------------------------------------------------------------------------
+    edge = GOLD / "edge"
+    write_edge_cases(edge)
+    zs_acg = {}
+    for f in sorted(edge.glob("*.fna")):
+        rec, z = run_reference(ref, created, f)
+        out[f"edge/{f.stem}"] = rec
+        if f.stem.startswith(("e04", "e05")):
+            zs_acg[f.stem] = z
+    out["edge/__corr_acg__"] = corr_json(ref, zs_acg)
+
+    # ---- (3) the repo's seeded synthetic CI set (N=8, L=50 000) ------------------------------------------
+    from pyani_amd import synth
+    cfg = synth.SETS["CI"]
+    zs = {}
+    for g in range(cfg["n"]):
+        seq, off = synth.genome(cfg["seed"], cfg["n"], g, cfg["L"])
+        p = tmp / f"{synth.genome_name(g)}.fna"
+        synth.write_fasta(p, seq, off, synth.genome_name(g))
+        rec, z = run_reference(ref, created, p)
+        out[f"synthCI/{p.stem}"] = rec
+        zs[p.stem] = z
+    out["synthCI/__corr__"] = corr_json(ref, zs)
+
+    with open(GOLD / "tetra_goldens.json", "w") as fh:
+        json.dump(out, fh, indent=0, sort_keys=True)
+    print("wrote", GOLD / "tetra_goldens.json", len(out), "entries")
+
+
+if __name__ == "__main__":
+    main()
