@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the hot path: TETRA N x N matrix on synthetic ~5 Mb genomes (BASELINE.json
+configs[1], SURVEY.md §8(d) set C2), genome-pairs/s on MI355X, with the kernel roofline and the CPU baseline.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+A "step" = one full pass of the path over the batch, inputs already resident in HBM (2-bit codes + 1-bit mask):
+  N = 1 : count kernel -> finalize/Z -> stats -> Pearson -> D2H of Z and the matrix       (200 genomes, 19 900 pairs)
+  N > 1 : weak scaling, 200 genomes per GPU (job = 200*N genomes, all 200N(200N-1)/2 pairs): every rank counts its
+          genomes, RCCL all-gather of Z (N*200 x 256 f64 + presence), every rank computes its row block of the
+          matrix, RCCL all-gather of the rows.  (two collectives, both tiny.)
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md); 6290 GB/s measured copy
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--genomes", type=int, default=200, help="genomes per GPU (C2: 200)")
+    ap.add_argument("--length", type=int, default=5_000_000, help="ancestor length in bases (C2: 5 Mb)")
+    ap.add_argument("--seed", type=int, default=20250228)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-genomes", type=int, default=2, help="genomes timed by the CPU baseline leg")
+    return ap.parse_args()
+
+
+def cpu_baseline(eng_z, sample, n_genomes, n_pairs):
+    """Time the pure-Python port of pyani's TETRA (oracle/tetra_port.py — checker code, used here ONLY as the
+    reported CPU baseline) on a bounded sample and extrapolate to the whole job: pyani runs TETRA sequentially on
+    one core (scripts/average_nucleotide_identity.py:606-608), so the job time is n*t_genome + pairs*t_pair."""
+    sys.path.insert(0, str(ROOT / "oracle"))
+    import tetra_port
+    from pyani_amd.tetra import TETRAMERS
+    t_gen, checked = [], 0
+    zs = {}
+    for k, (seq, off) in enumerate(sample):
+        recs = [bytes(seq[int(off[r]):int(off[r + 1])]).decode("latin-1") for r in range(len(off) - 1)]
+        t0 = time.perf_counter()
+        z = tetra_port.zscores_from_counts(*tetra_port.count_kmers(recs))
+        t_gen.append(time.perf_counter() - t0)
+        zs[f"g{k}"] = z
+        # full-size parity check while we are here: the port's Z == the GPU's Z, bit for bit
+        gpu = {TETRAMERS[t]: float(eng_z[k, t]) for t in range(256)}
+        checked += int(all(gpu[t] == v for t, v in z.items()) and len(z) == 256)
+    # correlation cost: 40 genomes' worth of GPU Z vectors -> 780 pairs
+    m = min(40, eng_z.shape[0])
+    zdicts = {f"o{k:03d}": {TETRAMERS[t]: float(eng_z[k, t]) for t in range(256)} for k in range(m)}
+    t0 = time.perf_counter()
+    tetra_port.correlations(zdicts)
+    t_pair = (time.perf_counter() - t0) / (m * (m - 1) / 2)
+    t_genome = sum(t_gen) / len(t_gen)
+    total = n_genomes * t_genome + n_pairs * t_pair
+    return {
+        "value": n_pairs / total, "unit": "genome-pairs/s", "cores": 1, "kind": "port",
+        "sample": f"{len(sample)} of {n_genomes} genomes counted+Z-scored by oracle/tetra_port.py "
+                  f"({t_genome:.2f} s/genome), {m * (m - 1) // 2} pairs correlated ({t_pair * 1e3:.3f} ms/pair); "
+                  f"extrapolated linearly to {n_genomes} genomes + {n_pairs} pairs = {total:.0f} s (pyani runs TETRA on 1 core)",
+        "job_seconds_extrapolated": total, "gpu_parity_on_sample": f"{checked}/{len(sample)} genomes bit-identical",
+    }
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("launch multi-GPU runs with torch.distributed.run (see module docstring)")
+        args.gpus = world
+    import torch
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X: the engine has no CPU fallback")
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    from pyani_amd import _lib, synth
+    from pyani_amd.engine import Engine
+    eng = Engine(local)
+    n_local, n_total = args.genomes, args.genomes * world
+    g0 = rank * n_local
+
+    # ---- synthetic inputs -> HBM (outside the timed region) ----------------------------------------------------
+    t_prep = time.perf_counter()
+    with ThreadPoolExecutor(max(1, min(16, (os.cpu_count() or 2) // max(1, world)))) as ex:
+        data = list(ex.map(lambda g: synth.genome(args.seed, n_total, g, args.length), range(g0, g0 + n_local)))
+        ids = list(ex.map(lambda d: eng.add_genome(d[0], d[1]), data))
+    eng.upload()
+    order = np.argsort(ids)
+    data = [data[k] for k in order]
+    ids_arr = np.ascontiguousarray(sorted(ids), dtype=np.int32)
+    t_prep = time.perf_counter() - t_prep
+    alg_bytes, bases = eng.tetra_algorithmic_bytes(ids_arr.tolist())
+
+    if world > 1:
+        z_loc = torch.empty((n_local, 256), dtype=torch.float64, device="cuda")
+        p_loc = torch.empty((n_local, 256), dtype=torch.uint8, device="cuda")
+        z_all = torch.empty((n_total, 256), dtype=torch.float64, device="cuda")
+        p_all = torch.empty((n_total, 256), dtype=torch.uint8, device="cuda")
+        rows = torch.empty((n_local, n_total), dtype=torch.float64, device="cuda")
+        corr_all = torch.empty((n_total, n_total), dtype=torch.float64, device="cuda")
+
+    def step():
+        if world == 1:
+            eng.tetra_matrix_enqueue(ids_arr)
+        else:
+            eng.tetra_zscores_dev(ids_arr.tolist(), z_loc.data_ptr(), p_loc.data_ptr())
+            dist.all_gather_into_tensor(z_all, z_loc)
+            dist.all_gather_into_tensor(p_all, p_loc)
+            torch.cuda.current_stream().synchronize()
+            eng.tetra_corr_rows_dev(z_all.data_ptr(), p_all.data_ptr(), n_total, g0, n_local, rows.data_ptr())
+            dist.all_gather_into_tensor(corr_all, rows)
+
+    def fence():
+        eng.sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    eng.profile_reset()
+    eng.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    eng.profile_enable(False)
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    prof = {eng.kernel_name(k): eng.profile_get(k) for k in range(4)}
+    count_ms, count_n = prof["tetra_count_kernel"]
+    if rank == 0:
+        if world == 1:
+            z, present, corr = eng.tetra_matrix_fetch(n_local)
+        else:
+            z, corr = z_all.cpu().numpy(), corr_all.cpu().numpy()
+        assert np.isfinite(corr).all() and (np.diag(corr) == 1.0).all() and (corr == corr.T).all()
+        pairs = n_total * (n_total - 1) // 2
+        ms_step = elapsed / args.steps * 1e3
+        avg_count_s = count_ms / max(count_n, 1) * 1e-3
+        achieved = alg_bytes / avg_count_s / 1e9 if count_n else 0.0
+        traffic = None
+        pmc = ROOT / "profiles" / "pmc_tetra_count.json"
+        if pmc.exists() and world == 1 and (args.genomes, args.length, args.seed) == (200, 5_000_000, 20250228):
+            traffic = json.loads(pmc.read_text()).get("hbm_bytes_per_launch")
+        out = {
+            "metric": "genome-pairs/sec for the TETRA N x N matrix (counts + Z + Pearson), inputs resident in HBM",
+            "value": pairs / (elapsed / args.steps), "unit": "genome-pairs/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u64 counts + f64 Z/Pearson", "data": "synthetic",
+            "config": {
+                "workload": f"C2: TETRA on {n_total} synthetic ~{args.length / 1e6:g} Mb genomes "
+                            f"(SURVEY.md §8(d) generator, seed {args.seed}), {pairs} unordered pairs",
+                "genomes_per_gpu": n_local, "genomes": n_total, "bases_per_gpu": int(bases), "pairs": pairs,
+                "parallelism": "1 process/GPU; genomes sharded; RCCL all-gather of Z then of matrix rows" if world > 1 else "1 GPU",
+                "wall_s_matrix": elapsed / args.steps, "genomes_per_s": n_total / (elapsed / args.steps),
+                "host_prep_s": t_prep,
+            },
+            "roofline": {
+                "bound": "hbm", "kernel": "tetra_count_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "algorithmic_bytes_per_launch": int(alg_bytes), "avg_launch_us": avg_count_s * 1e6, "launches": int(count_n),
+                "frac_of_measured_copy_peak_6290": achieved / 6290.0,
+                "other_kernels_us": {k: (v[0] / max(v[1], 1)) * 1e3 for k, v in prof.items() if k != "tetra_count_kernel"},
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(z, data[: args.cpu_genomes], n_total, pairs)
+            out["cpu_baseline"]["speedup_gpu_over_cpu_job"] = out["value"] / out["cpu_baseline"]["value"]
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()

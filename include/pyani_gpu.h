@@ -1,0 +1,115 @@
+/* pyani_gpu.h — C ABI of libpyani_gpu.so, the MI355X (gfx950) engine behind pyani's hot path.
+ *
+ * pyani (the reference) is 100 % Python and has no FFI: the boundary this library slots behind is the
+ * module API of pyani/tetra.py (and, next, the process/file boundary between pyani/anim.py and
+ * nucmer/delta-filter).  Each entry point below names the reference interface it replaces (file:line,
+ * relative to the reference checkout).  INTEGRATION.md shows the ctypes stub a pyani maintainer would add.
+ *
+ * Conventions
+ *   - plain C types only; the caller owns every buffer; the library keeps no caller pointer after return.
+ *   - every function returns PG_OK (0) or a negative PG_E_* code; pg_last_error(ctx) has the message.
+ *   - no exceptions cross the ABI; there is NO CPU fallback: without a usable GPU pg_create fails.
+ *   - one context per process and device; calls on one context must not be concurrent.
+ *   - k-mer index convention: first base most significant, A=0 C=1 G=2 T=3 (== sorted() string order
+ *     used by pyani/tetra.py:176), i.e. "ACGT" -> 0*64 + 1*16 + 2*4 + 3.
+ */
+#ifndef PYANI_GPU_H
+#define PYANI_GPU_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PG_OK 0
+#define PG_E_ARG (-1)      /* bad argument */
+#define PG_E_NODEVICE (-2) /* no usable HIP device (the product path never falls back to CPU) */
+#define PG_E_HIP (-3)      /* HIP runtime error, see pg_last_error */
+#define PG_E_IO (-4)       /* file could not be read */
+#define PG_E_NOMEM (-5)
+#define PG_E_KEYSET (-6)   /* genomes have different observed-tetramer key sets: pyani raises AssertionError (tetra.py:174-175) */
+#define PG_E_EMPTY (-7)    /* empty key set: pyani raises ZeroDivisionError (tetra.py:181) */
+#define PG_E_RNA (-8)      /* sequence contains U/u: Biopython complements it asymmetrically (U->A); unsupported */
+
+typedef struct pg_ctx pg_ctx;
+
+/* ---- context ------------------------------------------------------------------------------------------- */
+const char* pg_version(void);
+/* device: HIP device ordinal (use LOCAL_RANK for one-process-per-GPU jobs). */
+int pg_create(pg_ctx** out, int device);
+void pg_destroy(pg_ctx* ctx);
+const char* pg_last_error(const pg_ctx* ctx);
+/* blocks until all work queued by this context has finished */
+int pg_sync(pg_ctx* ctx);
+
+/* ---- genome store: 2-bit codes + 1-bit "clean" mask resident in HBM ------------------------------------- */
+/* Replaces Bio.SeqIO.parse(filename, "fasta") + str(rec.seq).upper() (pyani/tetra.py:98-99) and
+ * pyani_files.get_sequence_lengths (pyani/pyani_files.py:128-142: total_len = sum of len(record)).
+ * seq: concatenated record sequences (ASCII, any case, IUPAC allowed); rec_off[0..n_rec]: record boundaries. */
+int pg_add_genome(pg_ctx* ctx, const uint8_t* seq, const uint64_t* rec_off, uint32_t n_rec, int32_t* genome_id_out);
+/* Same, reading a FASTA file (records = '>' blocks; whitespace inside sequence lines removed). */
+int pg_add_fasta(pg_ctx* ctx, const char* path, int32_t* genome_id_out, uint64_t* total_len_out, uint32_t* n_rec_out);
+int pg_genome_count(const pg_ctx* ctx);
+int pg_genome_length(const pg_ctx* ctx, int32_t genome_id, uint64_t* total_len_out, uint32_t* n_rec_out);
+/* Drop all genomes (device arena is kept for reuse). */
+int pg_clear_genomes(pg_ctx* ctx);
+/* Push not-yet-resident genomes to HBM now (otherwise done lazily by the first compute call). */
+int pg_upload(pg_ctx* ctx);
+/* Bytes of the packed representation the count kernel streams for these genomes (2-bit codes + 1-bit mask,
+ * padding excluded): the "algorithmic bytes" of SURVEY.md §8(d).  genome_ids == NULL means all genomes. */
+int pg_tetra_algorithmic_bytes(const pg_ctx* ctx, const int32_t* genome_ids, uint32_t n, uint64_t* bytes_out,
+                               uint64_t* bases_out);
+
+/* ---- TETRA ----------------------------------------------------------------------------------------------
+ * kernel 1: exact integer k-mer counts over both strands, including the reference's quirk that the last
+ * tetranucleotide of each strand of each record is not counted.  Replaces the counting loops of
+ * calculate_tetra_zscore (pyani/tetra.py:98-116).  c2: n x 16, c3: n x 64, c4: n x 256 (host buffers). */
+int pg_tetra_counts(pg_ctx* ctx, const int32_t* genome_ids, uint32_t n, uint64_t* c2, uint64_t* c3, uint64_t* c4);
+
+/* Z-scores from counts in the reference's IEEE-754 operation order (pyani/tetra.py:119-138), computed on the
+ * device in fp64 without FMA contraction.  z: n x 256; present: n x 256 (1 where the tetramer is a key of the
+ * reference's result dict, i.e. c4 > 0). */
+int pg_tetra_zscores(pg_ctx* ctx, const uint64_t* c2, const uint64_t* c3, const uint64_t* c4, uint32_t n, double* z,
+                     uint8_t* present);
+
+/* kernel 2: all-vs-all Pearson matrix, bit-identical to calculate_correlations (pyani/tetra.py:158-194):
+ * sequential sums in tetramer order, diagonal = 1.0.  out: n x n row-major (host).
+ * PG_E_KEYSET if the present[] rows differ, PG_E_EMPTY if they are all-zero. */
+int pg_tetra_corr(pg_ctx* ctx, const double* z, const uint8_t* present, uint32_t n, double* out);
+
+/* Fused, device-resident pipeline for a batch of stored genomes: counts -> Z -> Pearson with no host round
+ * trip in between; replaces calculate_tetra (scripts/average_nucleotide_identity.py:582-612).
+ * Any of z_out / present_out / corr_out may be NULL.  Row/column order = order of genome_ids. */
+int pg_tetra_matrix(pg_ctx* ctx, const int32_t* genome_ids, uint32_t n, double* z_out, uint8_t* present_out,
+                    double* corr_out);
+/* Asynchronous form used for throughput runs: queues one pass (results land in an internal pinned buffer,
+ * fetched by pg_tetra_matrix_fetch after pg_sync).  Queue any number of passes, then pg_sync once. */
+int pg_tetra_matrix_enqueue(pg_ctx* ctx, const int32_t* genome_ids, uint32_t n);
+int pg_tetra_matrix_fetch(pg_ctx* ctx, uint32_t n, double* z_out, uint8_t* present_out, double* corr_out);
+
+/* Multi-GPU building blocks (one process per GPU; the exchange itself is an RCCL all-gather done by the host
+ * layer on these device buffers — SURVEY.md §8(e)).  d_* are DEVICE pointers owned by the caller.
+ * Both calls return after their work has completed on the device. */
+int pg_tetra_zscores_dev(pg_ctx* ctx, const int32_t* genome_ids, uint32_t n, double* d_z, uint8_t* d_present);
+/* rows [row0, row0+nrows) of the n x n matrix from the full (all-gathered) d_z / d_present; d_out: nrows x n */
+int pg_tetra_corr_rows_dev(pg_ctx* ctx, const double* d_z, const uint8_t* d_present, uint32_t n, uint32_t row0,
+                           uint32_t nrows, double* d_out);
+
+/* ---- measurement ---------------------------------------------------------------------------------------- */
+/* When enabled, every kernel launch is bracketed by HIP events on the context's stream. */
+int pg_profile_enable(pg_ctx* ctx, int on);
+int pg_profile_reset(pg_ctx* ctx);
+#define PG_K_TETRA_COUNT 0
+#define PG_K_TETRA_FINALIZE 1
+#define PG_K_TETRA_STATS 2
+#define PG_K_TETRA_PAIRS 3
+#define PG_K__COUNT 4
+/* total milliseconds and number of launches of kernel `which` since the last reset (synchronises). */
+int pg_profile_get(pg_ctx* ctx, int which, double* total_ms_out, uint64_t* launches_out);
+const char* pg_kernel_name(int which);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PYANI_GPU_H */

@@ -1,0 +1,64 @@
+"""ctypes binding of libpyani_gpu.so (include/pyani_gpu.h).  There is no CPU fallback: if the library is not
+built, or no MI355X is visible when a context is created, this raises."""
+import ctypes
+from pathlib import Path
+
+LIB_PATH = Path(__file__).resolve().parent / "libpyani_gpu.so"
+
+PG_OK, PG_E_ARG, PG_E_NODEVICE, PG_E_HIP, PG_E_IO, PG_E_NOMEM, PG_E_KEYSET, PG_E_EMPTY, PG_E_RNA = 0, -1, -2, -3, -4, -5, -6, -7, -8
+K_TETRA_COUNT, K_TETRA_FINALIZE, K_TETRA_STATS, K_TETRA_PAIRS = 0, 1, 2, 3
+
+# every symbol declared in include/pyani_gpu.h: (name, restype, argtypes)
+_vp, _i32, _u32, _u64, _int = ctypes.c_void_p, ctypes.c_int32, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_int
+_P = ctypes.POINTER
+SIGNATURES = {
+    "pg_version": (ctypes.c_char_p, []),
+    "pg_create": (_int, [_P(_vp), _int]),
+    "pg_destroy": (None, [_vp]),
+    "pg_last_error": (ctypes.c_char_p, [_vp]),
+    "pg_sync": (_int, [_vp]),
+    "pg_add_genome": (_int, [_vp, _vp, _vp, _u32, _P(_i32)]),
+    "pg_add_fasta": (_int, [_vp, ctypes.c_char_p, _P(_i32), _P(_u64), _P(_u32)]),
+    "pg_genome_count": (_int, [_vp]),
+    "pg_genome_length": (_int, [_vp, _i32, _P(_u64), _P(_u32)]),
+    "pg_clear_genomes": (_int, [_vp]),
+    "pg_upload": (_int, [_vp]),
+    "pg_tetra_algorithmic_bytes": (_int, [_vp, _vp, _u32, _P(_u64), _P(_u64)]),
+    "pg_tetra_counts": (_int, [_vp, _vp, _u32, _vp, _vp, _vp]),
+    "pg_tetra_zscores": (_int, [_vp, _vp, _vp, _vp, _u32, _vp, _vp]),
+    "pg_tetra_corr": (_int, [_vp, _vp, _vp, _u32, _vp]),
+    "pg_tetra_matrix": (_int, [_vp, _vp, _u32, _vp, _vp, _vp]),
+    "pg_tetra_matrix_enqueue": (_int, [_vp, _vp, _u32]),
+    "pg_tetra_matrix_fetch": (_int, [_vp, _u32, _vp, _vp, _vp]),
+    "pg_tetra_zscores_dev": (_int, [_vp, _vp, _u32, _vp, _vp]),
+    "pg_tetra_corr_rows_dev": (_int, [_vp, _vp, _vp, _u32, _u32, _u32, _vp]),
+    "pg_profile_enable": (_int, [_vp, _int]),
+    "pg_profile_reset": (_int, [_vp]),
+    "pg_profile_get": (_int, [_vp, _int, _P(ctypes.c_double), _P(_u64)]),
+    "pg_kernel_name": (ctypes.c_char_p, [_int]),
+}
+
+_lib = None
+
+
+class PyaniGpuError(RuntimeError):
+    """Any failure reported by libpyani_gpu.so (status code in .code)."""
+
+    def __init__(self, code, msg):
+        super().__init__(f"libpyani_gpu error {code}: {msg}")
+        self.code = code
+
+
+def load():
+    """Load the shared library and declare all prototypes; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise ImportError(f"{LIB_PATH} not built — run `python -m pyani_amd.build` (needs hipcc); "
+                              "pyani_amd has no CPU fallback")
+        lib = ctypes.CDLL(str(LIB_PATH))
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib

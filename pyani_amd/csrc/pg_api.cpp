@@ -1,0 +1,615 @@
+// pg_api.cpp — C ABI of libpyani_gpu.so: context, genome store (FASTA -> 2-bit/1-bit packed arena in HBM) and the
+// TETRA entry points declared in include/pyani_gpu.h.  Host-side C++ only; kernels live in pg_tetra.hip.
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <thread>
+
+#include "pg_internal.h"
+
+int pg_fail(pg_ctx* ctx, int code, const std::string& msg) {
+  if (ctx) ctx->err = msg;
+  return code;
+}
+
+static const char* const KERNEL_NAMES[PG_K__COUNT] = {"tetra_count_kernel", "tetra_finalize_kernel", "tetra_stats_kernel",
+                                                      "tetra_pairs_kernel"};
+
+// ---- profiling ----------------------------------------------------------------------------------------------
+void pg_prof_begin(pg_ctx* ctx, int which) {
+  if (!ctx->profiling) return;
+  PgEventPair p;
+  p.which = which;
+  if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return;
+  (void)hipEventRecord(p.a, ctx->stream);
+  ctx->events.push_back(p);
+}
+void pg_prof_end(pg_ctx* ctx) {
+  if (!ctx->profiling || ctx->events.empty()) return;
+  (void)hipEventRecord(ctx->events.back().b, ctx->stream);
+}
+static void prof_drain(pg_ctx* ctx) {
+  for (auto& p : ctx->events) {
+    float ms = 0.f;
+    if (hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+      ctx->prof_ms[p.which] += ms;
+      ctx->prof_n[p.which] += 1;
+    }
+    (void)hipEventDestroy(p.a);
+    (void)hipEventDestroy(p.b);
+  }
+  ctx->events.clear();
+}
+
+// ---- packing --------------------------------------------------------------------------------------------------
+namespace {
+
+struct Lut {
+  uint8_t v[256];
+  Lut() {
+    std::memset(v, 4, sizeof(v));
+    v['A'] = v['a'] = 0;
+    v['C'] = v['c'] = 1;
+    v['G'] = v['g'] = 2;
+    v['T'] = v['t'] = 3;
+    v['U'] = v['u'] = 5;  // flagged: Biopython's reverse complement maps U->A (asymmetric), unsupported
+  }
+};
+const Lut LUT;
+
+inline uint32_t rc4_index(uint32_t x) {
+  uint32_t c = 255u - x, r = 0;
+  for (int i = 0; i < 4; ++i) { r = (r << 2) | (c & 3u); c >>= 2; }
+  return r;
+}
+
+// Build the packed stream of one genome.  Returns PG_OK or PG_E_RNA.
+int pack_genome(const uint8_t* seq, const uint64_t* rec_off, uint32_t n_rec, PgGenome& g) {
+  g.n_rec = n_rec;
+  g.total_len = n_rec ? rec_off[n_rec] - rec_off[0] : 0;
+  g.stream_len = g.total_len + (n_rec > 1 ? n_rec - 1 : 0);
+  g.padded_len = ((g.stream_len + 1 + PG_SUPER - 1) / PG_SUPER) * PG_SUPER;  // >= 1 dirty base at the end
+  g.codes.assign(g.padded_len / 16, 0u);
+  g.mask.assign(g.padded_len / 32, 0u);
+  g.quirk.fill(0);
+  uint64_t s = 0;  // stream position
+  bool has_u = false;
+  for (uint32_t r = 0; r < n_rec; ++r) {
+    const uint8_t* p = seq + rec_off[r];
+    const uint64_t L = rec_off[r + 1] - rec_off[r];
+    if (r > 0) ++s;  // separator stays dirty (zero-initialised)
+    uint64_t i = 0;
+    // head: until s is 32-aligned
+    auto put = [&](uint64_t pos, uint8_t c) {
+      if (c < 4) {
+        g.codes[pos >> 4] |= (uint32_t)c << (2 * (pos & 15));
+        g.mask[pos >> 5] |= 1u << (pos & 31);
+      } else if (c == 5) {
+        has_u = true;
+      }
+    };
+    while (i < L && (s & 31)) put(s++, LUT.v[p[i++]]);
+    // body: 32 bases -> two code words + one mask word
+    while (i + 32 <= L) {
+      uint64_t cw = 0;
+      uint32_t mw = 0;
+      for (int k = 0; k < 32; ++k) {
+        const uint8_t c = LUT.v[p[i + k]];
+        const uint32_t ok = c < 4;
+        cw |= (uint64_t)(c & 3u & (0u - ok)) << (2 * k);
+        mw |= ok << k;
+        has_u |= (c == 5);
+      }
+      g.codes[s >> 4] = (uint32_t)cw;
+      g.codes[(s >> 4) + 1] = (uint32_t)(cw >> 32);
+      g.mask[s >> 5] = mw;
+      s += 32;
+      i += 32;
+    }
+    while (i < L) put(s++, LUT.v[p[i++]]);
+    // the reference never counts the LAST tetranucleotide of either strand of a record (tetra.py:106):
+    // forward strand: last4(rec); reverse strand: its last window is rc(first4(rec)).
+    if (L >= 4) {
+      uint32_t f = 0, l = 0;
+      bool fok = true, lok = true;
+      for (int k = 0; k < 4; ++k) {
+        const uint8_t cf = LUT.v[p[k]], cl = LUT.v[p[L - 4 + k]];
+        fok = fok && cf < 4;
+        lok = lok && cl < 4;
+        f = f * 4 + (cf & 3u);
+        l = l * 4 + (cl & 3u);
+      }
+      if (lok) g.quirk[l] += 1;
+      if (fok) g.quirk[rc4_index(f)] += 1;
+    }
+  }
+  return has_u ? PG_E_RNA : PG_OK;
+}
+
+int read_file(const char* path, std::vector<uint8_t>& buf) {
+  FILE* fh = std::fopen(path, "rb");
+  if (!fh) return -1;
+  std::fseek(fh, 0, SEEK_END);
+  const long sz = std::ftell(fh);
+  std::fseek(fh, 0, SEEK_SET);
+  if (sz < 0) { std::fclose(fh); return -1; }
+  buf.resize((size_t)sz);
+  const size_t got = sz ? std::fread(buf.data(), 1, (size_t)sz, fh) : 0;
+  std::fclose(fh);
+  return got == (size_t)sz ? 0 : -1;
+}
+
+// FASTA text -> concatenated record sequences + offsets.  Record = '>' line + following lines; lines before the
+// first '>' are ignored; spaces, CR and line breaks are removed from sequence lines, trailing blanks stripped.
+void parse_fasta(const std::vector<uint8_t>& txt, std::vector<uint8_t>& seq, std::vector<uint64_t>& off) {
+  seq.clear();
+  off.clear();
+  seq.reserve(txt.size());
+  size_t i = 0;
+  const size_t n = txt.size();
+  bool in_rec = false;
+  while (i < n) {
+    size_t e = i;
+    while (e < n && txt[e] != '\n') ++e;
+    if (txt[i] == '>') {
+      off.push_back(seq.size());
+      in_rec = true;
+    } else if (in_rec) {
+      size_t end = e;
+      while (end > i && (txt[end - 1] == ' ' || txt[end - 1] == '\t' || txt[end - 1] == '\r' || txt[end - 1] == '\v' ||
+                         txt[end - 1] == '\f'))
+        --end;
+      for (size_t k = i; k < end; ++k)
+        if (txt[k] != ' ' && txt[k] != '\r') seq.push_back(txt[k]);
+    }
+    i = e + 1;
+  }
+  off.push_back(seq.size());
+  if (off.size() == 1) off.clear();  // no records at all
+}
+
+int add_packed(pg_ctx* ctx, PgGenome&& g, int32_t* id_out) {
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  g.arena_start = ctx->arena_used;
+  ctx->arena_used += g.padded_len;
+  ctx->genomes.push_back(std::move(g));
+  if (id_out) *id_out = (int32_t)ctx->genomes.size() - 1;
+  return PG_OK;
+}
+
+template <typename T>
+int dev_realloc(pg_ctx* ctx, T*& p, size_t n_new) {
+  if (p) PG_HIP(ctx, hipFree(p));
+  p = nullptr;
+  PG_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&p), n_new * sizeof(T)));
+  return PG_OK;
+}
+template <typename T>
+int host_realloc(pg_ctx* ctx, T*& p, size_t n_new) {
+  if (p) PG_HIP(ctx, hipHostFree(p));
+  p = nullptr;
+  PG_HIP(ctx, hipHostMalloc(reinterpret_cast<void**>(&p), n_new * sizeof(T), hipHostMallocDefault));
+  return PG_OK;
+}
+
+int ensure_batch_scratch(pg_ctx* ctx, uint32_t n) {
+  if (n > ctx->batch_cap) {
+    const uint32_t cap = std::max<uint32_t>(n, ctx->batch_cap * 2);
+    int rc;
+    if ((rc = dev_realloc(ctx, ctx->d_batch_gid, cap))) return rc;
+    if ((rc = dev_realloc(ctx, ctx->d_acc, (size_t)cap * PG_ACC_WORDS))) return rc;
+    if ((rc = dev_realloc(ctx, ctx->d_counts, (size_t)cap * PG_ACC_WORDS))) return rc;
+    if ((rc = dev_realloc(ctx, ctx->d_z, (size_t)cap * 256))) return rc;
+    if ((rc = dev_realloc(ctx, ctx->d_present, (size_t)cap * 256))) return rc;
+    if ((rc = dev_realloc(ctx, ctx->d_dev, (size_t)cap * 256))) return rc;
+    if ((rc = dev_realloc(ctx, ctx->d_ss, (size_t)cap))) return rc;
+    ctx->batch_cap = cap;
+    ctx->batch_ids.clear();
+  }
+  if (!ctx->d_flags) {
+    int rc;
+    if ((rc = dev_realloc(ctx, ctx->d_flags, 2))) return rc;
+  }
+  if (n > ctx->h_batch_cap) {
+    const uint32_t cap = std::max<uint32_t>(n, ctx->h_batch_cap * 2);
+    int rc;
+    if ((rc = host_realloc(ctx, ctx->h_z, (size_t)cap * 256))) return rc;
+    if ((rc = host_realloc(ctx, ctx->h_present, (size_t)cap * 256))) return rc;
+    if ((rc = host_realloc(ctx, ctx->h_counts, (size_t)cap * PG_ACC_WORDS))) return rc;
+    if (!ctx->h_flags && (rc = host_realloc(ctx, ctx->h_flags, 2))) return rc;
+    ctx->h_batch_cap = cap;
+  }
+  return PG_OK;
+}
+
+int ensure_corr(pg_ctx* ctx, uint32_t n) {
+  const uint64_t need = (uint64_t)n * n;
+  int rc;
+  if (need > ctx->corr_cap) {
+    if ((rc = dev_realloc(ctx, ctx->d_corr, need))) return rc;
+    ctx->corr_cap = need;
+  }
+  if (need > ctx->h_corr_cap) {
+    if ((rc = host_realloc(ctx, ctx->h_corr, need))) return rc;
+    ctx->h_corr_cap = need;
+  }
+  return PG_OK;
+}
+
+// Make `ids` the current batch: genomes resident, work list (super-tile -> batch row) on the device.
+int ensure_batch(pg_ctx* ctx, const int32_t* ids, uint32_t n) {
+  int rc;
+  for (uint32_t i = 0; i < n; ++i)
+    if (ids[i] < 0 || (size_t)ids[i] >= ctx->genomes.size()) return pg_fail(ctx, PG_E_ARG, "genome id out of range");
+  if ((rc = pg_upload(ctx))) return rc;
+  if ((rc = ensure_batch_scratch(ctx, n))) return rc;
+  if (ctx->batch_ids.size() == n && std::equal(ids, ids + n, ctx->batch_ids.begin()) && n > 0) return PG_OK;
+  std::vector<uint32_t> w_tile, w_batch, gid(n);
+  for (uint32_t b = 0; b < n; ++b) {
+    const PgGenome& g = ctx->genomes[ids[b]];
+    gid[b] = (uint32_t)ids[b];
+    const uint64_t t0 = g.arena_start / PG_SUPER, nt = g.padded_len / PG_SUPER;
+    for (uint64_t t = 0; t < nt; ++t) {
+      w_tile.push_back((uint32_t)(t0 + t));
+      w_batch.push_back(b);
+    }
+  }
+  if (w_tile.size() > ctx->work_cap) {
+    const uint32_t cap = (uint32_t)std::max<size_t>(w_tile.size(), (size_t)ctx->work_cap * 2);
+    if ((rc = dev_realloc(ctx, ctx->d_w_tile, cap))) return rc;
+    if ((rc = dev_realloc(ctx, ctx->d_w_batch, cap))) return rc;
+    ctx->work_cap = cap;
+  }
+  ctx->n_work = (uint32_t)w_tile.size();
+  if (ctx->n_work) {
+    PG_HIP(ctx, hipMemcpyAsync(ctx->d_w_tile, w_tile.data(), w_tile.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    PG_HIP(ctx, hipMemcpyAsync(ctx->d_w_batch, w_batch.data(), w_batch.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+  }
+  if (n) PG_HIP(ctx, hipMemcpyAsync(ctx->d_batch_gid, gid.data(), n * 4, hipMemcpyHostToDevice, ctx->stream));
+  PG_HIP(ctx, hipStreamSynchronize(ctx->stream));  // host vectors go out of scope
+  ctx->batch_ids.assign(ids, ids + n);
+  return PG_OK;
+}
+
+int check_flags(pg_ctx* ctx, uint32_t n) {
+  if (n >= 2) {
+    if (ctx->h_flags[0] & 1) return pg_fail(ctx, PG_E_KEYSET, "genomes have different observed-tetranucleotide key sets");
+    if (ctx->h_flags[1] == 0) return pg_fail(ctx, PG_E_EMPTY, "no tetranucleotide observed in any genome");
+  }
+  return PG_OK;
+}
+
+}  // namespace
+
+// ---- context ------------------------------------------------------------------------------------------------
+extern "C" {
+
+const char* pg_version(void) { return "pyani_gpu 0.1.0 (gfx950)"; }
+
+const char* pg_kernel_name(int which) { return (which >= 0 && which < PG_K__COUNT) ? KERNEL_NAMES[which] : ""; }
+
+int pg_create(pg_ctx** out, int device) {
+  if (!out) return PG_E_ARG;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return PG_E_NODEVICE;
+  if (device < 0 || device >= ndev) return PG_E_ARG;
+  pg_ctx* ctx = new (std::nothrow) pg_ctx();
+  if (!ctx) return PG_E_NOMEM;
+  ctx->device = device;
+  if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete ctx;
+    return PG_E_HIP;
+  }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+    ctx->num_cu = prop.multiProcessorCount;
+  *out = ctx;
+  return PG_OK;
+}
+
+void pg_destroy(pg_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  prof_drain(ctx);
+  void* dev[] = {ctx->d_codes, ctx->d_mask, ctx->d_quirk, ctx->d_w_tile, ctx->d_w_batch, ctx->d_batch_gid, ctx->d_acc,
+                 ctx->d_counts, ctx->d_z, ctx->d_present, ctx->d_dev, ctx->d_ss, ctx->d_flags, ctx->d_corr};
+  for (void* p : dev)
+    if (p) (void)hipFree(p);
+  void* host[] = {ctx->h_z, ctx->h_present, ctx->h_corr, ctx->h_flags, ctx->h_counts};
+  for (void* p : host)
+    if (p) (void)hipHostFree(p);
+  (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+const char* pg_last_error(const pg_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int pg_sync(pg_ctx* ctx) {
+  if (!ctx) return PG_E_ARG;
+  PG_HIP(ctx, hipSetDevice(ctx->device));
+  PG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return PG_OK;
+}
+
+// ---- genome store -------------------------------------------------------------------------------------------
+int pg_add_genome(pg_ctx* ctx, const uint8_t* seq, const uint64_t* rec_off, uint32_t n_rec, int32_t* genome_id_out) {
+  if (!ctx || !rec_off || (!seq && n_rec && rec_off[n_rec] > rec_off[0])) return pg_fail(ctx, PG_E_ARG, "bad argument");
+  for (uint32_t r = 0; r < n_rec; ++r)
+    if (rec_off[r + 1] < rec_off[r]) return pg_fail(ctx, PG_E_ARG, "record offsets must be non-decreasing");
+  PgGenome g;
+  const int rc = pack_genome(seq, rec_off, n_rec, g);
+  if (rc == PG_E_RNA)
+    return pg_fail(ctx, PG_E_RNA, "sequence contains U/u (RNA); Biopython complements it asymmetrically, unsupported");
+  return add_packed(ctx, std::move(g), genome_id_out);
+}
+
+int pg_add_fasta(pg_ctx* ctx, const char* path, int32_t* genome_id_out, uint64_t* total_len_out, uint32_t* n_rec_out) {
+  if (!ctx || !path) return pg_fail(ctx, PG_E_ARG, "bad argument");
+  std::vector<uint8_t> txt, seq;
+  std::vector<uint64_t> off;
+  if (read_file(path, txt) != 0) return pg_fail(ctx, PG_E_IO, std::string("cannot read ") + path);
+  parse_fasta(txt, seq, off);
+  const uint64_t zero_off[1] = {0};
+  const uint32_t n_rec = off.empty() ? 0 : (uint32_t)off.size() - 1;
+  PgGenome g;
+  const int rc = pack_genome(seq.data(), off.empty() ? zero_off : off.data(), n_rec, g);
+  if (rc == PG_E_RNA) return pg_fail(ctx, PG_E_RNA, std::string(path) + ": sequence contains U/u (RNA), unsupported");
+  if (total_len_out) *total_len_out = g.total_len;
+  if (n_rec_out) *n_rec_out = n_rec;
+  return add_packed(ctx, std::move(g), genome_id_out);
+}
+
+int pg_genome_count(const pg_ctx* ctx) { return ctx ? (int)ctx->genomes.size() : PG_E_ARG; }
+
+int pg_genome_length(const pg_ctx* ctx, int32_t id, uint64_t* total_len_out, uint32_t* n_rec_out) {
+  if (!ctx || id < 0 || (size_t)id >= ctx->genomes.size()) return PG_E_ARG;
+  if (total_len_out) *total_len_out = ctx->genomes[id].total_len;
+  if (n_rec_out) *n_rec_out = ctx->genomes[id].n_rec;
+  return PG_OK;
+}
+
+int pg_clear_genomes(pg_ctx* ctx) {
+  if (!ctx) return PG_E_ARG;
+  PG_HIP(ctx, hipSetDevice(ctx->device));
+  PG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->genomes.clear();
+  ctx->arena_used = 0;
+  ctx->n_resident = 0;
+  ctx->batch_ids.clear();
+  return PG_OK;
+}
+
+int pg_upload(pg_ctx* ctx) {
+  if (!ctx) return PG_E_ARG;
+  PG_HIP(ctx, hipSetDevice(ctx->device));
+  const uint32_t ng = (uint32_t)ctx->genomes.size();
+  if (ctx->n_resident == ng) return PG_OK;
+  // arena (+ one zero guard super-tile so look-ahead loads past the last genome stay in bounds and read "dirty")
+  if (ctx->arena_used > ctx->arena_cap) {
+    const uint64_t cap = std::max<uint64_t>(ctx->arena_used, ctx->arena_cap + ctx->arena_cap / 2);
+    uint32_t *nc = nullptr, *nm = nullptr;
+    PG_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&nc), (cap + PG_SUPER) / 4));
+    PG_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&nm), (cap + PG_SUPER) / 8));
+    PG_HIP(ctx, hipMemsetAsync(nc, 0, (cap + PG_SUPER) / 4, ctx->stream));
+    PG_HIP(ctx, hipMemsetAsync(nm, 0, (cap + PG_SUPER) / 8, ctx->stream));
+    uint64_t res_bases = 0;
+    for (uint32_t i = 0; i < ctx->n_resident; ++i) res_bases = ctx->genomes[i].arena_start + ctx->genomes[i].padded_len;
+    if (res_bases && ctx->d_codes) {
+      PG_HIP(ctx, hipMemcpyAsync(nc, ctx->d_codes, res_bases / 4, hipMemcpyDeviceToDevice, ctx->stream));
+      PG_HIP(ctx, hipMemcpyAsync(nm, ctx->d_mask, res_bases / 8, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    PG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->d_codes) PG_HIP(ctx, hipFree(ctx->d_codes));
+    if (ctx->d_mask) PG_HIP(ctx, hipFree(ctx->d_mask));
+    ctx->d_codes = nc;
+    ctx->d_mask = nm;
+    ctx->arena_cap = cap;
+  }
+  if (ng > ctx->quirk_cap) {
+    const uint32_t cap = std::max<uint32_t>(ng, ctx->quirk_cap * 2);
+    uint32_t* nq = nullptr;
+    PG_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&nq), (size_t)cap * 256 * 4));
+    if (ctx->n_resident && ctx->d_quirk)
+      PG_HIP(ctx, hipMemcpy(nq, ctx->d_quirk, (size_t)ctx->n_resident * 256 * 4, hipMemcpyDeviceToDevice));
+    if (ctx->d_quirk) PG_HIP(ctx, hipFree(ctx->d_quirk));
+    ctx->d_quirk = nq;
+    ctx->quirk_cap = cap;
+  }
+  for (uint32_t i = ctx->n_resident; i < ng; ++i) {
+    PgGenome& g = ctx->genomes[i];
+    PG_HIP(ctx, hipMemcpyAsync(ctx->d_codes + g.arena_start / 16, g.codes.data(), g.codes.size() * 4,
+                               hipMemcpyHostToDevice, ctx->stream));
+    PG_HIP(ctx, hipMemcpyAsync(ctx->d_mask + g.arena_start / 32, g.mask.data(), g.mask.size() * 4, hipMemcpyHostToDevice,
+                               ctx->stream));
+    PG_HIP(ctx, hipMemcpyAsync(ctx->d_quirk + (size_t)i * 256, g.quirk.data(), 256 * 4, hipMemcpyHostToDevice,
+                               ctx->stream));
+  }
+  PG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (uint32_t i = ctx->n_resident; i < ng; ++i) {
+    PgGenome& g = ctx->genomes[i];
+    g.resident = true;
+    std::vector<uint32_t>().swap(g.codes);  // the HBM copy is now the only one
+    std::vector<uint32_t>().swap(g.mask);
+  }
+  ctx->n_resident = ng;
+  return PG_OK;
+}
+
+int pg_tetra_algorithmic_bytes(const pg_ctx* ctx, const int32_t* ids, uint32_t n, uint64_t* bytes_out, uint64_t* bases_out) {
+  if (!ctx) return PG_E_ARG;
+  uint64_t bytes = 0, bases = 0;
+  const uint32_t cnt = ids ? n : (uint32_t)ctx->genomes.size();
+  for (uint32_t i = 0; i < cnt; ++i) {
+    const int32_t id = ids ? ids[i] : (int32_t)i;
+    if (id < 0 || (size_t)id >= ctx->genomes.size()) return PG_E_ARG;
+    const PgGenome& g = ctx->genomes[id];
+    bases += g.total_len;
+    bytes += (g.stream_len + 3) / 4 + (g.stream_len + 7) / 8 + PG_ACC_WORDS * 8;  // codes + mask read, counts written
+  }
+  if (bytes_out) *bytes_out = bytes;
+  if (bases_out) *bases_out = bases;
+  return PG_OK;
+}
+
+// ---- TETRA ----------------------------------------------------------------------------------------------------
+int pg_tetra_counts(pg_ctx* ctx, const int32_t* ids, uint32_t n, uint64_t* c2, uint64_t* c3, uint64_t* c4) {
+  if (!ctx || (n && !ids)) return pg_fail(ctx, PG_E_ARG, "bad argument");
+  PG_HIP(ctx, hipSetDevice(ctx->device));
+  int rc;
+  if ((rc = ensure_batch(ctx, ids, n))) return rc;
+  if (n == 0) return PG_OK;
+  if ((rc = pg_launch_tetra_count(ctx, n))) return rc;
+  // finalize without Z (z == nullptr path needs d_z null): run the kernel with z outputs, cheap
+  if ((rc = pg_launch_tetra_finalize(ctx, n, ctx->d_acc))) return rc;
+  PG_HIP(ctx, hipMemcpyAsync(ctx->h_counts, ctx->d_counts, (size_t)n * PG_ACC_WORDS * 8, hipMemcpyDeviceToHost, ctx->stream));
+  PG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (uint32_t g = 0; g < n; ++g) {
+    const unsigned long long* src = ctx->h_counts + (size_t)g * PG_ACC_WORDS;
+    if (c2) std::memcpy(c2 + (size_t)g * 16, src, 16 * 8);
+    if (c3) std::memcpy(c3 + (size_t)g * 64, src + 16, 64 * 8);
+    if (c4) std::memcpy(c4 + (size_t)g * 256, src + 80, 256 * 8);
+  }
+  return PG_OK;
+}
+
+int pg_tetra_zscores(pg_ctx* ctx, const uint64_t* c2, const uint64_t* c3, const uint64_t* c4, uint32_t n, double* z,
+                     uint8_t* present) {
+  if (!ctx || (n && (!c2 || !c3 || !c4))) return pg_fail(ctx, PG_E_ARG, "bad argument");
+  PG_HIP(ctx, hipSetDevice(ctx->device));
+  int rc;
+  if ((rc = ensure_batch_scratch(ctx, n))) return rc;
+  if (n == 0) return PG_OK;
+  ctx->batch_ids.clear();  // d_batch_gid is not used on this path, but scratch contents change
+  for (uint32_t g = 0; g < n; ++g) {
+    unsigned long long* dst = ctx->h_counts + (size_t)g * PG_ACC_WORDS;
+    std::memcpy(dst, c2 + (size_t)g * 16, 16 * 8);
+    std::memcpy(dst + 16, c3 + (size_t)g * 64, 64 * 8);
+    std::memcpy(dst + 80, c4 + (size_t)g * 256, 256 * 8);
+  }
+  PG_HIP(ctx, hipMemcpyAsync(ctx->d_counts, ctx->h_counts, (size_t)n * PG_ACC_WORDS * 8, hipMemcpyHostToDevice, ctx->stream));
+  if ((rc = pg_launch_tetra_finalize(ctx, n, nullptr))) return rc;
+  PG_HIP(ctx, hipMemcpyAsync(ctx->h_z, ctx->d_z, (size_t)n * 256 * 8, hipMemcpyDeviceToHost, ctx->stream));
+  PG_HIP(ctx, hipMemcpyAsync(ctx->h_present, ctx->d_present, (size_t)n * 256, hipMemcpyDeviceToHost, ctx->stream));
+  PG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (z) std::memcpy(z, ctx->h_z, (size_t)n * 256 * 8);
+  if (present) std::memcpy(present, ctx->h_present, (size_t)n * 256);
+  return PG_OK;
+}
+
+int pg_tetra_corr(pg_ctx* ctx, const double* z, const uint8_t* present, uint32_t n, double* out) {
+  if (!ctx || (n && (!z || !present || !out))) return pg_fail(ctx, PG_E_ARG, "bad argument");
+  PG_HIP(ctx, hipSetDevice(ctx->device));
+  int rc;
+  if ((rc = ensure_batch_scratch(ctx, n))) return rc;
+  if ((rc = ensure_corr(ctx, n))) return rc;
+  if (n == 0) return PG_OK;
+  std::memcpy(ctx->h_z, z, (size_t)n * 256 * 8);
+  std::memcpy(ctx->h_present, present, (size_t)n * 256);
+  PG_HIP(ctx, hipMemcpyAsync(ctx->d_z, ctx->h_z, (size_t)n * 256 * 8, hipMemcpyHostToDevice, ctx->stream));
+  PG_HIP(ctx, hipMemcpyAsync(ctx->d_present, ctx->h_present, (size_t)n * 256, hipMemcpyHostToDevice, ctx->stream));
+  if ((rc = pg_launch_tetra_stats(ctx, ctx->d_z, ctx->d_present, n))) return rc;
+  if ((rc = pg_launch_tetra_pairs(ctx, n, 0, n, ctx->d_corr, true))) return rc;
+  PG_HIP(ctx, hipMemcpyAsync(ctx->h_corr, ctx->d_corr, (size_t)n * n * 8, hipMemcpyDeviceToHost, ctx->stream));
+  PG_HIP(ctx, hipMemcpyAsync(ctx->h_flags, ctx->d_flags, 2 * 4, hipMemcpyDeviceToHost, ctx->stream));
+  PG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if ((rc = check_flags(ctx, n))) return rc;
+  std::memcpy(out, ctx->h_corr, (size_t)n * n * 8);
+  return PG_OK;
+}
+
+int pg_tetra_matrix_enqueue(pg_ctx* ctx, const int32_t* ids, uint32_t n) {
+  if (!ctx || (n && !ids)) return pg_fail(ctx, PG_E_ARG, "bad argument");
+  PG_HIP(ctx, hipSetDevice(ctx->device));
+  int rc;
+  if ((rc = ensure_batch(ctx, ids, n))) return rc;
+  if ((rc = ensure_corr(ctx, n))) return rc;
+  if (n == 0) return PG_OK;
+  if ((rc = pg_launch_tetra_count(ctx, n))) return rc;
+  if ((rc = pg_launch_tetra_finalize(ctx, n, ctx->d_acc))) return rc;
+  if ((rc = pg_launch_tetra_stats(ctx, ctx->d_z, ctx->d_present, n))) return rc;
+  if ((rc = pg_launch_tetra_pairs(ctx, n, 0, n, ctx->d_corr, true))) return rc;
+  PG_HIP(ctx, hipMemcpyAsync(ctx->h_corr, ctx->d_corr, (size_t)n * n * 8, hipMemcpyDeviceToHost, ctx->stream));
+  PG_HIP(ctx, hipMemcpyAsync(ctx->h_z, ctx->d_z, (size_t)n * 256 * 8, hipMemcpyDeviceToHost, ctx->stream));
+  PG_HIP(ctx, hipMemcpyAsync(ctx->h_present, ctx->d_present, (size_t)n * 256, hipMemcpyDeviceToHost, ctx->stream));
+  PG_HIP(ctx, hipMemcpyAsync(ctx->h_flags, ctx->d_flags, 2 * 4, hipMemcpyDeviceToHost, ctx->stream));
+  return PG_OK;
+}
+
+int pg_tetra_matrix_fetch(pg_ctx* ctx, uint32_t n, double* z_out, uint8_t* present_out, double* corr_out) {
+  if (!ctx) return PG_E_ARG;
+  PG_HIP(ctx, hipSetDevice(ctx->device));
+  PG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (n > ctx->h_batch_cap || (uint64_t)n * n > ctx->h_corr_cap) return pg_fail(ctx, PG_E_ARG, "fetch larger than last batch");
+  if (z_out) std::memcpy(z_out, ctx->h_z, (size_t)n * 256 * 8);
+  if (present_out) std::memcpy(present_out, ctx->h_present, (size_t)n * 256);
+  if (corr_out) {
+    const int rc = check_flags(ctx, n);
+    if (rc) return rc;
+    std::memcpy(corr_out, ctx->h_corr, (size_t)n * n * 8);
+  }
+  return PG_OK;
+}
+
+int pg_tetra_matrix(pg_ctx* ctx, const int32_t* ids, uint32_t n, double* z_out, uint8_t* present_out, double* corr_out) {
+  const int rc = pg_tetra_matrix_enqueue(ctx, ids, n);
+  if (rc) return rc;
+  return pg_tetra_matrix_fetch(ctx, n, z_out, present_out, corr_out);
+}
+
+int pg_tetra_zscores_dev(pg_ctx* ctx, const int32_t* ids, uint32_t n, double* d_z, uint8_t* d_present) {
+  if (!ctx || (n && (!ids || !d_z || !d_present))) return pg_fail(ctx, PG_E_ARG, "bad argument");
+  PG_HIP(ctx, hipSetDevice(ctx->device));
+  int rc;
+  if ((rc = ensure_batch(ctx, ids, n))) return rc;
+  if (n == 0) return PG_OK;
+  if ((rc = pg_launch_tetra_count(ctx, n))) return rc;
+  if ((rc = pg_launch_tetra_finalize(ctx, n, ctx->d_acc))) return rc;
+  PG_HIP(ctx, hipMemcpyAsync(d_z, ctx->d_z, (size_t)n * 256 * 8, hipMemcpyDeviceToDevice, ctx->stream));
+  PG_HIP(ctx, hipMemcpyAsync(d_present, ctx->d_present, (size_t)n * 256, hipMemcpyDeviceToDevice, ctx->stream));
+  PG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return PG_OK;
+}
+
+int pg_tetra_corr_rows_dev(pg_ctx* ctx, const double* d_z, const uint8_t* d_present, uint32_t n, uint32_t row0,
+                           uint32_t nrows, double* d_out) {
+  if (!ctx || (n && (!d_z || !d_present)) || row0 + (uint64_t)nrows > n || (nrows && !d_out))
+    return pg_fail(ctx, PG_E_ARG, "bad argument");
+  PG_HIP(ctx, hipSetDevice(ctx->device));
+  int rc;
+  if ((rc = ensure_batch_scratch(ctx, n))) return rc;
+  if (n == 0) return PG_OK;
+  ctx->batch_ids.clear();
+  if ((rc = pg_launch_tetra_stats(ctx, d_z, d_present, n))) return rc;
+  if ((rc = pg_launch_tetra_pairs(ctx, n, row0, nrows, d_out, false))) return rc;
+  PG_HIP(ctx, hipMemcpyAsync(ctx->h_flags, ctx->d_flags, 2 * 4, hipMemcpyDeviceToHost, ctx->stream));
+  PG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return check_flags(ctx, n);
+}
+
+// ---- measurement -----------------------------------------------------------------------------------------------
+int pg_profile_enable(pg_ctx* ctx, int on) {
+  if (!ctx) return PG_E_ARG;
+  ctx->profiling = on != 0;
+  return PG_OK;
+}
+int pg_profile_reset(pg_ctx* ctx) {
+  if (!ctx) return PG_E_ARG;
+  PG_HIP(ctx, hipSetDevice(ctx->device));
+  PG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  prof_drain(ctx);
+  for (int i = 0; i < PG_K__COUNT; ++i) { ctx->prof_ms[i] = 0; ctx->prof_n[i] = 0; }
+  return PG_OK;
+}
+int pg_profile_get(pg_ctx* ctx, int which, double* total_ms_out, uint64_t* launches_out) {
+  if (!ctx || which < 0 || which >= PG_K__COUNT) return PG_E_ARG;
+  PG_HIP(ctx, hipSetDevice(ctx->device));
+  PG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  prof_drain(ctx);
+  if (total_ms_out) *total_ms_out = ctx->prof_ms[which];
+  if (launches_out) *launches_out = ctx->prof_n[which];
+  return PG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,100 @@
+// pg_internal.h — shared declarations of libpyani_gpu.so (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <array>
+#include <cstdint>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "pyani_gpu.h"
+
+// ---- HBM layout of the genome store -------------------------------------------------------------------------
+// One "base stream" per genome: its records back to back with ONE dirty separator base between records, then
+// dirty padding up to a multiple of PG_SUPER bases (always at least one dirty base at the end).  Streams of all
+// genomes are laid out in one arena:
+//   codes : 2 bits/base, base s of the arena in bits [2*(s%16), +2) of codes32[s/16]   (A=0 C=1 G=2 T=3, dirty=0)
+//   mask  : 1 bit/base,  bit (s%32) of mask32[s/32] = 1 iff the base is one of ACGT ("clean")
+// A k-mer window is valid iff all its k mask bits are 1; separators and padding make windows that would cross a
+// record or genome boundary invalid for free, so the count kernel needs no record table.
+constexpr uint32_t PG_SUPER = 65536;          // bases per super-tile = one block iteration (1024 lanes x 64 bases)
+constexpr uint32_t PG_ACC_WORDS = 16 + 64 + 256;  // per-genome accumulator: E2 | E3 | F4 (unsigned long long each)
+
+struct PgGenome {
+  uint64_t total_len = 0;    // sum of record lengths (pyani_files.get_sequence_lengths)
+  uint32_t n_rec = 0;
+  uint64_t stream_len = 0;   // total_len + (n_rec-1) separators
+  uint64_t padded_len = 0;   // multiple of PG_SUPER, > stream_len
+  uint64_t arena_start = 0;  // base offset in the device arena (multiple of PG_SUPER)
+  bool resident = false;
+  std::vector<uint32_t> codes, mask;  // host copy until uploaded
+  std::array<uint32_t, 256> quirk{};  // tetramers the reference does not count (last window of each strand)
+};
+
+struct PgEventPair {
+  hipEvent_t a, b;
+  int which;
+};
+
+struct pg_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  std::mutex mu;
+  std::vector<PgGenome> genomes;
+  uint64_t arena_used = 0;  // bases
+  // device arena
+  uint32_t* d_codes = nullptr;
+  uint32_t* d_mask = nullptr;
+  uint64_t arena_cap = 0;  // bases (device), excludes the trailing guard super-tile
+  uint32_t* d_quirk = nullptr;
+  uint32_t quirk_cap = 0;  // genomes
+  uint32_t n_resident = 0;
+  // batch scratch (device)
+  std::vector<int32_t> batch_ids;  // ids of the cached work list
+  uint32_t* d_w_tile = nullptr;
+  uint32_t* d_w_batch = nullptr;
+  uint32_t* d_batch_gid = nullptr;
+  uint32_t n_work = 0, work_cap = 0, batch_cap = 0;
+  unsigned long long* d_acc = nullptr;     // batch x PG_ACC_WORDS
+  unsigned long long* d_counts = nullptr;  // batch x (16+64+256): c2 | c3 | c4
+  double* d_z = nullptr;                   // batch x 256
+  uint8_t* d_present = nullptr;            // batch x 256
+  double* d_dev = nullptr;                 // batch x 256 compacted deviations
+  double* d_ss = nullptr;                  // batch
+  int32_t* d_flags = nullptr;              // [0]=keyset mismatch, [1]=n present keys
+  double* d_corr = nullptr;                // batch x batch
+  uint64_t corr_cap = 0;
+  // pinned host staging for the async pipeline
+  double* h_z = nullptr;
+  uint8_t* h_present = nullptr;
+  double* h_corr = nullptr;
+  int32_t* h_flags = nullptr;
+  unsigned long long* h_counts = nullptr;
+  uint32_t h_batch_cap = 0;
+  uint64_t h_corr_cap = 0;
+  // profiling
+  bool profiling = false;
+  std::vector<PgEventPair> events;
+  double prof_ms[PG_K__COUNT] = {0, 0, 0, 0};
+  uint64_t prof_n[PG_K__COUNT] = {0, 0, 0, 0};
+  int num_cu = 256;
+};
+
+int pg_fail(pg_ctx* ctx, int code, const std::string& msg);
+#define PG_HIP(ctx, call)                                                                                     \
+  do {                                                                                                        \
+    hipError_t _e = (call);                                                                                   \
+    if (_e != hipSuccess)                                                                                     \
+      return pg_fail((ctx), PG_E_HIP, std::string(#call) + ": " + hipGetErrorString(_e));                     \
+  } while (0)
+
+// profiling helpers (pg_api.cpp)
+void pg_prof_begin(pg_ctx* ctx, int which);
+void pg_prof_end(pg_ctx* ctx);
+
+// kernels' host launchers (pg_tetra.hip)
+int pg_launch_tetra_count(pg_ctx* ctx, uint32_t n_batch);
+int pg_launch_tetra_finalize(pg_ctx* ctx, uint32_t n_batch, const unsigned long long* d_counts_in);
+int pg_launch_tetra_stats(pg_ctx* ctx, const double* d_z, const uint8_t* d_present, uint32_t n);
+int pg_launch_tetra_pairs(pg_ctx* ctx, uint32_t n, uint32_t row0, uint32_t nrows, double* d_out, bool mirror);

@@ -1,0 +1,175 @@
+"""Engine — Python owner of one libpyani_gpu context (one per process and GPU).
+
+Holds genomes resident in HBM (2-bit codes + 1-bit mask) and exposes the TETRA kernels.  numpy arrays are the
+only currency across the ctypes boundary; nothing here computes on the CPU.
+"""
+import ctypes
+from pathlib import Path
+from typing import Iterable, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib
+
+
+def _ptr(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data
+
+
+class Engine:
+    def __init__(self, device: int = 0):
+        self.lib = _lib.load()
+        h = ctypes.c_void_p()
+        rc = self.lib.pg_create(ctypes.byref(h), device)
+        if rc == _lib.PG_E_NODEVICE:
+            raise _lib.PyaniGpuError(rc, "no HIP device visible: pyani_amd needs an MI355X (there is no CPU fallback)")
+        if rc != 0:
+            raise _lib.PyaniGpuError(rc, "pg_create failed")
+        self._h = h
+        self.device = device
+
+    # -- plumbing ---------------------------------------------------------------------------------------------
+    def _check(self, rc: int):
+        if rc != 0:
+            raise _lib.PyaniGpuError(rc, self.lib.pg_last_error(self._h).decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.pg_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def sync(self):
+        self._check(self.lib.pg_sync(self._h))
+
+    # -- genome store -------------------------------------------------------------------------------------------
+    def add_genome(self, seq: np.ndarray, rec_off: Sequence[int]) -> int:
+        seq = np.ascontiguousarray(seq, dtype=np.uint8)
+        off = np.ascontiguousarray(rec_off, dtype=np.uint64)
+        gid = ctypes.c_int32(-1)
+        self._check(self.lib.pg_add_genome(self._h, seq.ctypes.data if seq.size else None, off.ctypes.data,
+                                           max(len(off) - 1, 0), ctypes.byref(gid)))
+        return gid.value
+
+    def add_fasta(self, path) -> Tuple[int, int, int]:
+        """Returns (genome id, total length = sum of record lengths, number of records)."""
+        gid, tot, nrec = ctypes.c_int32(-1), ctypes.c_uint64(0), ctypes.c_uint32(0)
+        self._check(self.lib.pg_add_fasta(self._h, str(path).encode(), ctypes.byref(gid), ctypes.byref(tot),
+                                          ctypes.byref(nrec)))
+        return gid.value, tot.value, nrec.value
+
+    def genome_count(self) -> int:
+        return self.lib.pg_genome_count(self._h)
+
+    def genome_length(self, gid: int) -> Tuple[int, int]:
+        tot, nrec = ctypes.c_uint64(0), ctypes.c_uint32(0)
+        self._check(self.lib.pg_genome_length(self._h, gid, ctypes.byref(tot), ctypes.byref(nrec)))
+        return tot.value, nrec.value
+
+    def clear_genomes(self):
+        self._check(self.lib.pg_clear_genomes(self._h))
+
+    def upload(self):
+        self._check(self.lib.pg_upload(self._h))
+
+    def tetra_algorithmic_bytes(self, ids: Optional[Iterable[int]] = None) -> Tuple[int, int]:
+        b, n = ctypes.c_uint64(0), ctypes.c_uint64(0)
+        if ids is None:
+            self._check(self.lib.pg_tetra_algorithmic_bytes(self._h, None, 0, ctypes.byref(b), ctypes.byref(n)))
+        else:
+            a = np.ascontiguousarray(list(ids), dtype=np.int32)
+            self._check(self.lib.pg_tetra_algorithmic_bytes(self._h, a.ctypes.data, len(a), ctypes.byref(b), ctypes.byref(n)))
+        return b.value, n.value
+
+    # -- TETRA ------------------------------------------------------------------------------------------------------
+    @staticmethod
+    def _ids(ids) -> np.ndarray:
+        return np.ascontiguousarray(list(ids), dtype=np.int32)
+
+    def tetra_counts(self, ids) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+        a = self._ids(ids)
+        n = len(a)
+        c2, c3, c4 = (np.zeros((n, k), dtype=np.uint64) for k in (16, 64, 256))
+        self._check(self.lib.pg_tetra_counts(self._h, a.ctypes.data, n, c2.ctypes.data, c3.ctypes.data, c4.ctypes.data))
+        return c2, c3, c4
+
+    def tetra_zscores_from_counts(self, c2, c3, c4) -> Tuple[np.ndarray, np.ndarray]:
+        c2, c3, c4 = (np.ascontiguousarray(x, dtype=np.uint64).reshape(-1, k) for x, k in ((c2, 16), (c3, 64), (c4, 256)))
+        n = c4.shape[0]
+        z = np.zeros((n, 256), dtype=np.float64)
+        present = np.zeros((n, 256), dtype=np.uint8)
+        self._check(self.lib.pg_tetra_zscores(self._h, c2.ctypes.data, c3.ctypes.data, c4.ctypes.data, n, z.ctypes.data,
+                                              present.ctypes.data))
+        return z, present
+
+    def tetra_corr(self, z: np.ndarray, present: np.ndarray) -> np.ndarray:
+        z = np.ascontiguousarray(z, dtype=np.float64).reshape(-1, 256)
+        present = np.ascontiguousarray(present, dtype=np.uint8).reshape(-1, 256)
+        n = z.shape[0]
+        out = np.zeros((n, n), dtype=np.float64)
+        self._check(self.lib.pg_tetra_corr(self._h, z.ctypes.data, present.ctypes.data, n, out.ctypes.data))
+        return out
+
+    def tetra_matrix(self, ids, want_corr: bool = True) -> Tuple[np.ndarray, np.ndarray, Optional[np.ndarray]]:
+        """Fused counts -> Z -> Pearson on the device.  Returns (z, present, corr or None)."""
+        a = self._ids(ids)
+        n = len(a)
+        z = np.zeros((n, 256), dtype=np.float64)
+        present = np.zeros((n, 256), dtype=np.uint8)
+        corr = np.zeros((n, n), dtype=np.float64) if want_corr else None
+        self._check(self.lib.pg_tetra_matrix(self._h, a.ctypes.data, n, z.ctypes.data, present.ctypes.data, _ptr(corr)))
+        return z, present, corr
+
+    def tetra_matrix_enqueue(self, ids_array: np.ndarray):
+        self._check(self.lib.pg_tetra_matrix_enqueue(self._h, ids_array.ctypes.data, len(ids_array)))
+
+    def tetra_matrix_fetch(self, n: int) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+        z = np.zeros((n, 256), dtype=np.float64)
+        present = np.zeros((n, 256), dtype=np.uint8)
+        corr = np.zeros((n, n), dtype=np.float64)
+        self._check(self.lib.pg_tetra_matrix_fetch(self._h, n, z.ctypes.data, present.ctypes.data, corr.ctypes.data))
+        return z, present, corr
+
+    def tetra_zscores_dev(self, ids, d_z_ptr: int, d_present_ptr: int):
+        a = self._ids(ids)
+        self._check(self.lib.pg_tetra_zscores_dev(self._h, a.ctypes.data, len(a), d_z_ptr, d_present_ptr))
+
+    def tetra_corr_rows_dev(self, d_z_ptr: int, d_present_ptr: int, n: int, row0: int, nrows: int, d_out_ptr: int):
+        self._check(self.lib.pg_tetra_corr_rows_dev(self._h, d_z_ptr, d_present_ptr, n, row0, nrows, d_out_ptr))
+
+    # -- measurement ----------------------------------------------------------------------------------------------
+    def profile_enable(self, on: bool = True):
+        self._check(self.lib.pg_profile_enable(self._h, int(on)))
+
+    def profile_reset(self):
+        self._check(self.lib.pg_profile_reset(self._h))
+
+    def profile_get(self, which: int) -> Tuple[float, int]:
+        ms, n = ctypes.c_double(0), ctypes.c_uint64(0)
+        self._check(self.lib.pg_profile_get(self._h, which, ctypes.byref(ms), ctypes.byref(n)))
+        return ms.value, n.value
+
+    def kernel_name(self, which: int) -> str:
+        return self.lib.pg_kernel_name(which).decode()
+
+
+_default: List[Optional[Engine]] = [None]
+
+
+def default_engine() -> Engine:
+    """Process-wide engine on LOCAL_RANK's GPU (created on first use)."""
+    import os
+    if _default[0] is None:
+        _default[0] = Engine(int(os.environ.get("LOCAL_RANK", "0")))
+    return _default[0]
