@@ -197,6 +197,8 @@ int ensure_batch_scratch(pg_ctx* ctx, uint32_t n) {
     const uint32_t cap = std::max<uint32_t>(n, ctx->batch_cap * 2);
     int rc;
     if ((rc = dev_realloc(ctx, ctx->d_batch_gid, cap))) return rc;
+    if ((rc = dev_realloc(ctx, ctx->d_seg_tile0, cap))) return rc;
+    if ((rc = dev_realloc(ctx, ctx->d_seg_prefix, (size_t)cap + 1))) return rc;
     if ((rc = dev_realloc(ctx, ctx->d_acc, (size_t)cap * PG_ACC_WORDS))) return rc;
     if ((rc = dev_realloc(ctx, ctx->d_counts, (size_t)cap * PG_ACC_WORDS))) return rc;
     if ((rc = dev_realloc(ctx, ctx->d_z, (size_t)cap * 256))) return rc;
@@ -244,28 +246,19 @@ int ensure_batch(pg_ctx* ctx, const int32_t* ids, uint32_t n) {
   if ((rc = pg_upload(ctx))) return rc;
   if ((rc = ensure_batch_scratch(ctx, n))) return rc;
   if (ctx->batch_ids.size() == n && std::equal(ids, ids + n, ctx->batch_ids.begin()) && n > 0) return PG_OK;
-  std::vector<uint32_t> w_tile, w_batch, gid(n);
+  std::vector<uint32_t> tile0(n), prefix(n + 1, 0), gid(n);
   for (uint32_t b = 0; b < n; ++b) {
     const PgGenome& g = ctx->genomes[ids[b]];
     gid[b] = (uint32_t)ids[b];
-    const uint64_t t0 = g.arena_start / PG_SUPER, nt = g.padded_len / PG_SUPER;
-    for (uint64_t t = 0; t < nt; ++t) {
-      w_tile.push_back((uint32_t)(t0 + t));
-      w_batch.push_back(b);
-    }
+    tile0[b] = (uint32_t)(g.arena_start / PG_SUPER);
+    prefix[b + 1] = prefix[b] + (uint32_t)(g.padded_len / PG_SUPER);
   }
-  if (w_tile.size() > ctx->work_cap) {
-    const uint32_t cap = (uint32_t)std::max<size_t>(w_tile.size(), (size_t)ctx->work_cap * 2);
-    if ((rc = dev_realloc(ctx, ctx->d_w_tile, cap))) return rc;
-    if ((rc = dev_realloc(ctx, ctx->d_w_batch, cap))) return rc;
-    ctx->work_cap = cap;
+  ctx->n_work = prefix[n];
+  if (n) {
+    PG_HIP(ctx, hipMemcpyAsync(ctx->d_seg_tile0, tile0.data(), n * 4, hipMemcpyHostToDevice, ctx->stream));
+    PG_HIP(ctx, hipMemcpyAsync(ctx->d_batch_gid, gid.data(), n * 4, hipMemcpyHostToDevice, ctx->stream));
   }
-  ctx->n_work = (uint32_t)w_tile.size();
-  if (ctx->n_work) {
-    PG_HIP(ctx, hipMemcpyAsync(ctx->d_w_tile, w_tile.data(), w_tile.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-    PG_HIP(ctx, hipMemcpyAsync(ctx->d_w_batch, w_batch.data(), w_batch.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-  }
-  if (n) PG_HIP(ctx, hipMemcpyAsync(ctx->d_batch_gid, gid.data(), n * 4, hipMemcpyHostToDevice, ctx->stream));
+  PG_HIP(ctx, hipMemcpyAsync(ctx->d_seg_prefix, prefix.data(), (n + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
   PG_HIP(ctx, hipStreamSynchronize(ctx->stream));  // host vectors go out of scope
   ctx->batch_ids.assign(ids, ids + n);
   return PG_OK;
@@ -313,7 +306,7 @@ void pg_destroy(pg_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   prof_drain(ctx);
-  void* dev[] = {ctx->d_codes, ctx->d_mask, ctx->d_quirk, ctx->d_w_tile, ctx->d_w_batch, ctx->d_batch_gid, ctx->d_acc,
+  void* dev[] = {ctx->d_codes, ctx->d_mask, ctx->d_quirk, ctx->d_seg_tile0, ctx->d_seg_prefix, ctx->d_batch_gid, ctx->d_acc,
                  ctx->d_counts, ctx->d_z, ctx->d_present, ctx->d_dev, ctx->d_ss, ctx->d_flags, ctx->d_corr};
   for (void* p : dev)
     if (p) (void)hipFree(p);

@@ -52,10 +52,10 @@ struct pg_ctx {
   uint32_t n_resident = 0;
   // batch scratch (device)
   std::vector<int32_t> batch_ids;  // ids of the cached work list
-  uint32_t* d_w_tile = nullptr;
-  uint32_t* d_w_batch = nullptr;
+  uint32_t* d_seg_tile0 = nullptr;   // batch: first arena super-tile of each genome
+  uint32_t* d_seg_prefix = nullptr;  // batch + 1: cumulative super-tile counts
   uint32_t* d_batch_gid = nullptr;
-  uint32_t n_work = 0, work_cap = 0, batch_cap = 0;
+  uint32_t n_work = 0, batch_cap = 0;
   unsigned long long* d_acc = nullptr;     // batch x PG_ACC_WORDS
   unsigned long long* d_counts = nullptr;  // batch x (16+64+256): c2 | c3 | c4
   double* d_z = nullptr;                   // batch x 256

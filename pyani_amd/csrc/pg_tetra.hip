@@ -9,161 +9,13 @@
 // Built with -ffp-contract=off: the fp64 operation ORDER is part of the contract (bit-exact results).
 //
 // K0 design (integer/byte work — no MFMA on purpose):
-//   * one 1024-thread workgroup per CU (LDS-limited), each lane streams 64 bases per iteration with one
-//     16-byte code load + one 8-byte mask load (fully coalesced: a wave reads 1 KiB + 512 B contiguous);
-//   * LDS ds_add_u32 is the scarce resource (~16 lanes/clk/CU), so the kernel counts PENTAmers at stride 2
-//     (one atomic per 2 bases) into a 1024-bin histogram that is replicated 32x so that lane l always hits
-//     bank l%32: conflict-free by construction.  At flush each 5-mer bin is folded into its two tetramers.
-//   * di-/tri-nucleotide counts are NOT histogrammed: they are marginals of the tetramer counts plus the rare
-//     windows that end at a dirty base / record end (E2/E3), handled on a slow path taken only by waves that
-//     see a dirty base.  The reverse strand is never scanned: c_k[x] = F_k[x] + F_k[rc(x)].
-//   * neighbouring lanes exchange their 3-base look-ahead with one DPP wave_shl:1 (no LDS traffic).
+//   see pg_tetra_count.h: one 1024-thread workgroup per CU streams 64 bases per lane per tile and counts
+//   heptamers at stride 4 with LDS atomics (one atomic per 4 bases), folded to tetramers at flush.
 #include "pg_internal.h"
 
 namespace {
 
-constexpr int K0_BLOCK = 1024;
-constexpr int K0_REPL = 32;
-constexpr int K0_H5_WORDS = 1024 * K0_REPL;              // 128 KiB
-constexpr int K0_LDS_WORDS = K0_H5_WORDS + 256 + 64 + 16;  // + F4 | E3 | E2
-constexpr uint32_t K0_FORCE_FLUSH_TILES = 16384;         // 2^30 bases: keeps every u32 bin far from overflow
-
-__device__ __forceinline__ uint32_t nat4_from_lowfirst(uint32_t r) {
-  // r = b0 | b1<<2 | b2<<4 | b3<<6 (first base in the low bits)  ->  b0<<6 | b1<<4 | b2<<2 | b3
-  return ((r & 3u) << 6) | ((r & 0xCu) << 2) | ((r & 0x30u) >> 2) | ((r & 0xC0u) >> 6);
-}
-
-__device__ __forceinline__ void lds_inc(uint32_t* p) {
-  __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-
-struct LaneData {
-  uint4 c;   // 64 bases of codes
-  uint2 m;   // 64 mask bits
-  uint32_t nc, nm;  // first code / mask word of the NEXT lane's span (valid in lane 63 only before the DPP)
-};
-
-__device__ __forceinline__ LaneData k0_load(const uint32_t* __restrict__ codes, const uint32_t* __restrict__ mask,
-                                            uint32_t tile, uint32_t tid) {
-  LaneData d;
-  const uint64_t lane_span = (uint64_t)tile * K0_BLOCK + tid;  // index of this lane's 64-base span in the arena
-  d.c = *reinterpret_cast<const uint4*>(codes + lane_span * 4);
-  d.m = *reinterpret_cast<const uint2*>(mask + lane_span * 2);
-  d.nc = 0;
-  d.nm = 0;
-  if ((tid & 63u) == 63u) {  // the wave's last lane looks into the next wave's / next tile's first words
-    d.nc = codes[(lane_span + 1) * 4];
-    d.nm = mask[(lane_span + 1) * 2];
-  }
-  return d;
-}
-
-// generic path: every window checked against the mask (taken by a wave only if one of its lanes sees a dirty base)
-__device__ __noinline__ void k0_slow_lane(const LaneData& d, uint32_t* F4, uint32_t* E3, uint32_t* E2) {
-  const uint64_t M = (uint64_t)d.m.x | ((uint64_t)d.m.y << 32);
-  const uint32_t w[5] = {d.c.x, d.c.y, d.c.z, d.c.w, d.nc};
-  auto clean = [&](int p) -> bool { return p < 64 ? ((M >> p) & 1ull) != 0 : ((d.nm >> (p - 64)) & 1u) != 0; };
-  auto base = [&](int p) -> uint32_t { return (w[p >> 4] >> (2 * (p & 15))) & 3u; };
-  for (int p = 0; p < 64; ++p) {
-    if (!clean(p) || !clean(p + 1)) continue;
-    const uint32_t di = base(p) * 4 + base(p + 1);
-    if (!clean(p + 2)) { lds_inc(&E2[di]); continue; }
-    const uint32_t tri = di * 4 + base(p + 2);
-    if (!clean(p + 3)) { lds_inc(&E3[tri]); continue; }
-    lds_inc(&F4[tri * 4 + base(p + 3)]);
-  }
-}
-
-// fast path: all 64 + 3 look-ahead bases clean -> 32 pentamers at even offsets, one conflict-free LDS atomic each
-__device__ __forceinline__ void k0_fast_lane(const LaneData& d, uint32_t* h5_lane) {
-  const uint32_t w[5] = {d.c.x, d.c.y, d.c.z, d.c.w, d.nc};
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const uint32_t lo = w[j], hi = w[j + 1];
-#pragma unroll
-    for (int t = 0; t < 6; ++t) lds_inc(h5_lane + (((lo >> (4 * t)) & 0x3FFu) << 5));
-    const uint32_t x6 = __builtin_amdgcn_alignbit(hi, lo, 24);  // bits 24.. of hi:lo
-    lds_inc(h5_lane + ((x6 & 0x3FFu) << 5));
-    lds_inc(h5_lane + (((x6 >> 4) & 0x3FFu) << 5));
-  }
-}
-
-__device__ __forceinline__ void k0_process(LaneData d, uint32_t* lds, uint32_t tid) {
-  // look-ahead from the next lane (lane 63 keeps what it loaded itself)
-  d.nc = (uint32_t)__builtin_amdgcn_update_dpp((int)d.nc, (int)d.c.x, 0x130 /*wave_shl:1*/, 0xf, 0xf, false);
-  d.nm = (uint32_t)__builtin_amdgcn_update_dpp((int)d.nm, (int)d.m.x, 0x130, 0xf, 0xf, false);
-  const bool all_clean = (d.m.x & d.m.y) == 0xFFFFFFFFu && (d.nm & 7u) == 7u;
-  const bool none_clean = (d.m.x | d.m.y) == 0u;
-  if (__all(all_clean)) {
-    k0_fast_lane(d, lds + (tid & 31u));
-  } else if (!__all(none_clean)) {
-    if (all_clean) k0_fast_lane(d, lds + (tid & 31u));
-    else if (!none_clean) k0_slow_lane(d, lds + K0_H5_WORDS, lds + K0_H5_WORDS + 256, lds + K0_H5_WORDS + 320);
-  }
-}
-
-// fold the pentamer histogram into tetramers and push the block's partial counts to the genome's accumulator
-__device__ void k0_flush(uint32_t* lds, unsigned long long* __restrict__ acc_g, uint32_t tid) {
-  uint32_t* F4 = lds + K0_H5_WORDS;
-  uint32_t* E3 = F4 + 256;
-  uint32_t* E2 = E3 + 64;
-  uint32_t sum = 0;
-  uint32_t* bin = lds + tid * K0_REPL;
-#pragma unroll 8
-  for (int r = 0; r < K0_REPL; ++r) {
-    const uint32_t rr = (r + tid) & (K0_REPL - 1);  // rotate: consecutive lanes read consecutive banks
-    sum += bin[rr];
-    bin[rr] = 0;
-  }
-  if (sum) {
-    atomicAdd(&F4[nat4_from_lowfirst(tid & 255u)], sum);  // tetramer at the even position
-    atomicAdd(&F4[nat4_from_lowfirst(tid >> 2)], sum);    // tetramer at the following odd position
-  }
-  __syncthreads();
-  if (tid < PG_ACC_WORDS) {
-    // acc layout: E2[16] | E3[64] | F4[256]
-    uint32_t* src = tid < 16 ? &E2[tid] : tid < 80 ? &E3[tid - 16] : &F4[tid - 80];
-    const uint32_t v = *src;
-    if (v) atomicAdd(&acc_g[tid], (unsigned long long)v);
-    *src = 0;
-  }
-  __syncthreads();
-}
-
-__global__ __launch_bounds__(K0_BLOCK) void tetra_count_kernel(const uint32_t* __restrict__ codes,
-                                                               const uint32_t* __restrict__ mask,
-                                                               const uint32_t* __restrict__ w_tile,
-                                                               const uint32_t* __restrict__ w_batch, uint32_t n_work,
-                                                               unsigned long long* __restrict__ acc) {
-  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-  const uint32_t tid = threadIdx.x;
-  const uint32_t w0 = (uint32_t)(((uint64_t)blockIdx.x * n_work) / gridDim.x);
-  const uint32_t w1 = (uint32_t)(((uint64_t)(blockIdx.x + 1) * n_work) / gridDim.x);
-  if (w0 >= w1) return;
-  {
-    uint4* z = reinterpret_cast<uint4*>(lds);
-    for (uint32_t i = tid; i < K0_LDS_WORDS / 4; i += K0_BLOCK) z[i] = make_uint4(0, 0, 0, 0);
-  }
-  __syncthreads();
-  uint32_t cur = w_batch[w0];
-  uint32_t since_flush = 0;
-  LaneData nxt = k0_load(codes, mask, w_tile[w0], tid);
-  for (uint32_t w = w0; w < w1; ++w) {
-    const uint32_t b = w_batch[w];
-    if (b != cur || since_flush >= K0_FORCE_FLUSH_TILES) {
-      __syncthreads();
-      k0_flush(lds, acc + (size_t)cur * PG_ACC_WORDS, tid);
-      cur = b;
-      since_flush = 0;
-    }
-    const LaneData d = nxt;
-    if (w + 1 < w1) nxt = k0_load(codes, mask, w_tile[w + 1], tid);
-    k0_process(d, lds, tid);
-    ++since_flush;
-  }
-  __syncthreads();
-  k0_flush(lds, acc + (size_t)cur * PG_ACC_WORDS, tid);
-}
+#include "pg_tetra_count.h"
 
 // ---- K1: counts + Z-scores --------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t rc_index(uint32_t x, int k) {
@@ -309,11 +161,15 @@ __global__ __launch_bounds__(256) void tetra_pairs_kernel(const double* __restri
 }  // namespace
 
 // ---- host launchers ---------------------------------------------------------------------------------------------
+// configuration chosen on MI355X with tools/microbench/count_bench.hip (profiles/r01_count_variants.txt)
+constexpr int K0_PF = 2, K0_REPL = 1;
+
 int pg_launch_tetra_count(pg_ctx* ctx, uint32_t n_batch) {
   static bool attr_set = false;
-  const size_t lds_bytes = K0_LDS_WORDS * sizeof(uint32_t);
+  const size_t lds_bytes = K0Lds<K0_REPL>::WORDS * sizeof(uint32_t);
+  auto kern = tetra_count_kernel<K0_PF, 0, K0_REPL>;
   if (!attr_set) {
-    PG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(tetra_count_kernel),
+    PG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     attr_set = true;
   }
@@ -321,8 +177,8 @@ int pg_launch_tetra_count(pg_ctx* ctx, uint32_t n_batch) {
   if (ctx->n_work == 0) return PG_OK;
   const uint32_t grid = ctx->n_work < (uint32_t)ctx->num_cu ? ctx->n_work : (uint32_t)ctx->num_cu;
   pg_prof_begin(ctx, PG_K_TETRA_COUNT);
-  hipLaunchKernelGGL(tetra_count_kernel, dim3(grid), dim3(K0_BLOCK), lds_bytes, ctx->stream, ctx->d_codes, ctx->d_mask,
-                     ctx->d_w_tile, ctx->d_w_batch, ctx->n_work, ctx->d_acc);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(K0_BLOCK), lds_bytes, ctx->stream, ctx->d_codes, ctx->d_mask,
+                     ctx->d_seg_tile0, ctx->d_seg_prefix, n_batch, ctx->d_acc);
   pg_prof_end(ctx);
   PG_HIP(ctx, hipGetLastError());
   return PG_OK;

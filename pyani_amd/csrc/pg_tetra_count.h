@@ -1,0 +1,262 @@
+// pg_tetra_count.h — K0, the HBM-streaming k-mer histogram kernel (device code; included inside an anonymous
+// namespace by pg_tetra.hip and by tools/microbench/count_bench.hip, which times its variants).
+//
+// What bounds it (measured on MI355X, profiles/r01_*): the stream itself runs at the HBM copy peak (~6.1 TB/s) when the
+// LDS atomics are removed, and the LDS atomic pipe sustains ~32 ds_add_u32 lanes/ns/CU conflict-free (~20 with
+// random banks).  One atomic per base would be 5x too slow, so the kernel counts HEPTAmers at stride 4 — one
+// atomic per 4 bases — into a 16384-bin u32 histogram (64 KiB of LDS) and folds each heptamer bin into the four
+// tetramers it contains when a block leaves a genome (a cascade of marginal sums, ~30 LDS ops per thread).
+//
+// Other design points:
+//   * di-/tri-nucleotide counts are NOT histogrammed: they are marginals of the tetramer counts plus the rare
+//     windows that end at a dirty base / record end (E2/E3), produced by a slow path that only waves seeing a
+//     dirty base take.  The reverse strand is never scanned: c_k[x] = F_k[x] + F_k[rc(x)] (K1).
+//   * each lane streams 64 bases per tile: one 16 B code load + one 8 B mask load, coalesced (1 KiB + 512 B per
+//     wave); the 3-base look-ahead comes from the neighbour lane through DPP wave_shl:1, and for lane 63 from a
+//     wave-uniform dword load.  No branches around loads, no scalar loads in the hot loop: the compiler can count
+//     vmcnt exactly, so a PF-deep register prefetch ring really keeps PF tiles in flight.
+//   * blocks own contiguous ranges of super-tiles; tile indices inside a genome segment are arithmetic.
+//
+// Template knobs (the product instantiates ONE configuration; the microbenchmark times the others):
+//   PF    register prefetch depth in super-tiles
+//   MODE  0 = full kernel, 1 = loads only (no LDS atomics), 2 = atomics only (no global loads in the loop)
+//   REPL  histogram replicas (1 or 2; lane parity selects the replica)
+#pragma once
+
+constexpr int K0_BLOCK = 1024;
+constexpr int K0_H7_BINS = 16384;
+constexpr uint32_t K0_FORCE_FLUSH_TILES = 16384;  // 2^30 bases: keeps every u32 bin far from overflow
+
+// LDS layout in words: H7[REPL][16384] | S_hi[4096] | S_lo[4096] | S_hi2[1024] | S_lo2[1024] | F4[256] | E3[64] | E2[16]
+template <int REPL>
+struct K0Lds {
+  static constexpr int H7 = 0;
+  static constexpr int S_HI = H7 + REPL * K0_H7_BINS;
+  static constexpr int S_LO = S_HI + 4096;
+  static constexpr int S_HI2 = S_LO + 4096;
+  static constexpr int S_LO2 = S_HI2 + 1024;
+  static constexpr int F4 = S_LO2 + 1024;
+  static constexpr int E3 = F4 + 256;
+  static constexpr int E2 = E3 + 64;
+  static constexpr int WORDS = E2 + 16;
+  static_assert(WORDS * 4 <= 160 * 1024, "LDS budget of one gfx950 CU exceeded");
+};
+
+__device__ __forceinline__ uint32_t nat4_from_lowfirst(uint32_t r) {
+  // r = b0 | b1<<2 | b2<<4 | b3<<6 (first base in the low bits)  ->  b0<<6 | b1<<4 | b2<<2 | b3
+  return ((r & 3u) << 6) | ((r & 0xCu) << 2) | ((r & 0x30u) >> 2) | ((r & 0xC0u) >> 6);
+}
+
+__device__ __forceinline__ void lds_inc(uint32_t* p) {
+  __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+struct LaneData {
+  uint4 c;          // 64 bases of codes
+  uint2 m;          // 64 mask bits
+  uint32_t nc, nm;  // first code / mask word after the WAVE's span (same value in all lanes)
+};
+
+typedef uint32_t k0_v4u __attribute__((ext_vector_type(4)));
+typedef uint32_t k0_v2u __attribute__((ext_vector_type(2)));
+
+// Loads of one lane for the tile whose first 64-base span index is span0 (= tile * 1024).  Branch-free.
+__device__ __forceinline__ LaneData k0_load(const uint32_t* __restrict__ codes, const uint32_t* __restrict__ mask,
+                                            uint64_t span0, uint32_t tid) {
+  LaneData d;
+  const uint64_t lane_span = span0 + tid;
+  const k0_v4u cv = __builtin_nontemporal_load(reinterpret_cast<const k0_v4u*>(codes + lane_span * 4));  // streamed once
+  const k0_v2u mv = __builtin_nontemporal_load(reinterpret_cast<const k0_v2u*>(mask + lane_span * 2));
+  d.c = make_uint4(cv.x, cv.y, cv.z, cv.w);
+  d.m = make_uint2(mv.x, mv.y);
+  const uint64_t next_wave_span = (lane_span | 63u) + 1u;  // same address in all 64 lanes: one broadcast fetch
+  d.nc = codes[next_wave_span * 4];
+  d.nm = mask[next_wave_span * 2];
+  return d;
+}
+
+// One heptamer whose 7 mask bits are not all clean: its four window starts q = 0..3 are classified one by one.
+// m7: mask bits of bases p..p+6; h: the 14-bit heptamer code (dirty bases are 0).  Rare (record ends, N runs).
+__device__ __forceinline__ void k0_dirty_heptamer(uint32_t m7, uint32_t h, uint32_t* F4, uint32_t* E3, uint32_t* E2) {
+  const uint32_t v2 = m7 & (m7 >> 1), v3 = v2 & (m7 >> 2), v4 = v3 & (m7 >> 3);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const uint32_t r = h >> (2 * q);
+    if ((v4 >> q) & 1u) lds_inc(&F4[nat4_from_lowfirst(r & 0xFFu)]);
+    else if ((v3 >> q) & 1u) lds_inc(&E3[((r & 3u) << 4) | (r & 0xCu) | ((r >> 4) & 3u)]);   // trimer, first base MSB
+    else if ((v2 >> q) & 1u) lds_inc(&E2[((r & 3u) << 2) | ((r >> 2) & 3u)]);                 // dinucleotide
+  }
+}
+
+// 16 heptamers at offsets 0,4,..,60 of the lane's 64 bases (+3 look-ahead), one LDS atomic each.
+// CHECK = false: the whole wave is known clean (no mask work at all).  CHECK = true: every heptamer tests its 7 mask
+// bits and falls back to k0_dirty_heptamer when one is dirty — still one pass, ~1.5x the clean cost for that wave.
+template <bool CHECK>
+__device__ __forceinline__ void k0_count_lane(const LaneData& d, uint32_t* lds_h7, uint32_t* F4, uint32_t* E3, uint32_t* E2) {
+  const uint32_t w[5] = {d.c.x, d.c.y, d.c.z, d.c.w, d.nc};
+  // mask bits starting at base 0, 16, 32, 48 (each word holds >= 19 valid bits from there)
+  const uint32_t mw[4] = {d.m.x, __builtin_amdgcn_alignbit(d.m.y, d.m.x, 16), d.m.y, __builtin_amdgcn_alignbit(d.nm, d.m.y, 16)};
+  char* h7b = reinterpret_cast<char*>(lds_h7);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const uint32_t lo = w[j], hi = w[j + 1];
+    // byte offsets (heptamer << 2) of the four heptamers that start in this code word
+    const uint32_t off[4] = {lo << 2, lo >> 6, lo >> 14, __builtin_amdgcn_alignbit(hi, lo, 22)};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const uint32_t o = off[t] & 0xFFFCu;
+      if (!CHECK) {
+        lds_inc(reinterpret_cast<uint32_t*>(h7b + o));
+      } else {
+        const uint32_t m7 = (mw[j] >> (4 * t)) & 0x7Fu;
+        if (m7 == 0x7Fu) lds_inc(reinterpret_cast<uint32_t*>(h7b + o));
+        else if (m7 & 0xFu) k0_dirty_heptamer(m7, o >> 2, F4, E3, E2);
+      }
+    }
+  }
+}
+
+template <int MODE, int REPL>
+__device__ __forceinline__ void k0_process(LaneData d, uint32_t* lds, uint32_t tid, uint32_t& sink) {
+  // look-ahead from the next lane (lane 63 keeps the wave-uniform word it loaded)
+  d.nc = (uint32_t)__builtin_amdgcn_update_dpp((int)d.nc, (int)d.c.x, 0x130 /*wave_shl:1*/, 0xf, 0xf, false);
+  d.nm = (uint32_t)__builtin_amdgcn_update_dpp((int)d.nm, (int)d.m.x, 0x130, 0xf, 0xf, false);
+  if (MODE == 1) {  // loads only: consume the data so the loads are not dead
+    sink ^= d.c.x ^ d.c.y ^ d.c.z ^ d.c.w ^ d.m.x ^ d.m.y ^ d.nc ^ d.nm;
+    return;
+  }
+  using L = K0Lds<REPL>;
+  const bool all_clean = (d.m.x & d.m.y) == 0xFFFFFFFFu && (d.nm & 7u) == 7u;
+  const bool none_clean = (d.m.x | d.m.y) == 0u;
+  uint32_t* h7 = lds + L::H7 + (REPL == 2 ? ((tid & 1u) << 14) : 0u);
+  if (__all(all_clean)) {
+    k0_count_lane<false>(d, h7, nullptr, nullptr, nullptr);
+  } else if (!__all(none_clean)) {
+    if (!none_clean) k0_count_lane<true>(d, h7, lds + L::F4, lds + L::E3, lds + L::E2);
+  }
+}
+
+// Fold the heptamer histogram into the tetramers at its four offsets and push the block's partial counts to the
+// genome's accumulator.  Low-first encoding: heptamer f = b0 | b1<<2 | ... | b6<<12.
+//   S_hi[b0..b5] = sum_b6 H7      S_hi2[b0..b4] = sum_b5 S_hi     T0[b0..b3] = sum_b4 S_hi2   T1[b1..b4] = sum_b0 S_hi2
+//   S_lo[b1..b6] = sum_b0 H7      S_lo2[b2..b6] = sum_b1 S_lo     T2[b2..b5] = sum_b6 S_lo2   T3[b3..b6] = sum_b2 S_lo2
+template <int REPL>
+__device__ __forceinline__ void k0_flush(uint32_t* lds, unsigned long long* __restrict__ acc_g, uint32_t tid) {
+  using L = K0Lds<REPL>;
+  uint32_t* H7 = lds + L::H7;
+  uint32_t* S_hi = lds + L::S_HI;
+  uint32_t* S_lo = lds + L::S_LO;
+  uint32_t* S_hi2 = lds + L::S_HI2;
+  uint32_t* S_lo2 = lds + L::S_LO2;
+  uint32_t* F4 = lds + L::F4;
+  uint32_t* E3 = lds + L::E3;
+  uint32_t* E2 = lds + L::E2;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const uint32_t o = tid + i * K0_BLOCK;  // 0..4095
+    uint32_t hi = 0, lo = 0;
+#pragma unroll
+    for (int r = 0; r < REPL; ++r) {
+      const uint32_t* H = H7 + r * K0_H7_BINS;
+      hi += H[o] + H[o + 4096] + H[o + 8192] + H[o + 12288];
+      const uint4 q = *reinterpret_cast<const uint4*>(H + 4 * o);
+      lo += q.x + q.y + q.z + q.w;
+    }
+    S_hi[o] = hi;
+    S_lo[o] = lo;
+  }
+  __syncthreads();
+  {  // zero H7 for the next genome (all reads of H7 are done), and the second marginal
+    uint4* z = reinterpret_cast<uint4*>(H7);
+#pragma unroll
+    for (int i = 0; i < REPL * 4; ++i) z[tid + i * K0_BLOCK] = make_uint4(0, 0, 0, 0);
+    S_hi2[tid] = S_hi[tid] + S_hi[tid + 1024] + S_hi[tid + 2048] + S_hi[tid + 3072];
+    const uint4 q = *reinterpret_cast<const uint4*>(S_lo + 4 * tid);
+    S_lo2[tid] = q.x + q.y + q.z + q.w;
+  }
+  __syncthreads();
+  if (tid < 256) {
+    const uint32_t t0 = S_hi2[tid] + S_hi2[tid + 256] + S_hi2[tid + 512] + S_hi2[tid + 768];
+    const uint4 q1 = *reinterpret_cast<const uint4*>(S_hi2 + 4 * tid);
+    const uint32_t t2 = S_lo2[tid] + S_lo2[tid + 256] + S_lo2[tid + 512] + S_lo2[tid + 768];
+    const uint4 q3 = *reinterpret_cast<const uint4*>(S_lo2 + 4 * tid);
+    const uint32_t tot = t0 + (q1.x + q1.y + q1.z + q1.w) + t2 + (q3.x + q3.y + q3.z + q3.w);
+    if (tot) atomicAdd(&F4[nat4_from_lowfirst(tid)], tot);  // the slow path may have counted into F4 as well
+  }
+  __syncthreads();
+  if (tid < PG_ACC_WORDS) {
+    // acc layout: E2[16] | E3[64] | F4[256]
+    uint32_t* src = tid < 16 ? &E2[tid] : tid < 80 ? &E3[tid - 16] : &F4[tid - 80];
+    const uint32_t v = *src;
+    if (v) atomicAdd(&acc_g[tid], (unsigned long long)v);
+    *src = 0;
+  }
+  __syncthreads();
+}
+
+// One contiguous run of `n` super-tiles of ONE genome starting at arena tile `tile0`.
+template <int PF, int MODE, int REPL>
+__device__ __forceinline__ void k0_segment(const uint32_t* __restrict__ codes, const uint32_t* __restrict__ mask,
+                                           uint32_t tile0, uint32_t n, uint32_t* lds, uint32_t tid, uint32_t& sink) {
+  const uint32_t last = tile0 + n - 1;
+  LaneData ring[PF];
+#pragma unroll
+  for (int s = 0; s < PF; ++s) ring[s] = k0_load(codes, mask, (uint64_t)min(tile0 + s, last) * K0_BLOCK, tid);
+  for (uint32_t i = 0; i < n; i += PF) {
+#pragma unroll
+    for (int s = 0; s < PF; ++s) {
+      if (i + s < n) {  // uniform
+        const LaneData d = ring[s];
+        // refill this slot PF tiles ahead; past the end it re-reads the last tile (in bounds, result unused)
+        if (MODE != 2) ring[s] = k0_load(codes, mask, (uint64_t)min(tile0 + i + s + PF, last) * K0_BLOCK, tid);
+        k0_process<MODE, REPL>(d, lds, tid, sink);
+      }
+    }
+  }
+}
+
+// seg_prefix[0..n_batch]: cumulative super-tile counts of the batch genomes; seg_tile0[b]: first arena tile of genome b.
+template <int PF, int MODE, int REPL>
+__global__ __launch_bounds__(K0_BLOCK) void tetra_count_kernel(const uint32_t* __restrict__ codes,
+                                                               const uint32_t* __restrict__ mask,
+                                                               const uint32_t* __restrict__ seg_tile0,
+                                                               const uint32_t* __restrict__ seg_prefix, uint32_t n_batch,
+                                                               unsigned long long* __restrict__ acc) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  using L = K0Lds<REPL>;
+  const uint32_t tid = threadIdx.x;
+  const uint32_t n_work = seg_prefix[n_batch];
+  const uint32_t w0 = (uint32_t)(((uint64_t)blockIdx.x * n_work) / gridDim.x);
+  const uint32_t w1 = (uint32_t)(((uint64_t)(blockIdx.x + 1) * n_work) / gridDim.x);
+  if (w0 >= w1) return;
+  {
+    uint4* z = reinterpret_cast<uint4*>(lds);
+    for (uint32_t i = tid; i < L::WORDS / 4; i += K0_BLOCK) z[i] = make_uint4(0, 0, 0, 0);
+  }
+  // genome containing w0: largest b with seg_prefix[b] <= w0 (uniform binary search)
+  uint32_t lo = 0, hi = n_batch;
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (seg_prefix[mid] <= w0) lo = mid; else hi = mid;
+  }
+  __syncthreads();
+  uint32_t sink = 0;
+  uint32_t b = lo, w = w0;
+  while (w < w1) {
+    const uint32_t p0 = seg_prefix[b], p1 = seg_prefix[b + 1];
+    if (p1 > w) {
+      const uint32_t end = min(w1, p1);
+      uint32_t tile = seg_tile0[b] + (w - p0);
+      while (w < end) {  // chunked only to bound the u32 bins
+        const uint32_t n = min(end - w, K0_FORCE_FLUSH_TILES);
+        k0_segment<PF, MODE, REPL>(codes, mask, tile, n, lds, tid, sink);
+        __syncthreads();
+        k0_flush<REPL>(lds, acc + (size_t)b * PG_ACC_WORDS, tid);
+        w += n;
+        tile += n;
+      }
+    }
+    ++b;
+  }
+  if (MODE == 1 && sink == 0x12345678u) acc[0] = sink;  // keeps the loads alive, practically never true
+}
