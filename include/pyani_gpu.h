@@ -85,7 +85,9 @@ int pg_tetra_matrix(pg_ctx* ctx, const int32_t* genome_ids, uint32_t n, double* 
                     double* corr_out);
 /* Asynchronous form used for throughput runs: queues one pass (results land in an internal pinned buffer,
  * fetched by pg_tetra_matrix_fetch after pg_sync).  Queue any number of passes, then pg_sync once. */
-int pg_tetra_matrix_enqueue(pg_ctx* ctx, const int32_t* genome_ids, uint32_t n);
+/* fetch_z != 0: Z and presence are copied back too (otherwise only the matrix: the reference's calculate_tetra
+ * returns just the correlation DataFrame). */
+int pg_tetra_matrix_enqueue(pg_ctx* ctx, const int32_t* genome_ids, uint32_t n, int fetch_z);
 int pg_tetra_matrix_fetch(pg_ctx* ctx, uint32_t n, double* z_out, uint8_t* present_out, double* corr_out);
 
 /* Multi-GPU building blocks (one process per GPU; the exchange itself is an RCCL all-gather done by the host
@@ -99,6 +101,9 @@ int pg_tetra_corr_rows_dev(pg_ctx* ctx, const double* d_z, const uint8_t* d_pres
 /* ---- measurement ---------------------------------------------------------------------------------------- */
 /* When enabled, every kernel launch is bracketed by HIP events on the context's stream. */
 int pg_profile_enable(pg_ctx* ctx, int on);
+/* Restrict event bracketing to the kernels in `kernel_mask` (bit i = PG_K_*) and to every `every_n`-th launch of
+ * each, so that measuring inside a timed region costs next to nothing.  Default: all kernels, every launch. */
+int pg_profile_config(pg_ctx* ctx, uint32_t kernel_mask, uint32_t every_n);
 int pg_profile_reset(pg_ctx* ctx);
 #define PG_K_TETRA_COUNT 0
 #define PG_K_TETRA_FINALIZE 1

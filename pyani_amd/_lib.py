@@ -28,11 +28,12 @@ SIGNATURES = {
     "pg_tetra_zscores": (_int, [_vp, _vp, _vp, _vp, _u32, _vp, _vp]),
     "pg_tetra_corr": (_int, [_vp, _vp, _vp, _u32, _vp]),
     "pg_tetra_matrix": (_int, [_vp, _vp, _u32, _vp, _vp, _vp]),
-    "pg_tetra_matrix_enqueue": (_int, [_vp, _vp, _u32]),
+    "pg_tetra_matrix_enqueue": (_int, [_vp, _vp, _u32, _int]),
     "pg_tetra_matrix_fetch": (_int, [_vp, _u32, _vp, _vp, _vp]),
     "pg_tetra_zscores_dev": (_int, [_vp, _vp, _u32, _vp, _vp]),
     "pg_tetra_corr_rows_dev": (_int, [_vp, _vp, _vp, _u32, _u32, _u32, _vp]),
     "pg_profile_enable": (_int, [_vp, _int]),
+    "pg_profile_config": (_int, [_vp, _u32, _u32]),
     "pg_profile_reset": (_int, [_vp]),
     "pg_profile_get": (_int, [_vp, _int, _P(ctypes.c_double), _P(_u64)]),
     "pg_kernel_name": (ctypes.c_char_p, [_int]),

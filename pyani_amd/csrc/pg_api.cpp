@@ -17,15 +17,19 @@ static const char* const KERNEL_NAMES[PG_K__COUNT] = {"tetra_count_kernel", "tet
 
 // ---- profiling ----------------------------------------------------------------------------------------------
 void pg_prof_begin(pg_ctx* ctx, int which) {
-  if (!ctx->profiling) return;
+  ctx->prof_open = false;
+  if (!ctx->profiling || !((ctx->prof_mask >> which) & 1u)) return;
+  if ((ctx->prof_seen[which]++ % ctx->prof_every) != 0) return;
   PgEventPair p;
   p.which = which;
   if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return;
   (void)hipEventRecord(p.a, ctx->stream);
   ctx->events.push_back(p);
+  ctx->prof_open = true;
 }
 void pg_prof_end(pg_ctx* ctx) {
-  if (!ctx->profiling || ctx->events.empty()) return;
+  if (!ctx->prof_open || ctx->events.empty()) return;
+  ctx->prof_open = false;
   (void)hipEventRecord(ctx->events.back().b, ctx->stream);
 }
 static void prof_drain(pg_ctx* ctx) {
@@ -200,41 +204,50 @@ int ensure_batch_scratch(pg_ctx* ctx, uint32_t n) {
     if ((rc = dev_realloc(ctx, ctx->d_seg_tile0, cap))) return rc;
     if ((rc = dev_realloc(ctx, ctx->d_seg_prefix, (size_t)cap + 1))) return rc;
     if ((rc = dev_realloc(ctx, ctx->d_acc, (size_t)cap * PG_ACC_WORDS))) return rc;
+    PG_HIP(ctx, hipMemsetAsync(ctx->d_acc, 0, (size_t)cap * PG_ACC_WORDS * 8, ctx->stream));
     if ((rc = dev_realloc(ctx, ctx->d_counts, (size_t)cap * PG_ACC_WORDS))) return rc;
-    if ((rc = dev_realloc(ctx, ctx->d_z, (size_t)cap * 256))) return rc;
-    if ((rc = dev_realloc(ctx, ctx->d_present, (size_t)cap * 256))) return rc;
     if ((rc = dev_realloc(ctx, ctx->d_dev, (size_t)cap * 256))) return rc;
     if ((rc = dev_realloc(ctx, ctx->d_ss, (size_t)cap))) return rc;
+    if ((rc = dev_realloc(ctx, ctx->d_keybits, (size_t)cap * 4))) return rc;
     ctx->batch_cap = cap;
     ctx->batch_ids.clear();
-  }
-  if (!ctx->d_flags) {
-    int rc;
-    if ((rc = dev_realloc(ctx, ctx->d_flags, 2))) return rc;
   }
   if (n > ctx->h_batch_cap) {
     const uint32_t cap = std::max<uint32_t>(n, ctx->h_batch_cap * 2);
     int rc;
-    if ((rc = host_realloc(ctx, ctx->h_z, (size_t)cap * 256))) return rc;
-    if ((rc = host_realloc(ctx, ctx->h_present, (size_t)cap * 256))) return rc;
     if ((rc = host_realloc(ctx, ctx->h_counts, (size_t)cap * PG_ACC_WORDS))) return rc;
-    if (!ctx->h_flags && (rc = host_realloc(ctx, ctx->h_flags, 2))) return rc;
     ctx->h_batch_cap = cap;
   }
   return PG_OK;
 }
 
-int ensure_corr(pg_ctx* ctx, uint32_t n) {
-  const uint64_t need = (uint64_t)n * n;
-  int rc;
-  if (need > ctx->corr_cap) {
-    if ((rc = dev_realloc(ctx, ctx->d_corr, need))) return rc;
-    ctx->corr_cap = need;
+// result block layout for a pass over n genomes
+struct ResultLayout {
+  uint64_t off_z, off_corr, off_present, bytes, bytes_corr_only;
+  explicit ResultLayout(uint32_t n, bool corr) {
+    off_corr = 16;
+    off_z = off_corr + (corr ? (uint64_t)n * n * 8 : 0);
+    off_present = off_z + (uint64_t)n * 256 * 8;
+    bytes = off_present + (uint64_t)n * 256;
+    bytes_corr_only = off_z;
   }
-  if (need > ctx->h_corr_cap) {
-    if ((rc = host_realloc(ctx, ctx->h_corr, need))) return rc;
-    ctx->h_corr_cap = need;
+};
+
+int ensure_result(pg_ctx* ctx, uint32_t n, bool corr) {
+  const ResultLayout L(n, corr);
+  if (L.bytes > ctx->result_cap) {
+    const uint64_t cap = std::max<uint64_t>(L.bytes, ctx->result_cap + ctx->result_cap / 2);
+    int rc;
+    PG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if ((rc = dev_realloc(ctx, ctx->d_result, cap))) return rc;
+    if ((rc = host_realloc(ctx, ctx->h_result, cap))) return rc;
+    PG_HIP(ctx, hipMemsetAsync(ctx->d_result, 0, 16, ctx->stream));
+    ctx->result_cap = cap;
   }
+  ctx->d_flags = reinterpret_cast<int32_t*>(ctx->d_result);
+  ctx->d_z = reinterpret_cast<double*>(ctx->d_result + L.off_z);
+  ctx->d_corr = reinterpret_cast<double*>(ctx->d_result + L.off_corr);
+  ctx->d_present = ctx->d_result + L.off_present;
   return PG_OK;
 }
 
@@ -265,9 +278,10 @@ int ensure_batch(pg_ctx* ctx, const int32_t* ids, uint32_t n) {
 }
 
 int check_flags(pg_ctx* ctx, uint32_t n) {
+  const int32_t* h_flags = reinterpret_cast<const int32_t*>(ctx->h_result);
   if (n >= 2) {
-    if (ctx->h_flags[0] & 1) return pg_fail(ctx, PG_E_KEYSET, "genomes have different observed-tetranucleotide key sets");
-    if (ctx->h_flags[1] == 0) return pg_fail(ctx, PG_E_EMPTY, "no tetranucleotide observed in any genome");
+    if (h_flags[0] & 1) return pg_fail(ctx, PG_E_KEYSET, "genomes have different observed-tetranucleotide key sets");
+    if (h_flags[1] == 0) return pg_fail(ctx, PG_E_EMPTY, "no tetranucleotide observed in any genome");
   }
   return PG_OK;
 }
@@ -310,7 +324,7 @@ void pg_destroy(pg_ctx* ctx) {
                  ctx->d_counts, ctx->d_z, ctx->d_present, ctx->d_dev, ctx->d_ss, ctx->d_flags, ctx->d_corr};
   for (void* p : dev)
     if (p) (void)hipFree(p);
-  void* host[] = {ctx->h_z, ctx->h_present, ctx->h_corr, ctx->h_flags, ctx->h_counts};
+  void* host[] = {ctx->h_result, ctx->h_counts};
   for (void* p : host)
     if (p) (void)hipHostFree(p);
   (void)hipStreamDestroy(ctx->stream);
@@ -447,14 +461,22 @@ int pg_tetra_algorithmic_bytes(const pg_ctx* ctx, const int32_t* ids, uint32_t n
 }
 
 // ---- TETRA ----------------------------------------------------------------------------------------------------
+namespace {
+// queue: D2H of the first `bytes` of the result block
+int fetch_result_async(pg_ctx* ctx, uint64_t bytes) {
+  PG_HIP(ctx, hipMemcpyAsync(ctx->h_result, ctx->d_result, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  return PG_OK;
+}
+}  // namespace
+
 int pg_tetra_counts(pg_ctx* ctx, const int32_t* ids, uint32_t n, uint64_t* c2, uint64_t* c3, uint64_t* c4) {
   if (!ctx || (n && !ids)) return pg_fail(ctx, PG_E_ARG, "bad argument");
   PG_HIP(ctx, hipSetDevice(ctx->device));
   int rc;
   if ((rc = ensure_batch(ctx, ids, n))) return rc;
+  if ((rc = ensure_result(ctx, n, false))) return rc;
   if (n == 0) return PG_OK;
   if ((rc = pg_launch_tetra_count(ctx, n))) return rc;
-  // finalize without Z (z == nullptr path needs d_z null): run the kernel with z outputs, cheap
   if ((rc = pg_launch_tetra_finalize(ctx, n, ctx->d_acc))) return rc;
   PG_HIP(ctx, hipMemcpyAsync(ctx->h_counts, ctx->d_counts, (size_t)n * PG_ACC_WORDS * 8, hipMemcpyDeviceToHost, ctx->stream));
   PG_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -473,8 +495,8 @@ int pg_tetra_zscores(pg_ctx* ctx, const uint64_t* c2, const uint64_t* c3, const 
   PG_HIP(ctx, hipSetDevice(ctx->device));
   int rc;
   if ((rc = ensure_batch_scratch(ctx, n))) return rc;
+  if ((rc = ensure_result(ctx, n, false))) return rc;
   if (n == 0) return PG_OK;
-  ctx->batch_ids.clear();  // d_batch_gid is not used on this path, but scratch contents change
   for (uint32_t g = 0; g < n; ++g) {
     unsigned long long* dst = ctx->h_counts + (size_t)g * PG_ACC_WORDS;
     std::memcpy(dst, c2 + (size_t)g * 16, 16 * 8);
@@ -483,11 +505,11 @@ int pg_tetra_zscores(pg_ctx* ctx, const uint64_t* c2, const uint64_t* c3, const 
   }
   PG_HIP(ctx, hipMemcpyAsync(ctx->d_counts, ctx->h_counts, (size_t)n * PG_ACC_WORDS * 8, hipMemcpyHostToDevice, ctx->stream));
   if ((rc = pg_launch_tetra_finalize(ctx, n, nullptr))) return rc;
-  PG_HIP(ctx, hipMemcpyAsync(ctx->h_z, ctx->d_z, (size_t)n * 256 * 8, hipMemcpyDeviceToHost, ctx->stream));
-  PG_HIP(ctx, hipMemcpyAsync(ctx->h_present, ctx->d_present, (size_t)n * 256, hipMemcpyDeviceToHost, ctx->stream));
+  const ResultLayout L(n, false);
+  if ((rc = fetch_result_async(ctx, L.bytes))) return rc;
   PG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  if (z) std::memcpy(z, ctx->h_z, (size_t)n * 256 * 8);
-  if (present) std::memcpy(present, ctx->h_present, (size_t)n * 256);
+  if (z) std::memcpy(z, ctx->h_result + L.off_z, (size_t)n * 256 * 8);
+  if (present) std::memcpy(present, ctx->h_result + L.off_present, (size_t)n * 256);
   return PG_OK;
 }
 
@@ -496,57 +518,55 @@ int pg_tetra_corr(pg_ctx* ctx, const double* z, const uint8_t* present, uint32_t
   PG_HIP(ctx, hipSetDevice(ctx->device));
   int rc;
   if ((rc = ensure_batch_scratch(ctx, n))) return rc;
-  if ((rc = ensure_corr(ctx, n))) return rc;
+  if ((rc = ensure_result(ctx, n, true))) return rc;
   if (n == 0) return PG_OK;
-  std::memcpy(ctx->h_z, z, (size_t)n * 256 * 8);
-  std::memcpy(ctx->h_present, present, (size_t)n * 256);
-  PG_HIP(ctx, hipMemcpyAsync(ctx->d_z, ctx->h_z, (size_t)n * 256 * 8, hipMemcpyHostToDevice, ctx->stream));
-  PG_HIP(ctx, hipMemcpyAsync(ctx->d_present, ctx->h_present, (size_t)n * 256, hipMemcpyHostToDevice, ctx->stream));
+  const ResultLayout L(n, true);
+  PG_HIP(ctx, hipStreamSynchronize(ctx->stream));  // h_result is reused as the upload staging area
+  std::memcpy(ctx->h_result + L.off_z, z, (size_t)n * 256 * 8);
+  std::memcpy(ctx->h_result + L.off_present, present, (size_t)n * 256);
+  PG_HIP(ctx, hipMemcpyAsync(ctx->d_z, ctx->h_result + L.off_z, (size_t)n * 256 * 8, hipMemcpyHostToDevice, ctx->stream));
+  PG_HIP(ctx, hipMemcpyAsync(ctx->d_present, ctx->h_result + L.off_present, (size_t)n * 256, hipMemcpyHostToDevice, ctx->stream));
   if ((rc = pg_launch_tetra_stats(ctx, ctx->d_z, ctx->d_present, n))) return rc;
   if ((rc = pg_launch_tetra_pairs(ctx, n, 0, n, ctx->d_corr, true))) return rc;
-  PG_HIP(ctx, hipMemcpyAsync(ctx->h_corr, ctx->d_corr, (size_t)n * n * 8, hipMemcpyDeviceToHost, ctx->stream));
-  PG_HIP(ctx, hipMemcpyAsync(ctx->h_flags, ctx->d_flags, 2 * 4, hipMemcpyDeviceToHost, ctx->stream));
+  if ((rc = fetch_result_async(ctx, L.bytes))) return rc;
   PG_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if ((rc = check_flags(ctx, n))) return rc;
-  std::memcpy(out, ctx->h_corr, (size_t)n * n * 8);
+  std::memcpy(out, ctx->h_result + L.off_corr, (size_t)n * n * 8);
   return PG_OK;
 }
 
-int pg_tetra_matrix_enqueue(pg_ctx* ctx, const int32_t* ids, uint32_t n) {
+int pg_tetra_matrix_enqueue(pg_ctx* ctx, const int32_t* ids, uint32_t n, int fetch_z) {
   if (!ctx || (n && !ids)) return pg_fail(ctx, PG_E_ARG, "bad argument");
   PG_HIP(ctx, hipSetDevice(ctx->device));
   int rc;
   if ((rc = ensure_batch(ctx, ids, n))) return rc;
-  if ((rc = ensure_corr(ctx, n))) return rc;
+  if ((rc = ensure_result(ctx, n, true))) return rc;
   if (n == 0) return PG_OK;
   if ((rc = pg_launch_tetra_count(ctx, n))) return rc;
   if ((rc = pg_launch_tetra_finalize(ctx, n, ctx->d_acc))) return rc;
-  if ((rc = pg_launch_tetra_stats(ctx, ctx->d_z, ctx->d_present, n))) return rc;
   if ((rc = pg_launch_tetra_pairs(ctx, n, 0, n, ctx->d_corr, true))) return rc;
-  PG_HIP(ctx, hipMemcpyAsync(ctx->h_corr, ctx->d_corr, (size_t)n * n * 8, hipMemcpyDeviceToHost, ctx->stream));
-  PG_HIP(ctx, hipMemcpyAsync(ctx->h_z, ctx->d_z, (size_t)n * 256 * 8, hipMemcpyDeviceToHost, ctx->stream));
-  PG_HIP(ctx, hipMemcpyAsync(ctx->h_present, ctx->d_present, (size_t)n * 256, hipMemcpyDeviceToHost, ctx->stream));
-  PG_HIP(ctx, hipMemcpyAsync(ctx->h_flags, ctx->d_flags, 2 * 4, hipMemcpyDeviceToHost, ctx->stream));
-  return PG_OK;
+  const ResultLayout L(n, true);
+  return fetch_result_async(ctx, fetch_z ? L.bytes : L.bytes_corr_only);
 }
 
 int pg_tetra_matrix_fetch(pg_ctx* ctx, uint32_t n, double* z_out, uint8_t* present_out, double* corr_out) {
   if (!ctx) return PG_E_ARG;
   PG_HIP(ctx, hipSetDevice(ctx->device));
   PG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  if (n > ctx->h_batch_cap || (uint64_t)n * n > ctx->h_corr_cap) return pg_fail(ctx, PG_E_ARG, "fetch larger than last batch");
-  if (z_out) std::memcpy(z_out, ctx->h_z, (size_t)n * 256 * 8);
-  if (present_out) std::memcpy(present_out, ctx->h_present, (size_t)n * 256);
+  const ResultLayout L(n, true);
+  if (L.bytes > ctx->result_cap) return pg_fail(ctx, PG_E_ARG, "fetch larger than last batch");
+  if (z_out) std::memcpy(z_out, ctx->h_result + L.off_z, (size_t)n * 256 * 8);
+  if (present_out) std::memcpy(present_out, ctx->h_result + L.off_present, (size_t)n * 256);
   if (corr_out) {
     const int rc = check_flags(ctx, n);
     if (rc) return rc;
-    std::memcpy(corr_out, ctx->h_corr, (size_t)n * n * 8);
+    std::memcpy(corr_out, ctx->h_result + L.off_corr, (size_t)n * n * 8);
   }
   return PG_OK;
 }
 
 int pg_tetra_matrix(pg_ctx* ctx, const int32_t* ids, uint32_t n, double* z_out, uint8_t* present_out, double* corr_out) {
-  const int rc = pg_tetra_matrix_enqueue(ctx, ids, n);
+  const int rc = pg_tetra_matrix_enqueue(ctx, ids, n, (z_out || present_out) ? 1 : 0);
   if (rc) return rc;
   return pg_tetra_matrix_fetch(ctx, n, z_out, present_out, corr_out);
 }
@@ -556,6 +576,7 @@ int pg_tetra_zscores_dev(pg_ctx* ctx, const int32_t* ids, uint32_t n, double* d_
   PG_HIP(ctx, hipSetDevice(ctx->device));
   int rc;
   if ((rc = ensure_batch(ctx, ids, n))) return rc;
+  if ((rc = ensure_result(ctx, n, false))) return rc;
   if (n == 0) return PG_OK;
   if ((rc = pg_launch_tetra_count(ctx, n))) return rc;
   if ((rc = pg_launch_tetra_finalize(ctx, n, ctx->d_acc))) return rc;
@@ -572,11 +593,12 @@ int pg_tetra_corr_rows_dev(pg_ctx* ctx, const double* d_z, const uint8_t* d_pres
   PG_HIP(ctx, hipSetDevice(ctx->device));
   int rc;
   if ((rc = ensure_batch_scratch(ctx, n))) return rc;
+  if ((rc = ensure_result(ctx, 1, false))) return rc;  // only the flags words are used
   if (n == 0) return PG_OK;
-  ctx->batch_ids.clear();
+  ctx->batch_ids.clear();  // d_dev / d_ss no longer describe the cached batch
   if ((rc = pg_launch_tetra_stats(ctx, d_z, d_present, n))) return rc;
   if ((rc = pg_launch_tetra_pairs(ctx, n, row0, nrows, d_out, false))) return rc;
-  PG_HIP(ctx, hipMemcpyAsync(ctx->h_flags, ctx->d_flags, 2 * 4, hipMemcpyDeviceToHost, ctx->stream));
+  if ((rc = fetch_result_async(ctx, 16))) return rc;
   PG_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return check_flags(ctx, n);
 }
@@ -587,12 +609,18 @@ int pg_profile_enable(pg_ctx* ctx, int on) {
   ctx->profiling = on != 0;
   return PG_OK;
 }
+int pg_profile_config(pg_ctx* ctx, uint32_t kernel_mask, uint32_t every_n) {
+  if (!ctx || every_n == 0) return PG_E_ARG;
+  ctx->prof_mask = kernel_mask;
+  ctx->prof_every = every_n;
+  return PG_OK;
+}
 int pg_profile_reset(pg_ctx* ctx) {
   if (!ctx) return PG_E_ARG;
   PG_HIP(ctx, hipSetDevice(ctx->device));
   PG_HIP(ctx, hipStreamSynchronize(ctx->stream));
   prof_drain(ctx);
-  for (int i = 0; i < PG_K__COUNT; ++i) { ctx->prof_ms[i] = 0; ctx->prof_n[i] = 0; }
+  for (int i = 0; i < PG_K__COUNT; ++i) { ctx->prof_ms[i] = 0; ctx->prof_n[i] = 0; ctx->prof_seen[i] = 0; }
   return PG_OK;
 }
 int pg_profile_get(pg_ctx* ctx, int which, double* total_ms_out, uint64_t* launches_out) {

@@ -56,25 +56,27 @@ struct pg_ctx {
   uint32_t* d_seg_prefix = nullptr;  // batch + 1: cumulative super-tile counts
   uint32_t* d_batch_gid = nullptr;
   uint32_t n_work = 0, batch_cap = 0;
-  unsigned long long* d_acc = nullptr;     // batch x PG_ACC_WORDS
-  unsigned long long* d_counts = nullptr;  // batch x (16+64+256): c2 | c3 | c4
-  double* d_z = nullptr;                   // batch x 256
-  uint8_t* d_present = nullptr;            // batch x 256
-  double* d_dev = nullptr;                 // batch x 256 compacted deviations
-  double* d_ss = nullptr;                  // batch
-  int32_t* d_flags = nullptr;              // [0]=keyset mismatch, [1]=n present keys
-  double* d_corr = nullptr;                // batch x batch
-  uint64_t corr_cap = 0;
-  // pinned host staging for the async pipeline
-  double* h_z = nullptr;
-  uint8_t* h_present = nullptr;
-  double* h_corr = nullptr;
-  int32_t* h_flags = nullptr;
-  unsigned long long* h_counts = nullptr;
+  unsigned long long* d_acc = nullptr;      // batch x PG_ACC_WORDS (zero between passes)
+  unsigned long long* d_counts = nullptr;   // batch x (16+64+256): c2 | c3 | c4
+  double* d_dev = nullptr;                  // batch x 256 compacted deviations
+  double* d_ss = nullptr;                   // batch
+  unsigned long long* d_keybits = nullptr;  // batch x 4: bitmap of observed tetramers
+  // One result block per pass so that ONE device-to-host copy returns everything:
+  //   [ flags: 4 x int32 ] [ z: n x 256 f64 ] [ corr: n x n f64 ] [ present: n x 256 u8 ]
+  uint8_t* d_result = nullptr;
+  uint8_t* h_result = nullptr;  // pinned
+  uint64_t result_cap = 0;      // bytes
+  int32_t* d_flags = nullptr;   // [0]=keyset mismatch, [1]=n present keys      (pointers into d_result)
+  double* d_z = nullptr;
+  double* d_corr = nullptr;
+  uint8_t* d_present = nullptr;
+  unsigned long long* h_counts = nullptr;  // pinned
   uint32_t h_batch_cap = 0;
-  uint64_t h_corr_cap = 0;
   // profiling
   bool profiling = false;
+  uint32_t prof_mask = 0xFFFFFFFFu, prof_every = 1;
+  uint64_t prof_seen[PG_K__COUNT] = {0, 0, 0, 0};
+  bool prof_open = false;
   std::vector<PgEventPair> events;
   double prof_ms[PG_K__COUNT] = {0, 0, 0, 0};
   uint64_t prof_n[PG_K__COUNT] = {0, 0, 0, 0};
@@ -95,6 +97,6 @@ void pg_prof_end(pg_ctx* ctx);
 
 // kernels' host launchers (pg_tetra.hip)
 int pg_launch_tetra_count(pg_ctx* ctx, uint32_t n_batch);
-int pg_launch_tetra_finalize(pg_ctx* ctx, uint32_t n_batch, const unsigned long long* d_counts_in);
+int pg_launch_tetra_finalize(pg_ctx* ctx, uint32_t n_batch, unsigned long long* d_acc_in);
 int pg_launch_tetra_stats(pg_ctx* ctx, const double* d_z, const uint8_t* d_present, uint32_t n);
 int pg_launch_tetra_pairs(pg_ctx* ctx, uint32_t n, uint32_t row0, uint32_t nrows, double* d_out, bool mirror);

@@ -131,8 +131,8 @@ class Engine:
         self._check(self.lib.pg_tetra_matrix(self._h, a.ctypes.data, n, z.ctypes.data, present.ctypes.data, _ptr(corr)))
         return z, present, corr
 
-    def tetra_matrix_enqueue(self, ids_array: np.ndarray):
-        self._check(self.lib.pg_tetra_matrix_enqueue(self._h, ids_array.ctypes.data, len(ids_array)))
+    def tetra_matrix_enqueue(self, ids_array: np.ndarray, fetch_z: bool = True):
+        self._check(self.lib.pg_tetra_matrix_enqueue(self._h, ids_array.ctypes.data, len(ids_array), int(fetch_z)))
 
     def tetra_matrix_fetch(self, n: int) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
         z = np.zeros((n, 256), dtype=np.float64)
@@ -151,6 +151,9 @@ class Engine:
     # -- measurement ----------------------------------------------------------------------------------------------
     def profile_enable(self, on: bool = True):
         self._check(self.lib.pg_profile_enable(self._h, int(on)))
+
+    def profile_config(self, kernel_mask: int = 0xFFFFFFFF, every_n: int = 1):
+        self._check(self.lib.pg_profile_config(self._h, kernel_mask, every_n))
 
     def profile_reset(self):
         self._check(self.lib.pg_profile_reset(self._h))

@@ -1,0 +1,67 @@
+"""CPU-only, world_size 2 over gloo: the sharding / padding / all-gather logic of pyani_amd.parallel — the same code
+bench.py runs over RCCL — assembles exactly the single-process matrix.  The per-rank compute steps are played by
+the oracle here (there is no GPU in this container); on the GPU box they are the HIP kernels."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, n, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pyani_amd import parallel, synth
+        from tests import oracle_bind
+        orc = oracle_bind.load()
+        data = [synth.genome(20250228, 40, g, 30_000 + 997 * g) for g in range(n)]
+        cs = [orc.counts(s, o) for s, o in data]
+        z_ref, p_ref = orc.zscores(np.array([c[0] for c in cs]), np.array([c[1] for c in cs]), np.array([c[2] for c in cs]))
+        rc, corr_ref = orc.corr(z_ref, p_ref)
+        assert rc == 0
+        ag = parallel.TetraAllGather(n, torch.device("cpu"))
+
+        def compute_z(z_loc, p_loc):
+            z_loc[: ag.hi - ag.lo] = torch.from_numpy(z_ref[ag.lo: ag.hi])
+            p_loc[: ag.hi - ag.lo] = torch.from_numpy(p_ref[ag.lo: ag.hi])
+
+        def compute_rows(z_all, p_all, lo, nrows, rows):
+            rc2, full = orc.corr(z_all.numpy(), p_all.numpy())
+            assert rc2 == 0
+            rows[:nrows] = torch.from_numpy(full[lo: lo + nrows])
+
+        for _ in range(2):  # buffers are reusable
+            corr = ag.run(compute_z, compute_rows).numpy()
+        assert (ag.z_all.numpy().view(np.uint64) == z_ref.view(np.uint64)).all()
+        assert (corr.view(np.uint64) == corr_ref.view(np.uint64)).all()
+        np.save(os.path.join(out_dir, f"corr{rank}.npy"), corr)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [7, 8])   # 7: ragged shards (4 + 3) exercise the padding
+def test_two_rank_allgather_matches_single_process(tmp_path, n):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, n, str(tmp_path)), nprocs=2, join=True)
+    a, b = np.load(tmp_path / "corr0.npy"), np.load(tmp_path / "corr1.npy")
+    assert (a.view(np.uint64) == b.view(np.uint64)).all() and a.shape == (n, n)
+
+
+def test_shard_range_partitions():
+    from pyani_amd.parallel import shard_range, max_shard
+    for n in (0, 1, 7, 8, 200, 1001):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            assert max(hi - lo for lo, hi in spans) == max_shard(n, world) or n == 0
