@@ -89,11 +89,18 @@ def main():
     import torch
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: the engine has no CPU fallback")
+    # debugging aid for 1-GPU boxes: run the N>1 code path with every rank on GPU 0 over gloo (never the default)
+    one_gpu_debug = os.environ.get("PYANI_BENCH_DEBUG_ONE_GPU") == "1"
+    if one_gpu_debug:
+        local = 0
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if one_gpu_debug:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     from pyani_amd import _lib, synth
     from pyani_amd.engine import Engine
