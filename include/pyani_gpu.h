@@ -31,6 +31,7 @@ extern "C" {
 #define PG_E_KEYSET (-6)   /* genomes have different observed-tetramer key sets: pyani raises AssertionError (tetra.py:174-175) */
 #define PG_E_EMPTY (-7)    /* empty key set: pyani raises ZeroDivisionError (tetra.py:181) */
 #define PG_E_RNA (-8)      /* sequence contains U/u: Biopython complements it asymmetrically (U->A); unsupported */
+#define PG_E_CAPACITY (-9) /* a per-pair work buffer overflowed (pg_anim_result.status only) */
 
 typedef struct pg_ctx pg_ctx;
 
@@ -97,6 +98,29 @@ int pg_tetra_zscores_dev(pg_ctx* ctx, const int32_t* genome_ids, uint32_t n, dou
 /* rows [row0, row0+nrows) of the n x n matrix from the full (all-gathered) d_z / d_present; d_out: nrows x n */
 int pg_tetra_corr_rows_dev(pg_ctx* ctx, const double* d_z, const uint8_t* d_present, uint32_t n, uint32_t row0,
                            uint32_t nrows, double* d_out);
+
+/* ---- ANIm ------------------------------------------------------------------------------------------------
+ * In-process replacement for the `nucmer --mum` + `delta-filter -1` jobs pyani builds in
+ * construct_nucmer_cmdline (pyani/anim.py:240-289), runs through run_multiprocessing (run_multiprocessing.py:56-152)
+ * and reduces with parse_delta (anim.py:292-411).  One result per ORDERED pair:
+ *   ref_ids[i] = the genome in nucmer's *reference* role  (pyani's query genome, fname1 of anim.py:280)
+ *   qry_ids[i] = the genome in nucmer's *query* role      (pyani's subject genome, fname2)
+ * The tuple (ref_aln_len, qry_aln_len, identity, sim_errors) is what parse_delta returns for the pair's .filter
+ * file.  status: 0 = ok; PG_ANIM_NO_ALIGNMENT = no alignment survived (parse_delta would raise ZeroDivisionError,
+ * anim.py:396); PG_E_CAPACITY = internal buffers overflowed for this pair.
+ * MUMmer itself is third-party and absent from the reference tree: behaviour is reconstructed and calibrated against
+ * the MUMmer output files the reference's tests hold (DESIGN.md §ANIm lists the measured deviations). */
+typedef struct {
+  int64_t ref_aln_len, qry_aln_len, sim_errors, n_alignments;
+  double identity;
+  int32_t status;
+  int32_t reserved;
+} pg_anim_result;
+#define PG_ANIM_NO_ALIGNMENT 1
+/* maxmatch must be 0 (pyani's default --mum mode; --maxmatch is not implemented).  filter_1to1 = 0 reproduces
+ * pyani's --nofilter (reduction over the unfiltered alignments). */
+int pg_anim_pairs(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_ids, uint64_t n_pairs, int maxmatch,
+                  int filter_1to1, pg_anim_result* out);
 
 /* ---- measurement ---------------------------------------------------------------------------------------- */
 /* When enabled, every kernel launch is bracketed by HIP events on the context's stream. */

@@ -1,0 +1,129 @@
+"""oracle/anim_oracle.py — CPU restatement of pyani's ANIm *reduction*.   TEST INFRASTRUCTURE ONLY.
+
+Covers what pyani itself computes from MUMmer output (the alignment search is MUMmer 3.23, third-party, not under
+/root/reference — for that part parity is pinned only by the committed `.delta/.filter` fixtures):
+
+  read_delta(path)            MUMmer delta grammar (pyani/nucmer.py:292-351, pyani/anim.py:355-394)
+  parse_delta_records(recs)   (ref_aln_len, qry_aln_len, identity, sim_errors)        pyani/anim.py:292-411
+  anim_matrices(...)          legacy matrix assembly of process_deltadir               pyani/anim.py:415-497,
+                              pyani/pyani_tools.py:85-172 (ANIResults.add_*), incl. its overwrite order
+
+Pinned by the reference's own known answers: tests/fixtures/anim/test.delta -> (4016947, 4017751,
+0.9994621994447228, 2191) (tests/test_anim.py:96-100, tests/test_parsing.py:52-64) and
+tests/fixtures/anim/dataframes/deltadir_result.csv (6 d.p.).  Nothing under pyani_amd/ imports this file.
+"""
+import gzip
+from collections import defaultdict
+from typing import Dict, List, NamedTuple, Tuple
+
+
+class Aln(NamedTuple):
+    ref_id: str
+    qry_id: str
+    rs: int
+    re: int
+    qs: int
+    qe: int
+    errors: int
+    sim_errors: int
+    stops: int
+    indels: Tuple[int, ...]
+
+
+def _open(path):
+    return gzip.open(path, "rt") if str(path).endswith(".gz") else open(path, "r")
+
+
+def read_delta(path) -> Tuple[List[Aln], Dict[str, int], Dict[str, int]]:
+    """Return (alignments, ref sequence lengths, qry sequence lengths) of a .delta/.filter file."""
+    alns: List[Aln] = []
+    rlen: Dict[str, int] = {}
+    qlen: Dict[str, int] = {}
+    cur_ref = cur_qry = None
+    header = None
+    indels: List[int] = []
+    with _open(path) as fh:
+        for line in fh:
+            f = line.strip().split()
+            if not f or f[0] == "NUCMER":
+                continue
+            if f[0].startswith(">"):
+                cur_ref, cur_qry = f[0][1:], f[1]
+                rlen[cur_ref], qlen[cur_qry] = int(f[2]), int(f[3])
+            elif len(f) == 7:
+                header = [int(x) for x in f]
+                indels = []
+            elif len(f) == 1 and header is not None:
+                v = int(f[0])
+                if v == 0:
+                    alns.append(Aln(cur_ref, cur_qry, *header, tuple(indels)))
+                    header = None
+                else:
+                    indels.append(v)
+    return alns, rlen, qlen
+
+
+def _union_length(intervals: List[Tuple[int, int]]) -> int:
+    """IntervalTree.from_tuples + merge_overlaps(strict=False) + sum(end - begin + 1)   (anim.py:399-409)."""
+    total = 0
+    cur_b = cur_e = None
+    for b, e in sorted(intervals):
+        if cur_b is None:
+            cur_b, cur_e = b, e
+        elif b <= cur_e:          # overlapping or touching half-open intervals are merged
+            cur_e = max(cur_e, e)
+        else:
+            total += cur_e - cur_b + 1
+            cur_b, cur_e = b, e
+    if cur_b is not None:
+        total += cur_e - cur_b + 1
+    return total
+
+
+def parse_delta_records(alns) -> Tuple[int, int, float, int]:
+    """The reduction of pyani.anim.parse_delta over already-parsed alignment headers."""
+    regions_ref, regions_qry = defaultdict(list), defaultdict(list)
+    aligned, weighted, sim_error = 0, 0, 0
+    for a in alns:
+        regions_ref[a.ref_id].append(tuple(sorted((a.rs, a.re))))
+        regions_qry[a.qry_id].append(tuple(sorted((a.qs, a.qe))))
+        rl, ql = abs(a.re - a.rs) + 1, abs(a.qe - a.qs) + 1
+        aligned += rl + ql
+        sim_error += a.errors
+        weighted += rl + ql - 2 * a.errors
+    identity = weighted / aligned          # ZeroDivisionError when there are no alignments (anim.py:396)
+    qaln = sum(_union_length(v) for v in regions_qry.values())
+    raln = sum(_union_length(v) for v in regions_ref.values())
+    return raln, qaln, identity, sim_error
+
+
+def parse_delta(path) -> Tuple[int, int, float, int]:
+    return parse_delta_records(read_delta(path)[0])
+
+
+def anim_matrices(results: Dict[Tuple[str, str], Tuple[int, int, float, int]], org_lengths: Dict[str, int]):
+    """process_deltadir's five matrices as dict-of-dicts [query][subject] (anim.py:438-497).  `results` maps
+    (qname, sname) -> parse_delta tuple; files are visited in sorted path order "<q>/<q>_vs_<s>.filter", later
+    files overwrite the mirrored cells written by earlier ones (pyani_tools.py:108-167)."""
+    names = list(org_lengths)
+    nan = float("nan")
+    lengths = {a: {b: nan for b in names} for a in names}
+    errors = {a: {b: 0.0 for b in names} for a in names}
+    pid = {a: {b: 1.0 for b in names} for a in names}
+    cov = {a: {b: 1.0 for b in names} for a in names}
+    for org, length in org_lengths.items():
+        lengths[org][org] = float(length)
+    for (q, s) in sorted(results, key=lambda k: f"{k[0]}/{k[0]}_vs_{k[1]}.filter"):
+        raln, qaln, ident, err = results[(q, s)]
+        qcov, scov = float(raln) / org_lengths[q], float(qaln) / org_lengths[s]
+        lengths[q][s] = float(raln)
+        if qaln:
+            lengths[s][q] = float(qaln)
+        errors[q][s] = errors[s][q] = float(err)
+        pid[q][s] = ident
+        cov[q][s] = qcov
+        if scov:
+            cov[s][q] = scov
+    had = {a: {b: pid[a][b] * cov[a][b] for b in names} for a in names}
+    return {"alignment_lengths": lengths, "similarity_errors": errors, "percentage_identity": pid,
+            "alignment_coverage": cov, "hadamard": had}

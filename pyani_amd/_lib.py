@@ -6,6 +6,7 @@ from pathlib import Path
 LIB_PATH = Path(__file__).resolve().parent / "libpyani_gpu.so"
 
 PG_OK, PG_E_ARG, PG_E_NODEVICE, PG_E_HIP, PG_E_IO, PG_E_NOMEM, PG_E_KEYSET, PG_E_EMPTY, PG_E_RNA = 0, -1, -2, -3, -4, -5, -6, -7, -8
+PG_E_CAPACITY, PG_ANIM_NO_ALIGNMENT = -9, 1
 K_TETRA_COUNT, K_TETRA_FINALIZE, K_TETRA_STATS, K_TETRA_PAIRS = 0, 1, 2, 3
 
 # every symbol declared in include/pyani_gpu.h: (name, restype, argtypes)
@@ -32,6 +33,7 @@ SIGNATURES = {
     "pg_tetra_matrix_fetch": (_int, [_vp, _u32, _vp, _vp, _vp]),
     "pg_tetra_zscores_dev": (_int, [_vp, _vp, _u32, _vp, _vp]),
     "pg_tetra_corr_rows_dev": (_int, [_vp, _vp, _vp, _u32, _u32, _u32, _vp]),
+    "pg_anim_pairs": (_int, [_vp, _vp, _vp, _u64, _int, _int, _vp]),
     "pg_profile_enable": (_int, [_vp, _int]),
     "pg_profile_config": (_int, [_vp, _u32, _u32]),
     "pg_profile_reset": (_int, [_vp]),

@@ -1,0 +1,484 @@
+// pg_anim.hip — gfx950 kernels of the ANIm engine (kernel family 3 of BASELINE.json's north star): replaces the
+// `nucmer --mum` + `delta-filter -1` processes pyani shells out to (pyani/anim.py:240-289) and the parse_delta
+// reduction (anim.py:292-411) with an in-process pipeline over the 2-bit/1-bit packed genomes already resident in HBM.
+//
+//   A1 anim_index_kernel     20-mer hash table of the reference genome (open addressing, 8 B slots: kmer40 | pos24)
+//   A2 anim_seed_kernel      one thread per query-strand position: table probe, left-maximality test, right extension
+//                            -> maximal exact matches >= 20 (the only O(genome) stage; HBM/MALL-latency bound)
+//   A3 anim_cluster_kernel   per (pair, strand): MUM filter, mgaps clustering, chain extraction      (pg_anim_core.h)
+//   A4 anim_extend_kernel    per chain: gap fills + free forward extension, then backward extension towards the
+//                            previous chain's end (banded affine DP, band in registers/scratch)
+//   A5 anim_finish_kernel    per pair: stitch/fuse chains, 1-to-1 filter, parse_delta reduction -> pg_anim_result
+//
+// Round-1 state: correctness first — A3/A5 run one thread per unit (thousands of pairs give the parallelism), A2
+// extends base by base.  The DESIGN.md section "ANIm" lists what is measured and what comes next.
+#include "pg_internal.h"
+#include "pg_anim_core.h"
+
+using namespace pga;
+
+namespace {
+
+constexpr uint64_t SLOT_EMPTY = ~0ull;
+constexpr int MAX_HITS = 64;  // probes per lookup; 20-mers with more copies than this in one genome are skipped
+
+struct RefDesc {
+  const uint32_t* codes;
+  const uint32_t* mask;
+  int32_t len;
+  const int32_t* rec_start;  // n_rec + 1 entries
+  int32_t n_rec;
+  uint64_t* table;
+  uint32_t table_mask;
+};
+
+struct UnitDesc {   // one (pair, query strand)
+  const uint32_t* codes;
+  const uint32_t* mask;
+  int32_t len;
+  const int32_t* rec_start;
+  int32_t n_rec;
+  int32_t strand;
+  int32_t pair;  // index into the batch's pair list
+};
+
+__device__ __forceinline__ uint64_t mix40(uint64_t k) {
+  k *= 0x9E3779B97F4A7C15ull;
+  return k >> 24;
+}
+
+// 40-bit k-mer (20 bases, first base in the low bits) at stream position p, or false if a base is dirty
+__device__ __forceinline__ bool kmer_at(const uint32_t* __restrict__ codes, const uint32_t* __restrict__ mask, int32_t len,
+                                        int32_t p, uint64_t& out) {
+  if (p < 0 || p + MIN_MATCH > len) return false;
+  const uint32_t mw = p >> 5, ms = p & 31;
+  const uint64_t m = ((uint64_t)mask[mw] | ((uint64_t)mask[mw + 1] << 32)) >> ms;
+  if ((m & 0xFFFFFull) != 0xFFFFFull) return false;
+  const uint32_t cw = p >> 4, cs = 2 * (p & 15);
+  const uint64_t lo = (uint64_t)codes[cw] | ((uint64_t)codes[cw + 1] << 32);
+  uint64_t v = lo >> cs;
+  if (cs > 24) v |= (uint64_t)codes[cw + 2] << (64 - cs);
+  out = v & 0xFFFFFFFFFFull;
+  return true;
+}
+
+__device__ __forceinline__ uint64_t revcomp40(uint64_t k) {
+  uint64_t x = __brevll(k);                                                   // pair order reversed, bits in pairs swapped
+  x = ((x & 0xAAAAAAAAAAAAAAAAull) >> 1) | ((x & 0x5555555555555555ull) << 1);  // un-swap inside each pair
+  return (~(x >> 24)) & 0xFFFFFFFFFFull;
+}
+
+__global__ __launch_bounds__(256) void anim_index_kernel(RefDesc R) {
+  const int32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  uint64_t k;
+  if (!kmer_at(R.codes, R.mask, R.len, p, k)) return;
+  const uint64_t val = (k << 24) | (uint32_t)p;
+  uint32_t slot = (uint32_t)mix40(k) & R.table_mask;
+  for (;;) {
+    const unsigned long long prev = atomicCAS(reinterpret_cast<unsigned long long*>(&R.table[slot]), SLOT_EMPTY, val);
+    if (prev == SLOT_EMPTY) break;
+    slot = (slot + 1) & R.table_mask;
+  }
+}
+
+__global__ __launch_bounds__(256) void anim_seed_kernel(RefDesc R, const UnitDesc* __restrict__ units, Match* __restrict__ mem,
+                                                        uint32_t* __restrict__ mem_count, uint32_t cap_m) {
+  const UnitDesc U = units[blockIdx.y];
+  const int32_t q = blockIdx.x * blockDim.x + threadIdx.x;  // strand position
+  if (q + MIN_MATCH > U.len) return;
+  uint64_t k;
+  if (U.strand == 0) {
+    if (!kmer_at(U.codes, U.mask, U.len, q, k)) return;
+  } else {
+    if (!kmer_at(U.codes, U.mask, U.len, U.len - MIN_MATCH - q, k)) return;  // forward window of the same bases
+    k = revcomp40(k);
+  }
+  const SeqView RV{R.codes, R.mask, R.len};
+  const StrandView QV{SeqView{U.codes, U.mask, U.len}, U.strand};
+  uint32_t slot = (uint32_t)mix40(k) & R.table_mask;
+  for (int probe = 0; probe < MAX_HITS; ++probe) {
+    const uint64_t v = R.table[slot];
+    if (v == SLOT_EMPTY) break;
+    slot = (slot + 1) & R.table_mask;
+    if ((v >> 24) != k) continue;
+    const int32_t r = (int32_t)(v & 0xFFFFFFu);
+    if (RV.clean(r - 1) && QV.clean(q - 1) && RV.base(r - 1) == QV.base(q - 1)) continue;  // not left-maximal
+    int32_t L = MIN_MATCH;
+    while (RV.clean(r + L) && QV.clean(q + L) && RV.base(r + L) == QV.base(q + L)) ++L;
+    const uint32_t at = atomicAdd(&mem_count[blockIdx.y], 1u);
+    if (at < cap_m) mem[(size_t)blockIdx.y * cap_m + at] = Match{r, q, L, U.strand};
+  }
+}
+
+struct ClusterOut {
+  Match* cm;            // [U][cap_m]
+  Chain* chains;        // [U][cap_c]
+  int32_t* n_chains;    // [U]
+  int32_t* order;       // [U][cap_c] chains sorted by first-match ref start
+  int32_t* prev_of;     // [U][cap_c]
+  int32_t* status;      // [P]
+};
+
+__global__ __launch_bounds__(64) void anim_cluster_kernel(RefDesc R, const UnitDesc* __restrict__ units, uint32_t n_units,
+                                                          Match* __restrict__ mem, const uint32_t* __restrict__ mem_count,
+                                                          uint32_t cap_m, uint32_t cap_c, int32_t* __restrict__ iscratch,
+                                                          ClusterOut O) {
+  const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= n_units) return;
+  const UnitDesc U = units[u];
+  O.n_chains[u] = 0;
+  uint32_t n0 = mem_count[u];
+  if (n0 > cap_m) { atomicOr(&O.status[U.pair], 1); n0 = cap_m; }
+  Match* m = mem + (size_t)u * cap_m;
+  const int n = mum_filter(m, (int)n0, U.strand);
+  int32_t* s = iscratch + (size_t)u * 7 * cap_m;
+  int32_t *rrec = s, *qrec = s + cap_m, *parent = s + 2 * cap_m, *score = s + 3 * cap_m, *from = s + 4 * cap_m,
+          *adj = s + 5 * cap_m, *order = s + 6 * cap_m;
+  for (int i = 0; i < n; ++i) {
+    rrec[i] = record_of(R.rec_start, R.n_rec, m[i].r);
+    const int32_t qf = U.strand ? U.len - 1 - m[i].q : m[i].q;
+    qrec[i] = record_of(U.rec_start, U.n_rec, qf);
+  }
+  int n_chains = 0, n_cm = 0;
+  Chain* chains = O.chains + (size_t)u * cap_c;
+  Match* cm = O.cm + (size_t)u * cap_m;
+  mgaps_strand(m, n, U.strand, rrec, qrec, parent, score, from, adj, order, chains, n_chains, (int)cap_c, cm, n_cm, (int)cap_m);
+  int32_t* co = O.order + (size_t)u * cap_c;
+  int32_t* prev_of = O.prev_of + (size_t)u * cap_c;
+  for (int i = 0; i < n_chains; ++i) co[i] = i;
+  heapsort(co, n_chains, [&](int a, int b) { return cm[chains[a].first].r < cm[chains[b].first].r; });
+  for (int k = 0; k < n_chains; ++k) {
+    const int c = co[k];
+    int p = -1;
+    for (int kk = k - 1; kk >= 0 && kk >= k - 8; --kk) {   // nearest preceding chain of the same records
+      const int t = co[kk];
+      if (chains[t].rrec == chains[c].rrec && chains[t].qrec == chains[c].qrec) { p = t; break; }
+    }
+    prev_of[c] = p;
+  }
+  O.n_chains[u] = n_chains;
+}
+
+__device__ __forceinline__ void chain_bounds(const RefDesc& R, const UnitDesc& U, const Chain& c, int32_t& r_lo, int32_t& r_hi,
+                                             int32_t& q_lo, int32_t& q_hi) {
+  r_lo = R.rec_start[c.rrec]; r_hi = R.rec_start[c.rrec + 1] - 1;
+  q_lo = U.rec_start[c.qrec]; q_hi = U.rec_start[c.qrec + 1] - 1;
+  if (U.strand) { const int32_t a = U.len - q_hi, b = U.len - q_lo; q_lo = a; q_hi = b; }
+}
+
+// ---- wave-cooperative banded DP: the 64 lanes of a wave ARE the 64 diagonals of the band ----------------------------
+// Same cells, checks and tie-breaks as pga::extend_banded (pg_anim_core.h); neighbours' cells arrive through DPP
+// wave shifts, so a step costs a handful of VALU ops per lane and no LDS.  All lanes return the same result.
+__device__ __forceinline__ int32_t from_lane_above(int32_t v, int32_t fill) {  // lane l <- lane l+1 (lane 63 <- fill)
+  return __builtin_amdgcn_update_dpp(fill, v, 0x130 /*wave_shl:1*/, 0xf, 0xf, false);
+}
+__device__ __forceinline__ int32_t from_lane_below(int32_t v, int32_t fill) {  // lane l <- lane l-1 (lane 0 <- fill)
+  return __builtin_amdgcn_update_dpp(fill, v, 0x138 /*wave_shr:1*/, 0xf, 0xf, false);
+}
+__device__ __forceinline__ long long wave_max64(long long v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const long long t = __shfl_xor(v, o, 64);
+    v = t > v ? t : v;
+  }
+  return v;
+}
+
+__device__ ExtResult extend_wave(const SeqView& R, const StrandView& Q, int64_t r0, int64_t q0, int dir, int32_t rmax,
+                                 int32_t qmax, int32_t tr, int32_t tq) {
+  constexpr int W = BAND / 2;
+  static_assert(BAND == 64, "one lane per diagonal");
+  const int lane = threadIdx.x & 63, k = lane - W;
+  DpCell cur{NEG_INF, 0, NEG_INF, 0, NEG_INF, 0};
+  int32_t bs = NEG_INF, bd = 0, be = 0;
+  if (lane == W) { cur.h = 0; bs = 0; }
+  ExtResult res{0, 0, 0, 0, 0};
+  bool targeted = tr >= 0;
+  if (targeted && (tq - tr < -W || tq - tr >= W || tr > rmax || tq > qmax)) targeted = false;
+  if (targeted && tr == 0 && tq == 0) { res.reached = 1; return res; }
+  const int32_t d_end = targeted ? tr + tq : rmax + qmax;
+  constexpr long long BIAS = 1ll << 30;
+  for (int32_t d = 1; d <= d_end; ++d) {
+    const int32_t up_h = from_lane_above(cur.h, NEG_INF), up_he = from_lane_above(cur.he, 0);
+    const int32_t up_x = from_lane_above(cur.x, NEG_INF), up_xe = from_lane_above(cur.xe, 0);
+    const int32_t lf_h = from_lane_below(cur.h, NEG_INF), lf_he = from_lane_below(cur.he, 0);
+    const int32_t lf_y = from_lane_below(cur.y, NEG_INF), lf_ye = from_lane_below(cur.ye, 0);
+    if (!((d + k) & 1)) {
+      const int32_t i = (d - k) / 2, j = (d + k) / 2;
+      if (i < 0 || j < 0 || i > rmax || j > qmax) {
+        cur = DpCell{NEG_INF, 0, NEG_INF, 0, NEG_INF, 0};
+      } else {
+        const bool has_up = i >= 1 && lane + 1 < BAND, has_left = j >= 1 && lane >= 1, has_diag = i >= 1 && j >= 1;
+        bool ok = false;
+        if (has_diag) {
+          const int64_t rp = dir > 0 ? r0 + (i - 1) : r0 - i, qp = dir > 0 ? q0 + (j - 1) : q0 - j;
+          ok = R.clean(rp) && Q.clean(qp) && R.base(rp) == Q.base(qp);
+        }
+        cur = dp_cell(has_up, up_h, up_he, up_x, up_xe, has_left, lf_h, lf_he, lf_y, lf_ye, has_diag, cur.h, cur.he, ok);
+        if (cur.h > NEG_INF / 2 && (cur.h > bs || (cur.h == bs && d >= bd))) { bs = cur.h; bd = d; be = cur.he; }
+      }
+    }
+    if ((d % CHECK_EVERY) == 0 || d == d_end) {
+      const long long key = wave_max64((((long long)bs + BIAS) << 32) | (uint32_t)bd);  // max score, ties: larger d
+      const int32_t gbest_d = (int32_t)(key & 0xFFFFFFFFll);
+      if (d - gbest_d > BREAK_LEN) break;
+      if (!__any(cur.h > NEG_INF / 2)) break;
+    }
+    if (targeted && d == d_end) {
+      const int lt = (tq - tr) + W;
+      const int32_t th = __shfl(cur.h, lt, 64), the = __shfl(cur.he, lt, 64);
+      if (th > NEG_INF / 2) { res.di = tr; res.dj = tq; res.score = th; res.errors = the; res.reached = 1; return res; }
+    }
+  }
+  // best cell: max score, ties -> larger d, then larger diagonal
+  const long long key = wave_max64((((long long)bs + BIAS) << 32) | ((long long)(uint32_t)bd << 6) | (long long)lane);
+  const int bl = (int)(key & 63);
+  const int32_t gd = (int32_t)((key >> 6) & 0x3FFFFFF);
+  res.score = (int32_t)((key >> 32) - BIAS);
+  res.errors = __shfl(be, bl, 64);
+  const int kk = bl - W;
+  res.di = (gd - kk) / 2; res.dj = (gd + kk) / 2;
+  return res;
+}
+
+__device__ int32_t gap_errors_wave(const SeqView& R, const StrandView& Q, int64_t r0, int32_t n, int64_t q0, int32_t m) {
+  if (n == 0) return m;
+  if (m == 0) return n;
+  if (n == m && n <= 2) {
+    int32_t err = 0;
+    for (int32_t t = 0; t < n; ++t) err += (R.clean(r0 + t) && Q.clean(q0 + t) && R.base(r0 + t) == Q.base(q0 + t)) ? 0 : 1;
+    return err;
+  }
+  const ExtResult e = extend_wave(R, Q, r0, q0, +1, n, m, n, m);
+  if (e.reached) return e.errors;
+  int32_t kq = n < m ? n : m, err = (n > m ? n - m : m - n);
+  for (int32_t t = 0; t < kq; ++t) err += (R.clean(r0 + t) && Q.clean(q0 + t) && R.base(r0 + t) == Q.base(q0 + t)) ? 0 : 1;
+  return err;
+}
+
+// One WAVE per chain (work list wl: unit, chain).  phase 0: gap fills + free forward extension (extend_chain_fwd);
+// phase 1: backward extension towards the previous chain's forward end (extend_chain_bwd).
+__global__ __launch_bounds__(64) void anim_extend_kernel(RefDesc R, const UnitDesc* __restrict__ units, uint32_t cap_m,
+                                                         uint32_t cap_c, ClusterOut O, const uint2* __restrict__ wl,
+                                                         ChainFwd* __restrict__ fw, ChainBwd* __restrict__ bw, int phase) {
+  const uint32_t u = wl[blockIdx.x].x;
+  const int32_t c = (int32_t)wl[blockIdx.x].y;
+  const UnitDesc U = units[u];
+  const SeqView RV{R.codes, R.mask, R.len};
+  const StrandView QV{SeqView{U.codes, U.mask, U.len}, U.strand};
+  const Chain ch = O.chains[(size_t)u * cap_c + c];
+  int32_t r_lo, r_hi, q_lo, q_hi;
+  chain_bounds(R, U, ch, r_lo, r_hi, q_lo, q_hi);
+  ChainFwd* fwu = fw + (size_t)u * cap_c;
+  const Match* cm = O.cm + (size_t)u * cap_m;
+  if (phase == 0) {
+    ChainFwd e;
+    const Match f = cm[ch.first];
+    e.first_r = f.r; e.first_q = f.q;
+    int32_t inner = 0, er = f.r + f.len, eq = f.q + f.len;
+    for (int kq = 1; kq < ch.count; ++kq) {
+      Match t = cm[ch.first + kq];
+      int32_t trim = er - t.r;
+      if (eq - t.q > trim) trim = eq - t.q;
+      if (trim > 0) { t.r += trim; t.q += trim; t.len -= trim; }
+      if (t.len <= 0) continue;
+      inner += gap_errors_wave(RV, QV, er, t.r - er, eq, t.q - eq);
+      er = t.r + t.len; eq = t.q + t.len;
+    }
+    e.inner_err = inner;
+    const ExtResult x = extend_wave(RV, QV, er, eq, +1, r_hi - er, q_hi - eq, -1, -1);
+    e.re = er + x.di; e.qe = eq + x.dj; e.err_fwd = x.errors;
+    if ((threadIdx.x & 63) == 0) fwu[c] = e;
+  } else {
+    const int32_t p = O.prev_of[(size_t)u * cap_c + c];
+    const int32_t first_r = fwu[c].first_r, first_q = fwu[c].first_q;
+    const int32_t prev_re = p >= 0 ? fwu[p].re : -1, prev_qe = p >= 0 ? fwu[p].qe : -1;
+    int32_t tr = -1, tq = -1;
+    if (prev_re >= 0 && first_r >= prev_re && first_q >= prev_qe) { tr = first_r - prev_re; tq = first_q - prev_qe; }
+    const ExtResult b = extend_wave(RV, QV, first_r, first_q, -1, first_r - r_lo, first_q - q_lo, tr, tq);
+    ChainBwd e;
+    e.rs = first_r - b.di; e.qs = first_q - b.dj; e.err_back = b.errors;
+    e.reached = (tr >= 0 && b.reached) ? 1 : 0;
+    if ((threadIdx.x & 63) == 0) bw[(size_t)u * cap_c + c] = e;
+  }
+}
+
+struct FinishScratch {
+  Aln* alns;        // [P][cap_a]
+  int32_t* a_rrec;  // [P][cap_a]
+  int32_t* a_qrec;
+  int32_t* idx;
+  int32_t* from;
+  double* sc;
+  int32_t* aln_of;  // [U][cap_c]
+};
+
+__global__ __launch_bounds__(64) void anim_finish_kernel(RefDesc R, const UnitDesc* __restrict__ units, uint32_t n_pairs,
+                                                         uint32_t cap_m, uint32_t cap_c, uint32_t cap_a, ClusterOut O,
+                                                         const ChainFwd* __restrict__ fw, const ChainBwd* __restrict__ bw,
+                                                         FinishScratch S, int filter_1to1, pg_anim_result* __restrict__ out) {
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_pairs) return;
+  Aln* alns = S.alns + (size_t)p * cap_a;
+  int32_t* a_rrec = S.a_rrec + (size_t)p * cap_a;
+  int32_t* a_qrec = S.a_qrec + (size_t)p * cap_a;
+  int32_t* idx = S.idx + (size_t)p * cap_a;
+  int32_t* from = S.from + (size_t)p * cap_a;
+  double* sc = S.sc + (size_t)p * cap_a;
+  int n = 0;
+  for (int strand = 0; strand < 2; ++strand) {
+    const uint32_t u = 2 * p + strand;  // units are laid out pair-major: (pair, fwd), (pair, rev)
+    const UnitDesc U = units[u];
+    const int before = n;
+    n = stitch_chains(fw + (size_t)u * cap_c, bw + (size_t)u * cap_c, O.cm + (size_t)u * cap_m, O.chains + (size_t)u * cap_c,
+                      O.order + (size_t)u * cap_c, O.prev_of + (size_t)u * cap_c, O.n_chains[u], strand,
+                      S.aln_of + (size_t)u * cap_c, alns, n, (int)cap_a);
+    for (int i = before; i < n; ++i) {
+      Aln& a = alns[i];
+      a_rrec[i] = record_of(R.rec_start, R.n_rec, a.rs);
+      if (strand) { const int32_t qs = U.len - a.qe, qe = U.len - a.qs; a.qs = qs; a.qe = qe; }  // forward coordinates
+      a_qrec[i] = record_of(U.rec_start, U.n_rec, a.qs);
+    }
+  }
+  if (filter_1to1) {
+    lis_filter(alns, n, 0, a_rrec, idx, sc, from);
+    lis_filter(alns, n, 1, a_qrec, idx, sc, from);
+  } else {
+    for (int i = 0; i < n; ++i) alns[i].keep = 3;
+  }
+  const PairResult r = reduce_pair(alns, n, a_rrec, a_qrec, idx);
+  pg_anim_result o;
+  o.ref_aln_len = r.ref_aln_len;
+  o.qry_aln_len = r.qry_aln_len;
+  o.sim_errors = r.sim_errors;
+  o.n_alignments = r.n_alignments;
+  o.identity = r.aligned > 0 ? (double)r.weighted / (double)r.aligned : 0.0;  // int/int true division (anim.py:396)
+  o.status = O.status[p] ? PG_E_CAPACITY : (r.n_alignments == 0 ? PG_ANIM_NO_ALIGNMENT : 0);
+  out[p] = o;
+}
+
+template <typename T>
+int anim_alloc(pg_ctx* ctx, T*& p, size_t n) {
+  PG_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&p), n * sizeof(T)));
+  return PG_OK;
+}
+
+}  // namespace
+
+// ---- host driver ---------------------------------------------------------------------------------------------------
+// Processes all pairs that share one reference genome (= nucmer's reference = pyani's query genome, anim.py:280).
+int pg_anim_run_ref(pg_ctx* ctx, int32_t ref_id, const int32_t* qry_ids, uint32_t n_pairs, int filter_1to1,
+                    pg_anim_result* out_host) {
+  const PgGenome& G = ctx->genomes[ref_id];
+  constexpr uint32_t CAP_M = 1u << 17, CAP_C = 1u << 13, CAP_A = 1u << 14;
+  const uint32_t n_units = 2 * n_pairs;
+  // reference descriptor + table
+  RefDesc R;
+  R.codes = ctx->d_codes + G.arena_start / 16;
+  R.mask = ctx->d_mask + G.arena_start / 32;
+  R.len = (int32_t)G.stream_len;
+  R.n_rec = (int32_t)G.n_rec;
+  uint32_t tbits = 10;
+  while ((1ull << tbits) < (uint64_t)(G.stream_len + G.stream_len / 2 + 16)) ++tbits;
+  R.table_mask = (uint32_t)((1ull << tbits) - 1);
+  uint64_t* d_table = nullptr;
+  int32_t* d_recs = nullptr;
+  UnitDesc* d_units = nullptr;
+  Match *d_mem = nullptr, *d_cm = nullptr;
+  uint32_t* d_mem_count = nullptr;
+  int32_t *d_iscratch = nullptr, *d_nch = nullptr, *d_order = nullptr, *d_prev = nullptr, *d_status = nullptr, *d_alnof = nullptr;
+  Chain* d_chains = nullptr;
+  ChainFwd* d_fw = nullptr;
+  ChainBwd* d_bw = nullptr;
+  FinishScratch S{};
+  pg_anim_result* d_out = nullptr;
+  int rc = PG_OK;
+  std::vector<void*> to_free;
+  auto cleanup = [&]() { for (void* p : to_free) if (p) (void)hipFree(p); };
+#define AA(ptr, n) do { if ((rc = anim_alloc(ctx, ptr, (n)))) { cleanup(); return rc; } to_free.push_back(ptr); } while (0)
+  AA(d_table, (size_t)R.table_mask + 1);
+  // record-start tables: reference first, then each query
+  std::vector<int32_t> recs(G.rec_start.begin(), G.rec_start.end());
+  std::vector<uint32_t> rec_off(n_pairs);
+  for (uint32_t p = 0; p < n_pairs; ++p) {
+    const PgGenome& Q = ctx->genomes[qry_ids[p]];
+    rec_off[p] = (uint32_t)recs.size();
+    recs.insert(recs.end(), Q.rec_start.begin(), Q.rec_start.end());
+  }
+  AA(d_recs, recs.size());
+  PG_HIP(ctx, hipMemcpyAsync(d_recs, recs.data(), recs.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+  R.rec_start = d_recs;
+  R.table = d_table;
+  std::vector<UnitDesc> units(n_units);
+  int32_t max_qlen = 0;
+  for (uint32_t p = 0; p < n_pairs; ++p) {
+    const PgGenome& Q = ctx->genomes[qry_ids[p]];
+    for (int s = 0; s < 2; ++s) {
+      UnitDesc& U = units[2 * p + s];
+      U.codes = ctx->d_codes + Q.arena_start / 16;
+      U.mask = ctx->d_mask + Q.arena_start / 32;
+      U.len = (int32_t)Q.stream_len;
+      U.rec_start = d_recs + rec_off[p];
+      U.n_rec = (int32_t)Q.n_rec;
+      U.strand = s;
+      U.pair = (int32_t)p;
+    }
+    if ((int32_t)Q.stream_len > max_qlen) max_qlen = (int32_t)Q.stream_len;
+  }
+  AA(d_units, n_units);
+  PG_HIP(ctx, hipMemcpyAsync(d_units, units.data(), n_units * sizeof(UnitDesc), hipMemcpyHostToDevice, ctx->stream));
+  AA(d_mem, (size_t)n_units * CAP_M);
+  AA(d_cm, (size_t)n_units * CAP_M);
+  AA(d_mem_count, n_units);
+  AA(d_iscratch, (size_t)n_units * 7 * CAP_M);
+  AA(d_chains, (size_t)n_units * CAP_C);
+  AA(d_nch, n_units);
+  AA(d_order, (size_t)n_units * CAP_C);
+  AA(d_prev, (size_t)n_units * CAP_C);
+  AA(d_alnof, (size_t)n_units * CAP_C);
+  AA(d_status, n_pairs);
+  AA(d_fw, (size_t)n_units * CAP_C);
+  AA(d_bw, (size_t)n_units * CAP_C);
+  AA(S.alns, (size_t)n_pairs * CAP_A);
+  AA(S.a_rrec, (size_t)n_pairs * CAP_A);
+  AA(S.a_qrec, (size_t)n_pairs * CAP_A);
+  AA(S.idx, (size_t)n_pairs * CAP_A);
+  AA(S.from, (size_t)n_pairs * CAP_A);
+  AA(S.sc, (size_t)n_pairs * CAP_A);
+  AA(d_out, n_pairs);
+#undef AA
+  S.aln_of = d_alnof;
+  PG_HIP(ctx, hipMemsetAsync(d_table, 0xFF, ((size_t)R.table_mask + 1) * 8, ctx->stream));
+  PG_HIP(ctx, hipMemsetAsync(d_mem_count, 0, n_units * 4, ctx->stream));
+  PG_HIP(ctx, hipMemsetAsync(d_status, 0, n_pairs * 4, ctx->stream));
+  ClusterOut O{d_cm, d_chains, d_nch, d_order, d_prev, d_status};
+  hipLaunchKernelGGL(anim_index_kernel, dim3((R.len + 255) / 256), dim3(256), 0, ctx->stream, R);
+  hipLaunchKernelGGL(anim_seed_kernel, dim3((max_qlen + 255) / 256, n_units), dim3(256), 0, ctx->stream, R, d_units, d_mem,
+                     d_mem_count, CAP_M);
+  hipLaunchKernelGGL(anim_cluster_kernel, dim3((n_units + 63) / 64), dim3(64), 0, ctx->stream, R, d_units, n_units, d_mem,
+                     d_mem_count, CAP_M, CAP_C, d_iscratch, O);
+  // work list of (unit, chain): one wave each
+  std::vector<int32_t> nch(n_units);
+  PG_HIP(ctx, hipMemcpyAsync(nch.data(), d_nch, n_units * 4, hipMemcpyDeviceToHost, ctx->stream));
+  PG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  std::vector<uint2> wl;
+  for (uint32_t u = 0; u < n_units; ++u)
+    for (int32_t c = 0; c < nch[u]; ++c) wl.push_back(make_uint2(u, (uint32_t)c));
+  uint2* d_wl = nullptr;
+  if (!wl.empty()) {
+    if ((rc = anim_alloc(ctx, d_wl, wl.size()))) { cleanup(); return rc; }
+    to_free.push_back(d_wl);
+    PG_HIP(ctx, hipMemcpyAsync(d_wl, wl.data(), wl.size() * sizeof(uint2), hipMemcpyHostToDevice, ctx->stream));
+    for (int phase = 0; phase < 2; ++phase)
+      hipLaunchKernelGGL(anim_extend_kernel, dim3((uint32_t)wl.size()), dim3(64), 0, ctx->stream, R, d_units, CAP_M, CAP_C, O,
+                         d_wl, d_fw, d_bw, phase);
+  }
+  hipLaunchKernelGGL(anim_finish_kernel, dim3((n_pairs + 63) / 64), dim3(64), 0, ctx->stream, R, d_units, n_pairs, CAP_M,
+                     CAP_C, CAP_A, O, d_fw, d_bw, S, filter_1to1, d_out);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpyAsync(out_host, d_out, n_pairs * sizeof(pg_anim_result), hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  cleanup();
+  if (e != hipSuccess) return pg_fail(ctx, PG_E_HIP, std::string("anim pipeline: ") + hipGetErrorString(e));
+  return PG_OK;
+}

@@ -1,0 +1,501 @@
+// pg_anim_core.h — per-pair logic of the ANIm engine (MUM filter, mgaps-style clustering, banded affine extension,
+// 1-to-1 filter, parse_delta reduction) as plain C++ that compiles for the device (hipcc) AND for the host.
+// The host build exists only for tools/anim_debug (a development harness in the GPU-less build container); the
+// product runs these functions inside HIP kernels (pg_anim.hip).
+//
+// What it emulates: `nucmer --mum` + `delta-filter -1` of MUMmer 3.23 as pyani drives them (pyani/anim.py:280-288),
+// reduced as pyani.anim.parse_delta does (anim.py:292-411).  MUMmer's source is NOT in the reference tree; the
+// behaviour below is reconstructed from its published defaults (-l 20 -c 65 -g 90 -d 0.12 -D 5 -b 200) and calibrated
+// at the alignment-record level against the real MUMmer output the reference's tests hold (tests/golden/anim/):
+// scoring match +3 / mismatch -7 / first gap base -10 / further gap bases -7 reproduces 75 of 91 alignments of a
+// 83 %-identity Blochmannia pair coordinate-for-coordinate with identical error counts.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define PG_HD __host__ __device__ __forceinline__
+#else
+#define PG_HD inline
+#endif
+
+namespace pga {
+
+// ---- parameters (nucmer / mgaps / postnuc defaults used by pyani) ---------------------------------------------
+constexpr int MIN_MATCH = 20;        // nucmer -l
+constexpr int MIN_CLUSTER = 65;      // nucmer -c  (mgaps -l)
+constexpr int MAX_GAP = 90;          // nucmer -g  (mgaps -s)
+constexpr int DIAG_DIFF = 5;         // nucmer -D  (mgaps -d)
+constexpr double DIAG_FACTOR = 0.12; // nucmer -d  (mgaps -f)
+constexpr int BREAK_LEN = 200;       // nucmer -b  (anti-diagonals without a new high score)
+constexpr int SC_MATCH = 3, SC_MISMATCH = -7, SC_GAP_OPEN = -10, SC_GAP_EXT = -7;
+constexpr int BAND = 64;             // DP band: diagonal offsets -32 .. +31 around the start diagonal
+
+// ---- packed genome view ------------------------------------------------------------------------------------------
+// Same layout as the TETRA arena (pg_internal.h): 2-bit codes, 1-bit clean mask, records separated by one dirty base.
+struct SeqView {
+  const uint32_t* codes;
+  const uint32_t* mask;
+  int64_t len;  // stream length in bases (records + separators)
+  PG_HD int base(int64_t p) const { return (int)((codes[p >> 4] >> (2 * (p & 15))) & 3u); }
+  PG_HD bool clean(int64_t p) const { return p >= 0 && p < len && ((mask[p >> 5] >> (p & 31)) & 1u); }
+};
+
+// A query strand view: strand 0 = forward, 1 = reverse complement (position p of the strand = base len-1-p complemented)
+struct StrandView {
+  SeqView s;
+  int rc;
+  PG_HD int64_t len() const { return s.len; }
+  PG_HD bool clean(int64_t p) const { return rc ? s.clean(s.len - 1 - p) : s.clean(p); }
+  PG_HD int base(int64_t p) const { return rc ? 3 - s.base(s.len - 1 - p) : s.base(p); }
+};
+
+struct Match {   // exact match: ref [r, r+len), query-strand [q, q+len)
+  int32_t r, q, len;
+  int32_t strand;
+};
+
+struct Aln {     // alignment in ref / query-strand coordinates, half-open
+  int32_t rs, re, qs, qe;
+  int32_t errors;
+  int32_t strand;
+  int32_t keep;  // used by the 1-to-1 filter
+};
+
+// ---- banded affine extension -----------------------------------------------------------------------------------
+// Anti-diagonal order (d = i + j), band of BAND diagonals k = j - i in [-BAND/2, BAND/2).  This is the SCALAR statement
+// of the algorithm; pg_anim.hip holds the wave-cooperative version (one lane per diagonal, neighbours through DPP)
+// that computes exactly the same cells, checks and tie-breaks — the two must stay in lock-step.
+//   H: best score of a path ending at (i, j);  X: ending in a gap that consumed a ref base;  Y: ... a query base.
+//   X = max(H(i-1,j) + OPEN, X(i-1,j) + EXT)   (ties: open)      Y likewise from (i,j-1)
+//   H = max(diag + match/mismatch, X, Y)        (ties: diag, then X, then Y);  errors ride along.
+// Free search: the end is the best cell (ties: larger d, then larger k).  Every CHECK_EVERY anti-diagonals the search
+// stops if the best cell lies more than BREAK_LEN anti-diagonals back (nucmer -b) or no cell is alive.
+// Target search (tr >= 0): runs to d = tr + tq and reports whether the target cell was reached by a live path,
+// subject to the same break rule on the way.
+struct ExtResult {
+  int32_t di, dj;      // bases consumed on ref / query at the chosen end
+  int32_t score, errors;
+  int32_t reached;     // target reached (only when a target was given)
+};
+
+constexpr int32_t NEG_INF = -(1 << 28);
+constexpr int CHECK_EVERY = 16;
+
+struct DpCell { int32_t h, he, x, xe, y, ye; };
+
+// One cell update, shared by the scalar and the wave version.  up = cell (i-1, j), left = cell (i, j-1),
+// diag_h/diag_he = H of (i-1, j-1); ok = the two bases match.
+PG_HD DpCell dp_cell(bool has_up, int32_t up_h, int32_t up_he, int32_t up_x, int32_t up_xe, bool has_left, int32_t left_h,
+                     int32_t left_he, int32_t left_y, int32_t left_ye, bool has_diag, int32_t diag_h, int32_t diag_he, bool ok) {
+  DpCell c{NEG_INF, 0, NEG_INF, 0, NEG_INF, 0};
+  if (has_up) {
+    const int32_t ho = up_h + SC_GAP_OPEN, xo = up_x + SC_GAP_EXT;
+    if (ho >= xo) { c.x = ho; c.xe = up_he + 1; } else { c.x = xo; c.xe = up_xe + 1; }
+    if (c.x < NEG_INF / 2) c.x = NEG_INF;
+  }
+  if (has_left) {
+    const int32_t ho = left_h + SC_GAP_OPEN, yo = left_y + SC_GAP_EXT;
+    if (ho >= yo) { c.y = ho; c.ye = left_he + 1; } else { c.y = yo; c.ye = left_ye + 1; }
+    if (c.y < NEG_INF / 2) c.y = NEG_INF;
+  }
+  if (has_diag && diag_h > NEG_INF / 2) { c.h = diag_h + (ok ? SC_MATCH : SC_MISMATCH); c.he = diag_he + (ok ? 0 : 1); }
+  if (c.x > c.h) { c.h = c.x; c.he = c.xe; }
+  if (c.y > c.h) { c.h = c.y; c.he = c.ye; }
+  return c;
+}
+
+template <typename RefT, typename QryT>
+PG_HD ExtResult extend_banded(const RefT& R, const QryT& Q, int64_t r0, int64_t q0, int dir, int32_t rmax, int32_t qmax,
+                              int32_t tr, int32_t tq) {
+  constexpr int W = BAND / 2;
+  DpCell cur[BAND];                 // latest cell of every diagonal (index l <-> k = l - W)
+  int32_t bs[BAND], bd[BAND], be[BAND];  // per-diagonal best: score, d, errors
+  for (int l = 0; l < BAND; ++l) { cur[l] = DpCell{NEG_INF, 0, NEG_INF, 0, NEG_INF, 0}; bs[l] = NEG_INF; bd[l] = 0; be[l] = 0; }
+  cur[W].h = 0; bs[W] = 0;          // cell (0, 0)
+  ExtResult res{0, 0, 0, 0, 0};
+  bool targeted = tr >= 0;
+  if (targeted && (tq - tr < -W || tq - tr >= W || tr > rmax || tq > qmax)) targeted = false;  // unreachable: free search
+  if (targeted && tr == 0 && tq == 0) { res.reached = 1; return res; }
+  const int32_t d_end = targeted ? tr + tq : rmax + qmax;
+  int32_t gbest = 0, gbest_d = 0;
+  for (int32_t d = 1; d <= d_end; ++d) {
+    DpCell nxt[BAND];
+    bool alive = false;
+    for (int l = 0; l < BAND; ++l) {
+      const int k = l - W;
+      if ((d + k) & 1) { nxt[l] = cur[l]; continue; }        // this diagonal has no cell on anti-diagonal d
+      const int32_t i = (d - k) / 2, j = (d + k) / 2;
+      if (i < 0 || j < 0 || i > rmax || j > qmax) { nxt[l] = DpCell{NEG_INF, 0, NEG_INF, 0, NEG_INF, 0}; continue; }
+      const bool has_up = i >= 1 && l + 1 < BAND, has_left = j >= 1 && l >= 1, has_diag = i >= 1 && j >= 1;
+      bool ok = false;
+      if (has_diag) {
+        const int64_t rp = dir > 0 ? r0 + (i - 1) : r0 - i, qp = dir > 0 ? q0 + (j - 1) : q0 - j;
+        ok = R.clean(rp) && Q.clean(qp) && R.base(rp) == Q.base(qp);
+      }
+      const DpCell& U = cur[has_up ? l + 1 : l];
+      const DpCell& L = cur[has_left ? l - 1 : l];
+      nxt[l] = dp_cell(has_up, U.h, U.he, U.x, U.xe, has_left, L.h, L.he, L.y, L.ye, has_diag, cur[l].h, cur[l].he, ok);
+      if (nxt[l].h > NEG_INF / 2) {
+        alive = true;
+        if (nxt[l].h > bs[l] || (nxt[l].h == bs[l] && d >= bd[l])) { bs[l] = nxt[l].h; bd[l] = d; be[l] = nxt[l].he; }
+      }
+    }
+    for (int l = 0; l < BAND; ++l) cur[l] = nxt[l];
+    if ((d % CHECK_EVERY) == 0 || d == d_end) {
+      gbest = NEG_INF; gbest_d = 0;
+      for (int l = 0; l < BAND; ++l)
+        if (bs[l] > gbest || (bs[l] == gbest && bd[l] >= gbest_d)) { gbest = bs[l]; gbest_d = bd[l]; }
+      if (d - gbest_d > BREAK_LEN) break;
+      // `alive` of the last anti-diagonal only; two dead anti-diagonals in a row cannot revive
+      bool any = alive;
+      for (int l = 0; l < BAND && !any; ++l) any = cur[l].h > NEG_INF / 2;
+      if (!any) break;
+    }
+    if (targeted && d == d_end) {
+      const int l = (tq - tr) + W;
+      if (cur[l].h > NEG_INF / 2) { res.di = tr; res.dj = tq; res.score = cur[l].h; res.errors = cur[l].he; res.reached = 1; return res; }
+    }
+  }
+  // best cell: max score, ties -> larger d, then larger k
+  int bl = W; gbest = NEG_INF; gbest_d = -1;
+  for (int l = 0; l < BAND; ++l)
+    if (bs[l] > gbest || (bs[l] == gbest && bd[l] >= gbest_d)) { gbest = bs[l]; gbest_d = bd[l]; bl = l; }
+  const int k = bl - W;
+  res.score = gbest; res.errors = be[bl]; res.di = (gbest_d - k) / 2; res.dj = (gbest_d + k) / 2;
+  return res;
+}
+
+// Global alignment of the gap between two chained matches: ref gap n, query gap m (both small); returns errors.
+template <typename RefT, typename QryT>
+PG_HD int32_t gap_errors(const RefT& R, const QryT& Q, int64_t r0, int32_t n, int64_t q0, int32_t m) {
+  if (n == 0) return m;
+  if (m == 0) return n;
+  if (n == m && n <= 2) {   // isolated SNPs: substitutions always beat a gap pair (2 * -7 > 2 * -10)
+    int32_t err = 0;
+    for (int32_t t = 0; t < n; ++t)
+      err += (R.clean(r0 + t) && Q.clean(q0 + t) && R.base(r0 + t) == Q.base(q0 + t)) ? 0 : 1;
+    return err;
+  }
+  const ExtResult e = extend_banded(R, Q, r0, q0, +1, n, m, n, m);
+  if (e.reached) return e.errors;
+  // target outside the band (|n - m| >= BAND/2) or pruned: count the diagonal part + the length difference
+  int32_t k = n < m ? n : m, err = (n > m ? n - m : m - n);
+  for (int32_t t = 0; t < k; ++t) {
+    const bool ok = R.clean(r0 + t) && Q.clean(q0 + t) && R.base(r0 + t) == Q.base(q0 + t);
+    err += ok ? 0 : 1;
+  }
+  return err;
+}
+
+}  // namespace pga
+
+// =====================================================================================================================
+// Per-pair bookkeeping after seeding: MUM filter -> clusters/chains -> (extension, elsewhere) -> 1-to-1 filter -> reduce
+// All routines are single-threaded over small arrays (one GPU thread per ordered pair; thousands of pairs in flight).
+// =====================================================================================================================
+namespace pga {
+
+template <typename T, typename Less>
+PG_HD void heapsort(T* a, int n, Less less) {
+  auto sift = [&](int root, int end) {
+    for (;;) {
+      int child = 2 * root + 1;
+      if (child >= end) break;
+      if (child + 1 < end && less(a[child], a[child + 1])) ++child;
+      if (!less(a[root], a[child])) break;
+      T t = a[root]; a[root] = a[child]; a[child] = t;
+      root = child;
+    }
+  };
+  for (int i = n / 2 - 1; i >= 0; --i) sift(i, n);
+  for (int end = n - 1; end > 0; --end) {
+    T t = a[0]; a[0] = a[end]; a[end] = t;
+    sift(0, end);
+  }
+}
+
+// record index of stream position p: offsets[k] = first base of record k, offsets[n_rec] = stream length + 1
+PG_HD int record_of(const int32_t* rec_start, int n_rec, int32_t p) {
+  int lo = 0, hi = n_rec;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (rec_start[mid] <= p) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+// MUM filter (`mummer -mum`): keep maximal matches whose string occurs once in the reference and once in the query
+// strand.  A match is NOT unique in the reference iff another match (other ref position) covers its whole query
+// interval, and NOT unique in the query iff another match covers its whole ref interval.  m[0..n) of ONE strand; the
+// `strand` field is used as scratch flag and restored.  Returns the new count (order: by q).
+PG_HD int mum_filter(Match* m, int n, int strand) {
+  for (int i = 0; i < n; ++i) m[i].strand = 0;
+  // query-interval containment
+  heapsort(m, n, [](const Match& a, const Match& b) { return a.q < b.q || (a.q == b.q && a.len > b.len); });
+  int32_t maxend = -1;
+  for (int i = 0; i < n; ++i) {
+    const int32_t e = m[i].q + m[i].len;
+    if (e <= maxend) m[i].strand = 1;
+    else if (i + 1 < n && m[i + 1].q == m[i].q && m[i + 1].len == m[i].len) m[i].strand = 1;
+    if (e > maxend) maxend = e;
+  }
+  // ref-interval containment
+  heapsort(m, n, [](const Match& a, const Match& b) { return a.r < b.r || (a.r == b.r && a.len > b.len); });
+  maxend = -1;
+  for (int i = 0; i < n; ++i) {
+    const int32_t e = m[i].r + m[i].len;
+    if (e <= maxend) m[i].strand = 1;
+    else if (i + 1 < n && m[i + 1].r == m[i].r && m[i + 1].len == m[i].len) m[i].strand = 1;
+    if (e > maxend) maxend = e;
+  }
+  int k = 0;
+  for (int i = 0; i < n; ++i)
+    if (!m[i].strand) m[k++] = m[i];
+  for (int i = 0; i < k; ++i) m[i].strand = strand;
+  heapsort(m, k, [](const Match& a, const Match& b) { return a.q < b.q || (a.q == b.q && a.r < b.r); });
+  return k;
+}
+
+struct Chain {      // a cluster chain: matches cm[first .. first+count)
+  int32_t first, count;
+  int32_t strand;
+  int32_t rrec, qrec;  // record indices (ref, query-forward)
+};
+
+constexpr int CHAIN_LOOKBACK = 64;  // mgaps scans all earlier matches of the cluster; we bound the scan (documented)
+
+// mgaps: union-find clustering of one strand's MUMs (sorted by q) + best-chain extraction.
+// scratch: parent[n], score[n], from[n], adj[n], used[n] (int32 each).  Appends chains to chains[]/cm[].
+// Matches of different (ref record, query record) never join.
+PG_HD void mgaps_strand(const Match* m, int n, int strand, const int32_t* rrec_of, const int32_t* qrec_of,
+                        int32_t* parent, int32_t* score, int32_t* from, int32_t* adj, int32_t* order,
+                        Chain* chains, int& n_chains, int max_chains, Match* cm, int& n_cm, int max_cm) {
+  auto find = [&](int x) {
+    while (parent[x] != x) { parent[x] = parent[parent[x]]; x = parent[x]; }
+    return x;
+  };
+  for (int i = 0; i < n; ++i) parent[i] = i;
+  for (int i = 0; i < n; ++i) {
+    const int32_t iend = m[i].q + m[i].len, idiag = m[i].q - m[i].r;
+    for (int j = i + 1; j < n; ++j) {
+      const int32_t sep = m[j].q - iend;
+      if (sep > MAX_GAP) break;
+      if (rrec_of[i] != rrec_of[j] || qrec_of[i] != qrec_of[j]) continue;
+      int32_t dd = (m[j].q - m[j].r) - idiag;
+      if (dd < 0) dd = -dd;
+      int32_t lim = (int32_t)(DIAG_FACTOR * sep);
+      if (lim < DIAG_DIFF) lim = DIAG_DIFF;
+      if (dd <= lim) { const int a = find(i), b = find(j); if (a != b) parent[a] = b; }
+    }
+  }
+  for (int i = 0; i < n; ++i) { parent[i] = find(i); order[i] = i; }
+  // group by cluster id, keep q order inside
+  heapsort(order, n, [&](int a, int b) { return parent[a] < parent[b] || (parent[a] == parent[b] && a < b); });
+  int g0 = 0;
+  while (g0 < n) {
+    int g1 = g0;
+    while (g1 < n && parent[order[g1]] == parent[order[g0]]) ++g1;
+    // cluster = order[g0..g1); extract chains until nothing is left (adj doubles as "removed" marker via from = -2)
+    int remaining = g1 - g0;
+    for (int k = g0; k < g1; ++k) from[order[k]] = -1;
+    while (remaining > 0) {
+      int best = -1;
+      for (int k = g0; k < g1; ++k) {
+        const int i = order[k];
+        if (from[i] == -2) continue;
+        score[i] = m[i].len; from[i] = -1; adj[i] = 0;
+        int seen = 0;
+        for (int kk = k - 1; kk >= g0 && seen < CHAIN_LOOKBACK; --kk) {
+          const int j = order[kk];
+          if (from[j] == -2) continue;
+          ++seen;
+          int32_t ol = m[j].r + m[j].len - m[i].r;
+          if (ol < 0) ol = 0;
+          const int32_t ol2 = m[j].q + m[j].len - m[i].q;
+          if (ol2 > ol) ol = ol2;
+          int32_t dd = (m[i].q - m[i].r) - (m[j].q - m[j].r);
+          if (dd < 0) dd = -dd;
+          const int32_t cand = score[j] + m[i].len - (ol + dd);
+          if (cand > score[i]) { score[i] = cand; from[i] = j; adj[i] = ol; }
+        }
+        if (best < 0 || score[i] > score[best]) best = i;
+      }
+      // walk the chain
+      int32_t total = 0, cnt = 0;
+      for (int i = best; i >= 0; i = from[i]) { total += m[i].len; ++cnt; }
+      if (total >= MIN_CLUSTER && n_chains < max_chains && n_cm + cnt <= max_cm) {
+        Chain c;
+        c.first = n_cm; c.count = cnt; c.strand = strand; c.rrec = rrec_of[best]; c.qrec = qrec_of[best];
+        int pos = n_cm + cnt;
+        for (int i = best; i >= 0; i = from[i]) {
+          Match t = m[i];
+          t.r += adj[i]; t.q += adj[i]; t.len -= adj[i];
+          cm[--pos] = t;
+        }
+        n_cm += cnt;
+        chains[n_chains++] = c;
+      }
+      for (int i = best; i >= 0;) { const int nx = from[i]; from[i] = -2; --remaining; i = nx; }
+    }
+    g0 = g1;
+  }
+}
+
+// ---- chains -> alignments -------------------------------------------------------------------------------------------
+// postnuc semantics reconstructed from the fixtures: every chain is extended forward freely (stop = best-scoring
+// cell once BREAK_LEN anti-diagonals pass without a new high score); it is extended BACKWARD towards the end of the
+// preceding alignment as a target — if the target cell is reached before the break criterion fires, the two are
+// fused into one alignment (this is how nucmer bridges ~100-base junk between two clusters), otherwise the chain
+// starts a new alignment at its own best backward cell.
+struct ChainFwd {
+  int32_t first_r, first_q;     // first match start
+  int32_t inner_err;            // errors of the gaps between chained matches
+  int32_t re, qe, err_fwd;      // end after the free forward extension
+};
+struct ChainBwd {
+  int32_t rs, qs, err_back;     // start after the backward extension (== target cell when reached)
+  int32_t reached;              // landed exactly on the previous chain's forward end -> fuse
+};
+
+template <typename RefT, typename QryT>
+PG_HD ChainFwd extend_chain_fwd(const RefT& R, const QryT& Q, const Match* cm, const Chain& c, int32_t r_hi, int32_t q_hi) {
+  ChainFwd e;
+  const Match& f = cm[c.first];
+  e.first_r = f.r; e.first_q = f.q;
+  int32_t inner = 0;
+  int32_t er = f.r + f.len, eq = f.q + f.len;
+  for (int k = 1; k < c.count; ++k) {
+    Match t = cm[c.first + k];
+    int32_t trim = er - t.r;                 // chained matches may still overlap the running end
+    if (eq - t.q > trim) trim = eq - t.q;
+    if (trim > 0) { t.r += trim; t.q += trim; t.len -= trim; }
+    if (t.len <= 0) continue;
+    inner += gap_errors(R, Q, er, t.r - er, eq, t.q - eq);
+    er = t.r + t.len; eq = t.q + t.len;
+  }
+  e.inner_err = inner;
+  const ExtResult fw = extend_banded(R, Q, er, eq, +1, r_hi - er, q_hi - eq, -1, -1);
+  e.re = er + fw.di; e.qe = eq + fw.dj; e.err_fwd = fw.errors;
+  return e;
+}
+
+// prev_re/prev_qe: forward end of the preceding chain (same strand and records), or -1 if there is none.
+template <typename RefT, typename QryT>
+PG_HD ChainBwd extend_chain_bwd(const RefT& R, const QryT& Q, int32_t first_r, int32_t first_q, int32_t r_lo, int32_t q_lo,
+                                int32_t prev_re, int32_t prev_qe) {
+  int32_t tr = -1, tq = -1;
+  if (prev_re >= 0 && first_r >= prev_re && first_q >= prev_qe) { tr = first_r - prev_re; tq = first_q - prev_qe; }
+  const ExtResult b = extend_banded(R, Q, first_r, first_q, -1, first_r - r_lo, first_q - q_lo, tr, tq);
+  ChainBwd e;
+  e.rs = first_r - b.di; e.qs = first_q - b.dj; e.err_back = b.errors;
+  e.reached = (tr >= 0 && b.reached) ? 1 : 0;
+  return e;
+}
+
+// Sequential stitch of one strand's chains (order[] = sorted by first-match ref start).  prev_of[c] = the chain whose
+// forward end was c's backward target (or -1).  Chains lying inside an existing alignment are shadowed.
+PG_HD int stitch_chains(const ChainFwd* fw, const ChainBwd* bw, const Match* cm, const Chain* chains, const int32_t* order,
+                        const int32_t* prev_of, int n, int strand, int32_t* aln_of, Aln* out, int n_out, int max_out) {
+  const int out0 = n_out;
+  for (int k = 0; k < n; ++k) {
+    const int c = order[k];
+    aln_of[c] = -1;
+    const Match& l = cm[chains[c].first + chains[c].count - 1];
+    const int p = prev_of[c];
+    if (p >= 0 && bw[c].reached && aln_of[p] >= 0 && out[aln_of[p]].re == fw[p].re && out[aln_of[p]].qe == fw[p].qe) {
+      Aln& a = out[aln_of[p]];               // fuse: bridge errors + this chain's inner + forward extension
+      a.errors += bw[c].err_back + fw[c].inner_err + fw[c].err_fwd;
+      a.re = fw[c].re; a.qe = fw[c].qe;
+      aln_of[c] = aln_of[p];
+      continue;
+    }
+    bool shadow = false;
+    for (int t = out0; t < n_out && !shadow; ++t)
+      if (fw[c].first_r >= out[t].rs && l.r + l.len <= out[t].re && fw[c].first_q >= out[t].qs && l.q + l.len <= out[t].qe) {
+        shadow = true;
+        aln_of[c] = t;   // a later chain whose backward target was this chain's end fuses with the shadowing alignment
+      }
+    if (shadow) continue;
+    Aln a;
+    a.rs = bw[c].rs; a.qs = bw[c].qs; a.re = fw[c].re; a.qe = fw[c].qe; a.strand = strand; a.keep = 0;
+    a.errors = bw[c].err_back + fw[c].inner_err + fw[c].err_fwd;
+    if (n_out < max_out) { aln_of[c] = n_out; out[n_out++] = a; }
+  }
+  return n_out;
+}
+
+// delta-filter -1 (1-to-1: intersection of the best alignment sets on the reference and on the query):
+// weighted LIS over one coordinate; score of an alignment = length * identity^2; overlapping neighbours lose the
+// overlapped part.  side 0 = reference coordinates, 1 = query coordinates.  idx: scratch order; sc/from: scratch.
+PG_HD void lis_filter(Aln* a, int n, int side, const int32_t* grp, int32_t* idx, double* sc, int32_t* from) {
+  auto lo = [&](int i) { return side == 0 ? a[i].rs : a[i].qs; };   // a[] carries FORWARD query coordinates here
+  auto hi = [&](int i) { return side == 0 ? a[i].re : a[i].qe; };
+  for (int i = 0; i < n; ++i) idx[i] = i;
+  heapsort(idx, n, [&](int x, int y) { return grp[x] < grp[y] || (grp[x] == grp[y] && lo(x) < lo(y)); });
+  int g0 = 0;
+  while (g0 < n) {
+    int g1 = g0;
+    while (g1 < n && grp[idx[g1]] == grp[idx[g0]]) ++g1;
+    int best = -1;
+    for (int k = g0; k < g1; ++k) {
+      const int i = idx[k];
+      const double len = (double)(hi(i) - lo(i));
+      const double tot = (double)((a[i].re - a[i].rs) + (a[i].qe - a[i].qs));
+      const double idy = tot > 0 ? 1.0 - 2.0 * a[i].errors / tot : 0.0;
+      const double own = len * idy * idy;
+      sc[i] = own; from[i] = -1;
+      for (int kk = g0; kk < k; ++kk) {
+        const int j = idx[kk];
+        double ol = (double)(hi(j) - lo(i));
+        if (ol < 0) ol = 0;
+        if (ol >= len) continue;  // i contained in j's span: cannot extend the chain
+        const double cand = sc[j] + own * (1.0 - ol / len);
+        if (cand > sc[i]) { sc[i] = cand; from[i] = j; }
+      }
+      if (best < 0 || sc[i] > sc[best]) best = i;
+    }
+    for (int i = best; i >= 0; i = from[i]) a[i].keep |= (1 << side);
+    g0 = g1;
+  }
+}
+
+struct PairResult {
+  int64_t ref_aln_len, qry_aln_len, sim_errors, n_alignments;
+  int64_t weighted, aligned;  // identity = weighted / aligned (one correctly rounded division, anim.py:396)
+};
+
+// pyani.anim.parse_delta over the kept alignments (anim.py:355-411): sums + per-sequence interval unions of the
+// 1-based closed intervals.  a[] must carry FORWARD coordinates; rgrp/qgrp = record ids; idx: scratch.
+PG_HD PairResult reduce_pair(const Aln* a, int n, const int32_t* rgrp, const int32_t* qgrp, int32_t* idx) {
+  PairResult r{0, 0, 0, 0, 0, 0};
+  int k = 0;
+  for (int i = 0; i < n; ++i)
+    if (a[i].keep == 3) {
+      const int64_t rl = a[i].re - a[i].rs, ql = a[i].qe - a[i].qs;
+      r.aligned += rl + ql;
+      r.sim_errors += a[i].errors;
+      r.weighted += rl + ql - 2 * (int64_t)a[i].errors;
+      r.n_alignments += 1;
+      idx[k++] = i;
+    }
+  for (int side = 0; side < 2; ++side) {
+    auto grp = [&](int i) { return side == 0 ? rgrp[i] : qgrp[i]; };
+    auto lo = [&](int i) { return side == 0 ? a[i].rs : a[i].qs; };
+    auto hi = [&](int i) { return side == 0 ? a[i].re : a[i].qe; };
+    heapsort(idx, k, [&](int x, int y) { return grp(x) < grp(y) || (grp(x) == grp(y) && lo(x) < lo(y)); });
+    int64_t total = 0;
+    int32_t cb = 0, ce = 0, cg = -1;
+    bool open = false;
+    for (int t = 0; t < k; ++t) {
+      const int i = idx[t];
+      // closed 1-based interval [lo+1, hi]; intervals that overlap or share an end point are merged (anim.py:399-409)
+      if (open && grp(i) == cg && lo(i) + 1 <= ce) { if (hi(i) > ce) ce = hi(i); }
+      else { if (open) total += ce - cb; cb = lo(i); ce = hi(i); cg = grp(i); open = true; }
+    }
+    if (open) total += ce - cb;
+    if (side == 0) r.ref_aln_len = total; else r.qry_aln_len = total;
+  }
+  return r;
+}
+
+}  // namespace pga

@@ -76,12 +76,14 @@ int pack_genome(const uint8_t* seq, const uint64_t* rec_off, uint32_t n_rec, PgG
   g.codes.assign(g.padded_len / 16, 0u);
   g.mask.assign(g.padded_len / 32, 0u);
   g.quirk.fill(0);
+  g.rec_start.clear();
   uint64_t s = 0;  // stream position
   bool has_u = false;
   for (uint32_t r = 0; r < n_rec; ++r) {
     const uint8_t* p = seq + rec_off[r];
     const uint64_t L = rec_off[r + 1] - rec_off[r];
     if (r > 0) ++s;  // separator stays dirty (zero-initialised)
+    g.rec_start.push_back((int32_t)s);
     uint64_t i = 0;
     // head: until s is 32-aligned
     auto put = [&](uint64_t pos, uint8_t c) {
@@ -127,6 +129,7 @@ int pack_genome(const uint8_t* seq, const uint64_t* rec_off, uint32_t n_rec, PgG
       if (fok) g.quirk[rc4_index(f)] += 1;
     }
   }
+  g.rec_start.push_back((int32_t)g.stream_len + 1);
   return has_u ? PG_E_RNA : PG_OK;
 }
 
@@ -601,6 +604,39 @@ int pg_tetra_corr_rows_dev(pg_ctx* ctx, const double* d_z, const uint8_t* d_pres
   if ((rc = fetch_result_async(ctx, 16))) return rc;
   PG_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return check_flags(ctx, n);
+}
+
+// ---- ANIm -------------------------------------------------------------------------------------------------------
+int pg_anim_pairs(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_ids, uint64_t n_pairs, int maxmatch,
+                  int filter_1to1, pg_anim_result* out) {
+  if (!ctx || (n_pairs && (!ref_ids || !qry_ids || !out))) return pg_fail(ctx, PG_E_ARG, "bad argument");
+  if (maxmatch) return pg_fail(ctx, PG_E_ARG, "--maxmatch mode is not implemented (pyani's default is --mum)");
+  PG_HIP(ctx, hipSetDevice(ctx->device));
+  for (uint64_t i = 0; i < n_pairs; ++i)
+    if (ref_ids[i] < 0 || (size_t)ref_ids[i] >= ctx->genomes.size() || qry_ids[i] < 0 ||
+        (size_t)qry_ids[i] >= ctx->genomes.size())
+      return pg_fail(ctx, PG_E_ARG, "genome id out of range");
+  int rc;
+  if ((rc = pg_upload(ctx))) return rc;
+  // group the ordered pairs by reference genome: one k-mer table per reference, its queries in chunks
+  std::vector<uint64_t> order(n_pairs);
+  for (uint64_t i = 0; i < n_pairs; ++i) order[i] = i;
+  std::stable_sort(order.begin(), order.end(), [&](uint64_t a, uint64_t b) { return ref_ids[a] < ref_ids[b]; });
+  constexpr uint32_t CHUNK = 64;
+  std::vector<int32_t> q;
+  std::vector<pg_anim_result> res;
+  uint64_t i = 0;
+  while (i < n_pairs) {
+    uint64_t j = i;
+    while (j < n_pairs && j - i < CHUNK && ref_ids[order[j]] == ref_ids[order[i]]) ++j;
+    q.clear();
+    for (uint64_t k = i; k < j; ++k) q.push_back(qry_ids[order[k]]);
+    res.assign(j - i, pg_anim_result{});
+    if ((rc = pg_anim_run_ref(ctx, ref_ids[order[i]], q.data(), (uint32_t)(j - i), filter_1to1, res.data()))) return rc;
+    for (uint64_t k = i; k < j; ++k) out[order[k]] = res[k - i];
+    i = j;
+  }
+  return PG_OK;
 }
 
 // ---- measurement -----------------------------------------------------------------------------------------------

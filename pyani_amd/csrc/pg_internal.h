@@ -29,6 +29,7 @@ struct PgGenome {
   bool resident = false;
   std::vector<uint32_t> codes, mask;  // host copy until uploaded
   std::array<uint32_t, 256> quirk{};  // tetramers the reference does not count (last window of each strand)
+  std::vector<int32_t> rec_start;     // stream position of each record's first base; [n_rec] = stream_len + 1
 };
 
 struct PgEventPair {
@@ -100,3 +101,7 @@ int pg_launch_tetra_count(pg_ctx* ctx, uint32_t n_batch);
 int pg_launch_tetra_finalize(pg_ctx* ctx, uint32_t n_batch, unsigned long long* d_acc_in);
 int pg_launch_tetra_stats(pg_ctx* ctx, const double* d_z, const uint8_t* d_present, uint32_t n);
 int pg_launch_tetra_pairs(pg_ctx* ctx, uint32_t n, uint32_t row0, uint32_t nrows, double* d_out, bool mirror);
+
+// ANIm (pg_anim.hip): all pairs sharing one reference genome
+int pg_anim_run_ref(pg_ctx* ctx, int32_t ref_id, const int32_t* qry_ids, uint32_t n_pairs, int filter_1to1,
+                    pg_anim_result* out_host);

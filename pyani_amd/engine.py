@@ -148,6 +148,20 @@ class Engine:
     def tetra_corr_rows_dev(self, d_z_ptr: int, d_present_ptr: int, n: int, row0: int, nrows: int, d_out_ptr: int):
         self._check(self.lib.pg_tetra_corr_rows_dev(self._h, d_z_ptr, d_present_ptr, n, row0, nrows, d_out_ptr))
 
+    # -- ANIm -------------------------------------------------------------------------------------------------------
+    ANIM_DTYPE = np.dtype([("ref_aln_len", "<i8"), ("qry_aln_len", "<i8"), ("sim_errors", "<i8"), ("n_alignments", "<i8"),
+                           ("identity", "<f8"), ("status", "<i4"), ("reserved", "<i4")])
+
+    def anim_pairs(self, ref_ids, qry_ids, filter_1to1: bool = True, maxmatch: bool = False) -> np.ndarray:
+        """One record per ORDERED pair: ref = nucmer's reference (pyani's query genome), qry = nucmer's query."""
+        r, q = self._ids(ref_ids), self._ids(qry_ids)
+        if len(r) != len(q):
+            raise ValueError("ref_ids and qry_ids must have the same length")
+        out = np.zeros(len(r), dtype=self.ANIM_DTYPE)
+        self._check(self.lib.pg_anim_pairs(self._h, r.ctypes.data, q.ctypes.data, len(r), int(maxmatch), int(filter_1to1),
+                                           out.ctypes.data))
+        return out
+
     # -- measurement ----------------------------------------------------------------------------------------------
     def profile_enable(self, on: bool = True):
         self._check(self.lib.pg_profile_enable(self._h, int(on)))

@@ -1,0 +1,147 @@
+// anim_debug.cpp — HOST build of the ANIm per-pair core (pyani_amd/csrc/pg_anim_core.h) for development in the
+// GPU-less build container: reads two FASTA files, finds exact matches with a sorted 20-mer table on the CPU, then
+// runs the same MUM filter / clustering / extension / 1-to-1 filter / reduction functions the HIP kernels run.
+// NOT part of the product and NOT the oracle.   g++ -O2 -std=c++17 -I../../pyani_amd/csrc anim_debug.cpp -o anim_debug
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <string>
+#include <vector>
+#include "pg_anim_core.h"
+using namespace pga;
+
+struct Genome {
+  std::vector<uint32_t> codes, mask;
+  std::vector<int32_t> rec_start;  // stream position of each record's first base; last entry = stream length + 1
+  std::vector<std::string> ids;
+  int64_t len = 0;
+  SeqView view() const { return SeqView{codes.data(), mask.data(), len}; }
+};
+
+static Genome load(const char* path) {
+  Genome g;
+  std::ifstream in(path);
+  std::string line, seq;
+  std::vector<std::string> recs;
+  while (std::getline(in, line)) {
+    if (!line.empty() && line[0] == '>') { g.ids.push_back(line.substr(1, line.find_first_of(" \t\r") - 1)); recs.emplace_back(); }
+    else if (!recs.empty()) for (char c : line) if (c != ' ' && c != '\r' && c != '\n') recs.back().push_back(c);
+  }
+  std::string stream;
+  for (size_t r = 0; r < recs.size(); ++r) { if (r) stream.push_back('#'); g.rec_start.push_back((int32_t)stream.size()); stream += recs[r]; }
+  g.len = (int64_t)stream.size();
+  g.rec_start.push_back((int32_t)g.len + 1);
+  g.codes.assign(g.len / 16 + 2, 0); g.mask.assign(g.len / 32 + 2, 0);
+  for (int64_t p = 0; p < g.len; ++p) {
+    int c = -1;
+    switch (stream[p]) { case 'A': case 'a': c = 0; break; case 'C': case 'c': c = 1; break; case 'G': case 'g': c = 2; break; case 'T': case 't': c = 3; break; }
+    if (c >= 0) { g.codes[p >> 4] |= (uint32_t)c << (2 * (p & 15)); g.mask[p >> 5] |= 1u << (p & 31); }
+  }
+  return g;
+}
+
+// all maximal exact matches >= MIN_MATCH between ref and one query strand
+template <typename QV>
+static void find_mems(const Genome& G, const QV& Q, int strand, std::vector<Match>& out) {
+  const SeqView R = G.view();
+  const int K = MIN_MATCH;
+  std::vector<std::pair<uint64_t, int32_t>> tab;
+  auto kmer = [&](auto& S, int64_t p, uint64_t& v) { v = 0; for (int t = 0; t < K; ++t) { if (!S.clean(p + t)) return false; v = (v << 2) | (uint64_t)S.base(p + t); } return true; };
+  for (int64_t p = 0; p + K <= R.len; ++p) { uint64_t v; if (kmer(R, p, v)) tab.push_back({v, (int32_t)p}); }
+  std::sort(tab.begin(), tab.end());
+  for (int64_t q = 0; q + K <= Q.len(); ++q) {
+    uint64_t v;
+    if (!kmer(Q, q, v)) continue;
+    auto it = std::lower_bound(tab.begin(), tab.end(), std::make_pair(v, (int32_t)-1));
+    for (; it != tab.end() && it->first == v; ++it) {
+      const int64_t r = it->second;
+      if (R.clean(r - 1) && Q.clean(q - 1) && R.base(r - 1) == Q.base(q - 1)) continue;  // not left-maximal
+      int32_t L = K;
+      while (R.clean(r + L) && Q.clean(q + L) && R.base(r + L) == Q.base(q + L)) ++L;
+      out.push_back(Match{(int32_t)r, (int32_t)q, L, strand});
+    }
+  }
+}
+
+int main(int argc, char** argv) {
+  if (argc < 3) { fprintf(stderr, "usage: anim_debug ref.fna qry.fna [--dump]\n"); return 2; }
+  const bool dump = argc > 3 && !strcmp(argv[3], "--dump");
+  Genome G = load(argv[1]), H = load(argv[2]);
+  const SeqView R = G.view();
+  std::vector<Aln> alns;
+  std::vector<int32_t> a_rrec, a_qrec;
+  for (int strand = 0; strand < 2; ++strand) {
+    StrandView Q{H.view(), strand};
+    std::vector<Match> mem;
+    find_mems(G, Q, strand, mem);
+    int n = mum_filter(mem.data(), (int)mem.size(), strand);
+    mem.resize(n);
+    std::vector<int32_t> rrec(n), qrec(n), parent(n), score(n), from(n), adj(n), order(n);
+    const int nq = (int)H.rec_start.size() - 1;
+    for (int i = 0; i < n; ++i) {
+      rrec[i] = record_of(G.rec_start.data(), (int)G.rec_start.size() - 1, mem[i].r);
+      const int32_t qf = strand ? (int32_t)(H.len - 1 - mem[i].q) : mem[i].q;
+      qrec[i] = record_of(H.rec_start.data(), nq, qf);
+    }
+    std::vector<Chain> chains(n + 1);
+    std::vector<Match> cm(n + 1);
+    int n_chains = 0, n_cm = 0;
+    mgaps_strand(mem.data(), n, strand, rrec.data(), qrec.data(), parent.data(), score.data(), from.data(), adj.data(),
+                 order.data(), chains.data(), n_chains, (int)chains.size(), cm.data(), n_cm, (int)cm.size());
+    // order chains by first-match ref start; pick forward targets
+    std::vector<int32_t> co(n_chains);
+    for (int i = 0; i < n_chains; ++i) co[i] = i;
+    std::sort(co.begin(), co.end(), [&](int a, int b) { return cm[chains[a].first].r < cm[chains[b].first].r; });
+    std::vector<ChainFwd> fw(n_chains);
+    std::vector<ChainBwd> bw(n_chains);
+    std::vector<int32_t> prev_of(n_chains, -1), r_lo(n_chains), r_hi(n_chains), q_lo(n_chains), q_hi(n_chains);
+    for (int c = 0; c < n_chains; ++c) {
+      r_lo[c] = G.rec_start[chains[c].rrec]; r_hi[c] = G.rec_start[chains[c].rrec + 1] - 1;
+      q_lo[c] = H.rec_start[chains[c].qrec]; q_hi[c] = H.rec_start[chains[c].qrec + 1] - 1;
+      if (strand) { const int32_t a = (int32_t)H.len - q_hi[c], b = (int32_t)H.len - q_lo[c]; q_lo[c] = a; q_hi[c] = b; }
+      fw[c] = extend_chain_fwd(R, Q, cm.data(), chains[c], r_hi[c], q_hi[c]);
+    }
+    for (int k = 0; k < n_chains; ++k) {
+      const int c = co[k];
+      int p = -1;
+      for (int kk = k - 1; kk >= 0 && kk >= k - 8; --kk) {   // nearest preceding chain of the same records
+        const int t = co[kk];
+        if (chains[t].rrec == chains[c].rrec && chains[t].qrec == chains[c].qrec) { p = t; break; }
+      }
+      prev_of[c] = p;
+      bw[c] = extend_chain_bwd(R, Q, fw[c].first_r, fw[c].first_q, r_lo[c], q_lo[c], p >= 0 ? fw[p].re : -1, p >= 0 ? fw[p].qe : -1);
+    }
+    std::vector<int32_t> aln_of(n_chains + 1);
+    const int before = (int)alns.size();
+    alns.resize(before + n_chains);
+    const int after = stitch_chains(fw.data(), bw.data(), cm.data(), chains.data(), co.data(), prev_of.data(), n_chains, strand,
+                                    aln_of.data(), alns.data(), before, (int)alns.size());
+    alns.resize(after);
+    fprintf(stderr, "strand %d: MEMs->MUMs %d, chains %d, alignments %d\n", strand, n, n_chains, after - before);
+    for (int i = before; i < after; ++i) {
+      Aln& a = alns[i];
+      a_rrec.push_back(record_of(G.rec_start.data(), (int)G.rec_start.size() - 1, a.rs));
+      if (strand) { const int32_t qs = (int32_t)H.len - a.qe, qe = (int32_t)H.len - a.qs; a.qs = qs; a.qe = qe; }  // forward coords
+      a_qrec.push_back(record_of(H.rec_start.data(), nq, a.qs));
+    }
+  }
+  const int n = (int)alns.size();
+  std::vector<int32_t> idx(n + 1), from(n + 1);
+  std::vector<double> sc(n + 1);
+  const bool nofilter = argc > 3 && !strcmp(argv[3], "--nofilter");
+  if (nofilter) for (auto& a : alns) a.keep = 3;
+  else { lis_filter(alns.data(), n, 0, a_rrec.data(), idx.data(), sc.data(), from.data()); lis_filter(alns.data(), n, 1, a_qrec.data(), idx.data(), sc.data(), from.data()); }
+  PairResult pr = reduce_pair(alns.data(), n, a_rrec.data(), a_qrec.data(), idx.data());
+  printf("%lld %lld %.16g %lld %lld\n", (long long)pr.ref_aln_len, (long long)pr.qry_aln_len, (double)pr.weighted / (double)pr.aligned,
+         (long long)pr.sim_errors, (long long)pr.n_alignments);
+  if (dump)
+    for (int i = 0; i < n; ++i) {
+      const Aln& a = alns[i];
+      const int32_t ro = G.rec_start[a_rrec[i]], qo = H.rec_start[a_qrec[i]];
+      printf("ALN %s %s %d %d %d %d %d keep=%d\n", G.ids[a_rrec[i]].c_str(), H.ids[a_qrec[i]].c_str(), a.rs - ro + 1, a.re - ro,
+             a.strand ? a.qe - qo : a.qs - qo + 1, a.strand ? a.qs - qo + 1 : a.qe - qo, a.errors, a.keep);
+    }
+  return 0;
+}

@@ -189,5 +189,46 @@ def main():
     print("wrote", GOLD / "tetra_goldens.json", len(out), "entries")
 
 
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# ANIm: real MUMmer output held by the reference's tests (the only pin for the alignment search) + the reference's
+# known answers for parse_delta.  Run with:  python tools/make_goldens.py --anim-only
+def make_anim_goldens():
+    import tarfile
+    sys.path.insert(0, str(ROOT / "oracle"))
+    import anim_oracle
+    out_dir = GOLD / "anim"
+    tuples = {}
+
+    def store(src_bytes, rel):
+        dst = out_dir / (rel + ".gz")
+        dst.parent.mkdir(parents=True, exist_ok=True)
+        with open(dst, "wb") as raw:
+            with gzip.GzipFile(filename="", mode="wb", fileobj=raw, mtime=0, compresslevel=9) as fo:
+                fo.write(src_bytes)
+        tuples[rel] = list(anim_oracle.parse_delta(dst))
+
+    for d in sorted((REF / "tests/fixtures/anim/deltadir").iterdir()):
+        for f in sorted(d.glob("*_vs_*")):
+            if f.suffix in (".delta", ".filter"):
+                store(f.read_bytes(), f"caulobacter/{f.name}")
+    store((REF / "tests/fixtures/anim/test.delta").read_bytes(), "test.delta")
+    with tarfile.open(REF / "tests/test_targets/legacy_scripts/ANIm_mpl_Linux_3.1/nucmer_output.tar.gz") as tf:
+        for m in tf.getmembers():
+            if m.isfile() and m.name.endswith((".delta", ".filter")):
+                store(tf.extractfile(m).read(), f"blochmannia/{Path(m.name).name}")
+    shutil.copyfile(REF / "tests/fixtures/anim/dataframes/deltadir_result.csv", GOLD / "ref_targets" / "anim_deltadir_result.csv")
+    known = {"test.delta": [4016947, 4017751, 0.9994621994447228, 2191]}  # tests/test_anim.py:96-100
+    assert tuples["test.delta"] == known["test.delta"]
+    with open(GOLD / "anim_goldens.json", "w") as fh:
+        json.dump({"reference_known_answers": known, "parse_delta": tuples}, fh, indent=0, sort_keys=True)
+    print("wrote", GOLD / "anim_goldens.json", len(tuples), "files")
+
+
 if __name__ == "__main__":
-    main()
+    if "--anim-only" in sys.argv:
+        make_anim_goldens()
+    else:
+        main()
+        make_anim_goldens()
