@@ -122,6 +122,14 @@ typedef struct {
 int pg_anim_pairs(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_ids, uint64_t n_pairs, int maxmatch,
                   int filter_1to1, pg_anim_result* out);
 
+/* The reduction alone, on alignment records supplied by the caller (e.g. parsed from existing MUMmer .delta/.filter
+ * files — pyani's --recovery mode): replaces delta-filter -1 (apply_filter != 0; scripts/delta_filter_wrapper.py:70-93)
+ * and parse_delta (anim.py:292-411).  Pair p owns records [offsets[p], offsets[p+1]).  Coordinates are the 1-based
+ * closed MUMmer coordinates (qs > qe for reverse-strand hits); rseq / qseq are per-pair sequence (record) ordinals. */
+int pg_anim_reduce(pg_ctx* ctx, uint32_t n_pairs, const uint64_t* offsets, const int32_t* rseq, const int32_t* qseq,
+                   const int32_t* rs, const int32_t* re, const int32_t* qs, const int32_t* qe, const int32_t* errors,
+                   int apply_filter, pg_anim_result* out);
+
 /* ---- measurement ---------------------------------------------------------------------------------------- */
 /* When enabled, every kernel launch is bracketed by HIP events on the context's stream. */
 int pg_profile_enable(pg_ctx* ctx, int on);

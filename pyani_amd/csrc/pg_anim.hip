@@ -357,6 +357,29 @@ __global__ __launch_bounds__(64) void anim_finish_kernel(RefDesc R, const UnitDe
   out[p] = o;
 }
 
+// reduction of caller-supplied alignment records (pg_anim_reduce): one thread per pair
+__global__ __launch_bounds__(64) void anim_reduce_kernel(uint32_t n_pairs, const uint64_t* __restrict__ offsets, Aln* alns,
+                                                         const int32_t* __restrict__ rgrp, const int32_t* __restrict__ qgrp,
+                                                         int32_t* idx, int32_t* from, double* sc, int apply_filter,
+                                                         pg_anim_result* __restrict__ out) {
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_pairs) return;
+  const uint64_t o = offsets[p];
+  const int n = (int)(offsets[p + 1] - o);
+  if (apply_filter) {
+    lis_filter(alns + o, n, 0, rgrp + o, idx + o, sc + o, from + o);
+    lis_filter(alns + o, n, 1, qgrp + o, idx + o, sc + o, from + o);
+  }
+  const PairResult r = reduce_pair(alns + o, n, rgrp + o, qgrp + o, idx + o);
+  pg_anim_result res;
+  res.ref_aln_len = r.ref_aln_len; res.qry_aln_len = r.qry_aln_len; res.sim_errors = r.sim_errors;
+  res.n_alignments = r.n_alignments;
+  res.identity = r.aligned > 0 ? (double)r.weighted / (double)r.aligned : 0.0;
+  res.status = r.n_alignments == 0 ? PG_ANIM_NO_ALIGNMENT : 0;
+  res.reserved = 0;
+  out[p] = res;
+}
+
 template <typename T>
 int anim_alloc(pg_ctx* ctx, T*& p, size_t n) {
   PG_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&p), n * sizeof(T)));
@@ -480,5 +503,44 @@ int pg_anim_run_ref(pg_ctx* ctx, int32_t ref_id, const int32_t* qry_ids, uint32_
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
   cleanup();
   if (e != hipSuccess) return pg_fail(ctx, PG_E_HIP, std::string("anim pipeline: ") + hipGetErrorString(e));
+  return PG_OK;
+}
+
+int pg_anim_reduce_run(pg_ctx* ctx, uint32_t n_pairs, const uint64_t* offsets, const int32_t* rseq, const int32_t* qseq,
+                       const int32_t* rs, const int32_t* re, const int32_t* qs, const int32_t* qe, const int32_t* errors,
+                       int apply_filter, pg_anim_result* out) {
+  const uint64_t n = offsets[n_pairs];
+  std::vector<Aln> h(n);
+  for (uint64_t i = 0; i < n; ++i) {
+    Aln a;
+    a.strand = qs[i] > qe[i];
+    a.rs = (rs[i] < re[i] ? rs[i] : re[i]) - 1; a.re = rs[i] < re[i] ? re[i] : rs[i];
+    a.qs = (qs[i] < qe[i] ? qs[i] : qe[i]) - 1; a.qe = qs[i] < qe[i] ? qe[i] : qs[i];
+    a.errors = errors[i];
+    a.keep = apply_filter ? 0 : 3;
+    h[i] = a;
+  }
+  uint64_t* d_off = nullptr; Aln* d_a = nullptr; int32_t *d_rg = nullptr, *d_qg = nullptr, *d_idx = nullptr, *d_from = nullptr;
+  double* d_sc = nullptr; pg_anim_result* d_out = nullptr;
+  std::vector<void*> to_free;
+  auto cleanup = [&]() { for (void* p : to_free) if (p) (void)hipFree(p); };
+  int rc;
+#define AA(ptr, cnt) do { if ((rc = anim_alloc(ctx, ptr, (cnt)))) { cleanup(); return rc; } to_free.push_back(ptr); } while (0)
+  AA(d_off, n_pairs + 1); AA(d_a, n + 1); AA(d_rg, n + 1); AA(d_qg, n + 1); AA(d_idx, n + 1); AA(d_from, n + 1); AA(d_sc, n + 1);
+  AA(d_out, n_pairs + 1);
+#undef AA
+  hipError_t e = hipMemcpyAsync(d_off, offsets, (n_pairs + 1) * 8, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess && n) e = hipMemcpyAsync(d_a, h.data(), n * sizeof(Aln), hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess && n) e = hipMemcpyAsync(d_rg, rseq, n * 4, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess && n) e = hipMemcpyAsync(d_qg, qseq, n * 4, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(anim_reduce_kernel, dim3((n_pairs + 63) / 64), dim3(64), 0, ctx->stream, n_pairs, d_off, d_a, d_rg, d_qg,
+                       d_idx, d_from, d_sc, apply_filter, d_out);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, n_pairs * sizeof(pg_anim_result), hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  cleanup();
+  if (e != hipSuccess) return pg_fail(ctx, PG_E_HIP, std::string("anim reduce: ") + hipGetErrorString(e));
   return PG_OK;
 }

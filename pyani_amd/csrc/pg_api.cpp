@@ -639,6 +639,18 @@ int pg_anim_pairs(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_ids, u
   return PG_OK;
 }
 
+int pg_anim_reduce(pg_ctx* ctx, uint32_t n_pairs, const uint64_t* offsets, const int32_t* rseq, const int32_t* qseq,
+                   const int32_t* rs, const int32_t* re, const int32_t* qs, const int32_t* qe, const int32_t* errors,
+                   int apply_filter, pg_anim_result* out) {
+  if (!ctx || !offsets || (n_pairs && !out)) return pg_fail(ctx, PG_E_ARG, "bad argument");
+  if (offsets[n_pairs] && (!rseq || !qseq || !rs || !re || !qs || !qe || !errors)) return pg_fail(ctx, PG_E_ARG, "bad argument");
+  for (uint32_t p = 0; p < n_pairs; ++p)
+    if (offsets[p + 1] < offsets[p]) return pg_fail(ctx, PG_E_ARG, "offsets must be non-decreasing");
+  PG_HIP(ctx, hipSetDevice(ctx->device));
+  if (n_pairs == 0) return PG_OK;
+  return pg_anim_reduce_run(ctx, n_pairs, offsets, rseq, qseq, rs, re, qs, qe, errors, apply_filter, out);
+}
+
 // ---- measurement -----------------------------------------------------------------------------------------------
 int pg_profile_enable(pg_ctx* ctx, int on) {
   if (!ctx) return PG_E_ARG;

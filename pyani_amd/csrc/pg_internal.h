@@ -103,5 +103,8 @@ int pg_launch_tetra_stats(pg_ctx* ctx, const double* d_z, const uint8_t* d_prese
 int pg_launch_tetra_pairs(pg_ctx* ctx, uint32_t n, uint32_t row0, uint32_t nrows, double* d_out, bool mirror);
 
 // ANIm (pg_anim.hip): all pairs sharing one reference genome
+int pg_anim_reduce_run(pg_ctx* ctx, uint32_t n_pairs, const uint64_t* offsets, const int32_t* rseq, const int32_t* qseq,
+                       const int32_t* rs, const int32_t* re, const int32_t* qs, const int32_t* qe, const int32_t* errors,
+                       int apply_filter, pg_anim_result* out);
 int pg_anim_run_ref(pg_ctx* ctx, int32_t ref_id, const int32_t* qry_ids, uint32_t n_pairs, int filter_1to1,
                     pg_anim_result* out_host);

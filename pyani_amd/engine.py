@@ -162,6 +162,19 @@ class Engine:
                                            out.ctypes.data))
         return out
 
+    def anim_reduce(self, pairs, apply_filter: bool = False) -> np.ndarray:
+        """pairs: list of per-pair record lists [(rseq, qseq, rs, re, qs, qe, errors), ...] in MUMmer coordinates
+        (1-based closed, qs > qe on the reverse strand; rseq/qseq = sequence ordinals within the pair)."""
+        offsets = np.zeros(len(pairs) + 1, dtype=np.uint64)
+        for k, recs in enumerate(pairs):
+            offsets[k + 1] = offsets[k] + len(recs)
+        flat = np.array([r for recs in pairs for r in recs], dtype=np.int32).reshape(-1, 7)
+        cols = [np.ascontiguousarray(flat[:, c]) for c in range(7)]
+        out = np.zeros(len(pairs), dtype=self.ANIM_DTYPE)
+        self._check(self.lib.pg_anim_reduce(self._h, len(pairs), offsets.ctypes.data, *(c.ctypes.data for c in cols),
+                                            int(apply_filter), out.ctypes.data))
+        return out
+
     # -- measurement ----------------------------------------------------------------------------------------------
     def profile_enable(self, on: bool = True):
         self._check(self.lib.pg_profile_enable(self._h, int(on)))
