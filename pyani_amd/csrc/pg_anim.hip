@@ -116,6 +116,7 @@ struct ClusterOut {
   int32_t* n_chains;    // [U]
   int32_t* order;       // [U][cap_c] chains sorted by first-match ref start
   int32_t* prev_of;     // [U][cap_c]
+  int32_t* next_of;     // [U][cap_c]
   int32_t* status;      // [P]
 };
 
@@ -144,18 +145,9 @@ __global__ __launch_bounds__(64) void anim_cluster_kernel(RefDesc R, const UnitD
   Match* cm = O.cm + (size_t)u * cap_m;
   mgaps_strand(m, n, U.strand, rrec, qrec, parent, score, from, adj, order, chains, n_chains, (int)cap_c, cm, n_cm, (int)cap_m);
   int32_t* co = O.order + (size_t)u * cap_c;
-  int32_t* prev_of = O.prev_of + (size_t)u * cap_c;
   for (int i = 0; i < n_chains; ++i) co[i] = i;
   heapsort(co, n_chains, [&](int a, int b) { return cm[chains[a].first].r < cm[chains[b].first].r; });
-  for (int k = 0; k < n_chains; ++k) {
-    const int c = co[k];
-    int p = -1;
-    for (int kk = k - 1; kk >= 0 && kk >= k - 8; --kk) {   // nearest preceding chain of the same records
-      const int t = co[kk];
-      if (chains[t].rrec == chains[c].rrec && chains[t].qrec == chains[c].qrec) { p = t; break; }
-    }
-    prev_of[c] = p;
-  }
+  chain_neighbours(chains, co, n_chains, O.prev_of + (size_t)u * cap_c, O.next_of + (size_t)u * cap_c);
   O.n_chains[u] = n_chains;
 }
 
@@ -184,10 +176,31 @@ __device__ __forceinline__ long long wave_max64(long long v) {
   return v;
 }
 
+// LDS staging of the two sequences for one wave: base codes (0-3, 4 = dirty / out of range) of consumed indices
+// t = 0, 1, 2, ... in a 256-entry ring.  Cell (i, j) compares ring_r[i-1] with ring_q[j-1]; on anti-diagonal d every lane
+// needs indices within [d/2 - 17, d/2 + 15], so the ring is topped up 64 entries at a time, one base per lane.
+struct WaveSeq {
+  uint8_t* ring_r;
+  uint8_t* ring_q;
+  int32_t loaded;  // indices [0, loaded) have been staged (uniform)
+};
+
+__device__ __forceinline__ void wave_seq_fill(WaveSeq& ws, const SeqView& R, const StrandView& Q, int64_t r0, int64_t q0, int dir,
+                                              int32_t rmax, int32_t qmax, int lane) {
+  const int32_t t = ws.loaded + lane;
+  uint8_t rb = 4, qb = 4;
+  if (t < rmax) { const int64_t rp = dir > 0 ? r0 + t : r0 - 1 - t; if (R.clean(rp)) rb = (uint8_t)R.base(rp); }
+  if (t < qmax) { const int64_t qp = dir > 0 ? q0 + t : q0 - 1 - t; if (Q.clean(qp)) qb = (uint8_t)Q.base(qp); }
+  ws.ring_r[t & 255] = rb;
+  ws.ring_q[t & 255] = qb;
+  ws.loaded += 64;
+}
+
 __device__ ExtResult extend_wave(const SeqView& R, const StrandView& Q, int64_t r0, int64_t q0, int dir, int32_t rmax,
                                  int32_t qmax, int32_t tr, int32_t tq) {
   constexpr int W = BAND / 2;
   static_assert(BAND == 64, "one lane per diagonal");
+  __shared__ uint8_t s_ring[2][256];
   const int lane = threadIdx.x & 63, k = lane - W;
   DpCell cur{NEG_INF, 0, NEG_INF, 0, NEG_INF, 0};
   int32_t bs = NEG_INF, bd = 0, be = 0;
@@ -198,7 +211,16 @@ __device__ ExtResult extend_wave(const SeqView& R, const StrandView& Q, int64_t 
   if (targeted && tr == 0 && tq == 0) { res.reached = 1; return res; }
   const int32_t d_end = targeted ? tr + tq : rmax + qmax;
   constexpr long long BIAS = 1ll << 30;
+  WaveSeq ws{s_ring[0], s_ring[1], 0};
+  __syncthreads();  // previous user of the ring (same wave) is done
+  wave_seq_fill(ws, R, Q, r0, q0, dir, rmax, qmax, lane);
+  wave_seq_fill(ws, R, Q, r0, q0, dir, rmax, qmax, lane);
+  __syncthreads();
   for (int32_t d = 1; d <= d_end; ++d) {
+    if ((d >> 1) + 20 > ws.loaded) {   // uniform
+      wave_seq_fill(ws, R, Q, r0, q0, dir, rmax, qmax, lane);
+      __syncthreads();
+    }
     const int32_t up_h = from_lane_above(cur.h, NEG_INF), up_he = from_lane_above(cur.he, 0);
     const int32_t up_x = from_lane_above(cur.x, NEG_INF), up_xe = from_lane_above(cur.xe, 0);
     const int32_t lf_h = from_lane_below(cur.h, NEG_INF), lf_he = from_lane_below(cur.he, 0);
@@ -211,8 +233,8 @@ __device__ ExtResult extend_wave(const SeqView& R, const StrandView& Q, int64_t 
         const bool has_up = i >= 1 && lane + 1 < BAND, has_left = j >= 1 && lane >= 1, has_diag = i >= 1 && j >= 1;
         bool ok = false;
         if (has_diag) {
-          const int64_t rp = dir > 0 ? r0 + (i - 1) : r0 - i, qp = dir > 0 ? q0 + (j - 1) : q0 - j;
-          ok = R.clean(rp) && Q.clean(qp) && R.base(rp) == Q.base(qp);
+          const uint8_t rb = ws.ring_r[(i - 1) & 255], qb = ws.ring_q[(j - 1) & 255];
+          ok = rb == qb && rb < 4;
         }
         cur = dp_cell(has_up, up_h, up_he, up_x, up_xe, has_left, lf_h, lf_he, lf_y, lf_ye, has_diag, cur.h, cur.he, ok);
         if (cur.h > NEG_INF / 2 && (cur.h > bs || (cur.h == bs && d >= bd))) { bs = cur.h; bd = d; be = cur.he; }
@@ -286,15 +308,35 @@ __global__ __launch_bounds__(64) void anim_extend_kernel(RefDesc R, const UnitDe
       er = t.r + t.len; eq = t.q + t.len;
     }
     e.inner_err = inner;
-    const ExtResult x = extend_wave(RV, QV, er, eq, +1, r_hi - er, q_hi - eq, -1, -1);
+    e.lr = er; e.lq = eq;
+    const int32_t nx = O.next_of[(size_t)u * cap_c + c];
+    int32_t tr = -1, tq = -1;
+    if (nx >= 0) {
+      const Match nf = cm[O.chains[(size_t)u * cap_c + nx].first];
+      forward_target(er, eq, nf.r, nf.q, nf.len, tr, tq);
+    }
+    const ExtResult x = extend_wave(RV, QV, er, eq, +1, r_hi - er, q_hi - eq, tr, tq);
     e.re = er + x.di; e.qe = eq + x.dj; e.err_fwd = x.errors;
+    e.reached = (tr >= 0 && x.reached) ? 1 : 0;
     if ((threadIdx.x & 63) == 0) fwu[c] = e;
   } else {
     const int32_t p = O.prev_of[(size_t)u * cap_c + c];
     const int32_t first_r = fwu[c].first_r, first_q = fwu[c].first_q;
     const int32_t prev_re = p >= 0 ? fwu[p].re : -1, prev_qe = p >= 0 ? fwu[p].qe : -1;
+    if (p >= 0 && ((fwu[p].reached && O.next_of[(size_t)u * cap_c + p] == c) ||
+                   (fwu[p].first_r <= first_r && fwu[p].first_q <= first_q && prev_re >= fwu[c].lr && prev_qe >= fwu[c].lq))) {
+      if ((threadIdx.x & 63) == 0) bw[(size_t)u * cap_c + c] = ChainBwd{first_r, first_q, 0, 0};  // will be shadowed
+      return;
+    }
     int32_t tr = -1, tq = -1;
     if (prev_re >= 0 && first_r >= prev_re && first_q >= prev_qe) { tr = first_r - prev_re; tq = first_q - prev_qe; }
+    if (p >= 0) {   // never search into the previous chain's matches (same rule as pga::extend_chain_bwd)
+      const int32_t plr = fwu[p].lr, plq = fwu[p].lq;
+      if (plr <= first_r && plq <= first_q) {   // collinear predecessor only
+        if (plr > r_lo) r_lo = plr;
+        if (plq > q_lo) q_lo = plq;
+      }
+    }
     const ExtResult b = extend_wave(RV, QV, first_r, first_q, -1, first_r - r_lo, first_q - q_lo, tr, tq);
     ChainBwd e;
     e.rs = first_r - b.di; e.qs = first_q - b.dj; e.err_back = b.errors;
@@ -331,7 +373,7 @@ __global__ __launch_bounds__(64) void anim_finish_kernel(RefDesc R, const UnitDe
     const UnitDesc U = units[u];
     const int before = n;
     n = stitch_chains(fw + (size_t)u * cap_c, bw + (size_t)u * cap_c, O.cm + (size_t)u * cap_m, O.chains + (size_t)u * cap_c,
-                      O.order + (size_t)u * cap_c, O.prev_of + (size_t)u * cap_c, O.n_chains[u], strand,
+                      O.order + (size_t)u * cap_c, O.prev_of + (size_t)u * cap_c, O.next_of + (size_t)u * cap_c, O.n_chains[u], strand,
                       S.aln_of + (size_t)u * cap_c, alns, n, (int)cap_a);
     for (int i = before; i < n; ++i) {
       Aln& a = alns[i];
@@ -409,7 +451,8 @@ int pg_anim_run_ref(pg_ctx* ctx, int32_t ref_id, const int32_t* qry_ids, uint32_
   UnitDesc* d_units = nullptr;
   Match *d_mem = nullptr, *d_cm = nullptr;
   uint32_t* d_mem_count = nullptr;
-  int32_t *d_iscratch = nullptr, *d_nch = nullptr, *d_order = nullptr, *d_prev = nullptr, *d_status = nullptr, *d_alnof = nullptr;
+  int32_t *d_iscratch = nullptr, *d_nch = nullptr, *d_order = nullptr, *d_prev = nullptr, *d_next = nullptr, *d_status = nullptr,
+          *d_alnof = nullptr;
   Chain* d_chains = nullptr;
   ChainFwd* d_fw = nullptr;
   ChainBwd* d_bw = nullptr;
@@ -458,6 +501,7 @@ int pg_anim_run_ref(pg_ctx* ctx, int32_t ref_id, const int32_t* qry_ids, uint32_
   AA(d_nch, n_units);
   AA(d_order, (size_t)n_units * CAP_C);
   AA(d_prev, (size_t)n_units * CAP_C);
+  AA(d_next, (size_t)n_units * CAP_C);
   AA(d_alnof, (size_t)n_units * CAP_C);
   AA(d_status, n_pairs);
   AA(d_fw, (size_t)n_units * CAP_C);
@@ -474,7 +518,7 @@ int pg_anim_run_ref(pg_ctx* ctx, int32_t ref_id, const int32_t* qry_ids, uint32_
   PG_HIP(ctx, hipMemsetAsync(d_table, 0xFF, ((size_t)R.table_mask + 1) * 8, ctx->stream));
   PG_HIP(ctx, hipMemsetAsync(d_mem_count, 0, n_units * 4, ctx->stream));
   PG_HIP(ctx, hipMemsetAsync(d_status, 0, n_pairs * 4, ctx->stream));
-  ClusterOut O{d_cm, d_chains, d_nch, d_order, d_prev, d_status};
+  ClusterOut O{d_cm, d_chains, d_nch, d_order, d_prev, d_next, d_status};
   hipLaunchKernelGGL(anim_index_kernel, dim3((R.len + 255) / 256), dim3(256), 0, ctx->stream, R);
   hipLaunchKernelGGL(anim_seed_kernel, dim3((max_qlen + 255) / 256, n_units), dim3(256), 0, ctx->stream, R, d_units, d_mem,
                      d_mem_count, CAP_M);

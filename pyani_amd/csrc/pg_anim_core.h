@@ -347,23 +347,38 @@ PG_HD void mgaps_strand(const Match* m, int n, int strand, const int32_t* rrec_o
 // preceding alignment as a target — if the target cell is reached before the break criterion fires, the two are
 // fused into one alignment (this is how nucmer bridges ~100-base junk between two clusters), otherwise the chain
 // starts a new alignment at its own best backward cell.
+// nearest preceding / following chain of the same (ref record, query record) in ref order (looks 8 entries each way)
+PG_HD void chain_neighbours(const Chain* chains, const int32_t* order, int n, int32_t* prev_of, int32_t* next_of) {
+  for (int k = 0; k < n; ++k) {
+    const int c = order[k];
+    int p = -1, q = -1;
+    for (int kk = k - 1; kk >= 0 && kk >= k - 8 && p < 0; --kk)
+      if (chains[order[kk]].rrec == chains[c].rrec && chains[order[kk]].qrec == chains[c].qrec) p = order[kk];
+    for (int kk = k + 1; kk < n && kk <= k + 8 && q < 0; ++kk)
+      if (chains[order[kk]].rrec == chains[c].rrec && chains[order[kk]].qrec == chains[c].qrec) q = order[kk];
+    prev_of[c] = p;
+    next_of[c] = q;
+  }
+}
+
 struct ChainFwd {
   int32_t first_r, first_q;     // first match start
   int32_t inner_err;            // errors of the gaps between chained matches
-  int32_t re, qe, err_fwd;      // end after the free forward extension
+  int32_t lr, lq;               // end of the last chained match
+  int32_t re, qe, err_fwd;      // end after the forward extension (== next chain's first match when reached)
+  int32_t reached;              // forward extension landed exactly on the next chain's first match -> fuse
 };
 struct ChainBwd {
   int32_t rs, qs, err_back;     // start after the backward extension (== target cell when reached)
   int32_t reached;              // landed exactly on the previous chain's forward end -> fuse
 };
 
+// Gap fills between the chained matches; returns the end of the last match through er/eq.
 template <typename RefT, typename QryT>
-PG_HD ChainFwd extend_chain_fwd(const RefT& R, const QryT& Q, const Match* cm, const Chain& c, int32_t r_hi, int32_t q_hi) {
-  ChainFwd e;
+PG_HD int32_t chain_inner_errors(const RefT& R, const QryT& Q, const Match* cm, const Chain& c, int32_t& er, int32_t& eq) {
   const Match& f = cm[c.first];
-  e.first_r = f.r; e.first_q = f.q;
   int32_t inner = 0;
-  int32_t er = f.r + f.len, eq = f.q + f.len;
+  er = f.r + f.len; eq = f.q + f.len;
   for (int k = 1; k < c.count; ++k) {
     Match t = cm[c.first + k];
     int32_t trim = er - t.r;                 // chained matches may still overlap the running end
@@ -373,18 +388,60 @@ PG_HD ChainFwd extend_chain_fwd(const RefT& R, const QryT& Q, const Match* cm, c
     inner += gap_errors(R, Q, er, t.r - er, eq, t.q - eq);
     er = t.r + t.len; eq = t.q + t.len;
   }
-  e.inner_err = inner;
-  const ExtResult fw = extend_banded(R, Q, er, eq, +1, r_hi - er, q_hi - eq, -1, -1);
+  return inner;
+}
+
+// Forward target of a chain that ends at (er, eq): the first match (nr, nq, nlen) of the following chain.  If that match
+// starts before the end (overlapping matches around a small indel) it is trimmed, as postnuc trims overlapping matches.
+PG_HD void forward_target(int32_t er, int32_t eq, int32_t nr, int32_t nq, int32_t nlen, int32_t& tr, int32_t& tq) {
+  tr = -1; tq = -1;
+  if (nr < 0) return;
+  int32_t t = er - nr;
+  if (eq - nq > t) t = eq - nq;
+  if (t < 0) t = 0;
+  if (t >= nlen) return;
+  tr = nr + t - er; tq = nq + t - eq;
+}
+
+// next_*: first match of the following chain (same strand and records), next_r = -1 if there is none.
+template <typename RefT, typename QryT>
+PG_HD ChainFwd extend_chain_fwd(const RefT& R, const QryT& Q, const Match* cm, const Chain& c, int32_t r_hi, int32_t q_hi,
+                                int32_t next_r, int32_t next_q, int32_t next_len) {
+  ChainFwd e;
+  e.first_r = cm[c.first].r; e.first_q = cm[c.first].q;
+  int32_t er, eq;
+  e.inner_err = chain_inner_errors(R, Q, cm, c, er, eq);
+  e.lr = er; e.lq = eq;
+  int32_t tr, tq;
+  forward_target(er, eq, next_r, next_q, next_len, tr, tq);
+  const ExtResult fw = extend_banded(R, Q, er, eq, +1, r_hi - er, q_hi - eq, tr, tq);
   e.re = er + fw.di; e.qe = eq + fw.dj; e.err_fwd = fw.errors;
+  e.reached = (tr >= 0 && fw.reached) ? 1 : 0;
   return e;
 }
 
-// prev_re/prev_qe: forward end of the preceding chain (same strand and records), or -1 if there is none.
+// prev_re/prev_qe: forward end of the preceding chain (same strand and records), or -1 if there is none;
+// prev_lr/prev_lq: end of its last match — the backward search never needs to enter the previous chain's matches;
+// prev_fr/prev_fq: its first match start; my_lr/my_lq: end of THIS chain's last match.  If the previous chain's span
+// already covers this chain entirely, the stitch will shadow it and no backward search is needed at all.
 template <typename RefT, typename QryT>
 PG_HD ChainBwd extend_chain_bwd(const RefT& R, const QryT& Q, int32_t first_r, int32_t first_q, int32_t r_lo, int32_t q_lo,
-                                int32_t prev_re, int32_t prev_qe) {
+                                int32_t prev_re, int32_t prev_qe, int32_t prev_lr, int32_t prev_lq, int32_t prev_fr,
+                                int32_t prev_fq, int32_t my_lr, int32_t my_lq, bool prev_reached_me) {
+  // no search needed: the previous chain's forward extension already landed on this chain's first match (fusion),
+  // or its span covers this chain entirely (the stitch will shadow it)
+  if (prev_reached_me ||
+      (prev_re >= 0 && prev_fr <= first_r && prev_fq <= first_q && prev_re >= my_lr && prev_qe >= my_lq)) {
+    ChainBwd e;
+    e.rs = first_r; e.qs = first_q; e.err_back = 0; e.reached = 0;
+    return e;
+  }
   int32_t tr = -1, tq = -1;
   if (prev_re >= 0 && first_r >= prev_re && first_q >= prev_qe) { tr = first_r - prev_re; tq = first_q - prev_qe; }
+  if (prev_re >= 0 && prev_lr <= first_r && prev_lq <= first_q) {   // collinear predecessor only
+    if (prev_lr > r_lo) r_lo = prev_lr;
+    if (prev_lq > q_lo) q_lo = prev_lq;
+  }
   const ExtResult b = extend_banded(R, Q, first_r, first_q, -1, first_r - r_lo, first_q - q_lo, tr, tq);
   ChainBwd e;
   e.rs = first_r - b.di; e.qs = first_q - b.dj; e.err_back = b.errors;
@@ -392,34 +449,50 @@ PG_HD ChainBwd extend_chain_bwd(const RefT& R, const QryT& Q, int32_t first_r, i
   return e;
 }
 
-// Sequential stitch of one strand's chains (order[] = sorted by first-match ref start).  prev_of[c] = the chain whose
-// forward end was c's backward target (or -1).  Chains lying inside an existing alignment are shadowed.
+// Sequential stitch of one strand's chains (order[] = sorted by first-match ref start).  prev_of / next_of: the
+// neighbouring chains of the same records in that order (or -1).  A chain is fused into the running alignment when
+// the previous chain's forward extension reached its first match, or when its own backward extension reached the
+// previous chain's forward end; chains lying inside an existing alignment are shadowed.
 PG_HD int stitch_chains(const ChainFwd* fw, const ChainBwd* bw, const Match* cm, const Chain* chains, const int32_t* order,
-                        const int32_t* prev_of, int n, int strand, int32_t* aln_of, Aln* out, int n_out, int max_out) {
+                        const int32_t* prev_of, const int32_t* next_of, int n, int strand, int32_t* aln_of, Aln* out, int n_out,
+                        int max_out) {
   const int out0 = n_out;
+  for (int k = 0; k < n; ++k) aln_of[order[k]] = -1;
   for (int k = 0; k < n; ++k) {
     const int c = order[k];
-    aln_of[c] = -1;
+    if (aln_of[c] >= 0) continue;                       // already fused forward into an earlier alignment
     const Match& l = cm[chains[c].first + chains[c].count - 1];
     const int p = prev_of[c];
+    int ai = -1;
     if (p >= 0 && bw[c].reached && aln_of[p] >= 0 && out[aln_of[p]].re == fw[p].re && out[aln_of[p]].qe == fw[p].qe) {
-      Aln& a = out[aln_of[p]];               // fuse: bridge errors + this chain's inner + forward extension
-      a.errors += bw[c].err_back + fw[c].inner_err + fw[c].err_fwd;
-      a.re = fw[c].re; a.qe = fw[c].qe;
-      aln_of[c] = aln_of[p];
-      continue;
+      ai = aln_of[p];                                    // bridge the junk between the two chains
+      out[ai].errors += bw[c].err_back + fw[c].inner_err;
+    } else {
+      bool shadow = false;
+      for (int t = out0; t < n_out && !shadow; ++t)
+        if (fw[c].first_r >= out[t].rs && l.r + l.len <= out[t].re && fw[c].first_q >= out[t].qs && l.q + l.len <= out[t].qe) {
+          shadow = true;
+          aln_of[c] = t;
+        }
+      if (shadow) continue;
+      if (n_out >= max_out) continue;
+      Aln a;
+      a.rs = bw[c].rs; a.qs = bw[c].qs; a.re = a.rs; a.qe = a.qs; a.strand = strand; a.keep = 0;
+      a.errors = bw[c].err_back + fw[c].inner_err;
+      ai = n_out;
+      out[n_out++] = a;
     }
-    bool shadow = false;
-    for (int t = out0; t < n_out && !shadow; ++t)
-      if (fw[c].first_r >= out[t].rs && l.r + l.len <= out[t].re && fw[c].first_q >= out[t].qs && l.q + l.len <= out[t].qe) {
-        shadow = true;
-        aln_of[c] = t;   // a later chain whose backward target was this chain's end fuses with the shadowing alignment
-      }
-    if (shadow) continue;
-    Aln a;
-    a.rs = bw[c].rs; a.qs = bw[c].qs; a.re = fw[c].re; a.qe = fw[c].qe; a.strand = strand; a.keep = 0;
-    a.errors = bw[c].err_back + fw[c].inner_err + fw[c].err_fwd;
-    if (n_out < max_out) { aln_of[c] = n_out; out[n_out++] = a; }
+    int cur = c;
+    for (;;) {
+      out[ai].errors += fw[cur].err_fwd;
+      out[ai].re = fw[cur].re; out[ai].qe = fw[cur].qe;
+      aln_of[cur] = ai;
+      if (!fw[cur].reached) break;
+      const int t = next_of[cur];
+      if (t < 0 || aln_of[t] >= 0) break;
+      out[ai].errors += fw[t].inner_err;
+      cur = t;
+    }
   }
   return n_out;
 }

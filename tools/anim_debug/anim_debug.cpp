@@ -3,6 +3,7 @@
 // runs the same MUM filter / clustering / extension / 1-to-1 filter / reduction functions the HIP kernels run.
 // NOT part of the product and NOT the oracle.   g++ -O2 -std=c++17 -I../../pyani_amd/csrc anim_debug.cpp -o anim_debug
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -96,27 +97,33 @@ int main(int argc, char** argv) {
     std::sort(co.begin(), co.end(), [&](int a, int b) { return cm[chains[a].first].r < cm[chains[b].first].r; });
     std::vector<ChainFwd> fw(n_chains);
     std::vector<ChainBwd> bw(n_chains);
-    std::vector<int32_t> prev_of(n_chains, -1), r_lo(n_chains), r_hi(n_chains), q_lo(n_chains), q_hi(n_chains);
+    std::vector<int32_t> prev_of(n_chains, -1), next_of(n_chains, -1), r_lo(n_chains), r_hi(n_chains), q_lo(n_chains), q_hi(n_chains);
+    chain_neighbours(chains.data(), co.data(), n_chains, prev_of.data(), next_of.data());
     for (int c = 0; c < n_chains; ++c) {
       r_lo[c] = G.rec_start[chains[c].rrec]; r_hi[c] = G.rec_start[chains[c].rrec + 1] - 1;
       q_lo[c] = H.rec_start[chains[c].qrec]; q_hi[c] = H.rec_start[chains[c].qrec + 1] - 1;
       if (strand) { const int32_t a = (int32_t)H.len - q_hi[c], b = (int32_t)H.len - q_lo[c]; q_lo[c] = a; q_hi[c] = b; }
-      fw[c] = extend_chain_fwd(R, Q, cm.data(), chains[c], r_hi[c], q_hi[c]);
+      const int t = next_of[c];
+      auto t0 = std::chrono::steady_clock::now();
+      fw[c] = extend_chain_fwd(R, Q, cm.data(), chains[c], r_hi[c], q_hi[c], t >= 0 ? cm[chains[t].first].r : -1,
+                               t >= 0 ? cm[chains[t].first].q : -1, t >= 0 ? cm[chains[t].first].len : 0);
+      double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      if (ms > 20 && getenv("ANIM_TIMING")) fprintf(stderr, "FWD chain %d strand %d: %.0f ms, matches %d, first r %d q %d, last end r %d q %d -> re %d qe %d reached %d next %d\n", c, strand, ms, chains[c].count, fw[c].first_r, fw[c].first_q, fw[c].lr, fw[c].lq, fw[c].re, fw[c].qe, fw[c].reached, t);
     }
     for (int k = 0; k < n_chains; ++k) {
       const int c = co[k];
-      int p = -1;
-      for (int kk = k - 1; kk >= 0 && kk >= k - 8; --kk) {   // nearest preceding chain of the same records
-        const int t = co[kk];
-        if (chains[t].rrec == chains[c].rrec && chains[t].qrec == chains[c].qrec) { p = t; break; }
-      }
-      prev_of[c] = p;
-      bw[c] = extend_chain_bwd(R, Q, fw[c].first_r, fw[c].first_q, r_lo[c], q_lo[c], p >= 0 ? fw[p].re : -1, p >= 0 ? fw[p].qe : -1);
+      const int p = prev_of[c];
+      auto t0 = std::chrono::steady_clock::now();
+      bw[c] = extend_chain_bwd(R, Q, fw[c].first_r, fw[c].first_q, r_lo[c], q_lo[c], p >= 0 ? fw[p].re : -1, p >= 0 ? fw[p].qe : -1, p >= 0 ? fw[p].lr : -1, p >= 0 ? fw[p].lq : -1,
+                               p >= 0 ? fw[p].first_r : -1, p >= 0 ? fw[p].first_q : -1, fw[c].lr, fw[c].lq,
+                               p >= 0 && fw[p].reached && next_of[p] == c);
+      double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      if (ms > 20 && getenv("ANIM_TIMING")) fprintf(stderr, "BWD chain %d strand %d: %.0f ms first r %d q %d -> rs %d qs %d reached %d prev %d (prev re %d qe %d lr %d lq %d)\n", c, strand, ms, fw[c].first_r, fw[c].first_q, bw[c].rs, bw[c].qs, bw[c].reached, p, p>=0?fw[p].re:-1, p>=0?fw[p].qe:-1, p>=0?fw[p].lr:-1, p>=0?fw[p].lq:-1);
     }
     std::vector<int32_t> aln_of(n_chains + 1);
     const int before = (int)alns.size();
     alns.resize(before + n_chains);
-    const int after = stitch_chains(fw.data(), bw.data(), cm.data(), chains.data(), co.data(), prev_of.data(), n_chains, strand,
+    const int after = stitch_chains(fw.data(), bw.data(), cm.data(), chains.data(), co.data(), prev_of.data(), next_of.data(), n_chains, strand,
                                     aln_of.data(), alns.data(), before, (int)alns.size());
     alns.resize(after);
     fprintf(stderr, "strand %d: MEMs->MUMs %d, chains %d, alignments %d\n", strand, n, n_chains, after - before);
