@@ -40,6 +40,7 @@ struct UnitDesc {   // one (pair, query strand)
   int32_t n_rec;
   int32_t strand;
   int32_t pair;  // index into the batch's pair list
+  int32_t ref;   // index into the batch's reference list
 };
 
 __device__ __forceinline__ uint64_t mix40(uint64_t k) {
@@ -62,13 +63,25 @@ __device__ __forceinline__ bool kmer_at(const uint32_t* __restrict__ codes, cons
   return true;
 }
 
+// 16 bases starting at stream position p (p + 16 <= len): codes in 32 bits (first base low), clean bits in 16
+__device__ __forceinline__ void get16(const uint32_t* __restrict__ codes, const uint32_t* __restrict__ mask, int32_t p,
+                                      uint32_t& c, uint32_t& m) {
+  const uint32_t cw = p >> 4, cs = 2 * (p & 15);
+  const uint64_t lo = (uint64_t)codes[cw] | ((uint64_t)codes[cw + 1] << 32);
+  c = (uint32_t)(lo >> cs);
+  const uint32_t mw = p >> 5, ms = p & 31;
+  const uint64_t ml = (uint64_t)mask[mw] | ((uint64_t)mask[mw + 1] << 32);
+  m = (uint32_t)(ml >> ms) & 0xFFFFu;
+}
+
 __device__ __forceinline__ uint64_t revcomp40(uint64_t k) {
   uint64_t x = __brevll(k);                                                   // pair order reversed, bits in pairs swapped
   x = ((x & 0xAAAAAAAAAAAAAAAAull) >> 1) | ((x & 0x5555555555555555ull) << 1);  // un-swap inside each pair
   return (~(x >> 24)) & 0xFFFFFFFFFFull;
 }
 
-__global__ __launch_bounds__(256) void anim_index_kernel(RefDesc R) {
+__global__ __launch_bounds__(256) void anim_index_kernel(const RefDesc* __restrict__ refs) {
+  const RefDesc R = refs[blockIdx.y];
   const int32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   uint64_t k;
   if (!kmer_at(R.codes, R.mask, R.len, p, k)) return;
@@ -81,9 +94,10 @@ __global__ __launch_bounds__(256) void anim_index_kernel(RefDesc R) {
   }
 }
 
-__global__ __launch_bounds__(256) void anim_seed_kernel(RefDesc R, const UnitDesc* __restrict__ units, Match* __restrict__ mem,
-                                                        uint32_t* __restrict__ mem_count, uint32_t cap_m) {
+__global__ __launch_bounds__(256) void anim_seed_kernel(const RefDesc* __restrict__ refs, const UnitDesc* __restrict__ units,
+                                                        Match* __restrict__ mem, uint32_t* __restrict__ mem_count, uint32_t cap_m) {
   const UnitDesc U = units[blockIdx.y];
+  const RefDesc R = refs[U.ref];
   const int32_t q = blockIdx.x * blockDim.x + threadIdx.x;  // strand position
   if (q + MIN_MATCH > U.len) return;
   uint64_t k;
@@ -104,6 +118,30 @@ __global__ __launch_bounds__(256) void anim_seed_kernel(RefDesc R, const UnitDes
     const int32_t r = (int32_t)(v & 0xFFFFFFu);
     if (RV.clean(r - 1) && QV.clean(q - 1) && RV.base(r - 1) == QV.base(q - 1)) continue;  // not left-maximal
     int32_t L = MIN_MATCH;
+    // right extension, 16 bases per step (word compare of the packed codes and masks), then base by base
+    for (;;) {
+      if (r + L + 16 > R.len || q + L + 16 > U.len) break;
+      uint32_t rc_, rm_, qc_, qm_;
+      get16(R.codes, R.mask, r + L, rc_, rm_);
+      if (U.strand == 0) {
+        get16(U.codes, U.mask, q + L, qc_, qm_);
+      } else {
+        uint32_t fc, fm;
+        get16(U.codes, U.mask, U.len - 16 - (q + L), fc, fm);
+        uint32_t x = __brev(fc);
+        x = ((x & 0xAAAAAAAAu) >> 1) | ((x & 0x55555555u) << 1);
+        qc_ = ~x;
+        qm_ = __brev(fm) >> 16;
+      }
+      const uint32_t x = rc_ ^ qc_;
+      const uint32_t diff = (x | (x >> 1)) & 0x55555555u;
+      const uint32_t bad = ~(rm_ & qm_) & 0xFFFFu;
+      const int nd = diff ? (__ffs(diff) - 1) >> 1 : 16;
+      const int nb = bad ? __ffs(bad) - 1 : 16;
+      const int n = nd < nb ? nd : nb;
+      L += n;
+      if (n < 16) break;
+    }
     while (RV.clean(r + L) && QV.clean(q + L) && RV.base(r + L) == QV.base(q + L)) ++L;
     const uint32_t at = atomicAdd(&mem_count[blockIdx.y], 1u);
     if (at < cap_m) mem[(size_t)blockIdx.y * cap_m + at] = Match{r, q, L, U.strand};
@@ -120,13 +158,14 @@ struct ClusterOut {
   int32_t* status;      // [P]
 };
 
-__global__ __launch_bounds__(64) void anim_cluster_kernel(RefDesc R, const UnitDesc* __restrict__ units, uint32_t n_units,
+__global__ __launch_bounds__(64) void anim_cluster_kernel(const RefDesc* __restrict__ refs, const UnitDesc* __restrict__ units, uint32_t n_units,
                                                           Match* __restrict__ mem, const uint32_t* __restrict__ mem_count,
                                                           uint32_t cap_m, uint32_t cap_c, int32_t* __restrict__ iscratch,
                                                           ClusterOut O) {
   const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
   if (u >= n_units) return;
   const UnitDesc U = units[u];
+  const RefDesc R = refs[U.ref];
   O.n_chains[u] = 0;
   uint32_t n0 = mem_count[u];
   if (n0 > cap_m) { atomicOr(&O.status[U.pair], 1); n0 = cap_m; }
@@ -280,12 +319,13 @@ __device__ int32_t gap_errors_wave(const SeqView& R, const StrandView& Q, int64_
 
 // One WAVE per chain (work list wl: unit, chain).  phase 0: gap fills + free forward extension (extend_chain_fwd);
 // phase 1: backward extension towards the previous chain's forward end (extend_chain_bwd).
-__global__ __launch_bounds__(64) void anim_extend_kernel(RefDesc R, const UnitDesc* __restrict__ units, uint32_t cap_m,
+__global__ __launch_bounds__(64) void anim_extend_kernel(const RefDesc* __restrict__ refs, const UnitDesc* __restrict__ units, uint32_t cap_m,
                                                          uint32_t cap_c, ClusterOut O, const uint2* __restrict__ wl,
                                                          ChainFwd* __restrict__ fw, ChainBwd* __restrict__ bw, int phase) {
   const uint32_t u = wl[blockIdx.x].x;
   const int32_t c = (int32_t)wl[blockIdx.x].y;
   const UnitDesc U = units[u];
+  const RefDesc R = refs[U.ref];
   const SeqView RV{R.codes, R.mask, R.len};
   const StrandView QV{SeqView{U.codes, U.mask, U.len}, U.strand};
   const Chain ch = O.chains[(size_t)u * cap_c + c];
@@ -355,12 +395,13 @@ struct FinishScratch {
   int32_t* aln_of;  // [U][cap_c]
 };
 
-__global__ __launch_bounds__(64) void anim_finish_kernel(RefDesc R, const UnitDesc* __restrict__ units, uint32_t n_pairs,
+__global__ __launch_bounds__(64) void anim_finish_kernel(const RefDesc* __restrict__ refs, const UnitDesc* __restrict__ units, uint32_t n_pairs,
                                                          uint32_t cap_m, uint32_t cap_c, uint32_t cap_a, ClusterOut O,
                                                          const ChainFwd* __restrict__ fw, const ChainBwd* __restrict__ bw,
                                                          FinishScratch S, int filter_1to1, pg_anim_result* __restrict__ out) {
   const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n_pairs) return;
+  const RefDesc R = refs[units[2 * p].ref];
   Aln* alns = S.alns + (size_t)p * cap_a;
   int32_t* a_rrec = S.a_rrec + (size_t)p * cap_a;
   int32_t* a_qrec = S.a_qrec + (size_t)p * cap_a;
@@ -431,52 +472,131 @@ int anim_alloc(pg_ctx* ctx, T*& p, size_t n) {
 }  // namespace
 
 // ---- host driver ---------------------------------------------------------------------------------------------------
-// Processes all pairs that share one reference genome (= nucmer's reference = pyani's query genome, anim.py:280).
-int pg_anim_run_ref(pg_ctx* ctx, int32_t ref_id, const int32_t* qry_ids, uint32_t n_pairs, int filter_1to1,
-                    pg_anim_result* out_host) {
-  const PgGenome& G = ctx->genomes[ref_id];
-  constexpr uint32_t CAP_M = 1u << 17, CAP_C = 1u << 13, CAP_A = 1u << 14;
-  const uint32_t n_units = 2 * n_pairs;
-  // reference descriptor + table
-  RefDesc R;
-  R.codes = ctx->d_codes + G.arena_start / 16;
-  R.mask = ctx->d_mask + G.arena_start / 32;
-  R.len = (int32_t)G.stream_len;
-  R.n_rec = (int32_t)G.n_rec;
-  uint32_t tbits = 10;
-  while ((1ull << tbits) < (uint64_t)(G.stream_len + G.stream_len / 2 + 16)) ++tbits;
-  R.table_mask = (uint32_t)((1ull << tbits) - 1);
-  uint64_t* d_table = nullptr;
-  int32_t* d_recs = nullptr;
-  UnitDesc* d_units = nullptr;
-  Match *d_mem = nullptr, *d_cm = nullptr;
-  uint32_t* d_mem_count = nullptr;
-  int32_t *d_iscratch = nullptr, *d_nch = nullptr, *d_order = nullptr, *d_prev = nullptr, *d_next = nullptr, *d_status = nullptr,
-          *d_alnof = nullptr;
-  Chain* d_chains = nullptr;
-  ChainFwd* d_fw = nullptr;
-  ChainBwd* d_bw = nullptr;
+// One batch of ordered pairs (any mix of references): ref_ids[i] = nucmer's reference (pyani's query genome, anim.py:280).
+// Scratch lives in the context and only grows.  The per-unit kernels are latency-bound single-thread code, so the
+// batch should be as large as memory allows: thousands of units in flight are what fills the GPU.
+namespace {
+constexpr uint32_t CAP_M = 1u << 17, CAP_C = 1u << 13, CAP_A = 1u << 14;
+
+struct AnimScratch {
+  size_t units = 0, pairs = 0, refs = 0, table_slots = 0, recs = 0, wl = 0;
+  uint64_t* table = nullptr;
+  int32_t* recs_d = nullptr;
+  RefDesc* refs_d = nullptr;
+  UnitDesc* units_d = nullptr;
+  Match *mem = nullptr, *cm = nullptr;
+  uint32_t* mem_count = nullptr;
+  int32_t *iscratch = nullptr, *nch = nullptr, *order = nullptr, *prev = nullptr, *next = nullptr, *status = nullptr, *alnof = nullptr;
+  Chain* chains = nullptr;
+  ChainFwd* fw = nullptr;
+  ChainBwd* bw = nullptr;
   FinishScratch S{};
-  pg_anim_result* d_out = nullptr;
-  int rc = PG_OK;
-  std::vector<void*> to_free;
-  auto cleanup = [&]() { for (void* p : to_free) if (p) (void)hipFree(p); };
-#define AA(ptr, n) do { if ((rc = anim_alloc(ctx, ptr, (n)))) { cleanup(); return rc; } to_free.push_back(ptr); } while (0)
-  AA(d_table, (size_t)R.table_mask + 1);
-  // record-start tables: reference first, then each query
-  std::vector<int32_t> recs(G.rec_start.begin(), G.rec_start.end());
-  std::vector<uint32_t> rec_off(n_pairs);
+  pg_anim_result* out = nullptr;
+  uint2* wl_d = nullptr;
+};
+
+template <typename T>
+int grow(pg_ctx* ctx, T*& p, size_t& have, size_t need, size_t per) {
+  (void)have;
+  if (p) PG_HIP(ctx, hipFree(p));
+  p = nullptr;
+  PG_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&p), need * per * sizeof(T)));
+  return PG_OK;
+}
+}  // namespace
+
+static AnimScratch* anim_scratch(pg_ctx* ctx) {
+  if (!ctx->anim_scratch) ctx->anim_scratch = new AnimScratch();
+  return static_cast<AnimScratch*>(ctx->anim_scratch);
+}
+
+void pg_anim_free_scratch(pg_ctx* ctx) {
+  AnimScratch* A = static_cast<AnimScratch*>(ctx->anim_scratch);
+  if (!A) return;
+  void* ptrs[] = {A->table, A->recs_d, A->refs_d, A->units_d, A->mem, A->cm, A->mem_count, A->iscratch, A->nch, A->order, A->prev,
+                  A->next, A->status, A->alnof, A->chains, A->fw, A->bw, A->S.alns, A->S.a_rrec, A->S.a_qrec, A->S.idx, A->S.from,
+                  A->S.sc, A->out, A->wl_d};
+  for (void* p : ptrs) if (p) (void)hipFree(p);
+  delete A;
+  ctx->anim_scratch = nullptr;
+}
+
+int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_ids, uint32_t n_pairs, int filter_1to1,
+                      pg_anim_result* out_host) {
+  AnimScratch* A = anim_scratch(ctx);
+  const uint32_t n_units = 2 * n_pairs;
+  int rc;
+  // distinct references of the batch (ref_ids arrive grouped) and their tables
+  std::vector<int32_t> ref_list;
+  std::vector<uint32_t> ref_of_pair(n_pairs);
+  for (uint32_t p = 0; p < n_pairs; ++p) {
+    if (ref_list.empty() || ref_list.back() != ref_ids[p]) ref_list.push_back(ref_ids[p]);
+    ref_of_pair[p] = (uint32_t)ref_list.size() - 1;
+  }
+  const uint32_t n_refs = (uint32_t)ref_list.size();
+  std::vector<RefDesc> refs(n_refs);
+  std::vector<int32_t> recs;
+  std::vector<uint32_t> ref_rec_off(n_refs), qry_rec_off(n_pairs);
+  std::vector<size_t> table_off(n_refs);
+  size_t slots = 0;
+  int32_t max_rlen = 0, max_qlen = 0;
+  for (uint32_t r = 0; r < n_refs; ++r) {
+    const PgGenome& G = ctx->genomes[ref_list[r]];
+    uint32_t tbits = 10;
+    while ((1ull << tbits) < (uint64_t)(G.stream_len + G.stream_len / 2 + 16)) ++tbits;
+    refs[r].codes = ctx->d_codes + G.arena_start / 16;
+    refs[r].mask = ctx->d_mask + G.arena_start / 32;
+    refs[r].len = (int32_t)G.stream_len;
+    refs[r].n_rec = (int32_t)G.n_rec;
+    refs[r].table_mask = (uint32_t)((1ull << tbits) - 1);
+    table_off[r] = slots;
+    slots += (size_t)1 << tbits;
+    ref_rec_off[r] = (uint32_t)recs.size();
+    recs.insert(recs.end(), G.rec_start.begin(), G.rec_start.end());
+    if ((int32_t)G.stream_len > max_rlen) max_rlen = (int32_t)G.stream_len;
+  }
   for (uint32_t p = 0; p < n_pairs; ++p) {
     const PgGenome& Q = ctx->genomes[qry_ids[p]];
-    rec_off[p] = (uint32_t)recs.size();
+    qry_rec_off[p] = (uint32_t)recs.size();
     recs.insert(recs.end(), Q.rec_start.begin(), Q.rec_start.end());
+    if ((int32_t)Q.stream_len > max_qlen) max_qlen = (int32_t)Q.stream_len;
   }
-  AA(d_recs, recs.size());
-  PG_HIP(ctx, hipMemcpyAsync(d_recs, recs.data(), recs.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-  R.rec_start = d_recs;
-  R.table = d_table;
+  // grow scratch
+  if (slots > A->table_slots) { if ((rc = grow(ctx, A->table, A->table_slots, slots, 1))) return rc; A->table_slots = slots; }
+  if (recs.size() > A->recs) { if ((rc = grow(ctx, A->recs_d, A->recs, recs.size(), 1))) return rc; A->recs = recs.size(); }
+  if (n_refs > A->refs) { if ((rc = grow(ctx, A->refs_d, A->refs, n_refs, 1))) return rc; A->refs = n_refs; }
+  if (n_units > A->units) {
+    const size_t u = n_units;
+    if ((rc = grow(ctx, A->units_d, A->units, u, 1))) return rc;
+    if ((rc = grow(ctx, A->mem, A->units, u, CAP_M))) return rc;
+    if ((rc = grow(ctx, A->cm, A->units, u, CAP_M))) return rc;
+    if ((rc = grow(ctx, A->mem_count, A->units, u, 1))) return rc;
+    if ((rc = grow(ctx, A->iscratch, A->units, u, 7 * (size_t)CAP_M))) return rc;
+    if ((rc = grow(ctx, A->chains, A->units, u, CAP_C))) return rc;
+    if ((rc = grow(ctx, A->nch, A->units, u, 1))) return rc;
+    if ((rc = grow(ctx, A->order, A->units, u, CAP_C))) return rc;
+    if ((rc = grow(ctx, A->prev, A->units, u, CAP_C))) return rc;
+    if ((rc = grow(ctx, A->next, A->units, u, CAP_C))) return rc;
+    if ((rc = grow(ctx, A->alnof, A->units, u, CAP_C))) return rc;
+    if ((rc = grow(ctx, A->fw, A->units, u, CAP_C))) return rc;
+    if ((rc = grow(ctx, A->bw, A->units, u, CAP_C))) return rc;
+    A->units = u;
+  }
+  if (n_pairs > A->pairs) {
+    const size_t p = n_pairs;
+    if ((rc = grow(ctx, A->status, A->pairs, p, 1))) return rc;
+    if ((rc = grow(ctx, A->S.alns, A->pairs, p, CAP_A))) return rc;
+    if ((rc = grow(ctx, A->S.a_rrec, A->pairs, p, CAP_A))) return rc;
+    if ((rc = grow(ctx, A->S.a_qrec, A->pairs, p, CAP_A))) return rc;
+    if ((rc = grow(ctx, A->S.idx, A->pairs, p, CAP_A))) return rc;
+    if ((rc = grow(ctx, A->S.from, A->pairs, p, CAP_A))) return rc;
+    if ((rc = grow(ctx, A->S.sc, A->pairs, p, CAP_A))) return rc;
+    if ((rc = grow(ctx, A->out, A->pairs, p, 1))) return rc;
+    A->pairs = p;
+  }
+  A->S.aln_of = A->alnof;
+  for (uint32_t r = 0; r < n_refs; ++r) { refs[r].rec_start = A->recs_d + ref_rec_off[r]; refs[r].table = A->table + table_off[r]; }
   std::vector<UnitDesc> units(n_units);
-  int32_t max_qlen = 0;
   for (uint32_t p = 0; p < n_pairs; ++p) {
     const PgGenome& Q = ctx->genomes[qry_ids[p]];
     for (int s = 0; s < 2; ++s) {
@@ -484,69 +604,44 @@ int pg_anim_run_ref(pg_ctx* ctx, int32_t ref_id, const int32_t* qry_ids, uint32_
       U.codes = ctx->d_codes + Q.arena_start / 16;
       U.mask = ctx->d_mask + Q.arena_start / 32;
       U.len = (int32_t)Q.stream_len;
-      U.rec_start = d_recs + rec_off[p];
+      U.rec_start = A->recs_d + qry_rec_off[p];
       U.n_rec = (int32_t)Q.n_rec;
       U.strand = s;
       U.pair = (int32_t)p;
+      U.ref = (int32_t)ref_of_pair[p];
     }
-    if ((int32_t)Q.stream_len > max_qlen) max_qlen = (int32_t)Q.stream_len;
   }
-  AA(d_units, n_units);
-  PG_HIP(ctx, hipMemcpyAsync(d_units, units.data(), n_units * sizeof(UnitDesc), hipMemcpyHostToDevice, ctx->stream));
-  AA(d_mem, (size_t)n_units * CAP_M);
-  AA(d_cm, (size_t)n_units * CAP_M);
-  AA(d_mem_count, n_units);
-  AA(d_iscratch, (size_t)n_units * 7 * CAP_M);
-  AA(d_chains, (size_t)n_units * CAP_C);
-  AA(d_nch, n_units);
-  AA(d_order, (size_t)n_units * CAP_C);
-  AA(d_prev, (size_t)n_units * CAP_C);
-  AA(d_next, (size_t)n_units * CAP_C);
-  AA(d_alnof, (size_t)n_units * CAP_C);
-  AA(d_status, n_pairs);
-  AA(d_fw, (size_t)n_units * CAP_C);
-  AA(d_bw, (size_t)n_units * CAP_C);
-  AA(S.alns, (size_t)n_pairs * CAP_A);
-  AA(S.a_rrec, (size_t)n_pairs * CAP_A);
-  AA(S.a_qrec, (size_t)n_pairs * CAP_A);
-  AA(S.idx, (size_t)n_pairs * CAP_A);
-  AA(S.from, (size_t)n_pairs * CAP_A);
-  AA(S.sc, (size_t)n_pairs * CAP_A);
-  AA(d_out, n_pairs);
-#undef AA
-  S.aln_of = d_alnof;
-  PG_HIP(ctx, hipMemsetAsync(d_table, 0xFF, ((size_t)R.table_mask + 1) * 8, ctx->stream));
-  PG_HIP(ctx, hipMemsetAsync(d_mem_count, 0, n_units * 4, ctx->stream));
-  PG_HIP(ctx, hipMemsetAsync(d_status, 0, n_pairs * 4, ctx->stream));
-  ClusterOut O{d_cm, d_chains, d_nch, d_order, d_prev, d_next, d_status};
-  hipLaunchKernelGGL(anim_index_kernel, dim3((R.len + 255) / 256), dim3(256), 0, ctx->stream, R);
-  hipLaunchKernelGGL(anim_seed_kernel, dim3((max_qlen + 255) / 256, n_units), dim3(256), 0, ctx->stream, R, d_units, d_mem,
-                     d_mem_count, CAP_M);
-  hipLaunchKernelGGL(anim_cluster_kernel, dim3((n_units + 63) / 64), dim3(64), 0, ctx->stream, R, d_units, n_units, d_mem,
-                     d_mem_count, CAP_M, CAP_C, d_iscratch, O);
+  PG_HIP(ctx, hipMemcpyAsync(A->recs_d, recs.data(), recs.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+  PG_HIP(ctx, hipMemcpyAsync(A->refs_d, refs.data(), n_refs * sizeof(RefDesc), hipMemcpyHostToDevice, ctx->stream));
+  PG_HIP(ctx, hipMemcpyAsync(A->units_d, units.data(), n_units * sizeof(UnitDesc), hipMemcpyHostToDevice, ctx->stream));
+  PG_HIP(ctx, hipMemsetAsync(A->table, 0xFF, slots * 8, ctx->stream));
+  PG_HIP(ctx, hipMemsetAsync(A->mem_count, 0, n_units * 4, ctx->stream));
+  PG_HIP(ctx, hipMemsetAsync(A->status, 0, n_pairs * 4, ctx->stream));
+  ClusterOut O{A->cm, A->chains, A->nch, A->order, A->prev, A->next, A->status};
+  hipLaunchKernelGGL(anim_index_kernel, dim3((max_rlen + 255) / 256, n_refs), dim3(256), 0, ctx->stream, A->refs_d);
+  hipLaunchKernelGGL(anim_seed_kernel, dim3((max_qlen + 255) / 256, n_units), dim3(256), 0, ctx->stream, A->refs_d, A->units_d,
+                     A->mem, A->mem_count, CAP_M);
+  hipLaunchKernelGGL(anim_cluster_kernel, dim3((n_units + 63) / 64), dim3(64), 0, ctx->stream, A->refs_d, A->units_d, n_units,
+                     A->mem, A->mem_count, CAP_M, CAP_C, A->iscratch, O);
   // work list of (unit, chain): one wave each
   std::vector<int32_t> nch(n_units);
-  PG_HIP(ctx, hipMemcpyAsync(nch.data(), d_nch, n_units * 4, hipMemcpyDeviceToHost, ctx->stream));
+  PG_HIP(ctx, hipMemcpyAsync(nch.data(), A->nch, n_units * 4, hipMemcpyDeviceToHost, ctx->stream));
   PG_HIP(ctx, hipStreamSynchronize(ctx->stream));
   std::vector<uint2> wl;
   for (uint32_t u = 0; u < n_units; ++u)
     for (int32_t c = 0; c < nch[u]; ++c) wl.push_back(make_uint2(u, (uint32_t)c));
-  uint2* d_wl = nullptr;
   if (!wl.empty()) {
-    if ((rc = anim_alloc(ctx, d_wl, wl.size()))) { cleanup(); return rc; }
-    to_free.push_back(d_wl);
-    PG_HIP(ctx, hipMemcpyAsync(d_wl, wl.data(), wl.size() * sizeof(uint2), hipMemcpyHostToDevice, ctx->stream));
+    if (wl.size() > A->wl) { if ((rc = grow(ctx, A->wl_d, A->wl, wl.size() + wl.size() / 2, 1))) return rc; A->wl = wl.size() + wl.size() / 2; }
+    PG_HIP(ctx, hipMemcpyAsync(A->wl_d, wl.data(), wl.size() * sizeof(uint2), hipMemcpyHostToDevice, ctx->stream));
     for (int phase = 0; phase < 2; ++phase)
-      hipLaunchKernelGGL(anim_extend_kernel, dim3((uint32_t)wl.size()), dim3(64), 0, ctx->stream, R, d_units, CAP_M, CAP_C, O,
-                         d_wl, d_fw, d_bw, phase);
+      hipLaunchKernelGGL(anim_extend_kernel, dim3((uint32_t)wl.size()), dim3(64), 0, ctx->stream, A->refs_d, A->units_d, CAP_M,
+                         CAP_C, O, A->wl_d, A->fw, A->bw, phase);
   }
-  hipLaunchKernelGGL(anim_finish_kernel, dim3((n_pairs + 63) / 64), dim3(64), 0, ctx->stream, R, d_units, n_pairs, CAP_M,
-                     CAP_C, CAP_A, O, d_fw, d_bw, S, filter_1to1, d_out);
-  hipError_t e = hipGetLastError();
-  if (e == hipSuccess) e = hipMemcpyAsync(out_host, d_out, n_pairs * sizeof(pg_anim_result), hipMemcpyDeviceToHost, ctx->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-  cleanup();
-  if (e != hipSuccess) return pg_fail(ctx, PG_E_HIP, std::string("anim pipeline: ") + hipGetErrorString(e));
+  hipLaunchKernelGGL(anim_finish_kernel, dim3((n_pairs + 63) / 64), dim3(64), 0, ctx->stream, A->refs_d, A->units_d, n_pairs,
+                     CAP_M, CAP_C, CAP_A, O, A->fw, A->bw, A->S, filter_1to1, A->out);
+  PG_HIP(ctx, hipGetLastError());
+  PG_HIP(ctx, hipMemcpyAsync(out_host, A->out, n_pairs * sizeof(pg_anim_result), hipMemcpyDeviceToHost, ctx->stream));
+  PG_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return PG_OK;
 }
 

@@ -322,6 +322,7 @@ void pg_destroy(pg_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
+  pg_anim_free_scratch(ctx);
   prof_drain(ctx);
   void* dev[] = {ctx->d_codes, ctx->d_mask, ctx->d_quirk, ctx->d_seg_tile0, ctx->d_seg_prefix, ctx->d_batch_gid, ctx->d_acc,
                  ctx->d_counts, ctx->d_z, ctx->d_present, ctx->d_dev, ctx->d_ss, ctx->d_flags, ctx->d_corr};
@@ -622,17 +623,24 @@ int pg_anim_pairs(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_ids, u
   std::vector<uint64_t> order(n_pairs);
   for (uint64_t i = 0; i < n_pairs; ++i) order[i] = i;
   std::stable_sort(order.begin(), order.end(), [&](uint64_t a, uint64_t b) { return ref_ids[a] < ref_ids[b]; });
-  constexpr uint32_t CHUNK = 64;
-  std::vector<int32_t> q;
+  // batches: as many pairs as the scratch budget allows, at most MAX_REFS distinct references (one 20-mer table each)
+  const uint32_t MAX_PAIRS = ctx->anim_batch_pairs, MAX_REFS = 24;
+  std::vector<int32_t> r, q;
   std::vector<pg_anim_result> res;
   uint64_t i = 0;
   while (i < n_pairs) {
     uint64_t j = i;
-    while (j < n_pairs && j - i < CHUNK && ref_ids[order[j]] == ref_ids[order[i]]) ++j;
-    q.clear();
-    for (uint64_t k = i; k < j; ++k) q.push_back(qry_ids[order[k]]);
+    uint32_t nrefs = 0;
+    int32_t last = -1;
+    while (j < n_pairs && j - i < MAX_PAIRS) {
+      const int32_t rid = ref_ids[order[j]];
+      if (rid != last) { if (nrefs == MAX_REFS) break; ++nrefs; last = rid; }
+      ++j;
+    }
+    r.clear(); q.clear();
+    for (uint64_t k = i; k < j; ++k) { r.push_back(ref_ids[order[k]]); q.push_back(qry_ids[order[k]]); }
     res.assign(j - i, pg_anim_result{});
-    if ((rc = pg_anim_run_ref(ctx, ref_ids[order[i]], q.data(), (uint32_t)(j - i), filter_1to1, res.data()))) return rc;
+    if ((rc = pg_anim_run_batch(ctx, r.data(), q.data(), (uint32_t)(j - i), filter_1to1, res.data()))) return rc;
     for (uint64_t k = i; k < j; ++k) out[order[k]] = res[k - i];
     i = j;
   }

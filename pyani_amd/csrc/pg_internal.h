@@ -82,6 +82,8 @@ struct pg_ctx {
   double prof_ms[PG_K__COUNT] = {0, 0, 0, 0};
   uint64_t prof_n[PG_K__COUNT] = {0, 0, 0, 0};
   int num_cu = 256;
+  void* anim_scratch = nullptr;  // AnimScratch (pg_anim.hip), grows on demand
+  uint32_t anim_batch_pairs = 1024;
 };
 
 int pg_fail(pg_ctx* ctx, int code, const std::string& msg);
@@ -106,5 +108,6 @@ int pg_launch_tetra_pairs(pg_ctx* ctx, uint32_t n, uint32_t row0, uint32_t nrows
 int pg_anim_reduce_run(pg_ctx* ctx, uint32_t n_pairs, const uint64_t* offsets, const int32_t* rseq, const int32_t* qseq,
                        const int32_t* rs, const int32_t* re, const int32_t* qs, const int32_t* qe, const int32_t* errors,
                        int apply_filter, pg_anim_result* out);
-int pg_anim_run_ref(pg_ctx* ctx, int32_t ref_id, const int32_t* qry_ids, uint32_t n_pairs, int filter_1to1,
-                    pg_anim_result* out_host);
+int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_ids, uint32_t n_pairs, int filter_1to1,
+                      pg_anim_result* out_host);   // ref_ids must arrive grouped (equal ids adjacent)
+void pg_anim_free_scratch(pg_ctx* ctx);
