@@ -64,3 +64,45 @@ class TetraAllGather:
         dist.all_gather_into_tensor(self.rows_pad, self.rows, group=self.group)   # collective #2 (matrix rows)
         self._unpad(self.rows_pad, self.corr)
         return self.corr
+
+
+# ---- ANIm: the ordered-pair grid is sharded, results assembled with ONE all-gather ---------------
+ANIM_FIELDS = 6  # ref_aln_len, qry_aln_len, sim_errors, n_alignments, identity (bit pattern), status
+
+
+def anim_pair_shard(n_genomes: int, rank: int, world: int):
+    """Ordered pairs (q, s), q != s, owned by `rank`: reference genomes (rows of the grid) are dealt out round-robin so
+    that every rank builds each 20-mer table at most once and the near-identical (expensive) pairs spread evenly."""
+    return [(q, s) for q in range(rank, n_genomes, world) for s in range(n_genomes) if s != q]
+
+
+def anim_allgather(compute_pairs: Callable, n_genomes: int, device: torch.device, group=None) -> torch.Tensor:
+    """compute_pairs(pairs) -> int64 tensor [len(pairs), ANIM_FIELDS] on `device` (identity as its IEEE-754 bit pattern).
+    Returns the full [n, n, ANIM_FIELDS] int64 grid on every rank (diagonal zero).  One collective of 48 B per pair."""
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    mine = anim_pair_shard(n_genomes, rank, world)
+    rows_max = (n_genomes + world - 1) // world
+    cap = rows_max * max(n_genomes - 1, 0)
+    loc = torch.zeros((cap, ANIM_FIELDS + 2), dtype=torch.int64, device=device)   # + (q, s) so that the grid is self-describing
+    if mine:
+        vals = compute_pairs(mine)
+        loc[: len(mine), :ANIM_FIELDS] = vals
+        loc[: len(mine), ANIM_FIELDS:] = torch.tensor(mine, dtype=torch.int64, device=device)
+    loc[len(mine):, ANIM_FIELDS] = -1
+    allv = torch.zeros((world * cap, ANIM_FIELDS + 2), dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(allv, loc, group=group)
+    grid = torch.zeros((n_genomes, n_genomes, ANIM_FIELDS), dtype=torch.int64, device=device)
+    valid = allv[:, ANIM_FIELDS] >= 0
+    q, s = allv[valid, ANIM_FIELDS], allv[valid, ANIM_FIELDS + 1]
+    grid[q, s] = allv[valid, :ANIM_FIELDS]
+    return grid
+
+
+def anim_records_to_tensor(recs, device: torch.device) -> torch.Tensor:
+    """Engine.anim_pairs structured array -> int64 [n, ANIM_FIELDS] tensor (identity bit-cast, lossless)."""
+    import numpy as np
+    a = np.zeros((len(recs), ANIM_FIELDS), dtype=np.int64)
+    a[:, 0], a[:, 1], a[:, 2], a[:, 3] = recs["ref_aln_len"], recs["qry_aln_len"], recs["sim_errors"], recs["n_alignments"]
+    a[:, 4] = recs["identity"].view(np.int64)
+    a[:, 5] = recs["status"]
+    return torch.from_numpy(a).to(device)

@@ -65,3 +65,41 @@ def test_shard_range_partitions():
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
             assert max(hi - lo for lo, hi in spans) == max_shard(n, world) or n == 0
+
+
+def _anim_worker(rank, world, port, n, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pyani_amd import parallel
+
+        def fake_engine(pairs):   # stands in for Engine.anim_pairs: a deterministic function of (q, s)
+            t = torch.zeros((len(pairs), parallel.ANIM_FIELDS), dtype=torch.int64)
+            for k, (q, s) in enumerate(pairs):
+                ident = np.float64(0.8 + 0.001 * q + 0.00001 * s)
+                t[k] = torch.tensor([1000 * q + s, 2000 * s + q, q + s, 7, int(ident.view(np.int64)), 0])
+            return t
+
+        grid = parallel.anim_allgather(fake_engine, n, torch.device("cpu")).numpy()
+        np.save(os.path.join(out_dir, f"anim{rank}.npy"), grid)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [5, 6])
+def test_anim_pair_grid_allgather(tmp_path, n):
+    from pyani_amd import parallel
+    port = _free_port()
+    mp.spawn(_anim_worker, args=(2, port, n, str(tmp_path)), nprocs=2, join=True)
+    a, b = np.load(tmp_path / "anim0.npy"), np.load(tmp_path / "anim1.npy")
+    assert (a == b).all() and a.shape == (n, n, parallel.ANIM_FIELDS)
+    for q in range(n):
+        for s in range(n):
+            if q == s:
+                assert not a[q, s].any()
+            else:
+                assert a[q, s, 0] == 1000 * q + s and a[q, s, 1] == 2000 * s + q and a[q, s, 3] == 7
+                assert np.int64(a[q, s, 4]).view(np.float64) == np.float64(0.8 + 0.001 * q + 0.00001 * s)
+    # shards partition the ordered-pair grid
+    shards = [set(parallel.anim_pair_shard(n, r, 2)) for r in range(2)]
+    assert not (shards[0] & shards[1]) and len(shards[0] | shards[1]) == n * (n - 1)
