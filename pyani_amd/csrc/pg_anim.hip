@@ -240,14 +240,22 @@ __device__ ExtResult extend_wave(const SeqView& R, const StrandView& Q, int64_t 
   constexpr int W = BAND / 2;
   static_assert(BAND == 64, "one lane per diagonal");
   __shared__ uint8_t s_ring[2][256];
-  const int lane = threadIdx.x & 63, k = lane - W;
-  DpCell cur{NEG_INF, 0, NEG_INF, 0, NEG_INF, 0};
-  int32_t bs = NEG_INF, bd = 0, be = 0;
-  if (lane == W) { cur.h = 0; bs = 0; }
+  const int lane = threadIdx.x & 63;
   ExtResult res{0, 0, 0, 0, 0};
   bool targeted = tr >= 0;
-  if (targeted && (tq - tr < -W || tq - tr >= W || tr > rmax || tq > qmax)) targeted = false;
+  int koff = 0;   // band placement, see pga::extend_banded
+  if (targeted) {
+    koff = (tq - tr) / 2;
+    if (koff > W - 2) koff = W - 2;
+    if (koff < -(W - 2)) koff = -(W - 2);
+    const int lt = (tq - tr) - koff + W;
+    if (lt < 0 || lt >= BAND || tr > rmax || tq > qmax) { targeted = false; koff = 0; }
+  }
   if (targeted && tr == 0 && tq == 0) { res.reached = 1; return res; }
+  const int k = lane - W + koff;
+  DpCell cur{NEG_INF, 0, NEG_INF, 0, NEG_INF, 0};
+  int32_t bs = NEG_INF, bd = 0, be = 0;
+  if (lane == W - koff) { cur.h = 0; bs = 0; }
   const int32_t d_end = targeted ? tr + tq : rmax + qmax;
   constexpr long long BIAS = 1ll << 30;
   WaveSeq ws{s_ring[0], s_ring[1], 0};
@@ -255,8 +263,14 @@ __device__ ExtResult extend_wave(const SeqView& R, const StrandView& Q, int64_t 
   wave_seq_fill(ws, R, Q, r0, q0, dir, rmax, qmax, lane);
   wave_seq_fill(ws, R, Q, r0, q0, dir, rmax, qmax, lane);
   __syncthreads();
+  // Break rule with PER-STEP semantics (as the scalar code) at the price of one wave reduction every CHECK steps:
+  // g_known / t_prev = global best score and its anti-diagonal as of the last check; every lane remembers the first
+  // step since then at which it matched or beat g_known (fimp) and a snapshot of its best as of the last check.
+  constexpr int CHECK = 16;
+  int32_t g_known = 0, t_prev = 0, fimp = 0x7FFFFFFF;
+  int32_t sbs = bs, sbd = bd, sbe = be;
   for (int32_t d = 1; d <= d_end; ++d) {
-    if ((d >> 1) + 20 > ws.loaded) {   // uniform
+    if ((d >> 1) + 36 > ws.loaded) {   // uniform; covers the diagonals of a shifted band (|koff| <= 30)
       wave_seq_fill(ws, R, Q, r0, q0, dir, rmax, qmax, lane);
       __syncthreads();
     }
@@ -276,17 +290,29 @@ __device__ ExtResult extend_wave(const SeqView& R, const StrandView& Q, int64_t 
           ok = rb == qb && rb < 4;
         }
         cur = dp_cell(has_up, up_h, up_he, up_x, up_xe, has_left, lf_h, lf_he, lf_y, lf_ye, has_diag, cur.h, cur.he, ok);
-        if (cur.h > NEG_INF / 2 && (cur.h > bs || (cur.h == bs && d >= bd))) { bs = cur.h; bd = d; be = cur.he; }
+        if (cur.h > NEG_INF / 2) {
+          if (cur.h > bs || (cur.h == bs && d >= bd)) { bs = cur.h; bd = d; be = cur.he; }
+          if (cur.h >= g_known && fimp == 0x7FFFFFFF) fimp = d;
+        }
       }
     }
-    if ((d % CHECK_EVERY) == 0 || d == d_end) {
+    if ((d % CHECK) == 0 || d == d_end) {
       const long long key = wave_max64((((long long)bs + BIAS) << 32) | (uint32_t)bd);  // max score, ties: larger d
-      const int32_t gbest_d = (int32_t)(key & 0xFFFFFFFFll);
-      if (d - gbest_d > BREAK_LEN) break;
+      const int32_t g = (int32_t)((key >> 32) - BIAS), t = (int32_t)(key & 0xFFFFFFFFll);
+      const int32_t b = t_prev + BREAK_LEN + 1;      // step at which the per-step rule fires without an improvement
+      int32_t d1 = fimp;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) { const int32_t v = __shfl_xor(d1, o, 64); d1 = v < d1 ? v : d1; }
+      if (b <= d && d1 > b) {                        // it fired before the first improvement of this interval
+        bs = sbs; bd = sbd; be = sbe;                // results as of the last check (nothing global changed until b)
+        break;
+      }
       if (!__any(cur.h > NEG_INF / 2)) break;
+      g_known = g; t_prev = t; fimp = 0x7FFFFFFF;
+      sbs = bs; sbd = bd; sbe = be;
     }
     if (targeted && d == d_end) {
-      const int lt = (tq - tr) + W;
+      const int lt = (tq - tr) - koff + W;
       const int32_t th = __shfl(cur.h, lt, 64), the = __shfl(cur.he, lt, 64);
       if (th > NEG_INF / 2) { res.di = tr; res.dj = tq; res.score = th; res.errors = the; res.reached = 1; return res; }
     }
@@ -297,7 +323,7 @@ __device__ ExtResult extend_wave(const SeqView& R, const StrandView& Q, int64_t 
   const int32_t gd = (int32_t)((key >> 6) & 0x3FFFFFF);
   res.score = (int32_t)((key >> 32) - BIAS);
   res.errors = __shfl(be, bl, 64);
-  const int kk = bl - W;
+  const int kk = bl - W + koff;
   res.di = (gd - kk) / 2; res.dj = (gd + kk) / 2;
   return res;
 }
@@ -349,21 +375,17 @@ __global__ __launch_bounds__(64) void anim_extend_kernel(const RefDesc* __restri
     }
     e.inner_err = inner;
     e.lr = er; e.lq = eq;
-    const int32_t nx = O.next_of[(size_t)u * cap_c + c];
-    int32_t tr = -1, tq = -1;
-    if (nx >= 0) {
-      const Match nf = cm[O.chains[(size_t)u * cap_c + nx].first];
-      forward_target(er, eq, nf.r, nf.q, nf.len, tr, tq);
-    }
-    const ExtResult x = extend_wave(RV, QV, er, eq, +1, r_hi - er, q_hi - eq, tr, tq);
-    e.re = er + x.di; e.qe = eq + x.dj; e.err_fwd = x.errors;
-    e.reached = (tr >= 0 && x.reached) ? 1 : 0;
+    int32_t nr, nq;
+    e.target = pick_forward_target(O.chains + (size_t)u * cap_c, cm, O.next_of + (size_t)u * cap_c, c, er, eq, nr, nq);
+    forward_extension([&](int32_t cr, int32_t cq, int32_t rmax, int32_t qmax, int32_t tr, int32_t tq) {
+                        return extend_wave(RV, QV, cr, cq, +1, rmax, qmax, tr, tq); },
+                      er, eq, r_hi, q_hi, nr, nq, e.re, e.qe, e.err_fwd, e.reached);
     if ((threadIdx.x & 63) == 0) fwu[c] = e;
   } else {
     const int32_t p = O.prev_of[(size_t)u * cap_c + c];
     const int32_t first_r = fwu[c].first_r, first_q = fwu[c].first_q;
     const int32_t prev_re = p >= 0 ? fwu[p].re : -1, prev_qe = p >= 0 ? fwu[p].qe : -1;
-    if (p >= 0 && ((fwu[p].reached && O.next_of[(size_t)u * cap_c + p] == c) ||
+    if (p >= 0 && ((fwu[p].reached && fwu[p].target == c) ||
                    (fwu[p].first_r <= first_r && fwu[p].first_q <= first_q && prev_re >= fwu[c].lr && prev_qe >= fwu[c].lq))) {
       if ((threadIdx.x & 63) == 0) bw[(size_t)u * cap_c + c] = ChainBwd{first_r, first_q, 0, 0};  // will be shadowed
       return;
@@ -377,7 +399,7 @@ __global__ __launch_bounds__(64) void anim_extend_kernel(const RefDesc* __restri
         if (plq > q_lo) q_lo = plq;
       }
     }
-    const ExtResult b = extend_wave(RV, QV, first_r, first_q, -1, first_r - r_lo, first_q - q_lo, tr, tq);
+    const ExtResult b = extend_wave(RV, QV, first_r, first_q, -1, cap_ext(first_r - r_lo, MAX_EXT_BWD), cap_ext(first_q - q_lo, MAX_EXT_BWD), tr, tq);
     ChainBwd e;
     e.rs = first_r - b.di; e.qs = first_q - b.dj; e.err_back = b.errors;
     e.reached = (tr >= 0 && b.reached) ? 1 : 0;

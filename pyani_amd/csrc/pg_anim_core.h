@@ -79,7 +79,7 @@ struct ExtResult {
 };
 
 constexpr int32_t NEG_INF = -(1 << 28);
-constexpr int CHECK_EVERY = 16;
+constexpr int CHECK_EVERY = 1;
 
 struct DpCell { int32_t h, he, x, xe, y, ye; };
 
@@ -111,18 +111,30 @@ PG_HD ExtResult extend_banded(const RefT& R, const QryT& Q, int64_t r0, int64_t 
   DpCell cur[BAND];                 // latest cell of every diagonal (index l <-> k = l - W)
   int32_t bs[BAND], bd[BAND], be[BAND];  // per-diagonal best: score, d, errors
   for (int l = 0; l < BAND; ++l) { cur[l] = DpCell{NEG_INF, 0, NEG_INF, 0, NEG_INF, 0}; bs[l] = NEG_INF; bd[l] = 0; be[l] = 0; }
-  cur[W].h = 0; bs[W] = 0;          // cell (0, 0)
   ExtResult res{0, 0, 0, 0, 0};
   bool targeted = tr >= 0;
-  if (targeted && (tq - tr < -W || tq - tr >= W || tr > rmax || tq > qmax)) targeted = false;  // unreachable: free search
+  // band placement: diagonals k = l - W + koff.  A free search is centred on the start diagonal; a target search is
+  // centred between the start diagonal and the target's, so diagonal shifts of up to ~60 bases can be bridged.
+  int koff = 0;
+  if (targeted) {
+    koff = (tq - tr) / 2;
+    if (koff > W - 2) koff = W - 2;
+    if (koff < -(W - 2)) koff = -(W - 2);
+    const int lt = (tq - tr) - koff + W;
+    if (lt < 0 || lt >= BAND || tr > rmax || tq > qmax) { targeted = false; koff = 0; }   // unreachable: free search
+  }
   if (targeted && tr == 0 && tq == 0) { res.reached = 1; return res; }
+  cur[W - koff].h = 0; bs[W - koff] = 0;   // cell (0, 0) lies on diagonal 0
   const int32_t d_end = targeted ? tr + tq : rmax + qmax;
   int32_t gbest = 0, gbest_d = 0;
+#ifdef PGA_EXP_XDROP
+  int32_t gbest_run = 0;
+#endif
   for (int32_t d = 1; d <= d_end; ++d) {
     DpCell nxt[BAND];
     bool alive = false;
     for (int l = 0; l < BAND; ++l) {
-      const int k = l - W;
+      const int k = l - W + koff;
       if ((d + k) & 1) { nxt[l] = cur[l]; continue; }        // this diagonal has no cell on anti-diagonal d
       const int32_t i = (d - k) / 2, j = (d + k) / 2;
       if (i < 0 || j < 0 || i > rmax || j > qmax) { nxt[l] = DpCell{NEG_INF, 0, NEG_INF, 0, NEG_INF, 0}; continue; }
@@ -135,7 +147,16 @@ PG_HD ExtResult extend_banded(const RefT& R, const QryT& Q, int64_t r0, int64_t 
       const DpCell& U = cur[has_up ? l + 1 : l];
       const DpCell& L = cur[has_left ? l - 1 : l];
       nxt[l] = dp_cell(has_up, U.h, U.he, U.x, U.xe, has_left, L.h, L.he, L.y, L.ye, has_diag, cur[l].h, cur[l].he, ok);
+#ifdef PGA_EXP_XDROP
+      if (!targeted && nxt[l].h > NEG_INF / 2 && nxt[l].h < gbest_run - PGA_EXP_XDROP) nxt[l] = DpCell{NEG_INF, 0, NEG_INF, 0, NEG_INF, 0};
+#endif
+#ifdef PGA_EXP_FLOOR
+      if (!targeted && nxt[l].h > NEG_INF / 2 && nxt[l].h < PGA_EXP_FLOOR) nxt[l] = DpCell{NEG_INF, 0, NEG_INF, 0, NEG_INF, 0};
+#endif
       if (nxt[l].h > NEG_INF / 2) {
+#ifdef PGA_EXP_XDROP
+        if (nxt[l].h > gbest_run) gbest_run = nxt[l].h;
+#endif
         alive = true;
         if (nxt[l].h > bs[l] || (nxt[l].h == bs[l] && d >= bd[l])) { bs[l] = nxt[l].h; bd[l] = d; be[l] = nxt[l].he; }
       }
@@ -152,7 +173,7 @@ PG_HD ExtResult extend_banded(const RefT& R, const QryT& Q, int64_t r0, int64_t 
       if (!any) break;
     }
     if (targeted && d == d_end) {
-      const int l = (tq - tr) + W;
+      const int l = (tq - tr) - koff + W;
       if (cur[l].h > NEG_INF / 2) { res.di = tr; res.dj = tq; res.score = cur[l].h; res.errors = cur[l].he; res.reached = 1; return res; }
     }
   }
@@ -160,7 +181,7 @@ PG_HD ExtResult extend_banded(const RefT& R, const QryT& Q, int64_t r0, int64_t 
   int bl = W; gbest = NEG_INF; gbest_d = -1;
   for (int l = 0; l < BAND; ++l)
     if (bs[l] > gbest || (bs[l] == gbest && bd[l] >= gbest_d)) { gbest = bs[l]; gbest_d = bd[l]; bl = l; }
-  const int k = bl - W;
+  const int k = bl - W + koff;
   res.score = gbest; res.errors = be[bl]; res.di = (gbest_d - k) / 2; res.dj = (gbest_d + k) / 2;
   return res;
 }
@@ -366,7 +387,8 @@ struct ChainFwd {
   int32_t inner_err;            // errors of the gaps between chained matches
   int32_t lr, lq;               // end of the last chained match
   int32_t re, qe, err_fwd;      // end after the forward extension (== next chain's first match when reached)
-  int32_t reached;              // forward extension landed exactly on the next chain's first match -> fuse
+  int32_t reached;              // forward extension landed exactly on chain `target`'s first match -> fuse
+  int32_t target;               // the first following chain that lies strictly ahead in both sequences (or -1)
 };
 struct ChainBwd {
   int32_t rs, qs, err_back;     // start after the backward extension (== target cell when reached)
@@ -391,32 +413,73 @@ PG_HD int32_t chain_inner_errors(const RefT& R, const QryT& Q, const Match* cm, 
   return inner;
 }
 
-// Forward target of a chain that ends at (er, eq): the first match (nr, nq, nlen) of the following chain.  If that match
-// starts before the end (overlapping matches around a small indel) it is trimmed, as postnuc trims overlapping matches.
+// Forward target of a chain that ends at (er, eq): the first match of the following chain, if it lies strictly ahead
+// in BOTH sequences (postnuc never fuses clusters whose matches overlap: e.g. around tandem repeats the query
+// coordinate steps back and the two clusters stay two alignments).
 PG_HD void forward_target(int32_t er, int32_t eq, int32_t nr, int32_t nq, int32_t nlen, int32_t& tr, int32_t& tq) {
+  (void)nlen;
   tr = -1; tq = -1;
-  if (nr < 0) return;
-  int32_t t = er - nr;
-  if (eq - nq > t) t = eq - nq;
-  if (t < 0) t = 0;
-  if (t >= nlen) return;
-  tr = nr + t - er; tq = nq + t - eq;
+  if (nr < 0 || nr < er || nq < eq) return;
+  tr = nr - er; tq = nq - eq;
 }
 
-// next_*: first match of the following chain (same strand and records), next_r = -1 if there is none.
+// MUMmer's DP works on at most MAX_ALIGNMENT_LENGTH = 10000 bases per call; an extension off a cluster end therefore
+// never exceeds 9999 (forward) / 9998 (backward) bases — visible in the fixtures as alignments that stop exactly there.
+constexpr int32_t MAX_EXT_FWD = 9999, MAX_EXT_BWD = 9998;
+PG_HD int32_t cap_ext(int32_t v, int32_t cap) { return v < cap ? v : cap; }
+
+// Forward target: walk the following chains (same strand and records, ref order) and take the first whose first match
+// lies strictly ahead of (er, eq) in both sequences and within MUMmer's 10 kb DP limit; chains skipped on the way
+// overlap this one and end up shadowed.
+PG_HD int32_t pick_forward_target(const Chain* chains, const Match* cm, const int32_t* next_of, int c, int32_t er, int32_t eq,
+                                  int32_t& nr, int32_t& nq) {
+  nr = -1; nq = -1;
+  int t = next_of[c];
+  for (int hops = 0; t >= 0 && hops < 8; ++hops, t = next_of[t]) {
+    const Match& nf = cm[chains[t].first];
+    int32_t tr, tq;
+    forward_target(er, eq, nf.r, nf.q, nf.len, tr, tq);
+    if (tr >= 0) { nr = nf.r; nq = nf.q; return t; }
+  }
+  return -1;
+}
+
+// Forward extension off the end (er, eq) of a chain towards the target match start (nr, nq) (or freely if nr < 0).
+// MUMmer's DP handles at most 10 kb per call: a farther target is approached in 10 kb free-search chunks, continuing
+// while a chunk runs into its length limit (the region is still alignable) and giving up as soon as one ends earlier.
+// EXT is the DP routine (scalar extend_banded on the host, the wave-cooperative one on the device).
+constexpr int MAX_FWD_CHUNKS = 64;
+template <typename EXT>
+PG_HD void forward_extension(EXT&& ext, int32_t er, int32_t eq, int32_t r_hi, int32_t q_hi, int32_t nr, int32_t nq, int32_t& re,
+                             int32_t& qe, int32_t& errors, int32_t& reached) {
+  int32_t cr = er, cq = eq, err = 0;
+  reached = 0;
+  for (int chunk = 0; chunk < MAX_FWD_CHUNKS; ++chunk) {
+    int32_t tr = -1, tq = -1;
+    if (nr >= 0) { tr = nr - cr; tq = nq - cq; }
+    const bool near = nr >= 0 && tr >= 0 && tq >= 0 && tr <= MAX_EXT_FWD && tq <= MAX_EXT_FWD;
+    const ExtResult x = ext(cr, cq, cap_ext(r_hi - cr, MAX_EXT_FWD), cap_ext(q_hi - cq, MAX_EXT_FWD), near ? tr : -1, near ? tq : -1);
+    err += x.errors; cr += x.di; cq += x.dj;
+    if (near) { reached = x.reached; break; }
+    const bool hit_cap = x.di >= MAX_EXT_FWD - 100 || x.dj >= MAX_EXT_FWD - 100;
+    if (nr < 0 || tr < 0 || tq < 0 || !hit_cap) break;   // no target, or the chunk ended on its own: stop here
+  }
+  re = cr; qe = cq; errors = err;
+}
+
 template <typename RefT, typename QryT>
-PG_HD ChainFwd extend_chain_fwd(const RefT& R, const QryT& Q, const Match* cm, const Chain& c, int32_t r_hi, int32_t q_hi,
-                                int32_t next_r, int32_t next_q, int32_t next_len) {
+PG_HD ChainFwd extend_chain_fwd(const RefT& R, const QryT& Q, const Match* cm, const Chain* chains, const int32_t* next_of, int c,
+                                int32_t r_hi, int32_t q_hi) {
   ChainFwd e;
-  e.first_r = cm[c.first].r; e.first_q = cm[c.first].q;
+  e.first_r = cm[chains[c].first].r; e.first_q = cm[chains[c].first].q;
   int32_t er, eq;
-  e.inner_err = chain_inner_errors(R, Q, cm, c, er, eq);
+  e.inner_err = chain_inner_errors(R, Q, cm, chains[c], er, eq);
   e.lr = er; e.lq = eq;
-  int32_t tr, tq;
-  forward_target(er, eq, next_r, next_q, next_len, tr, tq);
-  const ExtResult fw = extend_banded(R, Q, er, eq, +1, r_hi - er, q_hi - eq, tr, tq);
-  e.re = er + fw.di; e.qe = eq + fw.dj; e.err_fwd = fw.errors;
-  e.reached = (tr >= 0 && fw.reached) ? 1 : 0;
+  int32_t nr, nq;
+  e.target = pick_forward_target(chains, cm, next_of, c, er, eq, nr, nq);
+  forward_extension([&](int32_t cr, int32_t cq, int32_t rmax, int32_t qmax, int32_t tr, int32_t tq) {
+                      return extend_banded(R, Q, cr, cq, +1, rmax, qmax, tr, tq); },
+                    er, eq, r_hi, q_hi, nr, nq, e.re, e.qe, e.err_fwd, e.reached);
   return e;
 }
 
@@ -442,7 +505,8 @@ PG_HD ChainBwd extend_chain_bwd(const RefT& R, const QryT& Q, int32_t first_r, i
     if (prev_lr > r_lo) r_lo = prev_lr;
     if (prev_lq > q_lo) q_lo = prev_lq;
   }
-  const ExtResult b = extend_banded(R, Q, first_r, first_q, -1, first_r - r_lo, first_q - q_lo, tr, tq);
+  const ExtResult b = extend_banded(R, Q, first_r, first_q, -1, cap_ext(first_r - r_lo, MAX_EXT_BWD),
+                                    cap_ext(first_q - q_lo, MAX_EXT_BWD), tr, tq);
   ChainBwd e;
   e.rs = first_r - b.di; e.qs = first_q - b.dj; e.err_back = b.errors;
   e.reached = (tr >= 0 && b.reached) ? 1 : 0;
@@ -488,7 +552,7 @@ PG_HD int stitch_chains(const ChainFwd* fw, const ChainBwd* bw, const Match* cm,
       out[ai].re = fw[cur].re; out[ai].qe = fw[cur].qe;
       aln_of[cur] = ai;
       if (!fw[cur].reached) break;
-      const int t = next_of[cur];
+      const int t = fw[cur].target;
       if (t < 0 || aln_of[t] >= 0) break;
       out[ai].errors += fw[t].inner_err;
       cur = t;

@@ -76,34 +76,32 @@ def fixture_runs(eng, genome_dir, gold):
 
 
 def test_alignment_search_vs_real_mummer_output(fixture_runs):
-    """17 ordered pairs with both genomes and real nucmer+delta-filter output.  Current engine state (round 1):
-    |d identity| <= 2.5e-2 everywhere, median <= 2e-3, aligned length within 4 %; the bar to reach is 1e-4."""
+    """17 ordered pairs with both genomes and real nucmer+delta-filter output.  Engine state (round 1): 14 of 17 pairs
+    within BASELINE.json's 1e-4 identity bar (11 of them to the last digit), the other three within 1e-2 (cluster
+    junctions with a > 60-base diagonal shift are not fused yet); aligned lengths within 1.5 % everywhere."""
     assert len(fixture_runs) == 17
     d_id = []
     for rel, a, b, r, want in fixture_runs:
         assert int(r["status"]) == 0, rel
         d_id.append(abs(float(r["identity"]) - want[2]))
-        assert d_id[-1] <= 2.5e-2, (rel, float(r["identity"]), want[2])
-        assert abs(int(r["ref_aln_len"]) - want[0]) <= 0.04 * want[0], rel
-        assert abs(int(r["qry_aln_len"]) - want[1]) <= 0.04 * want[1], rel
-    assert float(np.median(d_id)) <= 2e-3
-    assert sum(d <= 1e-4 for d in d_id) >= 4
+        assert d_id[-1] <= 1e-2, (rel, float(r["identity"]), want[2])
+        assert abs(int(r["ref_aln_len"]) - want[0]) <= 0.015 * want[0], rel
+        assert abs(int(r["qry_aln_len"]) - want[1]) <= 0.015 * want[1], rel
+    assert sum(d <= 1e-4 for d in d_id) >= 14
+    assert float(np.median(d_id)) == 0.0
 
 
 def test_pairs_reproduced_exactly(fixture_runs):
-    """Pairs the engine already reproduces to the last digit (alignment set identical to MUMmer's)."""
-    exact = {"GCF_000331065.1_ASM33106v1_genomic_vs_GCF_000973505.1_ASM97350v1_genomic",
-             "GCF_000973505.1_ASM97350v1_genomic_vs_GCF_000973545.1_ASM97354v1_genomic"}
-    seen = 0
+    """Pairs whose parse_delta tuple is reproduced to the last digit (same alignment set as MUMmer's)."""
+    n_exact = 0
     for rel, a, b, r, want in fixture_runs:
-        if f"{a}_vs_{b}" in exact:
-            seen += 1
+        exact = ([int(r["ref_aln_len"]), int(r["qry_aln_len"]), int(r["sim_errors"])] == [want[0], want[1], want[3]]
+                 and float(r["identity"]).hex() == float(want[2]).hex())
+        n_exact += exact
+        if a.startswith("NC_"):      # near-identical Caulobacter pair: lengths and errors exact, identity within 1e-10
             assert [int(r["ref_aln_len"]), int(r["qry_aln_len"]), int(r["sim_errors"])] == [want[0], want[1], want[3]]
-            assert float(r["identity"]).hex() == float(want[2]).hex()
-        if a.startswith("NC_"):      # near-identical Caulobacter pair: aligned lengths exact, identity within 1e-5
-            assert [int(r["ref_aln_len"]), int(r["qry_aln_len"])] == [want[0], want[1]]
-            assert abs(float(r["identity"]) - want[2]) < 1e-5
-    assert seen == 2
+            assert abs(float(r["identity"]) - want[2]) < 1e-10
+    assert n_exact >= 10
 
 
 def test_module_api_and_matrices(eng, genome_dir):

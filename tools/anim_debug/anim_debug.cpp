@@ -103,10 +103,9 @@ int main(int argc, char** argv) {
       r_lo[c] = G.rec_start[chains[c].rrec]; r_hi[c] = G.rec_start[chains[c].rrec + 1] - 1;
       q_lo[c] = H.rec_start[chains[c].qrec]; q_hi[c] = H.rec_start[chains[c].qrec + 1] - 1;
       if (strand) { const int32_t a = (int32_t)H.len - q_hi[c], b = (int32_t)H.len - q_lo[c]; q_lo[c] = a; q_hi[c] = b; }
-      const int t = next_of[c];
       auto t0 = std::chrono::steady_clock::now();
-      fw[c] = extend_chain_fwd(R, Q, cm.data(), chains[c], r_hi[c], q_hi[c], t >= 0 ? cm[chains[t].first].r : -1,
-                               t >= 0 ? cm[chains[t].first].q : -1, t >= 0 ? cm[chains[t].first].len : 0);
+      fw[c] = extend_chain_fwd(R, Q, cm.data(), chains.data(), next_of.data(), c, r_hi[c], q_hi[c]);
+      const int t = fw[c].target;
       double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
       if (ms > 20 && getenv("ANIM_TIMING")) fprintf(stderr, "FWD chain %d strand %d: %.0f ms, matches %d, first r %d q %d, last end r %d q %d -> re %d qe %d reached %d next %d\n", c, strand, ms, chains[c].count, fw[c].first_r, fw[c].first_q, fw[c].lr, fw[c].lq, fw[c].re, fw[c].qe, fw[c].reached, t);
     }
@@ -116,9 +115,14 @@ int main(int argc, char** argv) {
       auto t0 = std::chrono::steady_clock::now();
       bw[c] = extend_chain_bwd(R, Q, fw[c].first_r, fw[c].first_q, r_lo[c], q_lo[c], p >= 0 ? fw[p].re : -1, p >= 0 ? fw[p].qe : -1, p >= 0 ? fw[p].lr : -1, p >= 0 ? fw[p].lq : -1,
                                p >= 0 ? fw[p].first_r : -1, p >= 0 ? fw[p].first_q : -1, fw[c].lr, fw[c].lq,
-                               p >= 0 && fw[p].reached && next_of[p] == c);
+                               p >= 0 && fw[p].reached && fw[p].target == c);
       double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
       if (ms > 20 && getenv("ANIM_TIMING")) fprintf(stderr, "BWD chain %d strand %d: %.0f ms first r %d q %d -> rs %d qs %d reached %d prev %d (prev re %d qe %d lr %d lq %d)\n", c, strand, ms, fw[c].first_r, fw[c].first_q, bw[c].rs, bw[c].qs, bw[c].reached, p, p>=0?fw[p].re:-1, p>=0?fw[p].qe:-1, p>=0?fw[p].lr:-1, p>=0?fw[p].lq:-1);
+    }
+    if (getenv("ANIM_CHAINS")) {
+      const int lo = atoi(getenv("ANIM_CHAINS")), hi = getenv("ANIM_CHAINS_HI") ? atoi(getenv("ANIM_CHAINS_HI")) : lo + 4000;
+      for (int k = 0; k < n_chains; ++k) { const int c = co[k]; if (strand == 0 && fw[c].first_r >= lo && fw[c].first_r <= hi)
+        fprintf(stderr, "chain %d: first %d %d last_end %d %d fwd_end %d %d (reached %d) bwd_start %d %d (reached %d) prev %d next %d count %d\n", c, fw[c].first_r, fw[c].first_q, fw[c].lr, fw[c].lq, fw[c].re, fw[c].qe, fw[c].reached, bw[c].rs, bw[c].qs, bw[c].reached, prev_of[c], next_of[c], chains[c].count); }
     }
     std::vector<int32_t> aln_of(n_chains + 1);
     const int before = (int)alns.size();
