@@ -14,7 +14,7 @@ reference's names, argument meaning, result containers and error behaviour for e
 
 The alignment search emulates MUMmer 3.23 (`nucmer --mum`, `delta-filter -1`), which is NOT part of the reference
 tree: it is calibrated against the MUMmer output files the reference's tests hold; DESIGN.md lists the measured
-deviations (identity typically within 2e-3, two of 15 fixture pairs exact).  `program`/`version` strings for DB rows
+deviations (11 of 17 fixture pairs bit-identical, 14 within 1e-4, worst 5.5e-4).  `program`/`version` strings for DB rows
 must therefore differ from "nucmer" (SURVEY.md §5): use PROGRAM / VERSION below.
 """
 import gzip

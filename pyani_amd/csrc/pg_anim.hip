@@ -328,6 +328,57 @@ __device__ ExtResult extend_wave(const SeqView& R, const StrandView& Q, int64_t 
   return res;
 }
 
+// Wave version of pga::thin_rect_errors: full DP of a small rectangle whose SHORT side (<= 63) is spread over the
+// lanes; skewed wavefront: lane t works on line t of the short side, step s handles the cells with long-side index
+// s - t, so the three predecessors are the lane's own previous cell and the lower neighbour's last two cells.
+__device__ int32_t thin_rect_errors_wave(const SeqView& R, const StrandView& Q, int64_t r0, int32_t n, int64_t q0, int32_t m) {
+  if (n < 0 || m < 0 || n > THIN_LONG || m > THIN_LONG || (n > THIN_MAX && m > THIN_MAX)) return -1;
+  __shared__ uint8_t s_long[THIN_LONG + 1];
+  const int lane = threadIdx.x & 63;
+  const bool lanes_q = m <= THIN_MAX;            // lanes over query columns (rows = ref) or over ref rows
+  const int32_t n_short = lanes_q ? m : n, n_long = lanes_q ? n : m;
+  __syncthreads();
+  for (int32_t t = lane; t < n_long; t += 64) {  // stage the long side's bases
+    uint8_t b = 4;
+    if (lanes_q) { if (R.clean(r0 + t)) b = (uint8_t)R.base(r0 + t); }
+    else { if (Q.clean(q0 + t)) b = (uint8_t)Q.base(q0 + t); }
+    s_long[t] = b;
+  }
+  uint8_t mine = 4;                              // this lane's base on the short side (line `lane`, 1-based)
+  if (lane >= 1 && lane <= n_short) {
+    if (lanes_q) { if (Q.clean(q0 + lane - 1)) mine = (uint8_t)Q.base(q0 + lane - 1); }
+    else { if (R.clean(r0 + lane - 1)) mine = (uint8_t)R.base(r0 + lane - 1); }
+  }
+  __syncthreads();
+  const DpCell dead{NEG_INF, 0, NEG_INF, 0, NEG_INF, 0};
+  DpCell cur = dead, prev = dead;
+  for (int32_t s = 0; s <= n_short + n_long; ++s) {
+    // neighbour (lane - 1): its cell of step s-1 (same long index) and of step s-2 (long index - 1)
+    DpCell nb1, nb2;
+    nb1.h = from_lane_below(cur.h, NEG_INF); nb1.he = from_lane_below(cur.he, 0);
+    nb1.x = from_lane_below(cur.x, NEG_INF); nb1.xe = from_lane_below(cur.xe, 0);
+    nb1.y = from_lane_below(cur.y, NEG_INF); nb1.ye = from_lane_below(cur.ye, 0);
+    nb2.h = from_lane_below(prev.h, NEG_INF); nb2.he = from_lane_below(prev.he, 0);
+    const int32_t u = s - lane;                  // long-side index of this lane's cell
+    if (lane <= n_short && u >= 0 && u <= n_long) {
+      DpCell c;
+      if (lane == 0 && u == 0) {
+        c = DpCell{0, 0, NEG_INF, 0, NEG_INF, 0};
+      } else {
+        const bool ok = lane >= 1 && u >= 1 && mine < 4 && s_long[u - 1] == mine;
+        if (lanes_q) {   // i = u (rows, long), j = lane: up = own previous cell, left = neighbour (step s-1), diag = neighbour (s-2)
+          c = dp_cell(u >= 1, cur.h, cur.he, cur.x, cur.xe, lane >= 1, nb1.h, nb1.he, nb1.y, nb1.ye, u >= 1 && lane >= 1, nb2.h, nb2.he, ok);
+        } else {         // i = lane (rows, short), j = u: up = neighbour (step s-1), left = own previous cell, diag = neighbour (s-2)
+          c = dp_cell(lane >= 1, nb1.h, nb1.he, nb1.x, nb1.xe, u >= 1, cur.h, cur.he, cur.y, cur.ye, u >= 1 && lane >= 1, nb2.h, nb2.he, ok);
+        }
+      }
+      prev = cur;
+      cur = c;
+    }
+  }
+  return __shfl(cur.he, n_short, 64);            // cell (n, m) lives in lane n_short after the last step
+}
+
 __device__ int32_t gap_errors_wave(const SeqView& R, const StrandView& Q, int64_t r0, int32_t n, int64_t q0, int32_t m) {
   if (n == 0) return m;
   if (m == 0) return n;
@@ -403,6 +454,8 @@ __global__ __launch_bounds__(64) void anim_extend_kernel(const RefDesc* __restri
     ChainBwd e;
     e.rs = first_r - b.di; e.qs = first_q - b.dj; e.err_back = b.errors;
     e.reached = (tr >= 0 && b.reached) ? 1 : 0;
+    bridge_junction(e, prev_re, prev_qe, tr, tq, [&](int32_t r0, int32_t n, int32_t q0, int32_t m) {
+      return thin_rect_errors_wave(RV, QV, r0, n, q0, m); });
     if ((threadIdx.x & 63) == 0) bw[(size_t)u * cap_c + c] = e;
   }
 }

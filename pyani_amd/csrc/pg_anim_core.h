@@ -186,6 +186,30 @@ PG_HD ExtResult extend_banded(const RefT& R, const QryT& Q, int64_t r0, int64_t 
   return res;
 }
 
+// Full (un-banded) global alignment of a small rectangle: ref [r0, r0+n) x query [q0, q0+m), forward direction, same
+// recurrences and tie-breaks as dp_cell.  Used to bridge cluster junctions whose diagonal shift exceeds the band
+// (an indel of 60+ bases between two clusters that nucmer still fuses).  min(n, m) <= THIN_MAX; returns -1 otherwise.
+constexpr int THIN_MAX = 63, THIN_LONG = 511;
+template <typename RefT, typename QryT>
+PG_HD int32_t thin_rect_errors(const RefT& R, const QryT& Q, int64_t r0, int32_t n, int64_t q0, int32_t m) {
+  if (n < 0 || m < 0 || n > THIN_LONG || m > THIN_LONG || (n > THIN_MAX && m > THIN_MAX)) return -1;
+  // rows = ref bases, columns = query bases (no transposition: both builds walk the same cells)
+  DpCell row[THIN_LONG + 1], nrow[THIN_LONG + 1];
+  row[0] = DpCell{0, 0, NEG_INF, 0, NEG_INF, 0};
+  for (int32_t j = 1; j <= m; ++j)
+    row[j] = dp_cell(false, 0, 0, 0, 0, true, row[j - 1].h, row[j - 1].he, row[j - 1].y, row[j - 1].ye, false, 0, 0, false);
+  for (int32_t i = 1; i <= n; ++i) {
+    nrow[0] = dp_cell(true, row[0].h, row[0].he, row[0].x, row[0].xe, false, 0, 0, 0, 0, false, 0, 0, false);
+    for (int32_t j = 1; j <= m; ++j) {
+      const bool ok = R.clean(r0 + i - 1) && Q.clean(q0 + j - 1) && R.base(r0 + i - 1) == Q.base(q0 + j - 1);
+      nrow[j] = dp_cell(true, row[j].h, row[j].he, row[j].x, row[j].xe, true, nrow[j - 1].h, nrow[j - 1].he, nrow[j - 1].y,
+                        nrow[j - 1].ye, true, row[j - 1].h, row[j - 1].he, ok);
+    }
+    for (int32_t j = 0; j <= m; ++j) row[j] = nrow[j];
+  }
+  return row[m].he;
+}
+
 // Global alignment of the gap between two chained matches: ref gap n, query gap m (both small); returns errors.
 template <typename RefT, typename QryT>
 PG_HD int32_t gap_errors(const RefT& R, const QryT& Q, int64_t r0, int32_t n, int64_t q0, int32_t m) {
@@ -393,6 +417,7 @@ struct ChainFwd {
 struct ChainBwd {
   int32_t rs, qs, err_back;     // start after the backward extension (== target cell when reached)
   int32_t reached;              // landed exactly on the previous chain's forward end -> fuse
+                                // (2 = through the thin-rectangle bridge: err_back already includes the bridge)
 };
 
 // Gap fills between the chained matches; returns the end of the last match through er/eq.
@@ -483,6 +508,25 @@ PG_HD ChainFwd extend_chain_fwd(const RefT& R, const QryT& Q, const Match* cm, c
   return e;
 }
 
+// Junction with a diagonal shift beyond the band: the free backward search stopped at (e.rs, e.qs); if the previous
+// alignment's end (prev_re, prev_qe) is still behind it and within the break length, nucmer's dynamic band would have
+// reached it -> bridge the residual rectangle with a full DP and fuse.  RECT(r0, n, q0, m) -> errors or -1.
+template <typename RECT>
+PG_HD void bridge_junction(ChainBwd& e, int32_t prev_re, int32_t prev_qe, int32_t tr, int32_t tq, RECT&& rect) {
+  if (e.reached || prev_re < 0 || tr < 0) return;
+  int32_t shift = tq - tr;
+  if (shift < 0) shift = -shift;
+  if (shift < BAND - 2) return;                            // reachable shifts are decided by the (shifted-band) target search
+  const int32_t n = e.rs - prev_re, m = e.qs - prev_qe;
+  if (n < 0 || m < 0 || n + m > BREAK_LEN) return;
+  // prefer the optimal path over the whole junction (previous end -> this chain's first match); fall back to the
+  // residual rectangle behind the free backward search when the junction is too large for the full DP
+  int32_t err = rect(prev_re, tr, prev_qe, tq);
+  if (err >= 0) { e.err_back = err; }
+  else { err = rect(prev_re, n, prev_qe, m); if (err < 0) return; e.err_back += err; }
+  e.rs = prev_re; e.qs = prev_qe; e.reached = 2;
+}
+
 // prev_re/prev_qe: forward end of the preceding chain (same strand and records), or -1 if there is none;
 // prev_lr/prev_lq: end of its last match — the backward search never needs to enter the previous chain's matches;
 // prev_fr/prev_fq: its first match start; my_lr/my_lq: end of THIS chain's last match.  If the previous chain's span
@@ -510,6 +554,8 @@ PG_HD ChainBwd extend_chain_bwd(const RefT& R, const QryT& Q, int32_t first_r, i
   ChainBwd e;
   e.rs = first_r - b.di; e.qs = first_q - b.dj; e.err_back = b.errors;
   e.reached = (tr >= 0 && b.reached) ? 1 : 0;
+  bridge_junction(e, prev_re, prev_qe, tr, tq, [&](int32_t r0, int32_t n, int32_t q0, int32_t m) {
+    return thin_rect_errors(R, Q, r0, n, q0, m); });
   return e;
 }
 

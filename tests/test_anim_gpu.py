@@ -76,18 +76,19 @@ def fixture_runs(eng, genome_dir, gold):
 
 
 def test_alignment_search_vs_real_mummer_output(fixture_runs):
-    """17 ordered pairs with both genomes and real nucmer+delta-filter output.  Engine state (round 1): 14 of 17 pairs
-    within BASELINE.json's 1e-4 identity bar (11 of them to the last digit), the other three within 1e-2 (cluster
-    junctions with a > 60-base diagonal shift are not fused yet); aligned lengths within 1.5 % everywhere."""
+    """17 ordered pairs with both genomes and real nucmer+delta-filter output.  Engine state (round 1): 15 of 17 pairs
+    within 1.5e-4 of nucmer's identity (11 of them to the last digit; BASELINE.json's bar is 1e-4), worst 5.5e-4;
+    aligned lengths within 1 % everywhere."""
     assert len(fixture_runs) == 17
     d_id = []
     for rel, a, b, r, want in fixture_runs:
         assert int(r["status"]) == 0, rel
         d_id.append(abs(float(r["identity"]) - want[2]))
-        assert d_id[-1] <= 1e-2, (rel, float(r["identity"]), want[2])
-        assert abs(int(r["ref_aln_len"]) - want[0]) <= 0.015 * want[0], rel
-        assert abs(int(r["qry_aln_len"]) - want[1]) <= 0.015 * want[1], rel
+        assert d_id[-1] <= 1e-3, (rel, float(r["identity"]), want[2])
+        assert abs(int(r["ref_aln_len"]) - want[0]) <= 0.01 * want[0], rel
+        assert abs(int(r["qry_aln_len"]) - want[1]) <= 0.01 * want[1], rel
     assert sum(d <= 1e-4 for d in d_id) >= 14
+    assert sum(d <= 1.5e-4 for d in d_id) >= 15
     assert float(np.median(d_id)) == 0.0
 
 
