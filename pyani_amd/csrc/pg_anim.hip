@@ -94,8 +94,10 @@ __global__ __launch_bounds__(256) void anim_index_kernel(const RefDesc* __restri
   }
 }
 
+// moff[u] .. moff[u+1]: this unit's slice of every per-match array (exact size, from a first count-only pass)
 __global__ __launch_bounds__(256) void anim_seed_kernel(const RefDesc* __restrict__ refs, const UnitDesc* __restrict__ units,
-                                                        Match* __restrict__ mem, uint32_t* __restrict__ mem_count, uint32_t cap_m) {
+                                                        Match* __restrict__ mem, uint32_t* __restrict__ mem_count,
+                                                        const uint32_t* __restrict__ moff, int count_only) {
   const UnitDesc U = units[blockIdx.y];
   const RefDesc R = refs[U.ref];
   const int32_t q = blockIdx.x * blockDim.x + threadIdx.x;  // strand position
@@ -117,6 +119,7 @@ __global__ __launch_bounds__(256) void anim_seed_kernel(const RefDesc* __restric
     if ((v >> 24) != k) continue;
     const int32_t r = (int32_t)(v & 0xFFFFFFu);
     if (RV.clean(r - 1) && QV.clean(q - 1) && RV.base(r - 1) == QV.base(q - 1)) continue;  // not left-maximal
+    if (count_only) { atomicAdd(&mem_count[blockIdx.y], 1u); continue; }
     int32_t L = MIN_MATCH;
     // right extension, 16 bases per step (word compare of the packed codes and masks), then base by base
     for (;;) {
@@ -144,49 +147,52 @@ __global__ __launch_bounds__(256) void anim_seed_kernel(const RefDesc* __restric
     }
     while (RV.clean(r + L) && QV.clean(q + L) && RV.base(r + L) == QV.base(q + L)) ++L;
     const uint32_t at = atomicAdd(&mem_count[blockIdx.y], 1u);
-    if (at < cap_m) mem[(size_t)blockIdx.y * cap_m + at] = Match{r, q, L, U.strand};
+    if (at < moff[blockIdx.y + 1] - moff[blockIdx.y]) mem[(size_t)moff[blockIdx.y] + at] = Match{r, q, L, U.strand};
   }
 }
 
-struct ClusterOut {
-  Match* cm;            // [U][cap_m]
-  Chain* chains;        // [U][cap_c]
+struct ClusterOut {   // per-match arrays are sliced by moff[] (a chain has >= 1 match, so chains fit the same slices)
+  const uint32_t* moff; // [U + 1]
+  Match* cm;
+  Chain* chains;
   int32_t* n_chains;    // [U]
-  int32_t* order;       // [U][cap_c] chains sorted by first-match ref start
-  int32_t* prev_of;     // [U][cap_c]
-  int32_t* next_of;     // [U][cap_c]
+  int32_t* order;       // chains sorted by first-match ref start
+  int32_t* prev_of;
+  int32_t* next_of;
   int32_t* status;      // [P]
 };
 
 __global__ __launch_bounds__(64) void anim_cluster_kernel(const RefDesc* __restrict__ refs, const UnitDesc* __restrict__ units, uint32_t n_units,
                                                           Match* __restrict__ mem, const uint32_t* __restrict__ mem_count,
-                                                          uint32_t cap_m, uint32_t cap_c, int32_t* __restrict__ iscratch,
-                                                          ClusterOut O) {
+                                                          int32_t* __restrict__ iscratch, ClusterOut O) {
   const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
   if (u >= n_units) return;
   const UnitDesc U = units[u];
   const RefDesc R = refs[U.ref];
   O.n_chains[u] = 0;
+  const size_t off = O.moff[u];
+  const uint32_t cap = O.moff[u + 1] - O.moff[u];
   uint32_t n0 = mem_count[u];
-  if (n0 > cap_m) { atomicOr(&O.status[U.pair], 1); n0 = cap_m; }
-  Match* m = mem + (size_t)u * cap_m;
+  if (n0 > cap) { atomicOr(&O.status[U.pair], 1); n0 = cap; }
+  if (n0 == 0) return;
+  Match* m = mem + off;
   const int n = mum_filter(m, (int)n0, U.strand);
-  int32_t* s = iscratch + (size_t)u * 7 * cap_m;
-  int32_t *rrec = s, *qrec = s + cap_m, *parent = s + 2 * cap_m, *score = s + 3 * cap_m, *from = s + 4 * cap_m,
-          *adj = s + 5 * cap_m, *order = s + 6 * cap_m;
+  int32_t* s = iscratch + off * 7;
+  int32_t *rrec = s, *qrec = s + cap, *parent = s + 2 * (size_t)cap, *score = s + 3 * (size_t)cap, *from = s + 4 * (size_t)cap,
+          *adj = s + 5 * (size_t)cap, *order = s + 6 * (size_t)cap;
   for (int i = 0; i < n; ++i) {
     rrec[i] = record_of(R.rec_start, R.n_rec, m[i].r);
     const int32_t qf = U.strand ? U.len - 1 - m[i].q : m[i].q;
     qrec[i] = record_of(U.rec_start, U.n_rec, qf);
   }
   int n_chains = 0, n_cm = 0;
-  Chain* chains = O.chains + (size_t)u * cap_c;
-  Match* cm = O.cm + (size_t)u * cap_m;
-  mgaps_strand(m, n, U.strand, rrec, qrec, parent, score, from, adj, order, chains, n_chains, (int)cap_c, cm, n_cm, (int)cap_m);
-  int32_t* co = O.order + (size_t)u * cap_c;
+  Chain* chains = O.chains + off;
+  Match* cm = O.cm + off;
+  mgaps_strand(m, n, U.strand, rrec, qrec, parent, score, from, adj, order, chains, n_chains, (int)cap, cm, n_cm, (int)cap);
+  int32_t* co = O.order + off;
   for (int i = 0; i < n_chains; ++i) co[i] = i;
   heapsort(co, n_chains, [&](int a, int b) { return cm[chains[a].first].r < cm[chains[b].first].r; });
-  chain_neighbours(chains, co, n_chains, O.prev_of + (size_t)u * cap_c, O.next_of + (size_t)u * cap_c);
+  chain_neighbours(chains, co, n_chains, O.prev_of + off, O.next_of + off);
   O.n_chains[u] = n_chains;
 }
 
@@ -396,8 +402,8 @@ __device__ int32_t gap_errors_wave(const SeqView& R, const StrandView& Q, int64_
 
 // One WAVE per chain (work list wl: unit, chain).  phase 0: gap fills + free forward extension (extend_chain_fwd);
 // phase 1: backward extension towards the previous chain's forward end (extend_chain_bwd).
-__global__ __launch_bounds__(64) void anim_extend_kernel(const RefDesc* __restrict__ refs, const UnitDesc* __restrict__ units, uint32_t cap_m,
-                                                         uint32_t cap_c, ClusterOut O, const uint2* __restrict__ wl,
+__global__ __launch_bounds__(64) void anim_extend_kernel(const RefDesc* __restrict__ refs, const UnitDesc* __restrict__ units,
+                                                         ClusterOut O, const uint2* __restrict__ wl,
                                                          ChainFwd* __restrict__ fw, ChainBwd* __restrict__ bw, int phase) {
   const uint32_t u = wl[blockIdx.x].x;
   const int32_t c = (int32_t)wl[blockIdx.x].y;
@@ -405,11 +411,12 @@ __global__ __launch_bounds__(64) void anim_extend_kernel(const RefDesc* __restri
   const RefDesc R = refs[U.ref];
   const SeqView RV{R.codes, R.mask, R.len};
   const StrandView QV{SeqView{U.codes, U.mask, U.len}, U.strand};
-  const Chain ch = O.chains[(size_t)u * cap_c + c];
+  const size_t off = O.moff[u];
+  const Chain ch = O.chains[off + c];
   int32_t r_lo, r_hi, q_lo, q_hi;
   chain_bounds(R, U, ch, r_lo, r_hi, q_lo, q_hi);
-  ChainFwd* fwu = fw + (size_t)u * cap_c;
-  const Match* cm = O.cm + (size_t)u * cap_m;
+  ChainFwd* fwu = fw + off;
+  const Match* cm = O.cm + off;
   if (phase == 0) {
     ChainFwd e;
     const Match f = cm[ch.first];
@@ -427,18 +434,18 @@ __global__ __launch_bounds__(64) void anim_extend_kernel(const RefDesc* __restri
     e.inner_err = inner;
     e.lr = er; e.lq = eq;
     int32_t nr, nq;
-    e.target = pick_forward_target(O.chains + (size_t)u * cap_c, cm, O.next_of + (size_t)u * cap_c, c, er, eq, nr, nq);
+    e.target = pick_forward_target(O.chains + off, cm, O.next_of + off, c, er, eq, nr, nq);
     forward_extension([&](int32_t cr, int32_t cq, int32_t rmax, int32_t qmax, int32_t tr, int32_t tq) {
                         return extend_wave(RV, QV, cr, cq, +1, rmax, qmax, tr, tq); },
                       er, eq, r_hi, q_hi, nr, nq, e.re, e.qe, e.err_fwd, e.reached);
     if ((threadIdx.x & 63) == 0) fwu[c] = e;
   } else {
-    const int32_t p = O.prev_of[(size_t)u * cap_c + c];
+    const int32_t p = O.prev_of[off + c];
     const int32_t first_r = fwu[c].first_r, first_q = fwu[c].first_q;
     const int32_t prev_re = p >= 0 ? fwu[p].re : -1, prev_qe = p >= 0 ? fwu[p].qe : -1;
     if (p >= 0 && ((fwu[p].reached && fwu[p].target == c) ||
                    (fwu[p].first_r <= first_r && fwu[p].first_q <= first_q && prev_re >= fwu[c].lr && prev_qe >= fwu[c].lq))) {
-      if ((threadIdx.x & 63) == 0) bw[(size_t)u * cap_c + c] = ChainBwd{first_r, first_q, 0, 0};  // will be shadowed
+      if ((threadIdx.x & 63) == 0) bw[off + c] = ChainBwd{first_r, first_q, 0, 0};  // will be shadowed
       return;
     }
     int32_t tr = -1, tq = -1;
@@ -456,41 +463,42 @@ __global__ __launch_bounds__(64) void anim_extend_kernel(const RefDesc* __restri
     e.reached = (tr >= 0 && b.reached) ? 1 : 0;
     bridge_junction(e, prev_re, prev_qe, tr, tq, [&](int32_t r0, int32_t n, int32_t q0, int32_t m) {
       return thin_rect_errors_wave(RV, QV, r0, n, q0, m); });
-    if ((threadIdx.x & 63) == 0) bw[(size_t)u * cap_c + c] = e;
+    if ((threadIdx.x & 63) == 0) bw[off + c] = e;
   }
 }
 
-struct FinishScratch {
-  Aln* alns;        // [P][cap_a]
-  int32_t* a_rrec;  // [P][cap_a]
+struct FinishScratch {   // per-alignment arrays: pair p owns the slice [moff[2p], moff[2p+2])
+  Aln* alns;
+  int32_t* a_rrec;
   int32_t* a_qrec;
   int32_t* idx;
   int32_t* from;
   double* sc;
-  int32_t* aln_of;  // [U][cap_c]
+  int32_t* aln_of;  // per chain
 };
 
 __global__ __launch_bounds__(64) void anim_finish_kernel(const RefDesc* __restrict__ refs, const UnitDesc* __restrict__ units, uint32_t n_pairs,
-                                                         uint32_t cap_m, uint32_t cap_c, uint32_t cap_a, ClusterOut O,
-                                                         const ChainFwd* __restrict__ fw, const ChainBwd* __restrict__ bw,
+                                                         ClusterOut O, const ChainFwd* __restrict__ fw, const ChainBwd* __restrict__ bw,
                                                          FinishScratch S, int filter_1to1, pg_anim_result* __restrict__ out) {
   const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n_pairs) return;
   const RefDesc R = refs[units[2 * p].ref];
-  Aln* alns = S.alns + (size_t)p * cap_a;
-  int32_t* a_rrec = S.a_rrec + (size_t)p * cap_a;
-  int32_t* a_qrec = S.a_qrec + (size_t)p * cap_a;
-  int32_t* idx = S.idx + (size_t)p * cap_a;
-  int32_t* from = S.from + (size_t)p * cap_a;
-  double* sc = S.sc + (size_t)p * cap_a;
+  const size_t poff = O.moff[2 * p];
+  const int cap_a = (int)(O.moff[2 * p + 2] - O.moff[2 * p]);
+  Aln* alns = S.alns + poff;
+  int32_t* a_rrec = S.a_rrec + poff;
+  int32_t* a_qrec = S.a_qrec + poff;
+  int32_t* idx = S.idx + poff;
+  int32_t* from = S.from + poff;
+  double* sc = S.sc + poff;
   int n = 0;
   for (int strand = 0; strand < 2; ++strand) {
     const uint32_t u = 2 * p + strand;  // units are laid out pair-major: (pair, fwd), (pair, rev)
     const UnitDesc U = units[u];
+    const size_t off = O.moff[u];
     const int before = n;
-    n = stitch_chains(fw + (size_t)u * cap_c, bw + (size_t)u * cap_c, O.cm + (size_t)u * cap_m, O.chains + (size_t)u * cap_c,
-                      O.order + (size_t)u * cap_c, O.prev_of + (size_t)u * cap_c, O.next_of + (size_t)u * cap_c, O.n_chains[u], strand,
-                      S.aln_of + (size_t)u * cap_c, alns, n, (int)cap_a);
+    n = stitch_chains(fw + off, bw + off, O.cm + off, O.chains + off, O.order + off, O.prev_of + off, O.next_of + off,
+                      O.n_chains[u], strand, S.aln_of + off, alns, n, cap_a);
     for (int i = before; i < n; ++i) {
       Aln& a = alns[i];
       a_rrec[i] = record_of(R.rec_start, R.n_rec, a.rs);
@@ -512,6 +520,7 @@ __global__ __launch_bounds__(64) void anim_finish_kernel(const RefDesc* __restri
   o.n_alignments = r.n_alignments;
   o.identity = r.aligned > 0 ? (double)r.weighted / (double)r.aligned : 0.0;  // int/int true division (anim.py:396)
   o.status = O.status[p] ? PG_E_CAPACITY : (r.n_alignments == 0 ? PG_ANIM_NO_ALIGNMENT : 0);
+  o.reserved = 0;
   out[p] = o;
 }
 
@@ -551,31 +560,30 @@ int anim_alloc(pg_ctx* ctx, T*& p, size_t n) {
 // Scratch lives in the context and only grows.  The per-unit kernels are latency-bound single-thread code, so the
 // batch should be as large as memory allows: thousands of units in flight are what fills the GPU.
 namespace {
-constexpr uint32_t CAP_M = 1u << 17, CAP_C = 1u << 13, CAP_A = 1u << 14;
-
 struct AnimScratch {
-  size_t units = 0, pairs = 0, refs = 0, table_slots = 0, recs = 0, wl = 0;
+  size_t units = 0, pairs = 0, refs = 0, table_slots = 0, recs = 0, wl = 0, matches = 0;
   uint64_t* table = nullptr;
   int32_t* recs_d = nullptr;
   RefDesc* refs_d = nullptr;
   UnitDesc* units_d = nullptr;
+  uint32_t *mem_count = nullptr, *moff = nullptr;
+  int32_t *nch = nullptr, *status = nullptr;
+  pg_anim_result* out = nullptr;
+  // per-match arrays (sliced by moff)
   Match *mem = nullptr, *cm = nullptr;
-  uint32_t* mem_count = nullptr;
-  int32_t *iscratch = nullptr, *nch = nullptr, *order = nullptr, *prev = nullptr, *next = nullptr, *status = nullptr, *alnof = nullptr;
+  int32_t *iscratch = nullptr, *order = nullptr, *prev = nullptr, *next = nullptr, *alnof = nullptr;
   Chain* chains = nullptr;
   ChainFwd* fw = nullptr;
   ChainBwd* bw = nullptr;
   FinishScratch S{};
-  pg_anim_result* out = nullptr;
   uint2* wl_d = nullptr;
 };
 
 template <typename T>
-int grow(pg_ctx* ctx, T*& p, size_t& have, size_t need, size_t per) {
-  (void)have;
+int regrow(pg_ctx* ctx, T*& p, size_t n) {
   if (p) PG_HIP(ctx, hipFree(p));
   p = nullptr;
-  PG_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&p), need * per * sizeof(T)));
+  PG_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&p), (n ? n : 1) * sizeof(T)));
   return PG_OK;
 }
 }  // namespace
@@ -588,20 +596,23 @@ static AnimScratch* anim_scratch(pg_ctx* ctx) {
 void pg_anim_free_scratch(pg_ctx* ctx) {
   AnimScratch* A = static_cast<AnimScratch*>(ctx->anim_scratch);
   if (!A) return;
-  void* ptrs[] = {A->table, A->recs_d, A->refs_d, A->units_d, A->mem, A->cm, A->mem_count, A->iscratch, A->nch, A->order, A->prev,
-                  A->next, A->status, A->alnof, A->chains, A->fw, A->bw, A->S.alns, A->S.a_rrec, A->S.a_qrec, A->S.idx, A->S.from,
-                  A->S.sc, A->out, A->wl_d};
+  void* ptrs[] = {A->table, A->recs_d, A->refs_d, A->units_d, A->mem_count, A->moff, A->nch, A->status, A->out, A->mem, A->cm,
+                  A->iscratch, A->order, A->prev, A->next, A->alnof, A->chains, A->fw, A->bw, A->S.alns, A->S.a_rrec,
+                  A->S.a_qrec, A->S.idx, A->S.from, A->S.sc, A->wl_d};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   delete A;
   ctx->anim_scratch = nullptr;
 }
 
+// One batch of ordered pairs (ref_ids grouped).  Two seeding passes: the first only counts the maximal matches of every
+// (pair, strand) unit, so that every per-match array gets exactly the slice it needs; this is what lets thousands of
+// units — whose single-thread cluster kernels are latency-bound — be in flight at once within the HBM budget.
+// If the batch needs more than max_matches, only its first n_done pairs are processed (the caller continues from there).
 int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_ids, uint32_t n_pairs, int filter_1to1,
-                      pg_anim_result* out_host) {
+                      uint64_t max_matches, pg_anim_result* out_host, uint32_t* n_done) {
   AnimScratch* A = anim_scratch(ctx);
-  const uint32_t n_units = 2 * n_pairs;
+  uint32_t n_units = 2 * n_pairs;
   int rc;
-  // distinct references of the batch (ref_ids arrive grouped) and their tables
   std::vector<int32_t> ref_list;
   std::vector<uint32_t> ref_of_pair(n_pairs);
   for (uint32_t p = 0; p < n_pairs; ++p) {
@@ -636,40 +647,21 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
     recs.insert(recs.end(), Q.rec_start.begin(), Q.rec_start.end());
     if ((int32_t)Q.stream_len > max_qlen) max_qlen = (int32_t)Q.stream_len;
   }
-  // grow scratch
-  if (slots > A->table_slots) { if ((rc = grow(ctx, A->table, A->table_slots, slots, 1))) return rc; A->table_slots = slots; }
-  if (recs.size() > A->recs) { if ((rc = grow(ctx, A->recs_d, A->recs, recs.size(), 1))) return rc; A->recs = recs.size(); }
-  if (n_refs > A->refs) { if ((rc = grow(ctx, A->refs_d, A->refs, n_refs, 1))) return rc; A->refs = n_refs; }
+  if (slots > A->table_slots) { if ((rc = regrow(ctx, A->table, slots))) return rc; A->table_slots = slots; }
+  if (recs.size() > A->recs) { if ((rc = regrow(ctx, A->recs_d, recs.size()))) return rc; A->recs = recs.size(); }
+  if (n_refs > A->refs) { if ((rc = regrow(ctx, A->refs_d, n_refs))) return rc; A->refs = n_refs; }
   if (n_units > A->units) {
-    const size_t u = n_units;
-    if ((rc = grow(ctx, A->units_d, A->units, u, 1))) return rc;
-    if ((rc = grow(ctx, A->mem, A->units, u, CAP_M))) return rc;
-    if ((rc = grow(ctx, A->cm, A->units, u, CAP_M))) return rc;
-    if ((rc = grow(ctx, A->mem_count, A->units, u, 1))) return rc;
-    if ((rc = grow(ctx, A->iscratch, A->units, u, 7 * (size_t)CAP_M))) return rc;
-    if ((rc = grow(ctx, A->chains, A->units, u, CAP_C))) return rc;
-    if ((rc = grow(ctx, A->nch, A->units, u, 1))) return rc;
-    if ((rc = grow(ctx, A->order, A->units, u, CAP_C))) return rc;
-    if ((rc = grow(ctx, A->prev, A->units, u, CAP_C))) return rc;
-    if ((rc = grow(ctx, A->next, A->units, u, CAP_C))) return rc;
-    if ((rc = grow(ctx, A->alnof, A->units, u, CAP_C))) return rc;
-    if ((rc = grow(ctx, A->fw, A->units, u, CAP_C))) return rc;
-    if ((rc = grow(ctx, A->bw, A->units, u, CAP_C))) return rc;
-    A->units = u;
+    if ((rc = regrow(ctx, A->units_d, n_units))) return rc;
+    if ((rc = regrow(ctx, A->mem_count, n_units))) return rc;
+    if ((rc = regrow(ctx, A->moff, (size_t)n_units + 1))) return rc;
+    if ((rc = regrow(ctx, A->nch, n_units))) return rc;
+    A->units = n_units;
   }
   if (n_pairs > A->pairs) {
-    const size_t p = n_pairs;
-    if ((rc = grow(ctx, A->status, A->pairs, p, 1))) return rc;
-    if ((rc = grow(ctx, A->S.alns, A->pairs, p, CAP_A))) return rc;
-    if ((rc = grow(ctx, A->S.a_rrec, A->pairs, p, CAP_A))) return rc;
-    if ((rc = grow(ctx, A->S.a_qrec, A->pairs, p, CAP_A))) return rc;
-    if ((rc = grow(ctx, A->S.idx, A->pairs, p, CAP_A))) return rc;
-    if ((rc = grow(ctx, A->S.from, A->pairs, p, CAP_A))) return rc;
-    if ((rc = grow(ctx, A->S.sc, A->pairs, p, CAP_A))) return rc;
-    if ((rc = grow(ctx, A->out, A->pairs, p, 1))) return rc;
-    A->pairs = p;
+    if ((rc = regrow(ctx, A->status, n_pairs))) return rc;
+    if ((rc = regrow(ctx, A->out, n_pairs))) return rc;
+    A->pairs = n_pairs;
   }
-  A->S.aln_of = A->alnof;
   for (uint32_t r = 0; r < n_refs; ++r) { refs[r].rec_start = A->recs_d + ref_rec_off[r]; refs[r].table = A->table + table_off[r]; }
   std::vector<UnitDesc> units(n_units);
   for (uint32_t p = 0; p < n_pairs; ++p) {
@@ -691,13 +683,56 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
   PG_HIP(ctx, hipMemcpyAsync(A->units_d, units.data(), n_units * sizeof(UnitDesc), hipMemcpyHostToDevice, ctx->stream));
   PG_HIP(ctx, hipMemsetAsync(A->table, 0xFF, slots * 8, ctx->stream));
   PG_HIP(ctx, hipMemsetAsync(A->mem_count, 0, n_units * 4, ctx->stream));
-  PG_HIP(ctx, hipMemsetAsync(A->status, 0, n_pairs * 4, ctx->stream));
-  ClusterOut O{A->cm, A->chains, A->nch, A->order, A->prev, A->next, A->status};
   hipLaunchKernelGGL(anim_index_kernel, dim3((max_rlen + 255) / 256, n_refs), dim3(256), 0, ctx->stream, A->refs_d);
+  // pass 1: count
   hipLaunchKernelGGL(anim_seed_kernel, dim3((max_qlen + 255) / 256, n_units), dim3(256), 0, ctx->stream, A->refs_d, A->units_d,
-                     A->mem, A->mem_count, CAP_M);
+                     (Match*)nullptr, A->mem_count, (const uint32_t*)nullptr, 1);
+  std::vector<uint32_t> cnt(n_units), moff(n_units + 1, 0);
+  PG_HIP(ctx, hipMemcpyAsync(cnt.data(), A->mem_count, n_units * 4, hipMemcpyDeviceToHost, ctx->stream));
+  PG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  uint32_t pairs_fit = 0;
+  uint64_t tot = 0;
+  for (uint32_t p = 0; p < n_pairs; ++p) {
+    const uint64_t need = (uint64_t)cnt[2 * p] + cnt[2 * p + 1] + 2;   // +1 per unit: never a zero-size slice
+    if (p > 0 && tot + need > max_matches) break;
+    tot += need;
+    pairs_fit = p + 1;
+  }
+  n_pairs = pairs_fit;
+  n_units = 2 * n_pairs;
+  *n_done = n_pairs;
+  for (uint32_t u = 0; u < n_units; ++u) moff[u + 1] = moff[u] + cnt[u] + 1;
+  const size_t M = moff[n_units];
+  if (M > A->matches) {
+    const size_t cap = M + M / 4;
+    if ((rc = regrow(ctx, A->mem, cap))) return rc;
+    if ((rc = regrow(ctx, A->cm, cap))) return rc;
+    if ((rc = regrow(ctx, A->iscratch, cap * 7))) return rc;
+    if ((rc = regrow(ctx, A->chains, cap))) return rc;
+    if ((rc = regrow(ctx, A->order, cap))) return rc;
+    if ((rc = regrow(ctx, A->prev, cap))) return rc;
+    if ((rc = regrow(ctx, A->next, cap))) return rc;
+    if ((rc = regrow(ctx, A->alnof, cap))) return rc;
+    if ((rc = regrow(ctx, A->fw, cap))) return rc;
+    if ((rc = regrow(ctx, A->bw, cap))) return rc;
+    if ((rc = regrow(ctx, A->S.alns, cap))) return rc;
+    if ((rc = regrow(ctx, A->S.a_rrec, cap))) return rc;
+    if ((rc = regrow(ctx, A->S.a_qrec, cap))) return rc;
+    if ((rc = regrow(ctx, A->S.idx, cap))) return rc;
+    if ((rc = regrow(ctx, A->S.from, cap))) return rc;
+    if ((rc = regrow(ctx, A->S.sc, cap))) return rc;
+    A->matches = cap;
+  }
+  A->S.aln_of = A->alnof;
+  PG_HIP(ctx, hipMemcpyAsync(A->moff, moff.data(), ((size_t)n_units + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+  PG_HIP(ctx, hipMemsetAsync(A->mem_count, 0, n_units * 4, ctx->stream));
+  PG_HIP(ctx, hipMemsetAsync(A->status, 0, n_pairs * 4, ctx->stream));
+  ClusterOut O{A->moff, A->cm, A->chains, A->nch, A->order, A->prev, A->next, A->status};
+  // pass 2: write the matches
+  hipLaunchKernelGGL(anim_seed_kernel, dim3((max_qlen + 255) / 256, n_units), dim3(256), 0, ctx->stream, A->refs_d, A->units_d,
+                     A->mem, A->mem_count, A->moff, 0);
   hipLaunchKernelGGL(anim_cluster_kernel, dim3((n_units + 63) / 64), dim3(64), 0, ctx->stream, A->refs_d, A->units_d, n_units,
-                     A->mem, A->mem_count, CAP_M, CAP_C, A->iscratch, O);
+                     A->mem, A->mem_count, A->iscratch, O);
   // work list of (unit, chain): one wave each
   std::vector<int32_t> nch(n_units);
   PG_HIP(ctx, hipMemcpyAsync(nch.data(), A->nch, n_units * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -706,14 +741,14 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
   for (uint32_t u = 0; u < n_units; ++u)
     for (int32_t c = 0; c < nch[u]; ++c) wl.push_back(make_uint2(u, (uint32_t)c));
   if (!wl.empty()) {
-    if (wl.size() > A->wl) { if ((rc = grow(ctx, A->wl_d, A->wl, wl.size() + wl.size() / 2, 1))) return rc; A->wl = wl.size() + wl.size() / 2; }
+    if (wl.size() > A->wl) { if ((rc = regrow(ctx, A->wl_d, wl.size() + wl.size() / 2))) return rc; A->wl = wl.size() + wl.size() / 2; }
     PG_HIP(ctx, hipMemcpyAsync(A->wl_d, wl.data(), wl.size() * sizeof(uint2), hipMemcpyHostToDevice, ctx->stream));
     for (int phase = 0; phase < 2; ++phase)
-      hipLaunchKernelGGL(anim_extend_kernel, dim3((uint32_t)wl.size()), dim3(64), 0, ctx->stream, A->refs_d, A->units_d, CAP_M,
-                         CAP_C, O, A->wl_d, A->fw, A->bw, phase);
+      hipLaunchKernelGGL(anim_extend_kernel, dim3((uint32_t)wl.size()), dim3(64), 0, ctx->stream, A->refs_d, A->units_d, O,
+                         A->wl_d, A->fw, A->bw, phase);
   }
   hipLaunchKernelGGL(anim_finish_kernel, dim3((n_pairs + 63) / 64), dim3(64), 0, ctx->stream, A->refs_d, A->units_d, n_pairs,
-                     CAP_M, CAP_C, CAP_A, O, A->fw, A->bw, A->S, filter_1to1, A->out);
+                     O, A->fw, A->bw, A->S, filter_1to1, A->out);
   PG_HIP(ctx, hipGetLastError());
   PG_HIP(ctx, hipMemcpyAsync(out_host, A->out, n_pairs * sizeof(pg_anim_result), hipMemcpyDeviceToHost, ctx->stream));
   PG_HIP(ctx, hipStreamSynchronize(ctx->stream));

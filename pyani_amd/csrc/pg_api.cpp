@@ -624,7 +624,7 @@ int pg_anim_pairs(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_ids, u
   for (uint64_t i = 0; i < n_pairs; ++i) order[i] = i;
   std::stable_sort(order.begin(), order.end(), [&](uint64_t a, uint64_t b) { return ref_ids[a] < ref_ids[b]; });
   // batches: as many pairs as the scratch budget allows, at most MAX_REFS distinct references (one 20-mer table each)
-  const uint32_t MAX_PAIRS = ctx->anim_batch_pairs, MAX_REFS = 24;
+  const uint32_t MAX_PAIRS = ctx->anim_batch_pairs, MAX_REFS = 256;
   std::vector<int32_t> r, q;
   std::vector<pg_anim_result> res;
   uint64_t i = 0;
@@ -640,9 +640,11 @@ int pg_anim_pairs(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_ids, u
     r.clear(); q.clear();
     for (uint64_t k = i; k < j; ++k) { r.push_back(ref_ids[order[k]]); q.push_back(qry_ids[order[k]]); }
     res.assign(j - i, pg_anim_result{});
-    if ((rc = pg_anim_run_batch(ctx, r.data(), q.data(), (uint32_t)(j - i), filter_1to1, res.data()))) return rc;
-    for (uint64_t k = i; k < j; ++k) out[order[k]] = res[k - i];
-    i = j;
+    uint32_t done = 0;
+    if ((rc = pg_anim_run_batch(ctx, r.data(), q.data(), (uint32_t)(j - i), filter_1to1, ctx->anim_batch_matches, res.data(), &done)))
+      return rc;
+    for (uint64_t k = i; k < i + done; ++k) out[order[k]] = res[k - i];
+    i += done;   // pairs beyond the match budget are taken up by the next batch
   }
   return PG_OK;
 }

@@ -83,7 +83,8 @@ struct pg_ctx {
   uint64_t prof_n[PG_K__COUNT] = {0, 0, 0, 0};
   int num_cu = 256;
   void* anim_scratch = nullptr;  // AnimScratch (pg_anim.hip), grows on demand
-  uint32_t anim_batch_pairs = 1024;
+  uint32_t anim_batch_pairs = 16384;          // upper bound of ordered pairs per launch
+  uint64_t anim_batch_matches = 150ull << 20; // exact matches per launch (~210 B of scratch each: ~33 GB)
 };
 
 int pg_fail(pg_ctx* ctx, int code, const std::string& msg);
@@ -109,5 +110,5 @@ int pg_anim_reduce_run(pg_ctx* ctx, uint32_t n_pairs, const uint64_t* offsets, c
                        const int32_t* rs, const int32_t* re, const int32_t* qs, const int32_t* qe, const int32_t* errors,
                        int apply_filter, pg_anim_result* out);
 int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_ids, uint32_t n_pairs, int filter_1to1,
-                      pg_anim_result* out_host);   // ref_ids must arrive grouped (equal ids adjacent)
+                      uint64_t max_matches, pg_anim_result* out_host, uint32_t* n_done);   // ref_ids grouped (equal ids adjacent)
 void pg_anim_free_scratch(pg_ctx* ctx);
