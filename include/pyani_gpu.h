@@ -130,6 +130,17 @@ int pg_anim_reduce(pg_ctx* ctx, uint32_t n_pairs, const uint64_t* offsets, const
                    const int32_t* rs, const int32_t* re, const int32_t* qs, const int32_t* qe, const int32_t* errors,
                    int apply_filter, pg_anim_result* out);
 
+/* ---- ANIb reduction -------------------------------------------------------------------------------------
+ * parse_blast_tab of pyani/anib.py:569-667 (mode "ANIb", BLAST+ 15-column rows) for a batch of ordered pairs.
+ * Pair p owns rows [offsets[p], offsets[p+1]) in file order; frag[] = ordinal of the query fragment (0-based, < n_frags[p]).
+ * Per row: ani_alnlen = length - gaps, ani_alnids = ani_alnlen - mismatch; rows with ani_alnlen/qlen > 0.7 and
+ * ani_alnids/qlen > 0.3 are kept, then the first kept row of every fragment.  Outputs per pair: aln_length =
+ * sum(ani_alnlen), sim_errors = sum(mismatch) + sum(gaps), pid = mean(pident) over the kept rows in fragment order
+ * (0 if none) — sequential fp64 sum, within 1e-12 (relative) of pandas' pairwise mean. */
+int pg_anib_reduce(pg_ctx* ctx, uint32_t n_pairs, const uint64_t* offsets, const uint32_t* n_frags, const int32_t* frag,
+                   const int32_t* length, const int32_t* mismatch, const int32_t* gaps, const int32_t* qlen, const double* pident,
+                   int64_t* aln_length_out, int64_t* sim_errors_out, double* pid_out);
+
 /* ---- measurement ---------------------------------------------------------------------------------------- */
 /* When enabled, every kernel launch is bracketed by HIP events on the context's stream. */
 int pg_profile_enable(pg_ctx* ctx, int on);

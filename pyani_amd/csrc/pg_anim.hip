@@ -793,3 +793,75 @@ int pg_anim_reduce_run(pg_ctx* ctx, uint32_t n_pairs, const uint64_t* offsets, c
   if (e != hipSuccess) return pg_fail(ctx, PG_E_HIP, std::string("anim reduce: ") + hipGetErrorString(e));
   return PG_OK;
 }
+
+// ---- ANIb: parse_blast_tab reduction (pyani/anib.py:641-665), one thread per ordered pair ---------------------------
+namespace {
+__global__ __launch_bounds__(64) void anib_reduce_kernel(uint32_t n_pairs, const uint64_t* __restrict__ offsets,
+                                                         const uint64_t* __restrict__ foff, const int32_t* __restrict__ frag,
+                                                         const int32_t* __restrict__ length, const int32_t* __restrict__ mismatch,
+                                                         const int32_t* __restrict__ gaps, const int32_t* __restrict__ qlen,
+                                                         const double* __restrict__ pident, int64_t* first_row,
+                                                         int64_t* __restrict__ aln_out, int64_t* __restrict__ err_out,
+                                                         double* __restrict__ pid_out) {
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_pairs) return;
+  int64_t* first = first_row + foff[p];
+  const uint64_t nf = foff[p + 1] - foff[p];
+  for (uint64_t f = 0; f < nf; ++f) first[f] = -1;
+  for (uint64_t i = offsets[p]; i < offsets[p + 1]; ++i) {
+    const int32_t alnlen = length[i] - gaps[i], alnids = alnlen - mismatch[i];
+    const double cov = (double)alnlen / (double)qlen[i], pid = (double)alnids / (double)qlen[i];
+    if (cov > 0.7 && pid > 0.3 && (uint64_t)frag[i] < nf && first[frag[i]] < 0) first[frag[i]] = (int64_t)i;
+  }
+  int64_t aln = 0, err = 0, cnt = 0;
+  double sum = 0.0;
+  for (uint64_t f = 0; f < nf; ++f) {
+    const int64_t i = first[f];
+    if (i < 0) continue;
+    aln += length[i] - gaps[i];
+    err += (int64_t)mismatch[i] + gaps[i];
+    sum = sum + pident[i];
+    ++cnt;
+  }
+  aln_out[p] = aln;
+  err_out[p] = err;
+  pid_out[p] = cnt ? sum / (double)cnt : 0.0;
+}
+}  // namespace
+
+int pg_anib_reduce_run(pg_ctx* ctx, uint32_t n_pairs, const uint64_t* offsets, const uint32_t* n_frags, const int32_t* frag,
+                       const int32_t* length, const int32_t* mismatch, const int32_t* gaps, const int32_t* qlen,
+                       const double* pident, int64_t* aln_out, int64_t* err_out, double* pid_out) {
+  const uint64_t n = offsets[n_pairs];
+  std::vector<uint64_t> foff(n_pairs + 1, 0);
+  for (uint32_t p = 0; p < n_pairs; ++p) foff[p + 1] = foff[p] + n_frags[p];
+  std::vector<void*> to_free;
+  auto cleanup = [&]() { for (void* q : to_free) if (q) (void)hipFree(q); };
+  uint64_t *d_off = nullptr, *d_foff = nullptr;
+  int32_t *d_frag = nullptr, *d_len = nullptr, *d_mm = nullptr, *d_gap = nullptr, *d_ql = nullptr;
+  double *d_pid = nullptr, *d_pout = nullptr;
+  int64_t *d_first = nullptr, *d_aln = nullptr, *d_err = nullptr;
+  int rc;
+#define AA(ptr, cnt) do { if ((rc = anim_alloc(ctx, ptr, (cnt)))) { cleanup(); return rc; } to_free.push_back(ptr); } while (0)
+  AA(d_off, n_pairs + 1); AA(d_foff, n_pairs + 1); AA(d_frag, n + 1); AA(d_len, n + 1); AA(d_mm, n + 1); AA(d_gap, n + 1);
+  AA(d_ql, n + 1); AA(d_pid, n + 1); AA(d_first, foff[n_pairs] + 1); AA(d_aln, n_pairs); AA(d_err, n_pairs); AA(d_pout, n_pairs);
+#undef AA
+  hipError_t e = hipMemcpyAsync(d_off, offsets, (n_pairs + 1) * 8, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_foff, foff.data(), (n_pairs + 1) * 8, hipMemcpyHostToDevice, ctx->stream);
+  const struct { void* d; const void* h; size_t b; } cp[] = {{d_frag, frag, n * 4}, {d_len, length, n * 4}, {d_mm, mismatch, n * 4},
+                                                           {d_gap, gaps, n * 4}, {d_ql, qlen, n * 4}, {d_pid, pident, n * 8}};
+  for (const auto& c : cp)
+    if (e == hipSuccess && c.b) e = hipMemcpyAsync(c.d, c.h, c.b, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(anib_reduce_kernel, dim3((n_pairs + 63) / 64), dim3(64), 0, ctx->stream, n_pairs, d_off, d_foff, d_frag, d_len,
+                       d_mm, d_gap, d_ql, d_pid, d_first, d_aln, d_err, d_pout);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(aln_out, d_aln, n_pairs * 8, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(err_out, d_err, n_pairs * 8, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(pid_out, d_pout, n_pairs * 8, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  cleanup();
+  if (e != hipSuccess) return pg_fail(ctx, PG_E_HIP, std::string("anib reduce: ") + hipGetErrorString(e));
+  return PG_OK;
+}

@@ -661,6 +661,20 @@ int pg_anim_reduce(pg_ctx* ctx, uint32_t n_pairs, const uint64_t* offsets, const
   return pg_anim_reduce_run(ctx, n_pairs, offsets, rseq, qseq, rs, re, qs, qe, errors, apply_filter, out);
 }
 
+int pg_anib_reduce(pg_ctx* ctx, uint32_t n_pairs, const uint64_t* offsets, const uint32_t* n_frags, const int32_t* frag,
+                   const int32_t* length, const int32_t* mismatch, const int32_t* gaps, const int32_t* qlen, const double* pident,
+                   int64_t* aln_length_out, int64_t* sim_errors_out, double* pid_out) {
+  if (!ctx || !offsets || (n_pairs && (!n_frags || !aln_length_out || !sim_errors_out || !pid_out)))
+    return pg_fail(ctx, PG_E_ARG, "bad argument");
+  if (offsets[n_pairs] && (!frag || !length || !mismatch || !gaps || !qlen || !pident)) return pg_fail(ctx, PG_E_ARG, "bad argument");
+  for (uint64_t i = 0; i < offsets[n_pairs]; ++i)
+    if (qlen[i] <= 0) return pg_fail(ctx, PG_E_ARG, "qlen must be positive");
+  PG_HIP(ctx, hipSetDevice(ctx->device));
+  if (n_pairs == 0) return PG_OK;
+  return pg_anib_reduce_run(ctx, n_pairs, offsets, n_frags, frag, length, mismatch, gaps, qlen, pident, aln_length_out,
+                            sim_errors_out, pid_out);
+}
+
 // ---- measurement -----------------------------------------------------------------------------------------------
 int pg_profile_enable(pg_ctx* ctx, int on) {
   if (!ctx) return PG_E_ARG;

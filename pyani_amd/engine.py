@@ -175,6 +175,25 @@ class Engine:
                                             int(apply_filter), out.ctypes.data))
         return out
 
+    def anib_reduce(self, pairs):
+        """pairs: list of (n_frags, rows) with rows = [(frag ordinal, length, mismatch, gaps, qlen, pident), ...] in
+        file order.  Returns (aln_length int64[], sim_errors int64[], mean pident float64[])."""
+        n = len(pairs)
+        offsets = np.zeros(n + 1, dtype=np.uint64)
+        nfr = np.zeros(max(n, 1), dtype=np.uint32)
+        for k, (nf, rows) in enumerate(pairs):
+            offsets[k + 1] = offsets[k] + len(rows)
+            nfr[k] = nf
+        flat = [r for _, rows in pairs for r in rows]
+        ints = np.array([r[:5] for r in flat], dtype=np.int32).reshape(-1, 5)
+        cols = [np.ascontiguousarray(ints[:, c]) for c in range(5)]
+        pid = np.ascontiguousarray([r[5] for r in flat], dtype=np.float64)
+        aln, err, out = np.zeros(n, dtype=np.int64), np.zeros(n, dtype=np.int64), np.zeros(n, dtype=np.float64)
+        self._check(self.lib.pg_anib_reduce(self._h, n, offsets.ctypes.data, nfr.ctypes.data, cols[0].ctypes.data,
+                                            cols[1].ctypes.data, cols[2].ctypes.data, cols[3].ctypes.data, cols[4].ctypes.data,
+                                            pid.ctypes.data, aln.ctypes.data, err.ctypes.data, out.ctypes.data))
+        return aln, err, out
+
     # -- measurement ----------------------------------------------------------------------------------------------
     def profile_enable(self, on: bool = True):
         self._check(self.lib.pg_profile_enable(self._h, int(on)))

@@ -1,0 +1,64 @@
+"""ANIb row (a14): fragmenting rule and BLAST-tab reduction.  CPU tests pin the oracle to the reference's known answers;
+the GPU test runs the reduction through the C ABI (`pg_anib_reduce`)."""
+import csv
+import sys
+
+import pytest
+
+from tests.conftest import GOLD, ROOT
+
+sys.path.insert(0, str(ROOT / "oracle"))
+import anib_oracle  # noqa: E402
+
+FILES = ["NC_002696_vs_NC_011916", "NC_002696_vs_NC_010338", "NC_002696_vs_NC_014100", "NC_011916_vs_NC_002696"]
+
+
+def _matrix():
+    rows = list(csv.reader(open(GOLD / "ref_targets" / "anib_blastn_result.csv")))
+    names = rows[0][1:]
+    return {(r[0], s): v for r in rows[1:] for s, v in zip(names, r[1:])}
+
+
+def test_oracle_known_answers():
+    """tests/test_anib.py:387-391 of the reference (4 016 551, 93, 99.997 693 577 050 029) + blastn_result.csv (6 d.p.)."""
+    aln, err, pid = anib_oracle.parse_blast_tab(GOLD / "anib" / "NC_002696_vs_NC_011916.blast_tab.gz")
+    assert (aln, err) == (4_016_551, 93) and abs(pid - 99.997693577050029) < 1e-11
+    want = _matrix()
+    for name in FILES:
+        q, s = name.split("_vs_")
+        assert f"{0.01 * anib_oracle.parse_blast_tab(GOLD / 'anib' / (name + '.blast_tab.gz'))[2]:.6f}" == want[(q, s)]
+
+
+def test_fragmenting_rule():
+    from pyani_amd import anib
+    for lens in ([2500, 1020, 5], [1020], [1021], [0, 3], []):
+        got = anib.fragment_lengths(lens)
+        assert got == anib_oracle.fragment_lengths(lens)
+        assert all(0 < v <= 1020 for v in got.values()) and sum(got.values()) == sum(lens)
+    frs = anib.fragment_records([("a", "A" * 2041), ("b", "C" * 7)])
+    assert [f[0] for f in frs] == ["frag00001", "frag00002", "frag00003", "frag00004"]
+    assert [len(f[1]) for f in frs] == [1020, 1020, 1, 7]
+
+
+@pytest.mark.gpu
+def test_gpu_blast_tab_reduction():
+    from pyani_amd import anib
+    from pyani_amd.engine import Engine
+    want = _matrix()
+    with Engine(0) as eng:
+        pairs = [anib.read_blast_tab(GOLD / "anib" / (n + ".blast_tab.gz")) for n in FILES]
+        aln, err, pid = eng.anib_reduce(pairs)
+        for k, name in enumerate(FILES):
+            o = anib_oracle.parse_blast_tab(GOLD / "anib" / (name + ".blast_tab.gz"))
+            assert (int(aln[k]), int(err[k])) == (o[0], o[1])
+            assert abs(float(pid[k]) - o[2]) <= 1e-12 * o[2]          # sequential vs exactly-rounded mean
+            q, s = name.split("_vs_")
+            assert f"{0.01 * float(pid[k]):.6f}" == want[(q, s)]
+        assert anib.parse_blast_tab(GOLD / "anib" / "NC_002696_vs_NC_011916.blast_tab.gz", engine=eng)[:2] == (4_016_551, 93)
+        aln0, err0, pid0 = eng.anib_reduce([(0, [])])
+        assert (int(aln0[0]), int(err0[0]), float(pid0[0])) == (0, 0, 0.0)   # no hits -> pid 0 (anib.py:661-663)
+        res = {tuple(n.split("_vs_")): (int(aln[k]), int(err[k]), float(pid[k])) for k, n in enumerate(FILES)}
+        m = anib.process_blast_results(res, {"NC_002696": 4016947, "NC_011916": 4042929, "NC_010338": 5000000, "NC_014100": 5000000})
+        assert m["percentage_identity"].loc["NC_002696", "NC_011916"] == 0.01 * float(pid[0])
+        assert m["alignment_coverage"].loc["NC_002696", "NC_011916"] == float(aln[0]) / 4016947
+        assert m["percentage_identity"].loc["NC_010338", "NC_002696"] == 1.0     # cells never written keep their init value
