@@ -196,16 +196,6 @@ __global__ __launch_bounds__(64) void anim_cluster_kernel(const RefDesc* __restr
   O.n_chains[u] = n_chains;
 }
 
-__device__ __forceinline__ void chain_bounds(const RefDesc& R, const UnitDesc& U, const Chain& c, int32_t& r_lo, int32_t& r_hi,
-                                             int32_t& q_lo, int32_t& q_hi) {
-  r_lo = R.rec_start[c.rrec]; r_hi = R.rec_start[c.rrec + 1] - 1;
-  q_lo = U.rec_start[c.qrec]; q_hi = U.rec_start[c.qrec + 1] - 1;
-  if (U.strand) { const int32_t a = U.len - q_hi, b = U.len - q_lo; q_lo = a; q_hi = b; }
-}
-
-// ---- wave-cooperative banded DP: the 64 lanes of a wave ARE the 64 diagonals of the band ----------------------------
-// Same cells, checks and tie-breaks as pga::extend_banded (pg_anim_core.h); neighbours' cells arrive through DPP
-// wave shifts, so a step costs a handful of VALU ops per lane and no LDS.  All lanes return the same result.
 __device__ __forceinline__ int32_t from_lane_above(int32_t v, int32_t fill) {  // lane l <- lane l+1 (lane 63 <- fill)
   return __builtin_amdgcn_update_dpp(fill, v, 0x130 /*wave_shl:1*/, 0xf, 0xf, false);
 }
@@ -221,6 +211,338 @@ __device__ __forceinline__ long long wave_max64(long long v) {
   return v;
 }
 
+// =====================================================================================================================
+// A3, wave-cooperative: one WAVE per (pair, strand) unit.  Same results as the scalar statement (pga::mum_filter +
+// pga::mgaps_strand, which the one-thread kernel above runs): stable LSD radix sorts instead of heapsorts, wave scans
+// for the containment flags, a lock-free union-find, and a chain DP whose 64-deep look-back lives in the 64 lanes.
+// =====================================================================================================================
+__device__ __forceinline__ uint64_t lanemask_lt() { return (1ull << (threadIdx.x & 63)) - 1ull; }
+
+// Stable LSD radix sort of (key, val) pairs by `passes` 8-bit digits.  Result ends in (k0, v0) if passes is even,
+// else in (k1, v1).  hist: 256 words of LDS.
+__device__ void wave_radix_sort(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1, int n, int passes, uint32_t* hist) {
+  const int lane = threadIdx.x & 63;
+  for (int pass = 0; pass < passes; ++pass) {
+    const int shift = 8 * pass;
+    const uint32_t* ki = (pass & 1) ? k1 : k0;
+    const uint32_t* vi = (pass & 1) ? v1 : v0;
+    uint32_t* ko = (pass & 1) ? k0 : k1;
+    uint32_t* vo = (pass & 1) ? v0 : v1;
+    __syncthreads();
+    for (int b = lane; b < 256; b += 64) hist[b] = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 64) {
+      const int i = base + lane;
+      if (i < n) atomicAdd(&hist[(ki[i] >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    {  // exclusive scan of the 256 bins: 4 bins per lane
+      uint32_t c0 = hist[4 * lane], c1 = hist[4 * lane + 1], c2 = hist[4 * lane + 2], c3 = hist[4 * lane + 3];
+      const uint32_t tot = c0 + c1 + c2 + c3;
+      uint32_t incl = tot;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+      uint32_t ex = incl - tot;
+      __syncthreads();
+      hist[4 * lane] = ex; ex += c0;
+      hist[4 * lane + 1] = ex; ex += c1;
+      hist[4 * lane + 2] = ex; ex += c2;
+      hist[4 * lane + 3] = ex;
+    }
+    __syncthreads();
+    for (int base = 0; base < n; base += 64) {
+      const int i = base + lane;
+      const bool act = i < n;
+      const uint32_t key = act ? ki[i] : 0u, val = act ? vi[i] : 0u;
+      const uint32_t d = (key >> shift) & 255u;
+      uint64_t peers = __ballot(act);
+#pragma unroll
+      for (int b = 0; b < 8; ++b) {
+        const uint64_t vote = __ballot((d >> b) & 1u);
+        peers &= ((d >> b) & 1u) ? vote : ~vote;
+      }
+      const uint32_t rank = (uint32_t)__popcll(peers & lanemask_lt());
+      uint32_t pos = 0;
+      if (act) pos = hist[d] + rank;
+      __syncthreads();
+      if (act && rank == 0) hist[d] += (uint32_t)__popcll(peers);
+      __syncthreads();
+      if (act) { ko[pos] = key; vo[pos] = val; }
+    }
+  }
+  __syncthreads();
+}
+
+// containment flags over elements in sorted order (ascending start, ties: longer first): flag[idx] |= 1 if an earlier
+// element reaches at least as far, or if the next element has the same start and length.
+__device__ void wave_containment_flags(const uint32_t* order, const int32_t* start, const int32_t* len, int n, int32_t* flag) {
+  const int lane = threadIdx.x & 63;
+  int32_t carry = -1;
+  for (int base = 0; base < n; base += 64) {
+    const int t = base + lane;
+    const bool act = t < n;
+    const uint32_t idx = act ? order[t] : 0u;
+    const int32_t st = act ? start[idx] : 0, ln = act ? len[idx] : 0;
+    const int32_t e = act ? st + ln : -1;
+    int32_t incl = e;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int32_t v = __shfl_up(incl, o, 64); if (lane >= o && v > incl) incl = v; }
+    int32_t excl = __shfl_up(incl, 1, 64);
+    if (lane == 0) excl = -1;
+    const int32_t prevmax = excl > carry ? excl : carry;
+    if (act) {
+      bool f = e <= prevmax;
+      if (!f && t + 1 < n) { const uint32_t nx = order[t + 1]; f = start[nx] == st && len[nx] == ln; }
+      if (f) flag[idx] = 1;
+    }
+    const int32_t last = __shfl(incl, 63, 64);
+    if (last > carry) carry = last;
+  }
+}
+
+__device__ __forceinline__ int uf_find(int32_t* parent, int x) {
+  for (;;) {
+    const int p = parent[x];
+    if (p == x) return x;
+    x = p;
+  }
+}
+__device__ __forceinline__ void uf_union(int32_t* parent, int a, int b) {   // larger root -> smaller root (deterministic roots)
+  for (;;) {
+    a = uf_find(parent, a); b = uf_find(parent, b);
+    if (a == b) return;
+    if (a < b) { const int t = a; a = b; b = t; }
+    if (atomicCAS(&parent[a], a, b) == a) return;
+  }
+}
+
+__global__ __launch_bounds__(64) void anim_cluster_wave_kernel(const RefDesc* __restrict__ refs, const UnitDesc* __restrict__ units,
+                                                               Match* __restrict__ mem, const uint32_t* __restrict__ mem_count,
+                                                               int32_t* __restrict__ iscratch, ClusterOut O) {
+  __shared__ uint32_t hist[256];
+  const uint32_t u = blockIdx.x;
+  const int lane = threadIdx.x & 63;
+  const UnitDesc U = units[u];
+  const RefDesc R = refs[U.ref];
+  const size_t off = O.moff[u];
+  const uint32_t cap = O.moff[u + 1] - O.moff[u];
+  uint32_t n0 = mem_count[u];
+  if (n0 > cap) { if (lane == 0) atomicOr(&O.status[U.pair], 1); n0 = cap; }
+  if (n0 == 0) { if (lane == 0) O.n_chains[u] = 0; return; }
+  Match* m = mem + off;
+  Match* cm = O.cm + off;
+  // scratch slices (7 x cap ints): a..g
+  int32_t* sa = iscratch + off * 7;
+  int32_t *sb = sa + cap, *sc = sa + 2 * (size_t)cap, *sd = sa + 3 * (size_t)cap, *se = sa + 4 * (size_t)cap,
+          *sf = sa + 5 * (size_t)cap, *sg = sa + 6 * (size_t)cap;
+  const int n_in = (int)n0;
+  // ---- MUM filter -----------------------------------------------------------------------------------------------
+  // SoA copies: se = r, sf = q, sg = len; flags in sd
+  for (int i = lane; i < n_in; i += 64) { const Match t = m[i]; se[i] = t.r; sf[i] = t.q; sg[i] = t.len; sd[i] = 0; }
+  __syncthreads();
+  uint32_t *k0 = (uint32_t*)sa, *v0 = (uint32_t*)sb, *k1 = (uint32_t*)sc;
+  uint32_t* v1 = (uint32_t*)cm;   // cm is free until the chains are written (16 B per entry >= 4 B)
+  for (int side = 0; side < 2; ++side) {
+    const int32_t* start = side == 0 ? sf : se;   // query intervals first, then reference intervals
+    // sort by (start asc, len desc): LSD = len-desc key first, then start
+    for (int i = lane; i < n_in; i += 64) { const uint32_t l = (uint32_t)sg[i]; k0[i] = 0xFFFFFFu - (l > 0xFFFFFFu ? 0xFFFFFFu : l); v0[i] = (uint32_t)i; }
+    wave_radix_sort(k0, v0, k1, v1, n_in, 3, hist);            // result in (k1, v1)
+    for (int i = lane; i < n_in; i += 64) k1[i] = (uint32_t)start[v1[i]];
+    __syncthreads();
+    wave_radix_sort(k1, v1, k0, v0, n_in, 4, hist);            // 4 passes (even): result back in (k1, v1)
+    wave_containment_flags(v1, start, sg, n_in, sd);
+    __syncthreads();
+  }
+  // survivors in q order (distinct q among survivors): sort indices by q once more, compact
+  for (int i = lane; i < n_in; i += 64) { k0[i] = (uint32_t)sf[i]; v0[i] = (uint32_t)i; }
+  wave_radix_sort(k0, v0, k1, v1, n_in, 4, hist);              // result in (k0, v0)
+  int n = 0;
+  {
+    // compact into sb? v0 aliases sb; write survivors' Match into cm-temp is not possible (v1 lives there) -> use m itself
+    // two-step: first the survivor index list into k1 (sc), then gather through registers chunk by chunk into cm, copy back
+    for (int base = 0; base < n_in; base += 64) {
+      const int t = base + lane;
+      const bool keep = t < n_in && sd[v0[t]] == 0;
+      const uint64_t b = __ballot(keep);
+      if (keep) k1[n + __popcll(b & lanemask_lt())] = v0[t];
+      n += (int)__popcll(b);
+    }
+    __syncthreads();
+    for (int i = lane; i < n; i += 64) { const uint32_t idx = k1[i]; cm[i] = Match{se[idx], sf[idx], sg[idx], U.strand}; }
+    __syncthreads();
+    for (int i = lane; i < n; i += 64) m[i] = cm[i];
+    __syncthreads();
+  }
+  // ---- clustering (mgaps) ------------------------------------------------------------------------------------------
+  int32_t *rrec = sa, *qrec = sb, *parent = sc, *score = sd, *from = se, *adj = sf, *order = sg;
+  for (int i = lane; i < n; i += 64) {
+    rrec[i] = record_of(R.rec_start, R.n_rec, m[i].r);
+    const int32_t qf = U.strand ? U.len - 1 - m[i].q : m[i].q;
+    qrec[i] = record_of(U.rec_start, U.n_rec, qf);
+    parent[i] = i;
+  }
+  __syncthreads();
+  for (int i = lane; i < n; i += 64) {
+    const Match mi = m[i];
+    const int32_t iend = mi.q + mi.len, idiag = mi.q - mi.r;
+    for (int j = i + 1; j < n; ++j) {
+      const Match mj = m[j];
+      const int32_t sep = mj.q - iend;
+      if (sep > MAX_GAP) break;
+      if (rrec[i] != rrec[j] || qrec[i] != qrec[j]) continue;
+      int32_t dd = (mj.q - mj.r) - idiag;
+      if (dd < 0) dd = -dd;
+      int32_t lim = (int32_t)(DIAG_FACTOR * sep);
+      if (lim < DIAG_DIFF) lim = DIAG_DIFF;
+      if (dd <= lim) uf_union(parent, i, j);
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+  {  // group by root (stable: q order inside a cluster): radix sort of (root, index)
+    uint32_t *rk0 = (uint32_t*)score, *rv0 = (uint32_t*)from, *rk1 = (uint32_t*)adj, *rv1 = (uint32_t*)order;
+    for (int i = lane; i < n; i += 64) { rk0[i] = (uint32_t)uf_find(parent, i); rv0[i] = (uint32_t)i; }
+    __syncthreads();
+    wave_radix_sort(rk0, rv0, rk1, rv1, n, 4, hist);           // result in (rk0, rv0) = (score, from) slices
+    for (int i = lane; i < n; i += 64) { parent[i] = (int32_t)rk0[i]; }   // parent[] now = root id of the i-th element in grouped order
+    __syncthreads();
+    for (int i = lane; i < n; i += 64) order[i] = (int32_t)rv0[i];
+    __syncthreads();
+  }
+  // ---- chain extraction per cluster ----------------------------------------------------------------------------------
+  // grouped list: order[t] = match index, parent[t] = its root.  score/from/adj are indexed by LIST POSITION here.
+  // `lst` (compacted working list of the current cluster) lives in adj's slice after use... keep it simple: a cluster's
+  // live entries are kept contiguous in order[g0 .. g0+live).
+  int n_chains = 0, n_cm = 0;
+  Chain* chains = O.chains + off;
+  int g0 = 0;
+  while (g0 < n) {
+    int g1 = g0 + 1;
+    {  // cluster end: first position whose root differs (wave search)
+      const int32_t root = parent[g0];
+      for (;;) {
+        const int t = g1 + lane;
+        const uint64_t diff = __ballot(t >= n || parent[t] != root);
+        if (diff) { g1 += __ffsll((long long)diff) - 1; break; }
+        g1 += 64;
+      }
+    }
+    int live = g1 - g0;
+    while (live > 0) {
+      // DP over the live entries order[g0 .. g0+live): lane l holds the entry at position k-1-l (sliding window)
+      int32_t wr = 0, wq = 0, wl = 0, wsc = NEG_INF;   // window registers: r, q, len, score of predecessor k-1-lane
+      int32_t best_sc = NEG_INF, best_k = -1;
+      for (int k = 0; k < live; ++k) {
+        const Match mi = m[order[g0 + k]];
+        // candidate through my predecessor
+        int32_t cand = NEG_INF, ol = 0;
+        if (lane < k && wsc > NEG_INF / 2) {
+          ol = wr + wl - mi.r;
+          if (ol < 0) ol = 0;
+          const int32_t ol2 = wq + wl - mi.q;
+          if (ol2 > ol) ol = ol2;
+          int32_t dd = (mi.q - mi.r) - (wq - wr);
+          if (dd < 0) dd = -dd;
+          cand = wsc + mi.len - (ol + dd);
+        }
+        // best candidate: max cand, ties -> nearest predecessor (smallest lane)
+        long long key = (((long long)cand + (1ll << 30)) << 8) | (long long)(63 - lane);
+        key = wave_max64(key);
+        const int32_t bc = (int32_t)((key >> 8) - (1ll << 30));
+        const int bl = 63 - (int)(key & 63);
+        int32_t sc_k = mi.len, fr_k = -1, ad_k = 0;
+        if (bc > sc_k) { sc_k = bc; fr_k = k - 1 - bl; ad_k = __shfl(ol, bl, 64); }
+        if (lane == 0) { score[g0 + k] = sc_k; from[g0 + k] = fr_k; adj[g0 + k] = ad_k; }
+        if (sc_k > best_sc) { best_sc = sc_k; best_k = k; }
+        // slide the window: lane l <- lane l-1, lane 0 <- entry k
+        wr = from_lane_below(wr, mi.r); wq = from_lane_below(wq, mi.q); wl = from_lane_below(wl, mi.len);
+        wsc = from_lane_below(wsc, sc_k);
+      }
+      __threadfence_block();
+      __syncthreads();
+      // walk the best chain (lane 0), emit if long enough, mark removed (from = -2)
+      int32_t total = 0, cnt = 0;
+      if (lane == 0) {
+        for (int k = best_k; k >= 0; k = from[g0 + k]) { total += m[order[g0 + k]].len; ++cnt; }
+      }
+      total = __shfl(total, 0, 64); cnt = __shfl(cnt, 0, 64);
+      const bool emit = total >= MIN_CLUSTER && n_chains < (int)cap && n_cm + cnt <= (int)cap;
+      if (lane == 0) {
+        if (emit) {
+          const int first_idx = order[g0 + best_k];
+          Chain c;
+          c.first = n_cm; c.count = cnt; c.strand = U.strand; c.rrec = rrec[first_idx]; c.qrec = qrec[first_idx];
+          chains[n_chains] = c;
+        }
+        int pos = n_cm + cnt;
+        for (int k = best_k; k >= 0;) {
+          const int nx = from[g0 + k];
+          if (emit) {
+            Match t = m[order[g0 + k]];
+            const int32_t a = adj[g0 + k];
+            t.r += a; t.q += a; t.len -= a;
+            cm[--pos] = t;
+          }
+          from[g0 + k] = -2;
+          k = nx;
+        }
+      }
+      if (emit) { n_chains += 1; n_cm += cnt; }
+      __threadfence_block();
+      __syncthreads();
+      // compact the live list (drop removed entries), preserving order
+      int kept = 0;
+      for (int base = 0; base < live; base += 64) {
+        const int k = base + lane;
+        const bool keep = k < live && from[g0 + k] != -2;
+        const int32_t idx = k < live ? order[g0 + k] : 0;
+        const uint64_t b = __ballot(keep);
+        __syncthreads();
+        if (keep) order[g0 + kept + __popcll(b & lanemask_lt())] = idx;
+        kept += (int)__popcll(b);
+        __syncthreads();
+      }
+      live = kept;
+    }
+    g0 = g1;
+  }
+  // ---- chains in reference order + neighbours ------------------------------------------------------------------------
+  int32_t* co = O.order + off;
+  {
+    uint32_t *ck0 = (uint32_t*)score, *cv0 = (uint32_t*)from, *ck1 = (uint32_t*)adj, *cv1 = (uint32_t*)order;
+    __syncthreads();
+    for (int i = lane; i < n_chains; i += 64) { ck0[i] = (uint32_t)cm[chains[i].first].r; cv0[i] = (uint32_t)i; }
+    __syncthreads();
+    wave_radix_sort(ck0, cv0, ck1, cv1, n_chains, 4, hist);    // result in (ck0, cv0)
+    for (int i = lane; i < n_chains; i += 64) co[i] = (int32_t)cv0[i];
+    __threadfence_block();
+    __syncthreads();
+  }
+  int32_t* prev_of = O.prev_of + off;
+  int32_t* next_of = O.next_of + off;
+  for (int k = lane; k < n_chains; k += 64) {
+    const int c = co[k];
+    int p = -1, q = -1;
+    for (int kk = k - 1; kk >= 0 && kk >= k - 8 && p < 0; --kk)
+      if (chains[co[kk]].rrec == chains[c].rrec && chains[co[kk]].qrec == chains[c].qrec) p = co[kk];
+    for (int kk = k + 1; kk < n_chains && kk <= k + 8 && q < 0; ++kk)
+      if (chains[co[kk]].rrec == chains[c].rrec && chains[co[kk]].qrec == chains[c].qrec) q = co[kk];
+    prev_of[c] = p;
+    next_of[c] = q;
+  }
+  if (lane == 0) O.n_chains[u] = n_chains;
+}
+
+__device__ __forceinline__ void chain_bounds(const RefDesc& R, const UnitDesc& U, const Chain& c, int32_t& r_lo, int32_t& r_hi,
+                                             int32_t& q_lo, int32_t& q_hi) {
+  r_lo = R.rec_start[c.rrec]; r_hi = R.rec_start[c.rrec + 1] - 1;
+  q_lo = U.rec_start[c.qrec]; q_hi = U.rec_start[c.qrec + 1] - 1;
+  if (U.strand) { const int32_t a = U.len - q_hi, b = U.len - q_lo; q_lo = a; q_hi = b; }
+}
+
+// ---- wave-cooperative banded DP: the 64 lanes of a wave ARE the 64 diagonals of the band ----------------------------
+// Same cells, checks and tie-breaks as pga::extend_banded (pg_anim_core.h); neighbours' cells arrive through DPP
+// wave shifts, so a step costs a handful of VALU ops per lane and no LDS.  All lanes return the same result.
 // LDS staging of the two sequences for one wave: base codes (0-3, 4 = dirty / out of range) of consumed indices
 // t = 0, 1, 2, ... in a 256-entry ring.  Cell (i, j) compares ring_r[i-1] with ring_q[j-1]; on anti-diagonal d every lane
 // needs indices within [d/2 - 17, d/2 + 15], so the ring is topped up 64 entries at a time, one base per lane.
@@ -731,8 +1053,12 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
   // pass 2: write the matches
   hipLaunchKernelGGL(anim_seed_kernel, dim3((max_qlen + 255) / 256, n_units), dim3(256), 0, ctx->stream, A->refs_d, A->units_d,
                      A->mem, A->mem_count, A->moff, 0);
-  hipLaunchKernelGGL(anim_cluster_kernel, dim3((n_units + 63) / 64), dim3(64), 0, ctx->stream, A->refs_d, A->units_d, n_units,
-                     A->mem, A->mem_count, A->iscratch, O);
+  if (getenv("PYANI_ANIM_SCALAR_CLUSTER"))   // debugging aid: the one-thread-per-unit statement of the same algorithm
+    hipLaunchKernelGGL(anim_cluster_kernel, dim3((n_units + 63) / 64), dim3(64), 0, ctx->stream, A->refs_d, A->units_d, n_units,
+                       A->mem, A->mem_count, A->iscratch, O);
+  else
+    hipLaunchKernelGGL(anim_cluster_wave_kernel, dim3(n_units), dim3(64), 0, ctx->stream, A->refs_d, A->units_d, A->mem,
+                       A->mem_count, A->iscratch, O);
   // work list of (unit, chain): one wave each
   std::vector<int32_t> nch(n_units);
   PG_HIP(ctx, hipMemcpyAsync(nch.data(), A->nch, n_units * 4, hipMemcpyDeviceToHost, ctx->stream));

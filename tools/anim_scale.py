@@ -40,6 +40,7 @@ out = {
                                      float(np.max(res["identity"][ok & related]))] if (ok & related).any() else None,
     "coverage_related_median": float(np.median(res["ref_aln_len"][ok & related])) / args.length if (ok & related).any() else None,
     "unrelated_with_alignment": int((ok & ~related).sum()),
+    "results_sha1": __import__("hashlib").sha1(res.tobytes()).hexdigest(),
 }
 print(json.dumps(out))
 if args.out:
