@@ -2,9 +2,11 @@
 // `nucmer --mum` + `delta-filter -1` processes pyani shells out to (pyani/anim.py:240-289) and the parse_delta
 // reduction (anim.py:292-411) with an in-process pipeline over the 2-bit/1-bit packed genomes already resident in HBM.
 //
-//   A1 anim_index_kernel     20-mer hash table of the reference genome (open addressing, 8 B slots: kmer40 | pos24)
-//   A2 anim_seed_kernel      one thread per query-strand position: table probe, left-maximality test, right extension
-//                            -> maximal exact matches >= 20 (the only O(genome) stage; HBM/MALL-latency bound)
+//   A1 anim_list_kernel      per genome, once: its 16-mers as (k-mer, position) lists partitioned into 2048 hash groups
+//                            (every position for the reference role, every 5th strand position for the query role)
+//   A2 anim_seed_kernel      one workgroup per (reference, group): the group's reference k-mers become a hash table in
+//                            LDS; the same group of every query of that reference streams through it (coalesced,
+//                            sequential HBM reads; no random global access except to verify / extend actual hits)
 //   A3 anim_cluster_kernel   per (pair, strand): MUM filter, mgaps clustering, chain extraction      (pg_anim_core.h)
 //   A4 anim_extend_kernel    per chain: gap fills + free forward extension, then backward extension towards the
 //                            previous chain's end (banded affine DP, band in registers/scratch)
@@ -19,8 +21,8 @@ using namespace pga;
 
 namespace {
 
-constexpr uint64_t SLOT_EMPTY = ~0ull;
-constexpr int MAX_HITS = 64;  // probes per lookup; 20-mers with more copies than this in one genome are skipped
+constexpr unsigned long long SLOT_EMPTY = ~0ull;
+constexpr int MAX_HITS = 4096;  // copies of one seed k-mer examined per lookup (a bound for pathological repeats only)
 
 struct RefDesc {
   const uint32_t* codes;
@@ -28,8 +30,6 @@ struct RefDesc {
   int32_t len;
   const int32_t* rec_start;  // n_rec + 1 entries
   int32_t n_rec;
-  uint64_t* table;
-  uint32_t table_mask;
 };
 
 struct UnitDesc {   // one (pair, query strand)
@@ -43,26 +43,6 @@ struct UnitDesc {   // one (pair, query strand)
   int32_t ref;   // index into the batch's reference list
 };
 
-__device__ __forceinline__ uint64_t mix40(uint64_t k) {
-  k *= 0x9E3779B97F4A7C15ull;
-  return k >> 24;
-}
-
-// 40-bit k-mer (20 bases, first base in the low bits) at stream position p, or false if a base is dirty
-__device__ __forceinline__ bool kmer_at(const uint32_t* __restrict__ codes, const uint32_t* __restrict__ mask, int32_t len,
-                                        int32_t p, uint64_t& out) {
-  if (p < 0 || p + MIN_MATCH > len) return false;
-  const uint32_t mw = p >> 5, ms = p & 31;
-  const uint64_t m = ((uint64_t)mask[mw] | ((uint64_t)mask[mw + 1] << 32)) >> ms;
-  if ((m & 0xFFFFFull) != 0xFFFFFull) return false;
-  const uint32_t cw = p >> 4, cs = 2 * (p & 15);
-  const uint64_t lo = (uint64_t)codes[cw] | ((uint64_t)codes[cw + 1] << 32);
-  uint64_t v = lo >> cs;
-  if (cs > 24) v |= (uint64_t)codes[cw + 2] << (64 - cs);
-  out = v & 0xFFFFFFFFFFull;
-  return true;
-}
-
 // 16 bases starting at stream position p (p + 16 <= len): codes in 32 bits (first base low), clean bits in 16
 __device__ __forceinline__ void get16(const uint32_t* __restrict__ codes, const uint32_t* __restrict__ mask, int32_t p,
                                       uint32_t& c, uint32_t& m) {
@@ -74,80 +54,264 @@ __device__ __forceinline__ void get16(const uint32_t* __restrict__ codes, const 
   m = (uint32_t)(ml >> ms) & 0xFFFFu;
 }
 
-__device__ __forceinline__ uint64_t revcomp40(uint64_t k) {
-  uint64_t x = __brevll(k);                                                   // pair order reversed, bits in pairs swapped
-  x = ((x & 0xAAAAAAAAAAAAAAAAull) >> 1) | ((x & 0x5555555555555555ull) << 1);  // un-swap inside each pair
-  return (~(x >> 24)) & 0xFFFFFFFFFFull;
-}
+// ---- A1/A2: seeding ------------------------------------------------------------------------------------------------
+// Every maximal exact match of length >= MIN_MATCH (20) contains, whatever its offset, a query-strand position that is a
+// multiple of SEED_STEP and starts a SEED_K-mer lying wholly inside the match (SEED_K + SEED_STEP - 1 == MIN_MATCH).  So
+// the reference lists its 16-mers at EVERY position and the query strand is looked up at every 5th position only; of
+// the sampled positions inside one match, the first (left extension < SEED_STEP) is the one that reports it.
+constexpr int SEED_K = 16, SEED_STEP = 5;
+static_assert(SEED_K + SEED_STEP - 1 == MIN_MATCH, "sampling must not miss a minimal-length match");
 
-__global__ __launch_bounds__(256) void anim_index_kernel(const RefDesc* __restrict__ refs) {
-  const RefDesc R = refs[blockIdx.y];
-  const int32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-  uint64_t k;
-  if (!kmer_at(R.codes, R.mask, R.len, p, k)) return;
-  const uint64_t val = (k << 24) | (uint32_t)p;
-  uint32_t slot = (uint32_t)mix40(k) & R.table_mask;
-  for (;;) {
-    const unsigned long long prev = atomicCAS(reinterpret_cast<unsigned long long*>(&R.table[slot]), SLOT_EMPTY, val);
-    if (prev == SLOT_EMPTY) break;
-    slot = (slot + 1) & R.table_mask;
-  }
-}
-
-// moff[u] .. moff[u+1]: this unit's slice of every per-match array (exact size, from a first count-only pass)
-__global__ __launch_bounds__(256) void anim_seed_kernel(const RefDesc* __restrict__ refs, const UnitDesc* __restrict__ units,
-                                                        Match* __restrict__ mem, uint32_t* __restrict__ mem_count,
-                                                        const uint32_t* __restrict__ moff, int count_only) {
-  const UnitDesc U = units[blockIdx.y];
-  const RefDesc R = refs[U.ref];
-  const int32_t q = blockIdx.x * blockDim.x + threadIdx.x;  // strand position
-  if (q + MIN_MATCH > U.len) return;
-  uint64_t k;
-  if (U.strand == 0) {
-    if (!kmer_at(U.codes, U.mask, U.len, q, k)) return;
+// 16-mer (first base in the low bits) of strand `strand` at strand position q (q + 16 <= len), false if a base is dirty
+__device__ __forceinline__ bool seed_kmer(const uint32_t* __restrict__ codes, const uint32_t* __restrict__ mask, int32_t len,
+                                          int32_t strand, int32_t q, uint32_t& k) {
+  uint32_t c, m;
+  if (strand == 0) {
+    get16(codes, mask, q, c, m);
+    k = c;
   } else {
-    if (!kmer_at(U.codes, U.mask, U.len, U.len - MIN_MATCH - q, k)) return;  // forward window of the same bases
-    k = revcomp40(k);
+    get16(codes, mask, len - SEED_K - q, c, m);  // forward window holding the same bases
+    uint32_t x = __brev(c);
+    x = ((x & 0xAAAAAAAAu) >> 1) | ((x & 0x55555555u) << 1);
+    k = ~x;
   }
-  const SeqView RV{R.codes, R.mask, R.len};
-  const StrandView QV{SeqView{U.codes, U.mask, U.len}, U.strand};
-  uint32_t slot = (uint32_t)mix40(k) & R.table_mask;
-  for (int probe = 0; probe < MAX_HITS; ++probe) {
-    const uint64_t v = R.table[slot];
-    if (v == SLOT_EMPTY) break;
-    slot = (slot + 1) & R.table_mask;
-    if ((v >> 24) != k) continue;
-    const int32_t r = (int32_t)(v & 0xFFFFFFu);
-    if (RV.clean(r - 1) && QV.clean(q - 1) && RV.base(r - 1) == QV.base(q - 1)) continue;  // not left-maximal
-    if (count_only) { atomicAdd(&mem_count[blockIdx.y], 1u); continue; }
-    int32_t L = MIN_MATCH;
-    // right extension, 16 bases per step (word compare of the packed codes and masks), then base by base
-    for (;;) {
-      if (r + L + 16 > R.len || q + L + 16 > U.len) break;
-      uint32_t rc_, rm_, qc_, qm_;
-      get16(R.codes, R.mask, r + L, rc_, rm_);
-      if (U.strand == 0) {
-        get16(U.codes, U.mask, q + L, qc_, qm_);
-      } else {
-        uint32_t fc, fm;
-        get16(U.codes, U.mask, U.len - 16 - (q + L), fc, fm);
-        uint32_t x = __brev(fc);
-        x = ((x & 0xAAAAAAAAu) >> 1) | ((x & 0x55555555u) << 1);
-        qc_ = ~x;
-        qm_ = __brev(fm) >> 16;
-      }
-      const uint32_t x = rc_ ^ qc_;
-      const uint32_t diff = (x | (x >> 1)) & 0x55555555u;
-      const uint32_t bad = ~(rm_ & qm_) & 0xFFFFu;
-      const int nd = diff ? (__ffs(diff) - 1) >> 1 : 16;
-      const int nb = bad ? __ffs(bad) - 1 : 16;
-      const int n = nd < nb ? nd : nb;
-      L += n;
-      if (n < 16) break;
+  return m == 0xFFFFu;
+}
+
+// Hash of a seed k-mer: the top SEED_GROUP_BITS select the group (partition of the k-mer space shared by all genomes),
+// bits 5.. select the slot inside the group's LDS table.
+constexpr int SEED_GROUP_BITS = 11, SEED_GROUPS = 1 << SEED_GROUP_BITS;
+constexpr uint32_t SEED_MAX_SLOTS = 16384;   // 128 KiB of LDS
+__device__ __forceinline__ uint32_t seed_hash(uint32_t k) { return k * 0x9E3779B1u; }
+__device__ __forceinline__ uint32_t seed_group(uint32_t h) { return h >> (32 - SEED_GROUP_BITS); }
+
+// Per-genome seed lists.  role 0 (reference): every stream position, 1 sub-list per group; role 1 (query): every
+// SEED_STEP-th position of both strands, sub-list index = 2 * group + strand.
+// Entry (64 bit): [63:43] low 21 bits of the k-mer hash (the hash is a bijection of the 32-bit k-mer and its top 11 bits
+// are the group, so these 21 bits identify the k-mer within its group) | [42:33] the SEED_STEP bases to the LEFT of the
+// k-mer, nearest first | [32] 1 = all of them exist and are clean | [31:0] position.  With both flags set, the
+// left-maximality test of a hit needs no memory access at all.
+// pass 0 counts into cnt[], pass 1 writes at goff[] + cursor (cnt[] re-zeroed in between by anim_list_scan_kernel).
+constexpr uint64_t SEED_KEY_SHIFT = 43;
+__global__ __launch_bounds__(256) void anim_list_kernel(const uint32_t* __restrict__ codes, const uint32_t* __restrict__ mask,
+                                                        int32_t len, int role, uint32_t* __restrict__ cnt,
+                                                        const uint32_t* __restrict__ goff, uint64_t* __restrict__ list, int pass) {
+  const int32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int32_t strand = role ? (int32_t)blockIdx.y : 0;
+  const int32_t p = role ? idx * SEED_STEP : idx;
+  if (p + SEED_K > len) return;
+  uint32_t k;
+  if (!seed_kmer(codes, mask, len, strand, p, k)) return;
+  const uint32_t h = seed_hash(k);
+  const uint32_t g = seed_group(h);
+  const uint32_t sub = role ? 2 * g + (uint32_t)strand : g;
+  const uint32_t at = atomicAdd(&cnt[sub], 1u);
+  if (!pass) return;
+  const StrandView V{SeqView{codes, mask, len}, strand};
+  uint64_t left = 0, flag = 1;
+  for (int j = 1; j <= SEED_STEP; ++j) {
+    if (!V.clean(p - j)) { flag = 0; left = 0; break; }
+    left |= (uint64_t)V.base(p - j) << (2 * (j - 1));
+  }
+  list[goff[sub] + at] = ((uint64_t)(h & 0x1FFFFFu) << SEED_KEY_SHIFT) | (left << 33) | (flag << 32) | (uint32_t)p;
+}
+
+// goff[0..n] = exclusive prefix of cnt[0..n), goff[n + 1] = max(cnt); cnt re-zeroed.  One wave; n is 2048 or 4096.
+__global__ __launch_bounds__(64) void anim_list_scan_kernel(uint32_t* __restrict__ cnt, uint32_t* __restrict__ goff, uint32_t n) {
+  const uint32_t lane = threadIdx.x;
+  uint32_t run = 0, mx = 0;
+  for (uint32_t base = 0; base < n; base += 64) {
+    const uint32_t c = cnt[base + lane];
+    cnt[base + lane] = 0;
+    uint32_t incl = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(incl, o, 64); if ((int)lane >= o) incl += t; }
+    goff[base + lane] = run + incl - c;
+    run += __shfl(incl, 63, 64);
+    mx = c > mx ? c : mx;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { const uint32_t t = __shfl_xor(mx, o, 64); mx = t > mx ? t : mx; }
+  if (lane == 0) { goff[n] = run; goff[n + 1] = mx; }
+}
+
+struct SeedRef {            // one per reference of the batch
+  const uint64_t* list;
+  const uint32_t* goff;     // SEED_GROUPS + 2
+  uint32_t pair_begin, pair_end;
+};
+struct SeedQry {            // one per pair of the batch (its query genome)
+  const uint64_t* list;
+  const uint32_t* goff;     // 2 * SEED_GROUPS + 2
+};
+
+// One hit of a sampled query k-mer (strand position q) on reference position r: report the maximal match it lies in,
+// unless an earlier sampled position of the same match does.  Returns false if nothing is to be appended.
+__device__ __forceinline__ bool seed_hit(const RefDesc& R, const SeqView& RV, const UnitDesc& U0, const StrandView& QV, int strand,
+                                         int32_t r, int32_t q, int32_t left, Match& out) {
+  if (left < 0) {   // left context not decidable from the list entries (sequence start / ambiguity symbol nearby)
+    left = 0;
+    while (left < SEED_STEP && RV.clean(r - 1 - left) && QV.clean(q - 1 - left) && RV.base(r - 1 - left) == QV.base(q - 1 - left)) ++left;
+  }
+  if (left == SEED_STEP) return false;
+  int32_t L = SEED_K;
+  bool ended = false;
+  // right extension, 16 bases per step (word compare of the packed codes and masks), then base by base
+  for (;;) {
+    if (r + L + 16 > R.len || q + L + 16 > U0.len) break;
+    uint32_t rc_, rm_, qc_, qm_;
+    get16(R.codes, R.mask, r + L, rc_, rm_);
+    if (strand == 0) {
+      get16(U0.codes, U0.mask, q + L, qc_, qm_);
+    } else {
+      uint32_t fc, fm;
+      get16(U0.codes, U0.mask, U0.len - 16 - (q + L), fc, fm);
+      uint32_t x = __brev(fc);
+      x = ((x & 0xAAAAAAAAu) >> 1) | ((x & 0x55555555u) << 1);
+      qc_ = ~x;
+      qm_ = __brev(fm) >> 16;
     }
+    const uint32_t x = rc_ ^ qc_;
+    const uint32_t diff = (x | (x >> 1)) & 0x55555555u;
+    const uint32_t bad = ~(rm_ & qm_) & 0xFFFFu;
+    const int nd = diff ? (__ffs(diff) - 1) >> 1 : 16;
+    const int nb = bad ? __ffs(bad) - 1 : 16;
+    const int n = nd < nb ? nd : nb;
+    L += n;
+    if (n < 16) { ended = true; break; }
+  }
+  if (!ended)   // fewer than 16 bases left in one of the sequences
     while (RV.clean(r + L) && QV.clean(q + L) && RV.base(r + L) == QV.base(q + L)) ++L;
-    const uint32_t at = atomicAdd(&mem_count[blockIdx.y], 1u);
-    if (at < moff[blockIdx.y + 1] - moff[blockIdx.y]) mem[(size_t)moff[blockIdx.y] + at] = Match{r, q, L, U.strand};
+  if (left + L < MIN_MATCH) return false;
+  out = Match{r - left, q - left, left + L, 0};
+  return true;
+}
+
+// Workgroup (g, r): LDS table of reference r's group g, then every query of r streams its group-g entries through it.
+// Each of the 16 WAVES takes every 16th pair and keeps SEED_UNROLL coalesced 512-byte loads in flight, so the stream is
+// bandwidth- rather than latency-bound.  Matches are appended to one batch-wide buffer (the `strand` field carries the
+// unit index until the scatter); unit_count[] is exact even when the buffer overflows, which is what the host uses to
+// size the slices (and to re-run a prefix).
+constexpr int SEED_BLOCK = 1024, SEED_UNROLL = 4;
+constexpr uint32_t SEED_STAGE = 96;    // matches staged in LDS per wave (table 128 KiB + staging must fit 160 KiB)
+constexpr size_t SEED_STAGE_BYTES = (SEED_BLOCK / 64) * (SEED_STAGE * sizeof(Match) + 4);
+__global__ __launch_bounds__(SEED_BLOCK) void anim_seed_kernel(const RefDesc* __restrict__ refs, const UnitDesc* __restrict__ units,
+                                                               const SeedRef* __restrict__ srefs, const SeedQry* __restrict__ sqry,
+                                                               uint32_t slot_mask, Match* __restrict__ buf, uint32_t cap,
+                                                               uint32_t* __restrict__ total, uint32_t* __restrict__ unit_count) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long tab[];
+  Match* stage = reinterpret_cast<Match*>(tab + slot_mask + 1);                    // [waves][SEED_STAGE]
+  uint32_t* stage_n = reinterpret_cast<uint32_t*>(stage + (SEED_BLOCK / 64) * SEED_STAGE);   // [waves]
+  const uint32_t g = blockIdx.x;
+  const SeedRef SR = srefs[blockIdx.y];
+  const RefDesc R = refs[blockIdx.y];
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  for (uint32_t i = tid; i <= slot_mask; i += SEED_BLOCK) tab[i] = SLOT_EMPTY;
+  if (tid < SEED_BLOCK / 64) stage_n[tid] = 0;
+  __syncthreads();
+  for (uint32_t e = SR.goff[g] + tid; e < SR.goff[g + 1]; e += SEED_BLOCK) {
+    const unsigned long long v = SR.list[e];
+    uint32_t slot = (uint32_t)(v >> (SEED_KEY_SHIFT + 5)) & slot_mask;   // hash bits 5.. (slot_mask <= 2^14 - 1)
+    while (atomicCAS(&tab[slot], SLOT_EMPTY, v) != SLOT_EMPTY) slot = (slot + 1) & slot_mask;
+  }
+  __syncthreads();
+  const SeqView RV{R.codes, R.mask, R.len};
+  for (uint32_t p = SR.pair_begin + wave; p < SR.pair_end; p += SEED_BLOCK / 64) {
+    const SeedQry SQ = sqry[p];
+    const UnitDesc U0 = units[2 * p];
+    const uint32_t o0 = SQ.goff[2 * g], o1 = SQ.goff[2 * g + 1], o2 = SQ.goff[2 * g + 2];
+    for (int strand = 0; strand < 2; ++strand) {
+      const StrandView QV{SeqView{U0.codes, U0.mask, U0.len}, strand};
+      const uint32_t unit = 2 * p + (uint32_t)strand;
+      const uint32_t e_end = strand ? o2 : o1;
+      for (uint32_t e0 = (strand ? o1 : o0); e0 < e_end; e0 += 64 * SEED_UNROLL) {
+        unsigned long long qv[SEED_UNROLL];
+#pragma unroll
+        for (int t = 0; t < SEED_UNROLL; ++t) {
+          const uint32_t e = e0 + 64 * t + lane;
+          qv[t] = e < e_end ? __builtin_nontemporal_load(&SQ.list[e]) : SLOT_EMPTY;
+        }
+#pragma unroll
+        for (int t = 0; t < SEED_UNROLL; ++t) {
+          if (qv[t] == SLOT_EMPTY) continue;
+          const uint32_t key = (uint32_t)(qv[t] >> SEED_KEY_SHIFT);
+          const uint32_t qctx = (uint32_t)(qv[t] >> 32) & 0x7FFu;   // bit 0: flag, bits 1..10: left bases
+          const int32_t q = (int32_t)(uint32_t)qv[t];
+          uint32_t slot = (key >> 5) & slot_mask;
+          for (int hits = 0; hits < MAX_HITS;) {
+            const unsigned long long v = tab[slot];
+            if (v == SLOT_EMPTY) break;   // load factor <= 1/2: every probe sequence ends
+            slot = (slot + 1) & slot_mask;
+            if ((uint32_t)(v >> SEED_KEY_SHIFT) != key) continue;
+            ++hits;
+            int32_t left = -1;
+            const uint32_t rctx = (uint32_t)(v >> 32) & 0x7FFu;
+            if (rctx & qctx & 1u) {
+              const uint32_t x = (rctx ^ qctx) >> 1;
+              const uint32_t diff = (x | (x >> 1)) & 0x155u;
+              left = diff ? (__ffs(diff) - 1) >> 1 : SEED_STEP;
+              if (left == SEED_STEP) continue;   // inside a longer match: an earlier sampled position reports it
+            }
+            Match m;
+            if (!seed_hit(R, RV, U0, QV, strand, (int32_t)(uint32_t)v, q, left, m)) continue;
+            // stage in the wave's LDS buffer; it is flushed with one pair of global atomics per SEED_STAGE/2+ matches
+            m.strand = (int32_t)unit;
+            const uint32_t at = atomicAdd(&stage_n[wave], 1u);
+            if (at < SEED_STAGE) {
+              stage[wave * SEED_STAGE + at] = m;
+            } else {   // staging buffer full (a burst of hits): straight to the global buffer
+              const uint32_t ga = atomicAdd(total, 1u);
+              atomicAdd(&unit_count[unit], 1u);
+              if (ga < cap) buf[ga] = m;
+            }
+          }
+        }
+        // uniform point: flush once the buffer is half full, or at the end of this (pair, strand) unit
+        __builtin_amdgcn_wave_barrier();
+        uint32_t n_st = stage_n[wave];
+        if (n_st > SEED_STAGE) n_st = SEED_STAGE;
+        if (n_st >= SEED_STAGE / 2 || (n_st && e0 + 64 * SEED_UNROLL >= e_end)) {
+          uint32_t base = 0;
+          if (lane == 0) {
+            base = atomicAdd(total, n_st);
+            atomicAdd(&unit_count[unit], n_st);
+            stage_n[wave] = 0;
+          }
+          base = __shfl(base, 0);
+          for (uint32_t i = lane; i < n_st; i += 64)
+            if (base + i < cap) buf[base + i] = stage[wave * SEED_STAGE + i];
+          __builtin_amdgcn_wave_barrier();
+        }
+      }
+    }
+  }
+}
+
+// Deal the appended matches into their units' slices (moff[u] .. moff[u+1]); units >= n_units wait for the next batch.
+// The seed kernel flushes bursts of one unit, so a wave usually sees one to three distinct units: one atomic per
+// distinct unit and wave instead of one per match.
+__global__ __launch_bounds__(256) void anim_scatter_kernel(const Match* __restrict__ buf, uint32_t n, const uint32_t* __restrict__ moff,
+                                                           uint32_t n_units, uint32_t* __restrict__ cursor, Match* __restrict__ mem) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t lane = threadIdx.x & 63u;
+  Match m{0, 0, 0, -1};
+  if (i < n) m = buf[i];
+  const uint32_t u = (uint32_t)m.strand;
+  bool todo = i < n && u < n_units;
+  while (true) {
+    const uint64_t rest = __ballot(todo);
+    if (!rest) break;
+    const int leader = __ffsll((unsigned long long)rest) - 1;
+    const uint32_t lu = __shfl(u, leader);
+    const uint64_t same = __ballot(todo && u == lu);
+    uint32_t base = 0;
+    if ((int)lane == leader) base = atomicAdd(&cursor[lu], (uint32_t)__popcll(same));
+    base = __shfl(base, leader);
+    if (todo && u == lu) {
+      m.strand = (int32_t)(u & 1u);
+      mem[(size_t)moff[u] + base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull))] = m;
+      todo = false;
+    }
   }
 }
 
@@ -555,7 +719,7 @@ struct WaveSeq {
 __device__ __forceinline__ void wave_seq_fill(WaveSeq& ws, const SeqView& R, const StrandView& Q, int64_t r0, int64_t q0, int dir,
                                               int32_t rmax, int32_t qmax, int lane) {
   const int32_t t = ws.loaded + lane;
-  uint8_t rb = 4, qb = 4;
+  uint8_t rb = 4, qb = 5;   // dirty / out of range: two codes that never compare equal
   if (t < rmax) { const int64_t rp = dir > 0 ? r0 + t : r0 - 1 - t; if (R.clean(rp)) rb = (uint8_t)R.base(rp); }
   if (t < qmax) { const int64_t qp = dir > 0 ? q0 + t : q0 - 1 - t; if (Q.clean(qp)) qb = (uint8_t)Q.base(qp); }
   ws.ring_r[t & 255] = rb;
@@ -563,9 +727,18 @@ __device__ __forceinline__ void wave_seq_fill(WaveSeq& ws, const SeqView& R, con
   ws.loaded += 64;
 }
 
+#ifdef PGA_DP_STATS   // development aid: per call-site DP step / cycle totals and a log2 histogram of steps per call
+__device__ unsigned long long g_dp_stats[3][40];
+__device__ int g_dp_site;
+#endif
+
 __device__ ExtResult extend_wave(const SeqView& R, const StrandView& Q, int64_t r0, int64_t q0, int dir, int32_t rmax,
                                  int32_t qmax, int32_t tr, int32_t tq) {
   constexpr int W = BAND / 2;
+#ifdef PGA_DP_STATS
+  const unsigned long long t_begin = __builtin_readcyclecounter();
+  int32_t n_steps = 0;
+#endif
   static_assert(BAND == 64, "one lane per diagonal");
   __shared__ uint8_t s_ring[2][256];
   const int lane = threadIdx.x & 63;
@@ -581,9 +754,14 @@ __device__ ExtResult extend_wave(const SeqView& R, const StrandView& Q, int64_t 
   }
   if (targeted && tr == 0 && tq == 0) { res.reached = 1; return res; }
   const int k = lane - W + koff;
-  DpCell cur{NEG_INF, 0, NEG_INF, 0, NEG_INF, 0};
-  int32_t bs = NEG_INF, bd = 0, be = 0;
-  if (lane == W - koff) { cur.h = 0; bs = 0; }
+  // Cell (i, j) = ((d - k) / 2, (d + k) / 2) of this lane's diagonal exists on anti-diagonal d iff d_lo <= d <= d_hi.
+  // Cells outside are kept at NEG_INF; everything derived from them stays far below NEG_INF / 2 ("dead": at most
+  // 2 * 10^4 steps of at most +3 / -10 each), so no per-neighbour existence tests are needed in the step itself.
+  const int32_t d_lo = k < 0 ? -k : k;
+  const int32_t d_hi = (2 * rmax + k) < (2 * qmax - k) ? (2 * rmax + k) : (2 * qmax - k);
+  int32_t h = NEG_INF, he = 0, x = NEG_INF, xe = 0, y = NEG_INF, ye = 0;
+  int32_t bs = NEG_INF / 2, bd = 0, be = 0;   // per-lane best; NEG_INF / 2: no dead cell ever qualifies
+  if (lane == W - koff) { h = 0; bs = 0; }
   const int32_t d_end = targeted ? tr + tq : rmax + qmax;
   constexpr long long BIAS = 1ll << 30;
   WaveSeq ws{s_ring[0], s_ring[1], 0};
@@ -598,31 +776,36 @@ __device__ ExtResult extend_wave(const SeqView& R, const StrandView& Q, int64_t 
   int32_t g_known = 0, t_prev = 0, fimp = 0x7FFFFFFF;
   int32_t sbs = bs, sbd = bd, sbe = be;
   for (int32_t d = 1; d <= d_end; ++d) {
+#ifdef PGA_DP_STATS
+    ++n_steps;
+#endif
     if ((d >> 1) + 36 > ws.loaded) {   // uniform; covers the diagonals of a shifted band (|koff| <= 30)
       wave_seq_fill(ws, R, Q, r0, q0, dir, rmax, qmax, lane);
       __syncthreads();
     }
-    const int32_t up_h = from_lane_above(cur.h, NEG_INF), up_he = from_lane_above(cur.he, 0);
-    const int32_t up_x = from_lane_above(cur.x, NEG_INF), up_xe = from_lane_above(cur.xe, 0);
-    const int32_t lf_h = from_lane_below(cur.h, NEG_INF), lf_he = from_lane_below(cur.he, 0);
-    const int32_t lf_y = from_lane_below(cur.y, NEG_INF), lf_ye = from_lane_below(cur.ye, 0);
+    const int32_t up_h = from_lane_above(h, NEG_INF), up_he = from_lane_above(he, 0);
+    const int32_t up_x = from_lane_above(x, NEG_INF), up_xe = from_lane_above(xe, 0);
+    const int32_t lf_h = from_lane_below(h, NEG_INF), lf_he = from_lane_below(he, 0);
+    const int32_t lf_y = from_lane_below(y, NEG_INF), lf_ye = from_lane_below(ye, 0);
     if (!((d + k) & 1)) {
-      const int32_t i = (d - k) / 2, j = (d + k) / 2;
-      if (i < 0 || j < 0 || i > rmax || j > qmax) {
-        cur = DpCell{NEG_INF, 0, NEG_INF, 0, NEG_INF, 0};
-      } else {
-        const bool has_up = i >= 1 && lane + 1 < BAND, has_left = j >= 1 && lane >= 1, has_diag = i >= 1 && j >= 1;
-        bool ok = false;
-        if (has_diag) {
-          const uint8_t rb = ws.ring_r[(i - 1) & 255], qb = ws.ring_q[(j - 1) & 255];
-          ok = rb == qb && rb < 4;
-        }
-        cur = dp_cell(has_up, up_h, up_he, up_x, up_xe, has_left, lf_h, lf_he, lf_y, lf_ye, has_diag, cur.h, cur.he, ok);
-        if (cur.h > NEG_INF / 2) {
-          if (cur.h > bs || (cur.h == bs && d >= bd)) { bs = cur.h; bd = d; be = cur.he; }
-          if (cur.h >= g_known && fimp == 0x7FFFFFFF) fimp = d;
-        }
-      }
+      const int32_t i = (d - k) >> 1, j = (d + k) >> 1;
+      const bool ok = ws.ring_r[(i - 1) & 255] == ws.ring_q[(j - 1) & 255];   // dirty codes differ (4 vs 5): never equal
+      // same candidates and tie-breaks as pga::dp_cell
+      const int32_t xh = up_h + SC_GAP_OPEN, xx = up_x + SC_GAP_EXT;
+      const bool cx = xh >= xx;
+      const int32_t nx = cx ? xh : xx, nxe = (cx ? up_he : up_xe) + 1;
+      const int32_t yh = lf_h + SC_GAP_OPEN, yy = lf_y + SC_GAP_EXT;
+      const bool cy = yh >= yy;
+      const int32_t ny = cy ? yh : yy, nye = (cy ? lf_he : lf_ye) + 1;
+      int32_t nh = h + (ok ? SC_MATCH : SC_MISMATCH), nhe = he + (ok ? 0 : 1);
+      if (nx > nh) { nh = nx; nhe = nxe; }
+      if (ny > nh) { nh = ny; nhe = nye; }
+      const bool alive = d >= d_lo && d <= d_hi;
+      h = alive ? nh : NEG_INF; x = alive ? nx : NEG_INF; y = alive ? ny : NEG_INF;
+      he = nhe; xe = nxe; ye = nye;
+      if (h >= bs) { bs = h; bd = d; be = he; }           // ties: the later cell
+      const int32_t imp = h >= g_known ? d : 0x7FFFFFFF;   // g_known >= 0: only live cells
+      fimp = imp < fimp ? imp : fimp;
     }
     if ((d % CHECK) == 0 || d == d_end) {
       const long long key = wave_max64((((long long)bs + BIAS) << 32) | (uint32_t)bd);  // max score, ties: larger d
@@ -635,16 +818,26 @@ __device__ ExtResult extend_wave(const SeqView& R, const StrandView& Q, int64_t 
         bs = sbs; bd = sbd; be = sbe;                // results as of the last check (nothing global changed until b)
         break;
       }
-      if (!__any(cur.h > NEG_INF / 2)) break;
+      if (!__any(h > NEG_INF / 2)) break;
       g_known = g; t_prev = t; fimp = 0x7FFFFFFF;
       sbs = bs; sbd = bd; sbe = be;
     }
     if (targeted && d == d_end) {
       const int lt = (tq - tr) - koff + W;
-      const int32_t th = __shfl(cur.h, lt, 64), the = __shfl(cur.he, lt, 64);
-      if (th > NEG_INF / 2) { res.di = tr; res.dj = tq; res.score = th; res.errors = the; res.reached = 1; return res; }
+      const int32_t th = __shfl(h, lt, 64), the = __shfl(he, lt, 64);
+      if (th > NEG_INF / 2) { res.di = tr; res.dj = tq; res.score = th; res.errors = the; res.reached = 1; break; }
     }
   }
+#ifdef PGA_DP_STATS
+  if (lane == 0) {
+    const int site = dir < 0 ? 2 : (tr >= 0 && tr == rmax && tq == qmax ? 0 : 1);
+    atomicAdd(&g_dp_stats[site][0], 1ull);
+    atomicAdd(&g_dp_stats[site][1], (unsigned long long)n_steps);
+    atomicAdd(&g_dp_stats[site][2], __builtin_readcyclecounter() - t_begin);
+    atomicAdd(&g_dp_stats[site][8 + (31 - __clz(n_steps | 1))], 1ull);
+  }
+#endif
+  if (res.reached) return res;
   // best cell: max score, ties -> larger d, then larger diagonal
   const long long key = wave_max64((((long long)bs + BIAS) << 32) | ((long long)(uint32_t)bd << 6) | (long long)lane);
   const int bl = (int)(key & 63);
@@ -710,10 +903,10 @@ __device__ int32_t thin_rect_errors_wave(const SeqView& R, const StrandView& Q, 
 __device__ int32_t gap_errors_wave(const SeqView& R, const StrandView& Q, int64_t r0, int32_t n, int64_t q0, int32_t m) {
   if (n == 0) return m;
   if (m == 0) return n;
-  if (n == m && n <= 2) {
+  if (n == m && n <= GAP_DIAG_MAX) {   // see pga::gap_errors: <= 2 substitutions on one diagonal need no DP
     int32_t err = 0;
     for (int32_t t = 0; t < n; ++t) err += (R.clean(r0 + t) && Q.clean(q0 + t) && R.base(r0 + t) == Q.base(q0 + t)) ? 0 : 1;
-    return err;
+    if (err <= 2) return err;
   }
   const ExtResult e = extend_wave(R, Q, r0, q0, +1, n, m, n, m);
   if (e.reached) return e.errors;
@@ -722,8 +915,119 @@ __device__ int32_t gap_errors_wave(const SeqView& R, const StrandView& Q, int64_
   return err;
 }
 
-// One WAVE per chain (work list wl: unit, chain).  phase 0: gap fills + free forward extension (extend_chain_fwd);
-// phase 1: backward extension towards the previous chain's forward end (extend_chain_bwd).
+// ---- A4a: gaps between the chained matches ---------------------------------------------------------------------------
+// One wave per chain walks its matches 64 at a time (pga::chain_inner_errors' trimming, lane = match).  Gaps that need
+// no DP (empty on one side, or <= 2 substitutions on one diagonal) are settled in the lane; the others become GapTasks
+// for anim_gapdp_kernel, so that a chain with 10^5 matches no longer occupies a single wave for its whole DP work.
+struct GapTask {
+  uint32_t unit;
+  int32_t chain;
+  int32_t r0, n, q0, m;
+};
+
+__device__ __forceinline__ int32_t wave_sum32(int32_t v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+__global__ __launch_bounds__(64) void anim_gaps_kernel(const RefDesc* __restrict__ refs, const UnitDesc* __restrict__ units,
+                                                       ClusterOut O, const uint2* __restrict__ wl, ChainFwd* __restrict__ fw,
+                                                       GapTask* __restrict__ tasks, uint32_t* __restrict__ n_tasks) {
+  const uint32_t u = wl[blockIdx.x].x;
+  const int32_t c = (int32_t)wl[blockIdx.x].y;
+  const UnitDesc U = units[u];
+  const RefDesc R = refs[U.ref];
+  const SeqView RV{R.codes, R.mask, R.len};
+  const StrandView QV{SeqView{U.codes, U.mask, U.len}, U.strand};
+  const size_t off = O.moff[u];
+  const Chain ch = O.chains[off + c];
+  const Match* cm = O.cm + off + ch.first;
+  const int lane = threadIdx.x & 63;
+  const Match f = cm[0];
+  int32_t er = f.r + f.len, eq = f.q + f.len;   // uniform: end of the last kept match
+  int32_t inner = 0;                              // per-lane partial sum
+  for (int32_t base = 1; base < ch.count; base += 64) {
+    const int32_t kq = base + lane;
+    const bool valid = kq < ch.count;
+    Match t = valid ? cm[kq] : Match{0, 0, 0, 0};
+    const Match pm = (valid && lane > 0) ? cm[kq - 1] : Match{0, 0, 0, 0};
+    // optimistic: the predecessor is kept, so the running end is the predecessor's end
+    int32_t ger = lane == 0 ? er : pm.r + pm.len, geq = lane == 0 ? eq : pm.q + pm.len;
+    int32_t trim = ger - t.r;
+    if (geq - t.q > trim) trim = geq - t.q;
+    if (trim < 0) trim = 0;
+    bool skip = valid && t.len - trim <= 0;
+    if (__any(skip)) {
+      // a match swallowed by the running end: redo this block serially (uniform loop, every lane keeps its own result)
+      for (int i = 0; i < 64 && base + i < ch.count; ++i) {
+        const int32_t tr_ = __shfl(t.r, i, 64), tq_ = __shfl(t.q, i, 64), tl_ = __shfl(t.len, i, 64);
+        int32_t tm = er - tr_;
+        if (eq - tq_ > tm) tm = eq - tq_;
+        if (tm < 0) tm = 0;
+        const bool sk = tl_ - tm <= 0;
+        if (lane == i) { ger = er; geq = eq; trim = tm; skip = sk; }
+        if (!sk) { er = tr_ + tl_; eq = tq_ + tl_; }
+      }
+    } else {
+      const int last = (ch.count - base < 64 ? ch.count - base : 64) - 1;
+      er = __shfl(t.r + t.len, last, 64);
+      eq = __shfl(t.q + t.len, last, 64);
+    }
+    bool hard = false;
+    int32_t gn = 0, gm = 0;
+    if (valid && !skip) {
+      gn = t.r + trim - ger; gm = t.q + trim - geq;
+      if (gn == 0) inner += gm;
+      else if (gm == 0) inner += gn;
+      else {
+        hard = true;
+        if (gn == gm && gn <= GAP_DIAG_MAX) {
+          int32_t e = 0;
+          for (int32_t x = 0; x < gn; ++x)
+            e += (RV.clean(ger + x) && QV.clean(geq + x) && RV.base(ger + x) == QV.base(geq + x)) ? 0 : 1;
+          if (e <= 2) { inner += e; hard = false; }
+        }
+      }
+    }
+    const uint64_t hm = __ballot(hard);
+    if (hm) {
+      uint32_t at = 0;
+      if (lane == 0) at = atomicAdd(n_tasks, (uint32_t)__popcll(hm));
+      at = __shfl(at, 0, 64);
+      if (hard) tasks[at + __popcll(hm & lanemask_lt())] = GapTask{u, c, ger, gn, geq, gm};
+    }
+  }
+  inner = wave_sum32(inner);
+  if (lane == 0) {
+    ChainFwd e;
+    e.first_r = f.r; e.first_q = f.q;
+    e.inner_err = inner;
+    e.lr = er; e.lq = eq;
+    e.re = er; e.qe = eq; e.err_fwd = 0; e.reached = 0; e.target = -1;
+    fw[off + c] = e;
+  }
+}
+
+// One wave per GapTask at a time (grid-stride over the task list, whose length only the device knows).
+__global__ __launch_bounds__(64) void anim_gapdp_kernel(const RefDesc* __restrict__ refs, const UnitDesc* __restrict__ units,
+                                                        ClusterOut O, const GapTask* __restrict__ tasks,
+                                                        const uint32_t* __restrict__ n_tasks, ChainFwd* __restrict__ fw) {
+  const uint32_t n = *n_tasks;
+  for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
+    const GapTask T = tasks[i];
+    const UnitDesc U = units[T.unit];
+    const RefDesc R = refs[U.ref];
+    const SeqView RV{R.codes, R.mask, R.len};
+    const StrandView QV{SeqView{U.codes, U.mask, U.len}, U.strand};
+    const int32_t err = gap_errors_wave(RV, QV, T.r0, T.n, T.q0, T.m);
+    if ((threadIdx.x & 63) == 0 && err) atomicAdd(&fw[O.moff[T.unit] + T.chain].inner_err, err);
+  }
+}
+
+// One WAVE per chain (work list wl: unit, chain).  phase 0: forward extension off the last match (the rest of
+// pga::extend_chain_fwd is anim_gaps_kernel + anim_gapdp_kernel); phase 1: backward extension towards the previous
+// chain's forward end (extend_chain_bwd).
 __global__ __launch_bounds__(64) void anim_extend_kernel(const RefDesc* __restrict__ refs, const UnitDesc* __restrict__ units,
                                                          ClusterOut O, const uint2* __restrict__ wl,
                                                          ChainFwd* __restrict__ fw, ChainBwd* __restrict__ bw, int phase) {
@@ -740,27 +1044,16 @@ __global__ __launch_bounds__(64) void anim_extend_kernel(const RefDesc* __restri
   ChainFwd* fwu = fw + off;
   const Match* cm = O.cm + off;
   if (phase == 0) {
-    ChainFwd e;
-    const Match f = cm[ch.first];
-    e.first_r = f.r; e.first_q = f.q;
-    int32_t inner = 0, er = f.r + f.len, eq = f.q + f.len;
-    for (int kq = 1; kq < ch.count; ++kq) {
-      Match t = cm[ch.first + kq];
-      int32_t trim = er - t.r;
-      if (eq - t.q > trim) trim = eq - t.q;
-      if (trim > 0) { t.r += trim; t.q += trim; t.len -= trim; }
-      if (t.len <= 0) continue;
-      inner += gap_errors_wave(RV, QV, er, t.r - er, eq, t.q - eq);
-      er = t.r + t.len; eq = t.q + t.len;
-    }
-    e.inner_err = inner;
-    e.lr = er; e.lq = eq;
-    int32_t nr, nq;
-    e.target = pick_forward_target(O.chains + off, cm, O.next_of + off, c, er, eq, nr, nq);
+    ChainFwd e = fwu[c];   // first match, last match end and gap errors come from anim_gaps_kernel / anim_gapdp_kernel
+    const int32_t er = e.lr, eq = e.lq;
+    int32_t nr, nq, re, qe, err_fwd, reached;
+    const int32_t target = pick_forward_target(O.chains + off, cm, O.next_of + off, c, er, eq, nr, nq);
     forward_extension([&](int32_t cr, int32_t cq, int32_t rmax, int32_t qmax, int32_t tr, int32_t tq) {
                         return extend_wave(RV, QV, cr, cq, +1, rmax, qmax, tr, tq); },
-                      er, eq, r_hi, q_hi, nr, nq, e.re, e.qe, e.err_fwd, e.reached);
-    if ((threadIdx.x & 63) == 0) fwu[c] = e;
+                      er, eq, r_hi, q_hi, nr, nq, re, qe, err_fwd, reached);
+    if ((threadIdx.x & 63) == 0) {   // field-wise: inner_err may still be receiving atomics from the gap DP kernel
+      fwu[c].re = re; fwu[c].qe = qe; fwu[c].err_fwd = err_fwd; fwu[c].reached = reached; fwu[c].target = target;
+    }
   } else {
     const int32_t p = O.prev_of[off + c];
     const int32_t first_r = fwu[c].first_r, first_q = fwu[c].first_q;
@@ -883,8 +1176,17 @@ int anim_alloc(pg_ctx* ctx, T*& p, size_t n) {
 // batch should be as large as memory allows: thousands of units in flight are what fills the GPU.
 namespace {
 struct AnimScratch {
-  size_t units = 0, pairs = 0, refs = 0, table_slots = 0, recs = 0, wl = 0, matches = 0;
-  uint64_t* table = nullptr;
+  size_t units = 0, pairs = 0, refs = 0, recs = 0, wl = 0, matches = 0;
+  // per-genome seed lists (built once per resident genome and role, dropped by pg_clear_genomes)
+  struct GenomeIdx {
+    uint64_t *ref_list = nullptr, *qry_list = nullptr;
+    uint32_t *ref_goff = nullptr, *qry_goff = nullptr;
+    uint32_t ref_max = 0;   // largest reference group (sizes the LDS table)
+  };
+  std::vector<GenomeIdx> gidx;
+  uint32_t* list_cnt = nullptr;   // 2 * SEED_GROUPS counters shared by the list builds
+  SeedRef* srefs_d = nullptr;
+  SeedQry* sqry_d = nullptr;
   int32_t* recs_d = nullptr;
   RefDesc* refs_d = nullptr;
   UnitDesc* units_d = nullptr;
@@ -899,6 +1201,11 @@ struct AnimScratch {
   ChainBwd* bw = nullptr;
   FinishScratch S{};
   uint2* wl_d = nullptr;
+  GapTask* tasks_d = nullptr; // gaps that need the DP (at most one per match)
+  size_t tasks = 0;
+  Match* seedbuf = nullptr;   // batch-wide append buffer of the seed pass
+  size_t seed_cap = 0;
+  uint32_t* seed_total = nullptr;
 };
 
 template <typename T>
@@ -915,20 +1222,71 @@ static AnimScratch* anim_scratch(pg_ctx* ctx) {
   return static_cast<AnimScratch*>(ctx->anim_scratch);
 }
 
+void pg_anim_drop_lists(pg_ctx* ctx) {
+  AnimScratch* A = static_cast<AnimScratch*>(ctx->anim_scratch);
+  if (!A) return;
+  for (auto& g : A->gidx) {
+    void* ptrs[] = {g.ref_list, g.qry_list, g.ref_goff, g.qry_goff};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+  }
+  A->gidx.clear();
+}
+
+// Build the seed lists the batch needs and does not have yet: reference role for `ref_genomes`, query role for `qry_genomes`.
+static int anim_ensure_lists(pg_ctx* ctx, AnimScratch* A, const std::vector<int32_t>& ref_genomes, const std::vector<int32_t>& qry_genomes) {
+  int rc;
+  if (A->gidx.size() < ctx->genomes.size()) A->gidx.resize(ctx->genomes.size());
+  if (!A->list_cnt && (rc = regrow(ctx, A->list_cnt, (size_t)2 * SEED_GROUPS))) return rc;
+  std::vector<int32_t> fresh_refs;
+  for (int role = 0; role < 2; ++role) {
+    for (int32_t gid : role ? qry_genomes : ref_genomes) {
+      AnimScratch::GenomeIdx& X = A->gidx[gid];
+      if (role ? X.qry_list != nullptr : X.ref_list != nullptr) continue;
+      const PgGenome& G = ctx->genomes[gid];
+      const int32_t len = (int32_t)G.stream_len;
+      const uint32_t n_sub = role ? 2 * SEED_GROUPS : SEED_GROUPS;
+      const size_t bound = role ? 2 * ((size_t)len / SEED_STEP + 1) : (size_t)len + 1;
+      uint64_t*& list = role ? X.qry_list : X.ref_list;
+      uint32_t*& goff = role ? X.qry_goff : X.ref_goff;
+      if ((rc = regrow(ctx, list, bound))) return rc;
+      if ((rc = regrow(ctx, goff, (size_t)n_sub + 2))) return rc;
+      const uint32_t* codes = ctx->d_codes + G.arena_start / 16;
+      const uint32_t* mask = ctx->d_mask + G.arena_start / 32;
+      const int32_t n_idx = role ? len / SEED_STEP + 1 : len;
+      const dim3 grid((uint32_t)(n_idx + 255) / 256, role ? 2 : 1);
+      PG_HIP(ctx, hipMemsetAsync(A->list_cnt, 0, (size_t)n_sub * 4, ctx->stream));
+      hipLaunchKernelGGL(anim_list_kernel, grid, dim3(256), 0, ctx->stream, codes, mask, len, role, A->list_cnt,
+                         (const uint32_t*)nullptr, (uint64_t*)nullptr, 0);
+      hipLaunchKernelGGL(anim_list_scan_kernel, dim3(1), dim3(64), 0, ctx->stream, A->list_cnt, goff, n_sub);
+      hipLaunchKernelGGL(anim_list_kernel, grid, dim3(256), 0, ctx->stream, codes, mask, len, role, A->list_cnt,
+                         (const uint32_t*)goff, list, 1);
+      if (!role) fresh_refs.push_back(gid);
+    }
+  }
+  PG_HIP(ctx, hipGetLastError());
+  if (!fresh_refs.empty()) {
+    PG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int32_t gid : fresh_refs)
+      PG_HIP(ctx, hipMemcpy(&A->gidx[gid].ref_max, A->gidx[gid].ref_goff + SEED_GROUPS + 1, 4, hipMemcpyDeviceToHost));
+  }
+  return PG_OK;
+}
+
 void pg_anim_free_scratch(pg_ctx* ctx) {
   AnimScratch* A = static_cast<AnimScratch*>(ctx->anim_scratch);
   if (!A) return;
-  void* ptrs[] = {A->table, A->recs_d, A->refs_d, A->units_d, A->mem_count, A->moff, A->nch, A->status, A->out, A->mem, A->cm,
+  pg_anim_drop_lists(ctx);
+  void* ptrs[] = {A->list_cnt, A->srefs_d, A->sqry_d, A->recs_d, A->refs_d, A->units_d, A->mem_count, A->moff, A->nch, A->status, A->out, A->mem, A->cm,
                   A->iscratch, A->order, A->prev, A->next, A->alnof, A->chains, A->fw, A->bw, A->S.alns, A->S.a_rrec,
-                  A->S.a_qrec, A->S.idx, A->S.from, A->S.sc, A->wl_d};
+                  A->S.a_qrec, A->S.idx, A->S.from, A->S.sc, A->wl_d, A->seedbuf, A->seed_total, A->tasks_d};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   delete A;
   ctx->anim_scratch = nullptr;
 }
 
-// One batch of ordered pairs (ref_ids grouped).  Two seeding passes: the first only counts the maximal matches of every
-// (pair, strand) unit, so that every per-match array gets exactly the slice it needs; this is what lets thousands of
-// units — whose single-thread cluster kernels are latency-bound — be in flight at once within the HBM budget.
+// One batch of ordered pairs (ref_ids grouped).  The seed pass appends every unit's matches to one buffer and counts them
+// per (pair, strand) unit; a scatter then gives every per-match array exactly the slice it needs, which is what lets
+// thousands of units be in flight at once within the HBM budget.
 // If the batch needs more than max_matches, only its first n_done pairs are processed (the caller continues from there).
 int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_ids, uint32_t n_pairs, int filter_1to1,
                       uint64_t max_matches, pg_anim_result* out_host, uint32_t* n_done) {
@@ -945,20 +1303,13 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
   std::vector<RefDesc> refs(n_refs);
   std::vector<int32_t> recs;
   std::vector<uint32_t> ref_rec_off(n_refs), qry_rec_off(n_pairs);
-  std::vector<size_t> table_off(n_refs);
-  size_t slots = 0;
   int32_t max_rlen = 0, max_qlen = 0;
   for (uint32_t r = 0; r < n_refs; ++r) {
     const PgGenome& G = ctx->genomes[ref_list[r]];
-    uint32_t tbits = 10;
-    while ((1ull << tbits) < (uint64_t)(G.stream_len + G.stream_len / 2 + 16)) ++tbits;
     refs[r].codes = ctx->d_codes + G.arena_start / 16;
     refs[r].mask = ctx->d_mask + G.arena_start / 32;
     refs[r].len = (int32_t)G.stream_len;
     refs[r].n_rec = (int32_t)G.n_rec;
-    refs[r].table_mask = (uint32_t)((1ull << tbits) - 1);
-    table_off[r] = slots;
-    slots += (size_t)1 << tbits;
     ref_rec_off[r] = (uint32_t)recs.size();
     recs.insert(recs.end(), G.rec_start.begin(), G.rec_start.end());
     if ((int32_t)G.stream_len > max_rlen) max_rlen = (int32_t)G.stream_len;
@@ -969,9 +1320,12 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
     recs.insert(recs.end(), Q.rec_start.begin(), Q.rec_start.end());
     if ((int32_t)Q.stream_len > max_qlen) max_qlen = (int32_t)Q.stream_len;
   }
-  if (slots > A->table_slots) { if ((rc = regrow(ctx, A->table, slots))) return rc; A->table_slots = slots; }
   if (recs.size() > A->recs) { if ((rc = regrow(ctx, A->recs_d, recs.size()))) return rc; A->recs = recs.size(); }
-  if (n_refs > A->refs) { if ((rc = regrow(ctx, A->refs_d, n_refs))) return rc; A->refs = n_refs; }
+  if (n_refs > A->refs) {
+    if ((rc = regrow(ctx, A->refs_d, n_refs))) return rc;
+    if ((rc = regrow(ctx, A->srefs_d, n_refs))) return rc;
+    A->refs = n_refs;
+  }
   if (n_units > A->units) {
     if ((rc = regrow(ctx, A->units_d, n_units))) return rc;
     if ((rc = regrow(ctx, A->mem_count, n_units))) return rc;
@@ -981,10 +1335,11 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
   }
   if (n_pairs > A->pairs) {
     if ((rc = regrow(ctx, A->status, n_pairs))) return rc;
+    if ((rc = regrow(ctx, A->sqry_d, n_pairs))) return rc;
     if ((rc = regrow(ctx, A->out, n_pairs))) return rc;
     A->pairs = n_pairs;
   }
-  for (uint32_t r = 0; r < n_refs; ++r) { refs[r].rec_start = A->recs_d + ref_rec_off[r]; refs[r].table = A->table + table_off[r]; }
+  for (uint32_t r = 0; r < n_refs; ++r) refs[r].rec_start = A->recs_d + ref_rec_off[r];
   std::vector<UnitDesc> units(n_units);
   for (uint32_t p = 0; p < n_pairs; ++p) {
     const PgGenome& Q = ctx->genomes[qry_ids[p]];
@@ -1003,26 +1358,74 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
   PG_HIP(ctx, hipMemcpyAsync(A->recs_d, recs.data(), recs.size() * 4, hipMemcpyHostToDevice, ctx->stream));
   PG_HIP(ctx, hipMemcpyAsync(A->refs_d, refs.data(), n_refs * sizeof(RefDesc), hipMemcpyHostToDevice, ctx->stream));
   PG_HIP(ctx, hipMemcpyAsync(A->units_d, units.data(), n_units * sizeof(UnitDesc), hipMemcpyHostToDevice, ctx->stream));
-  PG_HIP(ctx, hipMemsetAsync(A->table, 0xFF, slots * 8, ctx->stream));
-  PG_HIP(ctx, hipMemsetAsync(A->mem_count, 0, n_units * 4, ctx->stream));
-  hipLaunchKernelGGL(anim_index_kernel, dim3((max_rlen + 255) / 256, n_refs), dim3(256), 0, ctx->stream, A->refs_d);
-  // pass 1: count
-  hipLaunchKernelGGL(anim_seed_kernel, dim3((max_qlen + 255) / 256, n_units), dim3(256), 0, ctx->stream, A->refs_d, A->units_d,
-                     (Match*)nullptr, A->mem_count, (const uint32_t*)nullptr, 1);
-  std::vector<uint32_t> cnt(n_units), moff(n_units + 1, 0);
-  PG_HIP(ctx, hipMemcpyAsync(cnt.data(), A->mem_count, n_units * 4, hipMemcpyDeviceToHost, ctx->stream));
-  PG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  uint32_t pairs_fit = 0;
-  uint64_t tot = 0;
-  for (uint32_t p = 0; p < n_pairs; ++p) {
-    const uint64_t need = (uint64_t)cnt[2 * p] + cnt[2 * p + 1] + 2;   // +1 per unit: never a zero-size slice
-    if (p > 0 && tot + need > max_matches) break;
-    tot += need;
-    pairs_fit = p + 1;
+  // seeding: LDS-resident reference groups, streamed query groups; one pass appends (unit, match) records and the
+  // per-unit counts it leaves are exact even if the buffer overflowed
+  {
+    std::vector<int32_t> qry_list(qry_ids, qry_ids + n_pairs);
+    std::sort(qry_list.begin(), qry_list.end());
+    qry_list.erase(std::unique(qry_list.begin(), qry_list.end()), qry_list.end());
+    if ((rc = anim_ensure_lists(ctx, A, ref_list, qry_list))) return rc;
   }
-  n_pairs = pairs_fit;
-  n_units = 2 * n_pairs;
+  uint32_t max_group = 1;
+  for (uint32_t r = 0; r < n_refs; ++r) if (A->gidx[ref_list[r]].ref_max > max_group) max_group = A->gidx[ref_list[r]].ref_max;
+  uint32_t slots = 256;
+  while (slots < 2 * max_group) slots <<= 1;
+  if (slots > SEED_MAX_SLOTS)
+    return pg_fail(ctx, PG_E_CAPACITY, "anim seeding: a reference k-mer group does not fit the LDS table (genome too large or too repetitive)");
+  std::vector<SeedRef> srefs(n_refs);
+  std::vector<SeedQry> sqry(n_pairs);
+  for (uint32_t p = 0; p < n_pairs; ++p) sqry[p] = SeedQry{A->gidx[qry_ids[p]].qry_list, A->gidx[qry_ids[p]].qry_goff};
+  auto fill_srefs = [&](uint32_t limit) {
+    for (uint32_t r = 0; r < n_refs; ++r) srefs[r] = SeedRef{A->gidx[ref_list[r]].ref_list, A->gidx[ref_list[r]].ref_goff, 0, 0};
+    for (uint32_t p = 0; p < limit; ++p) {
+      SeedRef& S = srefs[ref_of_pair[p]];
+      if (S.pair_end == 0) S.pair_begin = p;
+      S.pair_end = p + 1;
+    }
+  };
+  PG_HIP(ctx, hipMemcpyAsync(A->sqry_d, sqry.data(), n_pairs * sizeof(SeedQry), hipMemcpyHostToDevice, ctx->stream));
+  static bool lds_attr_set = false;
+  if (!lds_attr_set) {
+    PG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(anim_seed_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)(SEED_MAX_SLOTS * 8 + SEED_STAGE_BYTES)));
+    lds_attr_set = true;
+  }
+  if (!A->seedbuf) {
+    A->seed_cap = (size_t)1 << 26;   // 1 GiB to start with; grows on overflow
+    if ((rc = regrow(ctx, A->seedbuf, A->seed_cap))) return rc;
+    if ((rc = regrow(ctx, A->seed_total, 1))) return rc;
+  }
+  std::vector<uint32_t> cnt(n_units), moff;
+  uint32_t total = 0, pairs_fit = 0;
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    fill_srefs(n_pairs);
+    PG_HIP(ctx, hipMemcpyAsync(A->srefs_d, srefs.data(), n_refs * sizeof(SeedRef), hipMemcpyHostToDevice, ctx->stream));
+    PG_HIP(ctx, hipMemsetAsync(A->mem_count, 0, n_units * 4, ctx->stream));
+    PG_HIP(ctx, hipMemsetAsync(A->seed_total, 0, 4, ctx->stream));
+    hipLaunchKernelGGL(anim_seed_kernel, dim3(SEED_GROUPS, n_refs), dim3(SEED_BLOCK), (size_t)slots * 8 + SEED_STAGE_BYTES, ctx->stream, A->refs_d, A->units_d,
+                       A->srefs_d, A->sqry_d, slots - 1, A->seedbuf, (uint32_t)A->seed_cap, A->seed_total, A->mem_count);
+    PG_HIP(ctx, hipMemcpyAsync(cnt.data(), A->mem_count, n_units * 4, hipMemcpyDeviceToHost, ctx->stream));
+    PG_HIP(ctx, hipMemcpyAsync(&total, A->seed_total, 4, hipMemcpyDeviceToHost, ctx->stream));
+    PG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    uint64_t tot = 0, raw = 0;
+    pairs_fit = 0;
+    for (uint32_t p = 0; p < n_pairs; ++p) {
+      const uint64_t need = (uint64_t)cnt[2 * p] + cnt[2 * p + 1] + 2;   // +1 per unit: never a zero-size slice
+      if (p > 0 && tot + need > max_matches) break;
+      tot += need;
+      raw += need - 2;
+      pairs_fit = p + 1;
+    }
+    n_pairs = pairs_fit;
+    n_units = 2 * n_pairs;
+    if (total <= A->seed_cap) break;
+    if (attempt == 1) return pg_fail(ctx, PG_E_CAPACITY, "anim seeding: append buffer overflowed twice");
+    // overflow: make room for the prefix of pairs that fits the batch budget and seed that prefix again
+    A->seed_cap = (size_t)(raw + raw / 8 + 1024);
+    if ((rc = regrow(ctx, A->seedbuf, A->seed_cap))) return rc;
+  }
   *n_done = n_pairs;
+  moff.assign((size_t)n_units + 1, 0);
   for (uint32_t u = 0; u < n_units; ++u) moff[u + 1] = moff[u] + cnt[u] + 1;
   const size_t M = moff[n_units];
   if (M > A->matches) {
@@ -1050,9 +1453,9 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
   PG_HIP(ctx, hipMemsetAsync(A->mem_count, 0, n_units * 4, ctx->stream));
   PG_HIP(ctx, hipMemsetAsync(A->status, 0, n_pairs * 4, ctx->stream));
   ClusterOut O{A->moff, A->cm, A->chains, A->nch, A->order, A->prev, A->next, A->status};
-  // pass 2: write the matches
-  hipLaunchKernelGGL(anim_seed_kernel, dim3((max_qlen + 255) / 256, n_units), dim3(256), 0, ctx->stream, A->refs_d, A->units_d,
-                     A->mem, A->mem_count, A->moff, 0);
+  if (total)
+    hipLaunchKernelGGL(anim_scatter_kernel, dim3((total + 255) / 256), dim3(256), 0, ctx->stream, A->seedbuf, total, A->moff, n_units,
+                       A->mem_count, A->mem);
   if (getenv("PYANI_ANIM_SCALAR_CLUSTER"))   // debugging aid: the one-thread-per-unit statement of the same algorithm
     hipLaunchKernelGGL(anim_cluster_kernel, dim3((n_units + 63) / 64), dim3(64), 0, ctx->stream, A->refs_d, A->units_d, n_units,
                        A->mem, A->mem_count, A->iscratch, O);
@@ -1069,6 +1472,12 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
   if (!wl.empty()) {
     if (wl.size() > A->wl) { if ((rc = regrow(ctx, A->wl_d, wl.size() + wl.size() / 2))) return rc; A->wl = wl.size() + wl.size() / 2; }
     PG_HIP(ctx, hipMemcpyAsync(A->wl_d, wl.data(), wl.size() * sizeof(uint2), hipMemcpyHostToDevice, ctx->stream));
+    if (M > A->tasks) { if ((rc = regrow(ctx, A->tasks_d, M))) return rc; A->tasks = M; }
+    PG_HIP(ctx, hipMemsetAsync(A->seed_total, 0, 4, ctx->stream));   // reused as the gap-task counter
+    hipLaunchKernelGGL(anim_gaps_kernel, dim3((uint32_t)wl.size()), dim3(64), 0, ctx->stream, A->refs_d, A->units_d, O, A->wl_d,
+                       A->fw, A->tasks_d, A->seed_total);
+    hipLaunchKernelGGL(anim_gapdp_kernel, dim3((uint32_t)ctx->num_cu * 32u), dim3(64), 0, ctx->stream, A->refs_d, A->units_d, O,
+                       A->tasks_d, A->seed_total, A->fw);
     for (int phase = 0; phase < 2; ++phase)
       hipLaunchKernelGGL(anim_extend_kernel, dim3((uint32_t)wl.size()), dim3(64), 0, ctx->stream, A->refs_d, A->units_d, O,
                          A->wl_d, A->fw, A->bw, phase);
@@ -1078,6 +1487,18 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
   PG_HIP(ctx, hipGetLastError());
   PG_HIP(ctx, hipMemcpyAsync(out_host, A->out, n_pairs * sizeof(pg_anim_result), hipMemcpyDeviceToHost, ctx->stream));
   PG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+#ifdef PGA_DP_STATS
+  {
+    unsigned long long st[3][40];
+    PG_HIP(ctx, hipMemcpyFromSymbol(st, HIP_SYMBOL(g_dp_stats), sizeof(st)));
+    const char* names[3] = {"gap", "fwd", "bwd"};
+    for (int k = 0; k < 3; ++k) {
+      fprintf(stderr, "[dp-stats] %s calls %llu steps %llu cycles %llu  hist(log2 steps):", names[k], st[k][0], st[k][1], st[k][2]);
+      for (int b = 0; b < 20; ++b) fprintf(stderr, " %llu", st[k][8 + b]);
+      fprintf(stderr, "\n");
+    }
+  }
+#endif
   return PG_OK;
 }
 

@@ -80,6 +80,7 @@ struct ExtResult {
 
 constexpr int32_t NEG_INF = -(1 << 28);
 constexpr int CHECK_EVERY = 1;
+constexpr int GAP_DIAG_MAX = 64;  // same-diagonal gaps up to this length are first tried as pure substitutions
 
 struct DpCell { int32_t h, he, x, xe, y, ye; };
 
@@ -215,11 +216,13 @@ template <typename RefT, typename QryT>
 PG_HD int32_t gap_errors(const RefT& R, const QryT& Q, int64_t r0, int32_t n, int64_t q0, int32_t m) {
   if (n == 0) return m;
   if (m == 0) return n;
-  if (n == m && n <= 2) {   // isolated SNPs: substitutions always beat a gap pair (2 * -7 > 2 * -10)
+  if (n == m && n <= GAP_DIAG_MAX) {
+    // A gap on one diagonal with e <= 2 mismatches: the straight path scores 3n - 10e >= 3n - 20, any path with an
+    // insertion/deletion pair at most 3(n-1) - 20 -> the diagonal is the unique optimum and the DP would return e.
     int32_t err = 0;
     for (int32_t t = 0; t < n; ++t)
       err += (R.clean(r0 + t) && Q.clean(q0 + t) && R.base(r0 + t) == Q.base(q0 + t)) ? 0 : 1;
-    return err;
+    if (err <= 2) return err;
   }
   const ExtResult e = extend_banded(R, Q, r0, q0, +1, n, m, n, m);
   if (e.reached) return e.errors;

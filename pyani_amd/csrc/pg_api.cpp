@@ -385,6 +385,7 @@ int pg_clear_genomes(pg_ctx* ctx) {
   if (!ctx) return PG_E_ARG;
   PG_HIP(ctx, hipSetDevice(ctx->device));
   PG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  pg_anim_drop_lists(ctx);
   ctx->genomes.clear();
   ctx->arena_used = 0;
   ctx->n_resident = 0;

@@ -20,26 +20,23 @@
 // Template knobs (the product instantiates ONE configuration; the microbenchmark times the others):
 //   PF    register prefetch depth in super-tiles
 //   MODE  0 = full kernel, 1 = loads only (no LDS atomics), 2 = atomics only (no global loads in the loop)
-//   REPL  histogram replicas (1 or 2; lane parity selects the replica)
+//   BLOCK workgroup size (1024 or 512); two workgroups share a CU (73 KiB of LDS each), so one group's flush /
+//         prologue overlaps the other's streaming
 #pragma once
 
-constexpr int K0_BLOCK = 1024;
 constexpr int K0_H7_BINS = 16384;
-constexpr uint32_t K0_FORCE_FLUSH_TILES = 16384;  // 2^30 bases: keeps every u32 bin far from overflow
+constexpr uint32_t K0_FORCE_FLUSH_TILES = 16384;  // <= 2^30 bases: keeps every u32 bin far from overflow
 
-// LDS layout in words: H7[REPL][16384] | S_hi[4096] | S_lo[4096] | S_hi2[1024] | S_lo2[1024] | F4[256] | E3[64] | E2[16]
-template <int REPL>
+// LDS layout in words: H7[16384] | S_hi2[1024] | S_lo2[1024] | F4[256] | E3[64] | E2[16]   = 73.3 KiB: two workgroups per CU
 struct K0Lds {
   static constexpr int H7 = 0;
-  static constexpr int S_HI = H7 + REPL * K0_H7_BINS;
-  static constexpr int S_LO = S_HI + 4096;
-  static constexpr int S_HI2 = S_LO + 4096;
+  static constexpr int S_HI2 = H7 + K0_H7_BINS;
   static constexpr int S_LO2 = S_HI2 + 1024;
   static constexpr int F4 = S_LO2 + 1024;
   static constexpr int E3 = F4 + 256;
   static constexpr int E2 = E3 + 64;
   static constexpr int WORDS = E2 + 16;
-  static_assert(WORDS * 4 <= 160 * 1024, "LDS budget of one gfx950 CU exceeded");
+  static_assert(2 * WORDS * 4 <= 160 * 1024, "two workgroups must fit the 160 KiB of one gfx950 CU");
 };
 
 __device__ __forceinline__ uint32_t nat4_from_lowfirst(uint32_t r) {
@@ -116,7 +113,7 @@ __device__ __forceinline__ void k0_count_lane(const LaneData& d, uint32_t* lds_h
   }
 }
 
-template <int MODE, int REPL>
+template <int MODE>
 __device__ __forceinline__ void k0_process(LaneData d, uint32_t* lds, uint32_t tid, uint32_t& sink) {
   // look-ahead from the next lane (lane 63 keeps the wave-uniform word it loaded)
   d.nc = (uint32_t)__builtin_amdgcn_update_dpp((int)d.nc, (int)d.c.x, 0x130 /*wave_shl:1*/, 0xf, 0xf, false);
@@ -125,10 +122,10 @@ __device__ __forceinline__ void k0_process(LaneData d, uint32_t* lds, uint32_t t
     sink ^= d.c.x ^ d.c.y ^ d.c.z ^ d.c.w ^ d.m.x ^ d.m.y ^ d.nc ^ d.nm;
     return;
   }
-  using L = K0Lds<REPL>;
+  using L = K0Lds;
   const bool all_clean = (d.m.x & d.m.y) == 0xFFFFFFFFu && (d.nm & 7u) == 7u;
   const bool none_clean = (d.m.x | d.m.y) == 0u;
-  uint32_t* h7 = lds + L::H7 + (REPL == 2 ? ((tid & 1u) << 14) : 0u);
+  uint32_t* h7 = lds + L::H7;
   if (__all(all_clean)) {
     k0_count_lane<false>(d, h7, nullptr, nullptr, nullptr);
   } else if (!__all(none_clean)) {
@@ -138,50 +135,42 @@ __device__ __forceinline__ void k0_process(LaneData d, uint32_t* lds, uint32_t t
 
 // Fold the heptamer histogram into the tetramers at its four offsets and push the block's partial counts to the
 // genome's accumulator.  Low-first encoding: heptamer f = b0 | b1<<2 | ... | b6<<12.
-//   S_hi[b0..b5] = sum_b6 H7      S_hi2[b0..b4] = sum_b5 S_hi     T0[b0..b3] = sum_b4 S_hi2   T1[b1..b4] = sum_b0 S_hi2
-//   S_lo[b1..b6] = sum_b0 H7      S_lo2[b2..b6] = sum_b1 S_lo     T2[b2..b5] = sum_b6 S_lo2   T3[b3..b6] = sum_b2 S_lo2
-template <int REPL>
+//   S_hi2[b0..b4] = sum_{b5,b6} H7 (16 strided reads)     T0[b0..b3] = sum_b4 S_hi2   T1[b1..b4] = sum_b0 S_hi2
+//   S_lo2[b2..b6] = sum_{b0,b1} H7 (16 contiguous words)  T2[b2..b5] = sum_b6 S_lo2   T3[b3..b6] = sum_b2 S_lo2
+template <int BLOCK>
 __device__ __forceinline__ void k0_flush(uint32_t* lds, unsigned long long* __restrict__ acc_g, uint32_t tid) {
-  using L = K0Lds<REPL>;
+  using L = K0Lds;
   uint32_t* H7 = lds + L::H7;
-  uint32_t* S_hi = lds + L::S_HI;
-  uint32_t* S_lo = lds + L::S_LO;
   uint32_t* S_hi2 = lds + L::S_HI2;
   uint32_t* S_lo2 = lds + L::S_LO2;
   uint32_t* F4 = lds + L::F4;
   uint32_t* E3 = lds + L::E3;
   uint32_t* E2 = lds + L::E2;
+  for (uint32_t o = tid; o < 1024; o += BLOCK) {
+    uint32_t hi = 0;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const uint32_t o = tid + i * K0_BLOCK;  // 0..4095
-    uint32_t hi = 0, lo = 0;
+    for (int t = 0; t < 16; ++t) hi += H7[o + 1024 * t];
+    uint32_t lo = 0;
 #pragma unroll
-    for (int r = 0; r < REPL; ++r) {
-      const uint32_t* H = H7 + r * K0_H7_BINS;
-      hi += H[o] + H[o + 4096] + H[o + 8192] + H[o + 12288];
-      const uint4 q = *reinterpret_cast<const uint4*>(H + 4 * o);
+    for (int t = 0; t < 4; ++t) {
+      const uint4 q = *reinterpret_cast<const uint4*>(H7 + 16 * o + 4 * t);
       lo += q.x + q.y + q.z + q.w;
     }
-    S_hi[o] = hi;
-    S_lo[o] = lo;
+    S_hi2[o] = hi;
+    S_lo2[o] = lo;
   }
   __syncthreads();
-  {  // zero H7 for the next genome (all reads of H7 are done), and the second marginal
+  {  // zero H7 for the next genome (all reads of H7 are done)
     uint4* z = reinterpret_cast<uint4*>(H7);
-#pragma unroll
-    for (int i = 0; i < REPL * 4; ++i) z[tid + i * K0_BLOCK] = make_uint4(0, 0, 0, 0);
-    S_hi2[tid] = S_hi[tid] + S_hi[tid + 1024] + S_hi[tid + 2048] + S_hi[tid + 3072];
-    const uint4 q = *reinterpret_cast<const uint4*>(S_lo + 4 * tid);
-    S_lo2[tid] = q.x + q.y + q.z + q.w;
+    for (uint32_t i = tid; i < K0_H7_BINS / 4; i += BLOCK) z[i] = make_uint4(0, 0, 0, 0);
   }
-  __syncthreads();
   if (tid < 256) {
     const uint32_t t0 = S_hi2[tid] + S_hi2[tid + 256] + S_hi2[tid + 512] + S_hi2[tid + 768];
     const uint4 q1 = *reinterpret_cast<const uint4*>(S_hi2 + 4 * tid);
     const uint32_t t2 = S_lo2[tid] + S_lo2[tid + 256] + S_lo2[tid + 512] + S_lo2[tid + 768];
     const uint4 q3 = *reinterpret_cast<const uint4*>(S_lo2 + 4 * tid);
     const uint32_t tot = t0 + (q1.x + q1.y + q1.z + q1.w) + t2 + (q3.x + q3.y + q3.z + q3.w);
-    if (tot) atomicAdd(&F4[nat4_from_lowfirst(tid)], tot);  // the slow path may have counted into F4 as well
+    if (tot) atomicAdd(&F4[nat4_from_lowfirst(tid)], tot);  // the dirty path may have counted into F4 as well
   }
   __syncthreads();
   if (tid < PG_ACC_WORDS) {
@@ -194,64 +183,66 @@ __device__ __forceinline__ void k0_flush(uint32_t* lds, unsigned long long* __re
   __syncthreads();
 }
 
-// One contiguous run of `n` super-tiles of ONE genome starting at arena tile `tile0`.
-template <int PF, int MODE, int REPL>
+// One contiguous run of `n` tiles (BLOCK x 64 bases each) of ONE genome starting at arena tile `tile0`.
+template <int PF, int MODE, int BLOCK>
 __device__ __forceinline__ void k0_segment(const uint32_t* __restrict__ codes, const uint32_t* __restrict__ mask,
                                            uint32_t tile0, uint32_t n, uint32_t* lds, uint32_t tid, uint32_t& sink) {
   const uint32_t last = tile0 + n - 1;
   LaneData ring[PF];
 #pragma unroll
-  for (int s = 0; s < PF; ++s) ring[s] = k0_load(codes, mask, (uint64_t)min(tile0 + s, last) * K0_BLOCK, tid);
+  for (int s = 0; s < PF; ++s) ring[s] = k0_load(codes, mask, (uint64_t)min(tile0 + s, last) * BLOCK, tid);
   for (uint32_t i = 0; i < n; i += PF) {
 #pragma unroll
     for (int s = 0; s < PF; ++s) {
       if (i + s < n) {  // uniform
         const LaneData d = ring[s];
         // refill this slot PF tiles ahead; past the end it re-reads the last tile (in bounds, result unused)
-        if (MODE != 2) ring[s] = k0_load(codes, mask, (uint64_t)min(tile0 + i + s + PF, last) * K0_BLOCK, tid);
-        k0_process<MODE, REPL>(d, lds, tid, sink);
+        if (MODE != 2) ring[s] = k0_load(codes, mask, (uint64_t)min(tile0 + i + s + PF, last) * BLOCK, tid);
+        k0_process<MODE>(d, lds, tid, sink);
       }
     }
   }
 }
 
-// seg_prefix[0..n_batch]: cumulative super-tile counts of the batch genomes; seg_tile0[b]: first arena tile of genome b.
-template <int PF, int MODE, int REPL>
-__global__ __launch_bounds__(K0_BLOCK) void tetra_count_kernel(const uint32_t* __restrict__ codes,
-                                                               const uint32_t* __restrict__ mask,
-                                                               const uint32_t* __restrict__ seg_tile0,
-                                                               const uint32_t* __restrict__ seg_prefix, uint32_t n_batch,
-                                                               unsigned long long* __restrict__ acc) {
+// seg_prefix[0..n_batch]: cumulative SUPER-tile counts (65536 bases) of the batch genomes; seg_tile0[b]: first arena
+// super-tile of genome b.  A workgroup of BLOCK threads works in tiles of BLOCK x 64 bases (1024 / BLOCK per super-tile).
+template <int PF, int MODE, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void tetra_count_kernel(const uint32_t* __restrict__ codes,
+                                                            const uint32_t* __restrict__ mask,
+                                                            const uint32_t* __restrict__ seg_tile0,
+                                                            const uint32_t* __restrict__ seg_prefix, uint32_t n_batch,
+                                                            unsigned long long* __restrict__ acc) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-  using L = K0Lds<REPL>;
+  using L = K0Lds;
+  constexpr uint32_t TPS = 1024 / BLOCK;   // tiles per super-tile
   const uint32_t tid = threadIdx.x;
-  const uint32_t n_work = seg_prefix[n_batch];
+  const uint32_t n_work = seg_prefix[n_batch] * TPS;
   const uint32_t w0 = (uint32_t)(((uint64_t)blockIdx.x * n_work) / gridDim.x);
   const uint32_t w1 = (uint32_t)(((uint64_t)(blockIdx.x + 1) * n_work) / gridDim.x);
   if (w0 >= w1) return;
   {
     uint4* z = reinterpret_cast<uint4*>(lds);
-    for (uint32_t i = tid; i < L::WORDS / 4; i += K0_BLOCK) z[i] = make_uint4(0, 0, 0, 0);
+    for (uint32_t i = tid; i < L::WORDS / 4; i += BLOCK) z[i] = make_uint4(0, 0, 0, 0);
   }
-  // genome containing w0: largest b with seg_prefix[b] <= w0 (uniform binary search)
+  // genome containing w0: largest b with seg_prefix[b] * TPS <= w0 (uniform binary search)
   uint32_t lo = 0, hi = n_batch;
   while (hi - lo > 1) {
     const uint32_t mid = (lo + hi) >> 1;
-    if (seg_prefix[mid] <= w0) lo = mid; else hi = mid;
+    if (seg_prefix[mid] * TPS <= w0) lo = mid; else hi = mid;
   }
   __syncthreads();
   uint32_t sink = 0;
   uint32_t b = lo, w = w0;
   while (w < w1) {
-    const uint32_t p0 = seg_prefix[b], p1 = seg_prefix[b + 1];
+    const uint32_t p0 = seg_prefix[b] * TPS, p1 = seg_prefix[b + 1] * TPS;
     if (p1 > w) {
       const uint32_t end = min(w1, p1);
-      uint32_t tile = seg_tile0[b] + (w - p0);
+      uint32_t tile = seg_tile0[b] * TPS + (w - p0);
       while (w < end) {  // chunked only to bound the u32 bins
         const uint32_t n = min(end - w, K0_FORCE_FLUSH_TILES);
-        k0_segment<PF, MODE, REPL>(codes, mask, tile, n, lds, tid, sink);
+        k0_segment<PF, MODE, BLOCK>(codes, mask, tile, n, lds, tid, sink);
         __syncthreads();
-        k0_flush<REPL>(lds, acc + (size_t)b * PG_ACC_WORDS, tid);
+        k0_flush<BLOCK>(lds, acc + (size_t)b * PG_ACC_WORDS, tid);
         w += n;
         tile += n;
       }

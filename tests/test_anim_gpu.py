@@ -142,3 +142,26 @@ def test_unrelated_genomes_give_no_alignment(eng):
     c = eng.add_genome(*synth.genome(1, 50, 2, 60_000))       # same ancestor as genome 0, 0.1 % divergence
     r2 = eng.anim_pairs([a], [c])[0]
     assert int(r2["status"]) == 0 and float(r2["identity"]) > 0.99 and int(r2["ref_aln_len"]) > 50_000
+
+
+def test_gpu_pipeline_equals_scalar_host_statement_on_synthetic_pairs(eng):
+    """Self-consistency (not MUMmer parity): sampled-seed hashing + wave-cooperative clustering/extension on the GPU give
+    exactly what the exhaustive-seed scalar host build of the same core gave (tools/make_anim_synth_host.py), for every
+    divergence level of the synthetic generator, with and without the 1-to-1 filter."""
+    from pyani_amd import synth
+    fx = json.loads((GOLD / "anim_synth_host.json").read_text())
+    n, L, seed = fx["n"], fx["length"], fx["seed"]
+    eng.clear_genomes()
+    ids = [eng.add_genome(*synth.genome(seed, n, g, L)) for g in range(n)]
+    eng.upload()
+    pairs = [(a, b) for a in range(n) for b in range(n) if a != b]
+    for mode, filt in (("filter", True), ("nofilter", False)):
+        res = eng.anim_pairs([ids[a] for a, _ in pairs], [ids[b] for _, b in pairs], filter_1to1=filt)
+        bad = []
+        for (a, b), r in zip(pairs, res):
+            want = fx["pairs"][f"{a},{b},{mode}"]
+            got = [int(r["ref_aln_len"]), int(r["qry_aln_len"]), float(r["identity"]).hex(), int(r["sim_errors"]),
+                   int(r["n_alignments"])]
+            if got != want:
+                bad.append((a, b, got, want))
+        assert not bad, f"{mode}: {len(bad)} of {len(pairs)} pairs differ, first: {bad[0]}"

@@ -10,25 +10,25 @@ namespace {
 }
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
 
-template <int PF, int MODE, int REPL = 1>
+template <int PF, int MODE, int BLOCK = 1024>
 void run(const char* name, const uint32_t* codes, const uint32_t* mask, const uint32_t* wt, const uint32_t* wb, uint32_t nw,
          unsigned long long* acc, uint32_t nb, int grid, double bytes) {
-  auto k = tetra_count_kernel<PF, MODE, REPL>;
-  const size_t lds = K0Lds<REPL>::WORDS * 4;
+  auto k = tetra_count_kernel<PF, MODE, BLOCK>;
+  const size_t lds = K0Lds::WORDS * 4;
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipEvent_t a, b;
   CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
-  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k, dim3(grid), dim3(K0_BLOCK), lds, 0, codes, mask, wt, wb, nb, acc);
+  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k, dim3(grid), dim3(BLOCK), lds, 0, codes, mask, wt, wb, nb, acc);
   CK(hipDeviceSynchronize());
   const int reps = 20;
   CK(hipEventRecord(a));
-  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(k, dim3(grid), dim3(K0_BLOCK), lds, 0, codes, mask, wt, wb, nb, acc);
+  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(k, dim3(grid), dim3(BLOCK), lds, 0, codes, mask, wt, wb, nb, acc);
   CK(hipEventRecord(b));
   CK(hipDeviceSynchronize());
   float ms = 0;
   CK(hipEventElapsedTime(&ms, a, b));
   const double us = ms * 1e3 / reps;
-  printf("%-28s PF=%d grid=%d  %8.1f us  %7.1f GB/s (%.1f%% of 8 TB/s)\n", name, PF, grid, us, bytes / us * 1e-3, bytes / us * 1e-3 / 80.0);
+  printf("%-28s BLOCK=%d PF=%d grid=%d  %8.1f us  %7.1f GB/s (%.1f%% of 8 TB/s)\n", name, BLOCK, PF, grid, us, bytes / us * 1e-3, bytes / us * 1e-3 / 80.0);
 }
 
 int main(int argc, char** argv) {
@@ -68,9 +68,15 @@ int main(int argc, char** argv) {
   CK(hipMemset(acc, 0, (size_t)n_gen * PG_ACC_WORDS * 8));
   const double bytes = (double)bases * 0.375;
   printf("bases %.3e, bytes %.1f MB\n", (double)bases, bytes / 1e6);
-  run<1, 0>("full", codes, mask, wt, wb, nw, acc, n_gen, 256, bytes);
-  run<2, 0>("full", codes, mask, wt, wb, nw, acc, n_gen, 256, bytes);
-  run<1, 1>("loads only", codes, mask, wt, wb, nw, acc, n_gen, 256, bytes);
-  run<1, 2>("atomics only", codes, mask, wt, wb, nw, acc, n_gen, 256, bytes);
+  run<1, 0, 1024>("full", codes, mask, wt, wb, nw, acc, n_gen, 256, bytes);
+  run<2, 0, 1024>("full", codes, mask, wt, wb, nw, acc, n_gen, 256, bytes);
+  run<1, 0, 1024>("full", codes, mask, wt, wb, nw, acc, n_gen, 512, bytes);
+  run<2, 0, 1024>("full", codes, mask, wt, wb, nw, acc, n_gen, 512, bytes);
+  run<1, 0, 512>("full", codes, mask, wt, wb, nw, acc, n_gen, 512, bytes);
+  run<2, 0, 512>("full", codes, mask, wt, wb, nw, acc, n_gen, 512, bytes);
+  run<3, 0, 512>("full", codes, mask, wt, wb, nw, acc, n_gen, 512, bytes);
+  run<2, 0, 512>("full", codes, mask, wt, wb, nw, acc, n_gen, 1024, bytes);
+  run<1, 1, 1024>("loads only", codes, mask, wt, wb, nw, acc, n_gen, 512, bytes);
+  run<1, 2, 1024>("atomics only", codes, mask, wt, wb, nw, acc, n_gen, 512, bytes);
   return 0;
 }
