@@ -382,24 +382,32 @@ __device__ __forceinline__ long long wave_max64(long long v) {
 // =====================================================================================================================
 __device__ __forceinline__ uint64_t lanemask_lt() { return (1ull << (threadIdx.x & 63)) - 1ull; }
 
+// Orders this wave's LDS accesses (cross-lane read-after-write through LDS) without waiting for its outstanding global
+// stores, which a __syncthreads() of a one-wave workgroup would do (s_waitcnt vmcnt(0): ~1-2 us per use).
+__device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
 // Stable LSD radix sort of (key, val) pairs by `passes` 8-bit digits.  Result ends in (k0, v0) if passes is even,
-// else in (k1, v1).  hist: 256 words of LDS.
+// else in (k1, v1).  hist: 256 words of LDS.  Global loads are issued four 64-element rows ahead of their use.
 __device__ void wave_radix_sort(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1, int n, int passes, uint32_t* hist) {
   const int lane = threadIdx.x & 63;
+  constexpr int U = 4;
   for (int pass = 0; pass < passes; ++pass) {
     const int shift = 8 * pass;
     const uint32_t* ki = (pass & 1) ? k1 : k0;
     const uint32_t* vi = (pass & 1) ? v1 : v0;
     uint32_t* ko = (pass & 1) ? k0 : k1;
     uint32_t* vo = (pass & 1) ? v0 : v1;
-    __syncthreads();
+    __syncthreads();   // the previous pass's (or the caller's) global stores have landed
     for (int b = lane; b < 256; b += 64) hist[b] = 0;
-    __syncthreads();
-    for (int base = 0; base < n; base += 64) {
-      const int i = base + lane;
-      if (i < n) atomicAdd(&hist[(ki[i] >> shift) & 255u], 1u);
+    wave_lds_fence();
+    for (int base = 0; base < n; base += 64 * U) {
+      uint32_t kk[U];
+#pragma unroll
+      for (int t = 0; t < U; ++t) { const int i = base + 64 * t + lane; kk[t] = i < n ? ki[i] : 0u; }
+#pragma unroll
+      for (int t = 0; t < U; ++t) if (base + 64 * t + lane < n) atomicAdd(&hist[(kk[t] >> shift) & 255u], 1u);
     }
-    __syncthreads();
+    wave_lds_fence();
     {  // exclusive scan of the 256 bins: 4 bins per lane
       uint32_t c0 = hist[4 * lane], c1 = hist[4 * lane + 1], c2 = hist[4 * lane + 2], c3 = hist[4 * lane + 3];
       const uint32_t tot = c0 + c1 + c2 + c3;
@@ -407,31 +415,39 @@ __device__ void wave_radix_sort(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32
 #pragma unroll
       for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
       uint32_t ex = incl - tot;
-      __syncthreads();
+      wave_lds_fence();
       hist[4 * lane] = ex; ex += c0;
       hist[4 * lane + 1] = ex; ex += c1;
       hist[4 * lane + 2] = ex; ex += c2;
       hist[4 * lane + 3] = ex;
     }
-    __syncthreads();
-    for (int base = 0; base < n; base += 64) {
-      const int i = base + lane;
-      const bool act = i < n;
-      const uint32_t key = act ? ki[i] : 0u, val = act ? vi[i] : 0u;
-      const uint32_t d = (key >> shift) & 255u;
-      uint64_t peers = __ballot(act);
+    wave_lds_fence();
+    for (int base = 0; base < n; base += 64 * U) {
+      uint32_t kk[U], vv[U];
 #pragma unroll
-      for (int b = 0; b < 8; ++b) {
-        const uint64_t vote = __ballot((d >> b) & 1u);
-        peers &= ((d >> b) & 1u) ? vote : ~vote;
+      for (int t = 0; t < U; ++t) {
+        const int i = base + 64 * t + lane;
+        kk[t] = i < n ? ki[i] : 0u;
+        vv[t] = i < n ? vi[i] : 0u;
       }
-      const uint32_t rank = (uint32_t)__popcll(peers & lanemask_lt());
-      uint32_t pos = 0;
-      if (act) pos = hist[d] + rank;
-      __syncthreads();
-      if (act && rank == 0) hist[d] += (uint32_t)__popcll(peers);
-      __syncthreads();
-      if (act) { ko[pos] = key; vo[pos] = val; }
+#pragma unroll
+      for (int t = 0; t < U; ++t) {   // rows in order: the sort is stable
+        const bool act = base + 64 * t + lane < n;
+        const uint32_t d = (kk[t] >> shift) & 255u;
+        uint64_t peers = __ballot(act);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+          const uint64_t vote = __ballot((d >> b) & 1u);
+          peers &= ((d >> b) & 1u) ? vote : ~vote;
+        }
+        const uint32_t rank = (uint32_t)__popcll(peers & lanemask_lt());
+        uint32_t pos = 0;
+        if (act) pos = hist[d] + rank;
+        wave_lds_fence();   // every lane has read its bin before the bin's first lane advances it
+        if (act && rank == 0) hist[d] += (uint32_t)__popcll(peers);
+        wave_lds_fence();
+        if (act) { ko[pos] = kk[t]; vo[pos] = vv[t]; }
+      }
     }
   }
   __syncthreads();
@@ -480,10 +496,19 @@ __device__ __forceinline__ void uf_union(int32_t* parent, int a, int b) {   // l
   }
 }
 
+#ifdef PGA_DP_STATS
+__device__ unsigned long long g_cl_stats[16];   // per phase: sum of cycles [0..5], max [6..11], max n_in [12]
+#define CL_MARK(ph) do { const unsigned long long t_now = __builtin_readcyclecounter(); if (lane == 0) { \
+    atomicAdd(&g_cl_stats[ph], t_now - t_mark); atomicMax(&g_cl_stats[6 + ph], t_now - t_mark); } t_mark = t_now; } while (0)
+#else
+#define CL_MARK(ph) do {} while (0)
+#endif
 __global__ __launch_bounds__(64) void anim_cluster_wave_kernel(const RefDesc* __restrict__ refs, const UnitDesc* __restrict__ units,
                                                                Match* __restrict__ mem, const uint32_t* __restrict__ mem_count,
                                                                int32_t* __restrict__ iscratch, ClusterOut O) {
   __shared__ uint32_t hist[256];
+  constexpr int WALK_CHUNK = 4096;
+  __shared__ int32_t s_from[WALK_CHUNK];
   const uint32_t u = blockIdx.x;
   const int lane = threadIdx.x & 63;
   const UnitDesc U = units[u];
@@ -500,6 +525,10 @@ __global__ __launch_bounds__(64) void anim_cluster_wave_kernel(const RefDesc* __
   int32_t *sb = sa + cap, *sc = sa + 2 * (size_t)cap, *sd = sa + 3 * (size_t)cap, *se = sa + 4 * (size_t)cap,
           *sf = sa + 5 * (size_t)cap, *sg = sa + 6 * (size_t)cap;
   const int n_in = (int)n0;
+#ifdef PGA_DP_STATS
+  unsigned long long t_mark = __builtin_readcyclecounter();
+  if (lane == 0) atomicMax(&g_cl_stats[12], (unsigned long long)n_in);
+#endif
   // ---- MUM filter -----------------------------------------------------------------------------------------------
   // SoA copies: se = r, sf = q, sg = len; flags in sd
   for (int i = lane; i < n_in; i += 64) { const Match t = m[i]; se[i] = t.r; sf[i] = t.q; sg[i] = t.len; sd[i] = 0; }
@@ -537,6 +566,7 @@ __global__ __launch_bounds__(64) void anim_cluster_wave_kernel(const RefDesc* __
     for (int i = lane; i < n; i += 64) m[i] = cm[i];
     __syncthreads();
   }
+  CL_MARK(0);
   // ---- clustering (mgaps) ------------------------------------------------------------------------------------------
   int32_t *rrec = sa, *qrec = sb, *parent = sc, *score = sd, *from = se, *adj = sf, *order = sg;
   for (int i = lane; i < n; i += 64) {
@@ -563,6 +593,7 @@ __global__ __launch_bounds__(64) void anim_cluster_wave_kernel(const RefDesc* __
   }
   __threadfence_block();
   __syncthreads();
+  CL_MARK(1);
   {  // group by root (stable: q order inside a cluster): radix sort of (root, index)
     uint32_t *rk0 = (uint32_t*)score, *rv0 = (uint32_t*)from, *rk1 = (uint32_t*)adj, *rv1 = (uint32_t*)order;
     for (int i = lane; i < n; i += 64) { rk0[i] = (uint32_t)uf_find(parent, i); rv0[i] = (uint32_t)i; }
@@ -573,6 +604,7 @@ __global__ __launch_bounds__(64) void anim_cluster_wave_kernel(const RefDesc* __
     for (int i = lane; i < n; i += 64) order[i] = (int32_t)rv0[i];
     __syncthreads();
   }
+  CL_MARK(2);
   // ---- chain extraction per cluster ----------------------------------------------------------------------------------
   // grouped list: order[t] = match index, parent[t] = its root.  score/from/adj are indexed by LIST POSITION here.
   // `lst` (compacted working list of the current cluster) lives in adj's slice after use... keep it simple: a cluster's
@@ -593,83 +625,106 @@ __global__ __launch_bounds__(64) void anim_cluster_wave_kernel(const RefDesc* __
     }
     int live = g1 - g0;
     while (live > 0) {
-      // DP over the live entries order[g0 .. g0+live): lane l holds the entry at position k-1-l (sliding window)
-      int32_t wr = 0, wq = 0, wl = 0, wsc = NEG_INF;   // window registers: r, q, len, score of predecessor k-1-lane
-      int32_t best_sc = NEG_INF, best_k = -1;
-      for (int k = 0; k < live; ++k) {
-        const Match mi = m[order[g0 + k]];
-        // candidate through my predecessor
-        int32_t cand = NEG_INF, ol = 0;
-        if (lane < k && wsc > NEG_INF / 2) {
-          ol = wr + wl - mi.r;
-          if (ol < 0) ol = 0;
-          const int32_t ol2 = wq + wl - mi.q;
-          if (ol2 > ol) ol = ol2;
-          int32_t dd = (mi.q - mi.r) - (wq - wr);
-          if (dd < 0) dd = -dd;
-          cand = wsc + mi.len - (ol + dd);
-        }
-        // best candidate: max cand, ties -> nearest predecessor (smallest lane)
-        long long key = (((long long)cand + (1ll << 30)) << 8) | (long long)(63 - lane);
-        key = wave_max64(key);
-        const int32_t bc = (int32_t)((key >> 8) - (1ll << 30));
-        const int bl = 63 - (int)(key & 63);
-        int32_t sc_k = mi.len, fr_k = -1, ad_k = 0;
-        if (bc > sc_k) { sc_k = bc; fr_k = k - 1 - bl; ad_k = __shfl(ol, bl, 64); }
-        if (lane == 0) { score[g0 + k] = sc_k; from[g0 + k] = fr_k; adj[g0 + k] = ad_k; }
-        if (sc_k > best_sc) { best_sc = sc_k; best_k = k; }
-        // slide the window: lane l <- lane l-1, lane 0 <- entry k
-        wr = from_lane_below(wr, mi.r); wq = from_lane_below(wq, mi.q); wl = from_lane_below(wl, mi.len);
-        wsc = from_lane_below(wsc, sc_k);
-      }
-      __threadfence_block();
-      __syncthreads();
-      // walk the best chain (lane 0), emit if long enough, mark removed (from = -2)
-      int32_t total = 0, cnt = 0;
-      if (lane == 0) {
-        for (int k = best_k; k >= 0; k = from[g0 + k]) { total += m[order[g0 + k]].len; ++cnt; }
-      }
-      total = __shfl(total, 0, 64); cnt = __shfl(cnt, 0, 64);
-      const bool emit = total >= MIN_CLUSTER && n_chains < (int)cap && n_cm + cnt <= (int)cap;
-      if (lane == 0) {
-        if (emit) {
-          const int first_idx = order[g0 + best_k];
-          Chain c;
-          c.first = n_cm; c.count = cnt; c.strand = U.strand; c.rrec = rrec[first_idx]; c.qrec = qrec[first_idx];
-          chains[n_chains] = c;
-        }
-        int pos = n_cm + cnt;
-        for (int k = best_k; k >= 0;) {
-          const int nx = from[g0 + k];
-          if (emit) {
-            Match t = m[order[g0 + k]];
-            const int32_t a = adj[g0 + k];
-            t.r += a; t.q += a; t.len -= a;
-            cm[--pos] = t;
+      // Chain DP over the live entries order[g0 .. g0+live), 64 at a time: the entries are gathered lane-parallel (one
+      // round of global latency per 64), then handed out one by one through readlane.  Lane l's window registers hold
+      // the entry at position k-1-l: start, length, best score, and the matched bases / members of the best chain
+      // ending there, so the winner's totals are known without walking it.
+      int32_t wr = 0, wq = 0, wl = 0, wsc = NEG_INF, wtot = 0, wcnt = 0;
+      int32_t best_sc = NEG_INF, best_k = -1, best_tot = 0, best_cnt = 0;
+      for (int kb = 0; kb < live; kb += 64) {
+        const int kt = kb + lane;
+        Match mt{0, 0, 0, 0};
+        if (kt < live) mt = m[order[g0 + kt]];
+        int32_t my_from = -1, my_adj = 0;
+        const int kend = live - kb < 64 ? live - kb : 64;
+        for (int t = 0; t < kend; ++t) {
+          const int k = kb + t;
+          const int32_t mr = __builtin_amdgcn_readlane(mt.r, t), mq = __builtin_amdgcn_readlane(mt.q, t),
+                        ml = __builtin_amdgcn_readlane(mt.len, t);
+          int32_t cand = NEG_INF, ol = 0;
+          if (lane < k && wsc > NEG_INF / 2) {
+            ol = wr + wl - mr;
+            if (ol < 0) ol = 0;
+            const int32_t ol2 = wq + wl - mq;
+            if (ol2 > ol) ol = ol2;
+            int32_t dd = (mq - mr) - (wq - wr);
+            if (dd < 0) dd = -dd;
+            cand = wsc + ml - (ol + dd);
           }
-          from[g0 + k] = -2;
-          k = nx;
+          // best candidate: max cand, ties -> nearest predecessor (smallest lane)
+          long long key = (((long long)cand + (1ll << 30)) << 8) | (long long)(63 - lane);
+          key = wave_max64(key);
+          const int32_t bc = (int32_t)((key >> 8) - (1ll << 30));
+          const int bl = 63 - (int)(key & 63);
+          int32_t sc_k = ml, fr_k = -1, ad_k = 0, tot_k = ml, cnt_k = 1;
+          if (bc > sc_k) {
+            sc_k = bc; fr_k = k - 1 - bl; ad_k = __shfl(ol, bl, 64);
+            tot_k += __shfl(wtot, bl, 64); cnt_k += __shfl(wcnt, bl, 64);
+          }
+          if (lane == t) { my_from = fr_k; my_adj = ad_k; }
+          if (sc_k > best_sc) { best_sc = sc_k; best_k = k; best_tot = tot_k; best_cnt = cnt_k; }
+          // slide the window: lane l <- lane l-1, lane 0 <- entry k
+          wr = from_lane_below(wr, mr); wq = from_lane_below(wq, mq); wl = from_lane_below(wl, ml);
+          wsc = from_lane_below(wsc, sc_k); wtot = from_lane_below(wtot, tot_k); wcnt = from_lane_below(wcnt, cnt_k);
         }
+        if (kt < live) { from[g0 + kt] = my_from; adj[g0 + kt] = my_adj; }
       }
-      if (emit) { n_chains += 1; n_cm += cnt; }
       __threadfence_block();
       __syncthreads();
-      // compact the live list (drop removed entries), preserving order
+      const int32_t total = best_tot, cnt = best_cnt;
+      const bool emit = total >= MIN_CLUSTER && n_chains < (int)cap && n_cm + cnt <= (int)cap;
+      if (emit && lane == 0) {
+        const int first_idx = order[g0 + best_k];
+        Chain c;
+        c.first = n_cm; c.count = cnt; c.strand = U.strand; c.rrec = rrec[first_idx]; c.qrec = qrec[first_idx];
+        chains[n_chains] = c;
+      }
+      // Walk the best chain backwards (from[k] < k always) and tag its members from[k] = -3 - (slot in cm), or -2 if
+      // the chain is dropped.  The pointer chase runs in LDS: from[] is staged 4096 entries at a time, high to low.
+      {
+        int k = best_k, pos = n_cm + cnt;
+        for (int chunk = (best_k / WALK_CHUNK) * WALK_CHUNK; chunk >= 0 && k >= 0; chunk -= WALK_CHUNK) {
+          const int hi = chunk + WALK_CHUNK < live ? chunk + WALK_CHUNK : live;
+          for (int t = chunk + lane; t < hi; t += 64) s_from[t - chunk] = from[g0 + t];
+          __syncthreads();
+          if (lane == 0) {
+            while (k >= chunk) {
+              const int nx = s_from[k - chunk];
+              from[g0 + k] = emit ? -3 - (--pos) : -2;
+              k = nx;
+            }
+          }
+          k = __shfl(k, 0, 64); pos = __shfl(pos, 0, 64);
+          __syncthreads();
+        }
+      }
+      __threadfence_block();
+      __syncthreads();
+      // gather the tagged members into cm (lane-parallel) and compact the live list (drop them), preserving order
       int kept = 0;
       for (int base = 0; base < live; base += 64) {
         const int k = base + lane;
-        const bool keep = k < live && from[g0 + k] != -2;
+        const int32_t f = k < live ? from[g0 + k] : 0;
+        const bool keep = k < live && f > -2;
         const int32_t idx = k < live ? order[g0 + k] : 0;
-        const uint64_t b = __ballot(keep);
+        if (k < live && f <= -3) {
+          Match t = m[idx];
+          const int32_t a = adj[g0 + k];
+          t.r += a; t.q += a; t.len -= a;
+          cm[-3 - f] = t;
+        }
+        const uint64_t bmask = __ballot(keep);
         __syncthreads();
-        if (keep) order[g0 + kept + __popcll(b & lanemask_lt())] = idx;
-        kept += (int)__popcll(b);
+        if (keep) order[g0 + kept + __popcll(bmask & lanemask_lt())] = idx;
+        kept += (int)__popcll(bmask);
         __syncthreads();
       }
+      if (emit) { n_chains += 1; n_cm += cnt; }
       live = kept;
     }
     g0 = g1;
   }
+  CL_MARK(3);
   // ---- chains in reference order + neighbours ------------------------------------------------------------------------
   int32_t* co = O.order + off;
   {
@@ -695,6 +750,7 @@ __global__ __launch_bounds__(64) void anim_cluster_wave_kernel(const RefDesc* __
     next_of[c] = q;
   }
   if (lane == 0) O.n_chains[u] = n_chains;
+  CL_MARK(4);
 }
 
 __device__ __forceinline__ void chain_bounds(const RefDesc& R, const UnitDesc& U, const Chain& c, int32_t& r_lo, int32_t& r_hi,
@@ -755,13 +811,20 @@ __device__ ExtResult extend_wave(const SeqView& R, const StrandView& Q, int64_t 
   if (targeted && tr == 0 && tq == 0) { res.reached = 1; return res; }
   const int k = lane - W + koff;
   // Cell (i, j) = ((d - k) / 2, (d + k) / 2) of this lane's diagonal exists on anti-diagonal d iff d_lo <= d <= d_hi.
-  // Cells outside are kept at NEG_INF; everything derived from them stays far below NEG_INF / 2 ("dead": at most
-  // 2 * 10^4 steps of at most +3 / -10 each), so no per-neighbour existence tests are needed in the step itself.
+  //
+  // Score and error count of a cell travel as ONE key  K = score << 15 | (32767 - errors):  integer max on keys is
+  // exactly dp_cell's rule "higher score, then fewer errors", a move is one saturating add of a constant, and a wave
+  // shift moves both fields at once.  Ranges: |score| <= 3 * 9999 and errors <= 2 * 9999 within MUMmer's 10 kb DP
+  // limit, so no field overflows; dead cells sit at INT_MIN (saturation keeps them there for negative moves) and
+  // cannot climb above K_LIVE within 10^4 matches.
+  constexpr int32_t K_DEAD = INT32_MIN, K_LIVE = -(32768 << 15);
+  constexpr int32_t K_OPEN = SC_GAP_OPEN * 32768 - 1, K_EXT = SC_GAP_EXT * 32768 - 1;
+  constexpr int32_t K_MATCH = SC_MATCH * 32768, K_MISMATCH = SC_MISMATCH * 32768 - 1;
   const int32_t d_lo = k < 0 ? -k : k;
   const int32_t d_hi = (2 * rmax + k) < (2 * qmax - k) ? (2 * rmax + k) : (2 * qmax - k);
-  int32_t h = NEG_INF, he = 0, x = NEG_INF, xe = 0, y = NEG_INF, ye = 0;
-  int32_t bs = NEG_INF / 2, bd = 0, be = 0;   // per-lane best; NEG_INF / 2: no dead cell ever qualifies
-  if (lane == W - koff) { h = 0; bs = 0; }
+  int32_t H = K_DEAD, X = K_DEAD, Y = K_DEAD;
+  int32_t bs = -32768, bd = 0, be = 0;   // per-lane best (score only; ties: the later cell); be = its key.  Dead cells (score field <= -35536) never qualify
+  if (lane == W - koff) { H = 32767; bs = 0; be = 32767; }
   const int32_t d_end = targeted ? tr + tq : rmax + qmax;
   constexpr long long BIAS = 1ll << 30;
   WaveSeq ws{s_ring[0], s_ring[1], 0};
@@ -783,28 +846,22 @@ __device__ ExtResult extend_wave(const SeqView& R, const StrandView& Q, int64_t 
       wave_seq_fill(ws, R, Q, r0, q0, dir, rmax, qmax, lane);
       __syncthreads();
     }
-    const int32_t up_h = from_lane_above(h, NEG_INF), up_he = from_lane_above(he, 0);
-    const int32_t up_x = from_lane_above(x, NEG_INF), up_xe = from_lane_above(xe, 0);
-    const int32_t lf_h = from_lane_below(h, NEG_INF), lf_he = from_lane_below(he, 0);
-    const int32_t lf_y = from_lane_below(y, NEG_INF), lf_ye = from_lane_below(ye, 0);
+    const int32_t up_H = from_lane_above(H, K_DEAD), up_X = from_lane_above(X, K_DEAD);
+    const int32_t lf_H = from_lane_below(H, K_DEAD), lf_Y = from_lane_below(Y, K_DEAD);
     if (!((d + k) & 1)) {
       const int32_t i = (d - k) >> 1, j = (d + k) >> 1;
       const bool ok = ws.ring_r[(i - 1) & 255] == ws.ring_q[(j - 1) & 255];   // dirty codes differ (4 vs 5): never equal
-      // same candidates and tie-breaks as pga::dp_cell
-      const int32_t xh = up_h + SC_GAP_OPEN, xx = up_x + SC_GAP_EXT;
-      const bool cx = xh >= xx;
-      const int32_t nx = cx ? xh : xx, nxe = (cx ? up_he : up_xe) + 1;
-      const int32_t yh = lf_h + SC_GAP_OPEN, yy = lf_y + SC_GAP_EXT;
-      const bool cy = yh >= yy;
-      const int32_t ny = cy ? yh : yy, nye = (cy ? lf_he : lf_ye) + 1;
-      int32_t nh = h + (ok ? SC_MATCH : SC_MISMATCH), nhe = he + (ok ? 0 : 1);
-      if (nx > nh) { nh = nx; nhe = nxe; }
-      if (ny > nh) { nh = ny; nhe = nye; }
+      const int32_t xa = __builtin_elementwise_add_sat(up_H, K_OPEN), xb = __builtin_elementwise_add_sat(up_X, K_EXT);
+      const int32_t ya = __builtin_elementwise_add_sat(lf_H, K_OPEN), yb = __builtin_elementwise_add_sat(lf_Y, K_EXT);
+      const int32_t nx = xa > xb ? xa : xb, ny = ya > yb ? ya : yb;
+      int32_t nh = __builtin_elementwise_add_sat(H, ok ? K_MATCH : K_MISMATCH);
+      nh = nh > nx ? nh : nx;
+      nh = nh > ny ? nh : ny;
       const bool alive = d >= d_lo && d <= d_hi;
-      h = alive ? nh : NEG_INF; x = alive ? nx : NEG_INF; y = alive ? ny : NEG_INF;
-      he = nhe; xe = nxe; ye = nye;
-      if (h >= bs) { bs = h; bd = d; be = he; }           // ties: the later cell
-      const int32_t imp = h >= g_known ? d : 0x7FFFFFFF;   // g_known >= 0: only live cells
+      H = alive ? nh : K_DEAD; X = alive ? nx : K_DEAD; Y = alive ? ny : K_DEAD;
+      const int32_t sc = H >> 15;                          // floor: exact for every live key
+      if (sc >= bs) { bs = sc; bd = d; be = H; }           // ties: the later cell (score only, as the scalar code)
+      const int32_t imp = sc >= g_known ? d : 0x7FFFFFFF;   // g_known >= 0: only live cells
       fimp = imp < fimp ? imp : fimp;
     }
     if ((d % CHECK) == 0 || d == d_end) {
@@ -818,14 +875,14 @@ __device__ ExtResult extend_wave(const SeqView& R, const StrandView& Q, int64_t 
         bs = sbs; bd = sbd; be = sbe;                // results as of the last check (nothing global changed until b)
         break;
       }
-      if (!__any(h > NEG_INF / 2)) break;
+      if (!__any(H > K_LIVE)) break;
       g_known = g; t_prev = t; fimp = 0x7FFFFFFF;
       sbs = bs; sbd = bd; sbe = be;
     }
     if (targeted && d == d_end) {
       const int lt = (tq - tr) - koff + W;
-      const int32_t th = __shfl(h, lt, 64), the = __shfl(he, lt, 64);
-      if (th > NEG_INF / 2) { res.di = tr; res.dj = tq; res.score = th; res.errors = the; res.reached = 1; break; }
+      const int32_t tH = __shfl(H, lt, 64);
+      if (tH > K_LIVE) { res.di = tr; res.dj = tq; res.score = tH >> 15; res.errors = 32767 - (tH & 32767); res.reached = 1; break; }
     }
   }
 #ifdef PGA_DP_STATS
@@ -843,7 +900,7 @@ __device__ ExtResult extend_wave(const SeqView& R, const StrandView& Q, int64_t 
   const int bl = (int)(key & 63);
   const int32_t gd = (int32_t)((key >> 6) & 0x3FFFFFF);
   res.score = (int32_t)((key >> 32) - BIAS);
-  res.errors = __shfl(be, bl, 64);
+  res.errors = 32767 - (__shfl(be, bl, 64) & 32767);
   const int kk = bl - W + koff;
   res.di = (gd - kk) / 2; res.dj = (gd + kk) / 2;
   return res;
@@ -1092,10 +1149,57 @@ struct FinishScratch {   // per-alignment arrays: pair p owns the slice [moff[2p
   int32_t* aln_of;  // per chain
 };
 
+// pga::lis_filter with the O(n^2) look-back spread over the lanes of one wave.  Every lane runs the (cheap) serial parts
+// redundantly and writes identical values, so no intra-wave memory ordering is needed; candidates are evaluated by the
+// same expression as the scalar code and the reduction keeps its tie rule (the earliest predecessor reaching the max).
+__device__ void lis_filter_wave(Aln* a, int n, int side, const int32_t* grp, int32_t* idx, double* sc, int32_t* from) {
+  const int lane = threadIdx.x & 63;
+  auto lo = [&](int i) { return side == 0 ? a[i].rs : a[i].qs; };
+  auto hi = [&](int i) { return side == 0 ? a[i].re : a[i].qe; };
+  for (int i = 0; i < n; ++i) idx[i] = i;
+  heapsort(idx, n, [&](int x, int y) { return grp[x] < grp[y] || (grp[x] == grp[y] && lo(x) < lo(y)); });
+  int g0 = 0;
+  while (g0 < n) {
+    int g1 = g0;
+    while (g1 < n && grp[idx[g1]] == grp[idx[g0]]) ++g1;
+    int best = -1;
+    for (int k = g0; k < g1; ++k) {
+      const int i = idx[k];
+      const double len = (double)(hi(i) - lo(i));
+      const double tot = (double)((a[i].re - a[i].rs) + (a[i].qe - a[i].qs));
+      const double idy = tot > 0 ? 1.0 - 2.0 * a[i].errors / tot : 0.0;
+      const double own = len * idy * idy;
+      const int32_t lo_i = lo(i);
+      double bc = own;      // this lane's best candidate and its predecessor's rank (kk)
+      int bk = 0x7FFFFFFF;
+      for (int kk = g0 + lane; kk < k; kk += 64) {
+        const int j = idx[kk];
+        double ol = (double)(hi(j) - lo_i);
+        if (ol < 0) ol = 0;
+        if (ol >= len) continue;
+        const double cand = sc[j] + own * (1.0 - ol / len);
+        if (cand > bc) { bc = cand; bk = kk; }
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const double oc = __shfl_xor(bc, o, 64);
+        const int ok = __shfl_xor(bk, o, 64);
+        if (oc > bc || (oc == bc && ok < bk)) { bc = oc; bk = ok; }
+      }
+      sc[i] = bc;
+      from[i] = bk == 0x7FFFFFFF ? -1 : idx[bk];
+      if (best < 0 || sc[i] > sc[best]) best = i;
+    }
+    for (int i = best; i >= 0; i = from[i]) a[i].keep |= (1 << side);
+    g0 = g1;
+  }
+}
+
+// One WAVE per ordered pair: stitch both strands' chains into alignments, 1-to-1 filter, parse_delta reduction.
 __global__ __launch_bounds__(64) void anim_finish_kernel(const RefDesc* __restrict__ refs, const UnitDesc* __restrict__ units, uint32_t n_pairs,
                                                          ClusterOut O, const ChainFwd* __restrict__ fw, const ChainBwd* __restrict__ bw,
                                                          FinishScratch S, int filter_1to1, pg_anim_result* __restrict__ out) {
-  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t p = blockIdx.x;
   if (p >= n_pairs) return;
   const RefDesc R = refs[units[2 * p].ref];
   const size_t poff = O.moff[2 * p];
@@ -1122,8 +1226,8 @@ __global__ __launch_bounds__(64) void anim_finish_kernel(const RefDesc* __restri
     }
   }
   if (filter_1to1) {
-    lis_filter(alns, n, 0, a_rrec, idx, sc, from);
-    lis_filter(alns, n, 1, a_qrec, idx, sc, from);
+    lis_filter_wave(alns, n, 0, a_rrec, idx, sc, from);
+    lis_filter_wave(alns, n, 1, a_qrec, idx, sc, from);
   } else {
     for (int i = 0; i < n; ++i) alns[i].keep = 3;
   }
@@ -1136,7 +1240,7 @@ __global__ __launch_bounds__(64) void anim_finish_kernel(const RefDesc* __restri
   o.identity = r.aligned > 0 ? (double)r.weighted / (double)r.aligned : 0.0;  // int/int true division (anim.py:396)
   o.status = O.status[p] ? PG_E_CAPACITY : (r.n_alignments == 0 ? PG_ANIM_NO_ALIGNMENT : 0);
   o.reserved = 0;
-  out[p] = o;
+  if ((threadIdx.x & 63) == 0) out[p] = o;
 }
 
 // reduction of caller-supplied alignment records (pg_anim_reduce): one thread per pair
@@ -1482,7 +1586,7 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
       hipLaunchKernelGGL(anim_extend_kernel, dim3((uint32_t)wl.size()), dim3(64), 0, ctx->stream, A->refs_d, A->units_d, O,
                          A->wl_d, A->fw, A->bw, phase);
   }
-  hipLaunchKernelGGL(anim_finish_kernel, dim3((n_pairs + 63) / 64), dim3(64), 0, ctx->stream, A->refs_d, A->units_d, n_pairs,
+  hipLaunchKernelGGL(anim_finish_kernel, dim3(n_pairs), dim3(64), 0, ctx->stream, A->refs_d, A->units_d, n_pairs,
                      O, A->fw, A->bw, A->S, filter_1to1, A->out);
   PG_HIP(ctx, hipGetLastError());
   PG_HIP(ctx, hipMemcpyAsync(out_host, A->out, n_pairs * sizeof(pg_anim_result), hipMemcpyDeviceToHost, ctx->stream));
@@ -1491,6 +1595,10 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
   {
     unsigned long long st[3][40];
     PG_HIP(ctx, hipMemcpyFromSymbol(st, HIP_SYMBOL(g_dp_stats), sizeof(st)));
+    unsigned long long cl[16];
+    PG_HIP(ctx, hipMemcpyFromSymbol(cl, HIP_SYMBOL(g_cl_stats), sizeof(cl)));
+    fprintf(stderr, "[cluster-stats] phases mumfilter/unionfind/rootsort/chains/tail: sum cycles %llu %llu %llu %llu %llu  max %llu %llu %llu %llu %llu  max n_in %llu\n",
+            cl[0], cl[1], cl[2], cl[3], cl[4], cl[6], cl[7], cl[8], cl[9], cl[10], cl[12]);
     const char* names[3] = {"gap", "fwd", "bwd"};
     for (int k = 0; k < 3; ++k) {
       fprintf(stderr, "[dp-stats] %s calls %llu steps %llu cycles %llu  hist(log2 steps):", names[k], st[k][0], st[k][1], st[k][2]);

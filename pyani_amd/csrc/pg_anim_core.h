@@ -88,20 +88,22 @@ struct DpCell { int32_t h, he, x, xe, y, ye; };
 // diag_h/diag_he = H of (i-1, j-1); ok = the two bases match.
 PG_HD DpCell dp_cell(bool has_up, int32_t up_h, int32_t up_he, int32_t up_x, int32_t up_xe, bool has_left, int32_t left_h,
                      int32_t left_he, int32_t left_y, int32_t left_ye, bool has_diag, int32_t diag_h, int32_t diag_he, bool ok) {
+  // Every choice is the lexicographic maximum of (score, -errors): among equally scoring paths the one with fewer
+  // errors wins.  (This is what lets the device keep score and errors in one 32-bit key and use plain integer max.)
   DpCell c{NEG_INF, 0, NEG_INF, 0, NEG_INF, 0};
   if (has_up) {
     const int32_t ho = up_h + SC_GAP_OPEN, xo = up_x + SC_GAP_EXT;
-    if (ho >= xo) { c.x = ho; c.xe = up_he + 1; } else { c.x = xo; c.xe = up_xe + 1; }
+    if (ho > xo || (ho == xo && up_he <= up_xe)) { c.x = ho; c.xe = up_he + 1; } else { c.x = xo; c.xe = up_xe + 1; }
     if (c.x < NEG_INF / 2) c.x = NEG_INF;
   }
   if (has_left) {
     const int32_t ho = left_h + SC_GAP_OPEN, yo = left_y + SC_GAP_EXT;
-    if (ho >= yo) { c.y = ho; c.ye = left_he + 1; } else { c.y = yo; c.ye = left_ye + 1; }
+    if (ho > yo || (ho == yo && left_he <= left_ye)) { c.y = ho; c.ye = left_he + 1; } else { c.y = yo; c.ye = left_ye + 1; }
     if (c.y < NEG_INF / 2) c.y = NEG_INF;
   }
   if (has_diag && diag_h > NEG_INF / 2) { c.h = diag_h + (ok ? SC_MATCH : SC_MISMATCH); c.he = diag_he + (ok ? 0 : 1); }
-  if (c.x > c.h) { c.h = c.x; c.he = c.xe; }
-  if (c.y > c.h) { c.h = c.y; c.he = c.ye; }
+  if (c.x > c.h || (c.x == c.h && c.x > NEG_INF / 2 && c.xe < c.he)) { c.h = c.x; c.he = c.xe; }
+  if (c.y > c.h || (c.y == c.h && c.y > NEG_INF / 2 && c.ye < c.he)) { c.h = c.y; c.he = c.ye; }
   return c;
 }
 
