@@ -613,6 +613,90 @@ __global__ __launch_bounds__(64) void anim_cluster_wave_kernel(const RefDesc* __
   Chain* chains = O.chains + off;
   int g0 = 0;
   while (g0 < n) {
+    // ---- fast path: clusters of at most 64 matches (nearly all of them) are handled in registers -----------------------
+    // One window = the next 64 list positions, lane t <-> position g0 + t: two rounds of global latency per window
+    // instead of a dozen per cluster.  A cluster that reaches the window's end is retried at the start of the next
+    // window; only one that starts at lane 0 and still does not end takes the general path below.
+    {
+      const int posn = g0 + lane;
+      const bool valid = posn < n;
+      const int32_t root = valid ? parent[posn] : -1;
+      const int32_t idx = valid ? order[posn] : 0;
+      Match mt{0, 0, 0, 0};
+      int32_t rr = 0, qq = 0;
+      if (valid) { mt = m[idx]; rr = rrec[idx]; qq = qrec[idx]; }
+      int c0 = 0;
+      bool general = false;
+      while (c0 < 64 && g0 + c0 < n) {
+        const int32_t r0 = __shfl(root, c0, 64);
+        const uint64_t diff = __ballot(root != r0) & ~((1ull << c0) - 1ull);
+        const int c1 = diff ? __ffsll((long long)diff) - 1 : 64;
+        if (c1 == 64 && g0 + 64 < n) { general = c0 == 0; break; }
+        uint64_t L = (c1 == 64 ? ~0ull : (1ull << c1) - 1ull) & ~((1ull << c0) - 1ull);   // live members
+        while (L) {
+          int32_t my_sc = NEG_INF, my_from = -1, my_adj = 0, my_tot = 0, my_cnt = 0;
+          int32_t best_sc = NEG_INF, best_k = -1;
+          uint64_t done = 0;
+          for (uint64_t rem = L; rem; rem &= rem - 1) {
+            const int k = __ffsll((long long)rem) - 1;
+            const int32_t mr = __shfl(mt.r, k, 64), mq = __shfl(mt.q, k, 64), ml = __shfl(mt.len, k, 64);
+            int32_t cand = NEG_INF, ol = 0;
+            if ((done >> lane) & 1ull) {
+              ol = mt.r + mt.len - mr;
+              if (ol < 0) ol = 0;
+              const int32_t ol2 = mt.q + mt.len - mq;
+              if (ol2 > ol) ol = ol2;
+              int32_t dd = (mq - mr) - (mt.q - mt.r);
+              if (dd < 0) dd = -dd;
+              cand = my_sc + ml - (ol + dd);
+            }
+            // best candidate: max cand, ties -> nearest predecessor (largest lane)
+            long long key = (((long long)cand + (1ll << 30)) << 8) | (long long)lane;
+            key = wave_max64(key);
+            const int32_t bc = (int32_t)((key >> 8) - (1ll << 30));
+            const int bl = (int)(key & 63);
+            int32_t sc_k = ml, fr_k = -1, ad_k = 0, tot_k = ml, cnt_k = 1;
+            if (bc > sc_k) {
+              sc_k = bc; fr_k = bl; ad_k = __shfl(ol, bl, 64);
+              tot_k += __shfl(my_tot, bl, 64); cnt_k += __shfl(my_cnt, bl, 64);
+            }
+            if (lane == k) { my_sc = sc_k; my_from = fr_k; my_adj = ad_k; my_tot = tot_k; my_cnt = cnt_k; }
+            if (sc_k > best_sc) { best_sc = sc_k; best_k = k; }
+            done |= 1ull << k;
+          }
+          const int32_t total = __shfl(my_tot, best_k, 64), cnt = __shfl(my_cnt, best_k, 64);
+          const bool emit = total >= MIN_CLUSTER && n_chains < (int)cap && n_cm + cnt <= (int)cap;
+          uint64_t M = 0;
+          int32_t my_pos = -1;
+          {
+            int kk = best_k, pos = n_cm + cnt;
+            while (kk >= 0) {
+              M |= 1ull << kk;
+              --pos;
+              if (lane == kk) my_pos = pos;
+              kk = __shfl(my_from, kk, 64);
+            }
+          }
+          if (emit) {
+            if (lane == best_k) {
+              Chain c;
+              c.first = n_cm; c.count = cnt; c.strand = U.strand; c.rrec = rr; c.qrec = qq;
+              chains[n_chains] = c;
+            }
+            if ((M >> lane) & 1ull) {
+              Match t = mt;
+              t.r += my_adj; t.q += my_adj; t.len -= my_adj;
+              cm[my_pos] = t;
+            }
+            n_chains += 1; n_cm += cnt;
+          }
+          L &= ~M;
+        }
+        c0 = c1;
+      }
+      if (!general) { g0 += c0; continue; }
+    }
+    // ---- general path: a cluster of more than 64 matches ----------------------------------------------------------------
     int g1 = g0 + 1;
     {  // cluster end: first position whose root differs (wave search)
       const int32_t root = parent[g0];
