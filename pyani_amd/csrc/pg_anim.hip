@@ -951,7 +951,7 @@ __device__ ExtResult extend_wave(const SeqView& R, const StrandView& Q, int64_t 
     if ((d % CHECK) == 0 || d == d_end) {
       const long long key = wave_max64((((long long)bs + BIAS) << 32) | (uint32_t)bd);  // max score, ties: larger d
       const int32_t g = (int32_t)((key >> 32) - BIAS), t = (int32_t)(key & 0xFFFFFFFFll);
-      const int32_t b = t_prev + BREAK_LEN + 1;      // step at which the per-step rule fires without an improvement
+      const int32_t b = t_prev + BREAK_LEN;          // step at which the per-step rule (d - best_d >= BREAK_LEN) fires without an improvement
       int32_t d1 = fimp;
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) { const int32_t v = __shfl_xor(d1, o, 64); d1 = v < d1 ? v : d1; }
@@ -1213,12 +1213,15 @@ __global__ __launch_bounds__(64) void anim_extend_kernel(const RefDesc* __restri
         if (plq > q_lo) q_lo = plq;
       }
     }
-    const ExtResult b = extend_wave(RV, QV, first_r, first_q, -1, cap_ext(first_r - r_lo, MAX_EXT_BWD), cap_ext(first_q - q_lo, MAX_EXT_BWD), tr, tq);
+    ExtResult b = extend_wave(RV, QV, first_r, first_q, -1, cap_ext(first_r - r_lo, MAX_EXT_BWD), cap_ext(first_q - q_lo, MAX_EXT_BWD), tr, tq);
+    if (tr >= 0 && !b.reached && tr != tq)   // shifted band, unreachable target: search freely (as pga::extend_chain_bwd)
+      b = extend_wave(RV, QV, first_r, first_q, -1, cap_ext(first_r - r_lo, MAX_EXT_BWD), cap_ext(first_q - q_lo, MAX_EXT_BWD), -1, -1);
     ChainBwd e;
     e.rs = first_r - b.di; e.qs = first_q - b.dj; e.err_back = b.errors;
     e.reached = (tr >= 0 && b.reached) ? 1 : 0;
-    bridge_junction(e, prev_re, prev_qe, tr, tq, [&](int32_t r0, int32_t n, int32_t q0, int32_t m) {
-      return thin_rect_errors_wave(RV, QV, r0, n, q0, m); });
+    bridge_junction(e, prev_re, prev_qe, tr, tq, first_r, first_q, p >= 0 ? fwu[p].lr : -1, p >= 0 ? fwu[p].lq : -1,
+                    p >= 0 ? fwu[p].err_fwd : 0,
+                    [&](int32_t r0, int32_t n, int32_t q0, int32_t m) { return thin_rect_errors_wave(RV, QV, r0, n, q0, m); });
     if ((threadIdx.x & 63) == 0) bw[off + c] = e;
   }
 }

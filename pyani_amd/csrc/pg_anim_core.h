@@ -69,7 +69,7 @@ struct Aln {     // alignment in ref / query-strand coordinates, half-open
 //   X = max(H(i-1,j) + OPEN, X(i-1,j) + EXT)   (ties: open)      Y likewise from (i,j-1)
 //   H = max(diag + match/mismatch, X, Y)        (ties: diag, then X, then Y);  errors ride along.
 // Free search: the end is the best cell (ties: larger d, then larger k).  Every CHECK_EVERY anti-diagonals the search
-// stops if the best cell lies more than BREAK_LEN anti-diagonals back (nucmer -b) or no cell is alive.
+// stops once the best cell lies BREAK_LEN anti-diagonals back (nucmer -b; fitted: ">= 200", a tie at step 201 is too late) or no cell is alive.
 // Target search (tr >= 0): runs to d = tr + tq and reports whether the target cell was reached by a live path,
 // subject to the same break rule on the way.
 struct ExtResult {
@@ -80,6 +80,7 @@ struct ExtResult {
 
 constexpr int32_t NEG_INF = -(1 << 28);
 constexpr int CHECK_EVERY = 1;
+constexpr int TARGET_TRIM_MAX = 19;  // a following chain whose first match overlaps this one's end by < MIN_MATCH bases is still a target
 constexpr int GAP_DIAG_MAX = 64;  // same-diagonal gaps up to this length are first tried as pure substitutions
 
 struct DpCell { int32_t h, he, x, xe, y, ye; };
@@ -169,7 +170,7 @@ PG_HD ExtResult extend_banded(const RefT& R, const QryT& Q, int64_t r0, int64_t 
       gbest = NEG_INF; gbest_d = 0;
       for (int l = 0; l < BAND; ++l)
         if (bs[l] > gbest || (bs[l] == gbest && bd[l] >= gbest_d)) { gbest = bs[l]; gbest_d = bd[l]; }
-      if (d - gbest_d > BREAK_LEN) break;
+      if (d - gbest_d >= BREAK_LEN) break;
       // `alive` of the last anti-diagonal only; two dead anti-diagonals in a row cannot revive
       bool any = alive;
       for (int l = 0; l < BAND && !any; ++l) any = cur[l].h > NEG_INF / 2;
@@ -443,19 +444,24 @@ PG_HD int32_t chain_inner_errors(const RefT& R, const QryT& Q, const Match* cm, 
   return inner;
 }
 
-// Forward target of a chain that ends at (er, eq): the first match of the following chain, if it lies strictly ahead
-// in BOTH sequences (postnuc never fuses clusters whose matches overlap: e.g. around tandem repeats the query
-// coordinate steps back and the two clusters stay two alignments).
+// Forward target of a chain that ends at (er, eq): the start of the following chain's first match.  If that match
+// overlaps this chain's end in ONE sequence by fewer than MIN_MATCH bases (a short tandem repeat at the edge of an
+// indel), the target is the match trimmed by the overlap, as between the matches of one cluster (fixture: Blochmannia
+// NC_007292 / NC_020075, one 791 kb alignment across a 46-base insertion flanked by an 11-mer repeat); if it overlaps in
+// BOTH sequences the two clusters stay two alignments (fixture: the Caulobacter pair around 3.73 Mb).
 PG_HD void forward_target(int32_t er, int32_t eq, int32_t nr, int32_t nq, int32_t nlen, int32_t& tr, int32_t& tq) {
-  (void)nlen;
   tr = -1; tq = -1;
-  if (nr < 0 || nr < er || nq < eq) return;
-  tr = nr - er; tq = nq - eq;
+  if (nr < 0 || (nr < er && nq < eq)) return;   // overlapping in BOTH sequences: the two clusters stay two alignments
+  int32_t trim = er - nr;
+  if (eq - nq > trim) trim = eq - nq;
+  if (trim < 0) trim = 0;
+  if (trim >= nlen || trim > TARGET_TRIM_MAX) return;
+  tr = nr + trim - er; tq = nq + trim - eq;
 }
 
 // MUMmer's DP works on at most MAX_ALIGNMENT_LENGTH = 10000 bases per call; an extension off a cluster end therefore
-// never exceeds 9999 (forward) / 9998 (backward) bases — visible in the fixtures as alignments that stop exactly there.
-constexpr int32_t MAX_EXT_FWD = 9999, MAX_EXT_BWD = 9998;
+// never exceeds 9999 bases in either direction — visible in the fixtures as alignments that stop exactly there.
+constexpr int32_t MAX_EXT_FWD = 9999, MAX_EXT_BWD = 9999;
 PG_HD int32_t cap_ext(int32_t v, int32_t cap) { return v < cap ? v : cap; }
 
 // Forward target: walk the following chains (same strand and records, ref order) and take the first whose first match
@@ -469,7 +475,7 @@ PG_HD int32_t pick_forward_target(const Chain* chains, const Match* cm, const in
     const Match& nf = cm[chains[t].first];
     int32_t tr, tq;
     forward_target(er, eq, nf.r, nf.q, nf.len, tr, tq);
-    if (tr >= 0) { nr = nf.r; nq = nf.q; return t; }
+    if (tr >= 0) { nr = er + tr; nq = eq + tq; return t; }
   }
   return -1;
 }
@@ -488,7 +494,9 @@ PG_HD void forward_extension(EXT&& ext, int32_t er, int32_t eq, int32_t r_hi, in
     int32_t tr = -1, tq = -1;
     if (nr >= 0) { tr = nr - cr; tq = nq - cq; }
     const bool near = nr >= 0 && tr >= 0 && tq >= 0 && tr <= MAX_EXT_FWD && tq <= MAX_EXT_FWD;
-    const ExtResult x = ext(cr, cq, cap_ext(r_hi - cr, MAX_EXT_FWD), cap_ext(q_hi - cq, MAX_EXT_FWD), near ? tr : -1, near ? tq : -1);
+    ExtResult x = ext(cr, cq, cap_ext(r_hi - cr, MAX_EXT_FWD), cap_ext(q_hi - cq, MAX_EXT_FWD), near ? tr : -1, near ? tq : -1);
+    if (near && !x.reached && tr != tq)   // the band was shifted towards an unreachable target: search freely instead
+      x = ext(cr, cq, cap_ext(r_hi - cr, MAX_EXT_FWD), cap_ext(q_hi - cq, MAX_EXT_FWD), -1, -1);
     err += x.errors; cr += x.di; cq += x.dj;
     if (near) { reached = x.reached; break; }
     const bool hit_cap = x.di >= MAX_EXT_FWD - 100 || x.dj >= MAX_EXT_FWD - 100;
@@ -517,18 +525,24 @@ PG_HD ChainFwd extend_chain_fwd(const RefT& R, const QryT& Q, const Match* cm, c
 // alignment's end (prev_re, prev_qe) is still behind it and within the break length, nucmer's dynamic band would have
 // reached it -> bridge the residual rectangle with a full DP and fuse.  RECT(r0, n, q0, m) -> errors or -1.
 template <typename RECT>
-PG_HD void bridge_junction(ChainBwd& e, int32_t prev_re, int32_t prev_qe, int32_t tr, int32_t tq, RECT&& rect) {
+PG_HD void bridge_junction(ChainBwd& e, int32_t prev_re, int32_t prev_qe, int32_t tr, int32_t tq, int32_t first_r, int32_t first_q,
+                           int32_t prev_lr, int32_t prev_lq, int32_t prev_err_fwd, RECT&& rect) {
   if (e.reached || prev_re < 0 || tr < 0) return;
   int32_t shift = tq - tr;
   if (shift < 0) shift = -shift;
   if (shift < BAND - 2) return;                            // reachable shifts are decided by the (shifted-band) target search
   const int32_t n = e.rs - prev_re, m = e.qs - prev_qe;
   if (n < 0 || m < 0 || n + m > BREAK_LEN) return;
-  // prefer the optimal path over the whole junction (previous end -> this chain's first match); fall back to the
-  // residual rectangle behind the free backward search when the junction is too large for the full DP
-  int32_t err = rect(prev_re, tr, prev_qe, tq);
-  if (err >= 0) { e.err_back = err; }
-  else { err = rect(prev_re, n, prev_qe, m); if (err < 0) return; e.err_back += err; }
+  // prefer the optimal path over the WHOLE junction, from the end of the previous chain's last match to this chain's
+  // first match (its free forward extension is then replaced: minus prev_err_fwd); then from the previous forward end;
+  // fall back to the residual rectangle behind the free backward search when the junction is too large for the full DP
+  int32_t err = prev_lr >= 0 && prev_lr <= prev_re && prev_lq <= prev_qe ? rect(prev_lr, first_r - prev_lr, prev_lq, first_q - prev_lq) : -1;
+  if (err >= 0) { e.err_back = err - prev_err_fwd; }
+  else {
+    err = rect(prev_re, tr, prev_qe, tq);
+    if (err >= 0) { e.err_back = err; }
+    else { err = rect(prev_re, n, prev_qe, m); if (err < 0) return; e.err_back += err; }
+  }
   e.rs = prev_re; e.qs = prev_qe; e.reached = 2;
 }
 
@@ -539,7 +553,7 @@ PG_HD void bridge_junction(ChainBwd& e, int32_t prev_re, int32_t prev_qe, int32_
 template <typename RefT, typename QryT>
 PG_HD ChainBwd extend_chain_bwd(const RefT& R, const QryT& Q, int32_t first_r, int32_t first_q, int32_t r_lo, int32_t q_lo,
                                 int32_t prev_re, int32_t prev_qe, int32_t prev_lr, int32_t prev_lq, int32_t prev_fr,
-                                int32_t prev_fq, int32_t my_lr, int32_t my_lq, bool prev_reached_me) {
+                                int32_t prev_fq, int32_t my_lr, int32_t my_lq, bool prev_reached_me, int32_t prev_err_fwd) {
   // no search needed: the previous chain's forward extension already landed on this chain's first match (fusion),
   // or its span covers this chain entirely (the stitch will shadow it)
   if (prev_reached_me ||
@@ -554,13 +568,15 @@ PG_HD ChainBwd extend_chain_bwd(const RefT& R, const QryT& Q, int32_t first_r, i
     if (prev_lr > r_lo) r_lo = prev_lr;
     if (prev_lq > q_lo) q_lo = prev_lq;
   }
-  const ExtResult b = extend_banded(R, Q, first_r, first_q, -1, cap_ext(first_r - r_lo, MAX_EXT_BWD),
-                                    cap_ext(first_q - q_lo, MAX_EXT_BWD), tr, tq);
+  ExtResult b = extend_banded(R, Q, first_r, first_q, -1, cap_ext(first_r - r_lo, MAX_EXT_BWD),
+                              cap_ext(first_q - q_lo, MAX_EXT_BWD), tr, tq);
+  if (tr >= 0 && !b.reached && tr != tq)   // the band was shifted towards an unreachable target: search freely instead
+    b = extend_banded(R, Q, first_r, first_q, -1, cap_ext(first_r - r_lo, MAX_EXT_BWD), cap_ext(first_q - q_lo, MAX_EXT_BWD), -1, -1);
   ChainBwd e;
   e.rs = first_r - b.di; e.qs = first_q - b.dj; e.err_back = b.errors;
   e.reached = (tr >= 0 && b.reached) ? 1 : 0;
-  bridge_junction(e, prev_re, prev_qe, tr, tq, [&](int32_t r0, int32_t n, int32_t q0, int32_t m) {
-    return thin_rect_errors(R, Q, r0, n, q0, m); });
+  bridge_junction(e, prev_re, prev_qe, tr, tq, first_r, first_q, prev_lr, prev_lq, prev_err_fwd,
+                  [&](int32_t r0, int32_t n, int32_t q0, int32_t m) { return thin_rect_errors(R, Q, r0, n, q0, m); });
   return e;
 }
 

@@ -76,33 +76,15 @@ def fixture_runs(eng, genome_dir, gold):
 
 
 def test_alignment_search_vs_real_mummer_output(fixture_runs):
-    """17 ordered pairs with both genomes and real nucmer+delta-filter output.  Engine state (round 1): 15 of 17 pairs
-    within 1.5e-4 of nucmer's identity (11 of them to the last digit; BASELINE.json's bar is 1e-4), worst 5.5e-4;
-    aligned lengths within 1 % everywhere."""
+    """17 ordered pairs with both genomes and real nucmer+delta-filter output (15 Blochmannia pairs at 83-98 % identity,
+    the near-identical Caulobacter pair in both directions).  BASELINE.json's bar is identity and coverage within 1e-4;
+    the engine reproduces every one of these parse_delta tuples EXACTLY: aligned lengths, error counts, and the
+    identity to the last bit (tools/anim_host_fixture_check.py: 505 of 505 .delta alignment records)."""
     assert len(fixture_runs) == 17
-    d_id = []
     for rel, a, b, r, want in fixture_runs:
         assert int(r["status"]) == 0, rel
-        d_id.append(abs(float(r["identity"]) - want[2]))
-        assert d_id[-1] <= 1e-3, (rel, float(r["identity"]), want[2])
-        assert abs(int(r["ref_aln_len"]) - want[0]) <= 0.01 * want[0], rel
-        assert abs(int(r["qry_aln_len"]) - want[1]) <= 0.01 * want[1], rel
-    assert sum(d <= 1e-4 for d in d_id) >= 14
-    assert sum(d <= 1.5e-4 for d in d_id) >= 15
-    assert float(np.median(d_id)) == 0.0
-
-
-def test_pairs_reproduced_exactly(fixture_runs):
-    """Pairs whose parse_delta tuple is reproduced to the last digit (same alignment set as MUMmer's)."""
-    n_exact = 0
-    for rel, a, b, r, want in fixture_runs:
-        exact = ([int(r["ref_aln_len"]), int(r["qry_aln_len"]), int(r["sim_errors"])] == [want[0], want[1], want[3]]
-                 and float(r["identity"]).hex() == float(want[2]).hex())
-        n_exact += exact
-        if a.startswith("NC_"):      # near-identical Caulobacter pair: lengths and errors exact, identity within 1e-10
-            assert [int(r["ref_aln_len"]), int(r["qry_aln_len"]), int(r["sim_errors"])] == [want[0], want[1], want[3]]
-            assert abs(float(r["identity"]) - want[2]) < 1e-10
-    assert n_exact >= 10
+        got = [int(r["ref_aln_len"]), int(r["qry_aln_len"]), float(r["identity"]).hex(), int(r["sim_errors"])]
+        assert got == [want[0], want[1], float(want[2]).hex(), want[3]], rel
 
 
 def test_module_api_and_matrices(eng, genome_dir):

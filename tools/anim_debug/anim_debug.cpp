@@ -115,7 +115,7 @@ int main(int argc, char** argv) {
       auto t0 = std::chrono::steady_clock::now();
       bw[c] = extend_chain_bwd(R, Q, fw[c].first_r, fw[c].first_q, r_lo[c], q_lo[c], p >= 0 ? fw[p].re : -1, p >= 0 ? fw[p].qe : -1, p >= 0 ? fw[p].lr : -1, p >= 0 ? fw[p].lq : -1,
                                p >= 0 ? fw[p].first_r : -1, p >= 0 ? fw[p].first_q : -1, fw[c].lr, fw[c].lq,
-                               p >= 0 && fw[p].reached && fw[p].target == c);
+                               p >= 0 && fw[p].reached && fw[p].target == c, p >= 0 ? fw[p].err_fwd : 0);
       double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
       if (ms > 20 && getenv("ANIM_TIMING")) fprintf(stderr, "BWD chain %d strand %d: %.0f ms first r %d q %d -> rs %d qs %d reached %d prev %d (prev re %d qe %d lr %d lq %d)\n", c, strand, ms, fw[c].first_r, fw[c].first_q, bw[c].rs, bw[c].qs, bw[c].reached, p, p>=0?fw[p].re:-1, p>=0?fw[p].qe:-1, p>=0?fw[p].lr:-1, p>=0?fw[p].lq:-1);
     }

@@ -19,6 +19,7 @@ import anim_oracle  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("-j", type=int, default=8)
 ap.add_argument("--only", default="")
+ap.add_argument("--diff", action="store_true", help="print the records that differ")
 args = ap.parse_args()
 exe = ROOT / "tools/anim_debug/anim_debug"
 subprocess.run(["g++", "-O2", "-std=c++17", f"-I{ROOT}/pyani_amd/csrc", str(exe) + ".cpp", "-o", str(exe)], check=True)
@@ -48,6 +49,9 @@ def run(job):
             got.add((t[1], t[2], int(t[3]), int(t[4]), int(t[5]), int(t[6]), int(t[7])))
     want = {(x.ref_id, x.qry_id, x.rs, x.re, x.qs, x.qe, x.errors) for x in anim_oracle.read_delta(f)[0]}
     coords = {w[:6] for w in want} & {g[:6] for g in got}
+    if args.diff:
+        for w in sorted(want - got): print("  MUMMER", w, flush=True)
+        for g in sorted(got - want): print("  OURS  ", g, flush=True)
     return f.name, len(want), len(want & got), len(coords), len(got), r.stdout.splitlines()[0] if r.stdout else ""
 
 
