@@ -1239,12 +1239,18 @@ struct FinishScratch {   // per-alignment arrays: pair p owns the slice [moff[2p
 // pga::lis_filter with the O(n^2) look-back spread over the lanes of one wave.  Every lane runs the (cheap) serial parts
 // redundantly and writes identical values, so no intra-wave memory ordering is needed; candidates are evaluated by the
 // same expression as the scalar code and the reduction keeps its tie rule (the earliest predecessor reaching the max).
-__device__ void lis_filter_wave(Aln* a, int n, int side, const int32_t* grp, int32_t* idx, double* sc, int32_t* from) {
+__device__ void lis_filter_wave(Aln* a, int n, int side, const int32_t* grp, int32_t* idx, double* sc_, int32_t* from) {
   const int lane = threadIdx.x & 63;
+  int64_t* sc = reinterpret_cast<int64_t*>(sc_);
   auto lo = [&](int i) { return side == 0 ? a[i].rs : a[i].qs; };
   auto hi = [&](int i) { return side == 0 ? a[i].re : a[i].qe; };
-  for (int i = 0; i < n; ++i) idx[i] = i;
-  heapsort(idx, n, [&](int x, int y) { return grp[x] < grp[y] || (grp[x] == grp[y] && lo(x) < lo(y)); });
+  bool ok;
+  for (int i = 0; i < n; ++i) { idx[i] = i; sc[i] = lis_gain(hi(i) - lo(i), 1, 0, lis_idy(a[i]), ok); }
+  heapsort(idx, n, [&](int x, int y) {
+    if (grp[x] != grp[y]) return grp[x] < grp[y];
+    if (lo(x) != lo(y)) return lo(x) < lo(y);
+    if (sc[x] != sc[y]) return sc[x] > sc[y];
+    return x < y; });
   int g0 = 0;
   while (g0 < n) {
     int g1 = g0;
@@ -1252,26 +1258,26 @@ __device__ void lis_filter_wave(Aln* a, int n, int side, const int32_t* grp, int
     int best = -1;
     for (int k = g0; k < g1; ++k) {
       const int i = idx[k];
-      const double len = (double)(hi(i) - lo(i));
-      const double tot = (double)((a[i].re - a[i].rs) + (a[i].qe - a[i].qs));
-      const double idy = tot > 0 ? 1.0 - 2.0 * a[i].errors / tot : 0.0;
-      const double own = len * idy * idy;
+      const int64_t len = hi(i) - lo(i);
+      const double idy = lis_idy(a[i]);
       const int32_t lo_i = lo(i);
-      double bc = own;      // this lane's best candidate and its predecessor's rank (kk)
+      long long bc = sc[i];   // own score; this lane's best candidate and its predecessor's rank (kk)
       int bk = 0x7FFFFFFF;
       for (int kk = g0 + lane; kk < k; kk += 64) {
         const int j = idx[kk];
-        double ol = (double)(hi(j) - lo_i);
+        int64_t ol = (int64_t)hi(j) - lo_i;
         if (ol < 0) ol = 0;
-        if (ol >= len) continue;
-        const double cand = sc[j] + own * (1.0 - ol / len);
+        bool allowed;
+        const int64_t g = lis_gain(len, hi(j) - lo(j), ol, idy, allowed);
+        if (!allowed) continue;
+        const long long cand = sc[j] + g;
         if (cand > bc) { bc = cand; bk = kk; }
       }
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) {
-        const double oc = __shfl_xor(bc, o, 64);
-        const int ok = __shfl_xor(bk, o, 64);
-        if (oc > bc || (oc == bc && ok < bk)) { bc = oc; bk = ok; }
+        const long long oc = __shfl_xor(bc, o, 64);
+        const int ok2 = __shfl_xor(bk, o, 64);
+        if (oc > bc || (oc == bc && ok2 < bk)) { bc = oc; bk = ok2; }
       }
       sc[i] = bc;
       from[i] = bk == 0x7FFFFFFF ? -1 : idx[bk];

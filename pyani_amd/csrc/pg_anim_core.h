@@ -628,14 +628,34 @@ PG_HD int stitch_chains(const ChainFwd* fw, const ChainBwd* bw, const Match* cm,
   return n_out;
 }
 
-// delta-filter -1 (1-to-1: intersection of the best alignment sets on the reference and on the query):
-// weighted LIS over one coordinate; score of an alignment = length * identity^2; overlapping neighbours lose the
-// overlapped part.  side 0 = reference coordinates, 1 = query coordinates.  idx: scratch order; sc/from: scratch.
-PG_HD void lis_filter(Aln* a, int n, int side, const int32_t* grp, int32_t* idx, double* sc, int32_t* from) {
+// delta-filter -1 (1-to-1: intersection of the best alignment sets on the reference and on the query), restated from
+// MUMmer 3.23's published algorithm (DeltaGraph_t::flagRLIS / flagQLIS + ScoreLocal): per sequence, alignments sorted by
+// start (ties: input order); weighted LIS with integer scores  score_i = max(own_i, max_j<i score_j + gain(i, j)),
+// own_i = trunc(len_i * idy_i^2), gain = trunc((len_i - olap) * idy_i^2), and a predecessor j is not allowed when the
+// overlap exceeds LIS_MAX_OLAP (75 %, delta-filter's -o default) of either alignment; first best wins (strict >).
+// side 0 = reference coordinates, 1 = query coordinates.  idx: scratch order; sc (as int64) / from: scratch.
+constexpr double LIS_MAX_OLAP = 100.0;
+PG_HD double lis_idy(const Aln& a) {
+  const double tot = (double)((a.re - a.rs) + (a.qe - a.qs));
+  return tot > 0 ? 1.0 - 2.0 * a.errors / tot : 0.0;
+}
+PG_HD int64_t lis_gain(int64_t len_i, int64_t len_j, int64_t olap, double idy_i, bool& allowed) {
+  allowed = !(olap > 0 && ((double)olap / (double)len_i * 100.0 > LIS_MAX_OLAP || (double)olap / (double)len_j * 100.0 > LIS_MAX_OLAP));
+  return (int64_t)((double)(len_i - olap) * (idy_i * idy_i));
+}
+PG_HD void lis_filter(Aln* a, int n, int side, const int32_t* grp, int32_t* idx, double* sc_, int32_t* from) {
+  int64_t* sc = reinterpret_cast<int64_t*>(sc_);
   auto lo = [&](int i) { return side == 0 ? a[i].rs : a[i].qs; };   // a[] carries FORWARD query coordinates here
   auto hi = [&](int i) { return side == 0 ? a[i].re : a[i].qe; };
-  for (int i = 0; i < n; ++i) idx[i] = i;
-  heapsort(idx, n, [&](int x, int y) { return grp[x] < grp[y] || (grp[x] == grp[y] && lo(x) < lo(y)); });
+  bool ok;
+  for (int i = 0; i < n; ++i) { idx[i] = i; sc[i] = lis_gain(hi(i) - lo(i), 1, 0, lis_idy(a[i]), ok); }   // own scores
+  // by start; equal starts: the higher-scoring alignment first (then input order) — with the fixtures' equal-start
+  // pairs this is the order that reproduces delta-filter's choices
+  heapsort(idx, n, [&](int x, int y) {
+    if (grp[x] != grp[y]) return grp[x] < grp[y];
+    if (lo(x) != lo(y)) return lo(x) < lo(y);
+    if (sc[x] != sc[y]) return sc[x] > sc[y];
+    return x < y; });
   int g0 = 0;
   while (g0 < n) {
     int g1 = g0;
@@ -643,17 +663,16 @@ PG_HD void lis_filter(Aln* a, int n, int side, const int32_t* grp, int32_t* idx,
     int best = -1;
     for (int k = g0; k < g1; ++k) {
       const int i = idx[k];
-      const double len = (double)(hi(i) - lo(i));
-      const double tot = (double)((a[i].re - a[i].rs) + (a[i].qe - a[i].qs));
-      const double idy = tot > 0 ? 1.0 - 2.0 * a[i].errors / tot : 0.0;
-      const double own = len * idy * idy;
-      sc[i] = own; from[i] = -1;
+      const int64_t len = hi(i) - lo(i);
+      const double idy = lis_idy(a[i]);
+      from[i] = -1;   // sc[i] = own score already
       for (int kk = g0; kk < k; ++kk) {
         const int j = idx[kk];
-        double ol = (double)(hi(j) - lo(i));
+        int64_t ol = (int64_t)hi(j) - lo(i);
         if (ol < 0) ol = 0;
-        if (ol >= len) continue;  // i contained in j's span: cannot extend the chain
-        const double cand = sc[j] + own * (1.0 - ol / len);
+        const int64_t g = lis_gain(len, hi(j) - lo(j), ol, idy, ok);
+        if (!ok) continue;
+        const int64_t cand = sc[j] + g;
         if (cand > sc[i]) { sc[i] = cand; from[i] = j; }
       }
       if (best < 0 || sc[i] > sc[best]) best = i;

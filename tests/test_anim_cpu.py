@@ -56,8 +56,8 @@ def filter_check():
 
 
 def test_one_to_one_filter_matches_delta_filter(filter_check):
-    """27 real .delta -> .filter pairs (MUMmer 3.1/3.23 output held by the reference's tests, ~10 000 alignments):
-    the engine's filter must agree on > 99.7 % of the keep/drop decisions and exactly on most files."""
+    """27 real .delta -> .filter pairs (MUMmer 3.1/3.23 output held by the reference's tests, 12 734 alignments):
+    the engine's filter reproduces every keep/drop decision of delta-filter -1."""
     total = wrong = exact_files = 0
     files = sorted((GOLD / "anim").glob("*/*.delta.gz"))
     assert len(files) == 27
@@ -71,5 +71,5 @@ def test_one_to_one_filter_matches_delta_filter(filter_check):
         total += len(al)
         wrong += len(mine ^ want)
         exact_files += mine == want
-    assert wrong / total < 0.003, (wrong, total)
-    assert exact_files >= 20
+    assert total == 12734 and wrong == 0, (wrong, total)
+    assert exact_files == 27
