@@ -109,7 +109,8 @@ int pg_tetra_corr_rows_dev(pg_ctx* ctx, const double* d_z, const uint8_t* d_pres
  * file.  status: 0 = ok; PG_ANIM_NO_ALIGNMENT = no alignment survived (parse_delta would raise ZeroDivisionError,
  * anim.py:396); PG_E_CAPACITY = internal buffers overflowed for this pair.
  * MUMmer itself is third-party and absent from the reference tree: behaviour is reconstructed and calibrated against
- * the MUMmer output files the reference's tests hold (DESIGN.md §ANIm lists the measured deviations). */
+ * the MUMmer output files the reference's tests hold (every fixture reproduced exactly).
+ * reserved = number of alignments BEFORE the 1-to-1 filter (what nucmer's .delta would hold). */
 typedef struct {
   int64_t ref_aln_len, qry_aln_len, sim_errors, n_alignments;
   double identity;
@@ -121,6 +122,20 @@ typedef struct {
  * pyani's --nofilter (reduction over the unfiltered alignments). */
 int pg_anim_pairs(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_ids, uint64_t n_pairs, int maxmatch,
                   int filter_1to1, pg_anim_result* out);
+
+/* The alignment records of ONE ordered pair: the content of the .delta file nucmer would write (kept == 3 marks the
+ * records delta-filter -1 keeps, i.e. the .filter file), minus the indel offset lists, which parse_delta ignores
+ * (anim.py:374-393) and this engine does not trace back.  Coordinates as in MUMmer's alignment header lines
+ * (pyani/nucmer.py:333-351): 1-based, closed, relative to the record, qs > qe on the reverse strand; ref_rec / qry_rec
+ * = ordinal of the FASTA record (the '>' line names the ids).  At most `cap` records are written, *n_out = how many
+ * there are.  Used for alignment-level parity tests and to write recovery files (pyani_amd.anim.write_delta). */
+typedef struct {
+  int32_t ref_rec, qry_rec;
+  int32_t rs, re, qs, qe;
+  int32_t errors;
+  int32_t kept;   /* 3 = survives delta-filter -1 (bit 0: reference-side LIS, bit 1: query-side LIS) */
+} pg_anim_alignment;
+int pg_anim_pair_alignments(pg_ctx* ctx, int32_t ref_id, int32_t qry_id, pg_anim_alignment* out, uint32_t cap, uint32_t* n_out);
 
 /* The reduction alone, on alignment records supplied by the caller (e.g. parsed from existing MUMmer .delta/.filter
  * files — pyani's --recovery mode): replaces delta-filter -1 (apply_filter != 0; scripts/delta_filter_wrapper.py:70-93)

@@ -128,6 +128,45 @@ def read_delta(path):
     return recs
 
 
+def fasta_records(path) -> List[Tuple[str, int]]:
+    """(record id, length) of every record of a FASTA file, in file order (ids = first whitespace token, as nucmer)."""
+    out = []
+    opener = gzip.open if str(path).endswith(".gz") else open
+    with opener(path, "rt") as fh:
+        for line in fh:
+            if line.startswith(">"):
+                out.append([line[1:].split()[0] if line[1:].split() else "", 0])
+            elif out:
+                out[-1][1] += len(line.strip().replace(" ", ""))
+    return [(i, n) for i, n in out]
+
+
+def write_delta(path, ref_fasta, qry_fasta, alignments, filtered: bool = True) -> int:
+    """Write one pair's alignment records (Engine.anim_pair_alignments) as a MUMmer .filter (filtered=True: only the
+    records delta-filter -1 keeps) or .delta file: the file nucmer / delta_filter_wrapper leave in
+    <outdir>/nucmer_output/<stem1>/<stem1>_vs_<stem2>.{filter,delta} (anim.py:271-288) and pyani's --recovery mode
+    reads back with parse_delta.  Header lines follow pyani/nucmer.py:292-351.  The indel offset lists of a real
+    .delta are NOT written (no traceback in the engine; parse_delta ignores them): every alignment is its 7-field
+    header followed by the terminating 0, so the file is exact for pyani and for coordinate-level tools, but tools that
+    replay the alignment (show-aligns, dnadiff's SNP calls) cannot use it.  Returns the number of records written."""
+    rrec, qrec = fasta_records(ref_fasta), fasta_records(qry_fasta)
+    blocks = {}
+    for a in alignments:
+        if filtered and int(a["kept"]) != 3:
+            continue
+        blocks.setdefault((int(a["ref_rec"]), int(a["qry_rec"])), []).append(a)
+    n = 0
+    with open(path, "w") as fh:
+        fh.write(f"{Path(ref_fasta).resolve()} {Path(qry_fasta).resolve()}\nNUCMER\n")
+        for (r, q) in sorted(blocks):
+            fh.write(f">{rrec[r][0]} {qrec[q][0]} {rrec[r][1]} {qrec[q][1]}\n")
+            for a in sorted(blocks[(r, q)], key=lambda x: (int(x["rs"]), int(x["qs"]))):
+                e = int(a["errors"])
+                fh.write(f"{int(a['rs'])} {int(a['re'])} {int(a['qs'])} {int(a['qe'])} {e} {e} 0\n0\n")
+                n += 1
+    return n
+
+
 def parse_delta(filename, engine: Engine = None) -> Tuple[int, int, float, int]:
     """(reference alignment length, query alignment length, average identity, similarity errors) of a MUMmer
     .delta/.filter file — pyani.anim.parse_delta (anim.py:292-411), reduced on the GPU."""

@@ -1332,7 +1332,7 @@ __global__ __launch_bounds__(64) void anim_finish_kernel(const RefDesc* __restri
   o.n_alignments = r.n_alignments;
   o.identity = r.aligned > 0 ? (double)r.weighted / (double)r.aligned : 0.0;  // int/int true division (anim.py:396)
   o.status = O.status[p] ? PG_E_CAPACITY : (r.n_alignments == 0 ? PG_ANIM_NO_ALIGNMENT : 0);
-  o.reserved = 0;
+  o.reserved = n;   // alignments before the filter
   if ((threadIdx.x & 63) == 0) out[p] = o;
 }
 
@@ -1700,6 +1700,33 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
     }
   }
 #endif
+  return PG_OK;
+}
+
+// The alignment records of the pair a 1-pair batch has just processed (slice 0 of the finish scratch), converted to
+// MUMmer's per-record 1-based closed coordinates.
+int pg_anim_fetch_alignments(pg_ctx* ctx, int32_t ref_id, int32_t qry_id, uint32_t n, pg_anim_alignment* out) {
+  AnimScratch* A = anim_scratch(ctx);
+  std::vector<Aln> al(n);
+  std::vector<int32_t> rr(n), qr(n);
+  if (n) {
+    PG_HIP(ctx, hipMemcpy(al.data(), A->S.alns, n * sizeof(Aln), hipMemcpyDeviceToHost));
+    PG_HIP(ctx, hipMemcpy(rr.data(), A->S.a_rrec, n * 4, hipMemcpyDeviceToHost));
+    PG_HIP(ctx, hipMemcpy(qr.data(), A->S.a_qrec, n * 4, hipMemcpyDeviceToHost));
+  }
+  const PgGenome& G = ctx->genomes[ref_id];
+  const PgGenome& H = ctx->genomes[qry_id];
+  for (uint32_t i = 0; i < n; ++i) {
+    const Aln& a = al[i];            // forward stream coordinates, half-open
+    const int32_t ro = G.rec_start[rr[i]], qo = H.rec_start[qr[i]];
+    pg_anim_alignment x;
+    x.ref_rec = rr[i]; x.qry_rec = qr[i];
+    x.rs = a.rs - ro + 1; x.re = a.re - ro;
+    x.qs = a.strand ? a.qe - qo : a.qs - qo + 1;
+    x.qe = a.strand ? a.qs - qo + 1 : a.qe - qo;
+    x.errors = a.errors; x.kept = a.keep;
+    out[i] = x;
+  }
   return PG_OK;
 }
 

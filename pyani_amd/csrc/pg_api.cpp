@@ -650,6 +650,25 @@ int pg_anim_pairs(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_ids, u
   return PG_OK;
 }
 
+int pg_anim_pair_alignments(pg_ctx* ctx, int32_t ref_id, int32_t qry_id, pg_anim_alignment* out, uint32_t cap, uint32_t* n_out) {
+  if (!ctx || !n_out || (cap && !out)) return pg_fail(ctx, PG_E_ARG, "bad argument");
+  if (ref_id < 0 || (size_t)ref_id >= ctx->genomes.size() || qry_id < 0 || (size_t)qry_id >= ctx->genomes.size())
+    return pg_fail(ctx, PG_E_ARG, "genome id out of range");
+  PG_HIP(ctx, hipSetDevice(ctx->device));
+  int rc;
+  if ((rc = pg_upload(ctx))) return rc;
+  pg_anim_result res{};
+  uint32_t done = 0;
+  if ((rc = pg_anim_run_batch(ctx, &ref_id, &qry_id, 1, 1, ctx->anim_batch_matches, &res, &done))) return rc;
+  if (res.status == PG_E_CAPACITY) return pg_fail(ctx, PG_E_CAPACITY, "anim: work buffers overflowed for this pair");
+  *n_out = (uint32_t)res.reserved;
+  const uint32_t n = *n_out < cap ? *n_out : cap;
+  std::vector<pg_anim_alignment> tmp(*n_out);
+  if ((rc = pg_anim_fetch_alignments(ctx, ref_id, qry_id, *n_out, tmp.data()))) return rc;
+  for (uint32_t i = 0; i < n; ++i) out[i] = tmp[i];
+  return PG_OK;
+}
+
 int pg_anim_reduce(pg_ctx* ctx, uint32_t n_pairs, const uint64_t* offsets, const int32_t* rseq, const int32_t* qseq,
                    const int32_t* rs, const int32_t* re, const int32_t* qs, const int32_t* qe, const int32_t* errors,
                    int apply_filter, pg_anim_result* out) {

@@ -112,6 +112,7 @@ int pg_anim_reduce_run(pg_ctx* ctx, uint32_t n_pairs, const uint64_t* offsets, c
 int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_ids, uint32_t n_pairs, int filter_1to1,
                       uint64_t max_matches, pg_anim_result* out_host, uint32_t* n_done);   // ref_ids grouped (equal ids adjacent)
 void pg_anim_free_scratch(pg_ctx* ctx);
+int pg_anim_fetch_alignments(pg_ctx* ctx, int32_t ref_id, int32_t qry_id, uint32_t n, pg_anim_alignment* out);   // after a 1-pair batch
 void pg_anim_drop_lists(pg_ctx* ctx);   // per-genome seed lists: must go when the genome store is cleared
 int pg_anib_reduce_run(pg_ctx* ctx, uint32_t n_pairs, const uint64_t* offsets, const uint32_t* n_frags, const int32_t* frag,
                        const int32_t* length, const int32_t* mismatch, const int32_t* gaps, const int32_t* qlen,

@@ -162,6 +162,19 @@ class Engine:
                                            out.ctypes.data))
         return out
 
+    ALN_DTYPE = np.dtype([("ref_rec", "<i4"), ("qry_rec", "<i4"), ("rs", "<i4"), ("re", "<i4"), ("qs", "<i4"), ("qe", "<i4"),
+                          ("errors", "<i4"), ("kept", "<i4")])
+
+    def anim_pair_alignments(self, ref_id: int, qry_id: int) -> np.ndarray:
+        """Alignment records of one ordered pair (what nucmer's .delta would hold; kept == 3: survives delta-filter -1)."""
+        n = ctypes.c_uint32(0)
+        out = np.zeros(4096, dtype=self.ALN_DTYPE)
+        self._check(self.lib.pg_anim_pair_alignments(self._h, int(ref_id), int(qry_id), out.ctypes.data, len(out), ctypes.byref(n)))
+        if n.value > len(out):
+            out = np.zeros(n.value, dtype=self.ALN_DTYPE)
+            self._check(self.lib.pg_anim_pair_alignments(self._h, int(ref_id), int(qry_id), out.ctypes.data, len(out), ctypes.byref(n)))
+        return out[:n.value].copy()
+
     def anim_reduce(self, pairs, apply_filter: bool = False) -> np.ndarray:
         """pairs: list of per-pair record lists [(rseq, qseq, rs, re, qs, qe, errors), ...] in MUMmer coordinates
         (1-based closed, qs > qe on the reverse strand; rseq/qseq = sequence ordinals within the pair)."""

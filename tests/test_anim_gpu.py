@@ -147,3 +147,40 @@ def test_gpu_pipeline_equals_scalar_host_statement_on_synthetic_pairs(eng):
             if got != want:
                 bad.append((a, b, got, want))
         assert not bad, f"{mode}: {len(bad)} of {len(pairs)} pairs differ, first: {bad[0]}"
+
+
+def test_alignment_records_equal_mummer_delta_and_filter_files(eng, genome_dir, gold, tmp_path):
+    """Alignment level, on the GPU, through pg_anim_pair_alignments: for every fixture pair with both genomes the
+    engine's records ARE the records of nucmer's .delta file (coordinates and error counts, 505 in all) and the ones
+    flagged kept are exactly delta-filter -1's .filter file; the recovery file written from them gives pyani's own
+    parse_delta tuple (checked with the oracle restatement of anim.py:292-411)."""
+    from pyani_amd import anim
+    eng.clear_genomes()
+    ids, paths = {}, {}
+    for grp in ("blochmannia", "caulobacter"):
+        for stem, p in genome_dir[grp].items():
+            ids[stem] = eng.add_fasta(p)[0]
+            paths[stem] = p
+    n_records = n_pairs = 0
+    for grp in ("blochmannia", "caulobacter"):
+        for f in sorted((GOLD / "anim" / grp).glob("*.delta.gz")):
+            a, b = f.name[:-len(".delta.gz")].split("_vs_")
+            if a not in ids or b not in ids:
+                continue
+            rrec, qrec = anim.fasta_records(paths[a]), anim.fasta_records(paths[b])
+            al = eng.anim_pair_alignments(ids[a], ids[b])
+            mine = {(rrec[int(x["ref_rec"])][0], qrec[int(x["qry_rec"])][0], int(x["rs"]), int(x["re"]), int(x["qs"]), int(x["qe"]),
+                     int(x["errors"])) for x in al}
+            kept = {(rrec[int(x["ref_rec"])][0], qrec[int(x["qry_rec"])][0], int(x["rs"]), int(x["re"]), int(x["qs"]), int(x["qe"]),
+                     int(x["errors"])) for x in al if int(x["kept"]) == 3}
+            want = {(x.ref_id, x.qry_id, x.rs, x.re, x.qs, x.qe, x.errors) for x in anim_oracle.read_delta(f)[0]}
+            want_f = {(x.ref_id, x.qry_id, x.rs, x.re, x.qs, x.qe, x.errors)
+                      for x in anim_oracle.read_delta(str(f).replace(".delta.gz", ".filter.gz"))[0]}
+            assert mine == want, (f.name, sorted(mine ^ want)[:4])
+            assert kept == want_f, (f.name, sorted(kept ^ want_f)[:4])
+            out = tmp_path / f"{a}_vs_{b}.filter"
+            assert anim.write_delta(out, paths[a], paths[b], al, filtered=True) == len(want_f)
+            assert list(anim_oracle.parse_delta(out)) == gold[f"{grp}/{a}_vs_{b}.filter"]
+            n_records += len(want)
+            n_pairs += 1
+    assert (n_pairs, n_records) == (17, 505)
