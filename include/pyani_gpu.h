@@ -51,6 +51,11 @@ int pg_sync(pg_ctx* ctx);
 int pg_add_genome(pg_ctx* ctx, const uint8_t* seq, const uint64_t* rec_off, uint32_t n_rec, int32_t* genome_id_out);
 /* Same, reading a FASTA file (records = '>' blocks; whitespace inside sequence lines removed). */
 int pg_add_fasta(pg_ctx* ctx, const char* path, int32_t* genome_id_out, uint64_t* total_len_out, uint32_t* n_rec_out);
+/* Many files at once: read + parse + pack on `threads` host threads (0 = all hardware threads); ids are assigned in
+ * input order.  Replaces the per-file Bio.SeqIO loops of pyani_files.get_sequence_lengths (pyani_files.py:128-142) and
+ * tetra.calculate_tetra_zscores (tetra.py:66-74) on the ingest side.  Any of the three output arrays may be NULL. */
+int pg_add_fasta_batch(pg_ctx* ctx, const char* const* paths, uint32_t n, uint32_t threads, int32_t* genome_ids_out,
+                       uint64_t* total_len_out, uint32_t* n_rec_out);
 int pg_genome_count(const pg_ctx* ctx);
 int pg_genome_length(const pg_ctx* ctx, int32_t genome_id, uint64_t* total_len_out, uint32_t* n_rec_out);
 /* Drop all genomes (device arena is kept for reuse). */

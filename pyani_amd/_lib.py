@@ -20,6 +20,7 @@ SIGNATURES = {
     "pg_sync": (_int, [_vp]),
     "pg_add_genome": (_int, [_vp, _vp, _vp, _u32, _P(_i32)]),
     "pg_add_fasta": (_int, [_vp, ctypes.c_char_p, _P(_i32), _P(_u64), _P(_u32)]),
+    "pg_add_fasta_batch": (_int, [_vp, _vp, _u32, _u32, _vp, _vp, _vp]),
     "pg_genome_count": (_int, [_vp]),
     "pg_genome_length": (_int, [_vp, _i32, _P(_u64), _P(_u32)]),
     "pg_clear_genomes": (_int, [_vp]),

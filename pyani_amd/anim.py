@@ -93,8 +93,7 @@ def calculate_anim_pairs(infiles: Iterable, engine: Engine = None, nofilter: boo
     files = sorted(Path(f) for f in infiles)
     scratch_store = eng.genome_count() == 0
     ids, lengths = {}, {}
-    for f in files:
-        gid, total, _ = eng.add_fasta(f)
+    for f, (gid, total, _) in zip(files, eng.add_fasta_batch(files)):
         ids[f.stem], lengths[f.stem] = gid, total
     stems = [f.stem for f in files]
     pairs = [(a, b) for a in stems for b in stems if a != b]

@@ -93,27 +93,52 @@ __device__ __forceinline__ uint32_t seed_group(uint32_t h) { return h >> (32 - S
 // left-maximality test of a hit needs no memory access at all.
 // pass 0 counts into cnt[], pass 1 writes at goff[] + cursor (cnt[] re-zeroed in between by anim_list_scan_kernel).
 constexpr uint64_t SEED_KEY_SHIFT = 43;
-__global__ __launch_bounds__(256) void anim_list_kernel(const uint32_t* __restrict__ codes, const uint32_t* __restrict__ mask,
-                                                        int32_t len, int role, uint32_t* __restrict__ cnt,
-                                                        const uint32_t* __restrict__ goff, uint64_t* __restrict__ list, int pass) {
-  const int32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+constexpr int LIST_BLOCK = 1024, LIST_CHUNK = 16384;   // positions (or sampled positions) per workgroup
+__global__ __launch_bounds__(LIST_BLOCK) void anim_list_kernel(const uint32_t* __restrict__ codes, const uint32_t* __restrict__ mask,
+                                                               int32_t len, int role, uint32_t* __restrict__ cnt,
+                                                               const uint32_t* __restrict__ goff, uint64_t* __restrict__ list, int pass) {
+  // Sub-list counters are kept per workgroup in LDS; the global counters see one atomic per (workgroup, non-empty
+  // sub-list) instead of one per k-mer.  pass 1 counts again, reserves a range per sub-list, then writes.
+  __shared__ uint32_t s_cnt[2 * SEED_GROUPS];
   const int32_t strand = role ? (int32_t)blockIdx.y : 0;
-  const int32_t p = role ? idx * SEED_STEP : idx;
-  if (p + SEED_K > len) return;
-  uint32_t k;
-  if (!seed_kmer(codes, mask, len, strand, p, k)) return;
-  const uint32_t h = seed_hash(k);
-  const uint32_t g = seed_group(h);
-  const uint32_t sub = role ? 2 * g + (uint32_t)strand : g;
-  const uint32_t at = atomicAdd(&cnt[sub], 1u);
-  if (!pass) return;
-  const StrandView V{SeqView{codes, mask, len}, strand};
-  uint64_t left = 0, flag = 1;
-  for (int j = 1; j <= SEED_STEP; ++j) {
-    if (!V.clean(p - j)) { flag = 0; left = 0; break; }
-    left |= (uint64_t)V.base(p - j) << (2 * (j - 1));
+  const uint32_t n_sub = role ? 2 * SEED_GROUPS : SEED_GROUPS;
+  const int32_t idx0 = blockIdx.x * LIST_CHUNK;
+  for (uint32_t i = threadIdx.x; i < n_sub; i += LIST_BLOCK) s_cnt[i] = 0;
+  __syncthreads();
+  auto kmer_of = [&](int32_t idx, uint32_t& h, int32_t& p) -> bool {
+    p = role ? idx * SEED_STEP : idx;
+    if (p + SEED_K > len) return false;
+    uint32_t k;
+    if (!seed_kmer(codes, mask, len, strand, p, k)) return false;
+    h = seed_hash(k);
+    return true;
+  };
+  auto sub_of = [&](uint32_t h) { const uint32_t g = seed_group(h); return role ? 2 * g + (uint32_t)strand : g; };
+  for (int32_t t = threadIdx.x; t < LIST_CHUNK; t += LIST_BLOCK) {
+    uint32_t h; int32_t p;
+    if (kmer_of(idx0 + t, h, p)) atomicAdd(&s_cnt[sub_of(h)], 1u);
   }
-  list[goff[sub] + at] = ((uint64_t)(h & 0x1FFFFFu) << SEED_KEY_SHIFT) | (left << 33) | (flag << 32) | (uint32_t)p;
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < n_sub; i += LIST_BLOCK) {
+    const uint32_t c = s_cnt[i];
+    uint32_t base = 0;
+    if (c) base = atomicAdd(&cnt[i], c);
+    s_cnt[i] = pass ? goff[i] + base : 0;   // pass 1: this workgroup's write cursor in sub-list i
+  }
+  if (!pass) return;
+  __syncthreads();
+  const StrandView V{SeqView{codes, mask, len}, strand};
+  for (int32_t t = threadIdx.x; t < LIST_CHUNK; t += LIST_BLOCK) {
+    uint32_t h; int32_t p;
+    if (!kmer_of(idx0 + t, h, p)) continue;
+    const uint32_t at = atomicAdd(&s_cnt[sub_of(h)], 1u);
+    uint64_t left = 0, flag = 1;
+    for (int j = 1; j <= SEED_STEP; ++j) {
+      if (!V.clean(p - j)) { flag = 0; left = 0; break; }
+      left |= (uint64_t)V.base(p - j) << (2 * (j - 1));
+    }
+    list[at] = ((uint64_t)(h & 0x1FFFFFu) << SEED_KEY_SHIFT) | (left << 33) | (flag << 32) | (uint32_t)p;
+  }
 }
 
 // goff[0..n] = exclusive prefix of cnt[0..n), goff[n + 1] = max(cnt); cnt re-zeroed.  One wave; n is 2048 or 4096.
@@ -507,7 +532,7 @@ __global__ __launch_bounds__(64) void anim_cluster_wave_kernel(const RefDesc* __
                                                                Match* __restrict__ mem, const uint32_t* __restrict__ mem_count,
                                                                int32_t* __restrict__ iscratch, ClusterOut O) {
   __shared__ uint32_t hist[256];
-  constexpr int WALK_CHUNK = 4096;
+  constexpr int WALK_CHUNK = 1024;   // 4 KiB: keeps 32 one-wave workgroups per CU
   __shared__ int32_t s_from[WALK_CHUNK];
   const uint32_t u = blockIdx.x;
   const int lane = threadIdx.x & 63;
@@ -764,7 +789,7 @@ __global__ __launch_bounds__(64) void anim_cluster_wave_kernel(const RefDesc* __
         chains[n_chains] = c;
       }
       // Walk the best chain backwards (from[k] < k always) and tag its members from[k] = -3 - (slot in cm), or -2 if
-      // the chain is dropped.  The pointer chase runs in LDS: from[] is staged 4096 entries at a time, high to low.
+      // the chain is dropped.  The pointer chase runs in LDS: from[] is staged WALK_CHUNK entries at a time, high to low.
       {
         int k = best_k, pos = n_cm + cnt;
         for (int chunk = (best_k / WALK_CHUNK) * WALK_CHUNK; chunk >= 0 && k >= 0; chunk -= WALK_CHUNK) {
@@ -1054,6 +1079,12 @@ __device__ int32_t gap_errors_wave(const SeqView& R, const StrandView& Q, int64_
   int32_t kq = n < m ? n : m, err = (n > m ? n - m : m - n);
   for (int32_t t = 0; t < kq; ++t) err += (R.clean(r0 + t) && Q.clean(q0 + t) && R.base(r0 + t) == Q.base(q0 + t)) ? 0 : 1;
   return err;
+}
+
+// work list entries (unit, chain) of unit u at wl[choff[u] .. choff[u+1])
+__global__ __launch_bounds__(64) void anim_wl_kernel(const uint32_t* __restrict__ choff, uint2* __restrict__ wl) {
+  const uint32_t u = blockIdx.x, b = choff[u], n = choff[u + 1] - b;
+  for (uint32_t c = threadIdx.x; c < n; c += 64) wl[b + c] = make_uint2(u, c);
 }
 
 // ---- A4a: gaps between the chained matches ---------------------------------------------------------------------------
@@ -1450,12 +1481,12 @@ static int anim_ensure_lists(pg_ctx* ctx, AnimScratch* A, const std::vector<int3
       const uint32_t* codes = ctx->d_codes + G.arena_start / 16;
       const uint32_t* mask = ctx->d_mask + G.arena_start / 32;
       const int32_t n_idx = role ? len / SEED_STEP + 1 : len;
-      const dim3 grid((uint32_t)(n_idx + 255) / 256, role ? 2 : 1);
+      const dim3 grid((uint32_t)(n_idx + LIST_CHUNK - 1) / LIST_CHUNK, role ? 2 : 1);
       PG_HIP(ctx, hipMemsetAsync(A->list_cnt, 0, (size_t)n_sub * 4, ctx->stream));
-      hipLaunchKernelGGL(anim_list_kernel, grid, dim3(256), 0, ctx->stream, codes, mask, len, role, A->list_cnt,
+      hipLaunchKernelGGL(anim_list_kernel, grid, dim3(LIST_BLOCK), 0, ctx->stream, codes, mask, len, role, A->list_cnt,
                          (const uint32_t*)nullptr, (uint64_t*)nullptr, 0);
       hipLaunchKernelGGL(anim_list_scan_kernel, dim3(1), dim3(64), 0, ctx->stream, A->list_cnt, goff, n_sub);
-      hipLaunchKernelGGL(anim_list_kernel, grid, dim3(256), 0, ctx->stream, codes, mask, len, role, A->list_cnt,
+      hipLaunchKernelGGL(anim_list_kernel, grid, dim3(LIST_BLOCK), 0, ctx->stream, codes, mask, len, role, A->list_cnt,
                          (const uint32_t*)goff, list, 1);
       if (!role) fresh_refs.push_back(gid);
     }
@@ -1588,7 +1619,7 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
     lds_attr_set = true;
   }
   if (!A->seedbuf) {
-    A->seed_cap = (size_t)1 << 26;   // 1 GiB to start with; grows on overflow
+    A->seed_cap = (size_t)max_matches + 1024;   // the whole batch budget (2.4 GB by default): no overflow re-runs
     if ((rc = regrow(ctx, A->seedbuf, A->seed_cap))) return rc;
     if ((rc = regrow(ctx, A->seed_total, 1))) return rc;
   }
@@ -1663,20 +1694,24 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
   std::vector<int32_t> nch(n_units);
   PG_HIP(ctx, hipMemcpyAsync(nch.data(), A->nch, n_units * 4, hipMemcpyDeviceToHost, ctx->stream));
   PG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  std::vector<uint2> wl;
-  for (uint32_t u = 0; u < n_units; ++u)
-    for (int32_t c = 0; c < nch[u]; ++c) wl.push_back(make_uint2(u, (uint32_t)c));
-  if (!wl.empty()) {
-    if (wl.size() > A->wl) { if ((rc = regrow(ctx, A->wl_d, wl.size() + wl.size() / 2))) return rc; A->wl = wl.size() + wl.size() / 2; }
-    PG_HIP(ctx, hipMemcpyAsync(A->wl_d, wl.data(), wl.size() * sizeof(uint2), hipMemcpyHostToDevice, ctx->stream));
+  // (unit, chain) work list, one wave each: offsets by a host prefix over the per-unit chain counts, entries on device
+  std::vector<uint32_t> choff((size_t)n_units + 1, 0);
+  for (uint32_t u = 0; u < n_units; ++u) choff[u + 1] = choff[u] + (uint32_t)nch[u];
+  const size_t n_wl = choff[n_units];
+  if (n_wl) {
+    if (n_wl > A->wl) { if ((rc = regrow(ctx, A->wl_d, n_wl + n_wl / 2))) return rc; A->wl = n_wl + n_wl / 2; }
+    // moff is not needed by the seed stage any more: its device copy stays, the chain offsets go to seedbuf's head
+    uint32_t* choff_d = reinterpret_cast<uint32_t*>(A->seedbuf);
+    PG_HIP(ctx, hipMemcpyAsync(choff_d, choff.data(), choff.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(anim_wl_kernel, dim3(n_units), dim3(64), 0, ctx->stream, choff_d, A->wl_d);
     if (M > A->tasks) { if ((rc = regrow(ctx, A->tasks_d, M))) return rc; A->tasks = M; }
     PG_HIP(ctx, hipMemsetAsync(A->seed_total, 0, 4, ctx->stream));   // reused as the gap-task counter
-    hipLaunchKernelGGL(anim_gaps_kernel, dim3((uint32_t)wl.size()), dim3(64), 0, ctx->stream, A->refs_d, A->units_d, O, A->wl_d,
+    hipLaunchKernelGGL(anim_gaps_kernel, dim3((uint32_t)n_wl), dim3(64), 0, ctx->stream, A->refs_d, A->units_d, O, A->wl_d,
                        A->fw, A->tasks_d, A->seed_total);
     hipLaunchKernelGGL(anim_gapdp_kernel, dim3((uint32_t)ctx->num_cu * 32u), dim3(64), 0, ctx->stream, A->refs_d, A->units_d, O,
                        A->tasks_d, A->seed_total, A->fw);
     for (int phase = 0; phase < 2; ++phase)
-      hipLaunchKernelGGL(anim_extend_kernel, dim3((uint32_t)wl.size()), dim3(64), 0, ctx->stream, A->refs_d, A->units_d, O,
+      hipLaunchKernelGGL(anim_extend_kernel, dim3((uint32_t)n_wl), dim3(64), 0, ctx->stream, A->refs_d, A->units_d, O,
                          A->wl_d, A->fw, A->bw, phase);
   }
   hipLaunchKernelGGL(anim_finish_kernel, dim3(n_pairs), dim3(64), 0, ctx->stream, A->refs_d, A->units_d, n_pairs,

@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <atomic>
 #include <thread>
 
 #include "pg_internal.h"
@@ -370,6 +371,53 @@ int pg_add_fasta(pg_ctx* ctx, const char* path, int32_t* genome_id_out, uint64_t
   if (total_len_out) *total_len_out = g.total_len;
   if (n_rec_out) *n_rec_out = n_rec;
   return add_packed(ctx, std::move(g), genome_id_out);
+}
+
+// Host ingest: read + parse + 2-bit pack of many FASTA files on `threads` host threads; genome ids are
+// assigned in input order whatever the completion order.  On error nothing is added.
+int pg_add_fasta_batch(pg_ctx* ctx, const char* const* paths, uint32_t n, uint32_t threads, int32_t* genome_ids_out,
+                       uint64_t* total_len_out, uint32_t* n_rec_out) {
+  if (!ctx || (n && !paths)) return pg_fail(ctx, PG_E_ARG, "bad argument");
+  for (uint32_t i = 0; i < n; ++i) if (!paths[i]) return pg_fail(ctx, PG_E_ARG, "bad argument");
+  if (threads == 0) threads = std::thread::hardware_concurrency();
+  if (threads == 0) threads = 1;
+  if (threads > n) threads = n ? n : 1;
+  std::vector<PgGenome> packed(n);
+  std::vector<int> status(n, PG_OK);
+  std::vector<uint32_t> nrec(n, 0);
+  std::atomic<uint32_t> next{0};
+  auto worker = [&]() {
+    std::vector<uint8_t> txt, seq;
+    std::vector<uint64_t> off;
+    for (;;) {
+      const uint32_t i = next.fetch_add(1);
+      if (i >= n) break;
+      txt.clear(); seq.clear(); off.clear();
+      if (read_file(paths[i], txt) != 0) { status[i] = PG_E_IO; continue; }
+      parse_fasta(txt, seq, off);
+      const uint64_t zero_off[1] = {0};
+      nrec[i] = off.empty() ? 0 : (uint32_t)off.size() - 1;
+      status[i] = pack_genome(seq.data(), off.empty() ? zero_off : off.data(), nrec[i], packed[i]);
+    }
+  };
+  std::vector<std::thread> pool;
+  for (uint32_t t = 1; t < threads; ++t) pool.emplace_back(worker);
+  worker();
+  for (auto& th : pool) th.join();
+  for (uint32_t i = 0; i < n; ++i) {
+    if (status[i] == PG_E_IO) return pg_fail(ctx, PG_E_IO, std::string("cannot read ") + paths[i]);
+    if (status[i] == PG_E_RNA) return pg_fail(ctx, PG_E_RNA, std::string(paths[i]) + ": sequence contains U/u (RNA), unsupported");
+    if (status[i] != PG_OK) return pg_fail(ctx, status[i], std::string(paths[i]) + ": cannot pack");
+  }
+  for (uint32_t i = 0; i < n; ++i) {
+    if (total_len_out) total_len_out[i] = packed[i].total_len;
+    if (n_rec_out) n_rec_out[i] = nrec[i];
+    int32_t id = -1;
+    const int rc = add_packed(ctx, std::move(packed[i]), &id);
+    if (rc != PG_OK) return rc;
+    if (genome_ids_out) genome_ids_out[i] = id;
+  }
+  return PG_OK;
 }
 
 int pg_genome_count(const pg_ctx* ctx) { return ctx ? (int)ctx->genomes.size() : PG_E_ARG; }

@@ -69,6 +69,16 @@ class Engine:
                                           ctypes.byref(nrec)))
         return gid.value, tot.value, nrec.value
 
+    def add_fasta_batch(self, paths, threads: int = 0) -> List[Tuple[int, int, int]]:
+        """Multithreaded ingest of many files; returns [(genome id, total length, number of records)] in input order."""
+        paths = [str(p).encode() for p in paths]
+        n = len(paths)
+        arr = (ctypes.c_char_p * n)(*paths)
+        ids = np.zeros(n, dtype=np.int32); tot = np.zeros(n, dtype=np.uint64); nrec = np.zeros(n, dtype=np.uint32)
+        self._check(self.lib.pg_add_fasta_batch(self._h, ctypes.cast(arr, ctypes.c_void_p), n, int(threads), ids.ctypes.data,
+                                                tot.ctypes.data, nrec.ctypes.data))
+        return [(int(i), int(t), int(r)) for i, t, r in zip(ids, tot, nrec)]
+
     def genome_count(self) -> int:
         return self.lib.pg_genome_count(self._h)
 

@@ -40,7 +40,7 @@ def calculate_tetra_zscores(infilenames: Iterable, engine: Engine = None) -> Dic
     eng = engine or default_engine()
     files = [Path(f) for f in infilenames]
     scratch_store = eng.genome_count() == 0
-    ids = [eng.add_fasta(f)[0] for f in files]
+    ids = [g for g, _, _ in eng.add_fasta_batch(files)]   # multithreaded read + parse + pack
     z, present, _ = eng.tetra_matrix(ids, want_corr=False)
     if scratch_store:
         eng.clear_genomes()
@@ -91,7 +91,7 @@ def calculate_tetra(infiles: Iterable, engine: Engine = None) -> pd.DataFrame:
     stems = [f.stem for f in files]
     order = sorted(range(len(files)), key=lambda k: stems[k])
     scratch_store = eng.genome_count() == 0
-    ids = [eng.add_fasta(files[k])[0] for k in order]
+    ids = [g for g, _, _ in eng.add_fasta_batch([files[k] for k in order])]
     labels = [stems[k] for k in order]
     try:
         _, _, corr = eng.tetra_matrix(ids, want_corr=True)

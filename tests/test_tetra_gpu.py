@@ -202,3 +202,24 @@ def test_full_size_properties(eng):
     z, present, corr = eng.tetra_matrix(ids)
     assert present.all()
     assert (corr == corr.T).all() and (np.diag(corr) == 1.0).all() and (np.abs(corr) <= 1.0).all()
+
+
+def test_batch_ingest_equals_per_file_ingest(eng, genome_dir):
+    """pg_add_fasta_batch (multithreaded read + parse + pack): same ids order, lengths, record counts and counts as the
+    per-file path; a missing file fails the whole call and adds nothing."""
+    from pyani_amd._lib import PyaniGpuError
+    files = list(genome_dir["blochmannia"].values()) + list(genome_dir["edge"].values())
+    eng.clear_genomes()
+    one = [eng.add_fasta(f) for f in files]
+    c_one = eng.tetra_counts([g for g, _, _ in one])
+    eng.clear_genomes()
+    many = eng.add_fasta_batch(files, threads=5)
+    assert [(t, r) for _, t, r in many] == [(t, r) for _, t, r in one]
+    assert [g for g, _, _ in many] == list(range(len(files)))
+    c_many = eng.tetra_counts([g for g, _, _ in many])
+    for a, b in zip(c_one, c_many):
+        assert np.array_equal(a, b)
+    n0 = eng.genome_count()
+    with pytest.raises(PyaniGpuError):
+        eng.add_fasta_batch([files[0], "/nonexistent/x.fna"])
+    assert eng.genome_count() == n0
