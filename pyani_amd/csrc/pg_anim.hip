@@ -399,6 +399,20 @@ __device__ __forceinline__ long long wave_max64(long long v) {
   }
   return v;
 }
+// Wave-wide max / min of a 32-bit value through DPP (no LDS crossbar: a handful of cycles instead of six dependent
+// ds_bpermute round trips).  Every lane gets the result.
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+#define PG_DPP_MAX(ctrl, rmask) { const uint32_t t_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, rmask, 0xf, false); v = t_ > v ? t_ : v; }
+  PG_DPP_MAX(0xB1, 0xf)    // quad_perm [1,0,3,2]
+  PG_DPP_MAX(0x4E, 0xf)    // quad_perm [2,3,0,1]
+  PG_DPP_MAX(0x141, 0xf)   // row_half_mirror
+  PG_DPP_MAX(0x140, 0xf)   // row_mirror: every lane of a row holds the row's max
+  PG_DPP_MAX(0x142, 0xa)   // row_bcast15 into rows 1 and 3
+  PG_DPP_MAX(0x143, 0xc)   // row_bcast31 into rows 2 and 3: lane 63 holds the wave's max
+#undef PG_DPP_MAX
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) { return ~wave_max_u32(~v); }
 
 // =====================================================================================================================
 // A3, wave-cooperative: one WAVE per (pair, strand) unit.  Same results as the scalar statement (pga::mum_filter +
@@ -411,30 +425,29 @@ __device__ __forceinline__ uint64_t lanemask_lt() { return (1ull << (threadIdx.x
 // stores, which a __syncthreads() of a one-wave workgroup would do (s_waitcnt vmcnt(0): ~1-2 us per use).
 __device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
-// Stable LSD radix sort of (key, val) pairs by `passes` 8-bit digits.  Result ends in (k0, v0) if passes is even,
-// else in (k1, v1).  hist: 256 words of LDS.  Global loads are issued four 64-element rows ahead of their use.
-__device__ void wave_radix_sort(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1, int n, int passes, uint32_t* hist) {
+// Stable LSD radix sort of packed (key << 32 | val) words by `passes` 8-bit digits of the key.  Returns the buffer that
+// holds the result (a or b).  One 8-byte scattered store per element and pass; a pass whose digit is the same for
+// every element moves nothing; global loads are issued four 64-element rows ahead of their use.  hist: 256 words of LDS.
+__device__ uint64_t* wave_radix_sort(uint64_t* a, uint64_t* b, int n, int passes, uint32_t* hist) {
   const int lane = threadIdx.x & 63;
   constexpr int U = 4;
+  uint64_t *src = a, *dst = b;
   for (int pass = 0; pass < passes; ++pass) {
-    const int shift = 8 * pass;
-    const uint32_t* ki = (pass & 1) ? k1 : k0;
-    const uint32_t* vi = (pass & 1) ? v1 : v0;
-    uint32_t* ko = (pass & 1) ? k0 : k1;
-    uint32_t* vo = (pass & 1) ? v0 : v1;
+    const int shift = 32 + 8 * pass;
     __syncthreads();   // the previous pass's (or the caller's) global stores have landed
-    for (int b = lane; b < 256; b += 64) hist[b] = 0;
+    for (int i = lane; i < 256; i += 64) hist[i] = 0;
     wave_lds_fence();
     for (int base = 0; base < n; base += 64 * U) {
-      uint32_t kk[U];
+      uint64_t kk[U];
 #pragma unroll
-      for (int t = 0; t < U; ++t) { const int i = base + 64 * t + lane; kk[t] = i < n ? ki[i] : 0u; }
+      for (int t = 0; t < U; ++t) { const int i = base + 64 * t + lane; kk[t] = i < n ? src[i] : 0ull; }
 #pragma unroll
-      for (int t = 0; t < U; ++t) if (base + 64 * t + lane < n) atomicAdd(&hist[(kk[t] >> shift) & 255u], 1u);
+      for (int t = 0; t < U; ++t) if (base + 64 * t + lane < n) atomicAdd(&hist[(uint32_t)(kk[t] >> shift) & 255u], 1u);
     }
     wave_lds_fence();
+    uint32_t c0 = hist[4 * lane], c1 = hist[4 * lane + 1], c2 = hist[4 * lane + 2], c3 = hist[4 * lane + 3];
+    if (__any(c0 == (uint32_t)n || c1 == (uint32_t)n || c2 == (uint32_t)n || c3 == (uint32_t)n)) continue;   // constant digit
     {  // exclusive scan of the 256 bins: 4 bins per lane
-      uint32_t c0 = hist[4 * lane], c1 = hist[4 * lane + 1], c2 = hist[4 * lane + 2], c3 = hist[4 * lane + 3];
       const uint32_t tot = c0 + c1 + c2 + c3;
       uint32_t incl = tot;
 #pragma unroll
@@ -448,22 +461,18 @@ __device__ void wave_radix_sort(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32
     }
     wave_lds_fence();
     for (int base = 0; base < n; base += 64 * U) {
-      uint32_t kk[U], vv[U];
+      uint64_t kk[U];
 #pragma unroll
-      for (int t = 0; t < U; ++t) {
-        const int i = base + 64 * t + lane;
-        kk[t] = i < n ? ki[i] : 0u;
-        vv[t] = i < n ? vi[i] : 0u;
-      }
+      for (int t = 0; t < U; ++t) { const int i = base + 64 * t + lane; kk[t] = i < n ? src[i] : 0ull; }
 #pragma unroll
       for (int t = 0; t < U; ++t) {   // rows in order: the sort is stable
         const bool act = base + 64 * t + lane < n;
-        const uint32_t d = (kk[t] >> shift) & 255u;
+        const uint32_t d = (uint32_t)(kk[t] >> shift) & 255u;
         uint64_t peers = __ballot(act);
 #pragma unroll
-        for (int b = 0; b < 8; ++b) {
-          const uint64_t vote = __ballot((d >> b) & 1u);
-          peers &= ((d >> b) & 1u) ? vote : ~vote;
+        for (int bb = 0; bb < 8; ++bb) {
+          const uint64_t vote = __ballot((d >> bb) & 1u);
+          peers &= ((d >> bb) & 1u) ? vote : ~vote;
         }
         const uint32_t rank = (uint32_t)__popcll(peers & lanemask_lt());
         uint32_t pos = 0;
@@ -471,22 +480,24 @@ __device__ void wave_radix_sort(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32
         wave_lds_fence();   // every lane has read its bin before the bin's first lane advances it
         if (act && rank == 0) hist[d] += (uint32_t)__popcll(peers);
         wave_lds_fence();
-        if (act) { ko[pos] = kk[t]; vo[pos] = vv[t]; }
+        if (act) dst[pos] = kk[t];
       }
     }
+    uint64_t* tmp = src; src = dst; dst = tmp;
   }
   __syncthreads();
+  return src;
 }
 
 // containment flags over elements in sorted order (ascending start, ties: longer first): flag[idx] |= 1 if an earlier
 // element reaches at least as far, or if the next element has the same start and length.
-__device__ void wave_containment_flags(const uint32_t* order, const int32_t* start, const int32_t* len, int n, int32_t* flag) {
+__device__ void wave_containment_flags(const uint64_t* order, const int32_t* start, const int32_t* len, int n, int32_t* flag) {
   const int lane = threadIdx.x & 63;
   int32_t carry = -1;
   for (int base = 0; base < n; base += 64) {
     const int t = base + lane;
     const bool act = t < n;
-    const uint32_t idx = act ? order[t] : 0u;
+    const uint32_t idx = act ? (uint32_t)order[t] : 0u;
     const int32_t st = act ? start[idx] : 0, ln = act ? len[idx] : 0;
     const int32_t e = act ? st + ln : -1;
     int32_t incl = e;
@@ -497,7 +508,7 @@ __device__ void wave_containment_flags(const uint32_t* order, const int32_t* sta
     const int32_t prevmax = excl > carry ? excl : carry;
     if (act) {
       bool f = e <= prevmax;
-      if (!f && t + 1 < n) { const uint32_t nx = order[t + 1]; f = start[nx] == st && len[nx] == ln; }
+      if (!f && t + 1 < n) { const uint32_t nx = (uint32_t)order[t + 1]; f = start[nx] == st && len[nx] == ln; }
       if (f) flag[idx] = 1;
     }
     const int32_t last = __shfl(incl, 63, 64);
@@ -506,10 +517,13 @@ __device__ void wave_containment_flags(const uint32_t* order, const int32_t* sta
 }
 
 __device__ __forceinline__ int uf_find(int32_t* parent, int x) {
-  for (;;) {
+  for (;;) {   // with path halving: links only ever move to an ancestor (a smaller index), so the races are benign
     const int p = parent[x];
     if (p == x) return x;
-    x = p;
+    const int gp = parent[p];
+    if (gp == p) return p;
+    parent[x] = gp;
+    x = gp;
   }
 }
 __device__ __forceinline__ void uf_union(int32_t* parent, int a, int b) {   // larger root -> smaller root (deterministic roots)
@@ -545,55 +559,56 @@ __global__ __launch_bounds__(64) void anim_cluster_wave_kernel(const RefDesc* __
   if (n0 == 0) { if (lane == 0) O.n_chains[u] = 0; return; }
   Match* m = mem + off;
   Match* cm = O.cm + off;
-  // scratch slices (7 x cap ints): a..g
-  int32_t* sa = iscratch + off * 7;
+  // scratch slices (8 x cap ints): a..h; (a,b) and (c,d) double as the two packed sort buffers
+  int32_t* sa = iscratch + off * 8;
   int32_t *sb = sa + cap, *sc = sa + 2 * (size_t)cap, *sd = sa + 3 * (size_t)cap, *se = sa + 4 * (size_t)cap,
-          *sf = sa + 5 * (size_t)cap, *sg = sa + 6 * (size_t)cap;
+          *sf = sa + 5 * (size_t)cap, *sg = sa + 6 * (size_t)cap, *sh = sa + 7 * (size_t)cap;
+  uint64_t *P0 = reinterpret_cast<uint64_t*>(sa), *P1 = reinterpret_cast<uint64_t*>(sc);
   const int n_in = (int)n0;
 #ifdef PGA_DP_STATS
   unsigned long long t_mark = __builtin_readcyclecounter();
   if (lane == 0) atomicMax(&g_cl_stats[12], (unsigned long long)n_in);
 #endif
   // ---- MUM filter -----------------------------------------------------------------------------------------------
-  // SoA copies: se = r, sf = q, sg = len; flags in sd
-  for (int i = lane; i < n_in; i += 64) { const Match t = m[i]; se[i] = t.r; sf[i] = t.q; sg[i] = t.len; sd[i] = 0; }
+  // SoA copies: se = r, sf = q, sg = len; flags in sh
+  for (int i = lane; i < n_in; i += 64) { const Match t = m[i]; se[i] = t.r; sf[i] = t.q; sg[i] = t.len; sh[i] = 0; }
   __syncthreads();
-  uint32_t *k0 = (uint32_t*)sa, *v0 = (uint32_t*)sb, *k1 = (uint32_t*)sc;
-  uint32_t* v1 = (uint32_t*)cm;   // cm is free until the chains are written (16 B per entry >= 4 B)
-  for (int side = 0; side < 2; ++side) {
-    const int32_t* start = side == 0 ? sf : se;   // query intervals first, then reference intervals
+  const int start_passes = (R.len > U.len ? R.len : U.len) < (1 << 24) ? 3 : 4;
+  const uint64_t* qsorted = nullptr;
+  for (int side = 1; side >= 0; --side) {
+    const int32_t* start = side == 0 ? sf : se;   // reference intervals first, then query intervals (whose order is reused)
     // sort by (start asc, len desc): LSD = len-desc key first, then start
-    for (int i = lane; i < n_in; i += 64) { const uint32_t l = (uint32_t)sg[i]; k0[i] = 0xFFFFFFu - (l > 0xFFFFFFu ? 0xFFFFFFu : l); v0[i] = (uint32_t)i; }
-    wave_radix_sort(k0, v0, k1, v1, n_in, 3, hist);            // result in (k1, v1)
-    for (int i = lane; i < n_in; i += 64) k1[i] = (uint32_t)start[v1[i]];
+    for (int i = lane; i < n_in; i += 64) {
+      const uint32_t l = (uint32_t)sg[i];
+      P0[i] = ((uint64_t)(0xFFFFFFu - (l > 0xFFFFFFu ? 0xFFFFFFu : l)) << 32) | (uint32_t)i;
+    }
+    uint64_t* r1 = wave_radix_sort(P0, P1, n_in, 3, hist);
+    for (int i = lane; i < n_in; i += 64) { const uint32_t idx = (uint32_t)r1[i]; r1[i] = ((uint64_t)(uint32_t)start[idx] << 32) | idx; }
+    uint64_t* r2 = wave_radix_sort(r1, r1 == P0 ? P1 : P0, n_in, start_passes, hist);
+    wave_containment_flags(r2, start, sg, n_in, sh);
     __syncthreads();
-    wave_radix_sort(k1, v1, k0, v0, n_in, 4, hist);            // 4 passes (even): result back in (k1, v1)
-    wave_containment_flags(v1, start, sg, n_in, sd);
-    __syncthreads();
+    qsorted = r2;
   }
-  // survivors in q order (distinct q among survivors): sort indices by q once more, compact
-  for (int i = lane; i < n_in; i += 64) { k0[i] = (uint32_t)sf[i]; v0[i] = (uint32_t)i; }
-  wave_radix_sort(k0, v0, k1, v1, n_in, 4, hist);              // result in (k0, v0)
+  // survivors in q order (distinct q among survivors): the query-side order is still there -> compact
   int n = 0;
   {
-    // compact into sb? v0 aliases sb; write survivors' Match into cm-temp is not possible (v1 lives there) -> use m itself
-    // two-step: first the survivor index list into k1 (sc), then gather through registers chunk by chunk into cm, copy back
+    uint32_t* keepidx = reinterpret_cast<uint32_t*>(qsorted == P0 ? P1 : P0);   // the other sort buffer is free
     for (int base = 0; base < n_in; base += 64) {
       const int t = base + lane;
-      const bool keep = t < n_in && sd[v0[t]] == 0;
-      const uint64_t b = __ballot(keep);
-      if (keep) k1[n + __popcll(b & lanemask_lt())] = v0[t];
-      n += (int)__popcll(b);
+      const uint32_t idx = t < n_in ? (uint32_t)qsorted[t] : 0u;
+      const bool keep = t < n_in && sh[idx] == 0;
+      const uint64_t bm = __ballot(keep);
+      if (keep) keepidx[n + __popcll(bm & lanemask_lt())] = idx;
+      n += (int)__popcll(bm);
     }
     __syncthreads();
-    for (int i = lane; i < n; i += 64) { const uint32_t idx = k1[i]; cm[i] = Match{se[idx], sf[idx], sg[idx], U.strand}; }
-    __syncthreads();
-    for (int i = lane; i < n; i += 64) m[i] = cm[i];
+    for (int i = lane; i < n; i += 64) { const uint32_t idx = keepidx[i]; m[i] = Match{se[idx], sf[idx], sg[idx], U.strand}; }
     __syncthreads();
   }
   CL_MARK(0);
   // ---- clustering (mgaps) ------------------------------------------------------------------------------------------
-  int32_t *rrec = sa, *qrec = sb, *parent = sc, *score = sd, *from = se, *adj = sf, *order = sg;
+  int32_t *rrec = sa, *qrec = sb, *parent = sc, *from = se, *adj = sf, *order = sh;
+  uint64_t *Q0 = reinterpret_cast<uint64_t*>(sd), *Q1 = reinterpret_cast<uint64_t*>(sf);   // (sd,se) and (sf,sg): sort buffers
   for (int i = lane; i < n; i += 64) {
     rrec[i] = record_of(R.rec_start, R.n_rec, m[i].r);
     const int32_t qf = U.strand ? U.len - 1 - m[i].q : m[i].q;
@@ -620,14 +635,11 @@ __global__ __launch_bounds__(64) void anim_cluster_wave_kernel(const RefDesc* __
   __syncthreads();
   CL_MARK(1);
   {  // group by root (stable: q order inside a cluster): radix sort of (root, index)
-    uint32_t *rk0 = (uint32_t*)score, *rv0 = (uint32_t*)from, *rk1 = (uint32_t*)adj, *rv1 = (uint32_t*)order;
-    for (int i = lane; i < n; i += 64) { rk0[i] = (uint32_t)uf_find(parent, i); rv0[i] = (uint32_t)i; }
+    for (int i = lane; i < n; i += 64) Q0[i] = ((uint64_t)(uint32_t)uf_find(parent, i) << 32) | (uint32_t)i;
     __syncthreads();
-    wave_radix_sort(rk0, rv0, rk1, rv1, n, 4, hist);           // result in (rk0, rv0) = (score, from) slices
-    for (int i = lane; i < n; i += 64) { parent[i] = (int32_t)rk0[i]; }   // parent[] now = root id of the i-th element in grouped order
-    __syncthreads();
-    for (int i = lane; i < n; i += 64) order[i] = (int32_t)rv0[i];
-    __syncthreads();
+    const uint64_t* rs_ = wave_radix_sort(Q0, Q1, n, 4, hist);
+    for (int i = lane; i < n; i += 64) { const uint64_t x = rs_[i]; parent[i] = (int32_t)(x >> 32); order[i] = (int32_t)(uint32_t)x; }
+    __syncthreads();   // parent[] now = root id of the i-th element in grouped order
   }
   CL_MARK(2);
   // ---- chain extraction per cluster ----------------------------------------------------------------------------------
@@ -653,7 +665,7 @@ __global__ __launch_bounds__(64) void anim_cluster_wave_kernel(const RefDesc* __
       int c0 = 0;
       bool general = false;
       while (c0 < 64 && g0 + c0 < n) {
-        const int32_t r0 = __shfl(root, c0, 64);
+        const int32_t r0 = __builtin_amdgcn_readlane(root, c0);
         const uint64_t diff = __ballot(root != r0) & ~((1ull << c0) - 1ull);
         const int c1 = diff ? __ffsll((long long)diff) - 1 : 64;
         if (c1 == 64 && g0 + 64 < n) { general = c0 == 0; break; }
@@ -664,7 +676,7 @@ __global__ __launch_bounds__(64) void anim_cluster_wave_kernel(const RefDesc* __
           uint64_t done = 0;
           for (uint64_t rem = L; rem; rem &= rem - 1) {
             const int k = __ffsll((long long)rem) - 1;
-            const int32_t mr = __shfl(mt.r, k, 64), mq = __shfl(mt.q, k, 64), ml = __shfl(mt.len, k, 64);
+            const int32_t mr = __builtin_amdgcn_readlane(mt.r, k), mq = __builtin_amdgcn_readlane(mt.q, k), ml = __builtin_amdgcn_readlane(mt.len, k);
             int32_t cand = NEG_INF, ol = 0;
             if ((done >> lane) & 1ull) {
               ol = mt.r + mt.len - mr;
@@ -676,20 +688,20 @@ __global__ __launch_bounds__(64) void anim_cluster_wave_kernel(const RefDesc* __
               cand = my_sc + ml - (ol + dd);
             }
             // best candidate: max cand, ties -> nearest predecessor (largest lane)
-            long long key = (((long long)cand + (1ll << 30)) << 8) | (long long)lane;
-            key = wave_max64(key);
-            const int32_t bc = (int32_t)((key >> 8) - (1ll << 30));
-            const int bl = (int)(key & 63);
+            // (chain scores are sums of match lengths: < 2^24; invalid candidates become key 0)
+            const uint32_t key = wave_max_u32(cand > NEG_INF / 2 ? ((uint32_t)(cand + (1 << 24)) << 6) | (uint32_t)lane : 0u);
+            const int32_t bc = key ? (int32_t)(key >> 6) - (1 << 24) : NEG_INF;
+            const int bl = (int)(key & 63u);
             int32_t sc_k = ml, fr_k = -1, ad_k = 0, tot_k = ml, cnt_k = 1;
             if (bc > sc_k) {
-              sc_k = bc; fr_k = bl; ad_k = __shfl(ol, bl, 64);
-              tot_k += __shfl(my_tot, bl, 64); cnt_k += __shfl(my_cnt, bl, 64);
+              sc_k = bc; fr_k = bl; ad_k = __builtin_amdgcn_readlane(ol, bl);
+              tot_k += __builtin_amdgcn_readlane(my_tot, bl); cnt_k += __builtin_amdgcn_readlane(my_cnt, bl);
             }
             if (lane == k) { my_sc = sc_k; my_from = fr_k; my_adj = ad_k; my_tot = tot_k; my_cnt = cnt_k; }
             if (sc_k > best_sc) { best_sc = sc_k; best_k = k; }
             done |= 1ull << k;
           }
-          const int32_t total = __shfl(my_tot, best_k, 64), cnt = __shfl(my_cnt, best_k, 64);
+          const int32_t total = __builtin_amdgcn_readlane(my_tot, best_k), cnt = __builtin_amdgcn_readlane(my_cnt, best_k);
           const bool emit = total >= MIN_CLUSTER && n_chains < (int)cap && n_cm + cnt <= (int)cap;
           uint64_t M = 0;
           int32_t my_pos = -1;
@@ -699,7 +711,7 @@ __global__ __launch_bounds__(64) void anim_cluster_wave_kernel(const RefDesc* __
               M |= 1ull << kk;
               --pos;
               if (lane == kk) my_pos = pos;
-              kk = __shfl(my_from, kk, 64);
+              kk = __builtin_amdgcn_readlane(my_from, kk);
             }
           }
           if (emit) {
@@ -722,6 +734,9 @@ __global__ __launch_bounds__(64) void anim_cluster_wave_kernel(const RefDesc* __
       if (!general) { g0 += c0; continue; }
     }
     // ---- general path: a cluster of more than 64 matches ----------------------------------------------------------------
+#ifdef PGA_DP_STATS
+    const unsigned long long t_gen = __builtin_readcyclecounter();
+#endif
     int g1 = g0 + 1;
     {  // cluster end: first position whose root differs (wave search)
       const int32_t root = parent[g0];
@@ -734,6 +749,9 @@ __global__ __launch_bounds__(64) void anim_cluster_wave_kernel(const RefDesc* __
     }
     int live = g1 - g0;
     while (live > 0) {
+#ifdef PGA_DP_STATS
+      if (lane == 0) { atomicAdd(&g_cl_stats[13], 1ull); atomicAdd(&g_cl_stats[14], (unsigned long long)live); }
+#endif
       // Chain DP over the live entries order[g0 .. g0+live), 64 at a time: the entries are gathered lane-parallel (one
       // round of global latency per 64), then handed out one by one through readlane.  Lane l's window registers hold
       // the entry at position k-1-l: start, length, best score, and the matched bases / members of the best chain
@@ -761,14 +779,13 @@ __global__ __launch_bounds__(64) void anim_cluster_wave_kernel(const RefDesc* __
             cand = wsc + ml - (ol + dd);
           }
           // best candidate: max cand, ties -> nearest predecessor (smallest lane)
-          long long key = (((long long)cand + (1ll << 30)) << 8) | (long long)(63 - lane);
-          key = wave_max64(key);
-          const int32_t bc = (int32_t)((key >> 8) - (1ll << 30));
-          const int bl = 63 - (int)(key & 63);
+          const uint32_t key = wave_max_u32(cand > NEG_INF / 2 ? ((uint32_t)(cand + (1 << 24)) << 6) | (uint32_t)(63 - lane) : 0u);
+          const int32_t bc = key ? (int32_t)(key >> 6) - (1 << 24) : NEG_INF;
+          const int bl = 63 - (int)(key & 63u);
           int32_t sc_k = ml, fr_k = -1, ad_k = 0, tot_k = ml, cnt_k = 1;
           if (bc > sc_k) {
-            sc_k = bc; fr_k = k - 1 - bl; ad_k = __shfl(ol, bl, 64);
-            tot_k += __shfl(wtot, bl, 64); cnt_k += __shfl(wcnt, bl, 64);
+            sc_k = bc; fr_k = k - 1 - bl; ad_k = __builtin_amdgcn_readlane(ol, bl);
+            tot_k += __builtin_amdgcn_readlane(wtot, bl); cnt_k += __builtin_amdgcn_readlane(wcnt, bl);
           }
           if (lane == t) { my_from = fr_k; my_adj = ad_k; }
           if (sc_k > best_sc) { best_sc = sc_k; best_k = k; best_tot = tot_k; best_cnt = cnt_k; }
@@ -832,17 +849,19 @@ __global__ __launch_bounds__(64) void anim_cluster_wave_kernel(const RefDesc* __
       live = kept;
     }
     g0 = g1;
+#ifdef PGA_DP_STATS
+    if (lane == 0) atomicAdd(&g_cl_stats[15], __builtin_readcyclecounter() - t_gen);
+#endif
   }
   CL_MARK(3);
   // ---- chains in reference order + neighbours ------------------------------------------------------------------------
   int32_t* co = O.order + off;
   {
-    uint32_t *ck0 = (uint32_t*)score, *cv0 = (uint32_t*)from, *ck1 = (uint32_t*)adj, *cv1 = (uint32_t*)order;
     __syncthreads();
-    for (int i = lane; i < n_chains; i += 64) { ck0[i] = (uint32_t)cm[chains[i].first].r; cv0[i] = (uint32_t)i; }
+    for (int i = lane; i < n_chains; i += 64) Q0[i] = ((uint64_t)(uint32_t)cm[chains[i].first].r << 32) | (uint32_t)i;
     __syncthreads();
-    wave_radix_sort(ck0, cv0, ck1, cv1, n_chains, 4, hist);    // result in (ck0, cv0)
-    for (int i = lane; i < n_chains; i += 64) co[i] = (int32_t)cv0[i];
+    const uint64_t* cs_ = wave_radix_sort(Q0, Q1, n_chains, 4, hist);
+    for (int i = lane; i < n_chains; i += 64) co[i] = (int32_t)(uint32_t)cs_[i];
     __threadfence_block();
     __syncthreads();
   }
@@ -974,12 +993,11 @@ __device__ ExtResult extend_wave(const SeqView& R, const StrandView& Q, int64_t 
       fimp = imp < fimp ? imp : fimp;
     }
     if ((d % CHECK) == 0 || d == d_end) {
-      const long long key = wave_max64((((long long)bs + BIAS) << 32) | (uint32_t)bd);  // max score, ties: larger d
-      const int32_t g = (int32_t)((key >> 32) - BIAS), t = (int32_t)(key & 0xFFFFFFFFll);
+      // max score, ties: larger d.  bs in [-32768, 32767], bd <= 2 * 9999: (bs + 32768) << 15 | bd fits 32 bits
+      const uint32_t key = wave_max_u32(((uint32_t)(bs + 32768) << 15) | (uint32_t)bd);
+      const int32_t g = (int32_t)(key >> 15) - 32768, t = (int32_t)(key & 32767u);
       const int32_t b = t_prev + BREAK_LEN;          // step at which the per-step rule (d - best_d >= BREAK_LEN) fires without an improvement
-      int32_t d1 = fimp;
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) { const int32_t v = __shfl_xor(d1, o, 64); d1 = v < d1 ? v : d1; }
+      const int32_t d1 = (int32_t)wave_min_u32((uint32_t)fimp);
       if (b <= d && d1 > b) {                        // it fired before the first improvement of this interval
         bs = sbs; bd = sbd; be = sbe;                // results as of the last check (nothing global changed until b)
         break;
@@ -1638,10 +1656,10 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
     uint64_t tot = 0, raw = 0;
     pairs_fit = 0;
     for (uint32_t p = 0; p < n_pairs; ++p) {
-      const uint64_t need = (uint64_t)cnt[2 * p] + cnt[2 * p + 1] + 2;   // +1 per unit: never a zero-size slice
+      const uint64_t need = (uint64_t)cnt[2 * p] + cnt[2 * p + 1] + 4;   // per unit: count + 1 (never empty), rounded up to even
       if (p > 0 && tot + need > max_matches) break;
       tot += need;
-      raw += need - 2;
+      raw += need - 4;
       pairs_fit = p + 1;
     }
     n_pairs = pairs_fit;
@@ -1654,13 +1672,13 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
   }
   *n_done = n_pairs;
   moff.assign((size_t)n_units + 1, 0);
-  for (uint32_t u = 0; u < n_units; ++u) moff[u + 1] = moff[u] + cnt[u] + 1;
+  for (uint32_t u = 0; u < n_units; ++u) moff[u + 1] = moff[u] + ((cnt[u] + 2) & ~1u);   // even slice sizes: 8-byte aligned sub-slices
   const size_t M = moff[n_units];
   if (M > A->matches) {
     const size_t cap = M + M / 4;
     if ((rc = regrow(ctx, A->mem, cap))) return rc;
     if ((rc = regrow(ctx, A->cm, cap))) return rc;
-    if ((rc = regrow(ctx, A->iscratch, cap * 7))) return rc;
+    if ((rc = regrow(ctx, A->iscratch, cap * 8))) return rc;
     if ((rc = regrow(ctx, A->chains, cap))) return rc;
     if ((rc = regrow(ctx, A->order, cap))) return rc;
     if ((rc = regrow(ctx, A->prev, cap))) return rc;
@@ -1727,6 +1745,7 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
     PG_HIP(ctx, hipMemcpyFromSymbol(cl, HIP_SYMBOL(g_cl_stats), sizeof(cl)));
     fprintf(stderr, "[cluster-stats] phases mumfilter/unionfind/rootsort/chains/tail: sum cycles %llu %llu %llu %llu %llu  max %llu %llu %llu %llu %llu  max n_in %llu\n",
             cl[0], cl[1], cl[2], cl[3], cl[4], cl[6], cl[7], cl[8], cl[9], cl[10], cl[12]);
+    fprintf(stderr, "[cluster-stats] general-path rounds %llu, sum of live entries over rounds %llu, cycles in the general path %llu\n", cl[13], cl[14], cl[15]);
     const char* names[3] = {"gap", "fwd", "bwd"};
     for (int k = 0; k < 3; ++k) {
       fprintf(stderr, "[dp-stats] %s calls %llu steps %llu cycles %llu  hist(log2 steps):", names[k], st[k][0], st[k][1], st[k][2]);
