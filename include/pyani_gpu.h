@@ -128,6 +128,11 @@ typedef struct {
 int pg_anim_pairs(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_ids, uint64_t n_pairs, int maxmatch,
                   int filter_1to1, pg_anim_result* out);
 
+/* Work-memory budget of one internal launch of pg_anim_pairs: at most max_pairs ordered pairs and max_matches exact
+ * matches (about 230 bytes of device scratch each; default 16384 pairs / 150 Mi matches = ~36 GB).  Larger calls are
+ * split transparently; results do not depend on the split. */
+int pg_anim_set_batch_budget(pg_ctx* ctx, uint32_t max_pairs, uint64_t max_matches);
+
 /* The alignment records of ONE ordered pair: the content of the .delta file nucmer would write (kept == 3 marks the
  * records delta-filter -1 keeps, i.e. the .filter file), minus the indel offset lists, which parse_delta ignores
  * (anim.py:374-393) and this engine does not trace back.  Coordinates as in MUMmer's alignment header lines

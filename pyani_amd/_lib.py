@@ -36,6 +36,7 @@ SIGNATURES = {
     "pg_tetra_corr_rows_dev": (_int, [_vp, _vp, _vp, _u32, _u32, _u32, _vp]),
     "pg_anim_pairs": (_int, [_vp, _vp, _vp, _u64, _int, _int, _vp]),
     "pg_anim_reduce": (_int, [_vp, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _vp]),
+    "pg_anim_set_batch_budget": (_int, [_vp, _u32, ctypes.c_uint64]),
     "pg_anim_pair_alignments": (_int, [_vp, _i32, _i32, _vp, _u32, _P(_u32)]),
     "pg_anib_reduce": (_int, [_vp, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pg_profile_enable": (_int, [_vp, _int]),

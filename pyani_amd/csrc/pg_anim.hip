@@ -1436,7 +1436,7 @@ struct AnimScratch {
   int32_t* recs_d = nullptr;
   RefDesc* refs_d = nullptr;
   UnitDesc* units_d = nullptr;
-  uint32_t *mem_count = nullptr, *moff = nullptr;
+  uint32_t *mem_count = nullptr, *moff = nullptr, *choff_d = nullptr;
   int32_t *nch = nullptr, *status = nullptr;
   pg_anim_result* out = nullptr;
   // per-match arrays (sliced by moff)
@@ -1501,11 +1501,13 @@ static int anim_ensure_lists(pg_ctx* ctx, AnimScratch* A, const std::vector<int3
       const int32_t n_idx = role ? len / SEED_STEP + 1 : len;
       const dim3 grid((uint32_t)(n_idx + LIST_CHUNK - 1) / LIST_CHUNK, role ? 2 : 1);
       PG_HIP(ctx, hipMemsetAsync(A->list_cnt, 0, (size_t)n_sub * 4, ctx->stream));
-      hipLaunchKernelGGL(anim_list_kernel, grid, dim3(LIST_BLOCK), 0, ctx->stream, codes, mask, len, role, A->list_cnt,
-                         (const uint32_t*)nullptr, (uint64_t*)nullptr, 0);
+      if (grid.x)   // (an empty genome still gets its all-zero offset table from the scan)
+        hipLaunchKernelGGL(anim_list_kernel, grid, dim3(LIST_BLOCK), 0, ctx->stream, codes, mask, len, role, A->list_cnt,
+                           (const uint32_t*)nullptr, (uint64_t*)nullptr, 0);
       hipLaunchKernelGGL(anim_list_scan_kernel, dim3(1), dim3(64), 0, ctx->stream, A->list_cnt, goff, n_sub);
-      hipLaunchKernelGGL(anim_list_kernel, grid, dim3(LIST_BLOCK), 0, ctx->stream, codes, mask, len, role, A->list_cnt,
-                         (const uint32_t*)goff, list, 1);
+      if (grid.x)
+        hipLaunchKernelGGL(anim_list_kernel, grid, dim3(LIST_BLOCK), 0, ctx->stream, codes, mask, len, role, A->list_cnt,
+                           (const uint32_t*)goff, list, 1);
       if (!role) fresh_refs.push_back(gid);
     }
   }
@@ -1522,7 +1524,7 @@ void pg_anim_free_scratch(pg_ctx* ctx) {
   AnimScratch* A = static_cast<AnimScratch*>(ctx->anim_scratch);
   if (!A) return;
   pg_anim_drop_lists(ctx);
-  void* ptrs[] = {A->list_cnt, A->srefs_d, A->sqry_d, A->recs_d, A->refs_d, A->units_d, A->mem_count, A->moff, A->nch, A->status, A->out, A->mem, A->cm,
+  void* ptrs[] = {A->choff_d, A->list_cnt, A->srefs_d, A->sqry_d, A->recs_d, A->refs_d, A->units_d, A->mem_count, A->moff, A->nch, A->status, A->out, A->mem, A->cm,
                   A->iscratch, A->order, A->prev, A->next, A->alnof, A->chains, A->fw, A->bw, A->S.alns, A->S.a_rrec,
                   A->S.a_qrec, A->S.idx, A->S.from, A->S.sc, A->wl_d, A->seedbuf, A->seed_total, A->tasks_d};
   for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -1576,6 +1578,7 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
     if ((rc = regrow(ctx, A->units_d, n_units))) return rc;
     if ((rc = regrow(ctx, A->mem_count, n_units))) return rc;
     if ((rc = regrow(ctx, A->moff, (size_t)n_units + 1))) return rc;
+    if ((rc = regrow(ctx, A->choff_d, (size_t)n_units + 1))) return rc;
     if ((rc = regrow(ctx, A->nch, n_units))) return rc;
     A->units = n_units;
   }
@@ -1718,8 +1721,7 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
   const size_t n_wl = choff[n_units];
   if (n_wl) {
     if (n_wl > A->wl) { if ((rc = regrow(ctx, A->wl_d, n_wl + n_wl / 2))) return rc; A->wl = n_wl + n_wl / 2; }
-    // moff is not needed by the seed stage any more: its device copy stays, the chain offsets go to seedbuf's head
-    uint32_t* choff_d = reinterpret_cast<uint32_t*>(A->seedbuf);
+    uint32_t* choff_d = A->choff_d;
     PG_HIP(ctx, hipMemcpyAsync(choff_d, choff.data(), choff.size() * 4, hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(anim_wl_kernel, dim3(n_units), dim3(64), 0, ctx->stream, choff_d, A->wl_d);
     if (M > A->tasks) { if ((rc = regrow(ctx, A->tasks_d, M))) return rc; A->tasks = M; }

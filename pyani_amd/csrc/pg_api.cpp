@@ -657,6 +657,13 @@ int pg_tetra_corr_rows_dev(pg_ctx* ctx, const double* d_z, const uint8_t* d_pres
 }
 
 // ---- ANIm -------------------------------------------------------------------------------------------------------
+int pg_anim_set_batch_budget(pg_ctx* ctx, uint32_t max_pairs, uint64_t max_matches) {
+  if (!ctx || max_pairs == 0 || max_matches < 1024) return pg_fail(ctx, PG_E_ARG, "bad argument");
+  ctx->anim_batch_pairs = max_pairs;
+  ctx->anim_batch_matches = max_matches;
+  return PG_OK;
+}
+
 int pg_anim_pairs(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_ids, uint64_t n_pairs, int maxmatch,
                   int filter_1to1, pg_anim_result* out) {
   if (!ctx || (n_pairs && (!ref_ids || !qry_ids || !out))) return pg_fail(ctx, PG_E_ARG, "bad argument");

@@ -172,6 +172,9 @@ class Engine:
                                            out.ctypes.data))
         return out
 
+    def anim_set_batch_budget(self, max_pairs: int, max_matches: int) -> None:
+        self._check(self.lib.pg_anim_set_batch_budget(self._h, int(max_pairs), int(max_matches)))
+
     ALN_DTYPE = np.dtype([("ref_rec", "<i4"), ("qry_rec", "<i4"), ("rs", "<i4"), ("re", "<i4"), ("qs", "<i4"), ("qe", "<i4"),
                           ("errors", "<i4"), ("kept", "<i4")])
 

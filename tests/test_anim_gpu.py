@@ -184,3 +184,38 @@ def test_alignment_records_equal_mummer_delta_and_filter_files(eng, genome_dir, 
             n_records += len(want)
             n_pairs += 1
     assert (n_pairs, n_records) == (17, 505)
+
+
+def test_batch_split_does_not_change_results_and_edge_inputs(eng):
+    """The internal batching (pairs per launch, match budget) must be invisible: a call split into many tiny launches —
+    including launches that stop early because the match budget is exhausted — returns the same records.  Plus the edge
+    inputs: a genome against itself, genomes too short to seed, all-N and empty genomes, unknown ids, --maxmatch."""
+    from pyani_amd import synth
+    from pyani_amd._lib import PyaniGpuError
+    eng.clear_genomes()
+    n, L = 6, 120_000
+    ids = [eng.add_genome(*synth.genome(7, n, g, L)) for g in range(n)]
+    tiny = eng.add_genome(np.frombuffer(b"ACGTACGTACGTAC", dtype=np.uint8), np.array([0, 14], dtype=np.uint64))
+    alln = eng.add_genome(np.frombuffer(b"N" * 5000, dtype=np.uint8), np.array([0, 5000], dtype=np.uint64))
+    empty = eng.add_genome(np.zeros(0, dtype=np.uint8), np.array([0, 0], dtype=np.uint64))
+    eng.upload()
+    pairs = [(a, b) for a in ids for b in ids if a != b] + [(ids[0], ids[0]), (ids[0], tiny), (tiny, ids[0]), (alln, ids[1]),
+                                                             (ids[1], alln), (empty, ids[2]), (ids[2], empty), (tiny, alln)]
+    ra, qa = [a for a, _ in pairs], [b for _, b in pairs]
+    eng.anim_set_batch_budget(16384, 150 << 20)
+    ref = eng.anim_pairs(ra, qa)
+    for max_pairs, max_matches in ((3, 150 << 20), (16384, 4096), (2, 2048)):
+        eng.anim_set_batch_budget(max_pairs, max_matches)
+        assert eng.anim_pairs(ra, qa).tobytes() == ref.tobytes(), (max_pairs, max_matches)
+    eng.anim_set_batch_budget(16384, 150 << 20)
+    by = {p: r for p, r in zip(pairs, ref)}
+    self_hit = by[(ids[0], ids[0])]
+    assert int(self_hit["status"]) == 0 and float(self_hit["identity"]) == 1.0 and int(self_hit["sim_errors"]) == 0
+    assert int(self_hit["ref_aln_len"]) == int(self_hit["qry_aln_len"]) >= L - 100
+    for p in pairs[-7:]:
+        assert int(by[p]["status"]) == 1 and int(by[p]["n_alignments"]) == 0, p    # parse_delta would raise ZeroDivisionError
+    with pytest.raises(PyaniGpuError):
+        eng.anim_pairs([ids[0]], [999])
+    with pytest.raises(PyaniGpuError):
+        eng.anim_pairs([ids[0]], [ids[1]], maxmatch=True)
+    assert len(eng.anim_pairs([], [])) == 0
