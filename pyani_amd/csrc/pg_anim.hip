@@ -169,6 +169,17 @@ struct SeedQry {            // one per pair of the batch (its query genome)
   const uint64_t* list;
   const uint32_t* goff;     // 2 * SEED_GROUPS + 2
 };
+// Per batch, transposed: slice[g * n_pairs + p] = where pair p's query keeps group g.  A wave reads the descriptors of
+// 64 of its pairs with ONE coalesced load instead of chasing pair -> offset table -> entries once per pair.
+struct SeedSlice { uint32_t begin, n0, n1; };   // strand-0 entries [begin, begin + n0), strand-1 [begin + n0, begin + n0 + n1)
+__global__ __launch_bounds__(256) void anim_slice_kernel(const SeedQry* __restrict__ sqry, uint32_t n_pairs, SeedSlice* __restrict__ slice) {
+  const uint32_t p = blockIdx.x;
+  const uint32_t* goff = sqry[p].goff;
+  for (uint32_t g = threadIdx.x; g < SEED_GROUPS; g += 256) {
+    const uint32_t o0 = goff[2 * g], o1 = goff[2 * g + 1], o2 = goff[2 * g + 2];
+    slice[(size_t)g * n_pairs + p] = SeedSlice{o0, o1 - o0, o2 - o1};
+  }
+}
 
 // One hit of a sampled query k-mer (strand position q) on reference position r: report the maximal match it lies in,
 // unless an earlier sampled position of the same match does.  Returns false if nothing is to be appended.
@@ -222,6 +233,7 @@ constexpr uint32_t SEED_STAGE = 96;    // matches staged in LDS per wave (table 
 constexpr size_t SEED_STAGE_BYTES = (SEED_BLOCK / 64) * (SEED_STAGE * sizeof(Match) + 4);
 __global__ __launch_bounds__(SEED_BLOCK) void anim_seed_kernel(const RefDesc* __restrict__ refs, const UnitDesc* __restrict__ units,
                                                                const SeedRef* __restrict__ srefs, const SeedQry* __restrict__ sqry,
+                                                               const SeedSlice* __restrict__ slice, uint32_t n_pairs,
                                                                uint32_t slot_mask, Match* __restrict__ buf, uint32_t cap,
                                                                uint32_t* __restrict__ total, uint32_t* __restrict__ unit_count) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long tab[];
@@ -241,73 +253,119 @@ __global__ __launch_bounds__(SEED_BLOCK) void anim_seed_kernel(const RefDesc* __
   }
   __syncthreads();
   const SeqView RV{R.codes, R.mask, R.len};
-  for (uint32_t p = SR.pair_begin + wave; p < SR.pair_end; p += SEED_BLOCK / 64) {
-    const SeedQry SQ = sqry[p];
-    const UnitDesc U0 = units[2 * p];
-    const uint32_t o0 = SQ.goff[2 * g], o1 = SQ.goff[2 * g + 1], o2 = SQ.goff[2 * g + 2];
-    for (int strand = 0; strand < 2; ++strand) {
-      const StrandView QV{SeqView{U0.codes, U0.mask, U0.len}, strand};
-      const uint32_t unit = 2 * p + (uint32_t)strand;
-      const uint32_t e_end = strand ? o2 : o1;
-      for (uint32_t e0 = (strand ? o1 : o0); e0 < e_end; e0 += 64 * SEED_UNROLL) {
-        unsigned long long qv[SEED_UNROLL];
-#pragma unroll
-        for (int t = 0; t < SEED_UNROLL; ++t) {
-          const uint32_t e = e0 + 64 * t + lane;
-          qv[t] = e < e_end ? __builtin_nontemporal_load(&SQ.list[e]) : SLOT_EMPTY;
+  // this wave's share of the reference's pairs: a contiguous range, its descriptors fetched 64 at a time
+  const uint32_t n_mine_all = SR.pair_end - SR.pair_begin;
+  const uint32_t per_wave = (n_mine_all + SEED_BLOCK / 64 - 1) / (SEED_BLOCK / 64);
+  const uint32_t my_begin = SR.pair_begin + wave * per_wave;
+  const uint32_t my_end = my_begin + per_wave < SR.pair_end ? my_begin + per_wave : SR.pair_end;
+  const SeedSlice* __restrict__ row = slice + (size_t)g * n_pairs;
+  for (uint32_t chunk = my_begin; chunk < my_end; chunk += 64) {
+    SeedSlice mine{0, 0, 0};
+    const uint64_t* mylist = nullptr;
+    if (chunk + lane < my_end) { mine = row[chunk + lane]; mylist = sqry[chunk + lane].list; }
+    const uint32_t in_chunk = my_end - chunk < 64 ? my_end - chunk : 64;
+    // The chunk's work as a sequence of row blocks (<= SEED_UNROLL rows of 64 entries of one (pair, strand) slice),
+    // software-pipelined: the loads of block k+1 are in flight while block k is looked up.
+    struct Blk { uint32_t j, strand, e0, e_end; const uint64_t* list; bool valid; };
+    auto slice_of = [&](uint32_t j, uint32_t strand, Blk& o) {
+      const uint32_t begin = (uint32_t)__builtin_amdgcn_readlane((int)mine.begin, j);
+      const uint32_t n0 = (uint32_t)__builtin_amdgcn_readlane((int)mine.n0, j), n1 = (uint32_t)__builtin_amdgcn_readlane((int)mine.n1, j);
+      o.j = j; o.strand = strand;
+      o.e0 = strand ? begin + n0 : begin;
+      o.e_end = o.e0 + (strand ? n1 : n0);
+      o.list = reinterpret_cast<const uint64_t*>(
+          ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)((unsigned long long)mylist >> 32), j) << 32) |
+          (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(unsigned long long)mylist, j));
+    };
+    auto first_from = [&](uint32_t j, uint32_t strand) {   // first non-empty slice at or after (j, strand)
+      Blk o{0, 0, 0, 0, nullptr, false};
+      for (; j < in_chunk; ++j, strand = 0)
+        for (; strand < 2; ++strand) {
+          slice_of(j, strand, o);
+          if (o.e0 < o.e_end) { o.valid = true; return o; }
         }
+      return o;
+    };
+    auto next_of = [&](const Blk& c) {
+      if (c.e0 + 64 * SEED_UNROLL < c.e_end) { Blk o = c; o.e0 += 64 * SEED_UNROLL; return o; }
+      return c.strand == 0 ? first_from(c.j, 1) : first_from(c.j + 1, 0);
+    };
+    auto load = [&](const Blk& c, unsigned long long (&qv)[SEED_UNROLL]) {
 #pragma unroll
-        for (int t = 0; t < SEED_UNROLL; ++t) {
-          if (qv[t] == SLOT_EMPTY) continue;
-          const uint32_t key = (uint32_t)(qv[t] >> SEED_KEY_SHIFT);
-          const uint32_t qctx = (uint32_t)(qv[t] >> 32) & 0x7FFu;   // bit 0: flag, bits 1..10: left bases
-          const int32_t q = (int32_t)(uint32_t)qv[t];
-          uint32_t slot = (key >> 5) & slot_mask;
-          for (int hits = 0; hits < MAX_HITS;) {
-            const unsigned long long v = tab[slot];
-            if (v == SLOT_EMPTY) break;   // load factor <= 1/2: every probe sequence ends
-            slot = (slot + 1) & slot_mask;
-            if ((uint32_t)(v >> SEED_KEY_SHIFT) != key) continue;
-            ++hits;
-            int32_t left = -1;
-            const uint32_t rctx = (uint32_t)(v >> 32) & 0x7FFu;
-            if (rctx & qctx & 1u) {
-              const uint32_t x = (rctx ^ qctx) >> 1;
-              const uint32_t diff = (x | (x >> 1)) & 0x155u;
-              left = diff ? (__ffs(diff) - 1) >> 1 : SEED_STEP;
-              if (left == SEED_STEP) continue;   // inside a longer match: an earlier sampled position reports it
-            }
-            Match m;
-            if (!seed_hit(R, RV, U0, QV, strand, (int32_t)(uint32_t)v, q, left, m)) continue;
-            // stage in the wave's LDS buffer; it is flushed with one pair of global atomics per SEED_STAGE/2+ matches
-            m.strand = (int32_t)unit;
-            const uint32_t at = atomicAdd(&stage_n[wave], 1u);
-            if (at < SEED_STAGE) {
-              stage[wave * SEED_STAGE + at] = m;
-            } else {   // staging buffer full (a burst of hits): straight to the global buffer
-              const uint32_t ga = atomicAdd(total, 1u);
-              atomicAdd(&unit_count[unit], 1u);
-              if (ga < cap) buf[ga] = m;
-            }
+      for (int t = 0; t < SEED_UNROLL; ++t) {
+        const uint32_t e = c.e0 + 64 * t + lane;
+        qv[t] = e < c.e_end ? __builtin_nontemporal_load(&c.list[e]) : SLOT_EMPTY;
+      }
+    };
+    auto process = [&](const Blk& c, const unsigned long long (&qv)[SEED_UNROLL]) {
+      const uint32_t p = chunk + c.j;
+      const int strand = (int)c.strand;
+      const uint32_t unit = 2 * p + c.strand;
+#pragma unroll
+      for (int t = 0; t < SEED_UNROLL; ++t) {
+        if (qv[t] == SLOT_EMPTY) continue;
+        const uint32_t key = (uint32_t)(qv[t] >> SEED_KEY_SHIFT);
+        const uint32_t qctx = (uint32_t)(qv[t] >> 32) & 0x7FFu;   // bit 0: flag, bits 1..10: left bases
+        const int32_t q = (int32_t)(uint32_t)qv[t];
+        uint32_t slot = (key >> 5) & slot_mask;
+        for (int hits = 0; hits < MAX_HITS;) {
+          const unsigned long long v = tab[slot];
+          if (v == SLOT_EMPTY) break;   // load factor <= 1/2: every probe sequence ends
+          slot = (slot + 1) & slot_mask;
+          if ((uint32_t)(v >> SEED_KEY_SHIFT) != key) continue;
+          ++hits;
+          int32_t left = -1;
+          const uint32_t rctx = (uint32_t)(v >> 32) & 0x7FFu;
+          if (rctx & qctx & 1u) {
+            const uint32_t x = (rctx ^ qctx) >> 1;
+            const uint32_t diff = (x | (x >> 1)) & 0x155u;
+            left = diff ? (__ffs(diff) - 1) >> 1 : SEED_STEP;
+            if (left == SEED_STEP) continue;   // inside a longer match: an earlier sampled position reports it
           }
-        }
-        // uniform point: flush once the buffer is half full, or at the end of this (pair, strand) unit
-        __builtin_amdgcn_wave_barrier();
-        uint32_t n_st = stage_n[wave];
-        if (n_st > SEED_STAGE) n_st = SEED_STAGE;
-        if (n_st >= SEED_STAGE / 2 || (n_st && e0 + 64 * SEED_UNROLL >= e_end)) {
-          uint32_t base = 0;
-          if (lane == 0) {
-            base = atomicAdd(total, n_st);
-            atomicAdd(&unit_count[unit], n_st);
-            stage_n[wave] = 0;
+          const UnitDesc U0 = units[2 * p];   // the query's sequence: only needed to verify / extend an actual hit
+          const StrandView QV{SeqView{U0.codes, U0.mask, U0.len}, strand};
+          Match m;
+          if (!seed_hit(R, RV, U0, QV, strand, (int32_t)(uint32_t)v, q, left, m)) continue;
+          // stage in the wave's LDS buffer; it is flushed with one pair of global atomics per SEED_STAGE/2+ matches
+          m.strand = (int32_t)unit;
+          const uint32_t at = atomicAdd(&stage_n[wave], 1u);
+          if (at < SEED_STAGE) {
+            stage[wave * SEED_STAGE + at] = m;
+          } else {   // staging buffer full (a burst of hits): straight to the global buffer
+            const uint32_t ga = atomicAdd(total, 1u);
+            atomicAdd(&unit_count[unit], 1u);
+            if (ga < cap) buf[ga] = m;
           }
-          base = __shfl(base, 0);
-          for (uint32_t i = lane; i < n_st; i += 64)
-            if (base + i < cap) buf[base + i] = stage[wave * SEED_STAGE + i];
-          __builtin_amdgcn_wave_barrier();
         }
       }
+      // uniform point: flush once the buffer is half full, or at the end of this (pair, strand) unit
+      __builtin_amdgcn_wave_barrier();
+      uint32_t n_st = stage_n[wave];
+      if (n_st > SEED_STAGE) n_st = SEED_STAGE;
+      if (n_st >= SEED_STAGE / 2 || (n_st && c.e0 + 64 * SEED_UNROLL >= c.e_end)) {
+        uint32_t base = 0;
+        if (lane == 0) {
+          base = atomicAdd(total, n_st);
+          atomicAdd(&unit_count[unit], n_st);
+          stage_n[wave] = 0;
+        }
+        base = __shfl(base, 0);
+        for (uint32_t i = lane; i < n_st; i += 64)
+          if (base + i < cap) buf[base + i] = stage[wave * SEED_STAGE + i];
+        __builtin_amdgcn_wave_barrier();
+      }
+    };
+    unsigned long long qa[SEED_UNROLL], qb[SEED_UNROLL];
+    Blk A = first_from(0, 0);
+    if (A.valid) load(A, qa);
+    while (A.valid) {
+      Blk B = next_of(A);
+      if (B.valid) load(B, qb);
+      process(A, qa);
+      if (!B.valid) break;
+      A = next_of(B);
+      if (A.valid) load(A, qa);
+      process(B, qb);
     }
   }
 }
@@ -1433,6 +1491,8 @@ struct AnimScratch {
   uint32_t* list_cnt = nullptr;   // 2 * SEED_GROUPS counters shared by the list builds
   SeedRef* srefs_d = nullptr;
   SeedQry* sqry_d = nullptr;
+  SeedSlice* slice_d = nullptr;   // [SEED_GROUPS][pairs of the batch]
+  size_t slice_pairs = 0;
   int32_t* recs_d = nullptr;
   RefDesc* refs_d = nullptr;
   UnitDesc* units_d = nullptr;
@@ -1524,7 +1584,7 @@ void pg_anim_free_scratch(pg_ctx* ctx) {
   AnimScratch* A = static_cast<AnimScratch*>(ctx->anim_scratch);
   if (!A) return;
   pg_anim_drop_lists(ctx);
-  void* ptrs[] = {A->choff_d, A->list_cnt, A->srefs_d, A->sqry_d, A->recs_d, A->refs_d, A->units_d, A->mem_count, A->moff, A->nch, A->status, A->out, A->mem, A->cm,
+  void* ptrs[] = {A->slice_d, A->choff_d, A->list_cnt, A->srefs_d, A->sqry_d, A->recs_d, A->refs_d, A->units_d, A->mem_count, A->moff, A->nch, A->status, A->out, A->mem, A->cm,
                   A->iscratch, A->order, A->prev, A->next, A->alnof, A->chains, A->fw, A->bw, A->S.alns, A->S.a_rrec,
                   A->S.a_qrec, A->S.idx, A->S.from, A->S.sc, A->wl_d, A->seedbuf, A->seed_total, A->tasks_d};
   for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -1633,6 +1693,12 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
     }
   };
   PG_HIP(ctx, hipMemcpyAsync(A->sqry_d, sqry.data(), n_pairs * sizeof(SeedQry), hipMemcpyHostToDevice, ctx->stream));
+  if (n_pairs > A->slice_pairs) {
+    if ((rc = regrow(ctx, A->slice_d, (size_t)n_pairs * SEED_GROUPS))) return rc;
+    A->slice_pairs = n_pairs;
+  }
+  const uint32_t slice_stride = n_pairs;   // the table is laid out for the whole batch even if only a prefix is seeded again
+  hipLaunchKernelGGL(anim_slice_kernel, dim3(n_pairs), dim3(256), 0, ctx->stream, A->sqry_d, n_pairs, A->slice_d);
   static bool lds_attr_set = false;
   if (!lds_attr_set) {
     PG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(anim_seed_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1652,7 +1718,8 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
     PG_HIP(ctx, hipMemsetAsync(A->mem_count, 0, n_units * 4, ctx->stream));
     PG_HIP(ctx, hipMemsetAsync(A->seed_total, 0, 4, ctx->stream));
     hipLaunchKernelGGL(anim_seed_kernel, dim3(SEED_GROUPS, n_refs), dim3(SEED_BLOCK), (size_t)slots * 8 + SEED_STAGE_BYTES, ctx->stream, A->refs_d, A->units_d,
-                       A->srefs_d, A->sqry_d, slots - 1, A->seedbuf, (uint32_t)A->seed_cap, A->seed_total, A->mem_count);
+                       A->srefs_d, A->sqry_d, A->slice_d, slice_stride, slots - 1, A->seedbuf, (uint32_t)A->seed_cap, A->seed_total,
+                       A->mem_count);
     PG_HIP(ctx, hipMemcpyAsync(cnt.data(), A->mem_count, n_units * 4, hipMemcpyDeviceToHost, ctx->stream));
     PG_HIP(ctx, hipMemcpyAsync(&total, A->seed_total, 4, hipMemcpyDeviceToHost, ctx->stream));
     PG_HIP(ctx, hipStreamSynchronize(ctx->stream));
