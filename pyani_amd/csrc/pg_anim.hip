@@ -1601,6 +1601,7 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
   AnimScratch* A = anim_scratch(ctx);
   uint32_t n_units = 2 * n_pairs;
   int rc;
+  (void)hipGetLastError();   // launch checks below must only see this batch's errors
   std::vector<int32_t> ref_list;
   std::vector<uint32_t> ref_of_pair(n_pairs);
   for (uint32_t p = 0; p < n_pairs; ++p) {

@@ -315,6 +315,7 @@ int pg_create(pg_ctx** out, int device) {
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
     ctx->num_cu = prop.multiProcessorCount;
+  (void)hipGetLastError();   // the runtime's "last error" is per thread and sticky: start clean
   *out = ctx;
   return PG_OK;
 }
@@ -333,6 +334,7 @@ void pg_destroy(pg_ctx* ctx) {
   for (void* p : host)
     if (p) (void)hipHostFree(p);
   (void)hipStreamDestroy(ctx->stream);
+  (void)hipGetLastError();   // teardown errors must not surface in a later context's launch checks
   delete ctx;
 }
 
