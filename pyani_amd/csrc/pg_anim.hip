@@ -7,13 +7,17 @@
 //   A2 anim_seed_kernel      one workgroup per (reference, group): the group's reference k-mers become a hash table in
 //                            LDS; the same group of every query of that reference streams through it (coalesced,
 //                            sequential HBM reads; no random global access except to verify / extend actual hits)
-//   A3 anim_cluster_kernel   per (pair, strand): MUM filter, mgaps clustering, chain extraction      (pg_anim_core.h)
-//   A4 anim_extend_kernel    per chain: gap fills + free forward extension, then backward extension towards the
-//                            previous chain's end (banded affine DP, band in registers/scratch)
-//   A5 anim_finish_kernel    per pair: stitch/fuse chains, 1-to-1 filter, parse_delta reduction -> pg_anim_result
+//   A3 anim_cluster_wave_kernel  one WAVE per (pair, strand): MUM filter (packed radix sorts + wave-scan containment
+//                            flags), mgaps clustering (lock-free union-find), chain extraction (register / LDS resident)
+//   A4 anim_gaps_kernel      one wave per chain: trims the chained matches, settles trivial gaps, emits GapTasks
+//      anim_gapdp_kernel     one wave per GapTask: banded affine DP (64 lanes = 64 diagonals, DPP neighbour exchange)
+//      anim_extend_kernel    one wave per chain: forward extension towards the next chain, then backward extension /
+//                            junction bridge
+//   A5 anim_finish_kernel    one wave per pair: stitch/fuse chains, 1-to-1 filter, parse_delta reduction -> pg_anim_result
 //
-// Round-1 state: correctness first — A3/A5 run one thread per unit (thousands of pairs give the parallelism), A2
-// extends base by base.  The DESIGN.md section "ANIm" lists what is measured and what comes next.
+// Every kernel has a scalar statement in pg_anim_core.h that compiles for the host (tools/anim_debug); the two are kept
+// in lock-step and compared on the GPU by tests/test_anim_gpu.py.  Limits: genomes up to ~14 Mb (a reference k-mer
+// group must fit a 16384-slot LDS table; PG_E_CAPACITY otherwise), chain scores < 2^24.
 #include "pg_internal.h"
 #include "pg_anim_core.h"
 
