@@ -12,6 +12,10 @@ A "step" = one full pass of the path over the batch, inputs already resident in 
           genomes, RCCL all-gather of Z (N*200 x 256 f64 + presence), every rank computes its row block of the
           matrix, RCCL all-gather of the rows.  (two collectives, both tiny.)
 Rank 0 prints ONE JSON line.
+
+  --workload anim : the ANIm side of the same metric on the same genomes (C3: all 39 800 ordered pairs; a step is one
+          pass over the whole grid; N > 1 = strong scaling, pair grid dealt by reference row, one all-gather).  Not the
+          default: BASELINE.json quotes the metric on configs[1] (TETRA) for N = 1.
 """
 import argparse
 import json
@@ -32,14 +36,105 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICRO
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", choices=["tetra", "anim"], default="tetra",
+                    help="tetra = C2 (the default, BASELINE.json configs[1]); anim = C3 (all ordered pairs of the same genomes)")
+    ap.add_argument("--steps", type=int, default=None, help="default 50 (tetra) / 3 (anim)")
+    ap.add_argument("--warmup", type=int, default=None, help="default 5 (tetra) / 1 (anim)")
     ap.add_argument("--genomes", type=int, default=200, help="genomes per GPU (C2: 200)")
     ap.add_argument("--length", type=int, default=5_000_000, help="ancestor length in bases (C2: 5 Mb)")
     ap.add_argument("--seed", type=int, default=20250228)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-genomes", type=int, default=2, help="genomes timed by the CPU baseline leg")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 50 if args.workload == "tetra" else 3
+    if args.warmup is None:
+        args.warmup = 5 if args.workload == "tetra" else 1
+    return args
+
+
+def run_anim(args, rank, world, local, dist, torch):
+    """C3-shaped ANIm workload: every ordered pair of `--genomes` synthetic genomes (replicated on every GPU).  A step is
+    one pass over the whole ordered-pair grid; with N GPUs the grid is dealt by reference row and assembled with ONE
+    all-gather (pyani_amd/parallel.py), i.e. STRONG scaling of a fixed job."""
+    from pyani_amd import parallel, synth
+    from pyani_amd.engine import Engine
+    eng = Engine(local)
+    n = args.genomes
+    t_prep = time.perf_counter()
+    with ThreadPoolExecutor(max(1, min(16, (os.cpu_count() or 2) // max(1, world)))) as ex:
+        data = list(ex.map(lambda g: synth.genome(args.seed, n, g, args.length), range(n)))
+    ids = [eng.add_genome(s_, o_) for s_, o_ in data]
+    eng.upload()
+    t_prep = time.perf_counter() - t_prep
+    dev = torch.device("cuda", local)
+    mine = parallel.anim_pair_shard(n, rank, world)
+
+    def compute(pairs):
+        return parallel.anim_records_to_tensor(eng.anim_pairs([ids[q] for q, _ in pairs], [ids[s_] for _, s_ in pairs]), dev)
+
+    grid = None
+
+    def step():
+        nonlocal grid
+        grid = parallel.anim_allgather(compute, n, dev) if world > 1 else compute(mine)
+
+    def fence():
+        eng.sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        pairs = n * (n - 1)
+        g = grid.cpu().numpy().reshape(-1, parallel.ANIM_FIELDS)
+        status = g[:, 5] if world == 1 else g[np.arange(n * n) % (n + 1) != 0, 5]
+        step_s = elapsed / args.steps
+        lens = [len(d[0]) for d in data]
+        alg_bytes = sum((lens[q] + 3) // 4 + (lens[s_] + 3) // 4 + 32 for q in range(n) for s_ in range(n) if q != s_)
+        out = {
+            "metric": "genome-pairs/sec (ordered pairs) for the ANIm N x N grid: nucmer --mum + delta-filter -1 + parse_delta "
+                      "equivalent, genomes resident in HBM",
+            "value": pairs / step_s, "unit": "genome-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": step_s * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "int32 DP keys (score << 15 | errors), f64 identity", "data": "synthetic",
+            "config": {
+                "workload": f"C3: ANIm on {n} synthetic ~{args.length / 1e6:g} Mb genomes (SURVEY.md §8(d) generator, seed "
+                            f"{args.seed}), all {pairs} ordered pairs",
+                "genomes": n, "pairs": pairs, "pairs_with_alignment": int((status == 0).sum()),
+                "parallelism": "1 process/GPU; genomes replicated; pair grid dealt by reference row; one RCCL all-gather"
+                               if world > 1 else "1 GPU",
+                "wall_s_grid": step_s, "host_prep_s": t_prep,
+            },
+            "roofline": {
+                "bound": "hbm", "kernel": "whole ANIm pipeline (no single HBM-bound kernel: the extension DP is VALU-issue bound, "
+                                          "the seed stage streams 16 MB of k-mer list per pair; see DESIGN.md §8)",
+                "achieved": alg_bytes / step_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": alg_bytes / step_s / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                "algorithmic_bytes_per_launch": int(alg_bytes),
+            },
+            "cpu_baseline": {"value": None, "unit": "genome-pairs/s", "cores": 0, "kind": "reference",
+                             "sample": "unavailable: nucmer / delta-filter (MUMmer 3.23) are absent from this image and from "
+                                       "the GPU box, and their source is not in the reference tree (SURVEY.md §8c)"},
+        }
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    eng.close()
 
 
 def cpu_baseline(eng_z, sample, n_genomes, n_pairs):
@@ -102,6 +197,8 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
+    if args.workload == "anim":
+        return run_anim(args, rank, world, local, dist, torch)
     from pyani_amd import _lib, synth
     from pyani_amd.engine import Engine
     eng = Engine(local)
