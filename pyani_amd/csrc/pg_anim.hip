@@ -597,6 +597,232 @@ __device__ __forceinline__ void uf_union(int32_t* parent, int a, int b) {   // l
   }
 }
 
+// =====================================================================================================================
+// A3a, workgroup-cooperative: the front half of the per-unit work (MUM filter, union-find, grouping by cluster) run by
+// PREP_WAVES waves per unit, so that the largest unit of a launch no longer sets the launch time on one wave's latency
+// chain.  Same algorithms as the wave versions above (which remain as the single-wave statement): the stable counting
+// sort gives every wave a contiguous chunk and its own histogram row, offsets are the prefix over (digit, wave).
+// =====================================================================================================================
+constexpr int PREP_WAVES = 16, PREP_THREADS = PREP_WAVES * 64;
+
+__device__ uint64_t* block_radix_sort(uint64_t* a, uint64_t* b, int n, int passes, uint32_t* hist /*[PREP_WAVES][256]*/,
+                                      uint32_t* s_misc /*[4]*/) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int U = 4;
+  const int chunk = ((n + PREP_WAVES - 1) / PREP_WAVES + 63) & ~63;   // whole rows per wave
+  const int c0 = wave * chunk < n ? wave * chunk : n, c1 = c0 + chunk < n ? c0 + chunk : n;
+  uint64_t *src = a, *dst = b;
+  uint32_t* myh = hist + wave * 256;
+  for (int pass = 0; pass < passes; ++pass) {
+    const int shift = 32 + 8 * pass;
+    __syncthreads();   // previous pass's (or the caller's) global stores have landed; hist free
+    for (int i = tid; i < PREP_WAVES * 256; i += PREP_THREADS) hist[i] = 0;
+    if (tid == 0) s_misc[0] = 0;
+    __syncthreads();
+    for (int base = c0; base < c1; base += 64 * U) {
+      uint64_t kk[U];
+#pragma unroll
+      for (int t = 0; t < U; ++t) { const int i = base + 64 * t + lane; kk[t] = i < c1 ? src[i] : 0ull; }
+#pragma unroll
+      for (int t = 0; t < U; ++t) if (base + 64 * t + lane < c1) atomicAdd(&myh[(uint32_t)(kk[t] >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    // digit totals, constant-digit test, exclusive prefix over (digit, wave): thread d owns digit d
+    uint32_t col = 0;
+    if (tid < 256) {
+      for (int w = 0; w < PREP_WAVES; ++w) col += hist[w * 256 + tid];
+      if (col == (uint32_t)n) s_misc[0] = 1;
+    }
+    __syncthreads();
+    if (s_misc[0]) continue;   // every key has the same digit: nothing moves (uniform decision)
+    if (wave == 0) {           // exclusive scan of the 256 totals by wave 0 (4 per lane), result into s_tot via hist row reuse
+      uint32_t t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+      for (int w = 0; w < PREP_WAVES; ++w) {
+        t0 += hist[w * 256 + 4 * lane]; t1 += hist[w * 256 + 4 * lane + 1];
+        t2 += hist[w * 256 + 4 * lane + 2]; t3 += hist[w * 256 + 4 * lane + 3];
+      }
+      const uint32_t tot = t0 + t1 + t2 + t3;
+      uint32_t incl = tot;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+      uint32_t ex = incl - tot;
+      // turn every column into running offsets: hist[w][d] = base[d] + sum_{w' < w} count[w'][d]
+      uint32_t basev[4] = {ex, ex + t0, ex + t0 + t1, ex + t0 + t1 + t2};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        uint32_t run = basev[k];
+        for (int w = 0; w < PREP_WAVES; ++w) { const uint32_t c = hist[w * 256 + 4 * lane + k]; hist[w * 256 + 4 * lane + k] = run; run += c; }
+      }
+    }
+    __syncthreads();
+    for (int base = c0; base < c1; base += 64 * U) {
+      uint64_t kk[U];
+#pragma unroll
+      for (int t = 0; t < U; ++t) { const int i = base + 64 * t + lane; kk[t] = i < c1 ? src[i] : 0ull; }
+#pragma unroll
+      for (int t = 0; t < U; ++t) {   // rows in order: the sort is stable
+        const bool act = base + 64 * t + lane < c1;
+        const uint32_t d = (uint32_t)(kk[t] >> shift) & 255u;
+        uint64_t peers = __ballot(act);
+#pragma unroll
+        for (int bb = 0; bb < 8; ++bb) {
+          const uint64_t vote = __ballot((d >> bb) & 1u);
+          peers &= ((d >> bb) & 1u) ? vote : ~vote;
+        }
+        const uint32_t rank = (uint32_t)__popcll(peers & lanemask_lt());
+        uint32_t pos = 0;
+        if (act) pos = myh[d] + rank;
+        wave_lds_fence();
+        if (act && rank == 0) myh[d] += (uint32_t)__popcll(peers);
+        wave_lds_fence();
+        if (act) dst[pos] = kk[t];
+      }
+    }
+    uint64_t* tmp = src; src = dst; dst = tmp;
+  }
+  __syncthreads();
+  return src;
+}
+
+// containment flags (see wave_containment_flags): every wave scans its chunk of the sorted order; the running maximum
+// entering a chunk is the maximum of the earlier chunks' ends.
+__device__ void block_containment_flags(const uint64_t* order, const int32_t* start, const int32_t* len, int n, int32_t* flag,
+                                        int32_t* s_carry /*[PREP_WAVES]*/) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int chunk = ((n + PREP_WAVES - 1) / PREP_WAVES + 63) & ~63;
+  const int c0 = wave * chunk < n ? wave * chunk : n, c1 = c0 + chunk < n ? c0 + chunk : n;
+  int32_t mx = -1;
+  for (int t = c0 + lane; t < c1; t += 64) { const uint32_t idx = (uint32_t)order[t]; const int32_t e = start[idx] + len[idx]; mx = e > mx ? e : mx; }
+  mx = (int32_t)wave_max_u32((uint32_t)(mx + 1)) - 1;
+  if (lane == 0) s_carry[wave] = mx;
+  __syncthreads();
+  int32_t carry = -1;
+  for (int w = 0; w < wave; ++w) carry = s_carry[w] > carry ? s_carry[w] : carry;
+  for (int base = c0; base < c1; base += 64) {
+    const int t = base + lane;
+    const bool act = t < c1;
+    const uint32_t idx = act ? (uint32_t)order[t] : 0u;
+    const int32_t st = act ? start[idx] : 0, ln = act ? len[idx] : 0;
+    const int32_t e = act ? st + ln : -1;
+    int32_t incl = e;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int32_t v = __shfl_up(incl, o, 64); if (lane >= o && v > incl) incl = v; }
+    int32_t excl = __shfl_up(incl, 1, 64);
+    if (lane == 0) excl = -1;
+    const int32_t prevmax = excl > carry ? excl : carry;
+    if (act) {
+      bool f = e <= prevmax;
+      if (!f && t + 1 < n) { const uint32_t nx = (uint32_t)order[t + 1]; f = start[nx] == st && len[nx] == ln; }
+      if (f) flag[idx] = 1;
+    }
+    const int32_t last = __shfl(incl, 63, 64);
+    if (last > carry) carry = last;
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(PREP_THREADS) void anim_cluster_prep_kernel(const RefDesc* __restrict__ refs, const UnitDesc* __restrict__ units,
+                                                                         Match* __restrict__ mem, const uint32_t* __restrict__ mem_count,
+                                                                         int32_t* __restrict__ iscratch, ClusterOut O) {
+  __shared__ uint32_t hist[PREP_WAVES * 256];
+  __shared__ uint32_t s_misc[4];
+  __shared__ int32_t s_carry[PREP_WAVES];
+  __shared__ uint32_t s_cnt[PREP_WAVES];
+  const uint32_t u = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const UnitDesc U = units[u];
+  const RefDesc R = refs[U.ref];
+  const size_t off = O.moff[u];
+  const uint32_t cap = O.moff[u + 1] - O.moff[u];
+  uint32_t n0 = mem_count[u];
+  if (n0 > cap) { if (tid == 0) atomicOr(&O.status[U.pair], 1); n0 = cap; }
+  if (n0 == 0) { if (tid == 0) O.n_chains[u] = 0; return; }
+  Match* m = mem + off;
+  int32_t* sa = iscratch + off * 8;
+  int32_t *sb = sa + cap, *sc = sa + 2 * (size_t)cap, *sd = sa + 3 * (size_t)cap, *se = sa + 4 * (size_t)cap,
+          *sf = sa + 5 * (size_t)cap, *sg = sa + 6 * (size_t)cap, *sh = sa + 7 * (size_t)cap;
+  uint64_t *P0 = reinterpret_cast<uint64_t*>(sa), *P1 = reinterpret_cast<uint64_t*>(sc);
+  const int n_in = (int)n0;
+  // ---- MUM filter (as in the wave kernel) ---------------------------------------------------------------------------
+  for (int i = tid; i < n_in; i += PREP_THREADS) { const Match t = m[i]; se[i] = t.r; sf[i] = t.q; sg[i] = t.len; sh[i] = 0; }
+  __syncthreads();
+  const int start_passes = (R.len > U.len ? R.len : U.len) < (1 << 24) ? 3 : 4;
+  const uint64_t* qsorted = nullptr;
+  for (int side = 1; side >= 0; --side) {
+    const int32_t* start = side == 0 ? sf : se;
+    for (int i = tid; i < n_in; i += PREP_THREADS) {
+      const uint32_t l = (uint32_t)sg[i];
+      P0[i] = ((uint64_t)(0xFFFFFFu - (l > 0xFFFFFFu ? 0xFFFFFFu : l)) << 32) | (uint32_t)i;
+    }
+    uint64_t* r1 = block_radix_sort(P0, P1, n_in, 3, hist, s_misc);
+    for (int i = tid; i < n_in; i += PREP_THREADS) { const uint32_t idx = (uint32_t)r1[i]; r1[i] = ((uint64_t)(uint32_t)start[idx] << 32) | idx; }
+    uint64_t* r2 = block_radix_sort(r1, r1 == P0 ? P1 : P0, n_in, start_passes, hist, s_misc);
+    block_containment_flags(r2, start, sg, n_in, sh, s_carry);
+    qsorted = r2;
+  }
+  // survivors in q order: ordered compaction over the waves' chunks
+  int n = 0;
+  {
+    uint32_t* keepidx = reinterpret_cast<uint32_t*>(qsorted == P0 ? P1 : P0);
+    const int chunk = ((n_in + PREP_WAVES - 1) / PREP_WAVES + 63) & ~63;
+    const int c0 = wave * chunk < n_in ? wave * chunk : n_in, c1 = c0 + chunk < n_in ? c0 + chunk : n_in;
+    uint32_t mine = 0;
+    for (int base = c0; base < c1; base += 64) {
+      const int t = base + lane;
+      const bool keep = t < c1 && sh[(uint32_t)qsorted[t]] == 0;
+      mine += (uint32_t)__popcll(__ballot(keep));
+    }
+    if (lane == 0) s_cnt[wave] = mine;
+    __syncthreads();
+    uint32_t at = 0;
+    for (int w = 0; w < PREP_WAVES; ++w) { if (w < wave) at += s_cnt[w]; n += (int)s_cnt[w]; }
+    for (int base = c0; base < c1; base += 64) {
+      const int t = base + lane;
+      const uint32_t idx = t < c1 ? (uint32_t)qsorted[t] : 0u;
+      const bool keep = t < c1 && sh[idx] == 0;
+      const uint64_t bm = __ballot(keep);
+      if (keep) keepidx[at + __popcll(bm & lanemask_lt())] = idx;
+      at += (uint32_t)__popcll(bm);
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += PREP_THREADS) { const uint32_t idx = keepidx[i]; m[i] = Match{se[idx], sf[idx], sg[idx], U.strand}; }
+    __syncthreads();
+  }
+  // ---- clustering (mgaps): union-find over all threads, then grouping by root -------------------------------------------
+  int32_t *rrec = sa, *qrec = sb, *parent = sc, *order = sh;
+  uint64_t *Q0 = reinterpret_cast<uint64_t*>(sd), *Q1 = reinterpret_cast<uint64_t*>(sf);
+  for (int i = tid; i < n; i += PREP_THREADS) {
+    rrec[i] = record_of(R.rec_start, R.n_rec, m[i].r);
+    const int32_t qf = U.strand ? U.len - 1 - m[i].q : m[i].q;
+    qrec[i] = record_of(U.rec_start, U.n_rec, qf);
+    parent[i] = i;
+  }
+  __threadfence_block();
+  __syncthreads();
+  for (int i = tid; i < n; i += PREP_THREADS) {
+    const Match mi = m[i];
+    const int32_t iend = mi.q + mi.len, idiag = mi.q - mi.r;
+    for (int j = i + 1; j < n; ++j) {
+      const Match mj = m[j];
+      const int32_t sep = mj.q - iend;
+      if (sep > MAX_GAP) break;
+      if (rrec[i] != rrec[j] || qrec[i] != qrec[j]) continue;
+      int32_t dd = (mj.q - mj.r) - idiag;
+      if (dd < 0) dd = -dd;
+      int32_t lim = (int32_t)(DIAG_FACTOR * sep);
+      if (lim < DIAG_DIFF) lim = DIAG_DIFF;
+      if (dd <= lim) uf_union(parent, i, j);
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+  for (int i = tid; i < n; i += PREP_THREADS) Q0[i] = ((uint64_t)(uint32_t)uf_find(parent, i) << 32) | (uint32_t)i;
+  __syncthreads();
+  const uint64_t* rs_ = block_radix_sort(Q0, Q1, n, 4, hist, s_misc);
+  for (int i = tid; i < n; i += PREP_THREADS) { const uint64_t x = rs_[i]; parent[i] = (int32_t)(x >> 32); order[i] = (int32_t)(uint32_t)x; }
+  if (tid == 0) O.n_chains[u] = n;   // handed to the chain kernel (which overwrites it with the chain count)
+}
+
 #ifdef PGA_DP_STATS
 __device__ unsigned long long g_cl_stats[16];   // per phase: sum of cycles [0..5], max [6..11], max n_in [12]
 #define CL_MARK(ph) do { const unsigned long long t_now = __builtin_readcyclecounter(); if (lane == 0) { \
@@ -606,7 +832,7 @@ __device__ unsigned long long g_cl_stats[16];   // per phase: sum of cycles [0..
 #endif
 __global__ __launch_bounds__(64) void anim_cluster_wave_kernel(const RefDesc* __restrict__ refs, const UnitDesc* __restrict__ units,
                                                                Match* __restrict__ mem, const uint32_t* __restrict__ mem_count,
-                                                               int32_t* __restrict__ iscratch, ClusterOut O) {
+                                                               int32_t* __restrict__ iscratch, ClusterOut O, int prepared) {
   __shared__ uint32_t hist[256];
   constexpr int WALK_CHUNK = 1024;   // 4 KiB: keeps 32 one-wave workgroups per CU
   __shared__ int32_t s_from[WALK_CHUNK];
@@ -631,6 +857,12 @@ __global__ __launch_bounds__(64) void anim_cluster_wave_kernel(const RefDesc* __
   unsigned long long t_mark = __builtin_readcyclecounter();
   if (lane == 0) atomicMax(&g_cl_stats[12], (unsigned long long)n_in);
 #endif
+  int n = 0;
+  int32_t *rrec = sa, *qrec = sb, *parent = sc, *from = se, *adj = sf, *order = sh;
+  uint64_t *Q0 = reinterpret_cast<uint64_t*>(sd), *Q1 = reinterpret_cast<uint64_t*>(sf);   // (sd,se) and (sf,sg): sort buffers
+  if (prepared) {   // anim_cluster_prep_kernel has done the MUM filter, the union-find and the grouping
+    n = O.n_chains[u];
+  } else {
   // ---- MUM filter -----------------------------------------------------------------------------------------------
   // SoA copies: se = r, sf = q, sg = len; flags in sh
   for (int i = lane; i < n_in; i += 64) { const Match t = m[i]; se[i] = t.r; sf[i] = t.q; sg[i] = t.len; sh[i] = 0; }
@@ -652,7 +884,6 @@ __global__ __launch_bounds__(64) void anim_cluster_wave_kernel(const RefDesc* __
     qsorted = r2;
   }
   // survivors in q order (distinct q among survivors): the query-side order is still there -> compact
-  int n = 0;
   {
     uint32_t* keepidx = reinterpret_cast<uint32_t*>(qsorted == P0 ? P1 : P0);   // the other sort buffer is free
     for (int base = 0; base < n_in; base += 64) {
@@ -669,8 +900,6 @@ __global__ __launch_bounds__(64) void anim_cluster_wave_kernel(const RefDesc* __
   }
   CL_MARK(0);
   // ---- clustering (mgaps) ------------------------------------------------------------------------------------------
-  int32_t *rrec = sa, *qrec = sb, *parent = sc, *from = se, *adj = sf, *order = sh;
-  uint64_t *Q0 = reinterpret_cast<uint64_t*>(sd), *Q1 = reinterpret_cast<uint64_t*>(sf);   // (sd,se) and (sf,sg): sort buffers
   for (int i = lane; i < n; i += 64) {
     rrec[i] = record_of(R.rec_start, R.n_rec, m[i].r);
     const int32_t qf = U.strand ? U.len - 1 - m[i].q : m[i].q;
@@ -703,6 +932,7 @@ __global__ __launch_bounds__(64) void anim_cluster_wave_kernel(const RefDesc* __
     for (int i = lane; i < n; i += 64) { const uint64_t x = rs_[i]; parent[i] = (int32_t)(x >> 32); order[i] = (int32_t)(uint32_t)x; }
     __syncthreads();   // parent[] now = root id of the i-th element in grouped order
   }
+  }   // !prepared
   CL_MARK(2);
   // ---- chain extraction per cluster ----------------------------------------------------------------------------------
   // grouped list: order[t] = match index, parent[t] = its root.  score/from/adj are indexed by LIST POSITION here.
@@ -1746,6 +1976,8 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
     if ((rc = regrow(ctx, A->seedbuf, A->seed_cap))) return rc;
   }
   *n_done = n_pairs;
+  uint32_t n_nonempty = 0;
+  for (uint32_t u = 0; u < n_units; ++u) n_nonempty += cnt[u] != 0;
   moff.assign((size_t)n_units + 1, 0);
   for (uint32_t u = 0; u < n_units; ++u) moff[u + 1] = moff[u] + ((cnt[u] + 2) & ~1u);   // even slice sizes: 8-byte aligned sub-slices
   const size_t M = moff[n_units];
@@ -1780,9 +2012,17 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
   if (getenv("PYANI_ANIM_SCALAR_CLUSTER"))   // debugging aid: the one-thread-per-unit statement of the same algorithm
     hipLaunchKernelGGL(anim_cluster_kernel, dim3((n_units + 63) / 64), dim3(64), 0, ctx->stream, A->refs_d, A->units_d, n_units,
                        A->mem, A->mem_count, A->iscratch, O);
-  else
+  else if (n_nonempty > 3000 || getenv("PYANI_ANIM_WAVE_PREP"))
+    // thousands of units with matches: one wave per unit already fills the machine, and the radix scatters are bound by
+    // HBM's partial-line write rate, which more waves per unit only congest (measured: C3 574 ms vs 724 ms split)
     hipLaunchKernelGGL(anim_cluster_wave_kernel, dim3(n_units), dim3(64), 0, ctx->stream, A->refs_d, A->units_d, A->mem,
+                       A->mem_count, A->iscratch, O, 0);
+  else {   // few units: PREP_WAVES waves share each unit's sorts / union-find so that the largest unit is not the launch time
+    hipLaunchKernelGGL(anim_cluster_prep_kernel, dim3(n_units), dim3(PREP_THREADS), 0, ctx->stream, A->refs_d, A->units_d, A->mem,
                        A->mem_count, A->iscratch, O);
+    hipLaunchKernelGGL(anim_cluster_wave_kernel, dim3(n_units), dim3(64), 0, ctx->stream, A->refs_d, A->units_d, A->mem,
+                       A->mem_count, A->iscratch, O, 1);
+  }
   // work list of (unit, chain): one wave each
   std::vector<int32_t> nch(n_units);
   PG_HIP(ctx, hipMemcpyAsync(nch.data(), A->nch, n_units * 4, hipMemcpyDeviceToHost, ctx->stream));
