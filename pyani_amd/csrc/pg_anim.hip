@@ -453,6 +453,13 @@ __device__ __forceinline__ int32_t from_lane_above(int32_t v, int32_t fill) {  /
 __device__ __forceinline__ int32_t from_lane_below(int32_t v, int32_t fill) {  // lane l <- lane l-1 (lane 0 <- fill)
   return __builtin_amdgcn_update_dpp(fill, v, 0x138 /*wave_shr:1*/, 0xf, 0xf, false);
 }
+// the same shifts for unsigned DP keys whose "nothing there" value is 0: bound_ctrl delivers it, no fill register needed
+__device__ __forceinline__ uint32_t dpp_from_above0(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130 /*wave_shl:1*/, 0xf, 0xf, true);
+}
+__device__ __forceinline__ uint32_t dpp_from_below0(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138 /*wave_shr:1*/, 0xf, 0xf, true);
+}
 __device__ __forceinline__ long long wave_max64(long long v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -1232,32 +1239,37 @@ __device__ ExtResult extend_wave(const SeqView& R, const StrandView& Q, int64_t 
   const int k = lane - W + koff;
   // Cell (i, j) = ((d - k) / 2, (d + k) / 2) of this lane's diagonal exists on anti-diagonal d iff d_lo <= d <= d_hi.
   //
-  // Score and error count of a cell travel as ONE key  K = score << 15 | (32767 - errors):  integer max on keys is
-  // exactly dp_cell's rule "higher score, then fewer errors", a move is one saturating add of a constant, and a wave
-  // shift moves both fields at once.  Ranges: |score| <= 3 * 9999 and errors <= 2 * 9999 within MUMmer's 10 kb DP
-  // limit, so no field overflows; dead cells sit at INT_MIN (saturation keeps them there for negative moves) and
-  // cannot climb above K_LIVE within 10^4 matches.
-  constexpr int32_t K_DEAD = INT32_MIN, K_LIVE = -(32768 << 15);
-  constexpr int32_t K_OPEN = SC_GAP_OPEN * 32768 - 1, K_EXT = SC_GAP_EXT * 32768 - 1;
-  constexpr int32_t K_MATCH = SC_MATCH * 32768, K_MISMATCH = SC_MISMATCH * 32768 - 1;
+  // Score and error count of a cell travel as ONE unsigned key  K = (score + 65536) << 15 | (32767 - errors):  integer
+  // max on keys is exactly dp_cell's rule "higher score, then fewer errors", a move is one (saturating) add / subtract of
+  // a constant, a wave shift moves both fields at once, and 0 is "dead" (what a DPP shift delivers at the band's edges
+  // and what saturation keeps for negative moves).  Ranges: |score| <= 3 * 9999 and errors <= 2 * 9999 within MUMmer's
+  // 10 kb DP limit, so no field overflows; a dead cell cannot climb to K_LIVE (score -32768) within 10^4 matches.
+  // The per-lane best is one word too: (score + 65536) << 15 | d, so "higher score, ties: the later cell" is again max.
+  constexpr uint32_t K_LIVE = 32768u << 15, K_TOP = 0xFFFF8000u;
+  constexpr uint32_t K_OPEN = (uint32_t)(-SC_GAP_OPEN) * 32768u + 1u, K_EXT = (uint32_t)(-SC_GAP_EXT) * 32768u + 1u;
+  constexpr uint32_t K_MATCH = (uint32_t)SC_MATCH * 32768u, K_MISMATCH = (uint32_t)(-SC_MISMATCH) * 32768u + 1u;
   const int32_t d_lo = k < 0 ? -k : k;
   const int32_t d_hi = (2 * rmax + k) < (2 * qmax - k) ? (2 * rmax + k) : (2 * qmax - k);
-  int32_t H = K_DEAD, X = K_DEAD, Y = K_DEAD;
-  int32_t bs = -32768, bd = 0, be = 0;   // per-lane best (score only; ties: the later cell); be = its key.  Dead cells (score field <= -35536) never qualify
-  if (lane == W - koff) { H = 32767; bs = 0; be = 32767; }
+  uint32_t H = 0, X = 0, Y = 0;
+  uint32_t best = K_LIVE, be = 0;   // per-lane best cell: (score + 65536) << 15 | d, and that cell's key
+  if (lane == W - koff) { H = (65536u << 15) | 32767u; best = 65536u << 15; be = H; }
   const int32_t d_end = targeted ? tr + tq : rmax + qmax;
-  constexpr long long BIAS = 1ll << 30;
   WaveSeq ws{s_ring[0], s_ring[1], 0};
   __syncthreads();  // previous user of the ring (same wave) is done
   wave_seq_fill(ws, R, Q, r0, q0, dir, rmax, qmax, lane);
   wave_seq_fill(ws, R, Q, r0, q0, dir, rmax, qmax, lane);
   __syncthreads();
+  // ring positions of this lane's next cell (it has one on every other anti-diagonal; both advance by one each time)
+  const int32_t d_first = (k & 1) ? 1 : 2;
+  uint32_t ir = (uint32_t)(((d_first - k) >> 1) - 1) & 255u, iq = (uint32_t)(((d_first + k) >> 1) - 1) & 255u;
+  uint32_t par = (uint32_t)(1 + k) & 1u;   // (d + k) & 1 at d = 1; toggles every step
   // Break rule with PER-STEP semantics (as the scalar code) at the price of one wave reduction every CHECK steps:
-  // g_known / t_prev = global best score and its anti-diagonal as of the last check; every lane remembers the first
-  // step since then at which it matched or beat g_known (fimp) and a snapshot of its best as of the last check.
+  // g_key / t_prev = global best score (as a key with d = 0) and its anti-diagonal as of the last check; every lane
+  // remembers the first step since then at which it matched or beat it (fimp) and a snapshot of its best.
   constexpr int CHECK = 16;
-  int32_t g_known = 0, t_prev = 0, fimp = 0x7FFFFFFF;
-  int32_t sbs = bs, sbd = bd, sbe = be;
+  uint32_t g_key = 65536u << 15;
+  int32_t t_prev = 0, fimp = 0x7FFFFFFF;
+  uint32_t sbest = best, sbe = be;
   for (int32_t d = 1; d <= d_end; ++d) {
 #ifdef PGA_DP_STATS
     ++n_steps;
@@ -1266,42 +1278,46 @@ __device__ ExtResult extend_wave(const SeqView& R, const StrandView& Q, int64_t 
       wave_seq_fill(ws, R, Q, r0, q0, dir, rmax, qmax, lane);
       __syncthreads();
     }
-    const int32_t up_H = from_lane_above(H, K_DEAD), up_X = from_lane_above(X, K_DEAD);
-    const int32_t lf_H = from_lane_below(H, K_DEAD), lf_Y = from_lane_below(Y, K_DEAD);
-    if (!((d + k) & 1)) {
-      const int32_t i = (d - k) >> 1, j = (d + k) >> 1;
-      const bool ok = ws.ring_r[(i - 1) & 255] == ws.ring_q[(j - 1) & 255];   // dirty codes differ (4 vs 5): never equal
-      const int32_t xa = __builtin_elementwise_add_sat(up_H, K_OPEN), xb = __builtin_elementwise_add_sat(up_X, K_EXT);
-      const int32_t ya = __builtin_elementwise_add_sat(lf_H, K_OPEN), yb = __builtin_elementwise_add_sat(lf_Y, K_EXT);
-      const int32_t nx = xa > xb ? xa : xb, ny = ya > yb ? ya : yb;
-      int32_t nh = __builtin_elementwise_add_sat(H, ok ? K_MATCH : K_MISMATCH);
+    const uint32_t up_H = dpp_from_above0(H), up_X = dpp_from_above0(X);
+    const uint32_t lf_H = dpp_from_below0(H), lf_Y = dpp_from_below0(Y);
+    if (par == 0) {
+      const bool ok = ws.ring_r[ir] == ws.ring_q[iq];   // dirty codes differ (4 vs 5): never equal
+      ir = (ir + 1) & 255u; iq = (iq + 1) & 255u;
+      const uint32_t xa = __builtin_elementwise_sub_sat(up_H, K_OPEN), xb = __builtin_elementwise_sub_sat(up_X, K_EXT);
+      const uint32_t ya = __builtin_elementwise_sub_sat(lf_H, K_OPEN), yb = __builtin_elementwise_sub_sat(lf_Y, K_EXT);
+      const uint32_t nx = xa > xb ? xa : xb, ny = ya > yb ? ya : yb;
+      uint32_t nh = ok ? H + K_MATCH : __builtin_elementwise_sub_sat(H, K_MISMATCH);
       nh = nh > nx ? nh : nx;
       nh = nh > ny ? nh : ny;
       const bool alive = d >= d_lo && d <= d_hi;
-      H = alive ? nh : K_DEAD; X = alive ? nx : K_DEAD; Y = alive ? ny : K_DEAD;
-      const int32_t sc = H >> 15;                          // floor: exact for every live key
-      if (sc >= bs) { bs = sc; bd = d; be = H; }           // ties: the later cell (score only, as the scalar code)
-      const int32_t imp = sc >= g_known ? d : 0x7FFFFFFF;   // g_known >= 0: only live cells
+      H = alive ? nh : 0u; X = alive ? nx : 0u; Y = alive ? ny : 0u;
+      const uint32_t cellkey = (H & K_TOP) | (uint32_t)d;
+      if (cellkey > best) be = H;                          // higher score, or the same score on a later cell
+      best = cellkey > best ? cellkey : best;
+      const int32_t imp = cellkey >= g_key ? d : 0x7FFFFFFF;   // matched or beat the best known at the last check
       fimp = imp < fimp ? imp : fimp;
     }
+    par ^= 1u;
     if ((d % CHECK) == 0 || d == d_end) {
-      // max score, ties: larger d.  bs in [-32768, 32767], bd <= 2 * 9999: (bs + 32768) << 15 | bd fits 32 bits
-      const uint32_t key = wave_max_u32(((uint32_t)(bs + 32768) << 15) | (uint32_t)bd);
-      const int32_t g = (int32_t)(key >> 15) - 32768, t = (int32_t)(key & 32767u);
+      const uint32_t key = wave_max_u32(best);            // max score, ties: larger d
+      const int32_t t = (int32_t)(key & 32767u);
       const int32_t b = t_prev + BREAK_LEN;          // step at which the per-step rule (d - best_d >= BREAK_LEN) fires without an improvement
       const int32_t d1 = (int32_t)wave_min_u32((uint32_t)fimp);
       if (b <= d && d1 > b) {                        // it fired before the first improvement of this interval
-        bs = sbs; bd = sbd; be = sbe;                // results as of the last check (nothing global changed until b)
+        best = sbest; be = sbe;                      // results as of the last check (nothing global changed until b)
         break;
       }
-      if (!__any(H > K_LIVE)) break;
-      g_known = g; t_prev = t; fimp = 0x7FFFFFFF;
-      sbs = bs; sbd = bd; sbe = be;
+      if (!__any(H >= K_LIVE)) break;
+      g_key = key & K_TOP; t_prev = t; fimp = 0x7FFFFFFF;
+      sbest = best; sbe = be;
     }
     if (targeted && d == d_end) {
       const int lt = (tq - tr) - koff + W;
-      const int32_t tH = __shfl(H, lt, 64);
-      if (tH > K_LIVE) { res.di = tr; res.dj = tq; res.score = tH >> 15; res.errors = 32767 - (tH & 32767); res.reached = 1; break; }
+      const uint32_t tH = (uint32_t)__shfl((int)H, lt, 64);
+      if (tH >= K_LIVE) {
+        res.di = tr; res.dj = tq; res.score = (int32_t)(tH >> 15) - 65536; res.errors = 32767 - (int32_t)(tH & 32767u); res.reached = 1;
+        break;
+      }
     }
   }
 #ifdef PGA_DP_STATS
@@ -1315,11 +1331,12 @@ __device__ ExtResult extend_wave(const SeqView& R, const StrandView& Q, int64_t 
 #endif
   if (res.reached) return res;
   // best cell: max score, ties -> larger d, then larger diagonal
-  const long long key = wave_max64((((long long)bs + BIAS) << 32) | ((long long)(uint32_t)bd << 6) | (long long)lane);
+  const long long key = wave_max64(((long long)best << 6) | (long long)lane);
   const int bl = (int)(key & 63);
-  const int32_t gd = (int32_t)((key >> 6) & 0x3FFFFFF);
-  res.score = (int32_t)((key >> 32) - BIAS);
-  res.errors = 32767 - (__shfl(be, bl, 64) & 32767);
+  const uint32_t bkey = (uint32_t)(key >> 6);
+  const int32_t gd = (int32_t)(bkey & 32767u);
+  res.score = (int32_t)(bkey >> 15) - 65536;
+  res.errors = 32767 - (int32_t)((uint32_t)__shfl((int)be, bl, 64) & 32767u);
   const int kk = bl - W + koff;
   res.di = (gd - kk) / 2; res.dj = (gd + kk) / 2;
   return res;
@@ -1977,7 +1994,7 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
   }
   *n_done = n_pairs;
   uint32_t n_nonempty = 0;
-  for (uint32_t u = 0; u < n_units; ++u) n_nonempty += cnt[u] != 0;
+  for (uint32_t u = 0; u < n_units; ++u) n_nonempty += cnt[u] >= 1024;   // units with real work (unrelated pairs have ~50 chance matches)
   moff.assign((size_t)n_units + 1, 0);
   for (uint32_t u = 0; u < n_units; ++u) moff[u + 1] = moff[u] + ((cnt[u] + 2) & ~1u);   // even slice sizes: 8-byte aligned sub-slices
   const size_t M = moff[n_units];
