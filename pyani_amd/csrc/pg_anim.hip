@@ -1263,6 +1263,7 @@ __device__ ExtResult extend_wave(const SeqView& R, const StrandView& Q, int64_t 
   const int32_t d_first = (k & 1) ? 1 : 2;
   uint32_t ir = (uint32_t)(((d_first - k) >> 1) - 1) & 255u, iq = (uint32_t)(((d_first + k) >> 1) - 1) & 255u;
   uint32_t par = (uint32_t)(1 + k) & 1u;   // (d + k) & 1 at d = 1; toggles every step
+  uint8_t rb = ws.ring_r[ir], qb = ws.ring_q[iq];   // bases of the next cell, read one cell ahead (LDS latency off the path)
   // Break rule with PER-STEP semantics (as the scalar code) at the price of one wave reduction every CHECK steps:
   // g_key / t_prev = global best score (as a key with d = 0) and its anti-diagonal as of the last check; every lane
   // remembers the first step since then at which it matched or beat it (fimp) and a snapshot of its best.
@@ -1281,8 +1282,9 @@ __device__ ExtResult extend_wave(const SeqView& R, const StrandView& Q, int64_t 
     const uint32_t up_H = dpp_from_above0(H), up_X = dpp_from_above0(X);
     const uint32_t lf_H = dpp_from_below0(H), lf_Y = dpp_from_below0(Y);
     if (par == 0) {
-      const bool ok = ws.ring_r[ir] == ws.ring_q[iq];   // dirty codes differ (4 vs 5): never equal
+      const bool ok = rb == qb;   // dirty codes differ (4 vs 5): never equal
       ir = (ir + 1) & 255u; iq = (iq + 1) & 255u;
+      rb = ws.ring_r[ir]; qb = ws.ring_q[iq];   // staged at least 18 entries ahead of any cell of the next two steps
       const uint32_t xa = __builtin_elementwise_sub_sat(up_H, K_OPEN), xb = __builtin_elementwise_sub_sat(up_X, K_EXT);
       const uint32_t ya = __builtin_elementwise_sub_sat(lf_H, K_OPEN), yb = __builtin_elementwise_sub_sat(lf_Y, K_EXT);
       const uint32_t nx = xa > xb ? xa : xb, ny = ya > yb ? ya : yb;
