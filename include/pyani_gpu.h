@@ -123,8 +123,10 @@ typedef struct {
   int32_t reserved;
 } pg_anim_result;
 #define PG_ANIM_NO_ALIGNMENT 1
-/* maxmatch must be 0 (pyani's default --mum mode; --maxmatch is not implemented).  filter_1to1 = 0 reproduces
- * pyani's --nofilter (reduction over the unfiltered alignments). */
+/* maxmatch = 0: pyani's default `nucmer --mum` (anchors unique in both genomes); maxmatch != 0: `--maxmatch`
+ * (anim.py:246-289: every maximal match is an anchor) — same pipeline without the uniqueness filter; no MUMmer output
+ * for this mode exists among the reference's fixtures, so it is checked only for consistency with --mum on
+ * repeat-free genomes.  filter_1to1 = 0 reproduces pyani's --nofilter (reduction over the unfiltered alignments). */
 int pg_anim_pairs(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_ids, uint64_t n_pairs, int maxmatch,
                   int filter_1to1, pg_anim_result* out);
 

@@ -84,7 +84,8 @@ def _tuple(rec) -> Tuple[int, int, float, int]:
     return int(rec["ref_aln_len"]), int(rec["qry_aln_len"]), float(rec["identity"]), int(rec["sim_errors"])
 
 
-def calculate_anim_pairs(infiles: Iterable, engine: Engine = None, nofilter: bool = False, skip_zero: bool = False
+def calculate_anim_pairs(infiles: Iterable, engine: Engine = None, nofilter: bool = False, skip_zero: bool = False,
+                         maxmatch: bool = False
                          ) -> Tuple[Dict[Tuple[str, str], Tuple[int, int, float, int]], Dict[str, int]]:
     """All ordered comparisons between the FASTA files (what generate_nucmer_jobs + run_dependency_graph + parse_delta
     produce, anim.py:155-235).  Key (q, s): q is nucmer's reference / pyani's query genome.  Returns (results,
@@ -97,7 +98,7 @@ def calculate_anim_pairs(infiles: Iterable, engine: Engine = None, nofilter: boo
         ids[f.stem], lengths[f.stem] = gid, total
     stems = [f.stem for f in files]
     pairs = [(a, b) for a in stems for b in stems if a != b]
-    recs = eng.anim_pairs([ids[a] for a, _ in pairs], [ids[b] for _, b in pairs], filter_1to1=not nofilter)
+    recs = eng.anim_pairs([ids[a] for a, _ in pairs], [ids[b] for _, b in pairs], filter_1to1=not nofilter, maxmatch=maxmatch)
     if scratch_store:
         eng.clear_genomes()
     out = {}

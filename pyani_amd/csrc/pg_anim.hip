@@ -730,7 +730,7 @@ __device__ void block_containment_flags(const uint64_t* order, const int32_t* st
 
 __global__ __launch_bounds__(PREP_THREADS) void anim_cluster_prep_kernel(const RefDesc* __restrict__ refs, const UnitDesc* __restrict__ units,
                                                                          Match* __restrict__ mem, const uint32_t* __restrict__ mem_count,
-                                                                         int32_t* __restrict__ iscratch, ClusterOut O) {
+                                                                         int32_t* __restrict__ iscratch, ClusterOut O, int maxmatch) {
   __shared__ uint32_t hist[PREP_WAVES * 256];
   __shared__ uint32_t s_misc[4];
   __shared__ int32_t s_carry[PREP_WAVES];
@@ -755,16 +755,26 @@ __global__ __launch_bounds__(PREP_THREADS) void anim_cluster_prep_kernel(const R
   __syncthreads();
   const int start_passes = (R.len > U.len ? R.len : U.len) < (1 << 24) ? 3 : 4;
   const uint64_t* qsorted = nullptr;
-  for (int side = 1; side >= 0; --side) {
+  for (int side = maxmatch ? 0 : 1; side >= 0; --side) {
     const int32_t* start = side == 0 ? sf : se;
-    for (int i = tid; i < n_in; i += PREP_THREADS) {
-      const uint32_t l = (uint32_t)sg[i];
-      P0[i] = ((uint64_t)(0xFFFFFFu - (l > 0xFFFFFFu ? 0xFFFFFFu : l)) << 32) | (uint32_t)i;
+    uint64_t* r0 = P0;
+    if (maxmatch) {   // --maxmatch keeps every maximal match: no uniqueness filter, but a total order (q, len desc, r)
+      for (int i = tid; i < n_in; i += PREP_THREADS) P0[i] = ((uint64_t)(uint32_t)se[i] << 32) | (uint32_t)i;
+      r0 = block_radix_sort(P0, P1, n_in, start_passes, hist, s_misc);
+      for (int i = tid; i < n_in; i += PREP_THREADS) {
+        const uint32_t idx = (uint32_t)r0[i], l = (uint32_t)sg[idx];
+        r0[i] = ((uint64_t)(0xFFFFFFu - (l > 0xFFFFFFu ? 0xFFFFFFu : l)) << 32) | idx;
+      }
+    } else {
+      for (int i = tid; i < n_in; i += PREP_THREADS) {
+        const uint32_t l = (uint32_t)sg[i];
+        P0[i] = ((uint64_t)(0xFFFFFFu - (l > 0xFFFFFFu ? 0xFFFFFFu : l)) << 32) | (uint32_t)i;
+      }
     }
-    uint64_t* r1 = block_radix_sort(P0, P1, n_in, 3, hist, s_misc);
+    uint64_t* r1 = block_radix_sort(r0, r0 == P0 ? P1 : P0, n_in, 3, hist, s_misc);
     for (int i = tid; i < n_in; i += PREP_THREADS) { const uint32_t idx = (uint32_t)r1[i]; r1[i] = ((uint64_t)(uint32_t)start[idx] << 32) | idx; }
     uint64_t* r2 = block_radix_sort(r1, r1 == P0 ? P1 : P0, n_in, start_passes, hist, s_misc);
-    block_containment_flags(r2, start, sg, n_in, sh, s_carry);
+    if (!maxmatch) block_containment_flags(r2, start, sg, n_in, sh, s_carry);
     qsorted = r2;
   }
   // survivors in q order: ordered compaction over the waves' chunks
@@ -839,7 +849,7 @@ __device__ unsigned long long g_cl_stats[16];   // per phase: sum of cycles [0..
 #endif
 __global__ __launch_bounds__(64) void anim_cluster_wave_kernel(const RefDesc* __restrict__ refs, const UnitDesc* __restrict__ units,
                                                                Match* __restrict__ mem, const uint32_t* __restrict__ mem_count,
-                                                               int32_t* __restrict__ iscratch, ClusterOut O, int prepared) {
+                                                               int32_t* __restrict__ iscratch, ClusterOut O, int prepared, int maxmatch) {
   __shared__ uint32_t hist[256];
   constexpr int WALK_CHUNK = 1024;   // 4 KiB: keeps 32 one-wave workgroups per CU
   __shared__ int32_t s_from[WALK_CHUNK];
@@ -876,17 +886,27 @@ __global__ __launch_bounds__(64) void anim_cluster_wave_kernel(const RefDesc* __
   __syncthreads();
   const int start_passes = (R.len > U.len ? R.len : U.len) < (1 << 24) ? 3 : 4;
   const uint64_t* qsorted = nullptr;
-  for (int side = 1; side >= 0; --side) {
+  for (int side = maxmatch ? 0 : 1; side >= 0; --side) {
     const int32_t* start = side == 0 ? sf : se;   // reference intervals first, then query intervals (whose order is reused)
     // sort by (start asc, len desc): LSD = len-desc key first, then start
-    for (int i = lane; i < n_in; i += 64) {
-      const uint32_t l = (uint32_t)sg[i];
-      P0[i] = ((uint64_t)(0xFFFFFFu - (l > 0xFFFFFFu ? 0xFFFFFFu : l)) << 32) | (uint32_t)i;
+    uint64_t* r0 = P0;
+    if (maxmatch) {   // --maxmatch keeps every maximal match: no uniqueness filter, but a total order (q, len desc, r)
+      for (int i = lane; i < n_in; i += 64) P0[i] = ((uint64_t)(uint32_t)se[i] << 32) | (uint32_t)i;
+      r0 = wave_radix_sort(P0, P1, n_in, start_passes, hist);
+      for (int i = lane; i < n_in; i += 64) {
+        const uint32_t idx = (uint32_t)r0[i], l = (uint32_t)sg[idx];
+        r0[i] = ((uint64_t)(0xFFFFFFu - (l > 0xFFFFFFu ? 0xFFFFFFu : l)) << 32) | idx;
+      }
+    } else {
+      for (int i = lane; i < n_in; i += 64) {
+        const uint32_t l = (uint32_t)sg[i];
+        P0[i] = ((uint64_t)(0xFFFFFFu - (l > 0xFFFFFFu ? 0xFFFFFFu : l)) << 32) | (uint32_t)i;
+      }
     }
-    uint64_t* r1 = wave_radix_sort(P0, P1, n_in, 3, hist);
+    uint64_t* r1 = wave_radix_sort(r0, r0 == P0 ? P1 : P0, n_in, 3, hist);
     for (int i = lane; i < n_in; i += 64) { const uint32_t idx = (uint32_t)r1[i]; r1[i] = ((uint64_t)(uint32_t)start[idx] << 32) | idx; }
     uint64_t* r2 = wave_radix_sort(r1, r1 == P0 ? P1 : P0, n_in, start_passes, hist);
-    wave_containment_flags(r2, start, sg, n_in, sh);
+    if (!maxmatch) wave_containment_flags(r2, start, sg, n_in, sh);
     __syncthreads();
     qsorted = r2;
   }
@@ -1849,7 +1869,7 @@ void pg_anim_free_scratch(pg_ctx* ctx) {
 // per (pair, strand) unit; a scatter then gives every per-match array exactly the slice it needs, which is what lets
 // thousands of units be in flight at once within the HBM budget.
 // If the batch needs more than max_matches, only its first n_done pairs are processed (the caller continues from there).
-int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_ids, uint32_t n_pairs, int filter_1to1,
+int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_ids, uint32_t n_pairs, int filter_1to1, int maxmatch,
                       uint64_t max_matches, pg_anim_result* out_host, uint32_t* n_done) {
   AnimScratch* A = anim_scratch(ctx);
   uint32_t n_units = 2 * n_pairs;
@@ -2028,19 +2048,19 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
   if (total)
     hipLaunchKernelGGL(anim_scatter_kernel, dim3((total + 255) / 256), dim3(256), 0, ctx->stream, A->seedbuf, total, A->moff, n_units,
                        A->mem_count, A->mem);
-  if (getenv("PYANI_ANIM_SCALAR_CLUSTER"))   // debugging aid: the one-thread-per-unit statement of the same algorithm
+  if (getenv("PYANI_ANIM_SCALAR_CLUSTER") && !maxmatch)   // debugging aid: the one-thread-per-unit statement of the same algorithm
     hipLaunchKernelGGL(anim_cluster_kernel, dim3((n_units + 63) / 64), dim3(64), 0, ctx->stream, A->refs_d, A->units_d, n_units,
                        A->mem, A->mem_count, A->iscratch, O);
   else if (n_nonempty > 3000 || getenv("PYANI_ANIM_WAVE_PREP"))
     // thousands of units with matches: one wave per unit already fills the machine, and the radix scatters are bound by
     // HBM's partial-line write rate, which more waves per unit only congest (measured: C3 574 ms vs 724 ms split)
     hipLaunchKernelGGL(anim_cluster_wave_kernel, dim3(n_units), dim3(64), 0, ctx->stream, A->refs_d, A->units_d, A->mem,
-                       A->mem_count, A->iscratch, O, 0);
+                       A->mem_count, A->iscratch, O, 0, maxmatch);
   else {   // few units: PREP_WAVES waves share each unit's sorts / union-find so that the largest unit is not the launch time
     hipLaunchKernelGGL(anim_cluster_prep_kernel, dim3(n_units), dim3(PREP_THREADS), 0, ctx->stream, A->refs_d, A->units_d, A->mem,
-                       A->mem_count, A->iscratch, O);
+                       A->mem_count, A->iscratch, O, maxmatch);
     hipLaunchKernelGGL(anim_cluster_wave_kernel, dim3(n_units), dim3(64), 0, ctx->stream, A->refs_d, A->units_d, A->mem,
-                       A->mem_count, A->iscratch, O, 1);
+                       A->mem_count, A->iscratch, O, 1, maxmatch);
   }
   // work list of (unit, chain): one wave each
   std::vector<int32_t> nch(n_units);

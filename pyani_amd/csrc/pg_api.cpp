@@ -669,7 +669,6 @@ int pg_anim_set_batch_budget(pg_ctx* ctx, uint32_t max_pairs, uint64_t max_match
 int pg_anim_pairs(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_ids, uint64_t n_pairs, int maxmatch,
                   int filter_1to1, pg_anim_result* out) {
   if (!ctx || (n_pairs && (!ref_ids || !qry_ids || !out))) return pg_fail(ctx, PG_E_ARG, "bad argument");
-  if (maxmatch) return pg_fail(ctx, PG_E_ARG, "--maxmatch mode is not implemented (pyani's default is --mum)");
   PG_HIP(ctx, hipSetDevice(ctx->device));
   for (uint64_t i = 0; i < n_pairs; ++i)
     if (ref_ids[i] < 0 || (size_t)ref_ids[i] >= ctx->genomes.size() || qry_ids[i] < 0 ||
@@ -699,7 +698,7 @@ int pg_anim_pairs(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_ids, u
     for (uint64_t k = i; k < j; ++k) { r.push_back(ref_ids[order[k]]); q.push_back(qry_ids[order[k]]); }
     res.assign(j - i, pg_anim_result{});
     uint32_t done = 0;
-    if ((rc = pg_anim_run_batch(ctx, r.data(), q.data(), (uint32_t)(j - i), filter_1to1, ctx->anim_batch_matches, res.data(), &done)))
+    if ((rc = pg_anim_run_batch(ctx, r.data(), q.data(), (uint32_t)(j - i), filter_1to1, maxmatch != 0, ctx->anim_batch_matches, res.data(), &done)))
       return rc;
     for (uint64_t k = i; k < i + done; ++k) out[order[k]] = res[k - i];
     i += done;   // pairs beyond the match budget are taken up by the next batch
@@ -716,7 +715,7 @@ int pg_anim_pair_alignments(pg_ctx* ctx, int32_t ref_id, int32_t qry_id, pg_anim
   if ((rc = pg_upload(ctx))) return rc;
   pg_anim_result res{};
   uint32_t done = 0;
-  if ((rc = pg_anim_run_batch(ctx, &ref_id, &qry_id, 1, 1, ctx->anim_batch_matches, &res, &done))) return rc;
+  if ((rc = pg_anim_run_batch(ctx, &ref_id, &qry_id, 1, 1, 0, ctx->anim_batch_matches, &res, &done))) return rc;
   if (res.status == PG_E_CAPACITY) return pg_fail(ctx, PG_E_CAPACITY, "anim: work buffers overflowed for this pair");
   *n_out = (uint32_t)res.reserved;
   const uint32_t n = *n_out < cap ? *n_out : cap;

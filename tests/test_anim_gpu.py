@@ -189,7 +189,7 @@ def test_alignment_records_equal_mummer_delta_and_filter_files(eng, genome_dir, 
 def test_batch_split_does_not_change_results_and_edge_inputs(eng):
     """The internal batching (pairs per launch, match budget) must be invisible: a call split into many tiny launches —
     including launches that stop early because the match budget is exhausted — returns the same records.  Plus the edge
-    inputs: a genome against itself, genomes too short to seed, all-N and empty genomes, unknown ids, --maxmatch."""
+    inputs: a genome against itself, genomes too short to seed, all-N and empty genomes, unknown ids; and --maxmatch."""
     from pyani_amd import synth
     from pyani_amd._lib import PyaniGpuError
     eng.clear_genomes()
@@ -216,6 +216,7 @@ def test_batch_split_does_not_change_results_and_edge_inputs(eng):
         assert int(by[p]["status"]) == 1 and int(by[p]["n_alignments"]) == 0, p    # parse_delta would raise ZeroDivisionError
     with pytest.raises(PyaniGpuError):
         eng.anim_pairs([ids[0]], [999])
-    with pytest.raises(PyaniGpuError):
-        eng.anim_pairs([ids[0]], [ids[1]], maxmatch=True)
     assert len(eng.anim_pairs([], [])) == 0
+    # --maxmatch (every maximal match, not only unique ones): on repeat-free synthetic genomes it must agree with --mum
+    mm = eng.anim_pairs(ra[:30], qa[:30], maxmatch=True)
+    assert mm.tobytes() == ref[:30].tobytes()
