@@ -195,20 +195,28 @@ def assemble_legacy_results(pair_results: Dict[Tuple[str, str], Tuple[int, int, 
 def assemble_run_matrices(pair_results: Dict[Tuple[str, str], Tuple[int, int, float, int]], lengths: Dict[str, int]
                           ) -> Dict[str, pd.DataFrame]:
     """v0.3 semantics of update_comparison_matrices (pyani_orm.py:618-666): [q, s] cells only, diagonals 1 / 1 /
-    length / 0 / 1, hadamard = identity * cov_query."""
+    length / 0 / 1, hadamard = identity * cov_query.  Vectorised: the reference fills the five
+    matrices with one pandas scalar write per cell, which at N = 1000 takes longer than the GPU needs for the pairs."""
     labels = sorted(lengths)
     n = len(labels)
-    ident = pd.DataFrame(np.eye(n), index=labels, columns=labels)
-    cov = pd.DataFrame(np.eye(n), index=labels, columns=labels)
-    aln = pd.DataFrame(np.zeros((n, n)), index=labels, columns=labels)
-    sim = pd.DataFrame(np.zeros((n, n)), index=labels, columns=labels)
-    had = pd.DataFrame(np.eye(n), index=labels, columns=labels)
-    for g in labels:
-        aln.loc[g, g] = lengths[g]
-    for (q, s), (qaln, saln, pid, err) in pair_results.items():
-        ident.loc[q, s] = pid
-        cov.loc[q, s] = qaln / lengths[q]
-        aln.loc[q, s] = qaln
-        sim.loc[q, s] = err
-        had.loc[q, s] = pid * (qaln / lengths[q])
-    return {"identity": ident, "coverage": cov, "aln_lengths": aln, "sim_errors": sim, "hadamard": had}
+    idx = {g: k for k, g in enumerate(labels)}
+    length = np.array([lengths[g] for g in labels], dtype=np.float64)
+    m = len(pair_results)
+    qi = np.fromiter((idx[q] for q, _ in pair_results), dtype=np.int64, count=m)
+    si = np.fromiter((idx[s] for _, s in pair_results), dtype=np.int64, count=m)
+    vals = np.array(list(pair_results.values()), dtype=np.float64).reshape(m, 4)   # (qaln, saln, identity, errors); ints < 2^53
+    ident, cov, had = np.eye(n), np.eye(n), np.eye(n)
+    aln, sim = np.zeros((n, n)), np.zeros((n, n))
+    np.fill_diagonal(aln, length)
+    cq = vals[:, 0] / length[qi]
+    ident[qi, si] = vals[:, 2]
+    cov[qi, si] = cq
+    aln[qi, si] = vals[:, 0]
+    sim[qi, si] = vals[:, 3]
+    had[qi, si] = vals[:, 2] * cq
+
+    def frame(a):
+        return pd.DataFrame(a, index=labels, columns=labels)
+
+    return {"identity": frame(ident), "coverage": frame(cov), "aln_lengths": frame(aln), "sim_errors": frame(sim),
+            "hadamard": frame(had)}
