@@ -244,20 +244,13 @@ __global__ __launch_bounds__(256) void tetra_pairs_kernel(const double* __restri
 constexpr int K0_PF = 3, K0_BLOCK = 512, K0_BLOCKS_PER_CU = 2;
 
 int pg_launch_tetra_count(pg_ctx* ctx, uint32_t n_batch) {
-  static bool attr_set = false;
-  const size_t lds_bytes = K0Lds::WORDS * sizeof(uint32_t);
-  auto kern = tetra_count_kernel<K0_PF, 0, K0_BLOCK>;
-  if (!attr_set) {
-    PG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    attr_set = true;
-  }
+  auto kern = tetra_count_kernel<K0_PF, 0, K0_BLOCK>;   // 73 KiB of static LDS per workgroup
   // d_acc is zero here: zeroed at allocation and re-zeroed by the finalize kernel after every pass
   if (ctx->n_work == 0) return PG_OK;
   const uint32_t want = (uint32_t)ctx->num_cu * K0_BLOCKS_PER_CU, tiles = ctx->n_work * (1024 / K0_BLOCK);
   const uint32_t grid = tiles < want ? tiles : want;
   pg_prof_begin(ctx, PG_K_TETRA_COUNT);
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(K0_BLOCK), lds_bytes, ctx->stream, ctx->d_codes, ctx->d_mask,
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(K0_BLOCK), 0, ctx->stream, ctx->d_codes, ctx->d_mask,
                      ctx->d_seg_tile0, ctx->d_seg_prefix, n_batch, ctx->d_acc);
   pg_prof_end(ctx);
   PG_HIP(ctx, hipGetLastError());

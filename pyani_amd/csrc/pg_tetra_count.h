@@ -212,7 +212,9 @@ __global__ __launch_bounds__(BLOCK) void tetra_count_kernel(const uint32_t* __re
                                                             const uint32_t* __restrict__ seg_tile0,
                                                             const uint32_t* __restrict__ seg_prefix, uint32_t n_batch,
                                                             unsigned long long* __restrict__ acc) {
-  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  // static (not `extern`): the histogram's LDS offsets become instruction immediates; with a dynamic allocation the
+  // compiler emits one `v_add 0, idx` per atomic for the unknown base (97 instructions of the hot loop)
+  __shared__ __attribute__((aligned(16))) uint32_t lds[K0Lds::WORDS];
   using L = K0Lds;
   constexpr uint32_t TPS = 1024 / BLOCK;   // tiles per super-tile
   const uint32_t tid = threadIdx.x;

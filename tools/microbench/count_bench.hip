@@ -14,8 +14,7 @@ template <int PF, int MODE, int BLOCK = 1024>
 void run(const char* name, const uint32_t* codes, const uint32_t* mask, const uint32_t* wt, const uint32_t* wb, uint32_t nw,
          unsigned long long* acc, uint32_t nb, int grid, double bytes) {
   auto k = tetra_count_kernel<PF, MODE, BLOCK>;
-  const size_t lds = K0Lds::WORDS * 4;
-  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const size_t lds = 0;   // the kernel's LDS is static
   hipEvent_t a, b;
   CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
   for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k, dim3(grid), dim3(BLOCK), lds, 0, codes, mask, wt, wb, nb, acc);
