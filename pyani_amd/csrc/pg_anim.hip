@@ -233,19 +233,18 @@ __device__ __forceinline__ bool seed_hit(const RefDesc& R, const SeqView& RV, co
 // unit index until the scatter); unit_count[] is exact even when the buffer overflows, which is what the host uses to
 // size the slices (and to re-run a prefix).
 constexpr int SEED_BLOCK = 1024, SEED_UNROLL = 4;
-constexpr uint32_t SEED_STAGE = 96;    // matches staged in LDS per wave (table 128 KiB + staging must fit 160 KiB)
+constexpr uint32_t SEED_STAGE = 48;    // hits staged in LDS per wave (64 KiB table + staging: two workgroups per CU)
 constexpr size_t SEED_STAGE_BYTES = (SEED_BLOCK / 64) * (SEED_STAGE * sizeof(Match) + 4);
 __global__ __launch_bounds__(SEED_BLOCK) void anim_seed_kernel(const RefDesc* __restrict__ refs, const UnitDesc* __restrict__ units,
                                                                const SeedRef* __restrict__ srefs, const SeedQry* __restrict__ sqry,
                                                                const SeedSlice* __restrict__ slice, uint32_t n_pairs,
                                                                uint32_t slot_mask, Match* __restrict__ buf, uint32_t cap,
-                                                               uint32_t* __restrict__ total, uint32_t* __restrict__ unit_count) {
+                                                               uint32_t* __restrict__ total) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long tab[];
   Match* stage = reinterpret_cast<Match*>(tab + slot_mask + 1);                    // [waves][SEED_STAGE]
   uint32_t* stage_n = reinterpret_cast<uint32_t*>(stage + (SEED_BLOCK / 64) * SEED_STAGE);   // [waves]
   const uint32_t g = blockIdx.x;
   const SeedRef SR = srefs[blockIdx.y];
-  const RefDesc R = refs[blockIdx.y];
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   for (uint32_t i = tid; i <= slot_mask; i += SEED_BLOCK) tab[i] = SLOT_EMPTY;
   if (tid < SEED_BLOCK / 64) stage_n[tid] = 0;
@@ -256,7 +255,6 @@ __global__ __launch_bounds__(SEED_BLOCK) void anim_seed_kernel(const RefDesc* __
     while (atomicCAS(&tab[slot], SLOT_EMPTY, v) != SLOT_EMPTY) slot = (slot + 1) & slot_mask;
   }
   __syncthreads();
-  const SeqView RV{R.codes, R.mask, R.len};
   // this wave's share of the reference's pairs: a contiguous range, its descriptors fetched 64 at a time
   const uint32_t n_mine_all = SR.pair_end - SR.pair_begin;
   const uint32_t per_wave = (n_mine_all + SEED_BLOCK / 64 - 1) / (SEED_BLOCK / 64);
@@ -301,10 +299,8 @@ __global__ __launch_bounds__(SEED_BLOCK) void anim_seed_kernel(const RefDesc* __
         qv[t] = e < c.e_end ? __builtin_nontemporal_load(&c.list[e]) : SLOT_EMPTY;
       }
     };
-    auto process = [&](const Blk& c, const unsigned long long (&qv)[SEED_UNROLL]) {
-      const uint32_t p = chunk + c.j;
-      const int strand = (int)c.strand;
-      const uint32_t unit = 2 * p + c.strand;
+    auto process = [&](const Blk& c, const unsigned long long (&qv)[SEED_UNROLL], bool last) {
+      const uint32_t unit = 2 * (chunk + c.j) + c.strand;
 #pragma unroll
       for (int t = 0; t < SEED_UNROLL; ++t) {
         if (qv[t] == SLOT_EMPTY) continue;
@@ -326,31 +322,26 @@ __global__ __launch_bounds__(SEED_BLOCK) void anim_seed_kernel(const RefDesc* __
             left = diff ? (__ffs(diff) - 1) >> 1 : SEED_STEP;
             if (left == SEED_STEP) continue;   // inside a longer match: an earlier sampled position reports it
           }
-          const UnitDesc U0 = units[2 * p];   // the query's sequence: only needed to verify / extend an actual hit
-          const StrandView QV{SeqView{U0.codes, U0.mask, U0.len}, strand};
-          Match m;
-          if (!seed_hit(R, RV, U0, QV, strand, (int32_t)(uint32_t)v, q, left, m)) continue;
-          // stage in the wave's LDS buffer; it is flushed with one pair of global atomics per SEED_STAGE/2+ matches
-          m.strand = (int32_t)unit;
+          // a hit that may start a match: handed to anim_hit_kernel (verification / extension need the sequences and
+          // many registers; keeping them out of this kernel doubles its waves per SIMD).  Staged per wave in LDS.
+          const Match m{(int32_t)(uint32_t)v, q, left, (int32_t)unit};
           const uint32_t at = atomicAdd(&stage_n[wave], 1u);
           if (at < SEED_STAGE) {
             stage[wave * SEED_STAGE + at] = m;
           } else {   // staging buffer full (a burst of hits): straight to the global buffer
             const uint32_t ga = atomicAdd(total, 1u);
-            atomicAdd(&unit_count[unit], 1u);
             if (ga < cap) buf[ga] = m;
           }
         }
       }
-      // uniform point: flush once the buffer is half full, or at the end of this (pair, strand) unit
+      // uniform point: flush once the buffer is half full
       __builtin_amdgcn_wave_barrier();
       uint32_t n_st = stage_n[wave];
       if (n_st > SEED_STAGE) n_st = SEED_STAGE;
-      if (n_st >= SEED_STAGE / 2 || (n_st && c.e0 + 64 * SEED_UNROLL >= c.e_end)) {
+      if (n_st >= SEED_STAGE / 2 || (n_st && last)) {
         uint32_t base = 0;
         if (lane == 0) {
           base = atomicAdd(total, n_st);
-          atomicAdd(&unit_count[unit], n_st);
           stage_n[wave] = 0;
         }
         base = __shfl(base, 0);
@@ -365,11 +356,59 @@ __global__ __launch_bounds__(SEED_BLOCK) void anim_seed_kernel(const RefDesc* __
     while (A.valid) {
       Blk B = next_of(A);
       if (B.valid) load(B, qb);
-      process(A, qa);
+      process(A, qa, !B.valid && chunk + 64 >= my_end);
       if (!B.valid) break;
       A = next_of(B);
       if (A.valid) load(A, qa);
-      process(B, qb);
+      process(B, qb, !A.valid && chunk + 64 >= my_end);
+    }
+  }
+}
+
+// One thread per recorded hit {r, q, left (-1: undecided), unit}: decide the left extension where the list entries
+// could not, extend to the right, and append matches of at least MIN_MATCH bases to the batch buffer (the `strand`
+// field carries the unit until the scatter) while counting them per unit — exact even if the buffer overflows.
+__global__ __launch_bounds__(256) void anim_hit_kernel(const RefDesc* __restrict__ refs, const UnitDesc* __restrict__ units,
+                                                       const Match* __restrict__ hits, const uint32_t* __restrict__ n_hits, uint32_t hit_cap,
+                                                       Match* __restrict__ buf, uint32_t cap, uint32_t* __restrict__ total,
+                                                       uint32_t* __restrict__ unit_count) {
+  const uint32_t n = *n_hits < hit_cap ? *n_hits : hit_cap;
+  const uint32_t lane = threadIdx.x & 63u;
+  for (uint32_t base = blockIdx.x * blockDim.x; base < n; base += gridDim.x * blockDim.x) {
+    const uint32_t i = base + threadIdx.x;
+    Match m{0, 0, 0, -1};
+    bool have = false;
+    uint32_t unit = 0;
+    if (i < n) {
+      const Match h = hits[i];
+      unit = (uint32_t)h.strand;
+      const UnitDesc U0 = units[unit];
+      const RefDesc R = refs[U0.ref];
+      const SeqView RV{R.codes, R.mask, R.len};
+      const StrandView QV{SeqView{U0.codes, U0.mask, U0.len}, U0.strand};
+      have = seed_hit(R, RV, U0, QV, U0.strand, h.r, h.q, h.len, m);
+    }
+    // bursts of one unit: one pair of atomics per distinct unit and wave
+    bool todo = have;
+    while (true) {
+      const uint64_t rest = __ballot(todo);
+      if (!rest) break;
+      const int leader = __ffsll((unsigned long long)rest) - 1;
+      const uint32_t lu = __shfl(unit, leader);
+      const uint64_t same = __ballot(todo && unit == lu);
+      uint32_t at = 0;
+      if ((int)lane == leader) {
+        const uint32_t c = (uint32_t)__popcll(same);
+        at = atomicAdd(total, c);
+        atomicAdd(&unit_count[lu], c);
+      }
+      at = __shfl(at, leader);
+      if (todo && unit == lu) {
+        at += (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+        m.strand = (int32_t)unit;
+        if (at < cap) buf[at] = m;
+        todo = false;
+      }
     }
   }
 }
@@ -447,9 +486,6 @@ __global__ __launch_bounds__(64) void anim_cluster_kernel(const RefDesc* __restr
   O.n_chains[u] = n_chains;
 }
 
-__device__ __forceinline__ int32_t from_lane_above(int32_t v, int32_t fill) {  // lane l <- lane l+1 (lane 63 <- fill)
-  return __builtin_amdgcn_update_dpp(fill, v, 0x130 /*wave_shl:1*/, 0xf, 0xf, false);
-}
 __device__ __forceinline__ int32_t from_lane_below(int32_t v, int32_t fill) {  // lane l <- lane l-1 (lane 0 <- fill)
   return __builtin_amdgcn_update_dpp(fill, v, 0x138 /*wave_shr:1*/, 0xf, 0xf, false);
 }
@@ -1784,7 +1820,9 @@ struct AnimScratch {
   size_t tasks = 0;
   Match* seedbuf = nullptr;   // batch-wide append buffer of the seed pass
   size_t seed_cap = 0;
-  uint32_t* seed_total = nullptr;
+  uint32_t* seed_total = nullptr;   // [0] matches appended, [1] hits recorded
+  Match* hits_d = nullptr;          // hits recorded by the probe kernel for anim_hit_kernel
+  size_t hit_cap = 0;
 };
 
 template <typename T>
@@ -1857,7 +1895,7 @@ void pg_anim_free_scratch(pg_ctx* ctx) {
   AnimScratch* A = static_cast<AnimScratch*>(ctx->anim_scratch);
   if (!A) return;
   pg_anim_drop_lists(ctx);
-  void* ptrs[] = {A->slice_d, A->choff_d, A->list_cnt, A->srefs_d, A->sqry_d, A->recs_d, A->refs_d, A->units_d, A->mem_count, A->moff, A->nch, A->status, A->out, A->mem, A->cm,
+  void* ptrs[] = {A->hits_d, A->slice_d, A->choff_d, A->list_cnt, A->srefs_d, A->sqry_d, A->recs_d, A->refs_d, A->units_d, A->mem_count, A->moff, A->nch, A->status, A->out, A->mem, A->cm,
                   A->iscratch, A->order, A->prev, A->next, A->alnof, A->chains, A->fw, A->bw, A->S.alns, A->S.a_rrec,
                   A->S.a_qrec, A->S.idx, A->S.from, A->S.sc, A->wl_d, A->seedbuf, A->seed_total, A->tasks_d};
   for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -1982,21 +2020,41 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
   if (!A->seedbuf) {
     A->seed_cap = (size_t)max_matches + 1024;   // the whole batch budget (2.4 GB by default): no overflow re-runs
     if ((rc = regrow(ctx, A->seedbuf, A->seed_cap))) return rc;
-    if ((rc = regrow(ctx, A->seed_total, 1))) return rc;
+    if ((rc = regrow(ctx, A->seed_total, 2))) return rc;
   }
   std::vector<uint32_t> cnt(n_units), moff;
   uint32_t total = 0, pairs_fit = 0;
-  for (int attempt = 0; attempt < 2; ++attempt) {
+  // hit buffer: the matches of the batch budget plus the chance 16-mer hits of unrelated pairs (~1200 per 5 Mb unit)
+  {
+    const size_t want = (size_t)max_matches + (size_t)4096 * n_units + 1024;
+    if (want > A->hit_cap) { if ((rc = regrow(ctx, A->hits_d, want))) return rc; A->hit_cap = want; }
+  }
+  for (int attempt = 0;; ++attempt) {
+    if (attempt == 8) return pg_fail(ctx, PG_E_CAPACITY, "anim seeding: buffers still overflow after repeated splitting");
+    uint32_t counts[2] = {0, 0};   // matches appended, hits recorded
     fill_srefs(n_pairs);
     PG_HIP(ctx, hipMemcpyAsync(A->srefs_d, srefs.data(), n_refs * sizeof(SeedRef), hipMemcpyHostToDevice, ctx->stream));
     PG_HIP(ctx, hipMemsetAsync(A->mem_count, 0, n_units * 4, ctx->stream));
-    PG_HIP(ctx, hipMemsetAsync(A->seed_total, 0, 4, ctx->stream));
-    hipLaunchKernelGGL(anim_seed_kernel, dim3(SEED_GROUPS, n_refs), dim3(SEED_BLOCK), (size_t)slots * 8 + SEED_STAGE_BYTES, ctx->stream, A->refs_d, A->units_d,
-                       A->srefs_d, A->sqry_d, A->slice_d, slice_stride, slots - 1, A->seedbuf, (uint32_t)A->seed_cap, A->seed_total,
-                       A->mem_count);
+    PG_HIP(ctx, hipMemsetAsync(A->seed_total, 0, 8, ctx->stream));   // [0] matches, [1] hits
+    hipLaunchKernelGGL(anim_seed_kernel, dim3(SEED_GROUPS, n_refs), dim3(SEED_BLOCK), (size_t)slots * 8 + SEED_STAGE_BYTES, ctx->stream,
+                       A->refs_d, A->units_d, A->srefs_d, A->sqry_d, A->slice_d, slice_stride, slots - 1, A->hits_d,
+                       (uint32_t)A->hit_cap, A->seed_total + 1);
+    hipLaunchKernelGGL(anim_hit_kernel, dim3((uint32_t)ctx->num_cu * 8u), dim3(256), 0, ctx->stream, A->refs_d, A->units_d, A->hits_d,
+                       A->seed_total + 1, (uint32_t)A->hit_cap, A->seedbuf, (uint32_t)A->seed_cap, A->seed_total, A->mem_count);
     PG_HIP(ctx, hipMemcpyAsync(cnt.data(), A->mem_count, n_units * 4, hipMemcpyDeviceToHost, ctx->stream));
-    PG_HIP(ctx, hipMemcpyAsync(&total, A->seed_total, 4, hipMemcpyDeviceToHost, ctx->stream));
+    PG_HIP(ctx, hipMemcpyAsync(counts, A->seed_total, 8, hipMemcpyDeviceToHost, ctx->stream));
     PG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    total = counts[0];
+    if (counts[1] > A->hit_cap) {   // hits were dropped: the counts are incomplete -> seed half as many pairs
+      if (n_pairs == 1) {
+        A->hit_cap = (size_t)counts[1] + 1024;
+        if ((rc = regrow(ctx, A->hits_d, A->hit_cap))) return rc;
+      } else {
+        n_pairs = (n_pairs + 1) / 2;
+        n_units = 2 * n_pairs;
+      }
+      continue;
+    }
     uint64_t tot = 0, raw = 0;
     pairs_fit = 0;
     for (uint32_t p = 0; p < n_pairs; ++p) {
@@ -2009,7 +2067,6 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
     n_pairs = pairs_fit;
     n_units = 2 * n_pairs;
     if (total <= A->seed_cap) break;
-    if (attempt == 1) return pg_fail(ctx, PG_E_CAPACITY, "anim seeding: append buffer overflowed twice");
     // overflow: make room for the prefix of pairs that fits the batch budget and seed that prefix again
     A->seed_cap = (size_t)(raw + raw / 8 + 1024);
     if ((rc = regrow(ctx, A->seedbuf, A->seed_cap))) return rc;
