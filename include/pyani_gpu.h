@@ -131,7 +131,7 @@ int pg_anim_pairs(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_ids, u
                   int filter_1to1, pg_anim_result* out);
 
 /* Work-memory budget of one internal launch of pg_anim_pairs: at most max_pairs ordered pairs and max_matches exact
- * matches (about 230 bytes of device scratch each; default 16384 pairs / 150 Mi matches = ~36 GB).  Larger calls are
+ * matches (about 264 bytes of device scratch each; default 65536 pairs / 256 Mi matches = ~68 GB).  Larger calls are
  * split transparently; results do not depend on the split. */
 int pg_anim_set_batch_budget(pg_ctx* ctx, uint32_t max_pairs, uint64_t max_matches);
 

@@ -83,8 +83,8 @@ struct pg_ctx {
   uint64_t prof_n[PG_K__COUNT] = {0, 0, 0, 0};
   int num_cu = 256;
   void* anim_scratch = nullptr;  // AnimScratch (pg_anim.hip), grows on demand
-  uint32_t anim_batch_pairs = 16384;          // upper bound of ordered pairs per launch
-  uint64_t anim_batch_matches = 150ull << 20; // exact matches per launch (~210 B of scratch each: ~33 GB)
+  uint32_t anim_batch_pairs = 65536;          // upper bound of ordered pairs per launch (every launch pays its slowest unit once)
+  uint64_t anim_batch_matches = 256ull << 20; // exact matches per launch (~264 B of scratch each: ~68 GB of the 288 GB)
 };
 
 int pg_fail(pg_ctx* ctx, int code, const std::string& msg);
