@@ -131,9 +131,6 @@ PG_HD ExtResult extend_banded(const RefT& R, const QryT& Q, int64_t r0, int64_t 
   cur[W - koff].h = 0; bs[W - koff] = 0;   // cell (0, 0) lies on diagonal 0
   const int32_t d_end = targeted ? tr + tq : rmax + qmax;
   int32_t gbest = 0, gbest_d = 0;
-#ifdef PGA_EXP_XDROP
-  int32_t gbest_run = 0;
-#endif
   for (int32_t d = 1; d <= d_end; ++d) {
     DpCell nxt[BAND];
     bool alive = false;
@@ -151,16 +148,7 @@ PG_HD ExtResult extend_banded(const RefT& R, const QryT& Q, int64_t r0, int64_t 
       const DpCell& U = cur[has_up ? l + 1 : l];
       const DpCell& L = cur[has_left ? l - 1 : l];
       nxt[l] = dp_cell(has_up, U.h, U.he, U.x, U.xe, has_left, L.h, L.he, L.y, L.ye, has_diag, cur[l].h, cur[l].he, ok);
-#ifdef PGA_EXP_XDROP
-      if (!targeted && nxt[l].h > NEG_INF / 2 && nxt[l].h < gbest_run - PGA_EXP_XDROP) nxt[l] = DpCell{NEG_INF, 0, NEG_INF, 0, NEG_INF, 0};
-#endif
-#ifdef PGA_EXP_FLOOR
-      if (!targeted && nxt[l].h > NEG_INF / 2 && nxt[l].h < PGA_EXP_FLOOR) nxt[l] = DpCell{NEG_INF, 0, NEG_INF, 0, NEG_INF, 0};
-#endif
       if (nxt[l].h > NEG_INF / 2) {
-#ifdef PGA_EXP_XDROP
-        if (nxt[l].h > gbest_run) gbest_run = nxt[l].h;
-#endif
         alive = true;
         if (nxt[l].h > bs[l] || (nxt[l].h == bs[l] && d >= bd[l])) { bs[l] = nxt[l].h; bd[l] = d; be[l] = nxt[l].he; }
       }
