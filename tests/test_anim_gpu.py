@@ -220,3 +220,36 @@ def test_batch_split_does_not_change_results_and_edge_inputs(eng):
     # --maxmatch (every maximal match, not only unique ones): on repeat-free synthetic genomes it must agree with --mum
     mm = eng.anim_pairs(ra[:30], qa[:30], maxmatch=True)
     assert mm.tobytes() == ref[:30].tobytes()
+
+
+def _resplit(seq, step, salt):
+    """Same cutting rule as tools/make_anim_synth_host.py (contig-shaped records, some too short to seed)."""
+    cuts, p, k = [0], 0, 0
+    while p < len(seq):
+        p = min(len(seq), p + step + ((k * 7919 + salt) % step) - step // 2 + (12 if k % 9 == 4 else 0))
+        if k % 11 == 5:
+            p = min(len(seq), cuts[-1] + 15)
+        cuts.append(p)
+        k += 1
+    return np.array(sorted(set(cuts)), dtype=np.uint64)
+
+
+def test_many_records_equal_scalar_host_statement(eng):
+    """Draft-genome shape: ~150 records per genome of unequal length.  Alignments must stop at record ends and the
+    per-sequence interval unions must hold: GPU == scalar host build of the same core (tools/make_anim_synth_host.py)."""
+    from pyani_amd import synth
+    fx = json.loads((GOLD / "anim_synth_host.json").read_text())
+    n, L, seed, step = fx["n"], fx["length"], fx["seed"], fx["contigs"]["step"]
+    eng.clear_genomes()
+    ids = []
+    for g in range(3):
+        seq, _ = synth.genome(seed, n, g, L)
+        off = _resplit(seq, step, g)
+        assert len(off) > 100
+        ids.append(eng.add_genome(seq, off))
+    eng.upload()
+    pairs = [(a, b) for a in range(3) for b in range(3) if a != b]
+    res = eng.anim_pairs([ids[a] for a, _ in pairs], [ids[b] for _, b in pairs])
+    for (a, b), r in zip(pairs, res):
+        got = [int(r["ref_aln_len"]), int(r["qry_aln_len"]), float(r["identity"]).hex(), int(r["sim_errors"]), int(r["n_alignments"])]
+        assert got == fx["contigs"]["pairs"][f"{a},{b}"], (a, b, got)

@@ -37,4 +37,36 @@ for a in range(N):
             out["pairs"][f"{a},{b},{mode}"] = [int(f[0]), int(f[1]), float(f[2]).hex() if f[2] not in ("nan", "-nan") else "nan",
                                                int(f[3]), int(f[4])]
         print(a, b, out["pairs"][f"{a},{b},filter"], flush=True)
+# draft-genome shape: the same genomes cut into many records of unequal length (contigs), some of them shorter than a
+# seed; alignments must stop at record ends and the per-record bookkeeping (record_of, unions per sequence) must hold
+import numpy as np  # noqa: E402
+
+
+def resplit(seq, step, salt):
+    cuts, p, k = [0], 0, 0
+    while p < len(seq):
+        p = min(len(seq), p + step + ((k * 7919 + salt) % step) - step // 2 + (12 if k % 9 == 4 else 0))
+        if k % 11 == 5:
+            p = min(len(seq), cuts[-1] + 15)          # a contig too short to seed
+        cuts.append(p)
+        k += 1
+    return np.array(sorted(set(cuts)), dtype=np.uint64)
+
+
+out["contigs"] = {"step": 3000, "pairs": {}}
+cpaths = []
+for g in range(3):
+    seq, _ = synth.genome(SEED, N, g, L)
+    off = resplit(seq, 3000, g)
+    p = tmp / f"contigs_{g}.fna"
+    synth.write_fasta(p, seq, off, f"c{g}")
+    cpaths.append(p)
+for a in range(3):
+    for b in range(3):
+        if a == b:
+            continue
+        r = subprocess.run([str(exe), str(cpaths[a]), str(cpaths[b])], capture_output=True, text=True, check=True)
+        f = r.stdout.split()
+        out["contigs"]["pairs"][f"{a},{b}"] = [int(f[0]), int(f[1]), float(f[2]).hex(), int(f[3]), int(f[4])]
+        print("contigs", a, b, out["contigs"]["pairs"][f"{a},{b}"], flush=True)
 (ROOT / "tests" / "golden" / "anim_synth_host.json").write_text(json.dumps(out, indent=0, sort_keys=True))
