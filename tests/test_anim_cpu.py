@@ -73,3 +73,62 @@ def test_one_to_one_filter_matches_delta_filter(filter_check):
         exact_files += mine == want
     assert total == 12734 and wrong == 0, (wrong, total)
     assert exact_files == 27
+
+
+def test_run_matrices_vectorised_equals_cellwise_definition():
+    """assemble_run_matrices (pyani_orm.update_comparison_matrices semantics, vectorised) against the cell-by-cell
+    definition: [q, s] cells only, diagonals 1 / 1 / length / 0 / 1, hadamard = identity * cov_query."""
+    import numpy as np
+    from pyani_amd import anim
+    rng = np.random.default_rng(7)
+    labels = [f"g{k:02d}" for k in rng.permutation(12)]
+    lengths = {g: int(rng.integers(700_000, 6_000_000)) for g in labels}
+    res = {}
+    for q in labels:
+        for s in labels:
+            if q != s and rng.random() < 0.8:          # some pairs have no result (no alignment)
+                res[(q, s)] = (int(rng.integers(1, lengths[q])), int(rng.integers(1, lengths[s])), float(rng.random()),
+                               int(rng.integers(0, 50_000)))
+    m = anim.assemble_run_matrices(res, lengths)
+    order = sorted(labels)
+    for name in ("identity", "coverage", "aln_lengths", "sim_errors", "hadamard"):
+        assert list(m[name].index) == order and list(m[name].columns) == order
+    for q in order:
+        for s in order:
+            if q == s:
+                want = (1.0, 1.0, float(lengths[q]), 0.0, 1.0)
+            elif (q, s) in res:
+                qa, _, pid, err = res[(q, s)]
+                want = (pid, qa / lengths[q], float(qa), float(err), pid * (qa / lengths[q]))
+            else:
+                want = (0.0, 0.0, 0.0, 0.0, 0.0)
+            got = tuple(float(m[n].loc[q, s]) for n in ("identity", "coverage", "aln_lengths", "sim_errors", "hadamard"))
+            assert got == want, (q, s)
+
+
+def test_write_delta_round_trip_and_grammar(tmp_path):
+    """anim.write_delta: MUMmer .delta grammar (path line, NUCMER, '>' blocks, 7-field headers, 0 terminators), record ids
+    and lengths from the FASTA files, filtered / unfiltered variants; the oracle's parse_delta reads the result back."""
+    import numpy as np
+    from pyani_amd import anim
+    from pyani_amd.engine import Engine
+    ref = tmp_path / "r.fna"
+    qry = tmp_path / "q.fna"
+    ref.write_text(">r1 first\n" + "ACGT" * 50 + "\n>r2\n" + "A" * 120 + "\n")
+    qry.write_text(">q1\n" + "ACGT" * 40 + "\n" + "GG" * 5 + "\n")
+    assert anim.fasta_records(ref) == [("r1", 200), ("r2", 120)] and anim.fasta_records(qry) == [("q1", 170)]
+    al = np.zeros(3, dtype=Engine.ALN_DTYPE)
+    al[0] = (0, 0, 1, 160, 1, 160, 2, 3)
+    al[1] = (1, 0, 5, 60, 170, 115, 1, 3)      # reverse strand: qs > qe
+    al[2] = (0, 0, 150, 200, 100, 150, 9, 1)   # dropped by the 1-to-1 filter
+    out = tmp_path / "r_vs_q.filter"
+    assert anim.write_delta(out, ref, qry, al, filtered=True) == 2
+    lines = out.read_text().splitlines()
+    assert lines[1] == "NUCMER" and lines[0].split()[0].endswith("r.fna")
+    assert lines[2] == ">r1 q1 200 170" and lines[3] == "1 160 1 160 2 2 0" and lines[4] == "0"
+    assert lines[5] == ">r2 q1 120 170" and lines[6] == "5 60 170 115 1 1 0"
+    # reference intervals on two sequences: 160 + 56; query intervals 1-160 and 115-170 on one sequence: union 170
+    assert anim_oracle.parse_delta(out) == (160 + 56, 170, (160 * 2 - 4 + 56 * 2 - 2) / (160 * 2 + 56 * 2), 3)
+    out2 = tmp_path / "r_vs_q.delta"
+    assert anim.write_delta(out2, ref, qry, al, filtered=False) == 3
+    assert len(anim_oracle.read_delta(out2)[0]) == 3
