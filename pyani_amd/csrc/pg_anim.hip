@@ -239,7 +239,7 @@ __global__ __launch_bounds__(SEED_BLOCK) void anim_seed_kernel(const RefDesc* __
                                                                const SeedRef* __restrict__ srefs, const SeedQry* __restrict__ sqry,
                                                                const SeedSlice* __restrict__ slice, uint32_t n_pairs,
                                                                uint32_t slot_mask, Match* __restrict__ buf, uint32_t cap,
-                                                               uint32_t* __restrict__ total) {
+                                                               uint32_t* __restrict__ total, uint32_t* __restrict__ hit_count) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long tab[];
   Match* stage = reinterpret_cast<Match*>(tab + slot_mask + 1);                    // [waves][SEED_STAGE]
   uint32_t* stage_n = reinterpret_cast<uint32_t*>(stage + (SEED_BLOCK / 64) * SEED_STAGE);   // [waves]
@@ -330,23 +330,35 @@ __global__ __launch_bounds__(SEED_BLOCK) void anim_seed_kernel(const RefDesc* __
             stage[wave * SEED_STAGE + at] = m;
           } else {   // staging buffer full (a burst of hits): straight to the global buffer
             const uint32_t ga = atomicAdd(total, 1u);
+            atomicAdd(&hit_count[unit], 1u);
             if (ga < cap) buf[ga] = m;
           }
         }
       }
-      // uniform point: flush once the buffer is half full
+      // uniform point: flush once the buffer is half full (or at the very end).  Staged hits sit in processing order,
+      // i.e. in runs of one unit: every run adds its length to its unit's hit count (one atomic per run, not per hit).
       __builtin_amdgcn_wave_barrier();
       uint32_t n_st = stage_n[wave];
       if (n_st > SEED_STAGE) n_st = SEED_STAGE;
       if (n_st >= SEED_STAGE / 2 || (n_st && last)) {
+        static_assert(SEED_STAGE <= 64, "one staged hit per lane at flush time");
         uint32_t base = 0;
         if (lane == 0) {
           base = atomicAdd(total, n_st);
           stage_n[wave] = 0;
         }
         base = __shfl(base, 0);
-        for (uint32_t i = lane; i < n_st; i += 64)
-          if (base + i < cap) buf[base + i] = stage[wave * SEED_STAGE + i];
+        Match m{0, 0, 0, -1};
+        if (lane < n_st) m = stage[wave * SEED_STAGE + lane];
+        const int32_t prev_unit = __shfl_up(m.strand, 1, 64);
+        const bool start = lane < n_st && (lane == 0 || prev_unit != m.strand);
+        const uint64_t starts = __ballot(start);
+        if (start) {
+          const uint64_t later = starts >> 1 >> lane;   // starts after this lane
+          const uint32_t run = later ? (uint32_t)__ffsll((unsigned long long)later) : n_st - lane;
+          atomicAdd(&hit_count[(uint32_t)m.strand], run);
+        }
+        if (lane < n_st && base + lane < cap) buf[base + lane] = m;
         __builtin_amdgcn_wave_barrier();
       }
     };
@@ -365,49 +377,90 @@ __global__ __launch_bounds__(SEED_BLOCK) void anim_seed_kernel(const RefDesc* __
   }
 }
 
-// One thread per recorded hit {r, q, left (-1: undecided), unit}: decide the left extension where the list entries
-// could not, extend to the right, and append matches of at least MIN_MATCH bases to the batch buffer (the `strand`
-// field carries the unit until the scatter) while counting them per unit — exact even if the buffer overflows.
-__global__ __launch_bounds__(256) void anim_hit_kernel(const RefDesc* __restrict__ refs, const UnitDesc* __restrict__ units,
-                                                       const Match* __restrict__ hits, const uint32_t* __restrict__ n_hits, uint32_t hit_cap,
-                                                       Match* __restrict__ buf, uint32_t cap, uint32_t* __restrict__ total,
-                                                       uint32_t* __restrict__ unit_count) {
-  const uint32_t n = *n_hits < hit_cap ? *n_hits : hit_cap;
+// hoff[0..n] = exclusive prefix of cnt[0..n); cursor[] zeroed.  One workgroup (n <= 2 * pairs of a launch).
+__global__ __launch_bounds__(1024) void anim_hoff_kernel(const uint32_t* __restrict__ cnt, uint32_t n, uint32_t* __restrict__ hoff,
+                                                         uint32_t* __restrict__ cursor) {
+  __shared__ uint32_t s_part[1024];
+  const uint32_t tid = threadIdx.x;
+  const uint32_t per = (n + 1023) / 1024, lo = tid * per, hi = lo + per < n ? lo + per : n;
+  uint32_t sum = 0;
+  for (uint32_t i = lo; i < hi; ++i) sum += cnt[i];
+  s_part[tid] = sum;
+  __syncthreads();
+  if (tid == 0) { uint32_t run = 0; for (int i = 0; i < 1024; ++i) { const uint32_t t = s_part[i]; s_part[i] = run; run += t; } hoff[n] = run; }
+  __syncthreads();
+  uint32_t run = s_part[tid];
+  for (uint32_t i = lo; i < hi; ++i) { hoff[i] = run; run += cnt[i]; cursor[i] = 0; }
+}
+
+// hits -> per-unit slices (hoff): same dealing as anim_scatter_kernel, records unchanged
+__global__ __launch_bounds__(256) void anim_hit_scatter_kernel(const Match* __restrict__ buf, const uint32_t* __restrict__ n_hits, uint32_t cap,
+                                                               const uint32_t* __restrict__ hoff, uint32_t* __restrict__ cursor,
+                                                               Match* __restrict__ out) {
+  const uint32_t n = *n_hits < cap ? *n_hits : cap;
   const uint32_t lane = threadIdx.x & 63u;
   for (uint32_t base = blockIdx.x * blockDim.x; base < n; base += gridDim.x * blockDim.x) {
     const uint32_t i = base + threadIdx.x;
-    Match m{0, 0, 0, -1};
-    bool have = false;
-    uint32_t unit = 0;
-    if (i < n) {
-      const Match h = hits[i];
-      unit = (uint32_t)h.strand;
-      const UnitDesc U0 = units[unit];
-      const RefDesc R = refs[U0.ref];
-      const SeqView RV{R.codes, R.mask, R.len};
-      const StrandView QV{SeqView{U0.codes, U0.mask, U0.len}, U0.strand};
-      have = seed_hit(R, RV, U0, QV, U0.strand, h.r, h.q, h.len, m);
-    }
-    // bursts of one unit: one pair of atomics per distinct unit and wave
-    bool todo = have;
+    Match m{0, 0, 0, 0};
+    if (i < n) m = buf[i];
+    const uint32_t u = (uint32_t)m.strand;
+    bool todo = i < n;
     while (true) {
       const uint64_t rest = __ballot(todo);
       if (!rest) break;
       const int leader = __ffsll((unsigned long long)rest) - 1;
-      const uint32_t lu = __shfl(unit, leader);
-      const uint64_t same = __ballot(todo && unit == lu);
+      const uint32_t lu = __shfl(u, leader);
+      const uint64_t same = __ballot(todo && u == lu);
       uint32_t at = 0;
-      if ((int)lane == leader) {
-        const uint32_t c = (uint32_t)__popcll(same);
-        at = atomicAdd(total, c);
-        atomicAdd(&unit_count[lu], c);
-      }
+      if ((int)lane == leader) at = atomicAdd(&cursor[lu], (uint32_t)__popcll(same));
       at = __shfl(at, leader);
-      if (todo && unit == lu) {
-        at += (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+      if (todo && u == lu) {
+        out[(size_t)hoff[u] + at + (uint32_t)__popcll(same & ((1ull << lane) - 1ull))] = m;
+        todo = false;
+      }
+    }
+  }
+}
+
+// One WORKGROUP per unit walks that unit's recorded hits {r, q, left (-1: undecided), unit}: decide the left extension
+// where the list entries could not, extend to the right, and append matches of at least MIN_MATCH bases to the batch
+// buffer (the `strand` field carries the unit until the scatter) while counting them — exact even if the buffer
+// overflows.  A unit's hits touch only its own two genomes (≈ 4 MB packed): processed by one workgroup, i.e. on one XCD,
+// they are served by that XCD's L2 instead of one HBM line fetch per access.
+__global__ __launch_bounds__(256) void anim_hit_kernel(const RefDesc* __restrict__ refs, const UnitDesc* __restrict__ units,
+                                                       const Match* __restrict__ hits, const uint32_t* __restrict__ hoff,
+                                                       const uint32_t* __restrict__ n_hits, uint32_t hit_cap,
+                                                       Match* __restrict__ buf, uint32_t cap, uint32_t* __restrict__ total,
+                                                       uint32_t* __restrict__ unit_count) {
+  const uint32_t unit = blockIdx.x;
+  const uint32_t h0 = hoff[unit], h1 = hoff[unit + 1];
+  if (h0 == h1 || *n_hits > hit_cap) return;   // (hits were dropped: the slices are incomplete, the host retries with fewer pairs)
+  const uint32_t lane = threadIdx.x & 63u;
+  const UnitDesc U0 = units[unit];
+  const RefDesc R = refs[U0.ref];
+  const SeqView RV{R.codes, R.mask, R.len};
+  const StrandView QV{SeqView{U0.codes, U0.mask, U0.len}, U0.strand};
+  for (uint32_t base = h0; base < h1; base += blockDim.x) {
+    const uint32_t i = base + threadIdx.x;
+    Match m{0, 0, 0, (int32_t)unit};
+    bool have = false;
+    if (i < h1) {
+      const Match h = hits[i];
+      have = seed_hit(R, RV, U0, QV, U0.strand, h.r, h.q, h.len, m);
+    }
+    const uint64_t got = __ballot(have);
+    if (got) {
+      uint32_t at = 0;
+      if (lane == 0) {
+        const uint32_t c = (uint32_t)__popcll(got);
+        at = atomicAdd(total, c);
+        atomicAdd(&unit_count[unit], c);
+      }
+      at = __shfl(at, 0);
+      if (have) {
+        at += (uint32_t)__popcll(got & ((1ull << lane) - 1ull));
         m.strand = (int32_t)unit;
         if (at < cap) buf[at] = m;
-        todo = false;
       }
     }
   }
@@ -1822,6 +1875,8 @@ struct AnimScratch {
   size_t seed_cap = 0;
   uint32_t* seed_total = nullptr;   // [0] matches appended, [1] hits recorded
   Match* hits_d = nullptr;          // hits recorded by the probe kernel for anim_hit_kernel
+  Match* hits_sorted = nullptr;     // the same, dealt into per-unit slices (hoff)
+  uint32_t *hit_count = nullptr, *hoff = nullptr, *hit_cursor = nullptr;   // per unit
   size_t hit_cap = 0;
 };
 
@@ -1895,7 +1950,7 @@ void pg_anim_free_scratch(pg_ctx* ctx) {
   AnimScratch* A = static_cast<AnimScratch*>(ctx->anim_scratch);
   if (!A) return;
   pg_anim_drop_lists(ctx);
-  void* ptrs[] = {A->hits_d, A->slice_d, A->choff_d, A->list_cnt, A->srefs_d, A->sqry_d, A->recs_d, A->refs_d, A->units_d, A->mem_count, A->moff, A->nch, A->status, A->out, A->mem, A->cm,
+  void* ptrs[] = {A->hits_sorted, A->hit_count, A->hoff, A->hit_cursor, A->hits_d, A->slice_d, A->choff_d, A->list_cnt, A->srefs_d, A->sqry_d, A->recs_d, A->refs_d, A->units_d, A->mem_count, A->moff, A->nch, A->status, A->out, A->mem, A->cm,
                   A->iscratch, A->order, A->prev, A->next, A->alnof, A->chains, A->fw, A->bw, A->S.alns, A->S.a_rrec,
                   A->S.a_qrec, A->S.idx, A->S.from, A->S.sc, A->wl_d, A->seedbuf, A->seed_total, A->tasks_d};
   for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -1951,6 +2006,9 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
     if ((rc = regrow(ctx, A->mem_count, n_units))) return rc;
     if ((rc = regrow(ctx, A->moff, (size_t)n_units + 1))) return rc;
     if ((rc = regrow(ctx, A->choff_d, (size_t)n_units + 1))) return rc;
+    if ((rc = regrow(ctx, A->hit_count, n_units))) return rc;
+    if ((rc = regrow(ctx, A->hoff, (size_t)n_units + 1))) return rc;
+    if ((rc = regrow(ctx, A->hit_cursor, n_units))) return rc;
     if ((rc = regrow(ctx, A->nch, n_units))) return rc;
     A->units = n_units;
   }
@@ -2027,7 +2085,11 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
   // hit buffer: the matches of the batch budget plus the chance 16-mer hits of unrelated pairs (~1200 per 5 Mb unit)
   {
     const size_t want = (size_t)max_matches + (size_t)4096 * n_units + 1024;
-    if (want > A->hit_cap) { if ((rc = regrow(ctx, A->hits_d, want))) return rc; A->hit_cap = want; }
+    if (want > A->hit_cap) {
+      if ((rc = regrow(ctx, A->hits_d, want))) return rc;
+      if ((rc = regrow(ctx, A->hits_sorted, want))) return rc;
+      A->hit_cap = want;
+    }
   }
   for (int attempt = 0;; ++attempt) {
     if (attempt == 8) return pg_fail(ctx, PG_E_CAPACITY, "anim seeding: buffers still overflow after repeated splitting");
@@ -2036,10 +2098,15 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
     PG_HIP(ctx, hipMemcpyAsync(A->srefs_d, srefs.data(), n_refs * sizeof(SeedRef), hipMemcpyHostToDevice, ctx->stream));
     PG_HIP(ctx, hipMemsetAsync(A->mem_count, 0, n_units * 4, ctx->stream));
     PG_HIP(ctx, hipMemsetAsync(A->seed_total, 0, 8, ctx->stream));   // [0] matches, [1] hits
+    PG_HIP(ctx, hipMemsetAsync(A->hit_count, 0, n_units * 4, ctx->stream));
     hipLaunchKernelGGL(anim_seed_kernel, dim3(SEED_GROUPS, n_refs), dim3(SEED_BLOCK), (size_t)slots * 8 + SEED_STAGE_BYTES, ctx->stream,
                        A->refs_d, A->units_d, A->srefs_d, A->sqry_d, A->slice_d, slice_stride, slots - 1, A->hits_d,
-                       (uint32_t)A->hit_cap, A->seed_total + 1);
-    hipLaunchKernelGGL(anim_hit_kernel, dim3((uint32_t)ctx->num_cu * 8u), dim3(256), 0, ctx->stream, A->refs_d, A->units_d, A->hits_d,
+                       (uint32_t)A->hit_cap, A->seed_total + 1, A->hit_count);
+    // hits -> per-unit slices, then one workgroup per unit verifies / extends them
+    hipLaunchKernelGGL(anim_hoff_kernel, dim3(1), dim3(1024), 0, ctx->stream, A->hit_count, n_units, A->hoff, A->hit_cursor);
+    hipLaunchKernelGGL(anim_hit_scatter_kernel, dim3((uint32_t)ctx->num_cu * 8u), dim3(256), 0, ctx->stream, A->hits_d, A->seed_total + 1,
+                       (uint32_t)A->hit_cap, A->hoff, A->hit_cursor, A->hits_sorted);
+    hipLaunchKernelGGL(anim_hit_kernel, dim3(n_units), dim3(256), 0, ctx->stream, A->refs_d, A->units_d, A->hits_sorted, A->hoff,
                        A->seed_total + 1, (uint32_t)A->hit_cap, A->seedbuf, (uint32_t)A->seed_cap, A->seed_total, A->mem_count);
     PG_HIP(ctx, hipMemcpyAsync(cnt.data(), A->mem_count, n_units * 4, hipMemcpyDeviceToHost, ctx->stream));
     PG_HIP(ctx, hipMemcpyAsync(counts, A->seed_total, 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -2049,6 +2116,7 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
       if (n_pairs == 1) {
         A->hit_cap = (size_t)counts[1] + 1024;
         if ((rc = regrow(ctx, A->hits_d, A->hit_cap))) return rc;
+        if ((rc = regrow(ctx, A->hits_sorted, A->hit_cap))) return rc;
       } else {
         n_pairs = (n_pairs + 1) / 2;
         n_units = 2 * n_pairs;
