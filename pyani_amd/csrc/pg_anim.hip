@@ -308,31 +308,38 @@ __global__ __launch_bounds__(SEED_BLOCK) void anim_seed_kernel(const RefDesc* __
         const uint32_t qctx = (uint32_t)(qv[t] >> 32) & 0x7FFu;   // bit 0: flag, bits 1..10: left bases
         const int32_t q = (int32_t)(uint32_t)qv[t];
         uint32_t slot = (key >> 5) & slot_mask;
-        for (int hits = 0; hits < MAX_HITS;) {
-          const unsigned long long v = tab[slot];
-          if (v == SLOT_EMPTY) break;   // load factor <= 1/2: every probe sequence ends
+        // one exit condition and no break / continue inside: the compiler turns anything else into a state machine of
+        // exec-mask bookkeeping, and the per-CU scalar unit is a bottleneck of this kernel
+        int hits = 0;
+        unsigned long long v = tab[slot];
+        while (v != SLOT_EMPTY) {   // load factor <= 1/2: every probe sequence ends
+          if ((uint32_t)(v >> SEED_KEY_SHIFT) == key) {
+            int32_t left = -1;
+            bool report = true;
+            const uint32_t rctx = (uint32_t)(v >> 32) & 0x7FFu;
+            if (rctx & qctx & 1u) {
+              const uint32_t x = (rctx ^ qctx) >> 1;
+              const uint32_t diff = (x | (x >> 1)) & 0x155u;
+              left = diff ? (__ffs(diff) - 1) >> 1 : SEED_STEP;
+              report = left != SEED_STEP;   // inside a longer match: an earlier sampled position reports it
+            }
+            if (report) {
+              // a hit that may start a match: handed to anim_hit_kernel (verification / extension need the sequences and
+              // many registers; keeping them out of this kernel doubles its waves per SIMD).  Staged per wave in LDS.
+              const Match m{(int32_t)(uint32_t)v, q, left, (int32_t)unit};
+              const uint32_t at = atomicAdd(&stage_n[wave], 1u);
+              if (at < SEED_STAGE) {
+                stage[wave * SEED_STAGE + at] = m;
+              } else {   // staging buffer full (a burst of hits): straight to the global buffer
+                const uint32_t ga = atomicAdd(total, 1u);
+                atomicAdd(&hit_count[unit], 1u);
+                if (ga < cap) buf[ga] = m;
+              }
+            }
+            ++hits;
+          }
           slot = (slot + 1) & slot_mask;
-          if ((uint32_t)(v >> SEED_KEY_SHIFT) != key) continue;
-          ++hits;
-          int32_t left = -1;
-          const uint32_t rctx = (uint32_t)(v >> 32) & 0x7FFu;
-          if (rctx & qctx & 1u) {
-            const uint32_t x = (rctx ^ qctx) >> 1;
-            const uint32_t diff = (x | (x >> 1)) & 0x155u;
-            left = diff ? (__ffs(diff) - 1) >> 1 : SEED_STEP;
-            if (left == SEED_STEP) continue;   // inside a longer match: an earlier sampled position reports it
-          }
-          // a hit that may start a match: handed to anim_hit_kernel (verification / extension need the sequences and
-          // many registers; keeping them out of this kernel doubles its waves per SIMD).  Staged per wave in LDS.
-          const Match m{(int32_t)(uint32_t)v, q, left, (int32_t)unit};
-          const uint32_t at = atomicAdd(&stage_n[wave], 1u);
-          if (at < SEED_STAGE) {
-            stage[wave * SEED_STAGE + at] = m;
-          } else {   // staging buffer full (a burst of hits): straight to the global buffer
-            const uint32_t ga = atomicAdd(total, 1u);
-            atomicAdd(&hit_count[unit], 1u);
-            if (ga < cap) buf[ga] = m;
-          }
+          v = hits < MAX_HITS ? tab[slot] : SLOT_EMPTY;
         }
       }
       // uniform point: flush once the buffer is half full (or at the very end).  Staged hits sit in processing order,
