@@ -195,32 +195,27 @@ __device__ __forceinline__ bool seed_hit(const RefDesc& R, const SeqView& RV, co
   }
   if (left == SEED_STEP) return false;
   int32_t L = SEED_K;
-  bool ended = false;
-  // right extension, 16 bases per step (word compare of the packed codes and masks), then base by base
-  for (;;) {
-    if (r + L + 16 > R.len || q + L + 16 > U0.len) break;
+  // right extension, 16 bases per step (word compare of the packed codes and masks), then base by base near a sequence
+  // end.  Single-exit loops (state in `n`): break / continue shapes cost a lot of exec-mask bookkeeping.
+  int n = 16;
+  while (n == 16 && r + L + 16 <= R.len && q + L + 16 <= U0.len) {
     uint32_t rc_, rm_, qc_, qm_;
     get16(R.codes, R.mask, r + L, rc_, rm_);
-    if (strand == 0) {
-      get16(U0.codes, U0.mask, q + L, qc_, qm_);
-    } else {
-      uint32_t fc, fm;
-      get16(U0.codes, U0.mask, U0.len - 16 - (q + L), fc, fm);
-      uint32_t x = __brev(fc);
-      x = ((x & 0xAAAAAAAAu) >> 1) | ((x & 0x55555555u) << 1);
-      qc_ = ~x;
-      qm_ = __brev(fm) >> 16;
-    }
+    uint32_t fc, fm;
+    get16(U0.codes, U0.mask, strand == 0 ? q + L : U0.len - 16 - (q + L), fc, fm);
+    uint32_t rv = __brev(fc);
+    rv = ((rv & 0xAAAAAAAAu) >> 1) | ((rv & 0x55555555u) << 1);
+    qc_ = strand == 0 ? fc : ~rv;
+    qm_ = strand == 0 ? fm : __brev(fm) >> 16;
     const uint32_t x = rc_ ^ qc_;
     const uint32_t diff = (x | (x >> 1)) & 0x55555555u;
     const uint32_t bad = ~(rm_ & qm_) & 0xFFFFu;
     const int nd = diff ? (__ffs(diff) - 1) >> 1 : 16;
     const int nb = bad ? __ffs(bad) - 1 : 16;
-    const int n = nd < nb ? nd : nb;
+    n = nd < nb ? nd : nb;
     L += n;
-    if (n < 16) { ended = true; break; }
   }
-  if (!ended)   // fewer than 16 bases left in one of the sequences
+  if (n == 16)   // fewer than 16 bases left in one of the sequences
     while (RV.clean(r + L) && QV.clean(q + L) && RV.base(r + L) == QV.base(q + L)) ++L;
   if (left + L < MIN_MATCH) return false;
   out = Match{r - left, q - left, left + L, 0};
