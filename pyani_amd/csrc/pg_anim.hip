@@ -676,22 +676,25 @@ __device__ void wave_containment_flags(const uint64_t* order, const int32_t* sta
   }
 }
 
+// (single-exit loops throughout: on this hardware a divergent loop with break / continue / return inside compiles to a
+// state machine of exec-mask bookkeeping that costs more than the work)
 __device__ __forceinline__ int uf_find(int32_t* parent, int x) {
-  for (;;) {   // with path halving: links only ever move to an ancestor (a smaller index), so the races are benign
-    const int p = parent[x];
-    if (p == x) return x;
+  // with path halving: links only ever move to an ancestor (a smaller index), so the races are benign
+  int p = parent[x];
+  while (p != x) {
     const int gp = parent[p];
-    if (gp == p) return p;
-    parent[x] = gp;
-    x = gp;
+    if (gp != p) parent[x] = gp;
+    x = gp;          // == p when p is the root: the loop then ends
+    p = parent[x];
   }
+  return x;
 }
 __device__ __forceinline__ void uf_union(int32_t* parent, int a, int b) {   // larger root -> smaller root (deterministic roots)
-  for (;;) {
+  bool done = false;
+  while (!done) {
     a = uf_find(parent, a); b = uf_find(parent, b);
-    if (a == b) return;
-    if (a < b) { const int t = a; a = b; b = t; }
-    if (atomicCAS(&parent[a], a, b) == a) return;
+    const int hi = a > b ? a : b, lo = a > b ? b : a;
+    done = a == b || atomicCAS(&parent[hi], hi, lo) == hi;
   }
 }
 
@@ -910,16 +913,19 @@ __global__ __launch_bounds__(PREP_THREADS) void anim_cluster_prep_kernel(const R
   for (int i = tid; i < n; i += PREP_THREADS) {
     const Match mi = m[i];
     const int32_t iend = mi.q + mi.len, idiag = mi.q - mi.r;
-    for (int j = i + 1; j < n; ++j) {
+    int j = i + 1;
+    int32_t sep = j < n ? m[j].q - iend : MAX_GAP + 1;
+    while (sep <= MAX_GAP) {
       const Match mj = m[j];
-      const int32_t sep = mj.q - iend;
-      if (sep > MAX_GAP) break;
-      if (rrec[i] != rrec[j] || qrec[i] != qrec[j]) continue;
-      int32_t dd = (mj.q - mj.r) - idiag;
-      if (dd < 0) dd = -dd;
-      int32_t lim = (int32_t)(DIAG_FACTOR * sep);
-      if (lim < DIAG_DIFF) lim = DIAG_DIFF;
-      if (dd <= lim) uf_union(parent, i, j);
+      if (rrec[i] == rrec[j] && qrec[i] == qrec[j]) {
+        int32_t dd = (mj.q - mj.r) - idiag;
+        if (dd < 0) dd = -dd;
+        int32_t lim = (int32_t)(DIAG_FACTOR * sep);
+        if (lim < DIAG_DIFF) lim = DIAG_DIFF;
+        if (dd <= lim) uf_union(parent, i, j);
+      }
+      ++j;
+      sep = j < n ? m[j].q - iend : MAX_GAP + 1;
     }
   }
   __threadfence_block();
@@ -1028,16 +1034,19 @@ __global__ __launch_bounds__(64) void anim_cluster_wave_kernel(const RefDesc* __
   for (int i = lane; i < n; i += 64) {
     const Match mi = m[i];
     const int32_t iend = mi.q + mi.len, idiag = mi.q - mi.r;
-    for (int j = i + 1; j < n; ++j) {
+    int j = i + 1;
+    int32_t sep = j < n ? m[j].q - iend : MAX_GAP + 1;
+    while (sep <= MAX_GAP) {
       const Match mj = m[j];
-      const int32_t sep = mj.q - iend;
-      if (sep > MAX_GAP) break;
-      if (rrec[i] != rrec[j] || qrec[i] != qrec[j]) continue;
-      int32_t dd = (mj.q - mj.r) - idiag;
-      if (dd < 0) dd = -dd;
-      int32_t lim = (int32_t)(DIAG_FACTOR * sep);
-      if (lim < DIAG_DIFF) lim = DIAG_DIFF;
-      if (dd <= lim) uf_union(parent, i, j);
+      if (rrec[i] == rrec[j] && qrec[i] == qrec[j]) {
+        int32_t dd = (mj.q - mj.r) - idiag;
+        if (dd < 0) dd = -dd;
+        int32_t lim = (int32_t)(DIAG_FACTOR * sep);
+        if (lim < DIAG_DIFF) lim = DIAG_DIFF;
+        if (dd <= lim) uf_union(parent, i, j);
+      }
+      ++j;
+      sep = j < n ? m[j].q - iend : MAX_GAP + 1;
     }
   }
   __threadfence_block();
