@@ -1545,6 +1545,8 @@ struct GapTask {
   int32_t chain;
   int32_t r0, n, q0, m;
 };
+constexpr int GAP_LANE_MAX = 63;   // gaps up to 63 x 63 are solved by one lane (rows of the DP in LDS, 64 tasks per wave)
+constexpr int GAP_CLASSES = 4;     // size classes of those gaps (max side <= 16 / 31 / 47 / 63): a wave gets tasks of one class
 
 __device__ __forceinline__ int32_t wave_sum32(int32_t v) {
 #pragma unroll
@@ -1554,7 +1556,7 @@ __device__ __forceinline__ int32_t wave_sum32(int32_t v) {
 
 __global__ __launch_bounds__(64) void anim_gaps_kernel(const RefDesc* __restrict__ refs, const UnitDesc* __restrict__ units,
                                                        ClusterOut O, const uint2* __restrict__ wl, ChainFwd* __restrict__ fw,
-                                                       GapTask* __restrict__ tasks, uint32_t* __restrict__ n_tasks) {
+                                                       GapTask* __restrict__ tasks, uint8_t* __restrict__ task_cls) {
   const uint32_t u = wl[blockIdx.x].x;
   const int32_t c = (int32_t)wl[blockIdx.x].y;
   const UnitDesc U = units[u];
@@ -1611,12 +1613,13 @@ __global__ __launch_bounds__(64) void anim_gaps_kernel(const RefDesc* __restrict
         }
       }
     }
-    const uint64_t hm = __ballot(hard);
-    if (hm) {
-      uint32_t at = 0;
-      if (lane == 0) at = atomicAdd(n_tasks, (uint32_t)__popcll(hm));
-      at = __shfl(at, 0, 64);
-      if (hard) tasks[at + __popcll(hm & lanemask_lt())] = GapTask{u, c, ger, gn, geq, gm};
+    // A hard gap becomes a GapTask in the slot of the match it precedes (slots are unique, so no counter is contended);
+    // its size class goes to the byte plane that anim_gapsort_kernel turns into per-class task lists.
+    if (hard) {
+      const int32_t mx = gn > gm ? gn : gm;
+      const size_t slot = off + ch.first + kq;
+      tasks[slot] = GapTask{u, c, ger, gn, geq, gm};
+      task_cls[slot] = (uint8_t)(mx > GAP_LANE_MAX ? GAP_CLASSES : mx <= 16 ? 0 : mx <= 31 ? 1 : mx <= 47 ? 2 : 3);
     }
   }
   inner = wave_sum32(inner);
@@ -1630,19 +1633,254 @@ __global__ __launch_bounds__(64) void anim_gaps_kernel(const RefDesc* __restrict
   }
 }
 
-// One wave per GapTask at a time (grid-stride over the task list, whose length only the device knows).
+// Task lists by size class from the class plane (0xFF = no task in the slot): list k holds the slots of the gaps with
+// both sides <= 16 / 31 / 47 / 63 (k = 0..3, one LANE each in anim_gapdp_lane_kernel, so a wave gets 64 tasks of one
+// size) and of the larger ones (k = 4, one WAVE each in anim_gapdp_kernel).  A block sorts 4096 slots with LDS counters
+// and reserves its share of every list with one global atomic per class.
+constexpr int GAPSORT_BLOCK = 256;
+__global__ __launch_bounds__(GAPSORT_BLOCK) void anim_gapsort_kernel(const uint8_t* __restrict__ task_cls, uint32_t n_slots,
+                                                                     uint32_t* __restrict__ lists, uint32_t* __restrict__ n_tasks) {
+  __shared__ uint32_t cnt[GAP_CLASSES + 1], gbase[GAP_CLASSES + 1];
+  const uint32_t n_vec = (n_slots + 15u) / 16u;   // the plane is padded to whole 16-byte words
+  for (uint32_t v0 = blockIdx.x * GAPSORT_BLOCK; v0 < n_vec; v0 += gridDim.x * GAPSORT_BLOCK) {
+    if (threadIdx.x <= GAP_CLASSES) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t v = v0 + threadIdx.x;
+    uint4 w = make_uint4(~0u, ~0u, ~0u, ~0u);
+    if (v < n_vec) w = reinterpret_cast<const uint4*>(task_cls)[v];
+    const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+    uint32_t mine[GAP_CLASSES + 1] = {0, 0, 0, 0, 0};
+    if ((w.x & w.y & w.z & w.w) != ~0u) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const uint32_t c = (ww[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+#pragma unroll
+        for (int k = 0; k <= GAP_CLASSES; ++k) mine[k] += c == (uint32_t)k;
+      }
+    }
+    uint32_t lbase[GAP_CLASSES + 1];
+#pragma unroll
+    for (int k = 0; k <= GAP_CLASSES; ++k) lbase[k] = mine[k] ? atomicAdd(&cnt[k], mine[k]) : 0u;
+    __syncthreads();
+    if (threadIdx.x <= GAP_CLASSES) gbase[threadIdx.x] = cnt[threadIdx.x] ? atomicAdd(&n_tasks[threadIdx.x], cnt[threadIdx.x]) : 0u;
+    __syncthreads();
+    if ((w.x & w.y & w.z & w.w) != ~0u) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const uint32_t c = (ww[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+        if (c <= (uint32_t)GAP_CLASSES) {
+          uint32_t at = 0;
+#pragma unroll
+          for (int k = 0; k <= GAP_CLASSES; ++k)
+            if (c == (uint32_t)k) at = gbase[k] + lbase[k]++;
+          lists[(size_t)c * n_slots + at] = v * 16u + (uint32_t)i;
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// One wave per GapTask at a time (grid-stride over the list of large gaps, whose length only the device knows).
 __global__ __launch_bounds__(64) void anim_gapdp_kernel(const RefDesc* __restrict__ refs, const UnitDesc* __restrict__ units,
-                                                        ClusterOut O, const GapTask* __restrict__ tasks,
+                                                        ClusterOut O, const GapTask* __restrict__ tasks, const uint32_t* __restrict__ list,
                                                         const uint32_t* __restrict__ n_tasks, ChainFwd* __restrict__ fw) {
   const uint32_t n = *n_tasks;
   for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
-    const GapTask T = tasks[i];
+    const GapTask T = tasks[list[i]];
     const UnitDesc U = units[T.unit];
     const RefDesc R = refs[U.ref];
     const SeqView RV{R.codes, R.mask, R.len};
     const StrandView QV{SeqView{U.codes, U.mask, U.len}, U.strand};
     const int32_t err = gap_errors_wave(RV, QV, T.r0, T.n, T.q0, T.m);
     if ((threadIdx.x & 63) == 0 && err) atomicAdd(&fw[O.moff[T.unit] + T.chain].inner_err, err);
+  }
+}
+
+// ---- small gaps: one LANE per GapTask ---------------------------------------------------------------------------
+// 64 positions of a sequence starting at p0 (any sign): 2-bit codes in c[0..3] (position p0 in the low bits of c[0]) and
+// ok bit k = position p0 + k lies inside the sequence and is clean.
+__device__ __forceinline__ void seq_window64(const SeqView& s, int64_t p0, uint32_t c[4], uint64_t& ok) {
+  const int64_t last_c = (s.len - 1) >> 4, last_m = (s.len - 1) >> 5;
+  const int64_t w0 = p0 >> 4, m0 = p0 >> 5;   // floor
+  uint32_t w[5], mw[3];
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    int64_t i = w0 + k;
+    i = i < 0 ? 0 : i > last_c ? last_c : i;   // a clamped word only stands in for positions outside the sequence
+    w[k] = s.codes[i];
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    int64_t i = m0 + k;
+    i = i < 0 ? 0 : i > last_m ? last_m : i;
+    mw[k] = s.mask[i];
+  }
+  const uint32_t sc = 2u * (uint32_t)(p0 & 15), sm = (uint32_t)(p0 & 31);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) c[k] = __funnelshift_r(w[k], w[k + 1], sc);
+  ok = (uint64_t)__funnelshift_r(mw[0], mw[1], sm) | ((uint64_t)__funnelshift_r(mw[1], mw[2], sm) << 32);
+  const int64_t lo = p0 < 0 ? -p0 : 0, hi = s.len - p0;   // window bits [lo, hi) are inside the sequence
+  const uint64_t below_hi = hi >= 64 ? ~0ull : hi <= 0 ? 0ull : ((1ull << hi) - 1ull);
+  const uint64_t below_lo = lo >= 64 ? ~0ull : ((1ull << lo) - 1ull);
+  ok &= below_hi & ~below_lo;
+}
+__device__ __forceinline__ uint32_t rev_fields2(uint32_t x) {   // the 16 two-bit fields of x in reverse order
+  x = __brev(x);
+  return ((x & 0x55555555u) << 1) | ((x >> 1) & 0x55555555u);
+}
+__device__ __forceinline__ uint32_t spread16(uint32_t x) {   // bit k of the low half -> bit 2k
+  x = (x | (x << 8)) & 0x00FF00FFu;
+  x = (x | (x << 4)) & 0x0F0F0F0Fu;
+  x = (x | (x << 2)) & 0x33333333u;
+  return (x | (x << 1)) & 0x55555555u;
+}
+
+// Cells j = J .. C-1 of one DP row of the lane kernel below, as nested uniform ifs (columns beyond the wave's largest m
+// are skipped with one forward jump, and H / X stay in fixed registers).  hdiag = H(i-1, j-1), hleft = H(i, j-1),
+// yleft = Y(i, j-1).  In the banded variant only H of a cell outside [blo, blo + bwid] is killed: the X of a cell right
+// of the band derives only from killed cells above it and its Y only feeds cells further right; left of the band it is
+// the other way round (Y derives from killed cells, X only feeds cells further down) — neither reaches a band cell.
+template <int C, bool BANDED, int J>
+struct LaneRow {
+  static constexpr int QW = (C + 14) / 16;
+  static __device__ __forceinline__ void run(uint32_t (&H)[C], uint32_t (&X)[C], const uint32_t (&eq)[QW], bool row0, int32_t m_max,
+                                             uint32_t blo, uint32_t bwid, uint32_t hdiag, uint32_t hleft, uint32_t yleft) {
+    constexpr uint32_t K_START = (65536u << 15) | 32767u;
+    constexpr uint32_t K_OPEN = (uint32_t)(-SC_GAP_OPEN) * 32768u + 1u, K_EXT = (uint32_t)(-SC_GAP_EXT) * 32768u + 1u;
+    constexpr uint32_t K_MATCH = (uint32_t)SC_MATCH * 32768u, K_MISMATCH = (uint32_t)(-SC_MISMATCH) * 32768u + 1u;
+    if (J > m_max) return;   // uniform
+    const uint32_t up_h = H[J], up_x = X[J];
+    const uint32_t xa = __builtin_elementwise_sub_sat(up_h, K_OPEN), xb = __builtin_elementwise_sub_sat(up_x, K_EXT);
+    const uint32_t nx = xa > xb ? xa : xb;
+    uint32_t ny = 0, nh;
+    if (J == 0) {
+      nh = row0 ? K_START : nx;
+    } else {
+      const uint32_t ya = __builtin_elementwise_sub_sat(hleft, K_OPEN), yb = __builtin_elementwise_sub_sat(yleft, K_EXT);
+      ny = ya > yb ? ya : yb;
+      constexpr int Q = J > 0 ? J - 1 : 0;
+      const uint32_t bit = (eq[Q >> 4] >> (2 * (Q & 15))) & 1u;
+      nh = __umul24(bit, K_MATCH + K_MISMATCH) + __builtin_elementwise_sub_sat(hdiag, K_MISMATCH);
+      nh = nh > nx ? nh : nx;
+      nh = nh > ny ? nh : ny;
+    }
+    if (BANDED) nh = ((uint32_t)J - blo <= bwid) ? nh : 0u;
+    H[J] = nh; X[J] = nx;
+    LaneRow<C, BANDED, J + 1>::run(H, X, eq, row0, m_max, blo, bwid, up_h, nh, ny);
+  }
+};
+template <int C, bool BANDED>
+struct LaneRow<C, BANDED, C> {
+  static constexpr int QW = (C + 14) / 16;
+  static __device__ __forceinline__ void run(uint32_t (&)[C], uint32_t (&)[C], const uint32_t (&)[QW], bool, int32_t, uint32_t, uint32_t,
+                                             uint32_t, uint32_t, uint32_t) {}
+};
+
+// Small gaps, one LANE per GapTask (64 tasks of one size class per wave): the cells of the wave DP of a targeted gap
+// fill — the n x m rectangle restricted to the 64 diagonals centred between start and target (pga::extend_banded) —
+// row by row, the previous row's H and X keys held in REGISTERS (the column loop is fully unrolled, C - 1 = the largest
+// gap side of the class) and the same unsigned keys, so every choice is again "higher score, then fewer errors".
+//   * rows beyond a lane's n are masked off, so its registers end holding row n; columns beyond its m compute garbage
+//     that never flows back (a cell only reads columns <= its own) and that stays far below K_LIVE;
+//   * the reference base of the row is compared with all query bases at once (xor of the 2-bit codes, clean masks
+//     folded in), a cell takes its bit of that word: mismatch penalty always, + (match + mismatch) * bit;
+//   * BANDED = false (n + m <= 62): every diagonal of the rectangle is inside the band, no range test per cell;
+//     BANDED = true: H of the cells outside [i + klo, min(m, i + khi)] is killed (see LaneRow); a target outside the
+//     band falls back to the diagonal count exactly like pga::gap_errors.
+// A gap of at most 63 + 63 anti-diagonals can never trigger the break rule of the extension DP.
+// ~10 (13 banded) VALU per cell for 64 tasks at once, against ~35 per anti-diagonal for ONE task in the wave version.
+template <int C, bool BANDED>
+__global__ __launch_bounds__(64) void anim_gapdp_lane_kernel(const RefDesc* __restrict__ refs, const UnitDesc* __restrict__ units,
+                                                             ClusterOut O, const GapTask* __restrict__ tasks, const uint32_t* __restrict__ list,
+                                                             const uint32_t* __restrict__ n_tasks, ChainFwd* __restrict__ fw) {
+  constexpr int W = BAND / 2;
+  constexpr int QW = (C + 14) / 16;   // code words that hold query bases 0 .. C-2
+  constexpr uint32_t K_LIVE = 32768u << 15, K_START = (65536u << 15) | 32767u;
+  constexpr uint32_t K_OPEN = (uint32_t)(-SC_GAP_OPEN) * 32768u + 1u, K_EXT = (uint32_t)(-SC_GAP_EXT) * 32768u + 1u;
+  constexpr uint32_t K_MATCH = (uint32_t)SC_MATCH * 32768u, K_MISMATCH = (uint32_t)(-SC_MISMATCH) * 32768u + 1u;
+  const int lane = threadIdx.x & 63;
+  const uint32_t n_all = *n_tasks;
+  for (uint32_t base = blockIdx.x * 64u; base < n_all; base += gridDim.x * 64u) {
+    const bool valid = base + lane < n_all;
+    GapTask T{0, 0, 0, 0, 0, 0};
+    if (valid) T = tasks[list[base + lane]];
+    const UnitDesc U = units[T.unit];
+    const RefDesc R = refs[U.ref];
+    const SeqView RV{R.codes, R.mask, R.len};
+    const SeqView QS{U.codes, U.mask, U.len};
+    const int32_t n = T.n, m = T.m;
+    // band placement and target test of pga::extend_banded for tr = n, tq = m
+    int koff = (m - n) / 2;
+    if (koff > W - 2) koff = W - 2;
+    if (koff < -(W - 2)) koff = -(W - 2);
+    const int lt = (m - n) - koff + W;
+    const bool in_band = valid && lt >= 0 && lt < BAND;
+    const int klo = koff - W, khi = koff + W - 1;   // diagonals j - i inside the band
+    const int32_t n_max = (int32_t)wave_max_u32(in_band ? (uint32_t)n : 0u), m_max = (int32_t)wave_max_u32(in_band ? (uint32_t)m : 0u);
+    // the two windows: reference bases r0 .. r0+63, query-strand bases q0 .. q0+63
+    uint32_t rc[4], qc[4];
+    uint64_t rok, qok;
+    seq_window64(RV, T.r0, rc, rok);
+    if (U.strand) {   // strand position p = forward position len-1-p, complemented
+      uint32_t f[4];
+      uint64_t fok;
+      seq_window64(QS, U.len - 1 - (int64_t)T.q0 - 63, f, fok);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) qc[k] = ~rev_fields2(f[3 - k]);
+      qok = ((uint64_t)__brev((uint32_t)fok) << 32) | (uint64_t)__brev((uint32_t)(fok >> 32));
+    } else {
+      seq_window64(QS, T.q0, qc, qok);
+    }
+    uint32_t qs[QW];   // clean query bases, one bit per 2-bit field
+#pragma unroll
+    for (int k = 0; k < QW; ++k) qs[k] = spread16((uint32_t)(qok >> (16 * k)) & 0xFFFFu);
+    uint32_t H[C], X[C];
+#pragma unroll
+    for (int j = 0; j < C; ++j) { H[j] = 0; X[j] = 0; }
+    for (int32_t i = 0; i <= n_max; ++i) {
+      if (in_band && i <= n) {
+        // eq bit 2j = query base j equals the reference base of this row (row 0 has none)
+        uint32_t sel = (i >= 1 && (rok & 1ull)) ? ~0u : 0u;
+        const uint32_t rb = (rc[0] & 3u) * 0x55555555u;
+        uint32_t eq[QW];
+#pragma unroll
+        for (int k = 0; k < QW; ++k) {
+          const uint32_t x = qc[k] ^ rb;
+          eq[k] = ~(x | (x >> 1)) & qs[k] & sel;
+        }
+        if (i >= 1) {   // uniform
+          rc[0] = __funnelshift_r(rc[0], rc[1], 2); rc[1] = __funnelshift_r(rc[1], rc[2], 2);
+          rc[2] = __funnelshift_r(rc[2], rc[3], 2); rc[3] >>= 2;
+          rok >>= 1;
+        }
+        uint32_t blo = 0, bwid = 0;
+        if (BANDED) {
+          const int32_t lo = i + klo > 0 ? i + klo : 0, hi = i + khi < m ? i + khi : m;
+          blo = hi >= lo ? (uint32_t)lo : (1u << 20);
+          bwid = hi >= lo ? (uint32_t)(hi - lo) : 0u;
+        }
+        int32_t m_row = m_max;
+        asm volatile("" : "+s"(m_row));   // keeps the 64 column tests as scalar compares in the row instead of 64 hoisted masks
+        LaneRow<C, BANDED, 0>::run(H, X, eq, i == 0, m_row, blo, bwid, 0u, 0u, 0u);
+      }
+    }
+    if (valid) {
+      uint32_t tH = 0;
+#pragma unroll
+      for (int j = 0; j < C; ++j) tH = m == j ? H[j] : tH;
+      int32_t err;
+      if (in_band && tH >= K_LIVE) {
+        err = 32767 - (int32_t)(tH & 32767u);
+      } else {   // target outside the band or pruned: diagonal part + length difference (pga::gap_errors)
+        const StrandView QV{QS, U.strand};
+        const int32_t kq = n < m ? n : m;
+        err = n > m ? n - m : m - n;
+        for (int32_t t = 0; t < kq; ++t)
+          err += (RV.clean(T.r0 + t) && QV.clean(T.q0 + t) && RV.base(T.r0 + t) == QV.base(T.q0 + t)) ? 0 : 1;
+      }
+      if (err) atomicAdd(&fw[O.moff[T.unit] + T.chain].inner_err, err);
+    }
   }
 }
 
@@ -1885,6 +2123,9 @@ struct AnimScratch {
   Match* seedbuf = nullptr;   // batch-wide append buffer of the seed pass
   size_t seed_cap = 0;
   uint32_t* seed_total = nullptr;   // [0] matches appended, [1] hits recorded
+  uint32_t* gap_counts = nullptr;   // gap tasks per size class + the wave list
+  uint8_t* task_cls = nullptr;      // size class of the GapTask in every match slot (0xFF = none)
+  uint32_t* task_lists = nullptr;   // [GAP_CLASSES + 1][slots] slot lists by class
   Match* hits_d = nullptr;          // hits recorded by the probe kernel for anim_hit_kernel
   Match* hits_sorted = nullptr;     // the same, dealt into per-unit slices (hoff)
   uint32_t *hit_count = nullptr, *hoff = nullptr, *hit_cursor = nullptr;   // per unit
@@ -1961,7 +2202,7 @@ void pg_anim_free_scratch(pg_ctx* ctx) {
   AnimScratch* A = static_cast<AnimScratch*>(ctx->anim_scratch);
   if (!A) return;
   pg_anim_drop_lists(ctx);
-  void* ptrs[] = {A->hits_sorted, A->hit_count, A->hoff, A->hit_cursor, A->hits_d, A->slice_d, A->choff_d, A->list_cnt, A->srefs_d, A->sqry_d, A->recs_d, A->refs_d, A->units_d, A->mem_count, A->moff, A->nch, A->status, A->out, A->mem, A->cm,
+  void* ptrs[] = {A->gap_counts, A->task_cls, A->task_lists, A->hits_sorted, A->hit_count, A->hoff, A->hit_cursor, A->hits_d, A->slice_d, A->choff_d, A->list_cnt, A->srefs_d, A->sqry_d, A->recs_d, A->refs_d, A->units_d, A->mem_count, A->moff, A->nch, A->status, A->out, A->mem, A->cm,
                   A->iscratch, A->order, A->prev, A->next, A->alnof, A->chains, A->fw, A->bw, A->S.alns, A->S.a_rrec,
                   A->S.a_qrec, A->S.idx, A->S.from, A->S.sc, A->wl_d, A->seedbuf, A->seed_total, A->tasks_d};
   for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -2090,6 +2331,7 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
     A->seed_cap = (size_t)max_matches + 1024;   // the whole batch budget (2.4 GB by default): no overflow re-runs
     if ((rc = regrow(ctx, A->seedbuf, A->seed_cap))) return rc;
     if ((rc = regrow(ctx, A->seed_total, 2))) return rc;
+    if ((rc = regrow(ctx, A->gap_counts, GAP_CLASSES + 1))) return rc;
   }
   std::vector<uint32_t> cnt(n_units), moff;
   uint32_t total = 0, pairs_fit = 0;
@@ -2211,12 +2453,31 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
     uint32_t* choff_d = A->choff_d;
     PG_HIP(ctx, hipMemcpyAsync(choff_d, choff.data(), choff.size() * 4, hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(anim_wl_kernel, dim3(n_units), dim3(64), 0, ctx->stream, choff_d, A->wl_d);
-    if (M > A->tasks) { if ((rc = regrow(ctx, A->tasks_d, M))) return rc; A->tasks = M; }
-    PG_HIP(ctx, hipMemsetAsync(A->seed_total, 0, 4, ctx->stream));   // reused as the gap-task counter
+    // gap tasks: one slot per match (sparse), a class byte per slot, and GAP_CLASSES + 1 slot lists
+    const size_t Mp = (M + 15) & ~(size_t)15;
+    if (Mp > A->tasks) {
+      if ((rc = regrow(ctx, A->tasks_d, Mp))) return rc;
+      if ((rc = regrow(ctx, A->task_cls, Mp))) return rc;
+      if ((rc = regrow(ctx, A->task_lists, (GAP_CLASSES + 1) * Mp))) return rc;
+      A->tasks = Mp;
+    }
+    PG_HIP(ctx, hipMemsetAsync(A->gap_counts, 0, (GAP_CLASSES + 1) * 4, ctx->stream));
+    PG_HIP(ctx, hipMemsetAsync(A->task_cls, 0xFF, Mp, ctx->stream));
     hipLaunchKernelGGL(anim_gaps_kernel, dim3((uint32_t)n_wl), dim3(64), 0, ctx->stream, A->refs_d, A->units_d, O, A->wl_d,
-                       A->fw, A->tasks_d, A->seed_total);
+                       A->fw, A->tasks_d, A->task_cls);
+    hipLaunchKernelGGL(anim_gapsort_kernel, dim3((uint32_t)ctx->num_cu * 8u), dim3(GAPSORT_BLOCK), 0, ctx->stream, A->task_cls,
+                       (uint32_t)Mp, A->task_lists, A->gap_counts);
+    const dim3 lane_grid((uint32_t)ctx->num_cu * 8u);
+    hipLaunchKernelGGL((anim_gapdp_lane_kernel<17, false>), lane_grid, dim3(64), 0, ctx->stream, A->refs_d, A->units_d, O, A->tasks_d,
+                       A->task_lists, A->gap_counts, A->fw);
+    hipLaunchKernelGGL((anim_gapdp_lane_kernel<32, false>), lane_grid, dim3(64), 0, ctx->stream, A->refs_d, A->units_d, O, A->tasks_d,
+                       A->task_lists + Mp, A->gap_counts + 1, A->fw);
+    hipLaunchKernelGGL((anim_gapdp_lane_kernel<48, true>), lane_grid, dim3(64), 0, ctx->stream, A->refs_d, A->units_d, O, A->tasks_d,
+                       A->task_lists + 2 * Mp, A->gap_counts + 2, A->fw);
+    hipLaunchKernelGGL((anim_gapdp_lane_kernel<64, true>), lane_grid, dim3(64), 0, ctx->stream, A->refs_d, A->units_d, O, A->tasks_d,
+                       A->task_lists + 3 * Mp, A->gap_counts + 3, A->fw);
     hipLaunchKernelGGL(anim_gapdp_kernel, dim3((uint32_t)ctx->num_cu * 32u), dim3(64), 0, ctx->stream, A->refs_d, A->units_d, O,
-                       A->tasks_d, A->seed_total, A->fw);
+                       A->tasks_d, A->task_lists + GAP_CLASSES * Mp, A->gap_counts + GAP_CLASSES, A->fw);
     for (int phase = 0; phase < 2; ++phase)
       hipLaunchKernelGGL(anim_extend_kernel, dim3((uint32_t)n_wl), dim3(64), 0, ctx->stream, A->refs_d, A->units_d, O,
                          A->wl_d, A->fw, A->bw, phase);
