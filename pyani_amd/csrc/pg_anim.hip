@@ -1335,8 +1335,17 @@ __device__ unsigned long long g_dp_stats[3][40];
 __device__ int g_dp_site;
 #endif
 
+// A search that anim_extdp_lane_kernel hands over mid-way: the latest H of the 64 diagonals, X / Y of the 32 cells of
+// anti-diagonal d (diagonals l = (d + koff) mod 2, + 2, ...), and the best cell so far (its key with d in the low bits;
+// bpay = its error field << 6 | its diagonal).
+struct ExtDump {
+  uint32_t H[64], X[32], Y[32];
+  uint32_t best, bpay;
+  int32_t d, pad_;
+};
+
 __device__ ExtResult extend_wave(const SeqView& R, const StrandView& Q, int64_t r0, int64_t q0, int dir, int32_t rmax,
-                                 int32_t qmax, int32_t tr, int32_t tq) {
+                                 int32_t qmax, int32_t tr, int32_t tq, const ExtDump* resume = nullptr) {
   constexpr int W = BAND / 2;
 #ifdef PGA_DP_STATS
   const unsigned long long t_begin = __builtin_readcyclecounter();
@@ -1374,15 +1383,27 @@ __device__ ExtResult extend_wave(const SeqView& R, const StrandView& Q, int64_t 
   uint32_t best = K_LIVE, be = 0;   // per-lane best cell: (score + 65536) << 15 | d, and that cell's key
   if (lane == W - koff) { H = (65536u << 15) | 32767u; best = 65536u << 15; be = H; }
   const int32_t d_end = targeted ? tr + tq : rmax + qmax;
+  // A resumed search picks up after anti-diagonal resume->d: every lane takes its diagonal's H, the lanes of that
+  // anti-diagonal's parity their X / Y as well (the others' have been consumed), the best cell's lane the best.
+  int32_t d_start = 1;
+  if (resume) {
+    d_start = resume->d + 1;
+    H = resume->H[lane]; X = 0; Y = 0;
+    if (((resume->d + k) & 1) == 0) { X = resume->X[lane >> 1]; Y = resume->Y[lane >> 1]; }
+    best = K_LIVE; be = 0;
+    if (lane == (int)(resume->bpay & 63u)) { best = resume->best; be = resume->bpay >> 6; }
+  }
   WaveSeq ws{s_ring[0], s_ring[1], 0};
+  if (resume) { const int32_t first = (d_start >> 1) - 64; ws.loaded = first > 0 ? (first & ~63) : 0; }
   __syncthreads();  // previous user of the ring (same wave) is done
   wave_seq_fill(ws, R, Q, r0, q0, dir, rmax, qmax, lane);
   wave_seq_fill(ws, R, Q, r0, q0, dir, rmax, qmax, lane);
+  while ((d_start >> 1) + 36 > ws.loaded) wave_seq_fill(ws, R, Q, r0, q0, dir, rmax, qmax, lane);   // (resume only)
   __syncthreads();
   // ring positions of this lane's next cell (it has one on every other anti-diagonal; both advance by one each time)
-  const int32_t d_first = (k & 1) ? 1 : 2;
+  const int32_t d_first = ((d_start + k) & 1) ? d_start + 1 : d_start;
   uint32_t ir = (uint32_t)(((d_first - k) >> 1) - 1) & 255u, iq = (uint32_t)(((d_first + k) >> 1) - 1) & 255u;
-  uint32_t par = (uint32_t)(1 + k) & 1u;   // (d + k) & 1 at d = 1; toggles every step
+  uint32_t par = (uint32_t)(d_start + k) & 1u;   // (d + k) & 1 at the first step; toggles every step
   uint8_t rb = ws.ring_r[ir], qb = ws.ring_q[iq];   // bases of the next cell, read one cell ahead (LDS latency off the path)
   // Break rule with PER-STEP semantics (as the scalar code) at the price of one wave reduction every CHECK steps:
   // g_key / t_prev = global best score (as a key with d = 0) and its anti-diagonal as of the last check; every lane
@@ -1390,8 +1411,9 @@ __device__ ExtResult extend_wave(const SeqView& R, const StrandView& Q, int64_t 
   constexpr int CHECK = 16;
   uint32_t g_key = 65536u << 15;
   int32_t t_prev = 0, fimp = 0x7FFFFFFF;
+  if (resume) { g_key = resume->best & K_TOP; t_prev = (int32_t)(resume->best & 32767u); }   // the hand-over is a check point
   uint32_t sbest = best, sbe = be;
-  for (int32_t d = 1; d <= d_end; ++d) {
+  for (int32_t d = d_start; d <= d_end; ++d) {
 #ifdef PGA_DP_STATS
     ++n_steps;
 #endif
@@ -1796,9 +1818,7 @@ __global__ __launch_bounds__(64) void anim_gapdp_lane_kernel(const RefDesc* __re
                                                              const uint32_t* __restrict__ n_tasks, ChainFwd* __restrict__ fw) {
   constexpr int W = BAND / 2;
   constexpr int QW = (C + 14) / 16;   // code words that hold query bases 0 .. C-2
-  constexpr uint32_t K_LIVE = 32768u << 15, K_START = (65536u << 15) | 32767u;
-  constexpr uint32_t K_OPEN = (uint32_t)(-SC_GAP_OPEN) * 32768u + 1u, K_EXT = (uint32_t)(-SC_GAP_EXT) * 32768u + 1u;
-  constexpr uint32_t K_MATCH = (uint32_t)SC_MATCH * 32768u, K_MISMATCH = (uint32_t)(-SC_MISMATCH) * 32768u + 1u;
+  constexpr uint32_t K_LIVE = 32768u << 15;
   const int lane = threadIdx.x & 63;
   const uint32_t n_all = *n_tasks;
   for (uint32_t base = blockIdx.x * 64u; base < n_all; base += gridDim.x * 64u) {
@@ -1884,18 +1904,486 @@ __global__ __launch_bounds__(64) void anim_gapdp_lane_kernel(const RefDesc* __re
   }
 }
 
+// ---- extension DP, one LANE per task -------------------------------------------------------------------------------
+// The first DP calls of a chain in a phase need nothing but the chain tables (and the results of the calls before them),
+// so they are written down as ExtReqs by anim_extreq_kernel (one round per call), solved here 64 to a wave, and picked up
+// by anim_extend_kernel in place of its own extend_wave calls; whatever the lanes have not delivered still runs there.
+struct ExtReq {   // everything a lane needs, so that taking a request costs two dependent loads (request, sequence words)
+  const uint32_t* rcodes;
+  const uint32_t* rmask;
+  const uint32_t* qcodes;
+  const uint32_t* qmask;
+  int32_t rlen, qlen;
+  int32_t strand, dir;
+  int32_t r0, q0, rmax, qmax, tr, tq;
+  uint32_t chain;   // index into the work list: where the result goes
+  int32_t pad_;
+};
+struct ExtArgs {   // the arguments of one DP call, for the check in anim_extend_kernel
+  int32_t r0, q0, dir, rmax, qmax, tr, tq;
+};
+struct ExtPre {
+  ExtResult res;
+  ExtArgs args;
+  int32_t valid;
+};
+constexpr int EXT_ROUNDS = 2;   // DP calls per chain and phase that may go to the lanes (a third one is rare)
+constexpr int EXT_TAIL_LANES = 24, EXT_TAIL_BLOCKS = 64;   // see the tail rule in anim_extdp_lane_kernel
+constexpr uint32_t EXT_DUMP_CAP = 1u << 17;
+
+// One sequence of a lane task as a stream: element t = the base at stored position start + sgn * t (complemented for a
+// reverse query strand), valid while t < tmax and the position is a clean base.  Up to 32 elements are buffered (2-bit
+// codes, and valid flags as 01 per element), the next one in the low bits.
+struct LaneSeq {
+  const uint32_t* codes;
+  const uint32_t* mask;
+  int32_t len, start, sgn, tmax;
+  uint32_t comp;
+  uint32_t bc_lo, bc_hi, bo_lo, bo_hi;
+  int32_t cnt, chunk;   // buffered elements; next 16-element chunk to fetch
+};
+__device__ __forceinline__ void lane_seq_fetch(const LaneSeq& s, uint32_t& c, uint32_t& okf) {
+  const int32_t t0 = s.chunk * 16;
+  const int32_t p0 = s.sgn > 0 ? s.start + t0 : s.start - t0 - 15;
+  const int32_t last_c = (s.len - 1) >> 4, last_m = (s.len - 1) >> 5;
+  int32_t w0 = p0 >> 4, w1 = w0 + 1, m0 = p0 >> 5, m1 = m0 + 1;   // floor; a clamped word only stands in for outside positions
+  w0 = w0 < 0 ? 0 : w0 > last_c ? last_c : w0; w1 = w1 < 0 ? 0 : w1 > last_c ? last_c : w1;
+  m0 = m0 < 0 ? 0 : m0 > last_m ? last_m : m0; m1 = m1 < 0 ? 0 : m1 > last_m ? last_m : m1;
+  c = __funnelshift_r(s.codes[w0], s.codes[w1], 2u * (uint32_t)(p0 & 15));
+  uint32_t ok = __funnelshift_r(s.mask[m0], s.mask[m1], (uint32_t)(p0 & 31)) & 0xFFFFu;
+  const int32_t lo = p0 < 0 ? -p0 : 0, hi = s.len - p0;   // window bits [lo, hi) lie inside the sequence
+  uint32_t in = hi >= 16 ? 0xFFFFu : hi <= 0 ? 0u : ((1u << hi) - 1u);
+  in &= lo >= 16 ? 0u : ~((1u << lo) - 1u);
+  ok &= in;
+  if (s.sgn < 0) { c = rev_fields2(c); ok = __brev(ok) >> 16; }
+  if (s.comp) c = ~c;
+  const int32_t nv = s.tmax - t0;
+  ok &= nv >= 16 ? 0xFFFFu : nv <= 0 ? 0u : ((1u << nv) - 1u);
+  okf = spread16(ok);
+}
+__device__ __forceinline__ void lane_seq_append(LaneSeq& s) {   // needs cnt <= 16
+  uint32_t c, okf;
+  lane_seq_fetch(s, c, okf);
+  const uint32_t sh = 2u * (uint32_t)s.cnt;
+  const uint64_t bc = (((uint64_t)s.bc_hi << 32) | s.bc_lo) | ((uint64_t)c << sh);
+  const uint64_t bo = (((uint64_t)s.bo_hi << 32) | s.bo_lo) | ((uint64_t)okf << sh);
+  s.bc_lo = (uint32_t)bc; s.bc_hi = (uint32_t)(bc >> 32);
+  s.bo_lo = (uint32_t)bo; s.bo_hi = (uint32_t)(bo >> 32);
+  s.cnt += 16; s.chunk += 1;
+}
+__device__ __forceinline__ void lane_seq_pop(LaneSeq& s, uint32_t& c, uint32_t& o) {
+  c = s.bc_lo & 3u; o = s.bo_lo & 1u;
+  s.bc_lo = __funnelshift_r(s.bc_lo, s.bc_hi, 2); s.bc_hi >>= 2;
+  s.bo_lo = __funnelshift_r(s.bo_lo, s.bo_hi, 2); s.bo_hi >>= 2;
+  s.cnt -= 1;
+}
+// The two windows a lane compares on one anti-diagonal.  Its 32 cells sit on every other diagonal l = P, P+2, ...;
+// cell t' needs ref element i0 - t' and query element j0 + t', so the ref window is kept REVERSED (element i0 in field 0)
+// and the query window forward (element j0 in field 0): one xor compares all 32 pairs.  Stepping to the next
+// anti-diagonal of the other parity moves exactly one of them by one element.
+struct LaneWin {
+  uint32_t rc_lo, rc_hi, ro_lo, ro_hi;   // ref: codes, valid flags (01 per element)
+  uint32_t qc_lo, qc_hi, qo_lo, qo_hi;   // query
+};
+__device__ __forceinline__ void lane_win_push_ref(LaneWin& w, LaneSeq& s) {
+  uint32_t c, o;
+  lane_seq_pop(s, c, o);
+  w.rc_hi = __funnelshift_r(w.rc_lo, w.rc_hi, 30); w.rc_lo = (w.rc_lo << 2) | c;
+  w.ro_hi = __funnelshift_r(w.ro_lo, w.ro_hi, 30); w.ro_lo = (w.ro_lo << 2) | o;
+}
+__device__ __forceinline__ void lane_win_push_qry(LaneWin& w, LaneSeq& s) {
+  uint32_t c, o;
+  lane_seq_pop(s, c, o);
+  w.qc_lo = __funnelshift_r(w.qc_lo, w.qc_hi, 2); w.qc_hi = (w.qc_hi >> 2) | (c << 30);
+  w.qo_lo = __funnelshift_r(w.qo_lo, w.qo_hi, 2); w.qo_hi = (w.qo_hi >> 2) | (o << 30);
+}
+__device__ __forceinline__ uint32_t mad_u24(uint32_t a, uint32_t b_uniform, uint32_t c) {   // a * b + c, a and b below 2^24
+  uint32_t r;
+  asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b_uniform), "v"(c));
+  return r;
+}
+
+// Cells l = P + 2T, P + 2T + 2, ... of one anti-diagonal of a lane task: pga::dp_cell on the unsigned keys of
+// extend_wave, then the running best: higher score, ties the later anti-diagonal, then the larger diagonal (ascending l
+// with >=).  bpay = the best cell's key << 6 | l: its error field and its diagonal.
+// Registers: H[l] = H of the latest cell of diagonal l (the neighbours l - 1 and l + 1 belong to the other parity and
+// are not written in this step).  The X and Y of a cell are read exactly once, by its neighbours on the next
+// anti-diagonal, so ONE set of 32 serves both parities: oX / oY hold the previous anti-diagonal's (cell l + 1 is entry
+// T + P, cell l - 1 entry T + P - 1), nX / nY receive this one's.
+// LIMITS: H of the cells with i > rmax or j > qmax (bit l of alive_lo/hi clear) is killed — X of a cell past rmax only
+// feeds cells further past it and its Y derives from killed cells, and the other way round past qmax.
+template <int P, int T, bool LIMITS>
+struct ExtLaneCell {
+  static __device__ __forceinline__ void run(uint32_t (&H)[64], const uint32_t (&oX)[32], const uint32_t (&oY)[32], uint32_t (&nX)[32],
+                                             uint32_t (&nY)[32], uint32_t e_lo, uint32_t e_hi, uint32_t d, uint32_t alive_lo,
+                                             uint32_t alive_hi, uint32_t& best, uint32_t& bpay) {
+    constexpr int L = P + 2 * T;
+    constexpr uint32_t K_TOP = 0xFFFF8000u;
+    constexpr uint32_t K_OPEN = (uint32_t)(-SC_GAP_OPEN) * 32768u + 1u, K_EXT = (uint32_t)(-SC_GAP_EXT) * 32768u + 1u;
+    constexpr uint32_t K_MATCH = (uint32_t)SC_MATCH * 32768u, K_MISMATCH = (uint32_t)(-SC_MISMATCH) * 32768u + 1u;
+    uint32_t nx = 0, ny = 0;
+    if (L + 1 < 64) {
+      const uint32_t xa = __builtin_elementwise_sub_sat(H[L + 1 < 64 ? L + 1 : 0], K_OPEN);
+      const uint32_t xb = __builtin_elementwise_sub_sat(oX[T + P < 32 ? T + P : 0], K_EXT);
+      nx = xa > xb ? xa : xb;
+    }
+    if (L >= 1) {
+      const uint32_t ya = __builtin_elementwise_sub_sat(H[L >= 1 ? L - 1 : 0], K_OPEN);
+      const uint32_t yb = __builtin_elementwise_sub_sat(oY[T + P >= 1 ? T + P - 1 : 0], K_EXT);
+      ny = ya > yb ? ya : yb;
+    }
+    const uint32_t bit = ((T < 16 ? e_lo : e_hi) >> (2 * (T & 15))) & 1u;
+    uint32_t nh = mad_u24(bit, K_MATCH + K_MISMATCH, __builtin_elementwise_sub_sat(H[L], K_MISMATCH));
+    nh = nh > nx ? nh : nx;
+    nh = nh > ny ? nh : ny;
+    if (LIMITS) nh &= (uint32_t)((int32_t)((L < 32 ? alive_lo : alive_hi) << (31 - (L & 31))) >> 31);
+    H[L] = nh; nX[T] = nx; nY[T] = ny;
+    // P = 1 walks the cells upwards (ties: >=), P = 0 downwards (ties: >): either way the largest diagonal wins a tie, and
+    // an entry of oX / oY is dead by the time the same entry of nX / nY is written, so the two can share registers
+    const uint32_t ck = (nh & K_TOP) | d;
+    bpay = (P == 1 ? ck >= best : ck > best) ? ((nh << 6) | (uint32_t)L) : bpay;
+    best = ck > best ? ck : best;
+    ExtLaneCell<P, (P == 1 ? T + 1 : T - 1), LIMITS>::run(H, oX, oY, nX, nY, e_lo, e_hi, d, alive_lo, alive_hi, best, bpay);
+  }
+};
+template <bool LIMITS>
+struct ExtLaneCell<0, -1, LIMITS> {
+  static __device__ __forceinline__ void run(uint32_t (&)[64], const uint32_t (&)[32], const uint32_t (&)[32], uint32_t (&)[32],
+                                             uint32_t (&)[32], uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t&, uint32_t&) {}
+};
+template <bool LIMITS>
+struct ExtLaneCell<1, 32, LIMITS> {
+  static __device__ __forceinline__ void run(uint32_t (&)[64], const uint32_t (&)[32], const uint32_t (&)[32], uint32_t (&)[32],
+                                             uint32_t (&)[32], uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t&, uint32_t&) {}
+};
+
+// The per-lane scalars of a task.
+struct LaneTask {
+  uint32_t chain;          // where the result goes
+  int32_t d, d_end, koff, lt, targeted, tr, tq;
+  int32_t c1, c2;          // 2 * rmax - 32 + koff and 2 * qmax + 32 - koff: cell l is inside the limits iff d - c1 <= l <= c2 - d
+  uint32_t best, bpay;
+};
+__device__ __forceinline__ ExtResult lane_best_result(const LaneTask& t) {
+  ExtResult r{0, 0, 0, 0, 0};
+  const int32_t gd = (int32_t)(t.best & 32767u), kk = (int32_t)(t.bpay & 63u) - BAND / 2 + t.koff;
+  r.score = (int32_t)(t.best >> 15) - 65536; r.errors = 32767 - (int32_t)((t.bpay >> 6) & 32767u);
+  r.di = (gd - kk) / 2; r.dj = (gd + kk) / 2;
+  return r;
+}
+
+// One anti-diagonal (register parity P) for the lanes with go set.
+template <int P, bool LIMITS>
+__device__ __forceinline__ void ext_lane_step(bool go, uint32_t (&H)[64], uint32_t (&X)[32], uint32_t (&Y)[32], LaneWin& w, LaneSeq& rs,
+                                              LaneSeq& qs, LaneTask& t) {
+  if (go) {
+    t.d += 1;
+    if (P == 0) lane_win_push_ref(w, rs); else lane_win_push_qry(w, qs);
+    const uint32_t x_lo = w.rc_lo ^ w.qc_lo, x_hi = w.rc_hi ^ w.qc_hi;
+    const uint32_t e_lo = ~(x_lo | (x_lo >> 1)) & w.ro_lo & w.qo_lo, e_hi = ~(x_hi | (x_hi >> 1)) & w.ro_hi & w.qo_hi;
+    uint32_t alive_lo = ~0u, alive_hi = ~0u;
+    if (LIMITS) {
+      const int32_t lo = t.d - t.c1 > 0 ? t.d - t.c1 : 0, hi = t.c2 - t.d;   // diagonals lo .. hi are inside both sequences
+      uint64_t m = lo >= 64 ? 0ull : (~0ull << lo);
+      m &= hi < 0 ? 0ull : hi >= 63 ? ~0ull : ((2ull << hi) - 1ull);
+      alive_lo = (uint32_t)m; alive_hi = (uint32_t)(m >> 32);
+    }
+    uint32_t nX[32], nY[32];
+    ExtLaneCell<P, (P == 1 ? 0 : 31), LIMITS>::run(H, X, Y, nX, nY, e_lo, e_hi, (uint32_t)t.d, alive_lo, alive_hi, t.best, t.bpay);
+#pragma unroll
+    for (int k = 0; k < 32; ++k) { X[k] = nX[k]; Y[k] = nY[k]; }
+  }
+}
+
+// 32 anti-diagonals of every active lane, with the checks of pga::extend_banded after each: break rule first, then the
+// end / the target.  LIMITS (uniform): some lane may come within reach of rmax / qmax during the block.
+template <bool LIMITS>
+__device__ __forceinline__ void ext_lane_block(bool& active, uint32_t (&H)[64], uint32_t (&X)[32], uint32_t (&Y)[32], LaneWin& w, LaneSeq& rs,
+                                               LaneSeq& qs, LaneTask& t, ExtPre* __restrict__ pre) {
+  constexpr uint32_t K_LIVE = 32768u << 15;
+  for (int it = 0; it < 16; ++it) {
+#pragma unroll
+    for (int P = 0; P < 2; ++P) {
+      // a lane's next anti-diagonal d + 1 lives on the diagonals l = d + 1 + koff (mod 2)
+      const bool go = active && (((t.d + 1 + t.koff) & 1) == P);
+      if (P == 0) ext_lane_step<0, LIMITS>(go, H, X, Y, w, rs, qs, t); else ext_lane_step<1, LIMITS>(go, H, X, Y, w, rs, qs, t);
+      bool fin = false, want = false;
+      if (go) {
+        if (t.d - (int32_t)(t.best & 32767u) >= BREAK_LEN) fin = true;
+        else if (t.d == t.d_end) { fin = true; want = t.targeted != 0; }
+      }
+      if (__any(fin)) {   // uniform
+        uint32_t tH = 0;
+        if (__any(want)) {
+#pragma unroll
+          for (int l = 0; l < 64; ++l) tH = t.lt == l ? H[l] : tH;
+        }
+        if (fin) {
+          ExtResult r;
+          if (want && tH >= K_LIVE) {
+            r.di = t.tr; r.dj = t.tq; r.score = (int32_t)(tH >> 15) - 65536; r.errors = 32767 - (int32_t)(tH & 32767u); r.reached = 1;
+          } else {
+            r = lane_best_result(t);
+          }
+          pre[t.chain].res = r;
+          pre[t.chain].valid = 1;
+          active = false;
+        }
+      }
+    }
+  }
+}
+
+// Persistent waves, one per SIMD: every lane runs one request at a time (pga::extend_banded: same cells, checks and
+// tie-breaks as extend_wave), in lock-step anti-diagonals, and takes the next request when it is done.  The free
+// searches (list A: length unknown, up to 20 000 anti-diagonals) are handed out before the target searches (list B), so
+// that the long ones start early.  Register parity: step s of the wave updates the diagonals l = s mod 2, so a lane
+// whose band offset is odd simply starts one step later.  Sequence buffers are topped up, dead searches detected and
+// free lanes refilled every 32 steps.
+__global__ __launch_bounds__(64) void anim_extdp_lane_kernel(const ExtReq* __restrict__ reqs_a, const ExtReq* __restrict__ reqs_b,
+                                                             const uint32_t* __restrict__ n_reqs, uint32_t* __restrict__ cursor,
+                                                             ExtPre* __restrict__ pre, ExtDump* __restrict__ dumps, uint32_t dump_cap,
+                                                             uint32_t* __restrict__ n_dumps) {
+  constexpr int W = BAND / 2;
+  constexpr uint32_t K_LIVE = 32768u << 15;
+  const int lane = threadIdx.x & 63;
+  const uint32_t n_a = n_reqs[0], n_all = n_a + n_reqs[1];
+  uint32_t H[64], X[32], Y[32];   // see ExtLaneCell
+#pragma unroll
+  for (int l = 0; l < 64; ++l) { H[l] = 0; X[l >> 1] = 0; Y[l >> 1] = 0; }
+  LaneWin w{0, 0, 0, 0, 0, 0, 0, 0};
+  LaneSeq rs{nullptr, nullptr, 1, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0}, qs = rs;
+  LaneTask t{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  bool active = false, drained = false;   // drained (uniform): the lists have been handed out
+  int blocks_after = 0;                   // 32-step blocks run since then
+  for (;;) {
+    // ---- the tail: once the lists are empty a thinly occupied wave (a lane step costs the same for 1 or 64 searches, and
+    // one lane needs ~10x the time of a whole wave for the same anti-diagonals) hands its searches over to
+    // anim_extend_kernel, state and all; so does any wave after EXT_TAIL_BLOCKS more blocks
+    if (drained) {
+      const uint64_t am = __ballot(active);
+      if (am && (__popcll(am) < EXT_TAIL_LANES || blocks_after >= EXT_TAIL_BLOCKS)) {
+        uint32_t at = 0;
+        if (lane == 0) at = atomicAdd(n_dumps, (uint32_t)__popcll(am));
+        at = (uint32_t)__shfl((int)at, 0, 64);
+        if (active) {
+          const uint32_t slot = at + (uint32_t)__popcll(am & lanemask_lt());
+          if (slot < dump_cap) {
+            ExtDump* o = dumps + slot;
+#pragma unroll
+            for (int l = 0; l < 64; ++l) o->H[l] = H[l];
+#pragma unroll
+            for (int l = 0; l < 32; ++l) { o->X[l] = X[l]; o->Y[l] = Y[l]; }
+            o->best = t.best; o->bpay = t.bpay; o->d = t.d; o->pad_ = 0;
+            pre[t.chain].res.di = (int32_t)slot;
+            pre[t.chain].valid = 2;
+          }   // (no slot left: valid stays 0 and the wave kernel searches from the start)
+          active = false;
+        }
+      }
+      ++blocks_after;
+    }
+    // ---- every 32 steps: buffers, dead searches, refill ----------------------------------------------------------
+    if (active) {
+      if (rs.cnt <= 16) lane_seq_append(rs);
+      if (qs.cnt <= 16) lane_seq_append(qs);
+      uint32_t mx = 0;
+#pragma unroll
+      for (int l = 0; l < 64; ++l) mx = H[l] > mx ? H[l] : mx;
+      if (mx < K_LIVE) {   // nothing alive: the best so far stands (as the break of extend_wave)
+        pre[t.chain].res = lane_best_result(t);
+        pre[t.chain].valid = 1;
+        active = false;
+      }
+    }
+    const uint64_t idle = __ballot(!active);
+    if (idle && !drained) {   // uniform
+      uint32_t at = 0;
+      if (lane == 0) at = atomicAdd(cursor, (uint32_t)__popcll(idle));
+      at = (uint32_t)__shfl((int)at, 0, 64);
+      if (at + (uint32_t)__popcll(idle) >= n_all) drained = true;
+      const uint32_t mine = at + (uint32_t)__popcll(idle & lanemask_lt());
+      int32_t used_r = 0, used_q = 0;
+      const bool fresh = !active && mine < n_all;
+      if (fresh) {
+        const ExtReq q = mine < n_a ? reqs_a[mine] : reqs_b[mine - n_a];
+        t.chain = q.chain;
+        bool targeted = q.tr >= 0;
+        int koff = 0, lt = 0;
+        if (targeted) {   // band placement and target test of pga::extend_banded
+          koff = (q.tq - q.tr) / 2;
+          if (koff > W - 2) koff = W - 2;
+          if (koff < -(W - 2)) koff = -(W - 2);
+          lt = (q.tq - q.tr) - koff + W;
+          if (lt < 0 || lt >= BAND || q.tr > q.rmax || q.tq > q.qmax) { targeted = false; koff = 0; }
+        }
+        t.koff = koff; t.lt = lt; t.targeted = targeted ? 1 : 0; t.tr = q.tr; t.tq = q.tq;
+        t.d = 0; t.d_end = targeted ? q.tr + q.tq : q.rmax + q.qmax;
+        t.c1 = 2 * q.rmax - W + koff; t.c2 = 2 * q.qmax + W - koff;
+#pragma unroll
+        for (int l = 0; l < 64; ++l) { H[l] = (l == W - koff) ? ((65536u << 15) | 32767u) : 0u; X[l >> 1] = 0; Y[l >> 1] = 0; }
+        t.best = 65536u << 15; t.bpay = (32767u << 6) | (uint32_t)(W - koff);
+        // the two streams (see LaneSeq); query strand position p = stored position len-1-p, complemented
+        rs.codes = q.rcodes; rs.mask = q.rmask; rs.len = q.rlen; rs.comp = 0; rs.tmax = q.rmax;
+        rs.start = q.dir > 0 ? q.r0 : q.r0 - 1; rs.sgn = q.dir;
+        qs.codes = q.qcodes; qs.mask = q.qmask; qs.len = q.qlen; qs.comp = q.strand ? 1u : 0u; qs.tmax = q.qmax;
+        if (!q.strand) { qs.start = q.dir > 0 ? q.q0 : q.q0 - 1; qs.sgn = q.dir; }
+        else { qs.start = q.dir > 0 ? q.qlen - 1 - q.q0 : q.qlen - q.q0; qs.sgn = -q.dir; }
+        rs.bc_lo = rs.bc_hi = rs.bo_lo = rs.bo_hi = 0; rs.cnt = 0; rs.chunk = 0;
+        qs.bc_lo = qs.bc_hi = qs.bo_lo = qs.bo_hi = 0; qs.cnt = 0; qs.chunk = 0;
+        lane_seq_append(rs); lane_seq_append(rs);
+        lane_seq_append(qs); lane_seq_append(qs);
+        w = LaneWin{0, 0, 0, 0, 0, 0, 0, 0};
+        // elements already inside the windows just before the first anti-diagonal (which pushes one more of its own)
+        if (koff & 1) { used_r = (31 - koff) / 2; used_q = (koff + 31) / 2; }
+        else { used_r = 16 - koff / 2; used_q = koff / 2 + 15; }
+        active = true;
+        if (targeted && q.tr == 0 && q.tq == 0) {   // already there
+          pre[t.chain].res = ExtResult{0, 0, 0, 0, 1};
+          pre[t.chain].valid = 1;
+          active = false; used_r = 0; used_q = 0;
+        }
+      }
+      const int32_t roll = (int32_t)wave_max_u32((uint32_t)(used_r > used_q ? used_r : used_q));
+      for (int32_t it = 0; it < roll; ++it) {
+        if (it < used_r) lane_win_push_ref(w, rs);
+        if (it < used_q) lane_win_push_qry(w, qs);
+      }
+      if (fresh && active) {
+        if (rs.cnt <= 16) lane_seq_append(rs);
+        if (qs.cnt <= 16) lane_seq_append(qs);
+      }
+    }
+    if (!__any(active)) break;
+    // ---- 32 anti-diagonals ---------------------------------------------------------------------------------------------
+    const bool near_limit = active && (t.d + 34 - t.c1 > 0 || t.c2 - (t.d + 34) < 63);
+    if (__any(near_limit)) ext_lane_block<true>(active, H, X, Y, w, rs, qs, t, pre);
+    else ext_lane_block<false>(active, H, X, Y, w, rs, qs, t, pre);
+  }
+}
+
+// DP call number `round` of every chain of the work list in the given phase, one THREAD per chain: the same policy code
+// as anim_extend_kernel, with a DP routine that replays the delivered results of the earlier calls and only writes the
+// arguments of this one down — as a request for the lanes (free searches in list A, target searches in list B) and into
+// pre[round] for the check in anim_extend_kernel.  valid = 0 until a lane delivers.
+__global__ __launch_bounds__(256) void anim_extreq_kernel(const RefDesc* __restrict__ refs, const UnitDesc* __restrict__ units, ClusterOut O,
+                                                          const uint2* __restrict__ wl, uint32_t n_wl, const ChainFwd* __restrict__ fw,
+                                                          int phase, int round, ExtPre* __restrict__ pre_all, ExtReq* __restrict__ reqs_a,
+                                                          ExtReq* __restrict__ reqs_b, uint32_t* __restrict__ n_reqs) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  bool have = false, lost = false;
+  ExtArgs a{0, 0, 0, 0, 0, 0, 0};
+  ExtReq q;
+  if (i < n_wl) {
+    const uint32_t u = wl[i].x;
+    const int32_t c = (int32_t)wl[i].y;
+    const UnitDesc U = units[u];
+    const RefDesc R = refs[U.ref];
+    const size_t off = O.moff[u];
+    const Chain ch = O.chains[off + c];
+    int32_t r_lo, r_hi, q_lo, q_hi;
+    chain_bounds(R, U, ch, r_lo, r_hi, q_lo, q_hi);
+    const ChainFwd* fwu = fw + off;
+    const Match* cm = O.cm + off;
+    int call = 0;
+    const auto ext = [&](int32_t cr, int32_t cq, int dir, int32_t rmax, int32_t qmax, int32_t tr, int32_t tq) {
+      const ExtArgs now{cr, cq, dir, rmax, qmax, tr, tq};
+      const int k = call++;
+      if (k < round && !lost) {   // an earlier call: its result, if a lane delivered it
+        const ExtPre p = pre_all[(size_t)k * n_wl + i];
+        if (p.valid == 1 && p.args.r0 == cr && p.args.q0 == cq && p.args.dir == dir && p.args.rmax == rmax && p.args.qmax == qmax &&
+            p.args.tr == tr && p.args.tq == tq)
+          return p.res;
+        lost = true;
+      } else if (k == round && !lost) {
+        have = true; a = now;
+      }
+      return ExtResult{0, 0, 0, 0, 1};   // ends the policy code quickly
+    };
+    if (phase == 0) {
+      const int32_t er = fwu[c].lr, eq = fwu[c].lq;
+      int32_t nr, nq, re, qe, err_fwd, reached;
+      pick_forward_target(O.chains + off, cm, O.next_of + off, c, er, eq, nr, nq);
+      forward_extension([&](int32_t cr, int32_t cq, int32_t rmax, int32_t qmax, int32_t tr, int32_t tq) {
+                          return ext(cr, cq, +1, rmax, qmax, tr, tq); },
+                        er, eq, r_hi, q_hi, nr, nq, re, qe, err_fwd, reached);
+    } else {
+      const int32_t p = O.prev_of[off + c];
+      const int32_t first_r = fwu[c].first_r, first_q = fwu[c].first_q;
+      const int32_t prev_re = p >= 0 ? fwu[p].re : -1, prev_qe = p >= 0 ? fwu[p].qe : -1;
+      const bool shadowed = p >= 0 && ((fwu[p].reached && fwu[p].target == c) ||
+                                       (fwu[p].first_r <= first_r && fwu[p].first_q <= first_q && prev_re >= fwu[c].lr && prev_qe >= fwu[c].lq));
+      if (!shadowed) {
+        int32_t tr = -1, tq = -1;
+        if (prev_re >= 0 && first_r >= prev_re && first_q >= prev_qe) { tr = first_r - prev_re; tq = first_q - prev_qe; }
+        if (p >= 0) {
+          const int32_t plr = fwu[p].lr, plq = fwu[p].lq;
+          if (plr <= first_r && plq <= first_q) {
+            if (plr > r_lo) r_lo = plr;
+            if (plq > q_lo) q_lo = plq;
+          }
+        }
+        const int32_t rmax = cap_ext(first_r - r_lo, MAX_EXT_BWD), qmax = cap_ext(first_q - q_lo, MAX_EXT_BWD);
+        const ExtResult b = ext(first_r, first_q, -1, rmax, qmax, tr, tq);
+        if (tr >= 0 && !b.reached && tr != tq) ext(first_r, first_q, -1, rmax, qmax, -1, -1);
+      }
+    }
+    have = have && !lost;
+    ExtPre* mine = pre_all + (size_t)round * n_wl + i;
+    mine->args = a;
+    mine->valid = 0;
+    q.rcodes = R.codes; q.rmask = R.mask; q.qcodes = U.codes; q.qmask = U.mask;
+    q.rlen = (int32_t)R.len; q.qlen = (int32_t)U.len; q.strand = U.strand; q.dir = a.dir;
+    q.r0 = a.r0; q.q0 = a.q0; q.rmax = a.rmax; q.qmax = a.qmax; q.tr = a.tr; q.tq = a.tq;
+    q.chain = i; q.pad_ = 0;
+  }
+  // the lane kernel decides "free search" exactly like pga::extend_banded; here only the order of the hand-out depends on it
+  const bool free_search = have && (a.tr < 0 || a.tr > a.rmax || a.tq > a.qmax);
+  const uint64_t ma = __ballot(free_search), mb = __ballot(have && !free_search);
+  if (ma) {
+    uint32_t at = 0;
+    if (lane == 0) at = atomicAdd(&n_reqs[0], (uint32_t)__popcll(ma));
+    at = (uint32_t)__shfl((int)at, 0, 64);
+    if (free_search) reqs_a[at + (uint32_t)__popcll(ma & lanemask_lt())] = q;
+  }
+  if (mb) {
+    uint32_t at = 0;
+    if (lane == 0) at = atomicAdd(&n_reqs[1], (uint32_t)__popcll(mb));
+    at = (uint32_t)__shfl((int)at, 0, 64);
+    if (have && !free_search) reqs_b[at + (uint32_t)__popcll(mb & lanemask_lt())] = q;
+  }
+}
+
 // One WAVE per chain (work list wl: unit, chain).  phase 0: forward extension off the last match (the rest of
 // pga::extend_chain_fwd is anim_gaps_kernel + anim_gapdp_kernel); phase 1: backward extension towards the previous
 // chain's forward end (extend_chain_bwd).
 __global__ __launch_bounds__(64) void anim_extend_kernel(const RefDesc* __restrict__ refs, const UnitDesc* __restrict__ units,
                                                          ClusterOut O, const uint2* __restrict__ wl,
-                                                         ChainFwd* __restrict__ fw, ChainBwd* __restrict__ bw, int phase) {
+                                                         ChainFwd* __restrict__ fw, ChainBwd* __restrict__ bw, int phase,
+                                                         const ExtPre* __restrict__ pre, uint32_t n_wl, const ExtDump* __restrict__ dumps) {
   const uint32_t u = wl[blockIdx.x].x;
   const int32_t c = (int32_t)wl[blockIdx.x].y;
   const UnitDesc U = units[u];
   const RefDesc R = refs[U.ref];
   const SeqView RV{R.codes, R.mask, R.len};
   const StrandView QV{SeqView{U.codes, U.mask, U.len}, U.strand};
+  // the chain's first DP calls of the phase may have been solved by a lane of anim_extdp_lane_kernel already
+  int call = 0;
+  const auto ext = [&](int32_t cr, int32_t cq, int dir, int32_t rmax, int32_t qmax, int32_t tr, int32_t tq) {
+    const int k = call++;
+    if (k < EXT_ROUNDS) {   // uniform
+      const ExtPre pr = pre[(size_t)k * n_wl + blockIdx.x];
+      const bool same = pr.args.r0 == cr && pr.args.q0 == cq && pr.args.dir == dir && pr.args.rmax == rmax && pr.args.qmax == qmax &&
+                        pr.args.tr == tr && pr.args.tq == tq;
+#ifdef PGA_DP_STATS
+      if ((threadIdx.x & 63) == 0) atomicAdd(&g_dp_stats[dir < 0 ? 2 : 1][pr.valid == 1 && same ? 3 : pr.valid == 2 && same ? 6 : !same ? 5 : 4], 1ull);
+#endif
+      if (pr.valid == 1 && same) return pr.res;
+      if (pr.valid == 2 && same) return extend_wave(RV, QV, cr, cq, dir, rmax, qmax, tr, tq, dumps + pr.res.di);   // handed over mid-way
+    }
+    return ExtResult{0, 0, 0, 0, -1};   // not delivered
+  };
   const size_t off = O.moff[u];
   const Chain ch = O.chains[off + c];
   int32_t r_lo, r_hi, q_lo, q_hi;
@@ -1908,7 +2396,8 @@ __global__ __launch_bounds__(64) void anim_extend_kernel(const RefDesc* __restri
     int32_t nr, nq, re, qe, err_fwd, reached;
     const int32_t target = pick_forward_target(O.chains + off, cm, O.next_of + off, c, er, eq, nr, nq);
     forward_extension([&](int32_t cr, int32_t cq, int32_t rmax, int32_t qmax, int32_t tr, int32_t tq) {
-                        return extend_wave(RV, QV, cr, cq, +1, rmax, qmax, tr, tq); },
+                        const ExtResult x = ext(cr, cq, +1, rmax, qmax, tr, tq);
+                        return x.reached >= 0 ? x : extend_wave(RV, QV, cr, cq, +1, rmax, qmax, tr, tq); },
                       er, eq, r_hi, q_hi, nr, nq, re, qe, err_fwd, reached);
     if ((threadIdx.x & 63) == 0) {   // field-wise: inner_err may still be receiving atomics from the gap DP kernel
       fwu[c].re = re; fwu[c].qe = qe; fwu[c].err_fwd = err_fwd; fwu[c].reached = reached; fwu[c].target = target;
@@ -1931,9 +2420,14 @@ __global__ __launch_bounds__(64) void anim_extend_kernel(const RefDesc* __restri
         if (plq > q_lo) q_lo = plq;
       }
     }
-    ExtResult b = extend_wave(RV, QV, first_r, first_q, -1, cap_ext(first_r - r_lo, MAX_EXT_BWD), cap_ext(first_q - q_lo, MAX_EXT_BWD), tr, tq);
-    if (tr >= 0 && !b.reached && tr != tq)   // shifted band, unreachable target: search freely (as pga::extend_chain_bwd)
-      b = extend_wave(RV, QV, first_r, first_q, -1, cap_ext(first_r - r_lo, MAX_EXT_BWD), cap_ext(first_q - q_lo, MAX_EXT_BWD), -1, -1);
+    ExtResult b = ext(first_r, first_q, -1, cap_ext(first_r - r_lo, MAX_EXT_BWD), cap_ext(first_q - q_lo, MAX_EXT_BWD), tr, tq);
+    if (b.reached < 0)
+      b = extend_wave(RV, QV, first_r, first_q, -1, cap_ext(first_r - r_lo, MAX_EXT_BWD), cap_ext(first_q - q_lo, MAX_EXT_BWD), tr, tq);
+    if (tr >= 0 && !b.reached && tr != tq) {   // shifted band, unreachable target: search freely (as pga::extend_chain_bwd)
+      b = ext(first_r, first_q, -1, cap_ext(first_r - r_lo, MAX_EXT_BWD), cap_ext(first_q - q_lo, MAX_EXT_BWD), -1, -1);
+      if (b.reached < 0)
+        b = extend_wave(RV, QV, first_r, first_q, -1, cap_ext(first_r - r_lo, MAX_EXT_BWD), cap_ext(first_q - q_lo, MAX_EXT_BWD), -1, -1);
+    }
     ChainBwd e;
     e.rs = first_r - b.di; e.qs = first_q - b.dj; e.err_back = b.errors;
     e.reached = (tr >= 0 && b.reached) ? 1 : 0;
@@ -2124,6 +2618,10 @@ struct AnimScratch {
   size_t seed_cap = 0;
   uint32_t* seed_total = nullptr;   // [0] matches appended, [1] hits recorded
   uint32_t* gap_counts = nullptr;   // gap tasks per size class + the wave list
+  ExtReq* ext_reqs = nullptr;       // DP requests for the lanes: free searches, then (at n_wl) target searches
+  ExtPre* ext_pre = nullptr;        // [EXT_ROUNDS][n_wl] arguments of the chains' first DP calls and the delivered results
+  ExtDump* ext_dumps = nullptr;     // searches the lanes hand over to the wave kernel mid-way
+  size_t ext_cap = 0;
   uint8_t* task_cls = nullptr;      // size class of the GapTask in every match slot (0xFF = none)
   uint32_t* task_lists = nullptr;   // [GAP_CLASSES + 1][slots] slot lists by class
   Match* hits_d = nullptr;          // hits recorded by the probe kernel for anim_hit_kernel
@@ -2202,7 +2700,7 @@ void pg_anim_free_scratch(pg_ctx* ctx) {
   AnimScratch* A = static_cast<AnimScratch*>(ctx->anim_scratch);
   if (!A) return;
   pg_anim_drop_lists(ctx);
-  void* ptrs[] = {A->gap_counts, A->task_cls, A->task_lists, A->hits_sorted, A->hit_count, A->hoff, A->hit_cursor, A->hits_d, A->slice_d, A->choff_d, A->list_cnt, A->srefs_d, A->sqry_d, A->recs_d, A->refs_d, A->units_d, A->mem_count, A->moff, A->nch, A->status, A->out, A->mem, A->cm,
+  void* ptrs[] = {A->ext_reqs, A->ext_pre, A->ext_dumps, A->gap_counts, A->task_cls, A->task_lists, A->hits_sorted, A->hit_count, A->hoff, A->hit_cursor, A->hits_d, A->slice_d, A->choff_d, A->list_cnt, A->srefs_d, A->sqry_d, A->recs_d, A->refs_d, A->units_d, A->mem_count, A->moff, A->nch, A->status, A->out, A->mem, A->cm,
                   A->iscratch, A->order, A->prev, A->next, A->alnof, A->chains, A->fw, A->bw, A->S.alns, A->S.a_rrec,
                   A->S.a_qrec, A->S.idx, A->S.from, A->S.sc, A->wl_d, A->seedbuf, A->seed_total, A->tasks_d};
   for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -2478,9 +2976,27 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
                        A->task_lists + 3 * Mp, A->gap_counts + 3, A->fw);
     hipLaunchKernelGGL(anim_gapdp_kernel, dim3((uint32_t)ctx->num_cu * 32u), dim3(64), 0, ctx->stream, A->refs_d, A->units_d, O,
                        A->tasks_d, A->task_lists + GAP_CLASSES * Mp, A->gap_counts + GAP_CLASSES, A->fw);
-    for (int phase = 0; phase < 2; ++phase)
+    if (!A->ext_dumps && (rc = regrow(ctx, A->ext_dumps, EXT_DUMP_CAP))) return rc;
+    if (n_wl > A->ext_cap) {
+      const size_t cap = n_wl + n_wl / 2;
+      if ((rc = regrow(ctx, A->ext_reqs, 2 * cap))) return rc;
+      if ((rc = regrow(ctx, A->ext_pre, EXT_ROUNDS * cap))) return rc;
+      A->ext_cap = cap;
+    }
+    for (int phase = 0; phase < 2; ++phase) {
+      // the first DP calls of every chain: written down, solved one per LANE, then consumed by the wave kernel
+      PG_HIP(ctx, hipMemsetAsync(A->gap_counts + 3, 0, 4, ctx->stream));   // [3] searches handed over mid-way
+      for (int round = 0; round < EXT_ROUNDS; ++round) {
+        PG_HIP(ctx, hipMemsetAsync(A->gap_counts, 0, 12, ctx->stream));   // [0], [1] list lengths, [2] hand-out cursor
+        hipLaunchKernelGGL(anim_extreq_kernel, dim3((uint32_t)((n_wl + 255) / 256)), dim3(256), 0, ctx->stream, A->refs_d, A->units_d, O,
+                           A->wl_d, (uint32_t)n_wl, A->fw, phase, round, A->ext_pre, A->ext_reqs, A->ext_reqs + n_wl, A->gap_counts);
+        hipLaunchKernelGGL(anim_extdp_lane_kernel, dim3((uint32_t)ctx->num_cu * 4u), dim3(64), 0, ctx->stream, A->ext_reqs,
+                           A->ext_reqs + n_wl, A->gap_counts, A->gap_counts + 2, A->ext_pre + (size_t)round * n_wl, A->ext_dumps,
+                           EXT_DUMP_CAP, A->gap_counts + 3);
+      }
       hipLaunchKernelGGL(anim_extend_kernel, dim3((uint32_t)n_wl), dim3(64), 0, ctx->stream, A->refs_d, A->units_d, O,
-                         A->wl_d, A->fw, A->bw, phase);
+                         A->wl_d, A->fw, A->bw, phase, A->ext_pre, (uint32_t)n_wl, A->ext_dumps);
+    }
   }
   hipLaunchKernelGGL(anim_finish_kernel, dim3(n_pairs), dim3(64), 0, ctx->stream, A->refs_d, A->units_d, n_pairs,
                      O, A->fw, A->bw, A->S, filter_1to1, A->out);
@@ -2498,7 +3014,8 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
     fprintf(stderr, "[cluster-stats] general-path rounds %llu, sum of live entries over rounds %llu, cycles in the general path %llu\n", cl[13], cl[14], cl[15]);
     const char* names[3] = {"gap", "fwd", "bwd"};
     for (int k = 0; k < 3; ++k) {
-      fprintf(stderr, "[dp-stats] %s calls %llu steps %llu cycles %llu  hist(log2 steps):", names[k], st[k][0], st[k][1], st[k][2]);
+      fprintf(stderr, "[dp-stats] %s calls %llu steps %llu cycles %llu  first calls: delivered %llu, handed over %llu, not valid %llu, other arguments %llu  hist(log2 steps):",
+              names[k], st[k][0], st[k][1], st[k][2], st[k][3], st[k][6], st[k][4], st[k][5]);
       for (int b = 0; b < 20; ++b) fprintf(stderr, " %llu", st[k][8 + b]);
       fprintf(stderr, "\n");
     }
