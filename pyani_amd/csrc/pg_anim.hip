@@ -1703,21 +1703,6 @@ __global__ __launch_bounds__(GAPSORT_BLOCK) void anim_gapsort_kernel(const uint8
   }
 }
 
-// One wave per GapTask at a time (grid-stride over the list of large gaps, whose length only the device knows).
-__global__ __launch_bounds__(64) void anim_gapdp_kernel(const RefDesc* __restrict__ refs, const UnitDesc* __restrict__ units,
-                                                        ClusterOut O, const GapTask* __restrict__ tasks, const uint32_t* __restrict__ list,
-                                                        const uint32_t* __restrict__ n_tasks, ChainFwd* __restrict__ fw) {
-  const uint32_t n = *n_tasks;
-  for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
-    const GapTask T = tasks[list[i]];
-    const UnitDesc U = units[T.unit];
-    const RefDesc R = refs[U.ref];
-    const SeqView RV{R.codes, R.mask, R.len};
-    const StrandView QV{SeqView{U.codes, U.mask, U.len}, U.strand};
-    const int32_t err = gap_errors_wave(RV, QV, T.r0, T.n, T.q0, T.m);
-    if ((threadIdx.x & 63) == 0 && err) atomicAdd(&fw[O.moff[T.unit] + T.chain].inner_err, err);
-  }
-}
 
 // ---- small gaps: one LANE per GapTask ---------------------------------------------------------------------------
 // 64 positions of a sequence starting at p0 (any sign): 2-bit codes in c[0..3] (position p0 in the low bits of c[0]) and
@@ -2143,7 +2128,7 @@ __device__ __forceinline__ void ext_lane_block(bool& active, uint32_t (&H)[64], 
 __global__ __launch_bounds__(64) void anim_extdp_lane_kernel(const ExtReq* __restrict__ reqs_a, const ExtReq* __restrict__ reqs_b,
                                                              const uint32_t* __restrict__ n_reqs, uint32_t* __restrict__ cursor,
                                                              ExtPre* __restrict__ pre, ExtDump* __restrict__ dumps, uint32_t dump_cap,
-                                                             uint32_t* __restrict__ n_dumps) {
+                                                             uint32_t* __restrict__ n_dumps, int tail_lanes, int tail_blocks) {
   constexpr int W = BAND / 2;
   constexpr uint32_t K_LIVE = 32768u << 15;
   const int lane = threadIdx.x & 63;
@@ -2162,7 +2147,7 @@ __global__ __launch_bounds__(64) void anim_extdp_lane_kernel(const ExtReq* __res
     // anim_extend_kernel, state and all; so does any wave after EXT_TAIL_BLOCKS more blocks
     if (drained) {
       const uint64_t am = __ballot(active);
-      if (am && (__popcll(am) < EXT_TAIL_LANES || blocks_after >= EXT_TAIL_BLOCKS)) {
+      if (am && (__popcll(am) < tail_lanes || blocks_after >= tail_blocks)) {
         uint32_t at = 0;
         if (lane == 0) at = atomicAdd(n_dumps, (uint32_t)__popcll(am));
         at = (uint32_t)__shfl((int)at, 0, 64);
@@ -2352,6 +2337,76 @@ __global__ __launch_bounds__(256) void anim_extreq_kernel(const RefDesc* __restr
     if (lane == 0) at = atomicAdd(&n_reqs[1], (uint32_t)__popcll(mb));
     at = (uint32_t)__shfl((int)at, 0, 64);
     if (have && !free_search) reqs_b[at + (uint32_t)__popcll(mb & lanemask_lt())] = q;
+  }
+}
+
+// The gaps too large for anim_gapdp_lane_kernel (a side > 63) are target searches like any other: anim_gapreq_kernel turns
+// the entries of their list into requests for anim_extdp_lane_kernel (one THREAD per entry; a target outside the band
+// is not worth a search, pga::gap_errors counts the diagonal then), anim_gapdp_kernel picks the results up.
+__global__ __launch_bounds__(256) void anim_gapreq_kernel(const RefDesc* __restrict__ refs, const UnitDesc* __restrict__ units,
+                                                          const GapTask* __restrict__ tasks, const uint32_t* __restrict__ list, uint32_t n,
+                                                          ExtPre* __restrict__ pre, ExtReq* __restrict__ reqs_b, uint32_t* __restrict__ n_reqs) {
+  constexpr int W = BAND / 2;
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  bool have = false;
+  ExtReq q;
+  if (i < n) {
+    const GapTask T = tasks[list[i]];
+    const UnitDesc U = units[T.unit];
+    const RefDesc R = refs[U.ref];
+    int koff = (T.m - T.n) / 2;
+    if (koff > W - 2) koff = W - 2;
+    if (koff < -(W - 2)) koff = -(W - 2);
+    const int lt = (T.m - T.n) - koff + W;
+    have = lt >= 0 && lt < BAND;
+    pre[i].args = ExtArgs{T.r0, T.q0, +1, T.n, T.m, T.n, T.m};
+    pre[i].valid = have ? 0 : 3;   // 3: no search needed
+    q.rcodes = R.codes; q.rmask = R.mask; q.qcodes = U.codes; q.qmask = U.mask;
+    q.rlen = (int32_t)R.len; q.qlen = (int32_t)U.len; q.strand = U.strand; q.dir = +1;
+    q.r0 = T.r0; q.q0 = T.q0; q.rmax = T.n; q.qmax = T.m; q.tr = T.n; q.tq = T.m;
+    q.chain = i; q.pad_ = 0;
+  }
+  const uint64_t mb = __ballot(have);
+  if (mb) {
+    uint32_t at = 0;
+    if (lane == 0) at = atomicAdd(&n_reqs[1], (uint32_t)__popcll(mb));
+    at = (uint32_t)__shfl((int)at, 0, 64);
+    if (have) reqs_b[at + (uint32_t)__popcll(mb & lanemask_lt())] = q;
+  }
+}
+
+// One wave per large gap at a time (grid-stride over their list): the lanes' result, the rest of a search they handed
+// over, or the whole of pga::gap_errors.
+__global__ __launch_bounds__(64) void anim_gapdp_kernel(const RefDesc* __restrict__ refs, const UnitDesc* __restrict__ units,
+                                                        ClusterOut O, const GapTask* __restrict__ tasks, const uint32_t* __restrict__ list,
+                                                        uint32_t n, const ExtPre* __restrict__ pre, const ExtDump* __restrict__ dumps,
+                                                        ChainFwd* __restrict__ fw) {
+  for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
+    const GapTask T = tasks[list[i]];
+    const UnitDesc U = units[T.unit];
+    const RefDesc R = refs[U.ref];
+    const SeqView RV{R.codes, R.mask, R.len};
+    const StrandView QV{SeqView{U.codes, U.mask, U.len}, U.strand};
+    const ExtPre pr = pre[i];
+    int32_t err;
+    if (pr.valid == 0) {
+      err = gap_errors_wave(RV, QV, T.r0, T.n, T.q0, T.m);
+    } else {
+      ExtResult e{0, 0, 0, 0, 0};
+      if (pr.valid == 1) e = pr.res;
+      else if (pr.valid == 2) e = extend_wave(RV, QV, T.r0, T.q0, +1, T.n, T.m, T.n, T.m, dumps + pr.res.di);
+      if (e.reached) {
+        err = e.errors;
+      } else {   // target outside the band or pruned: the diagonal part + the length difference (pga::gap_errors)
+        const int32_t kq = T.n < T.m ? T.n : T.m;
+        int32_t part = 0;
+        for (int32_t t = threadIdx.x & 63; t < kq; t += 64)
+          part += (RV.clean(T.r0 + t) && QV.clean(T.q0 + t) && RV.base(T.r0 + t) == QV.base(T.q0 + t)) ? 0 : 1;
+        err = wave_sum32(part) + (T.n > T.m ? T.n - T.m : T.m - T.n);
+      }
+    }
+    if ((threadIdx.x & 63) == 0 && err) atomicAdd(&fw[O.moff[T.unit] + T.chain].inner_err, err);
   }
 }
 
@@ -2621,6 +2676,7 @@ struct AnimScratch {
   ExtReq* ext_reqs = nullptr;       // DP requests for the lanes: free searches, then (at n_wl) target searches
   ExtPre* ext_pre = nullptr;        // [EXT_ROUNDS][n_wl] arguments of the chains' first DP calls and the delivered results
   ExtDump* ext_dumps = nullptr;     // searches the lanes hand over to the wave kernel mid-way
+  uint32_t* ext_counts = nullptr;   // request list lengths, hand-out cursor, hand-over count of a lane launch
   size_t ext_cap = 0;
   uint8_t* task_cls = nullptr;      // size class of the GapTask in every match slot (0xFF = none)
   uint32_t* task_lists = nullptr;   // [GAP_CLASSES + 1][slots] slot lists by class
@@ -2700,7 +2756,7 @@ void pg_anim_free_scratch(pg_ctx* ctx) {
   AnimScratch* A = static_cast<AnimScratch*>(ctx->anim_scratch);
   if (!A) return;
   pg_anim_drop_lists(ctx);
-  void* ptrs[] = {A->ext_reqs, A->ext_pre, A->ext_dumps, A->gap_counts, A->task_cls, A->task_lists, A->hits_sorted, A->hit_count, A->hoff, A->hit_cursor, A->hits_d, A->slice_d, A->choff_d, A->list_cnt, A->srefs_d, A->sqry_d, A->recs_d, A->refs_d, A->units_d, A->mem_count, A->moff, A->nch, A->status, A->out, A->mem, A->cm,
+  void* ptrs[] = {A->ext_reqs, A->ext_pre, A->ext_dumps, A->ext_counts, A->gap_counts, A->task_cls, A->task_lists, A->hits_sorted, A->hit_count, A->hoff, A->hit_cursor, A->hits_d, A->slice_d, A->choff_d, A->list_cnt, A->srefs_d, A->sqry_d, A->recs_d, A->refs_d, A->units_d, A->mem_count, A->moff, A->nch, A->status, A->out, A->mem, A->cm,
                   A->iscratch, A->order, A->prev, A->next, A->alnof, A->chains, A->fw, A->bw, A->S.alns, A->S.a_rrec,
                   A->S.a_qrec, A->S.idx, A->S.from, A->S.sc, A->wl_d, A->seedbuf, A->seed_total, A->tasks_d};
   for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -2974,25 +3030,40 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
                        A->task_lists + 2 * Mp, A->gap_counts + 2, A->fw);
     hipLaunchKernelGGL((anim_gapdp_lane_kernel<64, true>), lane_grid, dim3(64), 0, ctx->stream, A->refs_d, A->units_d, O, A->tasks_d,
                        A->task_lists + 3 * Mp, A->gap_counts + 3, A->fw);
-    hipLaunchKernelGGL(anim_gapdp_kernel, dim3((uint32_t)ctx->num_cu * 32u), dim3(64), 0, ctx->stream, A->refs_d, A->units_d, O,
-                       A->tasks_d, A->task_lists + GAP_CLASSES * Mp, A->gap_counts + GAP_CLASSES, A->fw);
+    // the larger gaps go through the lanes of the extension DP (anim_gapreq_kernel); their number sizes the buffers
+    uint32_t gap_counts[GAP_CLASSES + 1];
+    PG_HIP(ctx, hipMemcpyAsync(gap_counts, A->gap_counts, sizeof(gap_counts), hipMemcpyDeviceToHost, ctx->stream));
+    PG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const size_t n_big = gap_counts[GAP_CLASSES], n_ext = n_wl > n_big ? n_wl : n_big;
+    static const int tail_lanes = getenv("PYANI_EXT_TAIL_LANES") ? atoi(getenv("PYANI_EXT_TAIL_LANES")) : EXT_TAIL_LANES;
+    static const int tail_blocks = getenv("PYANI_EXT_TAIL_BLOCKS") ? atoi(getenv("PYANI_EXT_TAIL_BLOCKS")) : EXT_TAIL_BLOCKS;
     if (!A->ext_dumps && (rc = regrow(ctx, A->ext_dumps, EXT_DUMP_CAP))) return rc;
-    if (n_wl > A->ext_cap) {
-      const size_t cap = n_wl + n_wl / 2;
+    if (!A->ext_counts && (rc = regrow(ctx, A->ext_counts, 4))) return rc;
+    if (n_ext > A->ext_cap) {
+      const size_t cap = n_ext + n_ext / 2;
       if ((rc = regrow(ctx, A->ext_reqs, 2 * cap))) return rc;
       if ((rc = regrow(ctx, A->ext_pre, EXT_ROUNDS * cap))) return rc;
       A->ext_cap = cap;
     }
+    if (n_big) {
+      PG_HIP(ctx, hipMemsetAsync(A->ext_counts, 0, 16, ctx->stream));   // [0], [1] list lengths, [2] hand-out cursor, [3] handed over
+      hipLaunchKernelGGL(anim_gapreq_kernel, dim3((uint32_t)((n_big + 255) / 256)), dim3(256), 0, ctx->stream, A->refs_d, A->units_d,
+                         A->tasks_d, A->task_lists + GAP_CLASSES * Mp, (uint32_t)n_big, A->ext_pre, A->ext_reqs, A->ext_counts);
+      hipLaunchKernelGGL(anim_extdp_lane_kernel, dim3((uint32_t)ctx->num_cu * 4u), dim3(64), 0, ctx->stream, A->ext_reqs, A->ext_reqs,
+                         A->ext_counts, A->ext_counts + 2, A->ext_pre, A->ext_dumps, EXT_DUMP_CAP, A->ext_counts + 3, tail_lanes, tail_blocks);
+      hipLaunchKernelGGL(anim_gapdp_kernel, dim3((uint32_t)ctx->num_cu * 32u), dim3(64), 0, ctx->stream, A->refs_d, A->units_d, O,
+                         A->tasks_d, A->task_lists + GAP_CLASSES * Mp, (uint32_t)n_big, A->ext_pre, A->ext_dumps, A->fw);
+    }
     for (int phase = 0; phase < 2; ++phase) {
       // the first DP calls of every chain: written down, solved one per LANE, then consumed by the wave kernel
-      PG_HIP(ctx, hipMemsetAsync(A->gap_counts + 3, 0, 4, ctx->stream));   // [3] searches handed over mid-way
+      PG_HIP(ctx, hipMemsetAsync(A->ext_counts + 3, 0, 4, ctx->stream));   // [3] searches handed over mid-way
       for (int round = 0; round < EXT_ROUNDS; ++round) {
-        PG_HIP(ctx, hipMemsetAsync(A->gap_counts, 0, 12, ctx->stream));   // [0], [1] list lengths, [2] hand-out cursor
+        PG_HIP(ctx, hipMemsetAsync(A->ext_counts, 0, 12, ctx->stream));   // [0], [1] list lengths, [2] hand-out cursor
         hipLaunchKernelGGL(anim_extreq_kernel, dim3((uint32_t)((n_wl + 255) / 256)), dim3(256), 0, ctx->stream, A->refs_d, A->units_d, O,
-                           A->wl_d, (uint32_t)n_wl, A->fw, phase, round, A->ext_pre, A->ext_reqs, A->ext_reqs + n_wl, A->gap_counts);
+                           A->wl_d, (uint32_t)n_wl, A->fw, phase, round, A->ext_pre, A->ext_reqs, A->ext_reqs + n_wl, A->ext_counts);
         hipLaunchKernelGGL(anim_extdp_lane_kernel, dim3((uint32_t)ctx->num_cu * 4u), dim3(64), 0, ctx->stream, A->ext_reqs,
-                           A->ext_reqs + n_wl, A->gap_counts, A->gap_counts + 2, A->ext_pre + (size_t)round * n_wl, A->ext_dumps,
-                           EXT_DUMP_CAP, A->gap_counts + 3);
+                           A->ext_reqs + n_wl, A->ext_counts, A->ext_counts + 2, A->ext_pre + (size_t)round * n_wl, A->ext_dumps,
+                           EXT_DUMP_CAP, A->ext_counts + 3, tail_lanes, tail_blocks);
       }
       hipLaunchKernelGGL(anim_extend_kernel, dim3((uint32_t)n_wl), dim3(64), 0, ctx->stream, A->refs_d, A->units_d, O,
                          A->wl_d, A->fw, A->bw, phase, A->ext_pre, (uint32_t)n_wl, A->ext_dumps);
