@@ -10,9 +10,14 @@
 //   A3 anim_cluster_wave_kernel  one WAVE per (pair, strand): MUM filter (packed radix sorts + wave-scan containment
 //                            flags), mgaps clustering (lock-free union-find), chain extraction (register / LDS resident)
 //   A4 anim_gaps_kernel      one wave per chain: trims the chained matches, settles trivial gaps, emits GapTasks
-//      anim_gapdp_kernel     one wave per GapTask: banded affine DP (64 lanes = 64 diagonals, DPP neighbour exchange)
+//      the banded affine DP (pga::extend_banded) in two forms with identical results:
+//      anim_gapdp_lane_kernel / anim_extdp_lane_kernel   one LANE per search, 64 per wave, the band in registers (small
+//                            gaps row by row; extensions and larger gaps by anti-diagonals in persistent waves)
+//      extend_wave           one WAVE per search (64 lanes = 64 diagonals, DPP neighbour exchange): takes over the
+//                            searches the lane waves hand over mid-way when they run thin, and the rare later calls
+//      anim_extreq_kernel    writes the DP calls of every chain down as requests for the lanes (policy code, no DP)
 //      anim_extend_kernel    one wave per chain: forward extension towards the next chain, then backward extension /
-//                            junction bridge
+//                            junction bridge, consuming the lanes' answers
 //   A5 anim_finish_kernel    one wave per pair: stitch/fuse chains, 1-to-1 filter, parse_delta reduction -> pg_anim_result
 //
 // Every kernel has a scalar statement in pg_anim_core.h that compiles for the host (tools/anim_debug); the two are kept
@@ -1561,13 +1566,13 @@ __global__ __launch_bounds__(64) void anim_wl_kernel(const uint32_t* __restrict_
 // ---- A4a: gaps between the chained matches ---------------------------------------------------------------------------
 // One wave per chain walks its matches 64 at a time (pga::chain_inner_errors' trimming, lane = match).  Gaps that need
 // no DP (empty on one side, or <= 2 substitutions on one diagonal) are settled in the lane; the others become GapTasks
-// for anim_gapdp_kernel, so that a chain with 10^5 matches no longer occupies a single wave for its whole DP work.
+// for the DP kernels, so that a chain with 10^5 matches no longer occupies a single wave for its whole DP work.
 struct GapTask {
   uint32_t unit;
   int32_t chain;
   int32_t r0, n, q0, m;
 };
-constexpr int GAP_LANE_MAX = 63;   // gaps up to 63 x 63 are solved by one lane (rows of the DP in LDS, 64 tasks per wave)
+constexpr int GAP_LANE_MAX = 63;   // gaps up to 63 x 63 are solved by one lane each in anim_gapdp_lane_kernel (64 tasks per wave)
 constexpr int GAP_CLASSES = 4;     // size classes of those gaps (max side <= 16 / 31 / 47 / 63): a wave gets tasks of one class
 
 __device__ __forceinline__ int32_t wave_sum32(int32_t v) {
@@ -1657,7 +1662,7 @@ __global__ __launch_bounds__(64) void anim_gaps_kernel(const RefDesc* __restrict
 
 // Task lists by size class from the class plane (0xFF = no task in the slot): list k holds the slots of the gaps with
 // both sides <= 16 / 31 / 47 / 63 (k = 0..3, one LANE each in anim_gapdp_lane_kernel, so a wave gets 64 tasks of one
-// size) and of the larger ones (k = 4, one WAVE each in anim_gapdp_kernel).  A block sorts 4096 slots with LDS counters
+// size) and of the larger ones (k = 4: requests for anim_extdp_lane_kernel, see anim_gapreq_kernel).  A block sorts 4096 slots with LDS counters
 // and reserves its share of every list with one global atomic per class.
 constexpr int GAPSORT_BLOCK = 256;
 __global__ __launch_bounds__(GAPSORT_BLOCK) void anim_gapsort_kernel(const uint8_t* __restrict__ task_cls, uint32_t n_slots,
