@@ -2257,11 +2257,13 @@ __global__ __launch_bounds__(64) void anim_extdp_lane_kernel(const ExtReq* __res
 // arguments of this one down — as a request for the lanes (free searches in list A, target searches in list B) and into
 // pre[round] for the check in anim_extend_kernel.  valid = 0 until a lane delivers.
 __global__ __launch_bounds__(256) void anim_extreq_kernel(const RefDesc* __restrict__ refs, const UnitDesc* __restrict__ units, ClusterOut O,
-                                                          const uint2* __restrict__ wl, uint32_t n_wl, const ChainFwd* __restrict__ fw,
+                                                          const uint2* __restrict__ wl, uint32_t n_wl, ChainFwd* fw, ChainBwd* __restrict__ bw,
                                                           int phase, int round, ExtPre* __restrict__ pre_all, ExtReq* __restrict__ reqs_a,
-                                                          ExtReq* __restrict__ reqs_b, uint32_t* __restrict__ n_reqs) {
+                                                          ExtReq* __restrict__ reqs_b, uint32_t* __restrict__ n_reqs,
+                                                          uint32_t* __restrict__ wave_list) {
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   const int lane = threadIdx.x & 63;
+  const bool final_round = round == EXT_ROUNDS;   // every call answered: finish the chain here; else: list it for anim_extend_kernel
   bool have = false, lost = false;
   ExtArgs a{0, 0, 0, 0, 0, 0, 0};
   ExtReq q;
@@ -2274,7 +2276,7 @@ __global__ __launch_bounds__(256) void anim_extreq_kernel(const RefDesc* __restr
     const Chain ch = O.chains[off + c];
     int32_t r_lo, r_hi, q_lo, q_hi;
     chain_bounds(R, U, ch, r_lo, r_hi, q_lo, q_hi);
-    const ChainFwd* fwu = fw + off;
+    ChainFwd* fwu = fw + off;
     const Match* cm = O.cm + off;
     int call = 0;
     const auto ext = [&](int32_t cr, int32_t cq, int dir, int32_t rmax, int32_t qmax, int32_t tr, int32_t tq) {
@@ -2288,16 +2290,20 @@ __global__ __launch_bounds__(256) void anim_extreq_kernel(const RefDesc* __restr
         lost = true;
       } else if (k == round && !lost) {
         have = true; a = now;
+        if (final_round) lost = true;   // a call the lanes were not asked
       }
       return ExtResult{0, 0, 0, 0, 1};   // ends the policy code quickly
     };
     if (phase == 0) {
       const int32_t er = fwu[c].lr, eq = fwu[c].lq;
       int32_t nr, nq, re, qe, err_fwd, reached;
-      pick_forward_target(O.chains + off, cm, O.next_of + off, c, er, eq, nr, nq);
+      const int32_t target = pick_forward_target(O.chains + off, cm, O.next_of + off, c, er, eq, nr, nq);
       forward_extension([&](int32_t cr, int32_t cq, int32_t rmax, int32_t qmax, int32_t tr, int32_t tq) {
                           return ext(cr, cq, +1, rmax, qmax, tr, tq); },
                         er, eq, r_hi, q_hi, nr, nq, re, qe, err_fwd, reached);
+      if (final_round && !lost) {   // field-wise, as anim_extend_kernel
+        fwu[c].re = re; fwu[c].qe = qe; fwu[c].err_fwd = err_fwd; fwu[c].reached = reached; fwu[c].target = target;
+      }
     } else {
       const int32_t p = O.prev_of[off + c];
       const int32_t first_r = fwu[c].first_r, first_q = fwu[c].first_q;
@@ -2315,18 +2321,42 @@ __global__ __launch_bounds__(256) void anim_extreq_kernel(const RefDesc* __restr
           }
         }
         const int32_t rmax = cap_ext(first_r - r_lo, MAX_EXT_BWD), qmax = cap_ext(first_q - q_lo, MAX_EXT_BWD);
-        const ExtResult b = ext(first_r, first_q, -1, rmax, qmax, tr, tq);
-        if (tr >= 0 && !b.reached && tr != tq) ext(first_r, first_q, -1, rmax, qmax, -1, -1);
+        ExtResult b = ext(first_r, first_q, -1, rmax, qmax, tr, tq);
+        if (tr >= 0 && !b.reached && tr != tq) b = ext(first_r, first_q, -1, rmax, qmax, -1, -1);
+        if (final_round && !lost) {   // as anim_extend_kernel; a junction that needs the rectangle DP goes there
+          ChainBwd e;
+          e.rs = first_r - b.di; e.qs = first_q - b.dj; e.err_back = b.errors;
+          e.reached = (tr >= 0 && b.reached) ? 1 : 0;
+          bridge_junction(e, prev_re, prev_qe, tr, tq, first_r, first_q, p >= 0 ? fwu[p].lr : -1, p >= 0 ? fwu[p].lq : -1,
+                          p >= 0 ? fwu[p].err_fwd : 0, [&](int32_t, int32_t, int32_t, int32_t) { lost = true; return -1; });
+          if (!lost) bw[off + c] = e;
+        }
+      } else if (final_round) {
+        bw[off + c] = ChainBwd{first_r, first_q, 0, 0};   // will be shadowed
       }
     }
-    have = have && !lost;
-    ExtPre* mine = pre_all + (size_t)round * n_wl + i;
-    mine->args = a;
-    mine->valid = 0;
-    q.rcodes = R.codes; q.rmask = R.mask; q.qcodes = U.codes; q.qmask = U.mask;
-    q.rlen = (int32_t)R.len; q.qlen = (int32_t)U.len; q.strand = U.strand; q.dir = a.dir;
-    q.r0 = a.r0; q.q0 = a.q0; q.rmax = a.rmax; q.qmax = a.qmax; q.tr = a.tr; q.tq = a.tq;
-    q.chain = i; q.pad_ = 0;
+    if (final_round) {
+      have = lost;   // "have" now means: has work for the wave kernel
+    } else {
+      have = have && !lost;
+      ExtPre* mine = pre_all + (size_t)round * n_wl + i;
+      mine->args = a;
+      mine->valid = 0;
+      q.rcodes = R.codes; q.rmask = R.mask; q.qcodes = U.codes; q.qmask = U.mask;
+      q.rlen = (int32_t)R.len; q.qlen = (int32_t)U.len; q.strand = U.strand; q.dir = a.dir;
+      q.r0 = a.r0; q.q0 = a.q0; q.rmax = a.rmax; q.qmax = a.qmax; q.tr = a.tr; q.tq = a.tq;
+      q.chain = i; q.pad_ = 0;
+    }
+  }
+  if (final_round) {
+    const uint64_t mw = __ballot(have);
+    if (mw) {
+      uint32_t at = 0;
+      if (lane == 0) at = atomicAdd(&n_reqs[0], (uint32_t)__popcll(mw));
+      at = (uint32_t)__shfl((int)at, 0, 64);
+      if (have) wave_list[at + (uint32_t)__popcll(mw & lanemask_lt())] = i;
+    }
+    return;
   }
   // the lane kernel decides "free search" exactly like pga::extend_banded; here only the order of the hand-out depends on it
   const bool free_search = have && (a.tr < 0 || a.tr > a.rmax || a.tq > a.qmax);
@@ -2421,9 +2451,19 @@ __global__ __launch_bounds__(64) void anim_gapdp_kernel(const RefDesc* __restric
 __global__ __launch_bounds__(64) void anim_extend_kernel(const RefDesc* __restrict__ refs, const UnitDesc* __restrict__ units,
                                                          ClusterOut O, const uint2* __restrict__ wl,
                                                          ChainFwd* __restrict__ fw, ChainBwd* __restrict__ bw, int phase,
-                                                         const ExtPre* __restrict__ pre, uint32_t n_wl, const ExtDump* __restrict__ dumps) {
-  const uint32_t u = wl[blockIdx.x].x;
-  const int32_t c = (int32_t)wl[blockIdx.x].y;
+                                                         const ExtPre* __restrict__ pre, uint32_t n_wl, const ExtDump* __restrict__ dumps,
+                                                         const uint32_t* __restrict__ wave_list, const uint32_t* __restrict__ n_list,
+                                                         uint32_t* __restrict__ cursor) {
+  // persistent waves over the chains anim_extreq_kernel's final round could not finish
+  const uint32_t n_todo = *n_list;
+  for (;;) {
+  uint32_t todo = 0;
+  if ((threadIdx.x & 63) == 0) todo = atomicAdd(cursor, 1u);
+  todo = (uint32_t)__shfl((int)todo, 0, 64);
+  if (todo >= n_todo) return;
+  const uint32_t ci = wave_list[todo];
+  const uint32_t u = wl[ci].x;
+  const int32_t c = (int32_t)wl[ci].y;
   const UnitDesc U = units[u];
   const RefDesc R = refs[U.ref];
   const SeqView RV{R.codes, R.mask, R.len};
@@ -2433,7 +2473,7 @@ __global__ __launch_bounds__(64) void anim_extend_kernel(const RefDesc* __restri
   const auto ext = [&](int32_t cr, int32_t cq, int dir, int32_t rmax, int32_t qmax, int32_t tr, int32_t tq) {
     const int k = call++;
     if (k < EXT_ROUNDS) {   // uniform
-      const ExtPre pr = pre[(size_t)k * n_wl + blockIdx.x];
+      const ExtPre pr = pre[(size_t)k * n_wl + ci];
       const bool same = pr.args.r0 == cr && pr.args.q0 == cq && pr.args.dir == dir && pr.args.rmax == rmax && pr.args.qmax == qmax &&
                         pr.args.tr == tr && pr.args.tq == tq;
 #ifdef PGA_DP_STATS
@@ -2469,7 +2509,7 @@ __global__ __launch_bounds__(64) void anim_extend_kernel(const RefDesc* __restri
     if (p >= 0 && ((fwu[p].reached && fwu[p].target == c) ||
                    (fwu[p].first_r <= first_r && fwu[p].first_q <= first_q && prev_re >= fwu[c].lr && prev_qe >= fwu[c].lq))) {
       if ((threadIdx.x & 63) == 0) bw[off + c] = ChainBwd{first_r, first_q, 0, 0};  // will be shadowed
-      return;
+      continue;
     }
     int32_t tr = -1, tq = -1;
     if (prev_re >= 0 && first_r >= prev_re && first_q >= prev_qe) { tr = first_r - prev_re; tq = first_q - prev_qe; }
@@ -2495,6 +2535,7 @@ __global__ __launch_bounds__(64) void anim_extend_kernel(const RefDesc* __restri
                     p >= 0 ? fwu[p].err_fwd : 0,
                     [&](int32_t r0, int32_t n, int32_t q0, int32_t m) { return thin_rect_errors_wave(RV, QV, r0, n, q0, m); });
     if ((threadIdx.x & 63) == 0) bw[off + c] = e;
+  }
   }
 }
 
@@ -2681,6 +2722,7 @@ struct AnimScratch {
   ExtReq* ext_reqs = nullptr;       // DP requests for the lanes: free searches, then (at n_wl) target searches
   ExtPre* ext_pre = nullptr;        // [EXT_ROUNDS][n_wl] arguments of the chains' first DP calls and the delivered results
   ExtDump* ext_dumps = nullptr;     // searches the lanes hand over to the wave kernel mid-way
+  uint32_t* ext_wave = nullptr;     // chains left for the wave kernel of a phase
   uint32_t* ext_counts = nullptr;   // request list lengths, hand-out cursor, hand-over count of a lane launch
   size_t ext_cap = 0;
   uint8_t* task_cls = nullptr;      // size class of the GapTask in every match slot (0xFF = none)
@@ -2761,7 +2803,7 @@ void pg_anim_free_scratch(pg_ctx* ctx) {
   AnimScratch* A = static_cast<AnimScratch*>(ctx->anim_scratch);
   if (!A) return;
   pg_anim_drop_lists(ctx);
-  void* ptrs[] = {A->ext_reqs, A->ext_pre, A->ext_dumps, A->ext_counts, A->gap_counts, A->task_cls, A->task_lists, A->hits_sorted, A->hit_count, A->hoff, A->hit_cursor, A->hits_d, A->slice_d, A->choff_d, A->list_cnt, A->srefs_d, A->sqry_d, A->recs_d, A->refs_d, A->units_d, A->mem_count, A->moff, A->nch, A->status, A->out, A->mem, A->cm,
+  void* ptrs[] = {A->ext_reqs, A->ext_pre, A->ext_dumps, A->ext_wave, A->ext_counts, A->gap_counts, A->task_cls, A->task_lists, A->hits_sorted, A->hit_count, A->hoff, A->hit_cursor, A->hits_d, A->slice_d, A->choff_d, A->list_cnt, A->srefs_d, A->sqry_d, A->recs_d, A->refs_d, A->units_d, A->mem_count, A->moff, A->nch, A->status, A->out, A->mem, A->cm,
                   A->iscratch, A->order, A->prev, A->next, A->alnof, A->chains, A->fw, A->bw, A->S.alns, A->S.a_rrec,
                   A->S.a_qrec, A->S.idx, A->S.from, A->S.sc, A->wl_d, A->seedbuf, A->seed_total, A->tasks_d};
   for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -3043,35 +3085,44 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
     static const int tail_lanes = getenv("PYANI_EXT_TAIL_LANES") ? atoi(getenv("PYANI_EXT_TAIL_LANES")) : EXT_TAIL_LANES;
     static const int tail_blocks = getenv("PYANI_EXT_TAIL_BLOCKS") ? atoi(getenv("PYANI_EXT_TAIL_BLOCKS")) : EXT_TAIL_BLOCKS;
     if (!A->ext_dumps && (rc = regrow(ctx, A->ext_dumps, EXT_DUMP_CAP))) return rc;
-    if (!A->ext_counts && (rc = regrow(ctx, A->ext_counts, 4))) return rc;
+    if (!A->ext_counts && (rc = regrow(ctx, A->ext_counts, 8))) return rc;
     if (n_ext > A->ext_cap) {
       const size_t cap = n_ext + n_ext / 2;
       if ((rc = regrow(ctx, A->ext_reqs, 2 * cap))) return rc;
       if ((rc = regrow(ctx, A->ext_pre, EXT_ROUNDS * cap))) return rc;
+      if ((rc = regrow(ctx, A->ext_wave, cap))) return rc;
       A->ext_cap = cap;
     }
     if (n_big) {
-      PG_HIP(ctx, hipMemsetAsync(A->ext_counts, 0, 16, ctx->stream));   // [0], [1] list lengths, [2] hand-out cursor, [3] handed over
+      PG_HIP(ctx, hipMemsetAsync(A->ext_counts, 0, 20, ctx->stream));   // [0], [1] list lengths, [2] hand-out cursor, [4] handed over
       hipLaunchKernelGGL(anim_gapreq_kernel, dim3((uint32_t)((n_big + 255) / 256)), dim3(256), 0, ctx->stream, A->refs_d, A->units_d,
                          A->tasks_d, A->task_lists + GAP_CLASSES * Mp, (uint32_t)n_big, A->ext_pre, A->ext_reqs, A->ext_counts);
       hipLaunchKernelGGL(anim_extdp_lane_kernel, dim3((uint32_t)ctx->num_cu * 4u), dim3(64), 0, ctx->stream, A->ext_reqs, A->ext_reqs,
-                         A->ext_counts, A->ext_counts + 2, A->ext_pre, A->ext_dumps, EXT_DUMP_CAP, A->ext_counts + 3, tail_lanes, tail_blocks);
+                         A->ext_counts, A->ext_counts + 2, A->ext_pre, A->ext_dumps, EXT_DUMP_CAP, A->ext_counts + 4, tail_lanes, tail_blocks);
       hipLaunchKernelGGL(anim_gapdp_kernel, dim3((uint32_t)ctx->num_cu * 32u), dim3(64), 0, ctx->stream, A->refs_d, A->units_d, O,
                          A->tasks_d, A->task_lists + GAP_CLASSES * Mp, (uint32_t)n_big, A->ext_pre, A->ext_dumps, A->fw);
     }
     for (int phase = 0; phase < 2; ++phase) {
       // the first DP calls of every chain: written down, solved one per LANE, then consumed by the wave kernel
-      PG_HIP(ctx, hipMemsetAsync(A->ext_counts + 3, 0, 4, ctx->stream));   // [3] searches handed over mid-way
+      PG_HIP(ctx, hipMemsetAsync(A->ext_counts + 4, 0, 4, ctx->stream));   // [4] searches handed over mid-way
       for (int round = 0; round < EXT_ROUNDS; ++round) {
-        PG_HIP(ctx, hipMemsetAsync(A->ext_counts, 0, 12, ctx->stream));   // [0], [1] list lengths, [2] hand-out cursor
+        PG_HIP(ctx, hipMemsetAsync(A->ext_counts, 0, 16, ctx->stream));   // [0], [1] list lengths, [2] hand-out cursor
         hipLaunchKernelGGL(anim_extreq_kernel, dim3((uint32_t)((n_wl + 255) / 256)), dim3(256), 0, ctx->stream, A->refs_d, A->units_d, O,
-                           A->wl_d, (uint32_t)n_wl, A->fw, phase, round, A->ext_pre, A->ext_reqs, A->ext_reqs + n_wl, A->ext_counts);
+                           A->wl_d, (uint32_t)n_wl, A->fw, A->bw, phase, round, A->ext_pre, A->ext_reqs, A->ext_reqs + n_wl, A->ext_counts,
+                           A->ext_wave);
         hipLaunchKernelGGL(anim_extdp_lane_kernel, dim3((uint32_t)ctx->num_cu * 4u), dim3(64), 0, ctx->stream, A->ext_reqs,
                            A->ext_reqs + n_wl, A->ext_counts, A->ext_counts + 2, A->ext_pre + (size_t)round * n_wl, A->ext_dumps,
-                           EXT_DUMP_CAP, A->ext_counts + 3, tail_lanes, tail_blocks);
+                           EXT_DUMP_CAP, A->ext_counts + 4, tail_lanes, tail_blocks);
       }
-      hipLaunchKernelGGL(anim_extend_kernel, dim3((uint32_t)n_wl), dim3(64), 0, ctx->stream, A->refs_d, A->units_d, O,
-                         A->wl_d, A->fw, A->bw, phase, A->ext_pre, (uint32_t)n_wl, A->ext_dumps);
+      // final round: chains whose calls were all answered are finished by a thread each; the others (handed-over searches,
+      // third calls, junction rectangles) are listed for the wave kernel
+      PG_HIP(ctx, hipMemsetAsync(A->ext_counts, 0, 12, ctx->stream));   // [0] list length, [2] hand-out cursor
+      hipLaunchKernelGGL(anim_extreq_kernel, dim3((uint32_t)((n_wl + 255) / 256)), dim3(256), 0, ctx->stream, A->refs_d, A->units_d, O,
+                         A->wl_d, (uint32_t)n_wl, A->fw, A->bw, phase, EXT_ROUNDS, A->ext_pre, A->ext_reqs, A->ext_reqs + n_wl,
+                         A->ext_counts, A->ext_wave);
+      hipLaunchKernelGGL(anim_extend_kernel, dim3((uint32_t)ctx->num_cu * 32u), dim3(64), 0, ctx->stream, A->refs_d, A->units_d, O,
+                         A->wl_d, A->fw, A->bw, phase, A->ext_pre, (uint32_t)n_wl, A->ext_dumps, A->ext_wave, A->ext_counts,
+                         A->ext_counts + 2);
     }
   }
   hipLaunchKernelGGL(anim_finish_kernel, dim3(n_pairs), dim3(64), 0, ctx->stream, A->refs_d, A->units_d, n_pairs,
