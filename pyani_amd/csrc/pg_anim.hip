@@ -3030,7 +3030,7 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
   if (getenv("PYANI_ANIM_SCALAR_CLUSTER") && !maxmatch)   // debugging aid: the one-thread-per-unit statement of the same algorithm
     hipLaunchKernelGGL(anim_cluster_kernel, dim3((n_units + 63) / 64), dim3(64), 0, ctx->stream, A->refs_d, A->units_d, n_units,
                        A->mem, A->mem_count, A->iscratch, O);
-  else if (n_nonempty > 3000 || getenv("PYANI_ANIM_WAVE_PREP"))
+  else if ((n_nonempty > 3000 && !getenv("PYANI_ANIM_SPLIT_CLUSTER")) || getenv("PYANI_ANIM_WAVE_PREP"))
     // thousands of units with matches: one wave per unit already fills the machine, and the radix scatters are bound by
     // HBM's partial-line write rate, which more waves per unit only congest (measured: C3 574 ms vs 724 ms split)
     hipLaunchKernelGGL(anim_cluster_wave_kernel, dim3(n_units), dim3(64), 0, ctx->stream, A->refs_d, A->units_d, A->mem,
@@ -3082,8 +3082,11 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
     PG_HIP(ctx, hipMemcpyAsync(gap_counts, A->gap_counts, sizeof(gap_counts), hipMemcpyDeviceToHost, ctx->stream));
     PG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const size_t n_big = gap_counts[GAP_CLASSES], n_ext = n_wl > n_big ? n_wl : n_big;
-    static const int tail_lanes = getenv("PYANI_EXT_TAIL_LANES") ? atoi(getenv("PYANI_EXT_TAIL_LANES")) : EXT_TAIL_LANES;
-    static const int tail_blocks = getenv("PYANI_EXT_TAIL_BLOCKS") ? atoi(getenv("PYANI_EXT_TAIL_BLOCKS")) : EXT_TAIL_BLOCKS;
+    // development / test knobs of the hand-over rule (results do not depend on them: tests/test_anim_gpu.py)
+    const int tail_lanes = getenv("PYANI_EXT_TAIL_LANES") ? atoi(getenv("PYANI_EXT_TAIL_LANES")) : EXT_TAIL_LANES;
+    const int tail_blocks = getenv("PYANI_EXT_TAIL_BLOCKS") ? atoi(getenv("PYANI_EXT_TAIL_BLOCKS")) : EXT_TAIL_BLOCKS;
+    uint32_t dump_cap = EXT_DUMP_CAP;
+    if (getenv("PYANI_EXT_DUMP_CAP") && (uint32_t)atoi(getenv("PYANI_EXT_DUMP_CAP")) < dump_cap) dump_cap = (uint32_t)atoi(getenv("PYANI_EXT_DUMP_CAP"));
     if (!A->ext_dumps && (rc = regrow(ctx, A->ext_dumps, EXT_DUMP_CAP))) return rc;
     if (!A->ext_counts && (rc = regrow(ctx, A->ext_counts, 8))) return rc;
     if (n_ext > A->ext_cap) {
@@ -3098,7 +3101,7 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
       hipLaunchKernelGGL(anim_gapreq_kernel, dim3((uint32_t)((n_big + 255) / 256)), dim3(256), 0, ctx->stream, A->refs_d, A->units_d,
                          A->tasks_d, A->task_lists + GAP_CLASSES * Mp, (uint32_t)n_big, A->ext_pre, A->ext_reqs, A->ext_counts);
       hipLaunchKernelGGL(anim_extdp_lane_kernel, dim3((uint32_t)ctx->num_cu * 4u), dim3(64), 0, ctx->stream, A->ext_reqs, A->ext_reqs,
-                         A->ext_counts, A->ext_counts + 2, A->ext_pre, A->ext_dumps, EXT_DUMP_CAP, A->ext_counts + 4, tail_lanes, tail_blocks);
+                         A->ext_counts, A->ext_counts + 2, A->ext_pre, A->ext_dumps, dump_cap, A->ext_counts + 4, tail_lanes, tail_blocks);
       hipLaunchKernelGGL(anim_gapdp_kernel, dim3((uint32_t)ctx->num_cu * 32u), dim3(64), 0, ctx->stream, A->refs_d, A->units_d, O,
                          A->tasks_d, A->task_lists + GAP_CLASSES * Mp, (uint32_t)n_big, A->ext_pre, A->ext_dumps, A->fw);
     }
@@ -3112,7 +3115,7 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
                            A->ext_wave);
         hipLaunchKernelGGL(anim_extdp_lane_kernel, dim3((uint32_t)ctx->num_cu * 4u), dim3(64), 0, ctx->stream, A->ext_reqs,
                            A->ext_reqs + n_wl, A->ext_counts, A->ext_counts + 2, A->ext_pre + (size_t)round * n_wl, A->ext_dumps,
-                           EXT_DUMP_CAP, A->ext_counts + 4, tail_lanes, tail_blocks);
+                           dump_cap, A->ext_counts + 4, tail_lanes, tail_blocks);
       }
       // final round: chains whose calls were all answered are finished by a thread each; the others (handed-over searches,
       // third calls, junction rectangles) are listed for the wave kernel

@@ -222,6 +222,29 @@ def test_batch_split_does_not_change_results_and_edge_inputs(eng):
     assert mm.tobytes() == ref[:30].tobytes()
 
 
+def test_lane_to_wave_hand_over_does_not_change_results(eng, monkeypatch):
+    """The extension / gap DP runs one search per LANE and hands the tail of a launch over to the wave form mid-search
+    (pg_anim.hip: anim_extdp_lane_kernel -> ExtDump -> extend_wave resume).  Where that happens must be invisible: hand
+    everything over at the first opportunity, never hand over, and run out of hand-over slots — same records."""
+    from pyani_amd import synth
+    eng.clear_genomes()
+    n, L = 8, 300_000
+    ids = [eng.add_genome(*synth.genome(11, n, g, L)) for g in range(n)]
+    eng.upload()
+    pairs = [(a, b) for a in ids for b in ids if a != b]
+    ra, qa = [a for a, _ in pairs], [b for _, b in pairs]
+    ref = eng.anim_pairs(ra, qa)
+    assert (ref["status"] == 0).sum() >= len(pairs) // 2
+    for lanes, blocks, cap in (("65", "0", None), ("0", "1000000", None), ("65", "0", "3"), ("65", "2", "100")):
+        monkeypatch.setenv("PYANI_EXT_TAIL_LANES", lanes)
+        monkeypatch.setenv("PYANI_EXT_TAIL_BLOCKS", blocks)
+        if cap is None:
+            monkeypatch.delenv("PYANI_EXT_DUMP_CAP", raising=False)
+        else:
+            monkeypatch.setenv("PYANI_EXT_DUMP_CAP", cap)
+        assert eng.anim_pairs(ra, qa).tobytes() == ref.tobytes(), (lanes, blocks, cap)
+
+
 def _resplit(seq, step, salt):
     """Same cutting rule as tools/make_anim_synth_host.py (contig-shaped records, some too short to seed)."""
     cuts, p, k = [0], 0, 0
