@@ -40,7 +40,7 @@ def hipcc_path() -> str:
 
 def build_gpu(force=False):
     srcs = sorted(CSRC.glob("pg_*.hip")) + sorted(CSRC.glob("pg_*.cpp"))
-    deps = srcs + sorted(CSRC.glob("*.h")) + sorted((ROOT / "include").glob("*.h"))
+    deps = srcs + sorted(CSRC.glob("*.h")) + sorted(CSRC.glob("*.inc")) + sorted((ROOT / "include").glob("*.h"))
     if not force and _newer(GPU_LIB, deps):
         return GPU_LIB
     _run([hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",

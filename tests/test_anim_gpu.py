@@ -224,7 +224,7 @@ def test_batch_split_does_not_change_results_and_edge_inputs(eng):
 
 def test_lane_to_wave_hand_over_does_not_change_results(eng, monkeypatch):
     """The extension / gap DP runs one search per LANE and hands the tail of a launch over to the wave form mid-search
-    (pg_anim.hip: anim_extdp_lane_kernel -> ExtDump -> extend_wave resume).  Where that happens must be invisible: hand
+    (pga_dp_lane.inc: anim_extdp_lane_kernel -> ExtDump -> extend_wave resume).  Where that happens must be invisible: hand
     everything over at the first opportunity, never hand over, and run out of hand-over slots — same records."""
     from pyani_amd import synth
     eng.clear_genomes()
