@@ -9,15 +9,18 @@ reference's names, argument meaning, result containers and error behaviour for e
     calculate_anim_pairs(infiles)         all N(N-1) ordered comparisons -> {(qstem, sstem): (ref_aln, qry_aln, id, errs)}
     parse_delta(filename)                 same 4-tuple from an existing MUMmer .delta/.filter file (GPU reduction;
                                           pyani's --recovery path)
+    process_deltadir(delta_dir, lengths)  the reference's directory walk over `*/*.filter` files, all files reduced in one GPU call
     process_deltadir-equivalent           `assemble_legacy_results(pair_results, org_lengths)` -> ANIResults
     update_comparison_matrices-equivalent `assemble_run_matrices(pair_results, lengths)` -> 5 DataFrames (v0.3 semantics)
 
 The alignment search emulates MUMmer 3.23 (`nucmer --mum`, `delta-filter -1`), which is NOT part of the reference
-tree: it is calibrated against the MUMmer output files the reference's tests hold; DESIGN.md lists the measured
-deviations (11 of 17 fixture pairs bit-identical, 14 within 1e-4, worst 5.5e-4).  `program`/`version` strings for DB rows
+tree: it is calibrated against the MUMmer output files the reference's tests hold (all 17 fixture pairs with
+FASTA inputs are reproduced bit for bit; beyond the fixtures parity is unpinned).  `program`/`version` strings for DB rows
 must therefore differ from "nucmer" (SURVEY.md §5): use PROGRAM / VERSION below.
 """
 import gzip
+import logging
+import sys
 from pathlib import Path
 from typing import Dict, Iterable, List, Tuple
 
@@ -172,6 +175,48 @@ def parse_delta(filename, engine: Engine = None) -> Tuple[int, int, float, int]:
     .delta/.filter file — pyani.anim.parse_delta (anim.py:292-411), reduced on the GPU."""
     eng = engine or default_engine()
     return _tuple(eng.anim_reduce([read_delta(filename)], apply_filter=False)[0])
+
+
+def process_deltadir(delta_dir, org_lengths: Dict[str, int], logger=None, engine: Engine = None) -> ANIResults:
+    """pyani.anim.process_deltadir (anim.py:415-497): ANIResults from the `<delta_dir>/*/*.filter` files of an earlier
+    (MUMmer or write_delta) run — same file order, same skipping of files whose organisms are not in `org_lengths`, same
+    overwrite order of the mirrored cells, PyaniANImException when the directory holds no .filter file, ZeroDivisionError
+    from an empty one.  The files are parsed on the host and reduced in ONE GPU call instead of one parse_delta each."""
+    logger = logger or logging.getLogger(__name__)
+    delta_dir = Path(delta_dir)
+    deltafiles = sorted(delta_dir.glob("*/*.filter"))
+    logger.info("%s has %d files to load", delta_dir, len(deltafiles))
+    if not deltafiles:
+        logger.error("%s empty? No filter files found", delta_dir)
+        raise PyaniANImException(f"{delta_dir} contains no filter files.")
+    todo = []
+    for deltafile in deltafiles:
+        qname, sname = deltafile.stem.split("_vs_")
+        if qname not in org_lengths:
+            logger.warning("Query name %s not in input sequence list, skipping %s", qname, deltafile)
+            continue
+        if sname not in org_lengths:
+            logger.warning("Subject name %s not in input sequence list, skipping %s", sname, deltafile)
+            continue
+        todo.append((qname, sname, deltafile))
+    results = ANIResults(list(org_lengths.keys()), "ANIm")
+    for org, length in org_lengths.items():
+        results.alignment_lengths.loc[org, org] = length
+    if not todo:
+        return results
+    eng = engine or default_engine()
+    recs = eng.anim_reduce([read_delta(f) for _, _, f in todo], apply_filter=False)
+    for (qname, sname, deltafile), rec in zip(todo, recs):
+        query_tot_length, subject_tot_length, weighted_identity, tot_sim_error = _tuple(rec)
+        if subject_tot_length == 0:
+            logger.warning("Total alignment length reported in %s is zero!", deltafile)
+            sys.exit("Zero length alignment!")
+        results.add_tot_length(qname, sname, query_tot_length, subject_tot_length)
+        results.add_sim_errors(qname, sname, tot_sim_error)
+        results.add_pid(qname, sname, weighted_identity)
+        results.add_coverage(qname, sname, float(query_tot_length) / org_lengths[qname],
+                             float(subject_tot_length) / org_lengths[sname])
+    return results
 
 
 def assemble_legacy_results(pair_results: Dict[Tuple[str, str], Tuple[int, int, float, int]], org_lengths: Dict[str, int]

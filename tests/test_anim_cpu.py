@@ -132,3 +132,55 @@ def test_write_delta_round_trip_and_grammar(tmp_path):
     out2 = tmp_path / "r_vs_q.delta"
     assert anim.write_delta(out2, ref, qry, al, filtered=False) == 3
     assert len(anim_oracle.read_delta(out2)[0]) == 3
+
+
+def test_process_deltadir_walk_and_assembly(tmp_path):
+    """pyani.anim.process_deltadir (anim.py:415-497) mirrored by pyani_amd.anim.process_deltadir: the directory walk, the
+    skipping of foreign files, the overwrite order and the error behaviour, with the pinned oracle standing in for the
+    GPU reduction (the reduction itself is compared on the GPU in tests/test_anim_gpu.py); identities against the
+    reference's deltadir_result.csv (tests/test_anim.py:243-255)."""
+    import gzip
+    import numpy as np
+    from pyani_amd import _lib, anim
+
+    from collections import namedtuple
+    from pyani_amd.engine import Engine
+    Rec = namedtuple("Rec", "ref_id qry_id rs re qs qe errors")
+
+    class OracleEngine:   # Engine.anim_reduce restated with the oracle's parse_delta arithmetic
+        def anim_reduce(self, files, apply_filter=False):
+            out = np.zeros(len(files), dtype=Engine.ANIM_DTYPE)
+            for i, recs in enumerate(files):
+                try:
+                    t = anim_oracle.parse_delta_records([Rec(*r) for r in recs])
+                except ZeroDivisionError:
+                    out[i]["status"] = _lib.PG_ANIM_NO_ALIGNMENT
+                    continue
+                out[i]["ref_aln_len"], out[i]["qry_aln_len"], out[i]["identity"], out[i]["sim_errors"] = t
+            return out
+
+    rows = list(csv.reader(open(GOLD / "ref_targets" / "anim_deltadir_result.csv")))
+    names = rows[0][1:]
+    for q in names:
+        (tmp_path / q).mkdir()
+        for s in names:
+            if q != s:
+                with gzip.open(GOLD / "anim" / "caulobacter" / f"{q}_vs_{s}.filter.gz", "rb") as fi:
+                    (tmp_path / q / f"{q}_vs_{s}.filter").write_bytes(fi.read())
+    (tmp_path / names[0] / f"{names[0]}_vs_stranger.filter").write_text("x y\nNUCMER\n")   # foreign file: skipped
+    lengths = {n: 4_000_000 + i for i, n in enumerate(names)}
+    res = anim.process_deltadir(tmp_path, lengths, engine=OracleEngine())
+    for r in rows[1:]:
+        for s, v in zip(names, r[1:]):
+            if r[0] != s:
+                assert f"{res.percentage_identity.loc[r[0], s]:.6f}" == v
+            else:
+                assert res.alignment_lengths.loc[s, s] == lengths[s]
+    q, s = names[0], names[1]   # the mirrored cells hold what the LATER file (sorted order) wrote
+    later = anim_oracle.parse_delta(GOLD / "anim" / "caulobacter" / f"{max(q, s)}_vs_{min(q, s)}.filter.gz")
+    assert res.similarity_errors.loc[q, s] == res.similarity_errors.loc[s, q] == later[3]
+    with pytest.raises(anim.PyaniANImException):
+        anim.process_deltadir(tmp_path / names[0] / "nothing_here", lengths, engine=OracleEngine())
+    (tmp_path / q / f"{q}_vs_{s}.filter").write_text("a b\nNUCMER\n")   # a run without alignments
+    with pytest.raises(ZeroDivisionError):
+        anim.process_deltadir(tmp_path, lengths, engine=OracleEngine())
