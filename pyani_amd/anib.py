@@ -1,6 +1,7 @@
 """ANIb pieces of the hot path — what pyani itself computes around BLAST (pyani/anib.py).
 
     fragment_lengths / fragment_records   the 1020-nt fragmenting rule          (anib.py:164-203, FRAGSIZE pyani_config.py:95)
+    fragment_fasta_files / get_fraglength_dict / get_fragment_lengths   the same rule at file level, names and returns as pyani
     parse_blast_tab(filename)             (aln_length, sim_errors, mean pident)  (anib.py:569-667, mode "ANIb"), reduced on the GPU
     process_blast_results(...)            identity / coverage / lengths / errors / hadamard matrices, [q, s] cells only
                                           (process_blast, anib.py:496-565)
@@ -42,6 +43,57 @@ def fragment_records(records: Iterable[Tuple[str, str]], fragsize: int = FRAGSIZ
             count += 1
             out.append(("frag%05d" % count, seq[idx: idx + fragsize]))
     return out
+
+
+def _read_fasta(path) -> List[Tuple[str, str]]:
+    """[(header line without '>', sequence)] of a (possibly gzipped) FASTA file; blank lines ignored."""
+    opener = gzip.open if str(path).endswith(".gz") else open
+    out, title, parts = [], None, []
+    with opener(path, "rt") as fh:
+        for line in fh:
+            line = line.rstrip("\r\n")
+            if line.startswith(">"):
+                if title is not None:
+                    out.append((title, "".join(parts)))
+                title, parts = line[1:], []
+            elif title is not None and line:
+                parts.append(line.strip())
+    if title is not None:
+        out.append((title, "".join(parts)))
+    return out
+
+
+def fragment_fasta_files(infiles: List[Path], outdirname: Path, fragsize: int = FRAGSIZE) -> Tuple[List[Path], Dict]:
+    """pyani.anib.fragment_fasta_files (anib.py:164-203): every sequence of every file cut into consecutive pieces of
+    `fragsize` (the last one may be shorter), written to `<outdirname>/<stem>-fragments<suffix>` with ids fragNNNNN
+    running across the records of a file and the original header kept as description (Biopython's FASTA writer:
+    `>fragNNNNN <original header>`, 60 columns).  Returns (filenames, {stem: {frag id: length}})."""
+    outdirname = Path(outdirname)
+    outfnames = []
+    for fname in (Path(f) for f in infiles):
+        outfname = outdirname / f"{fname.stem}-fragments{fname.suffix}"
+        count = 0
+        with open(outfname, "w") as fh:
+            for title, seq in _read_fasta(fname):
+                for idx in range(0, len(seq), fragsize):
+                    count += 1
+                    piece = seq[idx: idx + fragsize]
+                    fh.write(f">frag{count:05d} {title}\n")
+                    for col in range(0, len(piece), 60):
+                        fh.write(piece[col: col + 60] + "\n")
+        outfnames.append(outfname)
+    return outfnames, get_fraglength_dict(outfnames)
+
+
+def get_fraglength_dict(fastafiles: List[Path]) -> Dict[str, Dict[str, int]]:
+    """pyani.anib.get_fraglength_dict (anib.py:207-221): fragment lengths per file, keyed by the name before '-fragments'."""
+    return {Path(f).stem.split("-fragments")[0]: get_fragment_lengths(f) for f in fastafiles}
+
+
+def get_fragment_lengths(fastafile: Path) -> Dict[str, int]:
+    """pyani.anib.get_fragment_lengths (anib.py:224-238): sequence lengths keyed by sequence id (first word of the header);
+    ambiguity symbols are not discounted."""
+    return {(title.split(None, 1)[0] if title.split() else ""): len(seq) for title, seq in _read_fasta(fastafile)}
 
 
 def read_blast_tab(path):

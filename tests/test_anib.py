@@ -40,6 +40,33 @@ def test_fragmenting_rule():
     assert [len(f[1]) for f in frs] == [1020, 1020, 1, 7]
 
 
+def test_fragment_fasta_files(tmp_path):
+    """pyani.anib.fragment_fasta_files / get_fraglength_dict / get_fragment_lengths (anib.py:164-238): ids run across the
+    records of a file, every piece <= fragsize (reference tests/test_anib.py:317-324), headers kept as description,
+    60-column FASTA, and the pieces of a record concatenate back to it."""
+    from pyani_amd import anib
+    src = tmp_path / "in"
+    src.mkdir()
+    out = tmp_path / "out"
+    out.mkdir()
+    seq1, seq2 = "ACGTN" * 500, "GATTACA" * 3       # 2500 and 21 bases
+    (src / "genomeA.fna").write_text(">rec1 first record\n" + "\n".join(seq1[i:i + 70] for i in range(0, 2500, 70)) +
+                                     "\n>rec2\n" + seq2 + "\n")
+    (src / "genomeB.fasta").write_text(">only\n" + "A" * 1020 + "\n")
+    names, lengths = anib.fragment_fasta_files([src / "genomeA.fna", src / "genomeB.fasta"], out, 1020)
+    assert [n.name for n in names] == ["genomeA-fragments.fna", "genomeB-fragments.fasta"]
+    assert lengths == {"genomeA": {"frag00001": 1020, "frag00002": 1020, "frag00003": 460, "frag00004": 21},
+                       "genomeB": {"frag00001": 1020}}
+    assert lengths["genomeA"] == anib.fragment_lengths([2500, 21]) == anib.get_fragment_lengths(names[0])
+    text = names[0].read_text().splitlines()
+    assert text[0] == ">frag00001 rec1 first record" and max(len(x) for x in text if not x.startswith(">")) == 60
+    assert [x for x in text if x.startswith(">")][3] == ">frag00004 rec2"
+    recs = anib._read_fasta(names[0])
+    assert "".join(s for _, s in recs[:3]) == seq1 and recs[3][1] == seq2
+    assert anib.fragment_records(anib._read_fasta(src / "genomeA.fna")) == [(t.split()[0], s) for t, s in recs]
+    assert anib.get_fraglength_dict(names) == lengths
+
+
 @pytest.mark.gpu
 def test_gpu_blast_tab_reduction():
     from pyani_amd import anib
