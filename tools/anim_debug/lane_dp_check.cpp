@@ -1,0 +1,231 @@
+// lane_dp_check.cpp — HOST restatement of the one-LANE-per-search extension DP (pyani_amd/csrc/pga_dp_lane.inc:
+// anim_extdp_lane_kernel, ExtLaneCell, lane_seq_fetch, the windows and the pre-roll), checked against the scalar
+// statement of the algorithm, pga::extend_banded (pg_anim_core.h), on random searches.  It pins the DESIGN of the lane
+// form on the CPU — the anti-diagonal walk over register parities, the one shared set of 32 X / Y, the limits enforced by
+// killing H only, the reversed / forward 64-bit sequence windows with their pre-roll counts, the running best with its
+// tie order, the optional early stop on a dead band — not the HIP code itself (tests/test_anim_gpu.py does that on the GPU).
+//   g++ -O2 -std=c++17 -I../../pyani_amd/csrc lane_dp_check.cpp -o lane_dp_check && ./lane_dp_check [cases] [seed]
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "pg_anim_core.h"
+using namespace pga;
+
+static uint64_t rng_state = 88172645463325252ull;
+static uint64_t rnd() { rng_state ^= rng_state << 13; rng_state ^= rng_state >> 7; rng_state ^= rng_state << 17; return rng_state; }
+static int rnd_int(int lo, int hi) { return lo + (int)(rnd() % (uint64_t)(hi - lo + 1)); }
+
+struct Packed {
+  std::vector<uint32_t> codes, mask;
+  int32_t len = 0;
+  void set(const std::vector<int>& s) {   // s[i] in 0..3, or 4 = dirty
+    len = (int32_t)s.size();
+    codes.assign(len / 16 + 2, 0u); mask.assign(len / 32 + 2, 0u);
+    for (int i = 0; i < len; ++i) {
+      if (s[i] < 4) { codes[i >> 4] |= (uint32_t)s[i] << (2 * (i & 15)); mask[i >> 5] |= 1u << (i & 31); }
+      else codes[i >> 4] |= (uint32_t)(rnd() & 3u) << (2 * (i & 15));   // whatever lies under a dirty base must not matter
+    }
+  }
+  SeqView view() const { return SeqView{codes.data(), mask.data(), len}; }
+};
+
+// ---- the device helpers, restated (funnel shift, field reversal, bit spreading) -------------------------------------------
+static uint32_t funnelshift_r(uint32_t lo, uint32_t hi, uint32_t sh) { sh &= 31u; return sh ? (lo >> sh) | (hi << (32 - sh)) : lo; }
+static uint32_t brev32(uint32_t x) { uint32_t r = 0; for (int i = 0; i < 32; ++i) r |= ((x >> i) & 1u) << (31 - i); return r; }
+static uint32_t rev_fields2(uint32_t x) { x = brev32(x); return ((x & 0x55555555u) << 1) | ((x >> 1) & 0x55555555u); }
+static uint32_t spread16(uint32_t x) {
+  x = (x | (x << 8)) & 0x00FF00FFu; x = (x | (x << 4)) & 0x0F0F0F0Fu; x = (x | (x << 2)) & 0x33333333u;
+  return (x | (x << 1)) & 0x55555555u;
+}
+static uint32_t sub_sat(uint32_t a, uint32_t b) { return a > b ? a - b : 0u; }
+
+struct LaneSeq {
+  const uint32_t* codes; const uint32_t* mask;
+  int32_t len, start, sgn, tmax; uint32_t comp;
+  uint32_t bc_lo, bc_hi, bo_lo, bo_hi; int32_t cnt, chunk;
+};
+static void lane_seq_fetch(const LaneSeq& s, uint32_t& c, uint32_t& okf) {
+  const int32_t t0 = s.chunk * 16;
+  const int32_t p0 = s.sgn > 0 ? s.start + t0 : s.start - t0 - 15;
+  const int32_t last_c = (s.len - 1) >> 4, last_m = (s.len - 1) >> 5;
+  int32_t w0 = p0 >> 4, w1 = w0 + 1, m0 = p0 >> 5, m1 = m0 + 1;
+  w0 = w0 < 0 ? 0 : w0 > last_c ? last_c : w0; w1 = w1 < 0 ? 0 : w1 > last_c ? last_c : w1;
+  m0 = m0 < 0 ? 0 : m0 > last_m ? last_m : m0; m1 = m1 < 0 ? 0 : m1 > last_m ? last_m : m1;
+  c = funnelshift_r(s.codes[w0], s.codes[w1], 2u * (uint32_t)(p0 & 15));
+  uint32_t ok = funnelshift_r(s.mask[m0], s.mask[m1], (uint32_t)(p0 & 31)) & 0xFFFFu;
+  const int32_t lo = p0 < 0 ? -p0 : 0, hi = s.len - p0;
+  uint32_t in = hi >= 16 ? 0xFFFFu : hi <= 0 ? 0u : ((1u << hi) - 1u);
+  in &= lo >= 16 ? 0u : ~((1u << lo) - 1u);
+  ok &= in;
+  if (s.sgn < 0) { c = rev_fields2(c); ok = brev32(ok) >> 16; }
+  if (s.comp) c = ~c;
+  const int32_t nv = s.tmax - t0;
+  ok &= nv >= 16 ? 0xFFFFu : nv <= 0 ? 0u : ((1u << nv) - 1u);
+  okf = spread16(ok);
+}
+static void lane_seq_append(LaneSeq& s) {
+  uint32_t c, okf; lane_seq_fetch(s, c, okf);
+  const uint32_t sh = 2u * (uint32_t)s.cnt;
+  const uint64_t bc = (((uint64_t)s.bc_hi << 32) | s.bc_lo) | ((uint64_t)c << sh);
+  const uint64_t bo = (((uint64_t)s.bo_hi << 32) | s.bo_lo) | ((uint64_t)okf << sh);
+  s.bc_lo = (uint32_t)bc; s.bc_hi = (uint32_t)(bc >> 32); s.bo_lo = (uint32_t)bo; s.bo_hi = (uint32_t)(bo >> 32);
+  s.cnt += 16; s.chunk += 1;
+}
+static void lane_seq_pop(LaneSeq& s, uint32_t& c, uint32_t& o) {
+  c = s.bc_lo & 3u; o = s.bo_lo & 1u;
+  s.bc_lo = funnelshift_r(s.bc_lo, s.bc_hi, 2); s.bc_hi >>= 2;
+  s.bo_lo = funnelshift_r(s.bo_lo, s.bo_hi, 2); s.bo_hi >>= 2;
+  s.cnt -= 1;
+}
+struct LaneWin { uint32_t rc_lo, rc_hi, ro_lo, ro_hi, qc_lo, qc_hi, qo_lo, qo_hi; };
+static void push_ref(LaneWin& w, LaneSeq& s) {
+  uint32_t c, o; lane_seq_pop(s, c, o);
+  w.rc_hi = funnelshift_r(w.rc_lo, w.rc_hi, 30); w.rc_lo = (w.rc_lo << 2) | c;
+  w.ro_hi = funnelshift_r(w.ro_lo, w.ro_hi, 30); w.ro_lo = (w.ro_lo << 2) | o;
+}
+static void push_qry(LaneWin& w, LaneSeq& s) {
+  uint32_t c, o; lane_seq_pop(s, c, o);
+  w.qc_lo = funnelshift_r(w.qc_lo, w.qc_hi, 2); w.qc_hi = (w.qc_hi >> 2) | (c << 30);
+  w.qo_lo = funnelshift_r(w.qo_lo, w.qo_hi, 2); w.qo_hi = (w.qo_hi >> 2) | (o << 30);
+}
+
+// One search, start to end, as a lane of anim_extdp_lane_kernel runs it.  live_phase: the dead-band check happens when
+// (d + live_phase) % 32 == 0 (in the kernel: at the wave's 32-step boundaries, wherever they fall for this search).
+static ExtResult lane_extend(const SeqView& R, const SeqView& QS, int strand, int32_t r0, int32_t q0, int dir, int32_t rmax,
+                             int32_t qmax, int32_t tr, int32_t tq, int live_phase) {
+  constexpr int W = BAND / 2;
+  constexpr uint32_t K_LIVE = 32768u << 15, K_TOP = 0xFFFF8000u;
+  constexpr uint32_t K_OPEN = (uint32_t)(-SC_GAP_OPEN) * 32768u + 1u, K_EXT = (uint32_t)(-SC_GAP_EXT) * 32768u + 1u;
+  constexpr uint32_t K_MATCH = (uint32_t)SC_MATCH * 32768u, K_MISMATCH = (uint32_t)(-SC_MISMATCH) * 32768u + 1u;
+  bool targeted = tr >= 0;
+  int koff = 0, lt = 0;
+  if (targeted) {
+    koff = (tq - tr) / 2;
+    if (koff > W - 2) koff = W - 2;
+    if (koff < -(W - 2)) koff = -(W - 2);
+    lt = (tq - tr) - koff + W;
+    if (lt < 0 || lt >= BAND || tr > rmax || tq > qmax) { targeted = false; koff = 0; }
+  }
+  if (targeted && tr == 0 && tq == 0) return ExtResult{0, 0, 0, 0, 1};
+  const int32_t d_end = targeted ? tr + tq : rmax + qmax;
+  const int32_t c1 = 2 * rmax - W + koff, c2 = 2 * qmax + W - koff;
+  uint32_t H[64], X[32], Y[32];
+  for (int l = 0; l < 64; ++l) { H[l] = (l == W - koff) ? ((65536u << 15) | 32767u) : 0u; X[l >> 1] = 0; Y[l >> 1] = 0; }
+  uint32_t best = 65536u << 15, bpay = (32767u << 6) | (uint32_t)(W - koff);
+  LaneSeq rs{R.codes, R.mask, (int32_t)R.len, dir > 0 ? r0 : r0 - 1, dir, rmax, 0u, 0, 0, 0, 0, 0, 0};
+  LaneSeq qs{QS.codes, QS.mask, (int32_t)QS.len, 0, 0, qmax, strand ? 1u : 0u, 0, 0, 0, 0, 0, 0};
+  if (!strand) { qs.start = dir > 0 ? q0 : q0 - 1; qs.sgn = dir; }
+  else { qs.start = dir > 0 ? (int32_t)QS.len - 1 - q0 : (int32_t)QS.len - q0; qs.sgn = -dir; }
+  lane_seq_append(rs); lane_seq_append(rs); lane_seq_append(qs); lane_seq_append(qs);
+  LaneWin w{0, 0, 0, 0, 0, 0, 0, 0};
+  int used_r, used_q;
+  if (koff & 1) { used_r = (31 - koff) / 2; used_q = (koff + 31) / 2; }
+  else { used_r = 16 - koff / 2; used_q = koff / 2 + 15; }
+  for (int it = 0; it < 32; ++it) { if (it < used_r) push_ref(w, rs); if (it < used_q) push_qry(w, qs); }
+  if (rs.cnt <= 16) lane_seq_append(rs);
+  if (qs.cnt <= 16) lane_seq_append(qs);
+  auto best_result = [&]() {
+    ExtResult r{0, 0, 0, 0, 0};
+    const int32_t gd = (int32_t)(best & 32767u), kk = (int32_t)(bpay & 63u) - W + koff;
+    r.score = (int32_t)(best >> 15) - 65536; r.errors = 32767 - (int32_t)((bpay >> 6) & 32767u);
+    r.di = (gd - kk) / 2; r.dj = (gd + kk) / 2;
+    return r;
+  };
+  for (int32_t d = 1;; ++d) {
+    const int P = (d + koff) & 1;   // the register parity of anti-diagonal d
+    if (rs.cnt <= 16) lane_seq_append(rs);   // (the kernel tops the buffers up every 32 steps; any schedule that keeps >= 1 works)
+    if (qs.cnt <= 16) lane_seq_append(qs);
+    if (P == 0) push_ref(w, rs); else push_qry(w, qs);
+    const uint32_t x_lo = w.rc_lo ^ w.qc_lo, x_hi = w.rc_hi ^ w.qc_hi;
+    const uint32_t e_lo = ~(x_lo | (x_lo >> 1)) & w.ro_lo & w.qo_lo, e_hi = ~(x_hi | (x_hi >> 1)) & w.ro_hi & w.qo_hi;
+    const int32_t lo = d - c1 > 0 ? d - c1 : 0, hi = c2 - d;
+    uint64_t alive = lo >= 64 ? 0ull : (~0ull << lo);
+    alive &= hi < 0 ? 0ull : hi >= 63 ? ~0ull : ((2ull << hi) - 1ull);
+    uint32_t nX[32], nY[32];
+    for (int step = 0; step < 32; ++step) {
+      const int T = P == 1 ? step : 31 - step;   // P = 1 walks up (ties >=), P = 0 down (ties >)
+      const int L = P + 2 * T;
+      uint32_t nx = 0, ny = 0;
+      if (L + 1 < 64) { const uint32_t xa = sub_sat(H[L + 1], K_OPEN), xb = sub_sat(X[T + P], K_EXT); nx = xa > xb ? xa : xb; }
+      if (L >= 1) { const uint32_t ya = sub_sat(H[L - 1], K_OPEN), yb = sub_sat(Y[T + P - 1], K_EXT); ny = ya > yb ? ya : yb; }
+      const uint32_t bit = ((T < 16 ? e_lo : e_hi) >> (2 * (T & 15))) & 1u;
+      uint32_t nh = bit * (K_MATCH + K_MISMATCH) + sub_sat(H[L], K_MISMATCH);
+      nh = nh > nx ? nh : nx; nh = nh > ny ? nh : ny;
+      if (!((alive >> L) & 1ull)) nh = 0;
+      H[L] = nh; nX[T] = nx; nY[T] = ny;
+      const uint32_t ck = (nh & K_TOP) | (uint32_t)d;
+      if (P == 1 ? ck >= best : ck > best) bpay = (nh << 6) | (uint32_t)L;
+      if (ck > best) best = ck;
+    }
+    memcpy(X, nX, sizeof(X)); memcpy(Y, nY, sizeof(Y));
+    if (d - (int32_t)(best & 32767u) >= BREAK_LEN) return best_result();
+    if (d == d_end) {
+      if (targeted && H[lt] >= K_LIVE) {
+        const uint32_t tH = H[lt];
+        return ExtResult{tr, tq, (int32_t)(tH >> 15) - 65536, 32767 - (int32_t)(tH & 32767u), 1};
+      }
+      return best_result();
+    }
+    if ((d + live_phase) % 32 == 0) {
+      uint32_t mx = 0;
+      for (int l = 0; l < 64; ++l) mx = H[l] > mx ? H[l] : mx;
+      if (mx < K_LIVE) return best_result();
+    }
+  }
+}
+
+int main(int argc, char** argv) {
+  const int cases = argc > 1 ? atoi(argv[1]) : 3000;
+  if (argc > 2) rng_state ^= (uint64_t)atoll(argv[2]) * 0x9E3779B97F4A7C15ull;
+  int bad = 0, reached = 0, limited = 0, targeted_n = 0;
+  long long steps = 0;
+  for (int cs = 0; cs < cases; ++cs) {
+    // a reference, and a query derived from a window of it by substitutions / indels (or unrelated), some dirty bases
+    const int n = rnd_int(60, 2600);
+    std::vector<int> r(n), q;
+    for (auto& b : r) b = (int)(rnd() & 3u);
+    const int div = rnd_int(0, 5);   // 0: identical ... 4: heavily diverged, 5: unrelated
+    for (int i = 0; i < n; ++i) {
+      if (div == 5) { q.push_back((int)(rnd() & 3u)); continue; }
+      const int roll = rnd_int(0, 999), p = div * 25;
+      if (roll < p) q.push_back((int)(rnd() & 3u));
+      else if (roll < p + p / 4 + (div ? 2 : 0)) { if (rnd() & 1) { q.push_back((int)(rnd() & 3u)); q.push_back(r[i]); } }   // insertion / deletion
+      else q.push_back(r[i]);
+      if (div && rnd_int(0, 400) == 0) { const int run = rnd_int(1, 70); for (int k = 0; k < run; ++k) q.push_back((int)(rnd() & 3u)); }
+    }
+    if (q.empty()) q.push_back(0);
+    for (int k = rnd_int(0, 3); k > 0; --k) r[rnd_int(0, n - 1)] = 4;
+    for (int k = rnd_int(0, 3); k > 0; --k) q[rnd_int(0, (int)q.size() - 1)] = 4;
+    const int strand = (int)(rnd() & 1u);
+    std::vector<int> qstore = q;
+    if (strand) { for (size_t i = 0; i < q.size(); ++i) { const int b = q[q.size() - 1 - i]; qstore[i] = b < 4 ? 3 - b : 4; } }
+    Packed PR, PQ; PR.set(r); PQ.set(qstore);
+    const SeqView RV = PR.view(), QS = PQ.view();
+    const StrandView QV{QS, strand};
+    const int dir = (rnd() & 1u) ? 1 : -1;
+    const int m = (int)q.size();
+    int32_t r0 = dir > 0 ? rnd_int(0, n / 3) : rnd_int(2 * n / 3, n), q0 = dir > 0 ? rnd_int(0, m / 3) : rnd_int(2 * m / 3, m);
+    int32_t rmax = dir > 0 ? n - r0 : r0, qmax = dir > 0 ? m - q0 : q0;
+    if (rnd_int(0, 3) == 0) { rmax = rnd_int(0, rmax); qmax = rnd_int(0, qmax); ++limited; }
+    int32_t tr = -1, tq = -1;
+    const int tmode = rnd_int(0, 3);
+    if (tmode == 1) { tr = rnd_int(0, rmax); tq = tr + rnd_int(-70, 70); if (tq < 0) tq = 0; }
+    else if (tmode == 2) { tr = rnd_int(0, rmax > 300 ? 300 : rmax); tq = rnd_int(0, qmax > 300 ? 300 : qmax); }
+    else if (tmode == 3) { tr = rnd_int(0, rmax + 5); tq = rnd_int(0, qmax + 5); }
+    if (tr >= 0) ++targeted_n;
+    const ExtResult want = extend_banded(RV, QV, r0, q0, dir, rmax, qmax, tr, tq);
+    const ExtResult got = lane_extend(RV, QS, strand, r0, q0, dir, rmax, qmax, tr, tq, rnd_int(0, 31));
+    steps += want.di + want.dj;
+    reached += want.reached;
+    if (got.di != want.di || got.dj != want.dj || got.score != want.score || got.errors != want.errors || got.reached != want.reached) {
+      if (++bad <= 5)
+        printf("MISMATCH case %d: n %d m %d strand %d dir %d r0 %d q0 %d rmax %d qmax %d tr %d tq %d: lane (%d %d %d %d %d) scalar (%d %d %d %d %d)\n",
+               cs, n, m, strand, dir, r0, q0, rmax, qmax, tr, tq, got.di, got.dj, got.score, got.errors, got.reached, want.di, want.dj,
+               want.score, want.errors, want.reached);
+    }
+  }
+  printf("%d searches (%d with a target, %d reached it, %d with tight limits), %lld bases consumed: %d mismatches\n", cases, targeted_n,
+         reached, limited, steps, bad);
+  return bad ? 1 : 0;
+}
