@@ -1,6 +1,7 @@
 // lane_dp_check.cpp — HOST restatement of the one-LANE-per-search extension DP (pyani_amd/csrc/pga_dp_lane.inc:
 // anim_extdp_lane_kernel, ExtLaneCell, lane_seq_fetch, the windows and the pre-roll), checked against the scalar
-// statement of the algorithm, pga::extend_banded (pg_anim_core.h), on random searches.  It pins the DESIGN of the lane
+// statement of the algorithm, pga::extend_banded (pg_anim_core.h), on random searches; likewise the small-gap form
+// (anim_gapdp_lane_kernel, LaneRow) against pga::gap_errors.  It pins the DESIGN of the lane
 // form on the CPU — the anti-diagonal walk over register parities, the one shared set of 32 X / Y, the limits enforced by
 // killing H only, the reversed / forward 64-bit sequence windows with their pre-roll counts, the running best with its
 // tie order, the optional early stop on a dead band — not the HIP code itself (tests/test_anim_gpu.py does that on the GPU).
@@ -175,9 +176,133 @@ static ExtResult lane_extend(const SeqView& R, const SeqView& QS, int strand, in
   }
 }
 
+// ---- the small-gap form (anim_gapdp_lane_kernel<C, BANDED>, LaneRow): row-major, H / X rows "in registers" --------------
+static void seq_window64(const SeqView& s, int64_t p0, uint32_t c[4], uint64_t& ok) {
+  const int64_t last_c = (s.len - 1) >> 4, last_m = (s.len - 1) >> 5;
+  const int64_t w0 = p0 >> 4, m0 = p0 >> 5;
+  uint32_t w[5], mw[3];
+  for (int k = 0; k < 5; ++k) { int64_t i = w0 + k; i = i < 0 ? 0 : i > last_c ? last_c : i; w[k] = s.codes[i]; }
+  for (int k = 0; k < 3; ++k) { int64_t i = m0 + k; i = i < 0 ? 0 : i > last_m ? last_m : i; mw[k] = s.mask[i]; }
+  const uint32_t sc = 2u * (uint32_t)(p0 & 15), sm = (uint32_t)(p0 & 31);
+  for (int k = 0; k < 4; ++k) c[k] = funnelshift_r(w[k], w[k + 1], sc);
+  ok = (uint64_t)funnelshift_r(mw[0], mw[1], sm) | ((uint64_t)funnelshift_r(mw[1], mw[2], sm) << 32);
+  const int64_t lo = p0 < 0 ? -p0 : 0, hi = s.len - p0;
+  const uint64_t below_hi = hi >= 64 ? ~0ull : hi <= 0 ? 0ull : ((1ull << hi) - 1ull);
+  const uint64_t below_lo = lo >= 64 ? ~0ull : ((1ull << lo) - 1ull);
+  ok &= below_hi & ~below_lo;
+}
+static int32_t lane_gap_errors(const SeqView& RV, const SeqView& QS, int strand, int32_t r0, int32_t n, int32_t q0, int32_t m) {
+  constexpr int W = BAND / 2;
+  constexpr uint32_t K_LIVE = 32768u << 15, K_START = (65536u << 15) | 32767u;
+  constexpr uint32_t K_OPEN = (uint32_t)(-SC_GAP_OPEN) * 32768u + 1u, K_EXT = (uint32_t)(-SC_GAP_EXT) * 32768u + 1u;
+  constexpr uint32_t K_MATCH = (uint32_t)SC_MATCH * 32768u, K_MISMATCH = (uint32_t)(-SC_MISMATCH) * 32768u + 1u;
+  const bool banded = (n > m ? n : m) > 31;   // the classes with a side > 31 test the band per cell
+  int koff = (m - n) / 2;
+  if (koff > W - 2) koff = W - 2;
+  if (koff < -(W - 2)) koff = -(W - 2);
+  const int lt = (m - n) - koff + W;
+  const bool in_band = lt >= 0 && lt < BAND;
+  const int klo = koff - W, khi = koff + W - 1;
+  uint32_t rc[4], qc[4];
+  uint64_t rok, qok;
+  seq_window64(RV, r0, rc, rok);
+  if (strand) {
+    uint32_t f[4]; uint64_t fok;
+    seq_window64(QS, QS.len - 1 - (int64_t)q0 - 63, f, fok);
+    for (int k = 0; k < 4; ++k) qc[k] = ~rev_fields2(f[3 - k]);
+    qok = ((uint64_t)brev32((uint32_t)fok) << 32) | (uint64_t)brev32((uint32_t)(fok >> 32));
+  } else {
+    seq_window64(QS, q0, qc, qok);
+  }
+  uint32_t qsf[4];
+  for (int k = 0; k < 4; ++k) qsf[k] = spread16((uint32_t)(qok >> (16 * k)) & 0xFFFFu);
+  uint32_t H[64], X[64];
+  for (int j = 0; j < 64; ++j) { H[j] = 0; X[j] = 0; }
+  if (in_band) {
+    for (int32_t i = 0; i <= n; ++i) {
+      const uint32_t sel = (i >= 1 && (rok & 1ull)) ? ~0u : 0u;
+      const uint32_t rb = (rc[0] & 3u) * 0x55555555u;
+      uint32_t eq[4];
+      for (int k = 0; k < 4; ++k) { const uint32_t x = qc[k] ^ rb; eq[k] = ~(x | (x >> 1)) & qsf[k] & sel; }
+      if (i >= 1) {
+        rc[0] = funnelshift_r(rc[0], rc[1], 2); rc[1] = funnelshift_r(rc[1], rc[2], 2);
+        rc[2] = funnelshift_r(rc[2], rc[3], 2); rc[3] >>= 2;
+        rok >>= 1;
+      }
+      uint32_t blo = 0, bwid = 0;
+      if (banded) {
+        const int32_t lo = i + klo > 0 ? i + klo : 0, hi = i + khi < m ? i + khi : m;
+        blo = hi >= lo ? (uint32_t)lo : (1u << 20);
+        bwid = hi >= lo ? (uint32_t)(hi - lo) : 0u;
+      }
+      uint32_t hdiag = 0, hleft = 0, yleft = 0;
+      for (int j = 0; j <= m; ++j) {
+        const uint32_t up_h = H[j], up_x = X[j];
+        const uint32_t xa = sub_sat(up_h, K_OPEN), xb = sub_sat(up_x, K_EXT);
+        const uint32_t nx = xa > xb ? xa : xb;
+        uint32_t ny = 0, nh;
+        if (j == 0) {
+          nh = i == 0 ? K_START : nx;
+        } else {
+          const uint32_t ya = sub_sat(hleft, K_OPEN), yb = sub_sat(yleft, K_EXT);
+          ny = ya > yb ? ya : yb;
+          const uint32_t bit = (eq[(j - 1) >> 4] >> (2 * ((j - 1) & 15))) & 1u;
+          nh = bit * (K_MATCH + K_MISMATCH) + sub_sat(hdiag, K_MISMATCH);
+          nh = nh > nx ? nh : nx; nh = nh > ny ? nh : ny;
+        }
+        if (banded) nh = ((uint32_t)j - blo <= bwid) ? nh : 0u;
+        H[j] = nh; X[j] = nx;
+        hdiag = up_h; hleft = nh; yleft = ny;
+      }
+    }
+  }
+  const uint32_t tH = H[m];
+  if (in_band && tH >= K_LIVE) return 32767 - (int32_t)(tH & 32767u);
+  const StrandView QV{QS, strand};
+  const int32_t kq = n < m ? n : m;
+  int32_t err = n > m ? n - m : m - n;
+  for (int32_t t = 0; t < kq; ++t) err += (RV.clean(r0 + t) && QV.clean(q0 + t) && RV.base(r0 + t) == QV.base(q0 + t)) ? 0 : 1;
+  return err;
+}
+
+static int check_gaps(int cases) {
+  int bad = 0, dp = 0;
+  for (int cs = 0; cs < cases; ++cs) {
+    int n = rnd_int(1, 63), m = rnd_int(0, 9) ? n + rnd_int(-6, 6) : rnd_int(1, 63);
+    if (rnd_int(0, 99) == 0) { n = rnd() & 1 ? 1 : 63; m = 64 - n; }   // the one shape whose target lies outside the band
+    const int mm = m < 1 ? 1 : m > 63 ? 63 : m;
+    const int pad_l = rnd_int(0, 40), pad_r = rnd_int(0, 40);
+    std::vector<int> r(pad_l + n + pad_r), q;
+    for (auto& b : r) b = (int)(rnd() & 3u);
+    for (int i = 0; i < pad_l; ++i) q.push_back((int)(rnd() & 3u));
+    const int q0 = (int)q.size();
+    const int div = rnd_int(0, 4);
+    for (int j = 0; j < mm; ++j) {   // the query gap: a noisy copy of the reference gap, stretched or cut to mm bases
+      const int src = pad_l + (int)((long long)j * n / mm);
+      q.push_back(rnd_int(0, 99) < div * 12 ? (int)(rnd() & 3u) : r[src]);
+    }
+    for (int i = 0; i < pad_r; ++i) q.push_back((int)(rnd() & 3u));
+    if (rnd_int(0, 5) == 0) r[pad_l + rnd_int(0, n - 1)] = 4;
+    if (rnd_int(0, 5) == 0) q[q0 + rnd_int(0, mm - 1)] = 4;
+    const int strand = (int)(rnd() & 1u);
+    std::vector<int> qstore = q;
+    if (strand) { for (size_t i = 0; i < q.size(); ++i) { const int b = q[q.size() - 1 - i]; qstore[i] = b < 4 ? 3 - b : 4; } }
+    Packed PR, PQ; PR.set(r); PQ.set(qstore);
+    const SeqView RV = PR.view(), QS = PQ.view();
+    const StrandView QV{QS, strand};
+    const int32_t want = gap_errors(RV, QV, pad_l, n, q0, mm);
+    const int32_t got = lane_gap_errors(RV, QS, strand, pad_l, n, q0, mm);
+    dp += extend_banded(RV, QV, pad_l, q0, +1, n, mm, n, mm).reached;
+    if (got != want && ++bad <= 5) printf("GAP MISMATCH case %d: n %d m %d strand %d: lane %d scalar %d\n", cs, n, mm, strand, got, want);
+  }
+  printf("%d gaps (%d solved by the DP, the others by the diagonal count): %d mismatches\n", cases, dp, bad);
+  return bad;
+}
+
 int main(int argc, char** argv) {
   const int cases = argc > 1 ? atoi(argv[1]) : 3000;
   if (argc > 2) rng_state ^= (uint64_t)atoll(argv[2]) * 0x9E3779B97F4A7C15ull;
+  const int bad_gaps = check_gaps(cases * 4);
   int bad = 0, reached = 0, limited = 0, targeted_n = 0;
   long long steps = 0;
   for (int cs = 0; cs < cases; ++cs) {
@@ -227,5 +352,5 @@ int main(int argc, char** argv) {
   }
   printf("%d searches (%d with a target, %d reached it, %d with tight limits), %lld bases consumed: %d mismatches\n", cases, targeted_n,
          reached, limited, steps, bad);
-  return bad ? 1 : 0;
+  return bad || bad_gaps ? 1 : 0;
 }
