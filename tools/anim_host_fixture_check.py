@@ -20,44 +20,76 @@ ap = argparse.ArgumentParser()
 ap.add_argument("-j", type=int, default=8)
 ap.add_argument("--only", default="")
 ap.add_argument("--diff", action="store_true", help="print the records that differ")
+ap.add_argument("--json", default="", help="write the per-pair report (records + parse_delta tuples) here")
 args = ap.parse_args()
 exe = ROOT / "tools/anim_debug/anim_debug"
 subprocess.run(["g++", "-O2", "-std=c++17", f"-I{ROOT}/pyani_amd/csrc", str(exe) + ".cpp", "-o", str(exe)], check=True)
 tmp = Path(tempfile.mkdtemp())
 paths = {}
-for grp in ("blochmannia", "caulobacter"):
+for grp in ("blochmannia", "caulobacter", "group2"):
     for gz in sorted((ROOT / "tests/golden/genomes" / grp).glob("*.fna.gz")):
         dst = tmp / gz.name[:-3]
         with gzip.open(gz, "rb") as fi, open(dst, "wb") as fo:
             shutil.copyfileobj(fi, fo)
         paths[dst.stem] = dst
+# JSpecies ran nucmer on the single-record NC_002696 (= the two records of the fixture file joined)
+joined = tmp / "js" / "NC_002696.fna"
+joined.parent.mkdir()
+body = "".join(l.strip() for l in open(paths["NC_002696"]) if not l.startswith(">"))
+joined.write_text(">gi|16124256|ref|NC_002696.2| joined\n" + "\n".join(body[i:i + 70] for i in range(0, len(body), 70)) + "\n")
 jobs = []
-for grp in ("blochmannia", "caulobacter"):
+for grp in ("blochmannia", "caulobacter", "group2", "jspecies"):
     for f in sorted((ROOT / "tests/golden/anim" / grp).glob("*.delta.gz")):
         a, b = f.name[:-len(".delta.gz")].split("_vs_")
-        if a in paths and b in paths and args.only in f.name:
-            jobs.append((f, a, b))
+        if a in paths and b in paths and args.only in f"{grp}/{f.name}":
+            jobs.append((f, a, b, grp))
 
 
 def run(job):
-    f, a, b = job
-    r = subprocess.run([str(exe), str(paths[a]), str(paths[b]), "--dump"], capture_output=True, text=True)
-    got = set()
+    f, a, b, grp = job
+    pa, pb = (joined if grp == "jspecies" and s == "NC_002696" else paths[s] for s in (a, b))
+    r = subprocess.run([str(exe), str(pa), str(pb), "--dump"], capture_output=True, text=True)
+    got, kept = set(), []
     for line in r.stdout.splitlines():
         if line.startswith("ALN "):
             t = line.split()
             got.add((t[1], t[2], int(t[3]), int(t[4]), int(t[5]), int(t[6]), int(t[7])))
+            if t[8] == "keep=3":
+                kept.append(anim_oracle.Aln(t[1], t[2], int(t[3]), int(t[4]), int(t[5]), int(t[6]), int(t[7]), int(t[7]), 0, ()))
     want = {(x.ref_id, x.qry_id, x.rs, x.re, x.qs, x.qe, x.errors) for x in anim_oracle.read_delta(f)[0]}
     coords = {w[:6] for w in want} & {g[:6] for g in got}
     if args.diff:
         for w in sorted(want - got): print("  MUMMER", w, flush=True)
         for g in sorted(got - want): print("  OURS  ", g, flush=True)
-    return f.name, len(want), len(want & got), len(coords), len(got), r.stdout.splitlines()[0] if r.stdout else ""
+    rep = {"mummer_records": len(want), "exact": len(want & got), "same_coordinates": len(coords), "ours": len(got)}
+    allrecs = [anim_oracle.Aln(*g, g[6], 0, ()) for g in got]
+    rep["delta_tuple_mummer"] = list(anim_oracle.parse_delta(f))
+    rep["delta_tuple_ours"] = list(anim_oracle.parse_delta_records(allrecs)) if allrecs else None
+    flt = Path(str(f).replace(".delta.gz", ".filter.gz"))
+    if flt.exists():
+        rep["filter_tuple_mummer"] = list(anim_oracle.parse_delta(flt))
+        rep["filter_tuple_ours"] = list(anim_oracle.parse_delta_records(kept)) if kept else None
+    for k in ("delta", "filter"):
+        m, o = rep.get(f"{k}_tuple_mummer"), rep.get(f"{k}_tuple_ours")
+        if m and o:
+            rep[f"{k}_identity_abs_diff"] = abs(m[2] - o[2])
+            rep[f"{k}_ref_aln_len_rel_diff"] = abs(m[0] - o[0]) / m[0]
+            rep[f"{k}_qry_aln_len_rel_diff"] = abs(m[1] - o[1]) / m[1]
+    report[f"{grp}/{f.name[:-len('.delta.gz')]}"] = rep
+    return f"{grp}/{f.name}", len(want), len(want & got), len(coords), len(got), r.stdout.splitlines()[0] if r.stdout else ""
 
 
+report = {}
 tot_w = tot_e = tot_c = 0
 with ThreadPoolExecutor(args.j) as ex:
     for name, nw, ne, nc, ng, first in ex.map(run, jobs):
         tot_w += nw; tot_e += ne; tot_c += nc
         print(f"{name[:70]:70s} mummer {nw:4d}  exact {ne:4d}  coords-only {nc:4d}  ours {ng:4d}", flush=True)
 print(f"TOTAL records {tot_w}  exact {tot_e}  same coordinates {tot_c}")
+if args.json:
+    import json
+    worst = {k: max((r.get(k, 0.0) for r in report.values()), default=0.0) for k in
+             ("filter_identity_abs_diff", "filter_ref_aln_len_rel_diff", "filter_qry_aln_len_rel_diff", "delta_identity_abs_diff",
+              "delta_ref_aln_len_rel_diff", "delta_qry_aln_len_rel_diff")}
+    Path(args.json).write_text(json.dumps({"total_records": tot_w, "exact": tot_e, "same_coordinates": tot_c, "worst": worst,
+                                           "pairs": report}, indent=1, sort_keys=True))

@@ -194,20 +194,76 @@ def main():
 # ---------------------------------------------------------------------------------------------------------------
 # ANIm: real MUMmer output held by the reference's tests (the only pin for the alignment search) + the reference's
 # known answers for parse_delta.  Run with:  python tools/make_goldens.py --anim-only
+def load_reference_anim():
+    """The reference's own pyani/anim.py, imported as part of its package (tools/bio_shim supplies stand-ins for the two
+    absent third-party imports: Bio.SeqIO and intervaltree — neither holds pyani arithmetic)."""
+    sys.path.insert(0, str(REF))
+    import pyani.anim as ref_anim
+    return ref_anim
+
+
+def decode_blastdb_nsq(nsq: Path, nin: Path):
+    """One-sequence NCBI BLAST nucleotide database (formatdb v4) -> (sequence bytes, title).  The reference's JSpecies test
+    data keeps NC_010338 / NC_014100 only in this form (tests/test_JSpecies/pyani_tests/*.nsq; their FASTA files are
+    missing blobs).  .nin: big-endian version, dbtype, title, date, nseq, LITTLE-endian total length, max length, then the
+    header / sequence / ambiguity offset arrays; .nsq: ncbi2na, 4 bases per byte, first base in the high bits."""
+    import struct
+    import numpy as np
+    b = nin.read_bytes()
+    o = 8
+    tl, = struct.unpack(">i", b[o:o + 4]); o += 4 + tl
+    dl, = struct.unpack(">i", b[o:o + 4]); o += 4 + dl
+    nseq, = struct.unpack(">i", b[o:o + 4]); o += 4
+    total, = struct.unpack("<q", b[o:o + 8]); o += 8 + 4
+    n = nseq + 1
+    seq_off = struct.unpack(f">{n}i", b[o + 4 * n:o + 8 * n])
+    amb_off = struct.unpack(f">{n}i", b[o + 8 * n:o + 12 * n])
+    assert nseq == 1 and amb_off[0] == seq_off[1], "expected one sequence without ambiguity runs"
+    raw = np.fromfile(nsq, dtype=np.uint8)[seq_off[0]:seq_off[1]]
+    lut = np.frombuffer(b"ACGT", dtype=np.uint8)
+    out = np.empty((len(raw), 4), dtype=np.uint8)
+    for k in range(4):
+        out[:, k] = lut[(raw >> (6 - 2 * k)) & 3]
+    return out.reshape(-1)[:total].tobytes()
+
+
+def fasta_body(path: Path) -> bytes:
+    return b"".join(l.strip() for l in open(path, "rb") if not l.startswith(b">")).upper()
+
+
+def gz_bytes(data: bytes, dst: Path):
+    dst.parent.mkdir(parents=True, exist_ok=True)
+    with open(dst, "wb") as raw:
+        with gzip.GzipFile(filename="", mode="wb", fileobj=raw, mtime=0, compresslevel=9) as fo:
+            fo.write(data)
+
+
 def make_anim_goldens():
     import tarfile
     sys.path.insert(0, str(ROOT / "oracle"))
     import anim_oracle
+    ref_anim = load_reference_anim()
     out_dir = GOLD / "anim"
     tuples = {}
+    tmp = ROOT / "gpurun_out" / "_goldens_tmp"
+    tmp.mkdir(parents=True, exist_ok=True)
 
     def store(src_bytes, rel):
+        """Fixture file + the tuple the REFERENCE's parse_delta (pyani/anim.py:292-411, imported) returns for it."""
         dst = out_dir / (rel + ".gz")
-        dst.parent.mkdir(parents=True, exist_ok=True)
-        with open(dst, "wb") as raw:
-            with gzip.GzipFile(filename="", mode="wb", fileobj=raw, mtime=0, compresslevel=9) as fo:
-                fo.write(src_bytes)
-        tuples[rel] = list(anim_oracle.parse_delta(dst))
+        gz_bytes(src_bytes, dst)
+        plain = tmp / "cur.delta"
+        plain.write_bytes(src_bytes)
+        try:
+            tuples[rel] = list(ref_anim.parse_delta(plain))
+        except ZeroDivisionError:
+            tuples[rel] = None
+        mine = None
+        try:
+            mine = list(anim_oracle.parse_delta(dst))
+        except ZeroDivisionError:
+            pass
+        assert mine == tuples[rel], (rel, mine, tuples[rel])     # the restatement equals the reference on every fixture
 
     for d in sorted((REF / "tests/fixtures/anim/deltadir").iterdir()):
         for f in sorted(d.glob("*_vs_*")):
@@ -218,11 +274,38 @@ def make_anim_goldens():
         for m in tf.getmembers():
             if m.isfile() and m.name.endswith((".delta", ".filter")):
                 store(tf.extractfile(m).read(), f"blochmannia/{Path(m.name).name}")
+    # ---- out-of-sample MUMmer output (never looked at while the engine's constants were fitted) -----------
+    js = REF / "tests/test_JSpecies"
+    for f in sorted((js / "Group_2").glob("*.delta")):            # raw nucmer output, 2-record draft vs 1 record
+        a, b = f.name[:-len(".delta")].split("_vs_")
+        store(f.read_bytes(), f"group2/{a[:-4]}_vs_{b[:-4]}.delta")
+    for f in sorted((js / "Group_2").glob("*.fna")):
+        gz_copy(f, GOLD / "genomes" / "group2" / (f.name + ".gz"))
+    for f in sorted((js / "pyani_tests").glob("*.fna_vs_*.fna.delta")):   # JSpecies' own nucmer runs on the 4 Caulobacter genomes
+        a, b = f.name[:-len(".delta")].split("_vs_")
+        store(f.read_bytes(), f"jspecies/{a[:-4]}_vs_{b[:-4]}.delta")
+    # the two Caulobacter genomes whose FASTA files are missing blobs, recovered from JSpecies' BLAST databases; the decoder
+    # is validated on the two genomes that exist in both forms, and the lengths equal the .delta headers
+    pt = js / "pyani_tests"
+    for stem in ("NC_002696", "NC_011916"):
+        assert decode_blastdb_nsq(pt / f"{stem}.fna.nsq", pt / f"{stem}.fna.nin") == fasta_body(pt / f"{stem}.fna"), stem
+    # single-record NC_002696 of the JSpecies runs == the two records of fixtures/anim/sequences joined
+    assert fasta_body(pt / "NC_002696.fna") == fasta_body(REF / "tests/fixtures/anim/sequences/NC_002696.fna")
+    titles = {"NC_010338": ("gi|167643973|ref|NC_010338.1|", "Caulobacter sp. K31 chromosome, complete genome", 5477872),
+              "NC_014100": ("gi|295687459|ref|NC_014100.1|", "Caulobacter segnis ATCC 21756 chromosome, complete genome", 4655622)}
+    for stem, (sid, title, length) in titles.items():
+        seq = decode_blastdb_nsq(pt / f"{stem}.fna.nsq", pt / f"{stem}.fna.nin")
+        assert len(seq) == length and title.encode() in (pt / f"{stem}.fna.nhr").read_bytes()
+        lines = [f">{sid} {title}".encode()] + [seq[i:i + 70] for i in range(0, len(seq), 70)]
+        gz_bytes(b"\n".join(lines) + b"\n", GOLD / "genomes" / "caulobacter" / f"{stem}.fna.gz")
     shutil.copyfile(REF / "tests/fixtures/anim/dataframes/deltadir_result.csv", GOLD / "ref_targets" / "anim_deltadir_result.csv")
+    shutil.copyfile(js / "jspecies_results.tab", GOLD / "ref_targets" / "jspecies_results_caulobacter.tab")
     known = {"test.delta": [4016947, 4017751, 0.9994621994447228, 2191]}  # tests/test_anim.py:96-100
     assert tuples["test.delta"] == known["test.delta"]
     with open(GOLD / "anim_goldens.json", "w") as fh:
-        json.dump({"reference_known_answers": known, "parse_delta": tuples}, fh, indent=0, sort_keys=True)
+        json.dump({"reference_known_answers": known, "parse_delta": tuples,
+                   "generated_by": "pyani/anim.py:parse_delta imported from the reference (tools/make_goldens.py)"},
+                  fh, indent=0, sort_keys=True)
     print("wrote", GOLD / "anim_goldens.json", len(tuples), "files")
 
 
