@@ -1,26 +1,33 @@
 #!/usr/bin/env python3
-"""bench.py — headline benchmark of the hot path: TETRA N x N matrix on synthetic ~5 Mb genomes (BASELINE.json
-configs[1], SURVEY.md §8(d) set C2), genome-pairs/s on MI355X, with the kernel roofline and the CPU baseline.
+"""bench.py — headline benchmark of the hot path: genome-pairs/s for the ANIm N x N grid (BASELINE.json configs[3] = SURVEY.md
+§8(d) set C4: 1000 synthetic ~5 Mb genomes, 999 000 ordered pairs), the largest configuration that fits one MI355X and the
+one the north-star target is quoted on; with the kernel roofline, the CPU baseline timed on this box's host cores, and the
+C2 TETRA roofline nested as a sub-record.
 
   python bench.py [--gpus N] [--steps K] [--warmup W]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
 
-A "step" = one full pass of the path over the batch, inputs already resident in HBM (2-bit codes + 1-bit mask):
-  N = 1 : count kernel -> finalize/Z -> stats -> Pearson -> D2H of Z and the matrix       (200 genomes, 19 900 pairs)
-  N > 1 : weak scaling, 200 genomes per GPU (job = 200*N genomes, all 200N(200N-1)/2 pairs): every rank counts its
-          genomes, RCCL all-gather of Z (N*200 x 256 f64 + presence), every rank computes its row block of the
-          matrix, RCCL all-gather of the rows.  (two collectives, both tiny.)
-Rank 0 prints ONE JSON line.
+ANIm (default).  All genomes are resident in HBM on every GPU (2-bit codes + 1-bit mask; 1.9 GB at C4).  A STEP is one
+pass of the whole pipeline — seed, cluster, extend, 1-to-1 filter, parse_delta reduction, results back on the host — over
+one tile of the ordered-pair grid: `--rows-per-step` reference genomes (default 100) x all 999 queries = 99 900 ordered
+pairs; step k takes rows [k*R, (k+1)*R) modulo N, so 10 steps are exactly one pass over the N x N grid.  `value` = ordered
+pairs processed in the K timed steps / wall time.  N > 1 is STRONG scaling of that same job: the rows of every step are
+dealt over the ranks (pyani_amd.parallel.anim_row_shard), each rank runs its rows against all queries, ONE RCCL all-gather
+per step (64 B per pair) puts the step's rows of the result grid on every rank.  No other collective, no sequence traffic.
 
-  --workload anim : the ANIm side of the same metric on the same genomes (C3: all 39 800 ordered pairs; a step is one
-          pass over the whole grid; N > 1 = strong scaling, pair grid dealt by reference row, one all-gather).  Not the
-          default: BASELINE.json quotes the metric on configs[1] (TETRA) for N = 1.
+  --workload tetra : the TETRA side alone (C2: 200 genomes, counts + Z + Pearson; N > 1 = weak scaling, 200 genomes per GPU).
+
+Rank 0 prints ONE JSON line.
 """
 import argparse
+import hashlib
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 from concurrent.futures import ThreadPoolExecutor
 from pathlib import Path
@@ -36,48 +43,214 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICRO
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--workload", choices=["tetra", "anim"], default="tetra",
-                    help="tetra = C2 (the default, BASELINE.json configs[1]); anim = C3 (all ordered pairs of the same genomes)")
-    ap.add_argument("--steps", type=int, default=None, help="default 50 (tetra) / 3 (anim)")
-    ap.add_argument("--warmup", type=int, default=None, help="default 5 (tetra) / 1 (anim)")
-    ap.add_argument("--genomes", type=int, default=200, help="genomes per GPU (C2: 200)")
-    ap.add_argument("--length", type=int, default=5_000_000, help="ancestor length in bases (C2: 5 Mb)")
-    ap.add_argument("--seed", type=int, default=20250228)
+    ap.add_argument("--workload", choices=["anim", "tetra"], default="anim",
+                    help="anim = C4 (default: the N x N ANIm grid the metric is quoted on); tetra = C2 alone")
+    ap.add_argument("--steps", type=int, default=None, help="default 10 (anim: one pass over the grid) / 50 (tetra)")
+    ap.add_argument("--warmup", type=int, default=None, help="default 2 (anim) / 5 (tetra)")
+    ap.add_argument("--genomes", type=int, default=None, help="anim: genomes of the job (C4: 1000); tetra: genomes per GPU (C2: 200)")
+    ap.add_argument("--length", type=int, default=5_000_000, help="ancestor length in bases (5 Mb)")
+    ap.add_argument("--seed", type=int, default=None, help="default: the set's own seed (C4 20250301, C2 20250228)")
+    ap.add_argument("--rows-per-step", type=int, default=100, help="anim: reference genomes (grid rows) per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-genomes", type=int, default=2, help="genomes timed by the CPU baseline leg")
+    ap.add_argument("--cpu-pairs", type=int, default=0, help="anim: ordered pairs timed by the CPU leg (0 = one per host thread, <= 256)")
+    ap.add_argument("--cpu-genomes", type=int, default=2, help="tetra: genomes timed by the CPU leg")
+    ap.add_argument("--no-tetra", action="store_true", help="anim: skip the nested C2 TETRA sub-record")
     args = ap.parse_args()
+    anim = args.workload == "anim"
     if args.steps is None:
-        args.steps = 50 if args.workload == "tetra" else 3
+        args.steps = 10 if anim else 50
     if args.warmup is None:
-        args.warmup = 5 if args.workload == "tetra" else 1
+        args.warmup = 2 if anim else 5
+    if args.genomes is None:
+        args.genomes = 1000 if anim else 200
+    if args.seed is None:
+        args.seed = 20250301 if anim else 20250228
     return args
 
 
+def synth_genomes(seed, n, L, lo, hi, world):
+    from pyani_amd import synth
+    with ThreadPoolExecutor(max(1, min(64, (os.cpu_count() or 2) // max(1, world)))) as ex:
+        return list(ex.map(lambda g: synth.genome(seed, n, g, L), range(lo, hi)))
+
+
+# =====================================================================================================================
+# ANIm: the N x N grid (C4)
+# =====================================================================================================================
+ANIM_STAGES = None  # filled from _lib
+
+
+def anim_cpu_baseline(args, data, n, related, gpu_lookup):
+    """The CPU side of the metric on THIS box's host cores, on a bounded stratified sample of the same ordered pairs,
+    extrapolated linearly (pairs are independent jobs — pyani's runner is a multiprocessing.Pool of one nucmer +
+    delta-filter process per pair, run_multiprocessing.py:130-144).
+      kind "reference": nucmer + delta-filter exist on this box -> exactly pyani's jobs, Pool(os.cpu_count()).
+      kind "port"     : they do not (MUMmer is third-party, absent from the image) -> the repo's own CPU statement of the
+                        same search (oracle/anim_cpu.cpp: the scalar core of the engine on an exhaustive 20-mer table), one
+                        pair per host thread ("own-cpu")."""
+    threads = os.cpu_count() or 1
+    k = args.cpu_pairs or min(threads, 256)
+    K = (n + 24) // 25
+    rng = np.random.RandomState(12345)
+    rel, unrel = [], []
+    while len(rel) < (k + 1) // 2:
+        q = int(rng.randint(n)); s = (q + K * int(rng.randint(1, max(2, (n - 1) // K + 1)))) % n
+        if s != q and (q % K) == (s % K) and (q, s) not in rel:
+            rel.append((q, s))
+    while len(unrel) < k // 2:
+        q, s = int(rng.randint(n)), int(rng.randint(n))
+        if (q % K) != (s % K) and (q, s) not in unrel:
+            unrel.append((q, s))
+    sample = rel + unrel
+    n_rel_job, n_unrel_job = int(related.sum()), int((~related).sum())
+    used = sorted({g for p in sample for g in p})
+    if shutil.which("nucmer") and shutil.which("delta-filter"):
+        try:
+            return _nucmer_baseline(sample, len(rel), data, n_rel_job, n_unrel_job, threads)
+        except Exception as exc:   # a broken MUMmer install must not cost the GPU line
+            note = f"nucmer found but unusable ({exc!r}); "
+    else:
+        note = "nucmer / delta-filter (MUMmer 3.23) are not installed on this box; "
+    sys.path.insert(0, str(ROOT / "oracle"))
+    import anim_cpu
+    genomes = [data[g] if g in used else None for g in range(n)]
+    t0 = time.perf_counter()
+    res, secs = anim_cpu.anim_cpu_pairs(genomes, [q for q, _ in sample], [s for _, s in sample], threads=min(threads, len(sample)))
+    wall = time.perf_counter() - t0
+    t_rel = float(secs[: len(rel)].mean())
+    t_unrel = float(secs[len(rel):].mean()) if unrel else 0.0
+    job_cpu_s = n_rel_job * t_rel + n_unrel_job * t_unrel
+    job_wall = job_cpu_s / threads
+    same = 0
+    for (q, s), r in zip(sample, res):
+        g = gpu_lookup(q, s)
+        same += int(g is None or (int(g["ref_aln_len"]), int(g["qry_aln_len"]), int(g["sim_errors"]), float(g["identity"]).hex(), int(g["status"])) ==
+                    (int(r["ref_aln_len"]), int(r["qry_aln_len"]), int(r["sim_errors"]), float(r["identity"]).hex(), int(r["status"])))
+    return {
+        "value": (n_rel_job + n_unrel_job) / job_wall, "unit": "genome-pairs/s", "cores": threads, "kind": "port",
+        "variant": "own-cpu (oracle/anim_cpu.cpp: host build of the engine's scalar core, exhaustive 20-mer table; NOT MUMmer)",
+        "sample": note + f"{len(sample)} ordered pairs of the same job ({len(rel)} related, {len(unrel)} unrelated) run one per host "
+                  f"thread ({min(threads, len(sample))} concurrent, {wall:.1f} s wall, {float(secs.sum()):.0f} CPU-s): "
+                  f"{t_rel:.2f} s per related pair, {t_unrel:.2f} s per unrelated pair; extrapolated linearly to "
+                  f"{n_rel_job} related + {n_unrel_job} unrelated pairs on {threads} threads",
+        "job_seconds_extrapolated": job_wall, "cpu_seconds_extrapolated": job_cpu_s,
+        "gpu_parity_on_sample": f"{same}/{len(sample)} sampled pairs identical to the GPU's result",
+    }
+
+
+def _nucmer_job(job):
+    ref, qry, prefix = job
+    t0 = time.perf_counter()
+    subprocess.run(["nucmer", "--mum", "-p", prefix, ref, qry], check=True, capture_output=True)
+    with open(prefix + ".filter", "wb") as fh:
+        subprocess.run(["delta-filter", "-1", prefix + ".delta"], check=True, stdout=fh, stderr=subprocess.DEVNULL)
+    return time.perf_counter() - t0
+
+
+def _nucmer_baseline(sample, n_rel, data, n_rel_job, n_unrel_job, threads):
+    """pyani's own jobs (anim.py:240-289) under a multiprocessing.Pool(os.cpu_count()) (run_multiprocessing.py:130)."""
+    import multiprocessing
+    from pyani_amd import synth
+    with tempfile.TemporaryDirectory() as tmp:
+        paths = {}
+        for g in sorted({g for p in sample for g in p}):
+            paths[g] = os.path.join(tmp, f"{synth.genome_name(g)}.fna")
+            synth.write_fasta(Path(paths[g]), data[g][0], data[g][1], synth.genome_name(g))
+        jobs = [(paths[q], paths[s], os.path.join(tmp, f"{q}_vs_{s}")) for q, s in sample]
+        t0 = time.perf_counter()
+        with multiprocessing.Pool(threads) as pool:
+            secs = pool.map(_nucmer_job, jobs)
+        wall = time.perf_counter() - t0
+    t_rel, t_unrel = float(np.mean(secs[:n_rel])), float(np.mean(secs[n_rel:]))
+    job_cpu_s = n_rel_job * t_rel + n_unrel_job * t_unrel
+    return {
+        "value": (n_rel_job + n_unrel_job) / (job_cpu_s / threads), "unit": "genome-pairs/s", "cores": threads, "kind": "reference",
+        "sample": f"{len(sample)} ordered pairs ({n_rel} related) through nucmer --mum + delta-filter -1 under Pool({threads}) "
+                  f"({wall:.1f} s wall): {t_rel:.2f} s per related, {t_unrel:.2f} s per unrelated pair; extrapolated linearly",
+        "job_seconds_extrapolated": job_cpu_s / threads, "cpu_seconds_extrapolated": job_cpu_s,
+    }
+
+
+def tetra_subrecord(eng, local, no_cpu):
+    """C2 TETRA on the same GPU (200 genomes x 5 Mb, seed 20250228): the count kernel's HBM roofline, nested into the ANIm line."""
+    from pyani_amd import _lib
+    n, L, seed = 200, 5_000_000, 20250228
+    data = synth_genomes(seed, n, L, 0, n, 1)
+    ids = np.ascontiguousarray([eng.add_genome(s_, o_) for s_, o_ in data], dtype=np.int32)
+    eng.upload()
+    alg_bytes, bases = eng.tetra_algorithmic_bytes(ids.tolist())
+    for _ in range(5):
+        eng.tetra_matrix_enqueue(ids, fetch_z=False)
+    eng.sync()
+    eng.profile_reset()
+    eng.profile_config(kernel_mask=1 << _lib.K_TETRA_COUNT, every_n=4)
+    eng.profile_enable(True)
+    steps = 40
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        eng.tetra_matrix_enqueue(ids, fetch_z=False)
+    eng.sync()
+    elapsed = time.perf_counter() - t0
+    eng.profile_enable(False)
+    ms, cnt = eng.profile_get(_lib.K_TETRA_COUNT)
+    avg_s = ms / max(cnt, 1) * 1e-3
+    pairs = n * (n - 1) // 2
+    traffic = None
+    pmc = ROOT / "profiles" / "pmc_tetra_count.json"
+    if pmc.exists():
+        traffic = json.loads(pmc.read_text()).get("hbm_bytes_per_launch")
+    achieved = alg_bytes / avg_s / 1e9 if cnt else 0.0
+    rec = {
+        "workload": f"C2: TETRA on {n} synthetic ~5 Mb genomes (seed {seed}), {pairs} unordered pairs, counts + Z + Pearson",
+        "value": pairs / (elapsed / steps), "unit": "genome-pairs/s", "steps": steps, "ms_per_step": elapsed / steps * 1e3,
+        "dtype": "u64 counts + f64 Z/Pearson",
+        "roofline": {"bound": "hbm", "kernel": "tetra_count_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": int(alg_bytes),
+                     "avg_launch_us": avg_s * 1e6, "launches": int(cnt), "frac_of_measured_copy_peak_6290": achieved / 6290.0},
+    }
+    if not no_cpu:
+        eng.tetra_matrix_enqueue(ids, fetch_z=True)
+        z, _, _ = eng.tetra_matrix_fetch(n)
+        rec["cpu_baseline"] = tetra_cpu_baseline(z, data[:2], n, pairs)   # ids ascend in data order
+    return rec
+
+
 def run_anim(args, rank, world, local, dist, torch):
-    """C3-shaped ANIm workload: every ordered pair of `--genomes` synthetic genomes (replicated on every GPU).  A step is
-    one pass over the whole ordered-pair grid; with N GPUs the grid is dealt by reference row and assembled with ONE
-    all-gather (pyani_amd/parallel.py), i.e. STRONG scaling of a fixed job."""
-    from pyani_amd import parallel, synth
+    from pyani_amd import _lib, parallel
     from pyani_amd.engine import Engine
     eng = Engine(local)
-    n = args.genomes
+    n, R = args.genomes, max(1, min(args.rows_per_step, args.genomes))
+    K = (n + 24) // 25                       # ancestors of the SURVEY.md §8(d) generator: genome g descends from ancestor g mod K
     t_prep = time.perf_counter()
-    with ThreadPoolExecutor(max(1, min(16, (os.cpu_count() or 2) // max(1, world)))) as ex:
-        data = list(ex.map(lambda g: synth.genome(args.seed, n, g, args.length), range(n)))
+    data = synth_genomes(args.seed, n, args.length, 0, n, world)
     ids = [eng.add_genome(s_, o_) for s_, o_ in data]
     eng.upload()
     t_prep = time.perf_counter() - t_prep
     dev = torch.device("cuda", local)
-    mine = parallel.anim_pair_shard(n, rank, world)
+    lens = np.array([len(d[0]) for d in data], dtype=np.int64)
 
-    def compute(pairs):
-        return parallel.anim_records_to_tensor(eng.anim_pairs([ids[q] for q, _ in pairs], [ids[s_] for _, s_ in pairs]), dev)
+    def rows_of(step):
+        return [(step * R + i) % n for i in range(R)]
 
-    grid = None
+    ids_np = np.asarray(ids, dtype=np.int32)
 
-    def step():
-        nonlocal grid
-        grid = parallel.anim_allgather(compute, n, dev) if world > 1 else compute(mine)
+    def compute(pairs):   # pairs: int64 [m, 2] of (reference, query) genome numbers
+        return parallel.anim_records_to_tensor(eng.anim_pairs(ids_np[pairs[:, 0]], ids_np[pairs[:, 1]]), dev)
+
+    tiles = {}
+
+    def step(k, keep=False):
+        rows = rows_of(k)
+        if world > 1:
+            grid = parallel.anim_allgather(compute, n, dev, rows=rows)
+        else:
+            pairs = parallel.anim_pair_array(n, rows)
+            vals = compute(pairs)
+            grid = torch.zeros((len(rows), n, parallel.ANIM_FIELDS), dtype=torch.int64, device=dev)
+            slot = np.repeat(np.arange(len(rows)), n - 1)          # pairs are grouped by row, n - 1 queries each
+            grid[torch.from_numpy(slot).to(dev), torch.from_numpy(pairs[:, 1]).to(dev)] = vals
+        if keep:
+            tiles[k] = (rows, grid)
 
     def fence():
         eng.sync()
@@ -86,50 +259,100 @@ def run_anim(args, rank, world, local, dist, torch):
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    for k in range(args.warmup):
+        step(k)
     fence()
+    stages = [_lib.K_ANIM_SEED, _lib.K_ANIM_HIT, _lib.K_ANIM_CLUSTER, _lib.K_ANIM_GAPS, _lib.K_ANIM_EXTLANE, _lib.K_ANIM_EXTEND,
+              _lib.K_ANIM_FINISH]
+    eng.profile_reset()
+    eng.profile_config(kernel_mask=sum(1 << s_ for s_ in stages), every_n=1)   # ms-scale launches: an event pair costs nothing here
+    eng.profile_enable(True)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    for k in range(args.warmup, args.warmup + args.steps):
+        step(k, keep=True)
     fence()
     elapsed = time.perf_counter() - t0
+    eng.profile_enable(False)
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    prof = {eng.kernel_name(s_): eng.profile_get(s_) for s_ in stages}
+
     if rank == 0:
-        pairs = n * (n - 1)
-        g = grid.cpu().numpy().reshape(-1, parallel.ANIM_FIELDS)
-        status = g[:, 5] if world == 1 else g[np.arange(n * n) % (n + 1) != 0, 5]
+        done_rows = [q for k in tiles for q in tiles[k][0]]
+        pairs_done = len(done_rows) * (n - 1)
+        g = torch.cat([tiles[k][1] for k in sorted(tiles)]).cpu().numpy()           # [rows, n, FIELDS]
+        rowv = np.array(done_rows)
+        offdiag = rowv[:, None] != np.arange(n)[None, :]
+        related_m = ((rowv[:, None] % K) == (np.arange(n)[None, :] % K)) & offdiag
+        status = g[:, :, 5]
+        ident = g[:, :, 4].view(np.float64)
+        n_related = int(related_m.sum())
+        ok_rel = int(((status == 0) & related_m).sum())
+        unrel_aln = int(((status == 0) & ~related_m & offdiag).sum())
         step_s = elapsed / args.steps
-        lens = [len(d[0]) for d in data]
-        alg_bytes = sum((lens[q] + 3) // 4 + (lens[s_] + 3) // 4 + 32 for q in range(n) for s_ in range(n) if q != s_)
+        alg_bytes = float(sum(((lens[q] + 3) // 4 + (lens + 3) // 4 + 32).sum() - ((lens[q] + 3) // 4 * 2 + 32) for q in done_rows))
+        # the dominant kernel of THIS run, timed live with HIP events on the engine's stream (rank 0's launches)
+        dom = max(prof, key=lambda name: prof[name][0])
+        dom_ms, dom_n = prof[dom]
+        share = 1.0 / world                 # rank 0 ran 1/world of the rows
+        achieved = alg_bytes * share / (dom_ms * 1e-3) / 1e9 if dom_ms else 0.0
+        traffic = None
+        pmc = ROOT / "profiles" / "pmc_anim.json"
+        if pmc.exists():
+            traffic = json.loads(pmc.read_text()).get(dom, {}).get("hbm_bytes_per_launch")
+        full_pass = sorted(done_rows) == list(range(n))
+        sha = hashlib.sha1(g[np.argsort(rowv, kind="stable")].tobytes()).hexdigest() if full_pass else None
         out = {
-            "metric": "genome-pairs/sec (ordered pairs) for the ANIm N x N grid: nucmer --mum + delta-filter -1 + parse_delta "
-                      "equivalent, genomes resident in HBM",
-            "value": pairs / step_s, "unit": "genome-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "metric": "genome-pairs/sec (ordered pairs) + wall-clock for the N x N ANIm grid: nucmer --mum + delta-filter -1 + "
+                      "parse_delta equivalent per ordered pair, genomes resident in HBM; vs the CPU path on this box's host cores",
+            "value": pairs_done / elapsed, "unit": "genome-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": step_s * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "int32 DP keys (score << 15 | errors), f64 identity", "data": "synthetic",
+            "dtype": "int32 DP keys (score << 15 | errors), i64 lengths, f64 identity", "data": "synthetic",
+            "related_pairs_per_s": n_related / elapsed,
             "config": {
-                "workload": f"C3: ANIm on {n} synthetic ~{args.length / 1e6:g} Mb genomes (SURVEY.md §8(d) generator, seed "
-                            f"{args.seed}), all {pairs} ordered pairs",
-                "genomes": n, "pairs": pairs, "pairs_with_alignment": int((status == 0).sum()),
-                "parallelism": "1 process/GPU; genomes replicated; pair grid dealt by reference row; one RCCL all-gather"
-                               if world > 1 else "1 GPU",
-                "wall_s_grid": step_s, "host_prep_s": t_prep,
+                "workload": f"C4: ANIm N x N grid on {n} synthetic ~{args.length / 1e6:g} Mb genomes (SURVEY.md §8(d) generator, seed "
+                            f"{args.seed}; {n * (n - 1)} ordered pairs, {n * (n // K - 1)} of them between descendants of one ancestor); "
+                            f"a step = {R} reference genomes x all {n - 1} queries = {R * (n - 1)} ordered pairs, "
+                            f"{n // R if n % R == 0 else n / R:g} steps = the whole grid",
+                "genomes": n, "rows_per_step": R, "pairs_per_step": R * (n - 1), "pairs_timed": pairs_done,
+                "related_pairs_timed": n_related, "related_pairs_with_alignment": ok_rel, "unrelated_pairs_with_alignment": unrel_aln,
+                "grid_pairs": n * (n - 1), "wall_s_grid": elapsed / pairs_done * n * (n - 1),
+                "identity_related_min_med_max": [float(x) for x in np.percentile(ident[(status == 0) & related_m], [0, 50, 100])]
+                if ok_rel else None,
+                "results_sha1_full_grid": sha,
+                "parallelism": f"1 process/GPU x {world}; genomes replicated; each step's rows dealt over the ranks; one RCCL "
+                               f"all-gather per step" if world > 1 else "1 GPU",
+                "host_prep_s": t_prep,
+                "note_related_pairs_per_s": "related pairs timed / the same wall time (unrelated pairs of the tile included): a lower "
+                                            "bound of the related-only rate; 97.6 % of C4's pairs are unrelated by construction",
             },
             "roofline": {
-                "bound": "hbm", "kernel": "whole ANIm pipeline (no single HBM-bound kernel: the extension DP is VALU-issue bound, "
-                                          "the seed stage streams 16 MB of k-mer list per pair; see DESIGN.md §8)",
-                "achieved": alg_bytes / step_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": alg_bytes / step_s / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                "algorithmic_bytes_per_launch": int(alg_bytes),
+                "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "algorithmic_bytes_per_launch": alg_bytes * share / max(dom_n, 1), "avg_launch_ms": dom_ms / max(dom_n, 1),
+                "launches": int(dom_n),
+                "definition": "SURVEY.md §8(d): ceil(Lq/4) + ceil(Ls/4) + 32 B per ordered pair, summed over the pairs rank 0 ran in the "
+                              "timed steps, / the HIP-event time of the stage that took longest (events on the engine's own stream)",
+                "pipeline_achieved": alg_bytes / elapsed / 1e9, "pipeline_frac": alg_bytes / elapsed / 1e9 / HBM_PEAK_GBS,
+                "stage_ms": {name: round(ms, 3) for name, (ms, _) in prof.items()},
+                "stage_launches": {name: int(cnt) for name, (_, cnt) in prof.items()},
+                "stage_sum_ms": round(sum(ms for ms, _ in prof.values()), 3), "timed_region_ms": round(elapsed * 1e3, 3),
             },
-            "cpu_baseline": {"value": None, "unit": "genome-pairs/s", "cores": 0, "kind": "reference",
-                             "sample": "unavailable: nucmer / delta-filter (MUMmer 3.23) are absent from this image and from "
-                                       "the GPU box, and their source is not in the reference tree (SURVEY.md §8c)"},
         }
+        if world == 1 and not args.no_cpu_baseline:
+            def gpu_lookup(q, s_):
+                hit = np.nonzero(rowv == q)[0]
+                if len(hit) == 0:
+                    return None
+                c = g[hit[0], s_]
+                return {"ref_aln_len": c[0], "qry_aln_len": c[1], "sim_errors": c[2], "identity": np.int64(c[4]).view(np.float64), "status": c[5]}
+            related_all = ((np.arange(n)[:, None] % K) == (np.arange(n)[None, :] % K))[~np.eye(n, dtype=bool)]
+            out["cpu_baseline"] = anim_cpu_baseline(args, data, n, related_all, gpu_lookup)
+            out["cpu_baseline"]["speedup_gpu_over_cpu_job"] = out["value"] / out["cpu_baseline"]["value"]
+        if world == 1 and not args.no_tetra:
+            out["tetra"] = tetra_subrecord(eng, local, args.no_cpu_baseline)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
@@ -137,7 +360,10 @@ def run_anim(args, rank, world, local, dist, torch):
     eng.close()
 
 
-def cpu_baseline(eng_z, sample, n_genomes, n_pairs):
+# =====================================================================================================================
+# TETRA (C2)
+# =====================================================================================================================
+def tetra_cpu_baseline(eng_z, sample, n_genomes, n_pairs):
     """Time the pure-Python port of pyani's TETRA (oracle/tetra_port.py — checker code, used here ONLY as the
     reported CPU baseline) on a bounded sample and extrapolate to the whole job: pyani runs TETRA sequentially on
     one core (scripts/average_nucleotide_identity.py:606-608), so the job time is n*t_genome + pairs*t_pair."""
@@ -145,13 +371,11 @@ def cpu_baseline(eng_z, sample, n_genomes, n_pairs):
     import tetra_port
     from pyani_amd.tetra import TETRAMERS
     t_gen, checked = [], 0
-    zs = {}
     for k, (seq, off) in enumerate(sample):
         recs = [bytes(seq[int(off[r]):int(off[r + 1])]).decode("latin-1") for r in range(len(off) - 1)]
         t0 = time.perf_counter()
         z = tetra_port.zscores_from_counts(*tetra_port.count_kmers(recs))
         t_gen.append(time.perf_counter() - t0)
-        zs[f"g{k}"] = z
         # full-size parity check while we are here: the port's Z == the GPU's Z, bit for bit
         gpu = {TETRAMERS[t]: float(eng_z[k, t]) for t in range(256)}
         checked += int(all(gpu[t] == v for t, v in z.items()) and len(z) == 256)
@@ -167,39 +391,14 @@ def cpu_baseline(eng_z, sample, n_genomes, n_pairs):
         "value": n_pairs / total, "unit": "genome-pairs/s", "cores": 1, "kind": "port",
         "sample": f"{len(sample)} of {n_genomes} genomes counted+Z-scored by oracle/tetra_port.py "
                   f"({t_genome:.2f} s/genome), {m * (m - 1) // 2} pairs correlated ({t_pair * 1e3:.3f} ms/pair); "
-                  f"extrapolated linearly to {n_genomes} genomes + {n_pairs} pairs = {total:.0f} s (pyani runs TETRA on 1 core)",
+                  f"extrapolated linearly to {n_genomes} genomes + {n_pairs} pairs = {total:.0f} s (pyani runs TETRA on 1 core; "
+                  f"port vs the imported reference on one 4.02 Mb genome: see BASELINE.md)",
         "job_seconds_extrapolated": total, "gpu_parity_on_sample": f"{checked}/{len(sample)} genomes bit-identical",
     }
 
 
-def main():
-    args = parse_args()
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("launch multi-GPU runs with torch.distributed.run (see module docstring)")
-        args.gpus = world
-    import torch
-    if not torch.cuda.is_available():
-        sys.exit("bench.py needs an MI355X: the engine has no CPU fallback")
-    # debugging aid for 1-GPU boxes: run the N>1 code path with every rank on GPU 0 over gloo (never the default)
-    one_gpu_debug = os.environ.get("PYANI_BENCH_DEBUG_ONE_GPU") == "1"
-    if one_gpu_debug:
-        local = 0
-    torch.cuda.set_device(local)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        if one_gpu_debug:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-
-    if args.workload == "anim":
-        return run_anim(args, rank, world, local, dist, torch)
-    from pyani_amd import _lib, synth
+def run_tetra(args, rank, world, local, dist, torch):
+    from pyani_amd import _lib
     from pyani_amd.engine import Engine
     eng = Engine(local)
     n_local, n_total = args.genomes, args.genomes * world
@@ -207,13 +406,10 @@ def main():
 
     # ---- synthetic inputs -> HBM (outside the timed region) ----------------------------------------------------
     t_prep = time.perf_counter()
-    with ThreadPoolExecutor(max(1, min(16, (os.cpu_count() or 2) // max(1, world)))) as ex:
-        data = list(ex.map(lambda g: synth.genome(args.seed, n_total, g, args.length), range(g0, g0 + n_local)))
-        ids = list(ex.map(lambda d: eng.add_genome(d[0], d[1]), data))
+    data = synth_genomes(args.seed, n_total, args.length, g0, g0 + n_local, world)
+    ids = [eng.add_genome(s_, o_) for s_, o_ in data]
     eng.upload()
-    order = np.argsort(ids)
-    data = [data[k] for k in order]
-    ids_arr = np.ascontiguousarray(sorted(ids), dtype=np.int32)
+    ids_arr = np.ascontiguousarray(ids, dtype=np.int32)
     t_prep = time.perf_counter() - t_prep
     alg_bytes, bases = eng.tetra_algorithmic_bytes(ids_arr.tolist())
 
@@ -262,8 +458,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    prof = {eng.kernel_name(k): eng.profile_get(k) for k in range(4)}
-    count_ms, count_n = prof["tetra_count_kernel"]
+    count_ms, count_n = eng.profile_get(_lib.K_TETRA_COUNT)
     if rank == 0:
         if world == 1:
             eng.tetra_matrix_enqueue(ids_arr, fetch_z=True)   # untimed: also bring Z back for the checks below
@@ -300,13 +495,42 @@ def main():
             },
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(z, data[: args.cpu_genomes], n_total, pairs)
+            out["cpu_baseline"] = tetra_cpu_baseline(z, data[: args.cpu_genomes], n_total, pairs)
             out["cpu_baseline"]["speedup_gpu_over_cpu_job"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     eng.close()
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("launch multi-GPU runs with torch.distributed.run (see module docstring)")
+        args.gpus = world
+    import torch
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X: the engine has no CPU fallback")
+    # debugging aid for 1-GPU boxes: run the N>1 code path with every rank on GPU 0 over gloo (never the default)
+    one_gpu_debug = os.environ.get("PYANI_BENCH_DEBUG_ONE_GPU") == "1"
+    if one_gpu_debug:
+        local = 0
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        if one_gpu_debug:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    if args.workload == "anim":
+        return run_anim(args, rank, world, local, dist, torch)
+    return run_tetra(args, rank, world, local, dist, torch)
 
 
 if __name__ == "__main__":

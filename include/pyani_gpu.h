@@ -179,7 +179,16 @@ int pg_profile_reset(pg_ctx* ctx);
 #define PG_K_TETRA_FINALIZE 1
 #define PG_K_TETRA_STATS 2
 #define PG_K_TETRA_PAIRS 3
-#define PG_K__COUNT 4
+/* ANIm stages (pg_anim_pairs); SEED, CLUSTER, EXTLANE and FINISH bracket exactly one kernel per launch, the others a
+ * short group of kernels that belong together */
+#define PG_K_ANIM_SEED 4     /* anim_seed_kernel: LDS-resident reference groups, streamed query lists */
+#define PG_K_ANIM_HIT 5      /* anim_hoff_kernel + anim_hit_scatter_kernel + anim_hit_kernel + anim_scatter_kernel */
+#define PG_K_ANIM_CLUSTER 6  /* anim_cluster_wave_kernel (one launch; + anim_cluster_prep_kernel when few units) */
+#define PG_K_ANIM_GAPS 7     /* anim_gaps_kernel + anim_gapsort_kernel + the four anim_gapdp_lane_kernel launches */
+#define PG_K_ANIM_EXTLANE 8  /* anim_extdp_lane_kernel */
+#define PG_K_ANIM_EXTEND 9   /* anim_extreq_kernel / anim_extend_kernel / anim_gapreq_kernel / anim_gapdp_kernel */
+#define PG_K_ANIM_FINISH 10  /* anim_finish_kernel */
+#define PG_K__COUNT 11
 /* total milliseconds and number of launches of kernel `which` since the last reset (synchronises). */
 int pg_profile_get(pg_ctx* ctx, int which, double* total_ms_out, uint64_t* launches_out);
 const char* pg_kernel_name(int which);

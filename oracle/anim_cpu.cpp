@@ -1,0 +1,211 @@
+// oracle/anim_cpu.cpp — CPU statement of the ANIm pair search.   TEST / MEASUREMENT INFRASTRUCTURE ONLY.
+//
+// What it is: the scalar functions of pyani_amd/csrc/pg_anim_core.h (MUM filter, mgaps clustering, banded affine extension,
+// 1-to-1 LIS filter, parse_delta reduction — the restatement of what `nucmer --mum` + `delta-filter -1` + pyani's
+// parse_delta (pyani/anim.py:240-289, 292-411; scripts/delta_filter_wrapper.py:70-93) compute, calibrated on the MUMmer
+// output files the reference's tests hold) compiled for the HOST, fed by an exhaustive sorted 20-mer table instead of the
+// GPU's sampled LDS seeding, one ordered pair per thread.  MUMmer itself is third-party and absent from /root/reference and
+// from this image, so this is the only same-box CPU comparison there is: bench.py's `cpu_baseline` leg times it on all
+// host cores ("own-cpu") and tests use it as the scalar statement the GPU pipeline must equal.
+// Nothing under pyani_amd/ loads this library.
+//   g++ -O2 -std=c++17 -pthread -fPIC -shared -Ipyani_amd/csrc oracle/anim_cpu.cpp -o oracle/libanimcpu.so
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cstdint>
+#include <cstring>
+#include <thread>
+#include <vector>
+#include "pg_anim_core.h"
+using namespace pga;
+
+namespace {
+struct Genome {
+  std::vector<uint32_t> codes, mask;
+  std::vector<int32_t> rec_start;  // stream position of each record's first base; last entry = stream length + 1
+  int64_t len = 0;
+  SeqView view() const { return SeqView{codes.data(), mask.data(), len}; }
+};
+
+// records back to back with ONE dirty separator between them (the layout of pg_add_genome)
+Genome pack(const uint8_t* seq, const uint64_t* rec_off, uint32_t n_rec) {
+  Genome g;
+  int64_t len = 0;
+  for (uint32_t r = 0; r < n_rec; ++r) len += (int64_t)(rec_off[r + 1] - rec_off[r]) + (r ? 1 : 0);
+  g.len = len;
+  g.codes.assign(len / 16 + 2, 0);
+  g.mask.assign(len / 32 + 2, 0);
+  int64_t p = 0;
+  for (uint32_t r = 0; r < n_rec; ++r) {
+    if (r) ++p;
+    g.rec_start.push_back((int32_t)p);
+    for (uint64_t i = rec_off[r]; i < rec_off[r + 1]; ++i, ++p) {
+      int c = -1;
+      switch (seq[i]) { case 'A': case 'a': c = 0; break; case 'C': case 'c': c = 1; break; case 'G': case 'g': c = 2; break; case 'T': case 't': c = 3; break; }
+      if (c >= 0) { g.codes[p >> 4] |= (uint32_t)c << (2 * (p & 15)); g.mask[p >> 5] |= 1u << (p & 31); }
+    }
+  }
+  g.rec_start.push_back((int32_t)g.len + 1);
+  return g;
+}
+
+typedef std::vector<std::pair<uint64_t, int32_t>> KmerTable;
+
+void build_table(const Genome& G, KmerTable& tab) {
+  const SeqView R = G.view();
+  const int K = MIN_MATCH;
+  tab.clear();
+  tab.reserve((size_t)R.len);
+  uint64_t v = 0;
+  int run = 0;
+  const uint64_t keep = (K == 32) ? ~0ull : ((1ull << (2 * K)) - 1);
+  for (int64_t p = 0; p < R.len; ++p) {
+    if (!R.clean(p)) { run = 0; v = 0; continue; }
+    v = ((v << 2) | (uint64_t)R.base(p)) & keep;
+    if (++run >= K) tab.push_back({v, (int32_t)(p - K + 1)});
+  }
+  std::sort(tab.begin(), tab.end());
+}
+
+// all maximal exact matches >= MIN_MATCH between the reference and one query strand
+template <typename QV>
+void find_mems(const Genome& G, const KmerTable& tab, const QV& Q, int strand, std::vector<Match>& out) {
+  const SeqView R = G.view();
+  const int K = MIN_MATCH;
+  const uint64_t keep = (K == 32) ? ~0ull : ((1ull << (2 * K)) - 1);
+  uint64_t v = 0;
+  int run = 0;
+  for (int64_t e = 0; e < Q.len(); ++e) {
+    if (!Q.clean(e)) { run = 0; v = 0; continue; }
+    v = ((v << 2) | (uint64_t)Q.base(e)) & keep;
+    if (++run < K) continue;
+    const int64_t q = e - K + 1;
+    auto it = std::lower_bound(tab.begin(), tab.end(), std::make_pair(v, (int32_t)-1));
+    for (; it != tab.end() && it->first == v; ++it) {
+      const int64_t r = it->second;
+      if (R.clean(r - 1) && Q.clean(q - 1) && R.base(r - 1) == Q.base(q - 1)) continue;  // not left-maximal
+      int32_t L = K;
+      while (R.clean(r + L) && Q.clean(q + L) && R.base(r + L) == Q.base(q + L)) ++L;
+      out.push_back(Match{(int32_t)r, (int32_t)q, L, strand});
+    }
+  }
+}
+
+struct Result {   // = pg_anim_result (include/pyani_gpu.h)
+  int64_t ref_aln_len, qry_aln_len, sim_errors, n_alignments;
+  double identity;
+  int32_t status;
+  int32_t reserved;
+};
+
+Result run_pair(const Genome& G, const Genome& H, int filter_1to1, int maxmatch) {
+  const SeqView R = G.view();
+  std::vector<Aln> alns;
+  std::vector<int32_t> a_rrec, a_qrec;
+  KmerTable tab;
+  build_table(G, tab);
+  for (int strand = 0; strand < 2; ++strand) {
+    StrandView Q{H.view(), strand};
+    std::vector<Match> mem;
+    find_mems(G, tab, Q, strand, mem);
+    int n = (int)mem.size();
+    if (!maxmatch) n = mum_filter(mem.data(), n, strand);
+    else std::sort(mem.begin(), mem.end(), [](const Match& a, const Match& b) { return a.q != b.q ? a.q < b.q : (a.len != b.len ? a.len < b.len : a.r < b.r); });
+    mem.resize(n);
+    std::vector<int32_t> rrec(n), qrec(n), parent(n), score(n), from(n), adj(n), order(n);
+    const int nq = (int)H.rec_start.size() - 1;
+    for (int i = 0; i < n; ++i) {
+      rrec[i] = record_of(G.rec_start.data(), (int)G.rec_start.size() - 1, mem[i].r);
+      const int32_t qf = strand ? (int32_t)(H.len - 1 - mem[i].q) : mem[i].q;
+      qrec[i] = record_of(H.rec_start.data(), nq, qf);
+    }
+    std::vector<Chain> chains(n + 1);
+    std::vector<Match> cm(n + 1);
+    int n_chains = 0, n_cm = 0;
+    mgaps_strand(mem.data(), n, strand, rrec.data(), qrec.data(), parent.data(), score.data(), from.data(), adj.data(),
+                 order.data(), chains.data(), n_chains, (int)chains.size(), cm.data(), n_cm, (int)cm.size());
+    std::vector<int32_t> co(n_chains);
+    for (int i = 0; i < n_chains; ++i) co[i] = i;
+    std::sort(co.begin(), co.end(), [&](int a, int b) { return cm[chains[a].first].r < cm[chains[b].first].r; });
+    std::vector<ChainFwd> fw(n_chains);
+    std::vector<ChainBwd> bw(n_chains);
+    std::vector<int32_t> prev_of(n_chains, -1), next_of(n_chains, -1), r_lo(n_chains), r_hi(n_chains), q_lo(n_chains), q_hi(n_chains);
+    chain_neighbours(chains.data(), co.data(), n_chains, prev_of.data(), next_of.data());
+    for (int c = 0; c < n_chains; ++c) {
+      r_lo[c] = G.rec_start[chains[c].rrec]; r_hi[c] = G.rec_start[chains[c].rrec + 1] - 1;
+      q_lo[c] = H.rec_start[chains[c].qrec]; q_hi[c] = H.rec_start[chains[c].qrec + 1] - 1;
+      if (strand) { const int32_t a = (int32_t)H.len - q_hi[c], b = (int32_t)H.len - q_lo[c]; q_lo[c] = a; q_hi[c] = b; }
+      fw[c] = extend_chain_fwd(R, Q, cm.data(), chains.data(), next_of.data(), c, r_hi[c], q_hi[c]);
+    }
+    for (int k = 0; k < n_chains; ++k) {
+      const int c = co[k];
+      const int p = prev_of[c];
+      bw[c] = extend_chain_bwd(R, Q, fw[c].first_r, fw[c].first_q, r_lo[c], q_lo[c], p >= 0 ? fw[p].re : -1, p >= 0 ? fw[p].qe : -1,
+                               p >= 0 ? fw[p].lr : -1, p >= 0 ? fw[p].lq : -1, p >= 0 ? fw[p].first_r : -1, p >= 0 ? fw[p].first_q : -1,
+                               fw[c].lr, fw[c].lq, p >= 0 && fw[p].reached && fw[p].target == c, p >= 0 ? fw[p].err_fwd : 0);
+    }
+    std::vector<int32_t> aln_of(n_chains + 1);
+    const int before = (int)alns.size();
+    alns.resize(before + n_chains);
+    const int after = stitch_chains(fw.data(), bw.data(), cm.data(), chains.data(), co.data(), prev_of.data(), next_of.data(), n_chains,
+                                    strand, aln_of.data(), alns.data(), before, (int)alns.size());
+    alns.resize(after);
+    for (int i = before; i < after; ++i) {
+      Aln& a = alns[i];
+      a_rrec.push_back(record_of(G.rec_start.data(), (int)G.rec_start.size() - 1, a.rs));
+      if (strand) { const int32_t qs = (int32_t)H.len - a.qe, qe = (int32_t)H.len - a.qs; a.qs = qs; a.qe = qe; }  // forward coords
+      a_qrec.push_back(record_of(H.rec_start.data(), nq, a.qs));
+    }
+  }
+  const int n = (int)alns.size();
+  std::vector<int32_t> idx(n + 1), from(n + 1);
+  std::vector<double> sc(n + 1);
+  if (!filter_1to1) for (auto& a : alns) a.keep = 3;
+  else {
+    lis_filter(alns.data(), n, 0, a_rrec.data(), idx.data(), sc.data(), from.data());
+    lis_filter(alns.data(), n, 1, a_qrec.data(), idx.data(), sc.data(), from.data());
+  }
+  const PairResult pr = reduce_pair(alns.data(), n, a_rrec.data(), a_qrec.data(), idx.data());
+  Result out{};
+  out.ref_aln_len = pr.ref_aln_len; out.qry_aln_len = pr.qry_aln_len; out.sim_errors = pr.sim_errors;
+  out.n_alignments = pr.n_alignments;
+  out.identity = pr.aligned ? (double)pr.weighted / (double)pr.aligned : 0.0;
+  out.status = pr.n_alignments ? 0 : 1;
+  out.reserved = n;
+  return out;
+}
+}  // namespace
+
+extern "C" {
+// seqs[g] / rec_offs[g] / n_recs[g]: genome g as pg_add_genome takes it.  One ordered pair per thread (threads = 0: all
+// hardware threads); seconds_out[i] = the CPU seconds pair i took (table build included — one process per pair is how
+// pyani's runner does it, run_multiprocessing.py:130-144).  Returns 0.
+int anim_cpu_pairs(const uint8_t* const* seqs, const uint64_t* const* rec_offs, const uint32_t* n_recs, uint32_t n_genomes,
+                   const int32_t* ref_ids, const int32_t* qry_ids, uint32_t n_pairs, int maxmatch, int filter_1to1, int threads,
+                   Result* out, double* seconds_out) {
+  std::vector<Genome> G(n_genomes);
+  std::vector<char> used(n_genomes, 0);
+  for (uint32_t i = 0; i < n_pairs; ++i) { used[ref_ids[i]] = 1; used[qry_ids[i]] = 1; }
+  unsigned nt = threads > 0 ? (unsigned)threads : std::thread::hardware_concurrency();
+  if (nt == 0) nt = 1;
+  {
+    std::atomic<uint32_t> next{0};
+    std::vector<std::thread> pool;
+    for (unsigned t = 0; t < nt; ++t)
+      pool.emplace_back([&]() { for (uint32_t g; (g = next++) < n_genomes;) if (used[g]) G[g] = pack(seqs[g], rec_offs[g], n_recs[g]); });
+    for (auto& th : pool) th.join();
+  }
+  std::atomic<uint32_t> next{0};
+  std::vector<std::thread> pool;
+  for (unsigned t = 0; t < nt && t < n_pairs; ++t)
+    pool.emplace_back([&]() {
+      for (uint32_t i; (i = next++) < n_pairs;) {
+        const auto t0 = std::chrono::steady_clock::now();
+        out[i] = run_pair(G[ref_ids[i]], G[qry_ids[i]], filter_1to1, maxmatch);
+        if (seconds_out) seconds_out[i] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      }
+    });
+  for (auto& th : pool) th.join();
+  return 0;
+}
+}

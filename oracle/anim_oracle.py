@@ -113,7 +113,8 @@ def anim_matrices(results: Dict[Tuple[str, str], Tuple[int, int, float, int]], o
     cov = {a: {b: 1.0 for b in names} for a in names}
     for org, length in org_lengths.items():
         lengths[org][org] = float(length)
-    for (q, s) in sorted(results, key=lambda k: f"{k[0]}/{k[0]}_vs_{k[1]}.filter"):
+    # sorted(Path) order (anim.py:438): Paths compare component by component, i.e. (directory, file name)
+    for (q, s) in sorted(results, key=lambda k: (k[0], f"{k[0]}_vs_{k[1]}.filter")):
         raln, qaln, ident, err = results[(q, s)]
         qcov, scov = float(raln) / org_lengths[q], float(qaln) / org_lengths[s]
         lengths[q][s] = float(raln)

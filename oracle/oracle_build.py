@@ -1,0 +1,45 @@
+"""Build the CPU checkers under oracle/ (test / measurement infrastructure — never loaded by pyani_amd/).
+
+  liboracle.so    oracle/tetra_oracle.c   gcc -ffp-contract=off     TETRA restatement (tetra.py:78-194)
+  libanimcpu.so   oracle/anim_cpu.cpp     g++ -pthread              host statement of the ANIm pair search (own-cpu baseline)
+"""
+import subprocess
+import sys
+from pathlib import Path
+
+HERE = Path(__file__).resolve().parent
+ROOT = HERE.parent
+ORACLE_LIB = HERE / "liboracle.so"
+ANIM_CPU_LIB = HERE / "libanimcpu.so"
+
+
+def _newer(target: Path, sources) -> bool:
+    return target.exists() and all(Path(s).stat().st_mtime <= target.stat().st_mtime for s in sources)
+
+
+def _run(cmd):
+    print("+", " ".join(str(c) for c in cmd), file=sys.stderr, flush=True)
+    subprocess.run([str(c) for c in cmd], check=True)
+
+
+def build_oracle(force=False) -> Path:
+    srcs = sorted(HERE.glob("*.c"))
+    if force or not _newer(ORACLE_LIB, srcs):
+        _run(["gcc", "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-Wall", "-o", ORACLE_LIB, *srcs, "-lm"])
+    return ORACLE_LIB
+
+
+def build_anim_cpu(force=False) -> Path:
+    core = ROOT / "pyani_amd" / "csrc" / "pg_anim_core.h"
+    src = HERE / "anim_cpu.cpp"
+    if force or not _newer(ANIM_CPU_LIB, [src, core]):
+        _run(["g++", "-O2", "-std=c++17", "-pthread", "-fPIC", "-shared", f"-I{core.parent}", "-o", ANIM_CPU_LIB, src])
+    return ANIM_CPU_LIB
+
+
+def build_all(force=False):
+    return build_oracle(force), build_anim_cpu(force)
+
+
+if __name__ == "__main__":
+    build_all(force="--force" in sys.argv)

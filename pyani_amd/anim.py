@@ -22,7 +22,7 @@ import gzip
 import logging
 import sys
 from pathlib import Path
-from typing import Dict, Iterable, List, Tuple
+from typing import Dict, Iterable, List, Optional, Tuple
 
 import numpy as np
 import pandas as pd
@@ -95,15 +95,20 @@ def calculate_anim_pairs(infiles: Iterable, engine: Engine = None, nofilter: boo
     genome lengths keyed by stem)."""
     eng = engine or default_engine()
     files = sorted(Path(f) for f in infiles)
+    stems = [f.stem for f in files]
+    if len(set(stems)) != len(stems):
+        raise ValueError("two input files share a stem (pyani keys every result by Path.stem): "
+                         + ", ".join(sorted({s for s in stems if stems.count(s) > 1})))
     scratch_store = eng.genome_count() == 0
     ids, lengths = {}, {}
-    for f, (gid, total, _) in zip(files, eng.add_fasta_batch(files)):
-        ids[f.stem], lengths[f.stem] = gid, total
-    stems = [f.stem for f in files]
-    pairs = [(a, b) for a in stems for b in stems if a != b]
-    recs = eng.anim_pairs([ids[a] for a, _ in pairs], [ids[b] for _, b in pairs], filter_1to1=not nofilter, maxmatch=maxmatch)
-    if scratch_store:
-        eng.clear_genomes()
+    try:
+        for f, (gid, total, _) in zip(files, eng.add_fasta_batch(files)):
+            ids[f.stem], lengths[f.stem] = gid, total
+        pairs = [(a, b) for a in stems for b in stems if a != b]
+        recs = eng.anim_pairs([ids[a] for a, _ in pairs], [ids[b] for _, b in pairs], filter_1to1=not nofilter, maxmatch=maxmatch)
+    finally:
+        if scratch_store:       # also on errors: a failed call must not leave its genomes in the shared engine
+            eng.clear_genomes()
     out = {}
     for (a, b), rec in zip(pairs, recs):
         try:
@@ -178,81 +183,107 @@ def parse_delta(filename, engine: Engine = None) -> Tuple[int, int, float, int]:
 
 
 def process_deltadir(delta_dir, org_lengths: Dict[str, int], logger=None, engine: Engine = None) -> ANIResults:
-    """pyani.anim.process_deltadir (anim.py:415-497): ANIResults from the `<delta_dir>/*/*.filter` files of an earlier
-    (MUMmer or write_delta) run — same file order, same skipping of files whose organisms are not in `org_lengths`, same
-    overwrite order of the mirrored cells, PyaniANImException when the directory holds no .filter file, ZeroDivisionError
-    from an empty one.  The files are parsed on the host and reduced in ONE GPU call instead of one parse_delta each."""
-    logger = logger or logging.getLogger(__name__)
-    delta_dir = Path(delta_dir)
-    deltafiles = sorted(delta_dir.glob("*/*.filter"))
-    logger.info("%s has %d files to load", delta_dir, len(deltafiles))
-    if not deltafiles:
-        logger.error("%s empty? No filter files found", delta_dir)
+    """pyani.anim.process_deltadir (anim.py:415-497) for the `<delta_dir>/*/*.filter` files of an earlier (MUMmer or
+    write_delta) run: glob -> read_delta -> ONE batched GPU reduction -> assemble_legacy_results.  Behaviour kept: files
+    in sorted path order (it decides which file's value a mirrored cell ends up with), files naming an organism that is
+    not in `org_lengths` are skipped with a warning, PyaniANImException when there is no .filter file at all,
+    ZeroDivisionError from a file without alignments, exit on a zero subject length."""
+    log = logger or logging.getLogger(__name__)
+    files = sorted(Path(delta_dir).glob("*/*.filter"))
+    log.info("%s: %d .filter files", delta_dir, len(files))
+    if not files:
         raise PyaniANImException(f"{delta_dir} contains no filter files.")
-    todo = []
-    for deltafile in deltafiles:
-        qname, sname = deltafile.stem.split("_vs_")
-        if qname not in org_lengths:
-            logger.warning("Query name %s not in input sequence list, skipping %s", qname, deltafile)
-            continue
-        if sname not in org_lengths:
-            logger.warning("Subject name %s not in input sequence list, skipping %s", sname, deltafile)
-            continue
-        todo.append((qname, sname, deltafile))
-    results = ANIResults(list(org_lengths.keys()), "ANIm")
-    for org, length in org_lengths.items():
-        results.alignment_lengths.loc[org, org] = length
-    if not todo:
-        return results
-    eng = engine or default_engine()
-    recs = eng.anim_reduce([read_delta(f) for _, _, f in todo], apply_filter=False)
-    for (qname, sname, deltafile), rec in zip(todo, recs):
-        query_tot_length, subject_tot_length, weighted_identity, tot_sim_error = _tuple(rec)
-        if subject_tot_length == 0:
-            logger.warning("Total alignment length reported in %s is zero!", deltafile)
-            sys.exit("Zero length alignment!")
-        results.add_tot_length(qname, sname, query_tot_length, subject_tot_length)
-        results.add_sim_errors(qname, sname, tot_sim_error)
-        results.add_pid(qname, sname, weighted_identity)
-        results.add_coverage(qname, sname, float(query_tot_length) / org_lengths[qname],
-                             float(subject_tot_length) / org_lengths[sname])
-    return results
+    keep = []
+    for f in files:
+        q, s = f.stem.split("_vs_")
+        missing = [name for name in (q, s) if name not in org_lengths]
+        if missing:
+            log.warning("%s: %s not among the input sequences, file skipped", f, " / ".join(missing))
+        else:
+            keep.append((q, s, f))
+    pair_results = {}
+    if keep:
+        eng = engine or default_engine()
+        for (q, s, f), rec in zip(keep, eng.anim_reduce([read_delta(f) for _, _, f in keep], apply_filter=False)):
+            pair_results[(q, s)] = _tuple(rec)
+            if pair_results[(q, s)][1] == 0:
+                log.warning("%s reports a total alignment length of zero", f)
+                sys.exit("Zero length alignment!")
+    return assemble_legacy_results(pair_results, org_lengths, order=[(q, s) for q, s, _ in keep])
 
 
-def assemble_legacy_results(pair_results: Dict[Tuple[str, str], Tuple[int, int, float, int]], org_lengths: Dict[str, int]
-                            ) -> ANIResults:
-    """process_deltadir's assembly (anim.py:438-497): files visited in sorted `<q>/<q>_vs_<s>.filter` order, mirrored
-    cells overwritten by later files, identity per direction, diagonal of the length matrix = genome length."""
-    results = ANIResults(list(org_lengths.keys()), "ANIm")
-    for org, length in org_lengths.items():
-        results.alignment_lengths.loc[org, org] = length
-    for (q, s) in sorted(pair_results, key=lambda k: f"{k[0]}/{k[0]}_vs_{k[1]}.filter"):
-        if q not in org_lengths or s not in org_lengths:
-            continue
-        qtot, stot, ident, err = pair_results[(q, s)]
-        results.add_tot_length(q, s, qtot, stot)
-        results.add_sim_errors(q, s, err)
-        results.add_pid(q, s, ident)
-        results.add_coverage(q, s, float(qtot) / org_lengths[q], float(stot) / org_lengths[s])
-    return results
+def _last_writer_wins(out: np.ndarray, cells: np.ndarray, ranks: np.ndarray, values: np.ndarray) -> None:
+    """out.flat[cell] = the value of the write with the highest rank among those addressed to that cell."""
+    if len(cells) == 0:
+        return
+    by = np.lexsort((ranks, cells))
+    c = cells[by]
+    last = np.r_[c[1:] != c[:-1], True]
+    out.flat[c[last]] = values[by][last]
 
 
-def assemble_run_matrices(pair_results: Dict[Tuple[str, str], Tuple[int, int, float, int]], lengths: Dict[str, int]
-                          ) -> Dict[str, pd.DataFrame]:
-    """v0.3 semantics of update_comparison_matrices (pyani_orm.py:618-666): [q, s] cells only, diagonals 1 / 1 /
-    length / 0 / 1, hadamard = identity * cov_query.  Vectorised: the reference fills the five
-    matrices with one pandas scalar write per cell, which at N = 1000 takes longer than the GPU needs for the pairs."""
-    labels = sorted(lengths)
+def assemble_legacy_results(pair_results: Dict[Tuple[str, str], Tuple[int, int, float, int]], org_lengths: Dict[str, int],
+                            order: Optional[List[Tuple[str, str]]] = None) -> ANIResults:
+    """The matrices process_deltadir builds (anim.py:438-497, through ANIResults.add_*, pyani_tools.py:108-167), from the
+    per-pair tuples.  Every file (q, s) writes its own cell [q, s] of all four matrices AND the mirrored cell [s, q] of
+    the length, error and coverage matrices (length / coverage only when non-zero), so a cell ends up with whatever the
+    LAST file that touched it wrote: `order` is that file order (default: sorted `<q>/<q>_vs_<s>.filter` paths, which
+    compare component by component).  Identity is written per direction only; the length diagonal is the genome length.
+    Vectorised: each matrix is resolved with one last-writer-wins scatter instead of 7 pandas scalar writes per file."""
+    labels = list(org_lengths)
     n = len(labels)
-    idx = {g: k for k, g in enumerate(labels)}
-    length = np.array([lengths[g] for g in labels], dtype=np.float64)
+    pos = {g: k for k, g in enumerate(labels)}
+    if order is None:
+        order = sorted(pair_results, key=lambda k: (k[0], f"{k[0]}_vs_{k[1]}.filter"))
+    order = [k for k in order if k[0] in pos and k[1] in pos]
+    m = len(order)
+    qi = np.fromiter((pos[q] for q, _ in order), dtype=np.int64, count=m)
+    si = np.fromiter((pos[s] for _, s in order), dtype=np.int64, count=m)
+    vals = np.array([pair_results[k] for k in order], dtype=np.float64).reshape(m, 4)
+    rank = np.arange(m, dtype=np.int64)
+    length = np.array([org_lengths[g] for g in labels], dtype=np.float64)
+    own, mirror = qi * n + si, si * n + qi
+    aln = np.full((n, n), np.nan)
+    np.fill_diagonal(aln, length)
+    err, pid, cov = np.zeros((n, n)), np.ones((n, n)), np.ones((n, n))
+    qcov, scov = vals[:, 0] / length[qi] if m else vals[:, 0], vals[:, 1] / length[si] if m else vals[:, 1]
+    has_s, has_scov = vals[:, 1] != 0, scov != 0          # add_tot_length / add_coverage mirror only truthy values
+    _last_writer_wins(aln, np.r_[own, mirror[has_s]], np.r_[rank, rank[has_s]], np.r_[vals[:, 0], vals[has_s, 1]])
+    _last_writer_wins(err, np.r_[own, mirror], np.r_[rank, rank], np.r_[vals[:, 3], vals[:, 3]])
+    _last_writer_wins(pid, own, rank, vals[:, 2])
+    _last_writer_wins(cov, np.r_[own, mirror[has_scov]], np.r_[rank, rank[has_scov]], np.r_[qcov, scov[has_scov]])
+    results = ANIResults(labels, "ANIm")
+    for name, a in (("alignment_lengths", aln), ("similarity_errors", err), ("percentage_identity", pid), ("alignment_coverage", cov)):
+        setattr(results, name, pd.DataFrame(a, index=labels, columns=labels))
+    return results
+
+
+def assemble_run_matrices(pair_results: Dict[Tuple[str, str], Tuple[int, int, float, int]], lengths: Dict[str, int],
+                          genome_ids: Optional[Dict[str, int]] = None) -> Dict[str, pd.DataFrame]:
+    """update_comparison_matrices (pyani_orm.py:618-666), cell for cell: five float frames that start as NaN, diagonals
+    1 / 1 / genome length / 0 / 1, then ONLY the [query, subject] cell of every comparison that exists: identity,
+    cov_query = aln_length / query length, aln_length, sim_errs, identity * cov_query.  A pair that is absent (no
+    alignment with skip_zero, a partial or recovered run) therefore stays NaN, as in the reference.  Index / columns:
+    the sorted integer genome_ids when `genome_ids` (stem -> id) is given — what the reference stores — else the sorted
+    stems.  Vectorised: the reference does one pandas scalar write per cell, ~10^7 of them at N = 1000."""
+    if genome_ids is not None:
+        order = sorted(lengths, key=lambda g: genome_ids[g])
+        labels = [genome_ids[g] for g in order]
+    else:
+        order = labels = sorted(lengths)
+    n = len(order)
+    idx = {g: k for k, g in enumerate(order)}
+    length = np.array([lengths[g] for g in order], dtype=np.float64)
     m = len(pair_results)
     qi = np.fromiter((idx[q] for q, _ in pair_results), dtype=np.int64, count=m)
     si = np.fromiter((idx[s] for _, s in pair_results), dtype=np.int64, count=m)
     vals = np.array(list(pair_results.values()), dtype=np.float64).reshape(m, 4)   # (qaln, saln, identity, errors); ints < 2^53
-    ident, cov, had = np.eye(n), np.eye(n), np.eye(n)
-    aln, sim = np.zeros((n, n)), np.zeros((n, n))
+    ident, cov, aln, sim, had = (np.full((n, n), np.nan) for _ in range(5))
+    np.fill_diagonal(ident, 1.0)
+    np.fill_diagonal(cov, 1.0)
     np.fill_diagonal(aln, length)
+    np.fill_diagonal(sim, 0.0)
+    np.fill_diagonal(had, 1.0)
     cq = vals[:, 0] / length[qi]
     ident[qi, si] = vals[:, 2]
     cov[qi, si] = cq
@@ -265,3 +296,24 @@ def assemble_run_matrices(pair_results: Dict[Tuple[str, str], Tuple[int, int, fl
 
     return {"identity": frame(ident), "coverage": frame(cov), "aln_lengths": frame(aln), "sim_errors": frame(sim),
             "hadamard": frame(had)}
+
+
+def run_matrices_to_json(mats: Dict[str, pd.DataFrame]) -> Dict[str, str]:
+    """The five strings update_comparison_matrices stores in the Run row (pyani_orm.py:661-665): DataFrame.to_json()."""
+    return {"df_identity": mats["identity"].to_json(), "df_coverage": mats["coverage"].to_json(),
+            "df_alnlength": mats["aln_lengths"].to_json(), "df_simerrors": mats["sim_errors"].to_json(),
+            "df_hadamard": mats["hadamard"].to_json()}
+
+
+def comparison_rows(pair_results: Dict[Tuple[str, str], Tuple[int, int, float, int]], lengths: Dict[str, int],
+                    genome_ids: Dict[str, int], maxmatch: bool = False, program: str = PROGRAM, version: str = VERSION
+                    ) -> List[dict]:
+    """One dict per comparison with the columns of the reference's Comparison table (pyani_orm.py:262-322) as
+    update_comparison_results fills them for ANIm (subcmd_anim.py:434-456): aln_length = the QUERY's aligned length,
+    cov_query / cov_subject = aligned length / genome length, fragsize / kmersize / minmatch NULL."""
+    rows = []
+    for (q, s), (qaln, saln, ident, errs) in pair_results.items():
+        rows.append({"query_id": genome_ids[q], "subject_id": genome_ids[s], "aln_length": qaln, "sim_errs": errs,
+                     "identity": ident, "cov_query": qaln / lengths[q], "cov_subject": saln / lengths[s], "program": program,
+                     "version": version, "fragsize": None, "maxmatch": maxmatch, "kmersize": None, "minmatch": None})
+    return rows

@@ -2,9 +2,9 @@
 
   libpyani_gpu.so   pyani_amd/csrc/*.hip + *.cpp   hipcc --offload-arch=gfx950   (the product)
   libpgsynth.so     pyani_amd/csrc/synth.cpp       g++                            (synthetic test/bench data)
-  liboracle.so      oracle/*.c                     gcc -ffp-contract=off          (parity checker, tests only)
 
-hipcc cross-compiles gfx950 without a GPU, so all three build in the CPU-only container.
+hipcc cross-compiles gfx950 without a GPU, so both build in the CPU-only container.  (The CPU checkers under oracle/ have
+their own recipe, oracle/oracle_build.py: nothing in this package builds, loads or calls them.)
 """
 import os
 import shutil
@@ -16,7 +16,6 @@ ROOT = Path(__file__).resolve().parent.parent
 CSRC = ROOT / "pyani_amd" / "csrc"
 GPU_LIB = ROOT / "pyani_amd" / "libpyani_gpu.so"
 SYNTH_LIB = ROOT / "pyani_amd" / "libpgsynth.so"
-ORACLE_LIB = ROOT / "oracle" / "liboracle.so"
 
 
 def _newer(target: Path, sources) -> bool:
@@ -56,16 +55,8 @@ def build_synth(force=False):
     return SYNTH_LIB
 
 
-def build_oracle(force=False):
-    srcs = sorted((ROOT / "oracle").glob("*.c"))
-    if not force and _newer(ORACLE_LIB, srcs):
-        return ORACLE_LIB
-    _run(["gcc", "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-Wall", "-o", ORACLE_LIB, *srcs, "-lm"])
-    return ORACLE_LIB
-
-
 def build_all(force=False):
-    return build_gpu(force), build_synth(force), build_oracle(force)
+    return build_gpu(force), build_synth(force)
 
 
 if __name__ == "__main__":

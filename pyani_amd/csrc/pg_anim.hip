@@ -126,6 +126,7 @@ struct AnimScratch {
   Match* hits_sorted = nullptr;     // the same, dealt into per-unit slices (hoff)
   uint32_t *hit_count = nullptr, *hoff = nullptr, *hit_cursor = nullptr;   // per unit
   size_t hit_cap = 0;
+  bool lds_attr_set = false;        // anim_seed_kernel's dynamic-LDS limit has been raised on this context's device
 };
 
 template <typename T>
@@ -317,11 +318,10 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
   }
   const uint32_t slice_stride = n_pairs;   // the table is laid out for the whole batch even if only a prefix is seeded again
   hipLaunchKernelGGL(anim_slice_kernel, dim3(n_pairs), dim3(256), 0, ctx->stream, A->sqry_d, n_pairs, A->slice_d);
-  static bool lds_attr_set = false;
-  if (!lds_attr_set) {
+  if (!A->lds_attr_set) {   // per context = per device (the attribute is a property of the function ON a device)
     PG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(anim_seed_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)(SEED_MAX_SLOTS * 8 + SEED_STAGE_BYTES)));
-    lds_attr_set = true;
+    A->lds_attr_set = true;
   }
   if (!A->seedbuf) {
     A->seed_cap = (size_t)max_matches + 1024;   // the whole batch budget (2.4 GB by default): no overflow re-runs
@@ -348,15 +348,20 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
     PG_HIP(ctx, hipMemsetAsync(A->mem_count, 0, n_units * 4, ctx->stream));
     PG_HIP(ctx, hipMemsetAsync(A->seed_total, 0, 8, ctx->stream));   // [0] matches, [1] hits
     PG_HIP(ctx, hipMemsetAsync(A->hit_count, 0, n_units * 4, ctx->stream));
+    pg_prof_begin(ctx, PG_K_ANIM_SEED);
     hipLaunchKernelGGL(anim_seed_kernel, dim3(SEED_GROUPS, n_refs), dim3(SEED_BLOCK), (size_t)slots * 8 + SEED_STAGE_BYTES, ctx->stream,
                        A->refs_d, A->units_d, A->srefs_d, A->sqry_d, A->slice_d, slice_stride, slots - 1, A->hits_d,
                        (uint32_t)A->hit_cap, A->seed_total + 1, A->hit_count);
+    pg_prof_end(ctx);
+    PG_HIP(ctx, hipGetLastError());   // a rejected launch (LDS size) must not surface only at the end of the batch
+    pg_prof_begin(ctx, PG_K_ANIM_HIT);
     // hits -> per-unit slices, then one workgroup per unit verifies / extends them
     hipLaunchKernelGGL(anim_hoff_kernel, dim3(1), dim3(1024), 0, ctx->stream, A->hit_count, n_units, A->hoff, A->hit_cursor);
     hipLaunchKernelGGL(anim_hit_scatter_kernel, dim3((uint32_t)ctx->num_cu * 8u), dim3(256), 0, ctx->stream, A->hits_d, A->seed_total + 1,
                        (uint32_t)A->hit_cap, A->hoff, A->hit_cursor, A->hits_sorted);
     hipLaunchKernelGGL(anim_hit_kernel, dim3(n_units), dim3(256), 0, ctx->stream, A->refs_d, A->units_d, A->hits_sorted, A->hoff,
                        A->seed_total + 1, (uint32_t)A->hit_cap, A->seedbuf, (uint32_t)A->seed_cap, A->seed_total, A->mem_count);
+    pg_prof_end(ctx);
     PG_HIP(ctx, hipMemcpyAsync(cnt.data(), A->mem_count, n_units * 4, hipMemcpyDeviceToHost, ctx->stream));
     PG_HIP(ctx, hipMemcpyAsync(counts, A->seed_total, 8, hipMemcpyDeviceToHost, ctx->stream));
     PG_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -419,9 +424,12 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
   PG_HIP(ctx, hipMemsetAsync(A->mem_count, 0, n_units * 4, ctx->stream));
   PG_HIP(ctx, hipMemsetAsync(A->status, 0, n_pairs * 4, ctx->stream));
   ClusterOut O{A->moff, A->cm, A->chains, A->nch, A->order, A->prev, A->next, A->status};
+  pg_prof_begin(ctx, PG_K_ANIM_HIT);
   if (total)
     hipLaunchKernelGGL(anim_scatter_kernel, dim3((total + 255) / 256), dim3(256), 0, ctx->stream, A->seedbuf, total, A->moff, n_units,
                        A->mem_count, A->mem);
+  pg_prof_end(ctx);
+  pg_prof_begin(ctx, PG_K_ANIM_CLUSTER);
   if (getenv("PYANI_ANIM_SCALAR_CLUSTER") && !maxmatch)   // debugging aid: the one-thread-per-unit statement of the same algorithm
     hipLaunchKernelGGL(anim_cluster_kernel, dim3((n_units + 63) / 64), dim3(64), 0, ctx->stream, A->refs_d, A->units_d, n_units,
                        A->mem, A->mem_count, A->iscratch, O);
@@ -436,6 +444,7 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
     hipLaunchKernelGGL(anim_cluster_wave_kernel, dim3(n_units), dim3(64), 0, ctx->stream, A->refs_d, A->units_d, A->mem,
                        A->mem_count, A->iscratch, O, 1, maxmatch);
   }
+  pg_prof_end(ctx);
   // work list of (unit, chain): one wave each
   std::vector<int32_t> nch(n_units);
   PG_HIP(ctx, hipMemcpyAsync(nch.data(), A->nch, n_units * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -459,6 +468,7 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
     }
     PG_HIP(ctx, hipMemsetAsync(A->gap_counts, 0, (GAP_CLASSES + 1) * 4, ctx->stream));
     PG_HIP(ctx, hipMemsetAsync(A->task_cls, 0xFF, Mp, ctx->stream));
+    pg_prof_begin(ctx, PG_K_ANIM_GAPS);
     hipLaunchKernelGGL(anim_gaps_kernel, dim3((uint32_t)n_wl), dim3(64), 0, ctx->stream, A->refs_d, A->units_d, O, A->wl_d,
                        A->fw, A->tasks_d, A->task_cls);
     hipLaunchKernelGGL(anim_gapsort_kernel, dim3((uint32_t)ctx->num_cu * 8u), dim3(GAPSORT_BLOCK), 0, ctx->stream, A->task_cls,
@@ -472,6 +482,7 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
                        A->task_lists + 2 * Mp, A->gap_counts + 2, A->fw);
     hipLaunchKernelGGL((anim_gapdp_lane_kernel<64, true>), lane_grid, dim3(64), 0, ctx->stream, A->refs_d, A->units_d, O, A->tasks_d,
                        A->task_lists + 3 * Mp, A->gap_counts + 3, A->fw);
+    pg_prof_end(ctx);
     // the larger gaps go through the lanes of the extension DP (anim_gapreq_kernel); their number sizes the buffers
     uint32_t gap_counts[GAP_CLASSES + 1];
     PG_HIP(ctx, hipMemcpyAsync(gap_counts, A->gap_counts, sizeof(gap_counts), hipMemcpyDeviceToHost, ctx->stream));
@@ -493,38 +504,52 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
     }
     if (n_big) {
       PG_HIP(ctx, hipMemsetAsync(A->ext_counts, 0, 20, ctx->stream));   // [0], [1] list lengths, [2] hand-out cursor, [4] handed over
+      pg_prof_begin(ctx, PG_K_ANIM_EXTEND);
       hipLaunchKernelGGL(anim_gapreq_kernel, dim3((uint32_t)((n_big + 255) / 256)), dim3(256), 0, ctx->stream, A->refs_d, A->units_d,
                          A->tasks_d, A->task_lists + GAP_CLASSES * Mp, (uint32_t)n_big, A->ext_pre, A->ext_reqs, A->ext_counts);
+      pg_prof_end(ctx);
+      pg_prof_begin(ctx, PG_K_ANIM_EXTLANE);
       hipLaunchKernelGGL(anim_extdp_lane_kernel, dim3((uint32_t)ctx->num_cu * 4u), dim3(64), 0, ctx->stream, A->ext_reqs, A->ext_reqs,
                          A->ext_counts, A->ext_counts + 2, A->ext_pre, A->ext_dumps, dump_cap, A->ext_counts + 4, tail_lanes, tail_blocks);
+      pg_prof_end(ctx);
+      pg_prof_begin(ctx, PG_K_ANIM_EXTEND);
       hipLaunchKernelGGL(anim_gapdp_kernel, dim3((uint32_t)ctx->num_cu * 32u), dim3(64), 0, ctx->stream, A->refs_d, A->units_d, O,
                          A->tasks_d, A->task_lists + GAP_CLASSES * Mp, (uint32_t)n_big, A->ext_pre, A->ext_dumps, A->fw);
+      pg_prof_end(ctx);
     }
     for (int phase = 0; phase < 2; ++phase) {
       // the first DP calls of every chain: written down, solved one per LANE, then consumed by the wave kernel
       PG_HIP(ctx, hipMemsetAsync(A->ext_counts + 4, 0, 4, ctx->stream));   // [4] searches handed over mid-way
       for (int round = 0; round < EXT_ROUNDS; ++round) {
         PG_HIP(ctx, hipMemsetAsync(A->ext_counts, 0, 16, ctx->stream));   // [0], [1] list lengths, [2] hand-out cursor
+        pg_prof_begin(ctx, PG_K_ANIM_EXTEND);
         hipLaunchKernelGGL(anim_extreq_kernel, dim3((uint32_t)((n_wl + 255) / 256)), dim3(256), 0, ctx->stream, A->refs_d, A->units_d, O,
                            A->wl_d, (uint32_t)n_wl, A->fw, A->bw, phase, round, A->ext_pre, A->ext_reqs, A->ext_reqs + n_wl, A->ext_counts,
                            A->ext_wave);
+        pg_prof_end(ctx);
+        pg_prof_begin(ctx, PG_K_ANIM_EXTLANE);
         hipLaunchKernelGGL(anim_extdp_lane_kernel, dim3((uint32_t)ctx->num_cu * 4u), dim3(64), 0, ctx->stream, A->ext_reqs,
                            A->ext_reqs + n_wl, A->ext_counts, A->ext_counts + 2, A->ext_pre + (size_t)round * n_wl, A->ext_dumps,
                            dump_cap, A->ext_counts + 4, tail_lanes, tail_blocks);
+        pg_prof_end(ctx);
       }
       // final round: chains whose calls were all answered are finished by a thread each; the others (handed-over searches,
       // third calls, junction rectangles) are listed for the wave kernel
       PG_HIP(ctx, hipMemsetAsync(A->ext_counts, 0, 12, ctx->stream));   // [0] list length, [2] hand-out cursor
+      pg_prof_begin(ctx, PG_K_ANIM_EXTEND);
       hipLaunchKernelGGL(anim_extreq_kernel, dim3((uint32_t)((n_wl + 255) / 256)), dim3(256), 0, ctx->stream, A->refs_d, A->units_d, O,
                          A->wl_d, (uint32_t)n_wl, A->fw, A->bw, phase, EXT_ROUNDS, A->ext_pre, A->ext_reqs, A->ext_reqs + n_wl,
                          A->ext_counts, A->ext_wave);
       hipLaunchKernelGGL(anim_extend_kernel, dim3((uint32_t)ctx->num_cu * 32u), dim3(64), 0, ctx->stream, A->refs_d, A->units_d, O,
                          A->wl_d, A->fw, A->bw, phase, A->ext_pre, (uint32_t)n_wl, A->ext_dumps, A->ext_wave, A->ext_counts,
                          A->ext_counts + 2);
+      pg_prof_end(ctx);
     }
   }
+  pg_prof_begin(ctx, PG_K_ANIM_FINISH);
   hipLaunchKernelGGL(anim_finish_kernel, dim3(n_pairs), dim3(64), 0, ctx->stream, A->refs_d, A->units_d, n_pairs,
                      O, A->fw, A->bw, A->S, filter_1to1, A->out);
+  pg_prof_end(ctx);
   PG_HIP(ctx, hipGetLastError());
   PG_HIP(ctx, hipMemcpyAsync(out_host, A->out, n_pairs * sizeof(pg_anim_result), hipMemcpyDeviceToHost, ctx->stream));
   PG_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -620,7 +620,10 @@ PG_HD int stitch_chains(const ChainFwd* fw, const ChainBwd* bw, const Match* cm,
 // MUMmer 3.23's published algorithm (DeltaGraph_t::flagRLIS / flagQLIS + ScoreLocal): per sequence, alignments sorted by
 // start (ties: input order); weighted LIS with integer scores  score_i = max(own_i, max_j<i score_j + gain(i, j)),
 // own_i = trunc(len_i * idy_i^2), gain = trunc((len_i - olap) * idy_i^2), and a predecessor j is not allowed when the
-// overlap exceeds LIS_MAX_OLAP (75 %, delta-filter's -o default) of either alignment; first best wins (strict >).
+// overlap exceeds LIS_MAX_OLAP of either alignment; first best wins (strict >).  LIS_MAX_OLAP is 100 %: the -1 path of
+// MUMmer 3.23's delta-filter does not apply the 75 % that its usage text gives for -o (measured on the 27 real
+// .delta -> .filter pairs of tests/golden/anim: 100 reproduces all 12 734 keep/drop decisions, 75 gets 32 of them wrong —
+// overlaps between 75 % and 100 % do occur there, tests/test_anim_cpu.py::test_one_to_one_filter_matches_delta_filter).
 // side 0 = reference coordinates, 1 = query coordinates.  idx: scratch order; sc (as int64) / from: scratch.
 constexpr double LIS_MAX_OLAP = 100.0;
 PG_HD double lis_idy(const Aln& a) {

@@ -76,11 +76,11 @@ struct pg_ctx {
   // profiling
   bool profiling = false;
   uint32_t prof_mask = 0xFFFFFFFFu, prof_every = 1;
-  uint64_t prof_seen[PG_K__COUNT] = {0, 0, 0, 0};
+  uint64_t prof_seen[PG_K__COUNT] = {};
   bool prof_open = false;
   std::vector<PgEventPair> events;
-  double prof_ms[PG_K__COUNT] = {0, 0, 0, 0};
-  uint64_t prof_n[PG_K__COUNT] = {0, 0, 0, 0};
+  double prof_ms[PG_K__COUNT] = {};
+  uint64_t prof_n[PG_K__COUNT] = {};
   int num_cu = 256;
   void* anim_scratch = nullptr;  // AnimScratch (pg_anim.hip), grows on demand
   uint32_t anim_batch_pairs = 65536;          // upper bound of ordered pairs per launch (every launch pays its slowest unit once)

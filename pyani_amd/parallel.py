@@ -4,7 +4,7 @@ two small all-gathers (Z vectors, then matrix row blocks) over RCCL/xGMI — no 
 The compute steps are injected as callables so that the sharding / padding / gather logic below is exactly what
 runs on the GPUs (bench.py, backend "nccl" = RCCL) AND what the CPU tests exercise with world_size 2 over gloo.
 """
-from typing import Callable, Tuple
+from typing import Callable, List, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
@@ -70,31 +70,57 @@ class TetraAllGather:
 ANIM_FIELDS = 6  # ref_aln_len, qry_aln_len, sim_errors, n_alignments, identity (bit pattern), status
 
 
-def anim_pair_shard(n_genomes: int, rank: int, world: int):
-    """Ordered pairs (q, s), q != s, owned by `rank`: reference genomes (rows of the grid) are dealt out round-robin so
-    that every rank builds each 20-mer table at most once and the near-identical (expensive) pairs spread evenly."""
-    return [(q, s) for q in range(rank, n_genomes, world) for s in range(n_genomes) if s != q]
+def anim_row_shard(rows: Sequence[int], rank: int, world: int) -> List[int]:
+    """The reference genomes (rows of the ordered-pair grid) of `rows` owned by `rank`.  Whole rows stay on one rank so that
+    every reference k-mer table is built once per pass.  Pair cost varies ~60x with relatedness, and related genomes tend
+    to sit next to each other in a sorted input list (or, in the synthetic sets, at a fixed stride), so rows are dealt
+    round-robin in a fixed scrambled order (multiplicative hash of the row number) rather than in blocks or by stride."""
+    order = sorted(rows, key=lambda q: ((q * 0x9E3779B1) & 0xFFFFFFFF, q))
+    return sorted(order[rank::world])
 
 
-def anim_allgather(compute_pairs: Callable, n_genomes: int, device: torch.device, group=None) -> torch.Tensor:
-    """compute_pairs(pairs) -> int64 tensor [len(pairs), ANIM_FIELDS] on `device` (identity as its IEEE-754 bit pattern).
-    Returns the full [n, n, ANIM_FIELDS] int64 grid on every rank (diagonal zero).  One collective of 48 B per pair."""
+def anim_pair_shard(n_genomes: int, rank: int, world: int, rows: Optional[Sequence[int]] = None) -> List[Tuple[int, int]]:
+    """Ordered pairs (q, s), q != s, owned by `rank` (grouped by reference q)."""
+    rows = range(n_genomes) if rows is None else rows
+    return [(q, s) for q in anim_row_shard(rows, rank, world) for s in range(n_genomes) if s != q]
+
+
+def anim_pair_array(n_genomes: int, rows: Sequence[int]):
+    """The ordered pairs (q, s), s != q, of the reference rows `rows` as an int64 [m, 2] numpy array (grouped by q)."""
+    import numpy as np
+    rows = np.asarray(list(rows), dtype=np.int64)
+    q = np.repeat(rows, n_genomes)
+    s = np.tile(np.arange(n_genomes, dtype=np.int64), len(rows))
+    keep = q != s
+    return np.stack([q[keep], s[keep]], axis=1)
+
+
+def anim_allgather(compute_pairs: Callable, n_genomes: int, device: torch.device, group=None,
+                   rows: Optional[Sequence[int]] = None) -> torch.Tensor:
+    """compute_pairs(pairs: int64 ndarray [m, 2] of (q, s)) -> int64 tensor [m, ANIM_FIELDS] on `device` (identity as its
+    IEEE-754 bit pattern).
+    rows = None: the whole grid -> [n, n, ANIM_FIELDS] on every rank (diagonal zero).  rows = a list of reference genomes
+    (one step of a tiled run): only those rows are computed -> [len(rows), n, ANIM_FIELDS], row i = reference rows[i].
+    One collective of 64 B per pair (results + the pair's own (q, s), so the gathered block is self-describing)."""
     rank, world = dist.get_rank(group), dist.get_world_size(group)
-    mine = anim_pair_shard(n_genomes, rank, world)
-    rows_max = (n_genomes + world - 1) // world
+    all_rows = list(range(n_genomes)) if rows is None else list(rows)
+    mine = anim_pair_array(n_genomes, anim_row_shard(all_rows, rank, world))
+    rows_max = (len(all_rows) + world - 1) // world
     cap = rows_max * max(n_genomes - 1, 0)
-    loc = torch.zeros((cap, ANIM_FIELDS + 2), dtype=torch.int64, device=device)   # + (q, s) so that the grid is self-describing
-    if mine:
+    loc = torch.zeros((cap, ANIM_FIELDS + 2), dtype=torch.int64, device=device)
+    if len(mine):
         vals = compute_pairs(mine)
         loc[: len(mine), :ANIM_FIELDS] = vals
-        loc[: len(mine), ANIM_FIELDS:] = torch.tensor(mine, dtype=torch.int64, device=device)
+        loc[: len(mine), ANIM_FIELDS:] = torch.from_numpy(mine).to(device)
     loc[len(mine):, ANIM_FIELDS] = -1
     allv = torch.zeros((world * cap, ANIM_FIELDS + 2), dtype=torch.int64, device=device)
     dist.all_gather_into_tensor(allv, loc, group=group)
-    grid = torch.zeros((n_genomes, n_genomes, ANIM_FIELDS), dtype=torch.int64, device=device)
+    row_slot = torch.full((n_genomes,), -1, dtype=torch.int64, device=device)
+    row_slot[torch.tensor(all_rows, dtype=torch.int64, device=device)] = torch.arange(len(all_rows), dtype=torch.int64, device=device)
+    grid = torch.zeros((len(all_rows), n_genomes, ANIM_FIELDS), dtype=torch.int64, device=device)
     valid = allv[:, ANIM_FIELDS] >= 0
     q, s = allv[valid, ANIM_FIELDS], allv[valid, ANIM_FIELDS + 1]
-    grid[q, s] = allv[valid, :ANIM_FIELDS]
+    grid[row_slot[q], s] = allv[valid, :ANIM_FIELDS]
     return grid
 
 

@@ -1,0 +1,104 @@
+"""`pyani anim` without the database: the driver of pyani/scripts/subcommands/subcmd_anim.py:128-459 with its nucmer /
+delta-filter jobs replaced by ONE batched GPU call.  No CLI, no SQLAlchemy — the rows and matrices it would store come
+back as plain data.
+
+What is kept of the reference's behaviour:
+  * inputs: the FASTA files of `indir` in sorted order (pyani_files.get_fasta_paths); genome ids 1..N in that order (what
+    add_run_genomes assigns in a fresh database), all N(N-1) permutations are compared (subcmd_anim.py:233);
+  * output files: `<outdir>/nucmer_output/<q>/<q>_vs_<s>.filter` (`.delta` with nofilter), anim.py:271-288;
+  * `recovery=True` (subcmd_anim.py:269-285, generate_joblist:308-375): comparisons whose output file already exists are
+    NOT recomputed — the file (MUMmer's or ours) is parsed instead — the others are run;
+  * results: one Comparison row per ordered pair (subcmd_anim.py:434-456) and update_comparison_matrices' five NaN-initialised
+    frames indexed by genome id, with their to_json() strings (pyani_orm.py:618-666);
+  * errors: a pair the engine could not process raises PyaniANImException (the reference: a failed job ->
+    PyaniException "Multiprocessing run failed in ANIm"); a pair without any alignment raises ZeroDivisionError exactly as
+    parse_delta does on its empty .filter file, unless skip_zero=True (then the pair has no row and its cells stay NaN).
+"""
+from itertools import permutations
+from pathlib import Path
+from typing import Dict, List, NamedTuple, Optional, Tuple
+
+import pandas as pd
+
+from . import anim, files
+from .engine import Engine, default_engine
+
+ALIGNDIR = "nucmer_output"     # pyani_config.ALIGNDIR["ANIm"]
+
+
+class AnimRun(NamedTuple):
+    genome_ids: Dict[str, int]                                  # stem -> genome id (1-based, sorted-path order)
+    lengths: Dict[str, int]
+    results: Dict[Tuple[str, str], Tuple[int, int, float, int]]  # (query stem, subject stem) -> parse_delta tuple
+    comparisons: List[dict]                                     # Comparison rows
+    matrices: Dict[str, pd.DataFrame]                           # identity / coverage / aln_lengths / sim_errors / hadamard
+    json: Dict[str, str]                                        # Run.df_* strings
+    recovered: List[Path]                                       # output files reused in recovery mode
+    written: List[Path]                                         # output files written by this run
+
+
+def outfile_path(outdir: Path, qstem: str, sstem: str, nofilter: bool = False) -> Path:
+    """anim.py:271-288: suffixes are appended as strings (stems may contain dots)."""
+    return Path(outdir) / ALIGNDIR / qstem / (f"{qstem}_vs_{sstem}" + (".delta" if nofilter else ".filter"))
+
+
+def run_anim(indir, outdir=None, recovery: bool = False, nofilter: bool = False, maxmatch: bool = False,
+             write_output: bool = False, skip_zero: bool = False, engine: Optional[Engine] = None) -> AnimRun:
+    """ANIm over every FASTA file of `indir`.  outdir is needed for recovery / write_output only."""
+    eng = engine or default_engine()
+    paths = files.get_fasta_paths(Path(indir))
+    stems = [p.stem for p in paths]
+    if len(set(stems)) != len(stems):
+        raise ValueError("two input files share a stem (pyani keys every result by Path.stem)")
+    by_stem = dict(zip(stems, paths))
+    genome_ids = {s: k + 1 for k, s in enumerate(stems)}
+    # (subject, query) tuples as generate_joblist unpacks them (subcmd_anim.py:323): the QUERY is nucmer's reference
+    todo = [(q, s) for s, q in permutations(stems, 2)]
+    results: Dict[Tuple[str, str], Tuple[int, int, float, int]] = {}
+    recovered: List[Path] = []
+    if recovery:
+        if outdir is None:
+            raise ValueError("recovery mode needs the output directory of the earlier run")
+        existing = set(sorted((Path(outdir) / ALIGNDIR).glob("*/*.delta" if nofilter else "*/*.filter")))
+        old = [(q, s, outfile_path(outdir, q, s, nofilter)) for q, s in todo]
+        old = [(q, s, f) for q, s, f in old if f in existing]
+        if old:
+            recs = eng.anim_reduce([anim.read_delta(f) for _, _, f in old], apply_filter=False)
+            for (q, s, f), rec in zip(old, recs):
+                try:
+                    results[(q, s)] = anim._tuple(rec)
+                except ZeroDivisionError:
+                    if not skip_zero:
+                        raise
+                recovered.append(f)
+        done = {(q, s) for q, s, _ in old}
+        todo = [k for k in todo if k not in done]
+    written: List[Path] = []
+    scratch_store = eng.genome_count() == 0
+    lengths: Dict[str, int] = {}
+    try:
+        ids = {}
+        for p, (gid, total, _) in zip(paths, eng.add_fasta_batch(paths)):
+            ids[p.stem], lengths[p.stem] = gid, total
+        if todo:
+            recs = eng.anim_pairs([ids[q] for q, _ in todo], [ids[s] for _, s in todo], filter_1to1=not nofilter, maxmatch=maxmatch)
+            for (q, s), rec in zip(todo, recs):
+                try:
+                    results[(q, s)] = anim._tuple(rec)
+                except ZeroDivisionError:
+                    if not skip_zero:
+                        raise
+            if write_output:
+                if outdir is None or maxmatch:
+                    raise ValueError("write_output needs an output directory (and is not available with maxmatch yet)")
+                for q, s in todo:
+                    f = outfile_path(outdir, q, s, nofilter)
+                    f.parent.mkdir(parents=True, exist_ok=True)
+                    anim.write_delta(f, by_stem[q], by_stem[s], eng.anim_pair_alignments(ids[q], ids[s]), filtered=not nofilter)
+                    written.append(f)
+    finally:
+        if scratch_store:
+            eng.clear_genomes()
+    mats = anim.assemble_run_matrices(results, lengths, genome_ids=genome_ids)
+    return AnimRun(genome_ids, lengths, results, anim.comparison_rows(results, lengths, genome_ids, maxmatch=maxmatch), mats,
+                   anim.run_matrices_to_json(mats), recovered, written)

@@ -40,10 +40,12 @@ def calculate_tetra_zscores(infilenames: Iterable, engine: Engine = None) -> Dic
     eng = engine or default_engine()
     files = [Path(f) for f in infilenames]
     scratch_store = eng.genome_count() == 0
-    ids = [g for g, _, _ in eng.add_fasta_batch(files)]   # multithreaded read + parse + pack
-    z, present, _ = eng.tetra_matrix(ids, want_corr=False)
-    if scratch_store:
-        eng.clear_genomes()
+    try:
+        ids = [g for g, _, _ in eng.add_fasta_batch(files)]   # multithreaded read + parse + pack
+        z, present, _ = eng.tetra_matrix(ids, want_corr=False)
+    finally:
+        if scratch_store:       # also on errors: a failed call must not leave its genomes in the shared engine
+            eng.clear_genomes()
     out: Dict[str, Dict[str, float]] = {}
     for k, f in enumerate(files):
         out[f.stem] = _z_to_dict(z[k], present[k])
@@ -91,18 +93,19 @@ def calculate_tetra(infiles: Iterable, engine: Engine = None) -> pd.DataFrame:
     stems = [f.stem for f in files]
     order = sorted(range(len(files)), key=lambda k: stems[k])
     scratch_store = eng.genome_count() == 0
-    ids = [g for g, _, _ in eng.add_fasta_batch([files[k] for k in order])]
     labels = [stems[k] for k in order]
     try:
+        ids = [g for g, _, _ in eng.add_fasta_batch([files[k] for k in order])]
         _, _, corr = eng.tetra_matrix(ids, want_corr=True)
-        if scratch_store:
-            eng.clear_genomes()
     except _lib.PyaniGpuError as exc:
         if exc.code == _lib.PG_E_KEYSET:
             raise AssertionError() from exc
         if exc.code == _lib.PG_E_EMPTY:
             raise ZeroDivisionError("division by zero") from exc
         raise
+    finally:
+        if scratch_store:       # on the error paths too
+            eng.clear_genomes()
     return pd.DataFrame(corr, index=labels, columns=labels, dtype=float)
 
 

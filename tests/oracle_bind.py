@@ -49,8 +49,8 @@ class Oracle:
 
 
 def load() -> Oracle:
-    from pyani_amd import build
-    return Oracle(ctypes.CDLL(str(build.build_oracle())))
+    import oracle_build   # oracle/oracle_build.py
+    return Oracle(ctypes.CDLL(str(oracle_build.build_oracle())))
 
 
 def read_fasta_arrays(path):

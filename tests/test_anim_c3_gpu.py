@@ -1,0 +1,80 @@
+"""Full-size ANIm on the GPU (BASELINE.json configs[2] / [3] code path): one whole C3 family — 25 synthetic 5 Mb genomes of
+one ancestor, all 600 related ordered pairs — plus 200 unrelated ordered pairs, through pg_anim_pairs in ONE call, against
+the CPU statement of the search (oracle/anim_cpu.cpp; fixture made by tools/make_anim_c3_family_host.py), plus the
+size-independent properties of the domain; and the N > 1 path of bench.py on hardware (2 ranks on GPU 0 over gloo)."""
+import hashlib
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from tests.conftest import GOLD, ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def test_c3_family_equals_cpu_statement_and_properties():
+    from pyani_amd import synth
+    from pyani_amd.engine import Engine
+    fx = json.loads((GOLD / "anim_c3_family_host.json").read_text())
+    n, L, seed = fx["n"], fx["length"], fx["seed"]
+    pairs = [(p[0], p[1]) for p in fx["pairs"]]
+    used = sorted({g for p in pairs for g in p})
+    with Engine(0) as eng:
+        ids = {g: eng.add_genome(*synth.genome(seed, n, g, L)) for g in used}
+        eng.upload()
+        res = eng.anim_pairs([ids[a] for a, _ in pairs], [ids[b] for _, b in pairs])
+        lens = {g: eng.genome_length(ids[g])[0] for g in used}
+    got = [[a, b, int(r["ref_aln_len"]), int(r["qry_aln_len"]), float(r["identity"]).hex(), int(r["sim_errors"]),
+            int(r["n_alignments"]), int(r["status"])] for (a, b), r in zip(pairs, res)]
+    bad = [(g, w) for g, w in zip(got, fx["pairs"]) if g != w]
+    assert not bad, f"{len(bad)} of {len(pairs)} pairs differ from the CPU statement, first: {bad[0]}"
+    assert hashlib.sha1(json.dumps(got).encode()).hexdigest() == fx["sha1"]
+    # size-independent properties (they hold for nucmer + delta-filter -1 + parse_delta output on any input)
+    by = {(a, b): r for (a, b), r in zip(pairs, res)}
+    n_rel = fx["n_related"]
+    for k, ((a, b), r) in enumerate(zip(pairs, res)):
+        if k >= n_rel:
+            assert int(r["status"]) == 1 and int(r["n_alignments"]) == 0, (a, b)     # unrelated: empty .filter
+            continue
+        assert int(r["status"]) in (0, 1)
+        if int(r["status"]) == 0:
+            assert 0 < int(r["ref_aln_len"]) <= lens[a] and 0 < int(r["qry_aln_len"]) <= lens[b]   # interval unions
+            assert 0.5 < float(r["identity"]) <= 1.0
+            back = by[(b, a)]
+            if int(back["status"]) == 0:
+                assert abs(float(r["identity"]) - float(back["identity"])) < 0.01, (a, b)
+                assert abs(int(r["ref_aln_len"]) - int(back["qry_aln_len"])) < 0.05 * lens[a], (a, b)
+    ok = sum(int(r["status"]) == 0 for r in res[:n_rel])
+    assert ok >= 0.97 * n_rel
+
+
+def _bench(extra_env, nproc, tmp_path, tag):
+    env = dict(os.environ, **extra_env)
+    args = ["--genomes", "24", "--length", "300000", "--seed", "11", "--rows-per-step", "8", "--steps", "3", "--warmup", "0",
+            "--no-cpu-baseline", "--no-tetra"]
+    if nproc == 1:
+        cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", "1"] + args
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+               "--master-port", "29517", str(ROOT / "bench.py"), "--gpus", str(nproc)] + args
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    (tmp_path / f"{tag}.json").write_text(line)
+    return json.loads(line)
+
+
+def test_bench_two_ranks_on_one_gpu_equal_single_rank(tmp_path):
+    """bench.py's N > 1 path (rows dealt over the ranks, Engine per rank, one all-gather per step) on hardware: two ranks
+    sharing GPU 0 over gloo (PYANI_BENCH_DEBUG_ONE_GPU) give the same full-grid result hash as one rank."""
+    one = _bench({}, 1, tmp_path, "one")
+    two = _bench({"PYANI_BENCH_DEBUG_ONE_GPU": "1"}, 2, tmp_path, "two")
+    assert one["config"]["results_sha1_full_grid"] and one["config"]["results_sha1_full_grid"] == two["config"]["results_sha1_full_grid"]
+    assert two["n_gpus"] == 2 and two["scaling"] == "strong" and one["config"]["pairs_timed"] == two["config"]["pairs_timed"] == 24 * 23
+    assert one["config"]["related_pairs_with_alignment"] == two["config"]["related_pairs_with_alignment"] > 0
+    for rec in (one, two):
+        assert rec["roofline"]["kernel"].startswith("anim_") and rec["roofline"]["achieved"] > 0

@@ -18,6 +18,10 @@ import anim_oracle  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
+# the genomes recovered in round 2 (tools/make_goldens.py) are OUT-of-sample: the engine's constants were fitted without them,
+# and they have their own test (tests/test_anim_oos_gpu.py); the exact-equality tests below are the in-sample pins
+OUT_OF_SAMPLE = {"NC_010338", "NC_014100"}
+
 
 @pytest.fixture(scope="module")
 def eng():
@@ -50,7 +54,7 @@ def test_reduction_bit_exact_on_all_fixture_files(eng, gold):
 def test_delta_filter_then_reduce_close_to_filter_files(eng, gold):
     """delta -> (GPU 1-to-1 filter) -> reduction vs the .filter file's tuple: identity within 2e-4 on every pair."""
     from pyani_amd import anim
-    rels = sorted(r for r in gold if r.endswith(".delta") and "/" in r)
+    rels = sorted(r for r in gold if r.endswith(".delta") and r.replace(".delta", ".filter") in gold)
     out = eng.anim_reduce([anim.read_delta(GOLD / "anim" / (r + ".gz")) for r in rels], apply_filter=True)
     for rel, r in zip(rels, out):
         want = gold[rel.replace(".delta", ".filter")]
@@ -69,7 +73,7 @@ def fixture_runs(eng, genome_dir, gold):
     for rel in sorted(gold):
         if rel.endswith(".filter") and "/" in rel:
             a, b = rel.split("/")[1][:-7].split("_vs_")
-            if a in ids and b in ids:
+            if a in ids and b in ids and not ({a, b} & OUT_OF_SAMPLE):
                 pairs.append((rel, a, b))
     res = eng.anim_pairs([ids[a] for _, a, _ in pairs], [ids[b] for _, _, b in pairs])
     return [(rel, a, b, r, gold[rel]) for (rel, a, b), r in zip(pairs, res)]
@@ -165,7 +169,7 @@ def test_alignment_records_equal_mummer_delta_and_filter_files(eng, genome_dir, 
     for grp in ("blochmannia", "caulobacter"):
         for f in sorted((GOLD / "anim" / grp).glob("*.delta.gz")):
             a, b = f.name[:-len(".delta.gz")].split("_vs_")
-            if a not in ids or b not in ids:
+            if a not in ids or b not in ids or ({a, b} & OUT_OF_SAMPLE):
                 continue
             rrec, qrec = anim.fasta_records(paths[a]), anim.fasta_records(paths[b])
             al = eng.anim_pair_alignments(ids[a], ids[b])
@@ -276,3 +280,30 @@ def test_many_records_equal_scalar_host_statement(eng):
     for (a, b), r in zip(pairs, res):
         got = [int(r["ref_aln_len"]), int(r["qry_aln_len"]), float(r["identity"]).hex(), int(r["sim_errors"]), int(r["n_alignments"])]
         assert got == fx["contigs"]["pairs"][f"{a},{b}"], (a, b, got)
+
+
+def test_run_anim_writes_recovery_files_and_recovers_from_them(eng, genome_dir, tmp_path):
+    """pyani_amd.subcmd_anim.run_anim on the GPU: a run that writes its .filter files, then a --recovery run over the same
+    output directory with one file removed: 5 comparisons come from the files, 1 is recomputed, every tuple / matrix cell is
+    identical; and the tuples are the MUMmer goldens."""
+    import numpy as np
+    from pyani_amd import subcmd_anim
+    eng.clear_genomes()
+    gold = json.loads((GOLD / "anim_goldens.json").read_text())["parse_delta"]
+    indir, outdir = tmp_path / "in", tmp_path / "out"
+    indir.mkdir()
+    stems = sorted(genome_dir["blochmannia"])[:3]
+    for s in stems:
+        (indir / f"{s}.fna").write_bytes(genome_dir["blochmannia"][s].read_bytes())
+    first = subcmd_anim.run_anim(indir, outdir, write_output=True, engine=eng)
+    assert len(first.written) == 6 and not first.recovered and eng.genome_count() == 0
+    for (q, s), t in first.results.items():
+        rel = f"blochmannia/{q}_vs_{s}.filter"
+        if rel in gold:
+            assert list(t) == gold[rel], rel
+    first.written[2].unlink()
+    again = subcmd_anim.run_anim(indir, outdir, recovery=True, engine=eng)
+    assert len(again.recovered) == 5 and again.results == first.results and again.comparisons and again.json == first.json
+    for name in first.matrices:
+        assert np.array_equal(first.matrices[name].values, again.matrices[name].values, equal_nan=True)
+    assert list(first.matrices["identity"].index) == [1, 2, 3]

@@ -1,0 +1,105 @@
+"""Out-of-sample ANIm parity on the GPU: MUMmer output the engine's constants were NOT fitted on.
+
+  caulobacter  12 ordered pairs of the 4 Caulobacter genomes with real nucmer .delta + delta-filter .filter files
+               (tests/fixtures/anim/deltadir); NC_010338 / NC_014100 were recovered from the reference's JSpecies BLAST
+               databases (tools/make_goldens.py), so 10 of the 12 pairs (85-87 % identity, ~1200 alignments each) are new
+  group2       2 ordered pairs of draft genomes (tests/test_JSpecies/Group_2), raw .delta only
+  jspecies     12 raw .delta files JSpecies' own nucmer runs left behind (single-record NC_002696)
+
+Level reached is recorded per pair in gpurun_out/anim_oos_gpu_report.json (committed copies under profiles/); the first,
+unfitted score is profiles/r02_anim_oos_first_unfitted.json.  BASELINE.json's bar (identity and coverage within 1e-4) is its
+own test so that the distance to it stays visible.
+"""
+import json
+from pathlib import Path
+
+import pytest
+
+from tests.conftest import GOLD, ROOT
+
+import sys
+sys.path.insert(0, str(ROOT / "oracle"))
+import anim_oracle  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def _key(x):
+    return (x.ref_id, x.qry_id, x.rs, x.re, x.qs, x.qe, x.errors)
+
+
+@pytest.fixture(scope="module")
+def oos(genome_dir, tmp_path_factory):
+    from pyani_amd import anim
+    from pyani_amd.engine import Engine
+    gold = json.loads((GOLD / "anim_goldens.json").read_text())["parse_delta"]
+    tmp = tmp_path_factory.mktemp("oos")
+    paths = dict(genome_dir["caulobacter"])
+    paths.update(genome_dir["group2"])
+    # JSpecies ran nucmer on the single-record NC_002696 (= the fixture file's two records joined)
+    body = "".join(l.strip() for l in open(paths["NC_002696"]) if not l.startswith(">"))
+    joined = tmp / "NC_002696.fna"
+    joined.write_text(">gi|16124256|ref|NC_002696.2| joined\n" + "\n".join(body[i:i + 70] for i in range(0, len(body), 70)) + "\n")
+    report = {}
+    with Engine(0) as eng:
+        ids = {s: eng.add_fasta(p)[0] for s, p in paths.items()}
+        ids["NC_002696@joined"] = eng.add_fasta(joined)[0]
+        recs = {s: anim.fasta_records(p) for s, p in paths.items()}
+        recs["NC_002696@joined"] = anim.fasta_records(joined)
+        for grp in ("caulobacter", "group2", "jspecies"):
+            for f in sorted((GOLD / "anim" / grp).glob("*.delta.gz")):
+                a, b = f.name[:-len(".delta.gz")].split("_vs_")
+                ka, kb = (s + "@joined" if grp == "jspecies" and s == "NC_002696" else s for s in (a, b))
+                al = eng.anim_pair_alignments(ids[ka], ids[kb])
+                mine = {(recs[ka][int(x["ref_rec"])][0], recs[kb][int(x["qry_rec"])][0], int(x["rs"]), int(x["re"]), int(x["qs"]),
+                         int(x["qe"]), int(x["errors"])): int(x["kept"]) for x in al}
+                want = {_key(x) for x in anim_oracle.read_delta(f)[0]}
+                rep = {"mummer_records": len(want), "ours": len(mine), "exact": len(want & set(mine))}
+                allr = [anim_oracle.Aln(*k, k[6], 0, ()) for k in mine]
+                kept = [anim_oracle.Aln(*k, k[6], 0, ()) for k, v in mine.items() if v == 3]
+                cmp = [("delta", gold[f"{grp}/{a}_vs_{b}.delta"], allr)]
+                flt = Path(str(f).replace(".delta.gz", ".filter.gz"))
+                if flt.exists():
+                    want_f = {_key(x) for x in anim_oracle.read_delta(flt)[0]}
+                    rep["filter_records"], rep["filter_exact"] = len(want_f), len(want_f & {_key(x) for x in kept})
+                    cmp.append(("filter", gold[f"{grp}/{a}_vs_{b}.filter"], kept))
+                for name, m, rs in cmp:
+                    o = anim_oracle.parse_delta_records(rs)
+                    rep[name] = {"mummer": m, "ours": list(o), "identity_abs_diff": abs(m[2] - o[2]),
+                                 "ref_aln_len_rel_diff": abs(m[0] - o[0]) / m[0], "qry_aln_len_rel_diff": abs(m[1] - o[1]) / m[1]}
+                report[f"{grp}/{a}_vs_{b}"] = rep
+    out = ROOT / "gpurun_out"
+    out.mkdir(exist_ok=True)
+    tot = sum(r["mummer_records"] for r in report.values())
+    ex = sum(r["exact"] for r in report.values())
+    (out / "anim_oos_gpu_report.json").write_text(json.dumps({"total_records": tot, "exact": ex, "pairs": report}, indent=1, sort_keys=True))
+    return report
+
+
+def _worst(report, field):
+    return max(max(r[k][field] for k in ("delta", "filter") if k in r) for r in report.values())
+
+
+def test_oos_record_level_agreement(oos):
+    """Every pair: at least 90 % of MUMmer's alignment records reproduced coordinate for coordinate with the same error count
+    (first unfitted score: 95.5 % over all, 91.7 % on the worst pair), and the near-identical pairs exactly."""
+    assert len(oos) == 26
+    for name, r in oos.items():
+        assert r["exact"] >= 0.90 * r["mummer_records"], (name, r["exact"], r["mummer_records"])
+    for name in ("caulobacter/NC_002696_vs_NC_011916", "caulobacter/NC_011916_vs_NC_002696", "jspecies/NC_002696_vs_NC_011916",
+                 "jspecies/NC_011916_vs_NC_002696"):
+        assert oos[name]["exact"] == oos[name]["mummer_records"] == oos[name]["ours"], name
+    tot = sum(r["mummer_records"] for r in oos.values())
+    assert sum(r["exact"] for r in oos.values()) >= 0.95 * tot
+
+
+def test_oos_identity_and_coverage_level_reached(oos):
+    """parse_delta tuples of the engine's records vs MUMmer's, filtered and unfiltered: the level reached out of sample."""
+    assert _worst(oos, "identity_abs_diff") < 3e-3
+    assert _worst(oos, "ref_aln_len_rel_diff") < 3e-3 and _worst(oos, "qry_aln_len_rel_diff") < 3e-3
+
+
+@pytest.mark.xfail(strict=False, reason="BASELINE.json's bar (identity / coverage within 1e-4) is not yet met on the 85 % pairs")
+def test_oos_identity_and_coverage_within_baseline_bar(oos):
+    assert _worst(oos, "identity_abs_diff") < 1e-4
+    assert _worst(oos, "ref_aln_len_rel_diff") < 1e-4 and _worst(oos, "qry_aln_len_rel_diff") < 1e-4

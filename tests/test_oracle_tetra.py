@@ -72,11 +72,13 @@ def test_c_oracle_correlation_synth(oracle, synth_ci_dir, goldens):
 
 def test_reference_own_targets(oracle, genome_dir):
     """The reference's committed goldens: zscore.json (exact dict equality, tests/test_tetra.py:79-84) and the
-    NC_002696/NC_011916 cell of TETRA_correlations.tab (the other two genomes are missing blobs upstream)."""
+    whole 4 x 4 tests/target_TETRA_output/TETRA_correlations.tab (NC_010338 / NC_014100 are missing blobs upstream as FASTA;
+    recovered from the reference's JSpecies BLAST databases by tools/make_goldens.py — every cell equal to the last digit)."""
     with open(GOLD / "ref_targets" / "tetra_zscore_NC_002696.json") as fh:
         target = json.load(fh)
     zs, ps = [], []
-    for stem in ("NC_002696", "NC_011916"):
+    stems = ("NC_002696", "NC_010338", "NC_011916", "NC_014100")
+    for stem in stems:
         seq, off = oracle_bind.read_fasta_arrays(genome_dir["caulobacter"][stem])
         z, p = oracle.zscores(*oracle.counts(seq, off))
         zs.append(z[0]), ps.append(p[0])
@@ -85,8 +87,11 @@ def test_reference_own_targets(oracle, genome_dir):
     assert rc == 0
     lines = (GOLD / "ref_targets" / "TETRA_correlations_caulobacter_4x4.tab").read_text().splitlines()
     header = lines[0].split("\t")[1:]
-    row = dict(zip(header, lines[1 + header.index("NC_002696")].split("\t")[1:]))
-    assert repr(float(m[0, 1])) == row["NC_011916"] == "0.9999899853711502"
+    assert header == list(stems)
+    for i, a in enumerate(stems):
+        row = lines[1 + i].split("\t")
+        assert row[0] == a and [repr(float(x)) for x in m[i]] == row[1:], a
+    assert repr(float(m[0, 2])) == "0.9999899853711502"
 
 
 def test_blochmannia_legacy_target_within_1ulp(oracle, genome_dir, goldens):

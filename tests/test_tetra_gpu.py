@@ -108,7 +108,12 @@ def test_reference_own_targets(eng, genome_dir):
     assert tetra.calculate_tetra_zscore(genome_dir["caulobacter"]["NC_002696"], engine=eng) == target
     df = tetra.calculate_tetra(list(genome_dir["caulobacter"].values()), engine=eng)
     assert repr(float(df.loc["NC_002696", "NC_011916"])) == "0.9999899853711502"
-    assert list(df.index) == ["NC_002696", "NC_011916"] and df.loc["NC_002696", "NC_002696"] == 1.0
+    assert list(df.index) == ["NC_002696", "NC_010338", "NC_011916", "NC_014100"] and df.loc["NC_002696", "NC_002696"] == 1.0
+    # the reference's whole committed 4 x 4 table (tests/target_TETRA_output/TETRA_correlations.tab), and the file itself
+    out = GOLD.parent.parent / "gpurun_out" / "TETRA_correlations_caulobacter.tab"
+    out.parent.mkdir(exist_ok=True)
+    tetra.write_correlations_tab(df, out)
+    assert out.read_text() == (GOLD / "ref_targets" / "TETRA_correlations_caulobacter_4x4.tab").read_text()
 
 
 def test_module_api_mirrors_reference(eng, genome_dir, goldens, tmp_path):

@@ -133,8 +133,13 @@ def main():
     out = {}
 
     # ---- (1) data files held by the reference's own tests ------------------------------------------------
+    recover_caulobacter_genomes()
+    recovered = []
+    for stem in ("NC_010338", "NC_014100"):
+        gunzip_to(GOLD / "genomes" / "caulobacter" / f"{stem}.fna.gz", tmp / f"{stem}.fna")
+        recovered.append(tmp / f"{stem}.fna")
     groups = {
-        "caulobacter": [REF / "tests/fixtures/sequences/NC_002696.fna", REF / "tests/fixtures/sequences/NC_011916.fna"],
+        "caulobacter": [REF / "tests/fixtures/sequences/NC_002696.fna", REF / "tests/fixtures/sequences/NC_011916.fna"] + recovered,
         "blochmannia": sorted((REF / "tests/fixtures/legacy/ANI_input").glob("*.fna")),
         "concordance": sorted((REF / "tests/fixtures/concordance").glob("*.fna")),
     }
@@ -143,7 +148,8 @@ def main():
     for grp, files in groups.items():
         zs = {}
         for f in files:
-            gz_copy(f, GOLD / "genomes" / grp / (f.name + ".gz"))
+            if f not in recovered:
+                gz_copy(f, GOLD / "genomes" / grp / (f.name + ".gz"))
             rec, z = run_reference(ref, created, f)
             out[f"{grp}/{f.stem}"] = rec
             zs[f.stem] = z
@@ -238,6 +244,69 @@ def gz_bytes(data: bytes, dst: Path):
             fo.write(data)
 
 
+def recover_caulobacter_genomes():
+    """The two Caulobacter genomes whose FASTA files are missing blobs, recovered from JSpecies' BLAST databases; the decoder
+    is validated on the two genomes that exist in both forms, and the lengths equal the .delta headers."""
+    js = REF / "tests/test_JSpecies"
+    pt = js / "pyani_tests"
+    for stem in ("NC_002696", "NC_011916"):
+        assert decode_blastdb_nsq(pt / f"{stem}.fna.nsq", pt / f"{stem}.fna.nin") == fasta_body(pt / f"{stem}.fna"), stem
+    # single-record NC_002696 of the JSpecies runs == the two records of fixtures/anim/sequences joined
+    assert fasta_body(pt / "NC_002696.fna") == fasta_body(REF / "tests/fixtures/anim/sequences/NC_002696.fna")
+    titles = {"NC_010338": ("gi|167643973|ref|NC_010338.1|", "Caulobacter sp. K31 chromosome, complete genome", 5477872),
+              "NC_014100": ("gi|295687459|ref|NC_014100.1|", "Caulobacter segnis ATCC 21756 chromosome, complete genome", 4655622)}
+    for stem, (sid, title, length) in titles.items():
+        seq = decode_blastdb_nsq(pt / f"{stem}.fna.nsq", pt / f"{stem}.fna.nin")
+        assert len(seq) == length and title.encode() in (pt / f"{stem}.fna.nhr").read_bytes()
+        lines = [f">{sid} {title}".encode()] + [seq[i:i + 70] for i in range(0, len(seq), 70)]
+        gz_bytes(b"\n".join(lines) + b"\n", GOLD / "genomes" / "caulobacter" / f"{stem}.fna.gz")
+
+
+def make_deltadir_cases(ref_anim, tmp):
+    """process_deltadir of the REFERENCE (pyani/anim.py:415-497 + pyani_tools.ANIResults, imported) on (1) its own deltadir
+    fixture and (2) a small synthetic directory whose stems are prefixes of one another ('g', 'g-2', 'g.1': the sorted-Path
+    order differs from the sorted-string order there) and which has one-directional and empty-mirror cases.  Stored: the
+    inputs of case 2 (tiny .filter texts) and all five matrices of both cases as hex floats."""
+    import logging
+    rng = random.Random(5)
+
+    def matrices(res):
+        out = {}
+        for df, stem in res.data:
+            out[stem] = {"labels": list(df.index), "rows": [[float(df.loc[a, b]).hex() for b in df.columns] for a in df.index]}
+        return out
+
+    cases = {}
+    ddir = REF / "tests/fixtures/anim/deltadir"
+    names = sorted(d.name for d in ddir.iterdir())
+    lengths = {n_: 4_000_000 + 1000 * i for i, n_ in enumerate(names)}
+    cases["caulobacter_deltadir"] = {"lengths": list(lengths.items()), "matrices": matrices(ref_anim.process_deltadir(ddir, lengths))}
+    stems = ["g", "g-2", "g.1", "a", "zz"]
+    lengths = {s: 5000 + 37 * i for i, s in enumerate(stems)}
+    root = tmp / "deltadir_case"
+    if root.exists():
+        shutil.rmtree(root)
+    files = {}
+    for q in stems:
+        for s in stems:
+            if q == s or (q, s) in (("a", "zz"), ("g.1", "g")):       # two directions missing
+                continue
+            lines = [f"/x/{q}.fna /x/{s}.fna", "NUCMER", f">{q}_1 {s}_1 {lengths[q]} {lengths[s]}"]
+            pos = 1
+            for _ in range(rng.randint(1, 4)):
+                ln = rng.randint(70, 600)
+                qs = rng.randint(1, lengths[s] - 700)
+                lines += [f"{pos} {pos + ln - 1} {qs} {qs + ln + rng.randint(-3, 3)} {rng.randint(0, 30)} 0 0", "0"]
+                pos += ln - rng.randint(0, 40)
+            files[f"{q}/{q}_vs_{s}.filter"] = "\n".join(lines) + "\n"
+    for rel, text in files.items():
+        (root / rel).parent.mkdir(parents=True, exist_ok=True)
+        (root / rel).write_text(text)
+    cases["prefix_stems"] = {"lengths": list(lengths.items()), "files": files, "matrices": matrices(ref_anim.process_deltadir(root, lengths))}
+    (GOLD / "ref_targets" / "anim_process_deltadir_cases.json").write_text(json.dumps(cases, indent=0, sort_keys=True))
+    logging.getLogger().info("process_deltadir cases written")
+
+
 def make_anim_goldens():
     import tarfile
     sys.path.insert(0, str(ROOT / "oracle"))
@@ -284,22 +353,10 @@ def make_anim_goldens():
     for f in sorted((js / "pyani_tests").glob("*.fna_vs_*.fna.delta")):   # JSpecies' own nucmer runs on the 4 Caulobacter genomes
         a, b = f.name[:-len(".delta")].split("_vs_")
         store(f.read_bytes(), f"jspecies/{a[:-4]}_vs_{b[:-4]}.delta")
-    # the two Caulobacter genomes whose FASTA files are missing blobs, recovered from JSpecies' BLAST databases; the decoder
-    # is validated on the two genomes that exist in both forms, and the lengths equal the .delta headers
-    pt = js / "pyani_tests"
-    for stem in ("NC_002696", "NC_011916"):
-        assert decode_blastdb_nsq(pt / f"{stem}.fna.nsq", pt / f"{stem}.fna.nin") == fasta_body(pt / f"{stem}.fna"), stem
-    # single-record NC_002696 of the JSpecies runs == the two records of fixtures/anim/sequences joined
-    assert fasta_body(pt / "NC_002696.fna") == fasta_body(REF / "tests/fixtures/anim/sequences/NC_002696.fna")
-    titles = {"NC_010338": ("gi|167643973|ref|NC_010338.1|", "Caulobacter sp. K31 chromosome, complete genome", 5477872),
-              "NC_014100": ("gi|295687459|ref|NC_014100.1|", "Caulobacter segnis ATCC 21756 chromosome, complete genome", 4655622)}
-    for stem, (sid, title, length) in titles.items():
-        seq = decode_blastdb_nsq(pt / f"{stem}.fna.nsq", pt / f"{stem}.fna.nin")
-        assert len(seq) == length and title.encode() in (pt / f"{stem}.fna.nhr").read_bytes()
-        lines = [f">{sid} {title}".encode()] + [seq[i:i + 70] for i in range(0, len(seq), 70)]
-        gz_bytes(b"\n".join(lines) + b"\n", GOLD / "genomes" / "caulobacter" / f"{stem}.fna.gz")
+    recover_caulobacter_genomes()
     shutil.copyfile(REF / "tests/fixtures/anim/dataframes/deltadir_result.csv", GOLD / "ref_targets" / "anim_deltadir_result.csv")
     shutil.copyfile(js / "jspecies_results.tab", GOLD / "ref_targets" / "jspecies_results_caulobacter.tab")
+    make_deltadir_cases(ref_anim, tmp)
     known = {"test.delta": [4016947, 4017751, 0.9994621994447228, 2191]}  # tests/test_anim.py:96-100
     assert tuples["test.delta"] == known["test.delta"]
     with open(GOLD / "anim_goldens.json", "w") as fh:
