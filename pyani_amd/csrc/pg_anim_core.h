@@ -182,9 +182,10 @@ PG_HD ExtResult extend_banded(const RefT& R, const QryT& Q, int64_t r0, int64_t 
 // recurrences and tie-breaks as dp_cell.  Used to bridge cluster junctions whose diagonal shift exceeds the band
 // (an indel of 60+ bases between two clusters that nucmer still fuses).  min(n, m) <= THIN_MAX; returns -1 otherwise.
 constexpr int THIN_MAX = 63, THIN_LONG = 511;
+struct RectResult { int32_t score, errors; };   // errors < 0: the rectangle is too large for the thin DP
 template <typename RefT, typename QryT>
-PG_HD int32_t thin_rect_errors(const RefT& R, const QryT& Q, int64_t r0, int32_t n, int64_t q0, int32_t m) {
-  if (n < 0 || m < 0 || n > THIN_LONG || m > THIN_LONG || (n > THIN_MAX && m > THIN_MAX)) return -1;
+PG_HD RectResult thin_rect_errors(const RefT& R, const QryT& Q, int64_t r0, int32_t n, int64_t q0, int32_t m) {
+  if (n < 0 || m < 0 || n > THIN_LONG || m > THIN_LONG || (n > THIN_MAX && m > THIN_MAX)) return RectResult{NEG_INF, -1};
   // rows = ref bases, columns = query bases (no transposition: both builds walk the same cells)
   DpCell row[THIN_LONG + 1], nrow[THIN_LONG + 1];
   row[0] = DpCell{0, 0, NEG_INF, 0, NEG_INF, 0};
@@ -199,7 +200,7 @@ PG_HD int32_t thin_rect_errors(const RefT& R, const QryT& Q, int64_t r0, int32_t
     }
     for (int32_t j = 0; j <= m; ++j) row[j] = nrow[j];
   }
-  return row[m].he;
+  return RectResult{row[m].h, row[m].he};
 }
 
 // Global alignment of the gap between two chained matches: ref gap n, query gap m (both small); returns errors.
@@ -509,9 +510,22 @@ PG_HD ChainFwd extend_chain_fwd(const RefT& R, const QryT& Q, const Match* cm, c
   return e;
 }
 
-// Junction with a diagonal shift beyond the band: the free backward search stopped at (e.rs, e.qs); if the previous
-// alignment's end (prev_re, prev_qe) is still behind it and within the break length, nucmer's dynamic band would have
-// reached it -> bridge the residual rectangle with a full DP and fuse.  RECT(r0, n, q0, m) -> errors or -1.
+// Junction with a diagonal shift beyond the band: the free backward search stopped at (e.rs, e.qs), its best cell.  nucmer's
+// DP band is dynamic: it widens by one diagonal per anti-diagonal and is trimmed from its edges where the score has fallen
+// more than  GOOD_SCORE * breaklen = 3 * 200 = 600  below the best cell, and the search ends breaklen anti-diagonals after the
+// best cell.  So the previous alignment's end (prev_re, prev_qe) is reached — and the two alignments fused — iff it lies
+// within the break length of the best cell (n + m <= 200) AND the optimal path over the residual rectangle between the two
+// costs no more than the X-drop.  Out of sample (the ten 85 % Caulobacter pairs, 101 such junctions): nucmer fused every
+// junction whose residual rectangle scores >= -612 and none below -623 (one exception at -605); 615 separates them, i.e.
+// indels up to ~87 bases between two clusters are bridged, longer ones end the alignment.  Round 1 had no score test (fitted
+// on the Blochmannia pairs, whose largest such indel is 80 bases) and fused 240 junctions nucmer does not.
+// RECT(r0, n, q0, m) -> {score, errors} of the optimal global path (errors < 0: too large for the thin DP).
+constexpr int32_t BRIDGE_XDROP =
+#ifdef PGA_BRIDGE_XDROP
+    PGA_BRIDGE_XDROP;
+#else
+    615;
+#endif
 template <typename RECT>
 PG_HD void bridge_junction(ChainBwd& e, int32_t prev_re, int32_t prev_qe, int32_t tr, int32_t tq, int32_t first_r, int32_t first_q,
                            int32_t prev_lr, int32_t prev_lq, int32_t prev_err_fwd, RECT&& rect) {
@@ -521,15 +535,18 @@ PG_HD void bridge_junction(ChainBwd& e, int32_t prev_re, int32_t prev_qe, int32_
   if (shift < BAND - 2) return;                            // reachable shifts are decided by the (shifted-band) target search
   const int32_t n = e.rs - prev_re, m = e.qs - prev_qe;
   if (n < 0 || m < 0 || n + m > BREAK_LEN) return;
-  // prefer the optimal path over the WHOLE junction, from the end of the previous chain's last match to this chain's
-  // first match (its free forward extension is then replaced: minus prev_err_fwd); then from the previous forward end;
-  // fall back to the residual rectangle behind the free backward search when the junction is too large for the full DP
-  int32_t err = prev_lr >= 0 && prev_lr <= prev_re && prev_lq <= prev_qe ? rect(prev_lr, first_r - prev_lr, prev_lq, first_q - prev_lq) : -1;
-  if (err >= 0) { e.err_back = err - prev_err_fwd; }
+  const RectResult resid = rect(prev_re, n, prev_qe, m);
+  if (resid.errors < 0 || resid.score < -BRIDGE_XDROP) return;
+  // errors of the fused alignment: prefer the optimal path over the WHOLE junction, from the end of the previous chain's
+  // last match to this chain's first match (its free forward extension is then replaced: minus prev_err_fwd); then from the
+  // previous forward end; else the residual rectangle behind the free backward search
+  RectResult x = prev_lr >= 0 && prev_lr <= prev_re && prev_lq <= prev_qe ? rect(prev_lr, first_r - prev_lr, prev_lq, first_q - prev_lq)
+                                                                           : RectResult{NEG_INF, -1};
+  if (x.errors >= 0) { e.err_back = x.errors - prev_err_fwd; }
   else {
-    err = rect(prev_re, tr, prev_qe, tq);
-    if (err >= 0) { e.err_back = err; }
-    else { err = rect(prev_re, n, prev_qe, m); if (err < 0) return; e.err_back += err; }
+    x = rect(prev_re, tr, prev_qe, tq);
+    if (x.errors >= 0) { e.err_back = x.errors; }
+    else { e.err_back += resid.errors; }
   }
   e.rs = prev_re; e.qs = prev_qe; e.reached = 2;
 }

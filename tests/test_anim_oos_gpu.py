@@ -81,25 +81,29 @@ def _worst(report, field):
 
 
 def test_oos_record_level_agreement(oos):
-    """Every pair: at least 90 % of MUMmer's alignment records reproduced coordinate for coordinate with the same error count
-    (first unfitted score: 95.5 % over all, 91.7 % on the worst pair), and the near-identical pairs exactly."""
+    """Every pair: at least 97.5 % of MUMmer's alignment records reproduced coordinate for coordinate with the same error count
+    (first unfitted score: 95.5 % over all, 91.7 % on the worst pair; with the X-drop rule for junction bridges, the one rule
+    changed after looking at these files: 99.3 % over all — DESIGN.md §8), the 99.99 % pairs exactly; Group_2 (draft genomes,
+    never used for any fitting): 27 / 31 and 30 / 32 records."""
     assert len(oos) == 26
     for name, r in oos.items():
-        assert r["exact"] >= 0.90 * r["mummer_records"], (name, r["exact"], r["mummer_records"])
+        floor = 0.85 if name.startswith("group2") else 0.975
+        assert r["exact"] >= floor * r["mummer_records"], (name, r["exact"], r["mummer_records"])
     for name in ("caulobacter/NC_002696_vs_NC_011916", "caulobacter/NC_011916_vs_NC_002696", "jspecies/NC_002696_vs_NC_011916",
                  "jspecies/NC_011916_vs_NC_002696"):
         assert oos[name]["exact"] == oos[name]["mummer_records"] == oos[name]["ours"], name
     tot = sum(r["mummer_records"] for r in oos.values())
-    assert sum(r["exact"] for r in oos.values()) >= 0.95 * tot
+    assert sum(r["exact"] for r in oos.values()) >= 0.99 * tot
 
 
 def test_oos_identity_and_coverage_level_reached(oos):
     """parse_delta tuples of the engine's records vs MUMmer's, filtered and unfiltered: the level reached out of sample."""
-    assert _worst(oos, "identity_abs_diff") < 3e-3
-    assert _worst(oos, "ref_aln_len_rel_diff") < 3e-3 and _worst(oos, "qry_aln_len_rel_diff") < 3e-3
+    assert _worst(oos, "identity_abs_diff") < 1.5e-4           # host build of the same core: 1.34e-4 (Group_2), 7.0e-5 filtered
+    assert _worst(oos, "ref_aln_len_rel_diff") < 2e-4 and _worst(oos, "qry_aln_len_rel_diff") < 6e-4
 
 
-@pytest.mark.xfail(strict=False, reason="BASELINE.json's bar (identity / coverage within 1e-4) is not yet met on the 85 % pairs")
+@pytest.mark.xfail(strict=False, reason="BASELINE.json's bar (identity / coverage within 1e-4) is met for the filtered identity "
+                                        "(7e-5) but not yet for every aligned length (1.7e-4 filtered, 4.9e-4 unfiltered)")
 def test_oos_identity_and_coverage_within_baseline_bar(oos):
     assert _worst(oos, "identity_abs_diff") < 1e-4
     assert _worst(oos, "ref_aln_len_rel_diff") < 1e-4 and _worst(oos, "qry_aln_len_rel_diff") < 1e-4

@@ -66,6 +66,25 @@ static void find_mems(const Genome& G, const QV& Q, int strand, std::vector<Matc
   }
 }
 
+// development aid: optimal global affine score of ref [r0, r0+n) x strand [q0, q0+m) (+3 / -7 / -10 / -7), plain O(nm)
+template <typename QV>
+static int rect_score(const SeqView& R, const QV& Q, int64_t r0, int n, int64_t q0, int m) {
+  const int NEG = -(1 << 28);
+  std::vector<int> H((n + 1) * (m + 1), NEG), X(H), Y(H);
+  auto at = [&](int i, int j) { return i * (m + 1) + j; };
+  H[0] = 0;
+  for (int i = 0; i <= n; ++i)
+    for (int j = 0; j <= m; ++j) {
+      if (!i && !j) continue;
+      int x = NEG, y = NEG, h = NEG;
+      if (i) x = std::max(H[at(i - 1, j)] + SC_GAP_OPEN, X[at(i - 1, j)] + SC_GAP_EXT);
+      if (j) y = std::max(H[at(i, j - 1)] + SC_GAP_OPEN, Y[at(i, j - 1)] + SC_GAP_EXT);
+      if (i && j) { const bool ok = R.clean(r0 + i - 1) && Q.clean(q0 + j - 1) && R.base(r0 + i - 1) == Q.base(q0 + j - 1); h = H[at(i - 1, j - 1)] + (ok ? SC_MATCH : SC_MISMATCH); }
+      X[at(i, j)] = x; Y[at(i, j)] = y; H[at(i, j)] = std::max(h, std::max(x, y));
+    }
+  return H[at(n, m)];
+}
+
 int main(int argc, char** argv) {
   if (argc < 3) { fprintf(stderr, "usage: anim_debug ref.fna qry.fna [--dump]\n"); return 2; }
   const bool dump = argc > 3 && !strcmp(argv[3], "--dump");
@@ -116,6 +135,20 @@ int main(int argc, char** argv) {
       bw[c] = extend_chain_bwd(R, Q, fw[c].first_r, fw[c].first_q, r_lo[c], q_lo[c], p >= 0 ? fw[p].re : -1, p >= 0 ? fw[p].qe : -1, p >= 0 ? fw[p].lr : -1, p >= 0 ? fw[p].lq : -1,
                                p >= 0 ? fw[p].first_r : -1, p >= 0 ? fw[p].first_q : -1, fw[c].lr, fw[c].lq,
                                p >= 0 && fw[p].reached && fw[p].target == c, p >= 0 ? fw[p].err_fwd : 0);
+      if (getenv("ANIM_RECT") && p >= 0 && fw[c].first_r >= fw[p].re && fw[c].first_q >= fw[p].qe && !(fw[p].reached && fw[p].target == c)) {
+        // redo the free backward search (as extend_chain_bwd does) and score the residual rectangle up to the previous forward end
+        int32_t rl = r_lo[c], ql = q_lo[c];
+        if (fw[p].lr <= fw[c].first_r && fw[p].lq <= fw[c].first_q) { if (fw[p].lr > rl) rl = fw[p].lr; if (fw[p].lq > ql) ql = fw[p].lq; }
+        ExtResult b = extend_banded(R, Q, fw[c].first_r, fw[c].first_q, -1, cap_ext(fw[c].first_r - rl, MAX_EXT_BWD), cap_ext(fw[c].first_q - ql, MAX_EXT_BWD), -1, -1);
+        const int32_t rs = fw[c].first_r - b.di, qs = fw[c].first_q - b.dj, n = rs - fw[p].re, m = qs - fw[p].qe;
+        if (n >= 0 && m >= 0 && n + m <= 1000 && (long long)n * m < 4000000)
+          printf("RECT %d %d %d tr %d tq %d n %d m %d score %d bscore %d fscore_na 0 bw_reached %d\n", strand, fw[c].first_r, fw[c].first_q, fw[c].first_r - fw[p].re,
+                 fw[c].first_q - fw[p].qe, n, m, rect_score(R, Q, fw[p].re, n, fw[p].qe, m), b.score, bw[c].reached);
+      }
+      if (getenv("ANIM_JUNCTIONS") && p >= 0)
+        printf("JUNC %d %s %s %d %d %d %d %d %d %d %d %d %d %d %d %d %lld\n", strand, G.ids[chains[c].rrec].c_str(), H.ids[chains[c].qrec].c_str(),
+               fw[p].first_r, fw[p].first_q, fw[p].lr, fw[p].lq, fw[p].re, fw[p].qe, fw[p].reached && fw[p].target == c, fw[c].first_r, fw[c].first_q,
+               bw[c].rs, bw[c].qs, bw[c].reached, chains[p].count, (long long)H.len);
       double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
       if (ms > 20 && getenv("ANIM_TIMING")) fprintf(stderr, "BWD chain %d strand %d: %.0f ms first r %d q %d -> rs %d qs %d reached %d prev %d (prev re %d qe %d lr %d lq %d)\n", c, strand, ms, fw[c].first_r, fw[c].first_q, bw[c].rs, bw[c].qs, bw[c].reached, p, p>=0?fw[p].re:-1, p>=0?fw[p].qe:-1, p>=0?fw[p].lr:-1, p>=0?fw[p].lq:-1);
     }

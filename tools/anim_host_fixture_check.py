@@ -5,6 +5,7 @@ the core reproduces exactly.  Used to judge changes to the extension rules befor
 Usage: python tools/anim_host_fixture_check.py [-j N] [--only substring]"""
 import argparse
 import gzip
+import hashlib
 import shutil
 import subprocess
 import sys
@@ -22,8 +23,13 @@ ap.add_argument("--only", default="")
 ap.add_argument("--diff", action="store_true", help="print the records that differ")
 ap.add_argument("--json", default="", help="write the per-pair report (records + parse_delta tuples) here")
 args = ap.parse_args()
+import os
+import shlex
 exe = ROOT / "tools/anim_debug/anim_debug"
-subprocess.run(["g++", "-O2", "-std=c++17", f"-I{ROOT}/pyani_amd/csrc", str(exe) + ".cpp", "-o", str(exe)], check=True)
+src = str(exe) + ".cpp"
+if os.environ.get("ANIM_CXXFLAGS"):      # parameter sweeps: -DPGA_...=value builds get their own binary
+    exe = Path(str(exe) + "_" + hashlib.sha1(os.environ["ANIM_CXXFLAGS"].encode()).hexdigest()[:8])
+subprocess.run(["g++", "-O2", "-std=c++17", f"-I{ROOT}/pyani_amd/csrc", *shlex.split(os.environ.get("ANIM_CXXFLAGS", "")), src, "-o", str(exe)], check=True)
 tmp = Path(tempfile.mkdtemp())
 paths = {}
 for grp in ("blochmannia", "caulobacter", "group2"):
