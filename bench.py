@@ -52,7 +52,7 @@ def parse_args():
     ap.add_argument("--seed", type=int, default=None, help="default: the set's own seed (C4 20250301, C2 20250228)")
     ap.add_argument("--rows-per-step", type=int, default=100, help="anim: reference genomes (grid rows) per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-pairs", type=int, default=0, help="anim: ordered pairs timed by the CPU leg (0 = one per host thread, <= 256)")
+    ap.add_argument("--cpu-pairs", type=int, default=0, help="anim: ordered pairs timed by the CPU leg (0 = one per host thread, <= 128)")
     ap.add_argument("--cpu-genomes", type=int, default=2, help="tetra: genomes timed by the CPU leg")
     ap.add_argument("--no-tetra", action="store_true", help="anim: skip the nested C2 TETRA sub-record")
     args = ap.parse_args()
@@ -89,7 +89,7 @@ def anim_cpu_baseline(args, data, n, related, gpu_lookup):
                         same search (oracle/anim_cpu.cpp: the scalar core of the engine on an exhaustive 20-mer table), one
                         pair per host thread ("own-cpu")."""
     threads = os.cpu_count() or 1
-    k = args.cpu_pairs or min(threads, 256)
+    k = args.cpu_pairs or min(threads, 128)     # bounded: ~2-10 CPU-s per pair, one pair per thread
     K = (n + 24) // 25
     rng = np.random.RandomState(12345)
     rel, unrel = [], []

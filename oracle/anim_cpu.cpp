@@ -49,9 +49,16 @@ Genome pack(const uint8_t* seq, const uint64_t* rec_off, uint32_t n_rec) {
   return g;
 }
 
-typedef std::vector<std::pair<uint64_t, int32_t>> KmerTable;
+// sorted (20-mer, position) table + a direct index on the k-mer's top INDEX_BITS bits: a lookup costs two cache misses (index,
+// bucket) instead of the ~20 of a binary search over 80 MB — this leg is a baseline, it should not be slow for no reason
+constexpr int INDEX_BITS = 22;
+struct KmerTable {
+  std::vector<std::pair<uint64_t, int32_t>> tab;
+  std::vector<uint32_t> start;   // start[b] .. start[b + 1]: entries whose k-mer has prefix b
+};
 
-void build_table(const Genome& G, KmerTable& tab) {
+void build_table(const Genome& G, KmerTable& T) {
+  auto& tab = T.tab;
   const SeqView R = G.view();
   const int K = MIN_MATCH;
   tab.clear();
@@ -65,11 +72,16 @@ void build_table(const Genome& G, KmerTable& tab) {
     if (++run >= K) tab.push_back({v, (int32_t)(p - K + 1)});
   }
   std::sort(tab.begin(), tab.end());
+  const int shift = 2 * K - INDEX_BITS;
+  T.start.assign((size_t(1) << INDEX_BITS) + 1, 0);
+  for (const auto& e : tab) ++T.start[(e.first >> shift) + 1];
+  for (size_t b = 0; b < (size_t(1) << INDEX_BITS); ++b) T.start[b + 1] += T.start[b];
 }
 
 // all maximal exact matches >= MIN_MATCH between the reference and one query strand
 template <typename QV>
-void find_mems(const Genome& G, const KmerTable& tab, const QV& Q, int strand, std::vector<Match>& out) {
+void find_mems(const Genome& G, const KmerTable& T, const QV& Q, int strand, std::vector<Match>& out) {
+  const auto& tab = T.tab;
   const SeqView R = G.view();
   const int K = MIN_MATCH;
   const uint64_t keep = (K == 32) ? ~0ull : ((1ull << (2 * K)) - 1);
@@ -80,8 +92,11 @@ void find_mems(const Genome& G, const KmerTable& tab, const QV& Q, int strand, s
     v = ((v << 2) | (uint64_t)Q.base(e)) & keep;
     if (++run < K) continue;
     const int64_t q = e - K + 1;
-    auto it = std::lower_bound(tab.begin(), tab.end(), std::make_pair(v, (int32_t)-1));
-    for (; it != tab.end() && it->first == v; ++it) {
+    const uint64_t b = v >> (2 * K - INDEX_BITS);
+    auto it = tab.begin() + T.start[b];
+    const auto bucket_end = tab.begin() + T.start[b + 1];
+    while (it != bucket_end && it->first < v) ++it;
+    for (; it != bucket_end && it->first == v; ++it) {
       const int64_t r = it->second;
       if (R.clean(r - 1) && Q.clean(q - 1) && R.base(r - 1) == Q.base(q - 1)) continue;  // not left-maximal
       int32_t L = K;

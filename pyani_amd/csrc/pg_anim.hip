@@ -349,7 +349,7 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
     PG_HIP(ctx, hipMemsetAsync(A->seed_total, 0, 8, ctx->stream));   // [0] matches, [1] hits
     PG_HIP(ctx, hipMemsetAsync(A->hit_count, 0, n_units * 4, ctx->stream));
     pg_prof_begin(ctx, PG_K_ANIM_SEED);
-    hipLaunchKernelGGL(anim_seed_kernel, dim3(SEED_GROUPS, n_refs), dim3(SEED_BLOCK), (size_t)slots * 8 + SEED_STAGE_BYTES, ctx->stream,
+    hipLaunchKernelGGL(anim_seed_kernel, dim3(n_refs, SEED_GROUPS), dim3(SEED_BLOCK), (size_t)slots * 8 + SEED_STAGE_BYTES, ctx->stream,
                        A->refs_d, A->units_d, A->srefs_d, A->sqry_d, A->slice_d, slice_stride, slots - 1, A->hits_d,
                        (uint32_t)A->hit_cap, A->seed_total + 1, A->hit_count);
     pg_prof_end(ctx);

@@ -8,6 +8,7 @@
 import collections
 import csv
 import json
+import re
 import shutil
 import sys
 from pathlib import Path
@@ -28,7 +29,8 @@ def counter_by_kernel(path, counter):
     with open(path) as fh:
         for r in csv.DictReader(fh):
             if r["Counter_Name"] == counter:
-                acc[r["Kernel_Name"].split("(")[0].split("<")[0].strip()].append(float(r["Counter_Value"]))
+                m = re.search(r"(anim_\w+|tetra_\w+|anib_\w+)", r["Kernel_Name"])
+                acc[m.group(1) if m else r["Kernel_Name"][:60]].append(float(r["Counter_Value"]))
     return acc
 
 
