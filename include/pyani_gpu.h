@@ -168,6 +168,30 @@ int pg_anib_reduce(pg_ctx* ctx, uint32_t n_pairs, const uint64_t* offsets, const
                    const int32_t* length, const int32_t* mismatch, const int32_t* gaps, const int32_t* qlen, const double* pident,
                    int64_t* aln_length_out, int64_t* sim_errors_out, double* pid_out);
 
+/* ---- ANIb fragment mode -----------------------------------------------------------------------------------
+ * In-process replacement for the BLAST+ jobs pyani builds in construct_blastn_cmdline (pyani/anib.py:451-471: the
+ * `fragsize`-nt fragments of the query genome, anib.py:164-203, searched with blastn -task blastn against the subject
+ * genome) followed by parse_blast_tab (anib.py:569-667).  One result per ORDERED pair (qry_ids[i] = the fragmented genome,
+ * sbj_ids[i] = the BLAST database genome):  aln_length = sum of (length - gaps), sim_errors = sum of (mismatch + gaps),
+ * pid = mean pident over the fragments whose best hit has coverage > 0.7 and identity > 0.3 — the tuple parse_blast_tab
+ * returns.  BLAST+ is third-party and absent from the reference tree; the search is a restatement of its documented
+ * behaviour for this command line (blastn scoring 2 / -3 / 5 / 2, X-drop 150 bits, e-value 1e-15), calibrated on the BLAST+
+ * tables the reference's tests hold (level of agreement per fixture). */
+typedef struct {
+  int64_t aln_length, sim_errors;
+  double pid;
+  int32_t n_frags, n_kept;   /* fragments of the query genome / fragments that contributed */
+  int32_t status, reserved;  /* 0 = ok, PG_E_CAPACITY = a work buffer overflowed for this pair */
+} pg_anib_result;
+int pg_anib_pairs(pg_ctx* ctx, const int32_t* qry_ids, const int32_t* sbj_ids, uint64_t n_pairs, uint32_t fragsize, pg_anib_result* out);
+/* The table of ONE ordered pair, row for row as pyani reads it (anib.py:609-624): at most 4 rows per fragment (2 strands x
+ * 2 anchors), best score first; frag = 0-based fragment ordinal (frag00001 = 0), coordinates 1-based as BLAST prints them
+ * (sstart > send on the minus strand), srec = ordinal of the subject record, score = raw alignment score. */
+typedef struct {
+  int32_t frag, length, mismatch, gaps, nident, qlen, qstart, qend, sstart, send, srec, score;
+} pg_anib_row;
+int pg_anib_pair_rows(pg_ctx* ctx, int32_t qry_id, int32_t sbj_id, uint32_t fragsize, pg_anib_row* out, uint32_t cap, uint32_t* n_out);
+
 /* ---- measurement ---------------------------------------------------------------------------------------- */
 /* When enabled, every kernel launch is bracketed by HIP events on the context's stream. */
 int pg_profile_enable(pg_ctx* ctx, int on);

@@ -1,0 +1,177 @@
+// oracle/anib_cpu.cpp — CPU statement of fragment mode (ANIb).   TEST / MEASUREMENT INFRASTRUCTURE ONLY.
+//
+// The scalar functions of pyani_amd/csrc/pg_anib_core.h (anchor choice, X-drop extension, HSP row) compiled for the HOST and fed
+// with exactly the seeds the GPU's sampled LDS seeding reports: the maximal exact matches of at least 16 bases that contain a
+// 16-mer starting at a query-strand position divisible by 5 (pga_seed.inc), found here with an exhaustive sorted 16-mer table.
+// What it restates: pyani's ANIb per ordered pair — fragment the query genome into 1020-nt pieces (anib.py:164-203), blastn
+// every piece against the subject genome (anib.py:451-471; BLAST+ is third-party, absent: see pg_anib_core.h for what is
+// restated of it and tests/golden/anib for the BLAST+ tables it is calibrated on), keep per fragment the first HSP with
+// coverage > 70 % and identity > 30 % (anib.py:641-649).  Tests compare the GPU pipeline with this row for row; bench.py may
+// time it as the own-cpu baseline of the fragment workload.  Nothing under pyani_amd/ loads this library.
+//   g++ -O2 -std=c++17 -pthread -fPIC -shared -Ipyani_amd/csrc oracle/anib_cpu.cpp -o oracle/libanibcpu.so
+#include <algorithm>
+#include <atomic>
+#include <cstdint>
+#include <cstring>
+#include <thread>
+#include <vector>
+#include "pg_anib_core.h"
+using namespace pga;
+
+namespace {
+struct Genome {
+  std::vector<uint32_t> codes, mask;
+  std::vector<int32_t> rec_start;  // stream position of each record's first base; last entry = stream length + 1
+  int64_t len = 0;
+  SeqView view() const { return SeqView{codes.data(), mask.data(), len}; }
+};
+Genome pack(const uint8_t* seq, const uint64_t* rec_off, uint32_t n_rec) {
+  Genome g;
+  int64_t len = 0;
+  for (uint32_t r = 0; r < n_rec; ++r) len += (int64_t)(rec_off[r + 1] - rec_off[r]) + (r ? 1 : 0);
+  g.len = len;
+  g.codes.assign(len / 16 + 2, 0);
+  g.mask.assign(len / 32 + 2, 0);
+  int64_t p = 0;
+  for (uint32_t r = 0; r < n_rec; ++r) {
+    if (r) ++p;
+    g.rec_start.push_back((int32_t)p);
+    for (uint64_t i = rec_off[r]; i < rec_off[r + 1]; ++i, ++p) {
+      int c = -1;
+      switch (seq[i]) { case 'A': case 'a': c = 0; break; case 'C': case 'c': c = 1; break; case 'G': case 'g': c = 2; break; case 'T': case 't': c = 3; break; }
+      if (c >= 0) { g.codes[p >> 4] |= (uint32_t)c << (2 * (p & 15)); g.mask[p >> 5] |= 1u << (p & 31); }
+    }
+  }
+  g.rec_start.push_back((int32_t)g.len + 1);
+  return g;
+}
+
+struct Row {     // = pg_anib_row (include/pyani_gpu.h)
+  int32_t frag, length, mismatch, gaps, nident, qlen, qstart, qend, sstart, send, srec, score;
+};
+
+constexpr int SEED_K = 16, SEED_STEP = 5;
+
+// the seeds of the GPU pipeline for one query strand: maximal exact matches >= 16 containing a sampled 16-mer
+template <typename QV>
+void sampled_matches(const Genome& S, const std::vector<std::pair<uint32_t, int32_t>>& tab, const std::vector<uint32_t>& start,
+                     const QV& Q, std::vector<Match>& out) {
+  const SeqView R = S.view();
+  uint32_t v = 0;
+  int run = 0;
+  for (int64_t e = 0; e < Q.len(); ++e) {
+    if (!Q.clean(e)) { run = 0; v = 0; continue; }
+    v = (v << 2) | (uint32_t)Q.base(e);
+    if (++run < SEED_K) continue;
+    const int64_t q = e - SEED_K + 1;
+    if (q % SEED_STEP) continue;
+    const uint32_t b = v >> 10;                              // 22-bit bucket of the 32-bit 16-mer
+    for (uint32_t t = start[b]; t < start[b + 1]; ++t) {
+      if (tab[t].first != v) continue;
+      const int64_t r = tab[t].second;
+      int left = 0;
+      while (left < SEED_STEP && R.clean(r - 1 - left) && Q.clean(q - 1 - left) && R.base(r - 1 - left) == Q.base(q - 1 - left)) ++left;
+      if (left == SEED_STEP) continue;                       // an earlier sampled position of the same match reports it
+      int32_t L = SEED_K;
+      while (R.clean(r + L) && Q.clean(q + L) && R.base(r + L) == Q.base(q + L)) ++L;
+      out.push_back(Match{(int32_t)(r - left), (int32_t)(q - left), left + L, 0});
+    }
+  }
+}
+
+void run_pair(const Genome& Q, const Genome& S, int32_t fragsize, std::vector<Row>& rows) {
+  const SeqView SV = S.view(), QVw = Q.view();
+  std::vector<std::pair<uint32_t, int32_t>> tab;
+  {
+    uint32_t v = 0; int run = 0;
+    for (int64_t p = 0; p < SV.len; ++p) {
+      if (!SV.clean(p)) { run = 0; v = 0; continue; }
+      v = (v << 2) | (uint32_t)SV.base(p);
+      if (++run >= SEED_K) tab.push_back({v, (int32_t)(p - SEED_K + 1)});
+    }
+    std::sort(tab.begin(), tab.end());
+  }
+  std::vector<uint32_t> start((size_t(1) << 22) + 1, 0);
+  for (const auto& e : tab) ++start[(e.first >> 10) + 1];
+  for (size_t b = 0; b < (size_t(1) << 22); ++b) start[b + 1] += start[b];
+  // fragments of the query: (stream position, length), ids run across the records (anib.py:190-200)
+  std::vector<std::pair<int32_t, int32_t>> frags;
+  std::vector<int32_t> rec_frag0;
+  for (size_t rec = 0; rec + 1 < Q.rec_start.size(); ++rec) {
+    rec_frag0.push_back((int32_t)frags.size());
+    const int32_t r0 = Q.rec_start[rec], r1 = Q.rec_start[rec + 1] - 1;
+    for (int32_t f0 = r0; f0 < r1; f0 += fragsize) frags.push_back({f0, std::min(fragsize, r1 - f0)});
+  }
+  std::vector<std::vector<FragSeed>> seeds[2];
+  for (int strand = 0; strand < 2; ++strand) {
+    seeds[strand].assign(frags.size(), {});
+    StrandView QS{QVw, strand};
+    std::vector<Match> mem;
+    sampled_matches(S, tab, start, QS, mem);
+    for (const Match& m : mem) {
+      const int64_t a = strand ? Q.len - m.q - m.len : m.q, b = a + m.len;           // forward interval of the match in the query
+      const int rec = record_of(Q.rec_start.data(), (int)Q.rec_start.size() - 1, (int32_t)a);
+      const int32_t r0 = Q.rec_start[rec];
+      for (int32_t f = rec_frag0[rec] + (int32_t)((a - r0) / fragsize); f < (int32_t)frags.size() && frags[f].first < b; ++f) {
+        const int64_t fp = frags[f].first, fe = fp + frags[f].second;
+        if (fp >= Q.rec_start[rec + 1] - 1) break;
+        const int64_t lo = std::max(a, fp), hi = std::min(b, fe);
+        if (hi - lo < FRAG_MIN_CLIP) continue;
+        FragSeed e;
+        e.len = (int32_t)(hi - lo);
+        if (!strand) { e.q = (int32_t)(lo - fp); e.s = m.r + (int32_t)(lo - a); }
+        else { e.q = (int32_t)(fe - hi); e.s = m.r + (int32_t)(b - hi); }
+        seeds[strand][f].push_back(e);
+      }
+    }
+  }
+  for (size_t f = 0; f < frags.size(); ++f) {
+    const int32_t fp = frags[f].first, qlen = frags[f].second;
+    std::vector<Row> cand;
+    for (int strand = 0; strand < 2; ++strand) {
+      std::vector<FragSeed>& e = seeds[strand][f];
+      if (e.empty()) continue;
+      std::sort(e.begin(), e.end(), [](const FragSeed& x, const FragSeed& y) { return x.len != y.len ? x.len > y.len : (x.q != y.q ? x.q < y.q : x.s < y.s); });
+      if (e.size() > (size_t)FRAG_MAX_SEEDS) e.resize(FRAG_MAX_SEEDS);
+      int pick[2];
+      const int nc = frag_pick_anchors(e.data(), (int)e.size(), pick);
+      auto q_at = [&](int64_t p) -> int {
+        if (p < 0 || p >= qlen) return 4;
+        const int64_t g = strand ? fp + (qlen - 1 - p) : fp + p;
+        if (!QVw.clean(g)) return 4;
+        return strand ? 3 - QVw.base(g) : QVw.base(g);
+      };
+      for (int c = 0; c < nc; ++c) {
+        const FragSeed& A = e[pick[c]];
+        const int srec = record_of(S.rec_start.data(), (int)S.rec_start.size() - 1, A.s);
+        const int64_t s_lo = S.rec_start[srec], s_hi = S.rec_start[srec + 1] - 1;
+        auto s_at = [&](int64_t p) -> int { return (p >= s_lo && p < s_hi && SV.clean(p)) ? SV.base(p) : 5; };
+        const FragHit h = frag_hsp(q_at, qlen, s_at, s_lo, s_hi, A.q, A.s, A.len);
+        if (!frag_evalue_ok(h.score, qlen, s_hi - s_lo)) continue;
+        Row r;
+        r.frag = (int32_t)f; r.length = h.length; r.mismatch = h.mismatch; r.gaps = h.gaps; r.nident = h.nident; r.qlen = qlen;
+        r.srec = srec; r.score = h.score;
+        if (!strand) { r.qstart = h.qs + 1; r.qend = h.qe; r.sstart = h.ss - (int32_t)s_lo + 1; r.send = h.se - (int32_t)s_lo; }
+        else { r.qstart = qlen - h.qe + 1; r.qend = qlen - h.qs; r.sstart = h.se - (int32_t)s_lo; r.send = h.ss - (int32_t)s_lo + 1; }
+        cand.push_back(r);
+      }
+    }
+    // table order: best score first (ties: plus strand first, then the first candidate) — what the reduction walks
+    std::stable_sort(cand.begin(), cand.end(), [](const Row& x, const Row& y) { return x.score > y.score; });
+    for (const Row& r : cand) rows.push_back(r);
+  }
+}
+}  // namespace
+
+extern "C" {
+// One ordered pair: rows of the BLAST-shaped table (at most 4 per fragment: 2 strands x 2 anchors), best score first within a
+// fragment.  Returns the number of rows (written up to cap).
+int64_t anib_cpu_pair(const uint8_t* qseq, const uint64_t* qrec_off, uint32_t q_nrec, const uint8_t* sseq, const uint64_t* srec_off,
+                      uint32_t s_nrec, int32_t fragsize, Row* out, uint64_t cap) {
+  const Genome Q = pack(qseq, qrec_off, q_nrec), S = pack(sseq, srec_off, s_nrec);
+  std::vector<Row> rows;
+  run_pair(Q, S, fragsize, rows);
+  for (size_t i = 0; i < rows.size() && i < cap; ++i) out[i] = rows[i];
+  return (int64_t)rows.size();
+}
+}

@@ -2,6 +2,7 @@
 
   liboracle.so    oracle/tetra_oracle.c   gcc -ffp-contract=off     TETRA restatement (tetra.py:78-194)
   libanimcpu.so   oracle/anim_cpu.cpp     g++ -pthread              host statement of the ANIm pair search (own-cpu baseline)
+  libanibcpu.so   oracle/anib_cpu.cpp     g++ -pthread              host statement of fragment mode (ANIb)
 """
 import subprocess
 import sys
@@ -37,8 +38,19 @@ def build_anim_cpu(force=False) -> Path:
     return ANIM_CPU_LIB
 
 
+ANIB_CPU_LIB = HERE / "libanibcpu.so"
+
+
+def build_anib_cpu(force=False) -> Path:
+    csrc = ROOT / "pyani_amd" / "csrc"
+    src = HERE / "anib_cpu.cpp"
+    if force or not _newer(ANIB_CPU_LIB, [src, csrc / "pg_anib_core.h", csrc / "pg_anim_core.h"]):
+        _run(["g++", "-O2", "-std=c++17", "-pthread", "-fPIC", "-shared", f"-I{csrc}", "-o", ANIB_CPU_LIB, src])
+    return ANIB_CPU_LIB
+
+
 def build_all(force=False):
-    return build_oracle(force), build_anim_cpu(force)
+    return build_oracle(force), build_anim_cpu(force), build_anib_cpu(force)
 
 
 if __name__ == "__main__":

@@ -6,9 +6,14 @@
     process_blast_results(...)            identity / coverage / lengths / errors / hadamard matrices, [q, s] cells only
                                           (process_blast, anib.py:496-565)
 
-The fragment-vs-genome SEARCH (BLAST+ `blastn -task blastn`, external, absent from the reference tree) is not
-implemented yet: fragment mode of the GPU aligner is the next §8 row.  Until then this module reduces existing
-`.blast_tab` files exactly as pyani does.
+    calculate_anib_pairs(infiles)         all N(N-1) ordered comparisons on the GPU: fragment search + reduction
+                                          (what generate_blastn_commands + the BLAST jobs + parse_blast_tab produce, anib.py:383-667)
+    anib_pair_table / write_blast_tab     one pair's table in BLAST+'s 15-column layout (anib.py:465-471), which pyani's own
+                                          parse_blast_tab reads back
+
+The fragment-vs-genome SEARCH replaces BLAST+ (`blastn -task blastn`, third-party, absent from the reference tree) with the
+engine's fragment mode (pg_anib_pairs: seeds from the LDS-table seeding, X-drop gapped extension with blastn's scores);
+how closely it follows BLAST+'s own tables on the reference's fixtures is stated in DESIGN.md.
 """
 import gzip
 from pathlib import Path
@@ -114,6 +119,48 @@ def parse_blast_tab(filename, engine: Engine = None) -> Tuple[int, int, float]:
     eng = engine or default_engine()
     aln, err, pid = eng.anib_reduce([read_blast_tab(filename)])
     return int(aln[0]), int(err[0]), float(pid[0])
+
+
+def calculate_anib_pairs(infiles: Iterable, engine: Engine = None, fragsize: int = FRAGSIZE
+                         ) -> Tuple[Dict[Tuple[str, str], Tuple[int, int, float]], Dict[str, int]]:
+    """All ordered comparisons between the FASTA files: {(query stem, subject stem): (aln_length, sim_errors, mean pident)}
+    — parse_blast_tab's tuple for `<query>_vs_<subject>.blast_tab` — and the genome lengths keyed by stem."""
+    eng = engine or default_engine()
+    files = sorted(Path(f) for f in infiles)
+    stems = [f.stem for f in files]
+    if len(set(stems)) != len(stems):
+        raise ValueError("two input files share a stem (pyani keys every result by Path.stem)")
+    scratch_store = eng.genome_count() == 0
+    ids, lengths = {}, {}
+    try:
+        for f, (gid, total, _) in zip(files, eng.add_fasta_batch(files)):
+            ids[f.stem], lengths[f.stem] = gid, total
+        pairs = [(a, b) for a in stems for b in stems if a != b]
+        recs = eng.anib_pairs([ids[a] for a, _ in pairs], [ids[b] for _, b in pairs], fragsize)
+    finally:
+        if scratch_store:
+            eng.clear_genomes()
+    out = {}
+    for (a, b), r in zip(pairs, recs):
+        if int(r["status"]) != 0:
+            raise RuntimeError(f"GPU ANIb comparison {a} vs {b} failed with status {int(r['status'])}")
+        out[(a, b)] = (int(r["aln_length"]), int(r["sim_errors"]), float(r["pid"]))
+    return out, lengths
+
+
+def write_blast_tab(path, rows, subject_ids: List[str], subject_lengths: List[int]) -> int:
+    """Engine.anib_pair_rows -> a `.blast_tab` file in the column layout pyani asks BLAST+ for (anib.py:465-471):
+    qseqid sseqid length mismatch pident nident qlen slen qstart qend sstart send positive ppos gaps.
+    subject_ids / subject_lengths: id and length of every record of the subject FASTA.  Returns the number of rows."""
+    with open(path, "w") as fh:
+        for r in rows:
+            pid = 100.0 * int(r["nident"]) / int(r["length"])
+            rec = int(r["srec"])
+            fh.write("\t".join(str(x) for x in (
+                "frag%05d" % (int(r["frag"]) + 1), subject_ids[rec], int(r["length"]), int(r["mismatch"]), "%.3f" % pid, int(r["nident"]),
+                int(r["qlen"]), subject_lengths[rec], int(r["qstart"]), int(r["qend"]), int(r["sstart"]), int(r["send"]),
+                int(r["nident"]), "%.2f" % pid, int(r["gaps"]))) + "\n")
+    return len(rows)
 
 
 def process_blast_results(pair_results: Dict[Tuple[str, str], Tuple[int, int, float]], org_lengths: Dict[str, int]

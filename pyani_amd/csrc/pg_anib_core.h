@@ -1,7 +1,7 @@
 // pg_anib_core.h — fragment mode of the aligner (BASELINE.json configs[4]): the search pyani's ANIb
 // delegates to BLAST+,   blastn -task blastn -query <1020-nt fragments of genome Q> -db <genome S> -xdrop_gap_final 150
 // -dust no -evalue 1e-15 -max_target_seqs 1   (pyani/anib.py:451-471), as plain C++ that compiles for the device (hipcc)
-// AND for the host (tools/anib_debug, oracle/): every fragment gets its best local alignment against the subject genome,
+// AND for the host (the development harness and the CPU checker build): every fragment gets its best local alignment against the subject genome,
 // described by the columns pyani reads from the BLAST table (anib.py:609-624):
 //     length (alignment columns), mismatch, gaps (gap characters), nident -> pident = 100 * nident / length,
 //     qstart / qend (1-based in the fragment), sstart / send (1-based in the subject record, sstart > send on the minus strand)
@@ -18,6 +18,7 @@
 // is kept.  Ties: diagonal move, then gap in the subject (query base consumed), then gap in the query — and among cells of equal
 // score the earliest anti-diagonal, then the lowest diagonal; host and device walk the same cells in the same order.
 #pragma once
+#include <cmath>
 #include "pg_anim_core.h"
 
 namespace pga {
@@ -25,13 +26,10 @@ namespace pga {
 constexpr int FRAG_SIZE = 1020;                 // pyani_config.FRAGSIZE
 constexpr int FRAG_MATCH = 2, FRAG_MISMATCH = -3, FRAG_GAP_OPEN = -7, FRAG_GAP_EXT = -2;   // first gap base -(5 + 2), further -2
 #ifndef PGA_FRAG_BAND
-#define PGA_FRAG_BAND 64
+#define PGA_FRAG_BAND 256
 #endif
-constexpr int FRAG_BAND = PGA_FRAG_BAND;                   // diagonals of the DP band (one lane each on the device)
+constexpr int FRAG_BAND = PGA_FRAG_BAND;                   // diagonals of the DP band (4 per lane on the device): a 5 + 2k gap of ~80 bases still fits the X-drop
 constexpr int FRAG_SLACK = 200;                // subject bases an extension may use beyond the fragment's own length
-
-struct FragStat { int32_t mm, gaps; };            // mismatches and gap bases of the best path into a DP state
-struct FragCell { int32_t h, x, y; FragStat hs, xs, ys; };   // H: any end; X: ends in a gap consuming a query base; Y: ... a subject base
 
 struct FragExt {             // one directional extension off an anchor
   int32_t score;             // best score (>= 0; 0 = no extension)
@@ -48,79 +46,83 @@ struct FragHit {             // one HSP: the row of the BLAST table
 
 // Gapped X-drop extension off an anchor, as BLAST grows an HSP from a seed: cell (0, 0) scores 0, qbase(t) / sbase(t) give the
 // t-th base away from the anchor in the direction of the extension (0..3; 4 / 5 for dirty or out of range: never equal), at most
-// qmax / smax bases.  Anti-diagonal order; the band covers the FRAG_BAND diagonals K = j - i in [koff, koff + FRAG_BAND), starts
-// centred on the anchor's diagonal and FOLLOWS the alignment: every FRAG_TRACK anti-diagonals it is re-centred on the diagonal of
-// the best live H (ties: lowest diagonal), by an even number of diagonals (the cell / anti-diagonal parity pattern is kept),
-// at most FRAG_SHIFT_MAX; states that leave the band are lost, new ones start dead.  A cell more than FRAG_XDROP below the best
-// score so far is dead (BLAST's -xdrop_gap_final 150 bits = 166 in raw 2 / -3 scores); the search ends when a whole anti-diagonal
-// pair is dead.  The end is the best cell (ties: earliest anti-diagonal, then lowest diagonal).  On the device the 64 lanes of a
-// wave are the 64 diagonals and a re-centring is one wave shift of the state registers.
+// qmax / smax bases.  Anti-diagonal order (d = i + j); the band covers the FRAG_BAND diagonals K = j - i in [koff, koff + FRAG_BAND),
+// starts centred on the anchor's diagonal and FOLLOWS the alignment: before every FRAG_TRACK-th anti-diagonal it is re-centred on
+// the diagonal of the best live H (ties: lowest diagonal), by an even number of diagonals (the cell / anti-diagonal parity pattern
+// is kept), at most FRAG_SHIFT_MAX; states that leave the band are lost, new ones start dead.  A state more than FRAG_XDROP below
+// `xbest` is dead (BLAST's -xdrop_gap_final 150 bits = 166 in raw 2 / -3 scores), xbest being the best score as it stood before the
+// last anti-diagonal that is a multiple of FRAG_XSYNC (a wave refreshes its shared copy that often); the search ends after two
+// dead anti-diagonals.  The end is the best cell: highest score, ties -> earliest anti-diagonal, then lowest diagonal.
+// The device version (pga_frag.inc: the band in LDS, 4 diagonals per lane) walks the same cells and applies the same rules.
 #ifndef PGA_FRAG_XDROP
 #define PGA_FRAG_XDROP 166
 #endif
-constexpr int FRAG_TRACK = 16, FRAG_SHIFT_MAX = 8, FRAG_XDROP = PGA_FRAG_XDROP;
+constexpr int FRAG_TRACK = 16, FRAG_SHIFT_MAX = 8, FRAG_XDROP = PGA_FRAG_XDROP, FRAG_XSYNC = 4;
+constexpr int32_t FRAG_NEG = -(1 << 28);
+
+// one cell: u = state of diagonal K+1 (cell (i-1, j)), l = diagonal K-1 (cell (i, j-1)), g = this diagonal's previous cell (i-1, j-1)
+struct FragCellIn { int32_t h, x, y, hs, xs, ys; };      // stats packed: mismatches << 16 | gap bases
+PG_HD FragCellIn frag_cell(bool has_u, const FragCellIn& u, bool has_l, const FragCellIn& l, bool has_g, const FragCellIn& g, bool ok,
+                           int32_t xbest) {
+  FragCellIn c{FRAG_NEG, FRAG_NEG, FRAG_NEG, 0, 0, 0};
+  if (has_u) {                                           // X: gap consuming a query base (ties: extend the open gap)
+    const int32_t ho = u.h + FRAG_GAP_OPEN, xo = u.x + FRAG_GAP_EXT;
+    if (u.x > FRAG_NEG / 2 && xo >= ho) { c.x = xo; c.xs = u.xs + 1; } else if (u.h > FRAG_NEG / 2) { c.x = ho; c.xs = u.hs + 1; }
+  }
+  if (has_l) {                                           // Y: gap consuming a subject base
+    const int32_t ho = l.h + FRAG_GAP_OPEN, yo = l.y + FRAG_GAP_EXT;
+    if (l.y > FRAG_NEG / 2 && yo >= ho) { c.y = yo; c.ys = l.ys + 1; } else if (l.h > FRAG_NEG / 2) { c.y = ho; c.ys = l.hs + 1; }
+  }
+  if (has_g && g.h > FRAG_NEG / 2) { c.h = g.h + (ok ? FRAG_MATCH : FRAG_MISMATCH); c.hs = g.hs + (ok ? 0 : 65536); }
+  if (c.x > c.h) { c.h = c.x; c.hs = c.xs; }
+  if (c.y > c.h) { c.h = c.y; c.hs = c.ys; }
+  if (c.h < xbest - FRAG_XDROP) c.h = FRAG_NEG;
+  if (c.x < xbest - FRAG_XDROP) c.x = FRAG_NEG;
+  if (c.y < xbest - FRAG_XDROP) c.y = FRAG_NEG;
+  return c;
+}
+
 template <typename QB, typename SB>
 PG_HD FragExt frag_extend(QB&& qbase, int32_t qmax, SB&& sbase, int32_t smax) {
-  constexpr int32_t NEG = -(1 << 28);
-  FragCell cur[FRAG_BAND], prv[FRAG_BAND];   // latest cell of every diagonal (index k <-> diagonal K = k + koff)
-  const FragStat z{0, 0};
-  const FragCell dead{NEG, NEG, NEG, z, z, z};
-  for (int k = 0; k < FRAG_BAND; ++k) cur[k] = dead;
+  if (qmax <= 0 || smax <= 0) return FragExt{0, 0, 0, 0, 0};   // nothing to extend into (the anchor reaches the fragment's end)
+  FragCellIn S[FRAG_BAND];                  // latest cell of every diagonal (index k <-> diagonal K = k + koff)
+  const FragCellIn dead{FRAG_NEG, FRAG_NEG, FRAG_NEG, 0, 0, 0};
+  for (int k = 0; k < FRAG_BAND; ++k) S[k] = dead;
   int32_t koff = -FRAG_BAND / 2;
-  cur[0 - koff].h = 0;                       // the anchor cell (0, 0) on diagonal 0
+  S[0 - koff].h = 0;                        // the anchor cell (0, 0) on diagonal 0
   FragExt best{0, 0, 0, 0, 0};
+  int32_t xbest = 0;
   int dead_run = 0;
   for (int32_t d = 1; d <= qmax + smax; ++d) {
-    if ((d % FRAG_TRACK) == 0) {             // re-centre the band on the best live H
-      int32_t bh = NEG / 2, bk = -1;
-      for (int k = 0; k < FRAG_BAND; ++k) if (cur[k].h > bh) { bh = cur[k].h; bk = k; }
+    if ((d % FRAG_TRACK) == 0) {            // re-centre the band on the best live H
+      int32_t bh = FRAG_NEG / 2, bk = -1;
+      for (int k = 0; k < FRAG_BAND; ++k) if (S[k].h > bh) { bh = S[k].h; bk = k; }
       if (bk >= 0) {
         int32_t s = bk - FRAG_BAND / 2;
         if (s > FRAG_SHIFT_MAX) s = FRAG_SHIFT_MAX;
         if (s < -FRAG_SHIFT_MAX) s = -FRAG_SHIFT_MAX;
         s &= ~1;
-        if (s != 0) {
-          for (int k = 0; k < FRAG_BAND; ++k) prv[k] = cur[k];
-          for (int k = 0; k < FRAG_BAND; ++k) { const int f = k + s; cur[k] = (f >= 0 && f < FRAG_BAND) ? prv[f] : dead; }
-          koff += s;
-        }
+        if (s > 0) { for (int k = 0; k < FRAG_BAND; ++k) S[k] = k + s < FRAG_BAND ? S[k + s] : dead; }
+        if (s < 0) { for (int k = FRAG_BAND - 1; k >= 0; --k) S[k] = k + s >= 0 ? S[k + s] : dead; }
+        koff += s;
       }
     }
-    for (int k = 0; k < FRAG_BAND; ++k) prv[k] = cur[k];
+    if ((d % FRAG_XSYNC) == 0) xbest = best.score;
     bool alive = false;
+    // cells of one anti-diagonal read only diagonals of the other parity (last written one step ago) and their own previous
+    // cell (two steps ago), so updating in place is the same as updating from a copy
     for (int k = 0; k < FRAG_BAND; ++k) {
       const int32_t K = k + koff;
-      if ((d + K) & 1) continue;                       // no cell of this diagonal on this anti-diagonal
+      if ((d + K) & 1) continue;
       const int32_t i = (d - K) / 2, j = (d + K) / 2;
-      if (i < 0 || j < 0 || i > qmax || j > smax) { cur[k] = dead; continue; }
-      FragCell c = dead;
-      if (i >= 1 && k + 1 < FRAG_BAND) {               // X: gap consuming a query base, from (i-1, j): diagonal K+1
-        const FragCell& u = prv[k + 1];
-        const int32_t ho = u.h + FRAG_GAP_OPEN, xo = u.x + FRAG_GAP_EXT;
-        if (u.x > NEG / 2 && xo >= ho) { c.x = xo; c.xs = u.xs; } else if (u.h > NEG / 2) { c.x = ho; c.xs = u.hs; }
-        if (c.x > NEG / 2) c.xs.gaps += 1;
-      }
-      if (j >= 1 && k >= 1) {                          // Y: gap consuming a subject base, from (i, j-1): diagonal K-1
-        const FragCell& l = prv[k - 1];
-        const int32_t ho = l.h + FRAG_GAP_OPEN, yo = l.y + FRAG_GAP_EXT;
-        if (l.y > NEG / 2 && yo >= ho) { c.y = yo; c.ys = l.ys; } else if (l.h > NEG / 2) { c.y = ho; c.ys = l.hs; }
-        if (c.y > NEG / 2) c.ys.gaps += 1;
-      }
-      if (i >= 1 && j >= 1 && prv[k].h > NEG / 2) {    // H: diagonal move from (i-1, j-1): same diagonal, anti-diagonal d-2
-        const int qb = qbase(i - 1), sb = sbase(j - 1);
-        const bool ok = qb < 4 && qb == sb;
-        c.h = prv[k].h + (ok ? FRAG_MATCH : FRAG_MISMATCH);
-        c.hs = prv[k].hs;
-        if (!ok) c.hs.mm += 1;
-      }
-      if (c.x > c.h) { c.h = c.x; c.hs = c.xs; }
-      if (c.y > c.h) { c.h = c.y; c.hs = c.ys; }
-      if (c.h < best.score - FRAG_XDROP) c.h = NEG;    // X-drop
-      if (c.x < best.score - FRAG_XDROP) c.x = NEG;
-      if (c.y < best.score - FRAG_XDROP) c.y = NEG;
-      cur[k] = c;
-      if (c.h > NEG / 2 || c.x > NEG / 2 || c.y > NEG / 2) alive = true;
-      if (c.h > best.score) { best.score = c.h; best.di = i; best.dj = j; best.mm = c.hs.mm; best.gaps = c.hs.gaps; }
+      if (i < 0 || j < 0 || i > qmax || j > smax) { S[k] = dead; continue; }
+      bool ok = false;
+      if (i >= 1 && j >= 1) { const int qb = qbase(i - 1), sb = sbase(j - 1); ok = qb < 4 && qb == sb; }
+      const FragCellIn c = frag_cell(i >= 1 && k + 1 < FRAG_BAND, S[k + 1 < FRAG_BAND ? k + 1 : k], j >= 1 && k >= 1, S[k >= 1 ? k - 1 : k],
+                                     i >= 1 && j >= 1, S[k], ok, xbest);
+      S[k] = c;
+      if (c.h > FRAG_NEG / 2 || c.x > FRAG_NEG / 2 || c.y > FRAG_NEG / 2) alive = true;
+      if (c.h > best.score) { best.score = c.h; best.di = i; best.dj = j; best.mm = c.hs >> 16; best.gaps = c.hs & 0xFFFF; }
     }
     dead_run = alive ? 0 : dead_run + 1;
     if (dead_run >= 2) break;
@@ -128,14 +130,8 @@ PG_HD FragExt frag_extend(QB&& qbase, int32_t qmax, SB&& sbase, int32_t smax) {
   return best;
 }
 
-// The HSP grown from an exact anchor  query [aq, aq + alen)  ==  subject [as, as + alen)  (both within their limits): leftward
-// and rightward extension + the anchor itself.  q_at(p) / s_at(p): base at absolute query / subject position p (4 / 5 outside).
-template <typename QA, typename SA>
-PG_HD FragHit frag_hsp(QA&& q_at, int32_t qlen, SA&& s_at, int64_t s_lo, int64_t s_hi, int32_t aq, int64_t as, int32_t alen) {
-  const FragExt R = frag_extend([&](int32_t t) { return q_at(aq + alen + t); }, qlen - (aq + alen),
-                                [&](int32_t t) { return s_at(as + alen + t); }, (int32_t)(s_hi - (as + alen) < FRAG_SIZE + FRAG_SLACK ? s_hi - (as + alen) : FRAG_SIZE + FRAG_SLACK));
-  const FragExt L = frag_extend([&](int32_t t) { return q_at(aq - 1 - t); }, aq,
-                                [&](int32_t t) { return s_at(as - 1 - t); }, (int32_t)(as - s_lo < FRAG_SIZE + FRAG_SLACK ? as - s_lo : FRAG_SIZE + FRAG_SLACK));
+// left extension + anchor + right extension -> the HSP's table row
+PG_HD FragHit frag_join(const FragExt& L, const FragExt& R, int32_t aq, int64_t as, int32_t alen) {
   FragHit h;
   h.score = FRAG_MATCH * alen + L.score + R.score;
   h.qs = aq - L.di; h.qe = aq + alen + R.di;
@@ -144,6 +140,61 @@ PG_HD FragHit frag_hsp(QA&& q_at, int32_t qlen, SA&& s_at, int64_t s_lo, int64_t
   const int32_t m = ((h.qe - h.qs) + (h.se - h.ss) - h.gaps) / 2;       // diagonal columns
   h.length = m + h.gaps; h.nident = m - h.mismatch;
   return h;
+}
+
+// ---- anchors ---------------------------------------------------------------------------------------------------------
+// The exact matches of one (fragment, strand), clipped to the fragment: s = subject stream position, q = position in the fragment
+// (on the searched strand), len.  Candidate anchors: every match scores the total length of the matches within FRAG_VOTE_WIN
+// diagonals of its own; the first candidate is the match with the highest (score, len, -q, -s), the second the best one at least
+// FRAG_VOTE_FAR diagonals away from the first.  Returns the number of candidates (0..2), their indices in cand[].
+struct FragSeed { int32_t s, q, len; };
+constexpr int FRAG_VOTE_WIN = 16, FRAG_VOTE_FAR = 48, FRAG_MAX_SEEDS = 64, FRAG_MIN_CLIP = 11;
+PG_HD int frag_pick_anchors(const FragSeed* e, int n, int* cand) {
+  int nc = 0;
+  int64_t first_diag = 0;
+  for (int round = 0; round < 2; ++round) {
+    int best = -1;
+    int64_t best_votes = -1;
+    for (int a = 0; a < n; ++a) {
+      const int64_t da = (int64_t)e[a].s - e[a].q;
+      if (round == 1 && (da - first_diag < FRAG_VOTE_FAR && first_diag - da < FRAG_VOTE_FAR)) continue;
+      int64_t votes = 0;
+      for (int b = 0; b < n; ++b) {
+        const int64_t db = (int64_t)e[b].s - e[b].q;
+        if (db - da <= FRAG_VOTE_WIN && da - db <= FRAG_VOTE_WIN) votes += e[b].len;
+      }
+      bool better = best < 0 || votes > best_votes;
+      if (!better && votes == best_votes) {
+        const FragSeed& o = e[best];
+        better = e[a].len > o.len || (e[a].len == o.len && (e[a].q < o.q || (e[a].q == o.q && e[a].s < o.s)));
+      }
+      if (better) { best = a; best_votes = votes; }
+    }
+    if (best < 0) break;
+    cand[nc++] = best;
+    first_diag = (int64_t)e[best].s - e[best].q;
+  }
+  return nc;
+}
+
+// BLAST's e-value for raw score S (blastn 2 / -3, gap costs 5 / 2: lambda = 0.625, K = 0.41), search space m * n without length
+// adjustment; pyani runs blastn with -evalue 1e-15 (anib.py:466).
+PG_HD bool frag_evalue_ok(int32_t score, int32_t qlen, int64_t slen) {
+  const double bits_nat = 0.625 * (double)score - (-0.8915981192837836);   // lambda * S - ln K
+  return (double)qlen * (double)slen * exp(-bits_nat) <= 1e-15;
+}
+
+// The HSP grown from an exact anchor  query [aq, aq + alen)  ==  subject [as, as + alen)  (both within their limits): leftward
+// and rightward extension + the anchor itself.  q_at(p) / s_at(p): base at absolute query / subject position p (4 / 5 outside).
+template <typename QA, typename SA>
+PG_HD FragHit frag_hsp(QA&& q_at, int32_t qlen, SA&& s_at, int64_t s_lo, int64_t s_hi, int32_t aq, int64_t as, int32_t alen) {
+  const int64_t room_r = s_hi - (as + alen), room_l = as - s_lo;
+  const int32_t cap = FRAG_SIZE + FRAG_SLACK;
+  const FragExt R = frag_extend([&](int32_t t) { return q_at(aq + alen + t); }, qlen - (aq + alen),
+                                [&](int32_t t) { return s_at(as + alen + t); }, (int32_t)(room_r < cap ? room_r : cap));
+  const FragExt L = frag_extend([&](int32_t t) { return q_at(aq - 1 - t); }, aq,
+                                [&](int32_t t) { return s_at(as - 1 - t); }, (int32_t)(room_l < cap ? room_l : cap));
+  return frag_join(L, R, aq, as, alen);
 }
 
 }  // namespace pga

@@ -29,12 +29,14 @@
 // group must fit a 16384-slot LDS table; PG_E_CAPACITY otherwise), chain scores < 2^24.
 #include "pg_internal.h"
 #include "pg_anim_core.h"
+#include "pg_anib_core.h"
 
 using namespace pga;
 
 namespace {
 
 constexpr unsigned long long SLOT_EMPTY = ~0ull;
+constexpr int FRAG_SEED_MIN = 16;   // fragment mode keeps every sampled 16-mer hit (SEED_K)
 constexpr int MAX_HITS = 4096;  // copies of one seed k-mer examined per lookup (a bound for pathological repeats only)
 
 struct RefDesc {
@@ -72,6 +74,7 @@ __device__ __forceinline__ void get16(const uint32_t* __restrict__ codes, const 
 #include "pga_dp_wave.inc"
 #include "pga_dp_lane.inc"
 #include "pga_finish.inc"
+#include "pga_frag.inc"
 
 }  // namespace
 
@@ -127,6 +130,15 @@ struct AnimScratch {
   uint32_t *hit_count = nullptr, *hoff = nullptr, *hit_cursor = nullptr;   // per unit
   size_t hit_cap = 0;
   bool lds_attr_set = false;        // anim_seed_kernel's dynamic-LDS limit has been raised on this context's device
+  // fragment mode (ANIb)
+  int32_t* fr_tables = nullptr;     // frag_pos | frag_len | rec_frag0 of every distinct query genome of the batch
+  FragPair* fr_pairs = nullptr;
+  uint32_t *fr_slot_pair = nullptr, *fr_off = nullptr, *fr_nrows = nullptr;
+  uint64_t* fr_ebase = nullptr;
+  FragSeed* fr_entries = nullptr;
+  FragRow* fr_rows = nullptr;
+  pg_anib_result* fr_out = nullptr;
+  size_t fr_tables_cap = 0, fr_pairs_cap = 0, fr_slots_cap = 0, fr_off_cap = 0, fr_units_cap = 0, fr_entries_cap = 0;
 };
 
 template <typename T>
@@ -201,7 +213,8 @@ void pg_anim_free_scratch(pg_ctx* ctx) {
   pg_anim_drop_lists(ctx);
   void* ptrs[] = {A->ext_reqs, A->ext_pre, A->ext_dumps, A->ext_wave, A->ext_counts, A->gap_counts, A->task_cls, A->task_lists, A->hits_sorted, A->hit_count, A->hoff, A->hit_cursor, A->hits_d, A->slice_d, A->choff_d, A->list_cnt, A->srefs_d, A->sqry_d, A->recs_d, A->refs_d, A->units_d, A->mem_count, A->moff, A->nch, A->status, A->out, A->mem, A->cm,
                   A->iscratch, A->order, A->prev, A->next, A->alnof, A->chains, A->fw, A->bw, A->S.alns, A->S.a_rrec,
-                  A->S.a_qrec, A->S.idx, A->S.from, A->S.sc, A->wl_d, A->seedbuf, A->seed_total, A->tasks_d};
+                  A->S.a_qrec, A->S.idx, A->S.from, A->S.sc, A->wl_d, A->seedbuf, A->seed_total, A->tasks_d, A->fr_tables, A->fr_pairs,
+                  A->fr_slot_pair, A->fr_off, A->fr_nrows, A->fr_ebase, A->fr_entries, A->fr_rows, A->fr_out};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   delete A;
   ctx->anim_scratch = nullptr;
@@ -211,12 +224,31 @@ void pg_anim_free_scratch(pg_ctx* ctx) {
 // per (pair, strand) unit; a scatter then gives every per-match array exactly the slice it needs, which is what lets
 // thousands of units be in flight at once within the HBM budget.
 // If the batch needs more than max_matches, only its first n_done pairs are processed (the caller continues from there).
+static_assert(sizeof(FragRow) == sizeof(pg_anib_row), "FragRow is pg_anib_row");
+static int anib_frag_stage(pg_ctx* ctx, AnimScratch* A, const int32_t* qry_ids, uint32_t n_pairs, const std::vector<uint32_t>& cnt,
+                           const PgFragArgs& F);
+
 int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_ids, uint32_t n_pairs, int filter_1to1, int maxmatch,
-                      uint64_t max_matches, pg_anim_result* out_host, uint32_t* n_done) {
+                      uint64_t max_matches, pg_anim_result* out_host, uint32_t* n_done, const PgFragArgs* frag) {
   AnimScratch* A = anim_scratch(ctx);
-  uint32_t n_units = 2 * n_pairs;
   int rc;
   (void)hipGetLastError();   // launch checks below must only see this batch's errors
+  if (frag) {   // fragment mode: a launch holds at most max_slots (pair, fragment) slots
+    uint64_t slots = 0;
+    uint32_t fit = 0;
+    for (uint32_t p = 0; p < n_pairs; ++p) {
+      const PgGenome& Q = ctx->genomes[qry_ids[p]];
+      uint64_t nf = 0;
+      for (uint32_t r = 0; r < Q.n_rec; ++r) nf += ((uint64_t)(Q.rec_start[r + 1] - 1 - Q.rec_start[r]) + frag->fragsize - 1) / frag->fragsize;
+      if (nf > (uint64_t)FRAG_MAX_FRAGS)
+        return pg_fail(ctx, PG_E_CAPACITY, "fragment mode: a query genome has more fragments than the per-genome limit (15872)");
+      if (p > 0 && slots + nf > frag->max_slots) break;
+      slots += nf;
+      fit = p + 1;
+    }
+    n_pairs = fit;
+  }
+  uint32_t n_units = 2 * n_pairs;
   std::vector<int32_t> ref_list;
   std::vector<uint32_t> ref_of_pair(n_pairs);
   for (uint32_t p = 0; p < n_pairs; ++p) {
@@ -360,7 +392,8 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
     hipLaunchKernelGGL(anim_hit_scatter_kernel, dim3((uint32_t)ctx->num_cu * 8u), dim3(256), 0, ctx->stream, A->hits_d, A->seed_total + 1,
                        (uint32_t)A->hit_cap, A->hoff, A->hit_cursor, A->hits_sorted);
     hipLaunchKernelGGL(anim_hit_kernel, dim3(n_units), dim3(256), 0, ctx->stream, A->refs_d, A->units_d, A->hits_sorted, A->hoff,
-                       A->seed_total + 1, (uint32_t)A->hit_cap, A->seedbuf, (uint32_t)A->seed_cap, A->seed_total, A->mem_count);
+                       A->seed_total + 1, (uint32_t)A->hit_cap, A->seedbuf, (uint32_t)A->seed_cap, A->seed_total, A->mem_count,
+                       frag ? FRAG_SEED_MIN : MIN_MATCH);
     pg_prof_end(ctx);
     PG_HIP(ctx, hipMemcpyAsync(cnt.data(), A->mem_count, n_units * 4, hipMemcpyDeviceToHost, ctx->stream));
     PG_HIP(ctx, hipMemcpyAsync(counts, A->seed_total, 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -429,6 +462,10 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
     hipLaunchKernelGGL(anim_scatter_kernel, dim3((total + 255) / 256), dim3(256), 0, ctx->stream, A->seedbuf, total, A->moff, n_units,
                        A->mem_count, A->mem);
   pg_prof_end(ctx);
+  if (frag) {   // fragment mode: the matches of every unit are in place; the rest of the batch is the fragment kernels
+    PG_HIP(ctx, hipGetLastError());
+    return anib_frag_stage(ctx, A, qry_ids, n_pairs, cnt, *frag);
+  }
   pg_prof_begin(ctx, PG_K_ANIM_CLUSTER);
   if (getenv("PYANI_ANIM_SCALAR_CLUSTER") && !maxmatch)   // debugging aid: the one-thread-per-unit statement of the same algorithm
     hipLaunchKernelGGL(anim_cluster_kernel, dim3((n_units + 63) / 64), dim3(64), 0, ctx->stream, A->refs_d, A->units_d, n_units,
@@ -571,6 +608,99 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
     }
   }
 #endif
+  return PG_OK;
+}
+
+// Fragment mode after seeding: A->mem / A->moff / A->mem_count hold every unit's exact matches (>= 16, sampled), A->units_d /
+// A->refs_d the descriptors.  Builds the fragment tables of the batch's query genomes, runs F1-F3 (pga_frag.inc), returns
+// the pair results (and, optionally, the rows of pair 0).
+static int anib_frag_stage(pg_ctx* ctx, AnimScratch* A, const int32_t* qry_ids, uint32_t n_pairs, const std::vector<uint32_t>& cnt,
+                           const PgFragArgs& F) {
+  int rc;
+  const uint32_t n_units = 2 * n_pairs;
+  // fragment tables, one per distinct query genome
+  std::vector<int32_t> tables;
+  struct Tab { size_t pos, len, rec0; int32_t n_frags; };
+  std::vector<Tab> tab_of(ctx->genomes.size(), Tab{0, 0, 0, -1});
+  std::vector<FragPair> fp(n_pairs);
+  std::vector<size_t> tab_ref(n_pairs);
+  uint64_t slots = 0;
+  for (uint32_t p = 0; p < n_pairs; ++p) {
+    const int32_t gid = qry_ids[p];
+    Tab& T = tab_of[gid];
+    if (T.n_frags < 0) {
+      const PgGenome& Q = ctx->genomes[gid];
+      std::vector<int32_t> pos, len, rec0;
+      for (uint32_t r = 0; r < Q.n_rec; ++r) {
+        rec0.push_back((int32_t)pos.size());
+        const int32_t r0 = Q.rec_start[r], r1 = Q.rec_start[r + 1] - 1;
+        for (int32_t f0 = r0; f0 < r1; f0 += F.fragsize) { pos.push_back(f0); len.push_back(r1 - f0 < F.fragsize ? r1 - f0 : F.fragsize); }
+      }
+      T.n_frags = (int32_t)pos.size();
+      T.pos = tables.size(); tables.insert(tables.end(), pos.begin(), pos.end());
+      T.len = tables.size(); tables.insert(tables.end(), len.begin(), len.end());
+      T.rec0 = tables.size(); tables.insert(tables.end(), rec0.begin(), rec0.end());
+    }
+    fp[p].n_frags = T.n_frags;
+    fp[p].slot0 = (uint32_t)slots;
+    slots += (uint64_t)T.n_frags;
+  }
+  if (slots >= (1ull << 31)) return pg_fail(ctx, PG_E_CAPACITY, "fragment mode: too many (pair, fragment) slots in one launch");
+  if (tables.size() + 1 > A->fr_tables_cap) { if ((rc = regrow(ctx, A->fr_tables, tables.size() + 1024))) return rc; A->fr_tables_cap = tables.size() + 1024; }
+  for (uint32_t p = 0; p < n_pairs; ++p) {
+    const Tab& T = tab_of[qry_ids[p]];
+    fp[p].frag_pos = A->fr_tables + T.pos; fp[p].frag_len = A->fr_tables + T.len; fp[p].rec_frag0 = A->fr_tables + T.rec0;
+  }
+  if (n_pairs > A->fr_pairs_cap) {
+    if ((rc = regrow(ctx, A->fr_pairs, n_pairs))) return rc;
+    if ((rc = regrow(ctx, A->fr_out, n_pairs))) return rc;
+    A->fr_pairs_cap = n_pairs;
+  }
+  if (n_units > A->fr_units_cap) { if ((rc = regrow(ctx, A->fr_ebase, n_units))) return rc; A->fr_units_cap = n_units; }
+  const size_t n_off = 2 * (size_t)slots + 2 * (size_t)n_pairs;
+  if (n_off > A->fr_off_cap) { if ((rc = regrow(ctx, A->fr_off, n_off + n_off / 4))) return rc; A->fr_off_cap = n_off + n_off / 4; }
+  if (slots > A->fr_slots_cap) {
+    const size_t cap = (size_t)slots + (size_t)slots / 4;
+    if ((rc = regrow(ctx, A->fr_slot_pair, cap))) return rc;
+    if ((rc = regrow(ctx, A->fr_nrows, cap))) return rc;
+    if ((rc = regrow(ctx, A->fr_rows, cap * FRAG_ROWS))) return rc;
+    A->fr_slots_cap = cap;
+  }
+  std::vector<uint32_t> slot_pair((size_t)slots);
+  for (uint32_t p = 0; p < n_pairs; ++p) std::fill(slot_pair.begin() + fp[p].slot0, slot_pair.begin() + fp[p].slot0 + fp[p].n_frags, p);
+  // a match is clipped into at most 1 + (fragment boundaries it crosses) seeds: <= count + n_frags per unit
+  std::vector<uint64_t> ebase(n_units);
+  uint64_t n_entries = 0;
+  for (uint32_t u = 0; u < n_units; ++u) { ebase[u] = n_entries; n_entries += (uint64_t)cnt[u] + (uint64_t)fp[u / 2].n_frags; }
+  if (n_entries > A->fr_entries_cap) { if ((rc = regrow(ctx, A->fr_entries, (size_t)n_entries + (size_t)n_entries / 4))) return rc; A->fr_entries_cap = (size_t)n_entries + (size_t)n_entries / 4; }
+  if (!tables.empty()) PG_HIP(ctx, hipMemcpyAsync(A->fr_tables, tables.data(), tables.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+  PG_HIP(ctx, hipMemcpyAsync(A->fr_pairs, fp.data(), n_pairs * sizeof(FragPair), hipMemcpyHostToDevice, ctx->stream));
+  if (slots) PG_HIP(ctx, hipMemcpyAsync(A->fr_slot_pair, slot_pair.data(), (size_t)slots * 4, hipMemcpyHostToDevice, ctx->stream));
+  PG_HIP(ctx, hipMemcpyAsync(A->fr_ebase, ebase.data(), n_units * 8, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(anib_bucket_kernel, dim3(n_units), dim3(256), 0, ctx->stream, A->units_d, A->fr_pairs, A->mem, A->moff, A->mem_count,
+                     A->fr_ebase, F.fragsize, A->fr_off, A->fr_entries);
+  if (slots)
+    hipLaunchKernelGGL(anib_frag_kernel, dim3((uint32_t)slots), dim3(64), 0, ctx->stream, A->refs_d, A->units_d, A->fr_pairs, A->fr_slot_pair,
+                       A->fr_off, A->fr_entries, A->fr_ebase, A->fr_rows, A->fr_nrows);
+  hipLaunchKernelGGL(anib_reduce_pairs_kernel, dim3((n_pairs + 63) / 64), dim3(64), 0, ctx->stream, A->fr_pairs, n_pairs, A->fr_rows, A->fr_nrows,
+                     A->fr_out);
+  PG_HIP(ctx, hipGetLastError());
+  PG_HIP(ctx, hipMemcpyAsync(F.out, A->fr_out, n_pairs * sizeof(pg_anib_result), hipMemcpyDeviceToHost, ctx->stream));
+  PG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (F.n_rows_out) {   // the table of pair 0
+    const uint32_t nf = (uint32_t)fp[0].n_frags;
+    std::vector<uint32_t> nr(nf);
+    std::vector<FragRow> rows((size_t)nf * FRAG_ROWS);
+    if (nf) {
+      PG_HIP(ctx, hipMemcpy(nr.data(), A->fr_nrows + fp[0].slot0, nf * 4, hipMemcpyDeviceToHost));
+      PG_HIP(ctx, hipMemcpy(rows.data(), A->fr_rows + (size_t)fp[0].slot0 * FRAG_ROWS, rows.size() * sizeof(FragRow), hipMemcpyDeviceToHost));
+    }
+    uint32_t n = 0;
+    for (uint32_t f = 0; f < nf; ++f)
+      for (uint32_t i = 0; i < nr[f]; ++i, ++n)
+        if (F.rows_out && n < F.rows_cap) F.rows_out[n] = *reinterpret_cast<const pg_anib_row*>(&rows[(size_t)f * FRAG_ROWS + i]);
+    *F.n_rows_out = n;
+  }
   return PG_OK;
 }
 

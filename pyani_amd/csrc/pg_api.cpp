@@ -753,6 +753,60 @@ int pg_anib_reduce(pg_ctx* ctx, uint32_t n_pairs, const uint64_t* offsets, const
                             sim_errors_out, pid_out);
 }
 
+// ---- ANIb fragment mode ----------------------------------------------------------------------------------------
+static constexpr uint64_t ANIB_MAX_SLOTS = 4ull << 20;   // (pair, fragment) slots per launch: 192 B of rows each
+
+int pg_anib_pairs(pg_ctx* ctx, const int32_t* qry_ids, const int32_t* sbj_ids, uint64_t n_pairs, uint32_t fragsize, pg_anib_result* out) {
+  if (!ctx || fragsize == 0 || fragsize > 1020 || (n_pairs && (!qry_ids || !sbj_ids || !out)))
+    return pg_fail(ctx, PG_E_ARG, "bad argument (fragment sizes up to pyani's 1020 are supported)");
+  PG_HIP(ctx, hipSetDevice(ctx->device));
+  for (uint64_t i = 0; i < n_pairs; ++i)
+    if (qry_ids[i] < 0 || (size_t)qry_ids[i] >= ctx->genomes.size() || sbj_ids[i] < 0 || (size_t)sbj_ids[i] >= ctx->genomes.size())
+      return pg_fail(ctx, PG_E_ARG, "genome id out of range");
+  int rc;
+  if ((rc = pg_upload(ctx))) return rc;
+  // grouped by subject genome (the LDS-table role of the seeding stage), then in chunks the launch budgets allow
+  std::vector<uint64_t> order(n_pairs);
+  for (uint64_t i = 0; i < n_pairs; ++i) order[i] = i;
+  std::stable_sort(order.begin(), order.end(), [&](uint64_t a, uint64_t b) { return sbj_ids[a] < sbj_ids[b]; });
+  const uint32_t MAX_PAIRS = ctx->anim_batch_pairs, MAX_REFS = 256;
+  std::vector<int32_t> s, q;
+  std::vector<pg_anib_result> res;
+  uint64_t i = 0;
+  while (i < n_pairs) {
+    uint64_t j = i;
+    uint32_t nrefs = 0;
+    int32_t last = -1;
+    while (j < n_pairs && j - i < MAX_PAIRS) {
+      const int32_t rid = sbj_ids[order[j]];
+      if (rid != last) { if (nrefs == MAX_REFS) break; ++nrefs; last = rid; }
+      ++j;
+    }
+    s.clear(); q.clear();
+    for (uint64_t k = i; k < j; ++k) { s.push_back(sbj_ids[order[k]]); q.push_back(qry_ids[order[k]]); }
+    res.assign(j - i, pg_anib_result{});
+    PgFragArgs F{(int32_t)fragsize, res.data(), nullptr, 0, nullptr, ANIB_MAX_SLOTS};
+    uint32_t done = 0;
+    if ((rc = pg_anim_run_batch(ctx, s.data(), q.data(), (uint32_t)(j - i), 0, 1, ctx->anim_batch_matches, nullptr, &done, &F))) return rc;
+    for (uint64_t k = i; k < i + done; ++k) out[order[k]] = res[k - i];
+    i += done;
+  }
+  return PG_OK;
+}
+
+int pg_anib_pair_rows(pg_ctx* ctx, int32_t qry_id, int32_t sbj_id, uint32_t fragsize, pg_anib_row* out, uint32_t cap, uint32_t* n_out) {
+  if (!ctx || !n_out || fragsize == 0 || fragsize > 1020 || (cap && !out)) return pg_fail(ctx, PG_E_ARG, "bad argument");
+  if (qry_id < 0 || (size_t)qry_id >= ctx->genomes.size() || sbj_id < 0 || (size_t)sbj_id >= ctx->genomes.size())
+    return pg_fail(ctx, PG_E_ARG, "genome id out of range");
+  PG_HIP(ctx, hipSetDevice(ctx->device));
+  int rc;
+  if ((rc = pg_upload(ctx))) return rc;
+  pg_anib_result res{};
+  PgFragArgs F{(int32_t)fragsize, &res, out, cap, n_out, ANIB_MAX_SLOTS};
+  uint32_t done = 0;
+  return pg_anim_run_batch(ctx, &sbj_id, &qry_id, 1, 0, 1, ctx->anim_batch_matches, nullptr, &done, &F);
+}
+
 // ---- measurement -----------------------------------------------------------------------------------------------
 int pg_profile_enable(pg_ctx* ctx, int on) {
   if (!ctx) return PG_E_ARG;

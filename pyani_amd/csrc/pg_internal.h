@@ -109,8 +109,19 @@ int pg_launch_tetra_pairs(pg_ctx* ctx, uint32_t n, uint32_t row0, uint32_t nrows
 int pg_anim_reduce_run(pg_ctx* ctx, uint32_t n_pairs, const uint64_t* offsets, const int32_t* rseq, const int32_t* qseq,
                        const int32_t* rs, const int32_t* re, const int32_t* qs, const int32_t* qe, const int32_t* errors,
                        int apply_filter, pg_anim_result* out);
+// frag != nullptr: fragment mode (ANIb) — ref_ids are the subject genomes, qry_ids the fragmented ones; the batch stops after
+// the seeding stage and runs the fragment kernels instead of clustering / extension
+struct PgFragArgs {
+  int32_t fragsize;
+  pg_anib_result* out;        // n_pairs results (host)
+  pg_anib_row* rows_out;      // optional: the rows of pair 0 (host), at most rows_cap; *n_rows_out = how many there are
+  uint32_t rows_cap;
+  uint32_t* n_rows_out;
+  uint64_t max_slots;         // (pair, fragment) slots per launch
+};
 int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_ids, uint32_t n_pairs, int filter_1to1, int maxmatch,
-                      uint64_t max_matches, pg_anim_result* out_host, uint32_t* n_done);   // ref_ids grouped (equal ids adjacent)
+                      uint64_t max_matches, pg_anim_result* out_host, uint32_t* n_done,
+                      const PgFragArgs* frag = nullptr);   // ref_ids grouped (equal ids adjacent)
 void pg_anim_free_scratch(pg_ctx* ctx);
 int pg_anim_fetch_alignments(pg_ctx* ctx, int32_t ref_id, int32_t qry_id, uint32_t n, pg_anim_alignment* out);   // after a 1-pair batch
 void pg_anim_drop_lists(pg_ctx* ctx);   // per-genome seed lists: must go when the genome store is cleared

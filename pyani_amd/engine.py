@@ -220,6 +220,33 @@ class Engine:
                                             pid.ctypes.data, aln.ctypes.data, err.ctypes.data, out.ctypes.data))
         return aln, err, out
 
+    # -- ANIb fragment mode ---------------------------------------------------------------------------------------
+    ANIB_DTYPE = np.dtype([("aln_length", "<i8"), ("sim_errors", "<i8"), ("pid", "<f8"), ("n_frags", "<i4"), ("n_kept", "<i4"),
+                           ("status", "<i4"), ("reserved", "<i4")])
+    ANIB_ROW_DTYPE = np.dtype([("frag", "<i4"), ("length", "<i4"), ("mismatch", "<i4"), ("gaps", "<i4"), ("nident", "<i4"),
+                               ("qlen", "<i4"), ("qstart", "<i4"), ("qend", "<i4"), ("sstart", "<i4"), ("send", "<i4"), ("srec", "<i4"),
+                               ("score", "<i4")])
+
+    def anib_pairs(self, qry_ids, sbj_ids, fragsize: int = 1020) -> np.ndarray:
+        """One record per ORDERED pair: the fragments of genome qry against genome sbj (pyani's blastn job + parse_blast_tab)."""
+        q, s = self._ids(qry_ids), self._ids(sbj_ids)
+        if len(q) != len(s):
+            raise ValueError("qry_ids and sbj_ids must have the same length")
+        out = np.zeros(len(q), dtype=self.ANIB_DTYPE)
+        self._check(self.lib.pg_anib_pairs(self._h, q.ctypes.data, s.ctypes.data, len(q), int(fragsize), out.ctypes.data))
+        return out
+
+    def anib_pair_rows(self, qry_id: int, sbj_id: int, fragsize: int = 1020) -> np.ndarray:
+        """The BLAST-shaped table of one ordered pair (<= 4 rows per fragment, best score first)."""
+        n = ctypes.c_uint32(0)
+        nfr, _ = self.genome_length(qry_id)
+        out = np.zeros(4 * (nfr // max(1, fragsize) + 4096), dtype=self.ANIB_ROW_DTYPE)
+        self._check(self.lib.pg_anib_pair_rows(self._h, int(qry_id), int(sbj_id), int(fragsize), out.ctypes.data, len(out), ctypes.byref(n)))
+        if n.value > len(out):
+            out = np.zeros(n.value, dtype=self.ANIB_ROW_DTYPE)
+            self._check(self.lib.pg_anib_pair_rows(self._h, int(qry_id), int(sbj_id), int(fragsize), out.ctypes.data, len(out), ctypes.byref(n)))
+        return out[:n.value].copy()
+
     # -- measurement ----------------------------------------------------------------------------------------------
     def profile_enable(self, on: bool = True):
         self._check(self.lib.pg_profile_enable(self._h, int(on)))

@@ -55,7 +55,7 @@ def test_no_cpu_fallback(lib):
 def test_product_never_touches_oracle():
     """The package must not import, link or execute anything under oracle/ (that would void parity claims)."""
     for py in (ROOT / "pyani_amd").rglob("*"):
-        if py.suffix in {".py", ".cpp", ".hip", ".h"}:
+        if py.suffix in {".py", ".cpp", ".hip", ".h", ".inc"}:
             txt = py.read_text()
             assert "oracle" not in txt.lower() or py.name == "build.py", py
     # build.py only COMPILES the checker; it must not load it

@@ -1,0 +1,148 @@
+"""Fragment mode (ANIb, BASELINE.json configs[4]) on the GPU, through the C ABI (pg_anib_pairs / pg_anib_pair_rows).
+
+Two bars, as for ANIm:
+  * GPU == the CPU statement of the same search (oracle/anib_cpu.cpp: same seeds, same anchor rule, same X-drop DP) ROW FOR ROW —
+    integers, so bit-exact — on synthetic pairs of every divergence level and on a real Caulobacter pair;
+  * the search emulates BLAST+ (third-party, absent): compared with the BLAST+ tables the reference's tests hold for the four
+    Caulobacter genomes (tests/golden/anib/*.blast_tab, all 12 ordered pairs) and with blastn_result.csv, at the level reached
+    (the reference's own concordance tolerances for ANIb are 0.2 percentage points above 90 % identity and 5 below,
+    tests/test_concordance.py:131-153).
+"""
+import csv
+import json
+import sys
+
+import numpy as np
+import pytest
+
+from tests.conftest import GOLD, ROOT
+
+sys.path.insert(0, str(ROOT / "oracle"))
+import anib_cpu  # noqa: E402
+import anib_oracle  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+FIELDS = ("frag", "length", "mismatch", "gaps", "nident", "qlen", "qstart", "qend", "sstart", "send", "srec", "score")
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from pyani_amd.engine import Engine
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+def _rows(a):
+    return [tuple(int(r[k]) for k in FIELDS) for r in a]
+
+
+def test_rows_equal_cpu_statement_on_synthetic_pairs(eng):
+    """Every divergence level of the synthetic generator (0.1 % ... 15 % per genome), multi-record genomes, both strands
+    (inversions): the table of every ordered pair equals the CPU statement's, row for row; so do the pair tuples."""
+    from pyani_amd import synth
+    eng.clear_genomes()
+    n, L, seed = 6, 150_000, 20250302
+    data = [synth.genome(seed, n, g, L) for g in range(n)]
+    ids = [eng.add_genome(*d) for d in data]
+    eng.upload()
+    pairs = [(a, b) for a in range(n) for b in range(n) if a != b]
+    res = eng.anib_pairs([ids[a] for a, _ in pairs], [ids[b] for _, b in pairs])
+    n_rows = 0
+    for (a, b), r in zip(pairs, res):
+        want = anib_cpu.anib_cpu_pair(data[a], data[b])
+        got = eng.anib_pair_rows(ids[a], ids[b])
+        assert _rows(got) == _rows(want), (a, b, len(got), len(want))
+        aln, err, pid, kept = anib_cpu.reduce_rows(want)
+        assert (int(r["aln_length"]), int(r["sim_errors"]), int(r["n_kept"])) == (aln, err, len(kept)), (a, b)
+        assert abs(float(r["pid"]) - pid) <= 1e-12 * max(1.0, pid) and int(r["status"]) == 0
+        n_rows += len(want)
+    assert n_rows > 1000 and (res["n_kept"] > 100).all()
+
+
+def test_edge_inputs(eng):
+    """A genome against itself (every fragment one exact full-length hit), fragments shorter than a seed, all-N and empty
+    genomes, a non-default fragment size."""
+    from pyani_amd import synth
+    eng.clear_genomes()
+    g = synth.genome(5, 4, 0, 60_000)
+    a = eng.add_genome(*g)
+    tiny = eng.add_genome(np.frombuffer(b"ACGTACGTACGTAC", dtype=np.uint8), np.array([0, 14], dtype=np.uint64))
+    alln = eng.add_genome(np.frombuffer(b"N" * 3000, dtype=np.uint8), np.array([0, 3000], dtype=np.uint64))
+    empty = eng.add_genome(np.zeros(0, dtype=np.uint8), np.array([0, 0], dtype=np.uint64))
+    res = eng.anib_pairs([a, a, tiny, alln, a, empty, a], [a, tiny, a, a, alln, a, empty])
+    me = res[0]
+    total = sum(int(g[1][k + 1] - g[1][k]) for k in range(len(g[1]) - 1))
+    assert int(me["aln_length"]) == total and int(me["sim_errors"]) == 0 and float(me["pid"]) == 100.0 and int(me["n_kept"]) == int(me["n_frags"])
+    for r in res[1:]:
+        assert int(r["status"]) == 0 and int(r["n_kept"]) == 0 and float(r["pid"]) == 0.0 and int(r["aln_length"]) == 0
+    assert int(res[3]["n_frags"]) == 3 and int(res[5]["n_frags"]) == 0
+    half = eng.anib_pairs([a], [a], fragsize=500)[0]
+    assert int(half["aln_length"]) == total and int(half["n_frags"]) > int(me["n_frags"])
+    assert _rows(eng.anib_pair_rows(a, a, 500)) == _rows(anib_cpu.anib_cpu_pair(g, g, 500))
+
+
+@pytest.fixture(scope="module")
+def caulobacter(eng, genome_dir):
+    eng.clear_genomes()
+    stems = sorted(genome_dir["caulobacter"])
+    ids = {s: eng.add_fasta(genome_dir["caulobacter"][s])[0] for s in stems}
+    pairs = [(q, s) for q in stems for s in stems if q != s]
+    res = eng.anib_pairs([ids[q] for q, _ in pairs], [ids[s] for _, s in pairs])
+    return ids, {p: r for p, r in zip(pairs, res)}
+
+
+def test_real_pair_equals_cpu_statement(eng, caulobacter, genome_dir):
+    """NC_014100 fragments against NC_002696 (84 % ANIb, 4 565 fragments, two subject records): row for row."""
+    from tests import oracle_bind
+    ids, _ = caulobacter
+    q = oracle_bind.read_fasta_arrays(genome_dir["caulobacter"]["NC_014100"])
+    s = oracle_bind.read_fasta_arrays(genome_dir["caulobacter"]["NC_002696"])
+    assert _rows(eng.anib_pair_rows(ids["NC_014100"], ids["NC_002696"])) == _rows(anib_cpu.anib_cpu_pair(q, s))
+
+
+def test_agreement_with_blast_plus_tables(eng, caulobacter):
+    """All 12 ordered Caulobacter pairs against the BLAST+ tables and blastn_result.csv of the reference's tests: mean identity
+    within 0.5 percentage points for the 78-84 % pairs and within 0.001 for the 99.99 % pair (reference tolerance: 5 / 0.2),
+    aligned length within 6 %; per pair the level reached goes to gpurun_out/anib_blast_agreement.json."""
+    ids, res = caulobacter
+    rows = list(csv.reader(open(GOLD / "ref_targets" / "anib_blastn_result.csv")))
+    names = rows[0][1:]
+    ident = {(r[0], s): float(v) for r in rows[1:] for s, v in zip(names, r[1:])}
+    report = {}
+    for (q, s), r in res.items():
+        aln, err, pid = anib_oracle.parse_blast_tab(GOLD / "anib" / f"{q}_vs_{s}.blast_tab.gz")
+        assert f"{0.01 * pid:.6f}" == f"{ident[(q, s)]:.6f}"            # the fixture table IS what blastn_result.csv was made from
+        report[f"{q}_vs_{s}"] = {"blast": [aln, err, pid], "ours": [int(r["aln_length"]), int(r["sim_errors"]), float(r["pid"])],
+                                 "identity_pp_diff": float(r["pid"]) - pid, "aln_length_rel_diff": (int(r["aln_length"]) - aln) / aln,
+                                 "fragments_kept": int(r["n_kept"])}
+    (ROOT / "gpurun_out").mkdir(exist_ok=True)
+    (ROOT / "gpurun_out" / "anib_blast_agreement.json").write_text(json.dumps(report, indent=1, sort_keys=True))
+    for name, rep in report.items():
+        close = rep["blast"][2] > 99.0
+        assert abs(rep["identity_pp_diff"]) < (1e-3 if close else 0.5), (name, rep)
+        assert abs(rep["aln_length_rel_diff"]) < (1e-4 if close else 0.06), (name, rep)
+    near = report["NC_002696_vs_NC_011916"]
+    assert near["ours"][1] == near["blast"][1] == 93                   # the reference's known answer: 93 similarity errors
+
+
+def test_module_api_tables_and_matrices(eng, genome_dir, tmp_path):
+    """calculate_anib_pairs -> process_blast_results; a pair's table written in BLAST+'s column layout is read back by the
+    oracle restatement of pyani's parse_blast_tab to the same tuple."""
+    from pyani_amd import anib, anim
+    eng.clear_genomes()
+    files = [genome_dir["blochmannia"][s] for s in sorted(genome_dir["blochmannia"])[:3]]
+    res, lengths = anib.calculate_anib_pairs(files, engine=eng)
+    assert len(res) == 6 and eng.genome_count() == 0
+    mats = anib.process_blast_results(res, lengths)
+    q, s = files[0].stem, files[1].stem
+    assert mats["percentage_identity"].loc[q, s] == 0.01 * res[(q, s)][2] and mats["alignment_coverage"].loc[q, s] == res[(q, s)][0] / lengths[q]
+    assert 0.7 < mats["percentage_identity"].loc[q, s] < 1.0 and mats["alignment_lengths"].loc[q, q] == lengths[q]
+    ids = [eng.add_fasta(f)[0] for f in files[:2]]
+    table = eng.anib_pair_rows(ids[0], ids[1])
+    recs = anim.fasta_records(files[1])
+    out = tmp_path / f"{q}_vs_{s}.blast_tab"
+    assert anib.write_blast_tab(out, table, [r[0] for r in recs], [r[1] for r in recs]) == len(table)
+    aln, err, pid = anib_oracle.parse_blast_tab(out)
+    assert (aln, err) == res[(q, s)][:2] and abs(pid - res[(q, s)][2]) < 1e-9

@@ -43,7 +43,7 @@ static Genome load(const char* path) {
 
 int main(int argc, char** argv) {
   if (argc < 3) { fprintf(stderr, "usage: anib_debug query.fna subject.fna [K=16] [top=2]\n"); return 2; }
-  const int K = argc > 3 ? atoi(argv[3]) : 16, TOP = argc > 4 ? atoi(argv[4]) : 2;
+  const int K = argc > 3 ? atoi(argv[3]) : 16, TOP = argc > 4 ? atoi(argv[4]) : 2, STEP = argc > 5 ? atoi(argv[5]) : 1;
   Genome Q = load(argv[1]), S = load(argv[2]);
   const SeqView SV = S.view(), QV = Q.view();
   // subject K-mer table (forward strand)
@@ -80,6 +80,9 @@ int main(int argc, char** argv) {
           v = ((v << 2) | (uint64_t)b) & keep;
           if (++run < K) continue;
           const int32_t q = e - K + 1;
+          // the engine samples the query genome's STRAND position (every STEP-th), not the fragment's
+          const int64_t gp = strand ? (QV.len - 1 - (f0 + (qlen - 1 - q))) : f0 + q;
+          if (gp % STEP) continue;
           auto it = std::lower_bound(tab.begin(), tab.end(), std::make_pair(v, (int32_t)-1));
           for (int cnt = 0; it != tab.end() && it->first == v && cnt < 64; ++it, ++cnt) seeds.push_back({it->second - q, q});
         }

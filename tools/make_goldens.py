@@ -307,6 +307,13 @@ def make_deltadir_cases(ref_anim, tmp):
     logging.getLogger().info("process_deltadir cases written")
 
 
+def make_anib_goldens():
+    """The BLAST+ tables the reference's tests hold for the four Caulobacter genomes (tests/fixtures/anib/blastn): data files."""
+    for f in sorted((REF / "tests/fixtures/anib/blastn").glob("*.blast_tab")):
+        gz_copy(f, GOLD / "anib" / (f.name + ".gz"))
+    shutil.copyfile(REF / "tests/fixtures/anib/dataframes/blastn_result.csv", GOLD / "ref_targets" / "anib_blastn_result.csv")
+
+
 def make_anim_goldens():
     import tarfile
     sys.path.insert(0, str(ROOT / "oracle"))
@@ -372,3 +379,4 @@ if __name__ == "__main__":
     else:
         main()
         make_anim_goldens()
+        make_anib_goldens()
