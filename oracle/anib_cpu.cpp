@@ -1,8 +1,8 @@
 // oracle/anib_cpu.cpp — CPU statement of fragment mode (ANIb).   TEST / MEASUREMENT INFRASTRUCTURE ONLY.
 //
 // The scalar functions of pyani_amd/csrc/pg_anib_core.h (anchor choice, X-drop extension, HSP row) compiled for the HOST and fed
-// with exactly the seeds the GPU's sampled LDS seeding reports: the maximal exact matches of at least 16 bases that contain a
-// 16-mer starting at a query-strand position divisible by 5 (pga_seed.inc), found here with an exhaustive sorted 16-mer table.
+// with exactly the seeds the GPU's LDS seeding reports in fragment mode: the maximal exact matches of at least 16 bases (every
+// query-strand position is looked up: FRAG_QSTEP = 1; pga_seed.inc), found here with an exhaustive sorted 16-mer table.
 // What it restates: pyani's ANIb per ordered pair — fragment the query genome into 1020-nt pieces (anib.py:164-203), blastn
 // every piece against the subject genome (anib.py:451-471; BLAST+ is third-party, absent: see pg_anib_core.h for what is
 // restated of it and tests/golden/anib for the BLAST+ tables it is calibrated on), keep per fragment the first HSP with
@@ -50,7 +50,7 @@ struct Row {     // = pg_anib_row (include/pyani_gpu.h)
   int32_t frag, length, mismatch, gaps, nident, qlen, qstart, qend, sstart, send, srec, score;
 };
 
-constexpr int SEED_K = 16, SEED_STEP = 5;
+constexpr int SEED_K = 16, SEED_STEP = FRAG_QSTEP;   // the engine's fragment-mode seeding: every query-strand position
 
 // the seeds of the GPU pipeline for one query strand: maximal exact matches >= 16 containing a sampled 16-mer
 template <typename QV>

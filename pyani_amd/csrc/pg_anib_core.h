@@ -24,6 +24,7 @@
 namespace pga {
 
 constexpr int FRAG_SIZE = 1020;                 // pyani_config.FRAGSIZE
+constexpr int FRAG_QSTEP = 1;                   // seeds: every 16-mer of the fragmented genome is looked up (ANIm samples every 5th)
 constexpr int FRAG_MATCH = 2, FRAG_MISMATCH = -3, FRAG_GAP_OPEN = -7, FRAG_GAP_EXT = -2;   // first gap base -(5 + 2), further -2
 #ifndef PGA_FRAG_BAND
 #define PGA_FRAG_BAND 256
@@ -145,10 +146,15 @@ PG_HD FragHit frag_join(const FragExt& L, const FragExt& R, int32_t aq, int64_t 
 // ---- anchors ---------------------------------------------------------------------------------------------------------
 // The exact matches of one (fragment, strand), clipped to the fragment: s = subject stream position, q = position in the fragment
 // (on the searched strand), len.  Candidate anchors: every match scores the total length of the matches within FRAG_VOTE_WIN
-// diagonals of its own; the first candidate is the match with the highest (score, len, -q, -s), the second the best one at least
-// FRAG_VOTE_FAR diagonals away from the first.  Returns the number of candidates (0..2), their indices in cand[].
+// diagonals of its own; the best-scoring match (ties: longer, then smaller q, then smaller s) marks the locus, and the ANCHOR is
+// the longest match within FRAG_VOTE_WIN diagonals of it (same ties) — in a tandem repeat the short off-diagonal copies can
+// out-vote the long true match, but they cannot out-grow it.  The second candidate is found the same way among the matches at
+// least FRAG_VOTE_FAR diagonals away from the first anchor.  Returns the number of candidates (0..2), their indices in cand[].
 struct FragSeed { int32_t s, q, len; };
 constexpr int FRAG_VOTE_WIN = 16, FRAG_VOTE_FAR = 48, FRAG_MAX_SEEDS = 64, FRAG_MIN_CLIP = 11;
+PG_HD bool frag_seed_before(const FragSeed& a, const FragSeed& o) {      // a is preferred to o at equal votes / as the longer anchor
+  return a.len > o.len || (a.len == o.len && (a.q < o.q || (a.q == o.q && a.s < o.s)));
+}
 PG_HD int frag_pick_anchors(const FragSeed* e, int n, int* cand) {
   int nc = 0;
   int64_t first_diag = 0;
@@ -163,16 +169,19 @@ PG_HD int frag_pick_anchors(const FragSeed* e, int n, int* cand) {
         const int64_t db = (int64_t)e[b].s - e[b].q;
         if (db - da <= FRAG_VOTE_WIN && da - db <= FRAG_VOTE_WIN) votes += e[b].len;
       }
-      bool better = best < 0 || votes > best_votes;
-      if (!better && votes == best_votes) {
-        const FragSeed& o = e[best];
-        better = e[a].len > o.len || (e[a].len == o.len && (e[a].q < o.q || (e[a].q == o.q && e[a].s < o.s)));
-      }
-      if (better) { best = a; best_votes = votes; }
+      if (best < 0 || votes > best_votes || (votes == best_votes && frag_seed_before(e[a], e[best]))) { best = a; best_votes = votes; }
     }
     if (best < 0) break;
-    cand[nc++] = best;
-    first_diag = (int64_t)e[best].s - e[best].q;
+    const int64_t dl = (int64_t)e[best].s - e[best].q;
+    int anchor = best;
+    for (int b = 0; b < n; ++b) {
+      const int64_t db = (int64_t)e[b].s - e[b].q;
+      if (db - dl > FRAG_VOTE_WIN || dl - db > FRAG_VOTE_WIN) continue;
+      if (round == 1 && (db - first_diag < FRAG_VOTE_FAR && first_diag - db < FRAG_VOTE_FAR)) continue;
+      if (frag_seed_before(e[b], e[anchor])) anchor = b;
+    }
+    cand[nc++] = anchor;
+    first_diag = (int64_t)e[anchor].s - e[anchor].q;
   }
   return nc;
 }

@@ -87,8 +87,8 @@ struct AnimScratch {
   size_t units = 0, pairs = 0, refs = 0, recs = 0, wl = 0, matches = 0;
   // per-genome seed lists (built once per resident genome and role, dropped by pg_clear_genomes)
   struct GenomeIdx {
-    uint64_t *ref_list = nullptr, *qry_list = nullptr;
-    uint32_t *ref_goff = nullptr, *qry_goff = nullptr;
+    uint64_t *ref_list = nullptr, *qry_list = nullptr, *qry_list1 = nullptr;   // qry_list1: every position (fragment mode)
+    uint32_t *ref_goff = nullptr, *qry_goff = nullptr, *qry_goff1 = nullptr;
     uint32_t ref_max = 0;   // largest reference group (sizes the LDS table)
   };
   std::vector<GenomeIdx> gidx;
@@ -159,14 +159,15 @@ void pg_anim_drop_lists(pg_ctx* ctx) {
   AnimScratch* A = static_cast<AnimScratch*>(ctx->anim_scratch);
   if (!A) return;
   for (auto& g : A->gidx) {
-    void* ptrs[] = {g.ref_list, g.qry_list, g.ref_goff, g.qry_goff};
+    void* ptrs[] = {g.ref_list, g.qry_list, g.ref_goff, g.qry_goff, g.qry_list1, g.qry_goff1};
     for (void* p : ptrs) if (p) (void)hipFree(p);
   }
   A->gidx.clear();
 }
 
 // Build the seed lists the batch needs and does not have yet: reference role for `ref_genomes`, query role for `qry_genomes`.
-static int anim_ensure_lists(pg_ctx* ctx, AnimScratch* A, const std::vector<int32_t>& ref_genomes, const std::vector<int32_t>& qry_genomes) {
+static int anim_ensure_lists(pg_ctx* ctx, AnimScratch* A, const std::vector<int32_t>& ref_genomes, const std::vector<int32_t>& qry_genomes,
+                             int qstep) {
   int rc;
   if (A->gidx.size() < ctx->genomes.size()) A->gidx.resize(ctx->genomes.size());
   if (!A->list_cnt && (rc = regrow(ctx, A->list_cnt, (size_t)2 * SEED_GROUPS))) return rc;
@@ -174,27 +175,29 @@ static int anim_ensure_lists(pg_ctx* ctx, AnimScratch* A, const std::vector<int3
   for (int role = 0; role < 2; ++role) {
     for (int32_t gid : role ? qry_genomes : ref_genomes) {
       AnimScratch::GenomeIdx& X = A->gidx[gid];
-      if (role ? X.qry_list != nullptr : X.ref_list != nullptr) continue;
+      uint64_t*& qlist = qstep == 1 ? X.qry_list1 : X.qry_list;
+      uint32_t*& qgoff = qstep == 1 ? X.qry_goff1 : X.qry_goff;
+      if (role ? qlist != nullptr : X.ref_list != nullptr) continue;
       const PgGenome& G = ctx->genomes[gid];
       const int32_t len = (int32_t)G.stream_len;
       const uint32_t n_sub = role ? 2 * SEED_GROUPS : SEED_GROUPS;
-      const size_t bound = role ? 2 * ((size_t)len / SEED_STEP + 1) : (size_t)len + 1;
-      uint64_t*& list = role ? X.qry_list : X.ref_list;
-      uint32_t*& goff = role ? X.qry_goff : X.ref_goff;
+      const size_t bound = role ? 2 * ((size_t)len / qstep + 1) : (size_t)len + 1;
+      uint64_t*& list = role ? qlist : X.ref_list;
+      uint32_t*& goff = role ? qgoff : X.ref_goff;
       if ((rc = regrow(ctx, list, bound))) return rc;
       if ((rc = regrow(ctx, goff, (size_t)n_sub + 2))) return rc;
       const uint32_t* codes = ctx->d_codes + G.arena_start / 16;
       const uint32_t* mask = ctx->d_mask + G.arena_start / 32;
-      const int32_t n_idx = role ? len / SEED_STEP + 1 : len;
+      const int32_t n_idx = role ? len / qstep + 1 : len;
       const dim3 grid((uint32_t)(n_idx + LIST_CHUNK - 1) / LIST_CHUNK, role ? 2 : 1);
       PG_HIP(ctx, hipMemsetAsync(A->list_cnt, 0, (size_t)n_sub * 4, ctx->stream));
       if (grid.x)   // (an empty genome still gets its all-zero offset table from the scan)
         hipLaunchKernelGGL(anim_list_kernel, grid, dim3(LIST_BLOCK), 0, ctx->stream, codes, mask, len, role, A->list_cnt,
-                           (const uint32_t*)nullptr, (uint64_t*)nullptr, 0);
+                           (const uint32_t*)nullptr, (uint64_t*)nullptr, 0, qstep);
       hipLaunchKernelGGL(anim_list_scan_kernel, dim3(1), dim3(64), 0, ctx->stream, A->list_cnt, goff, n_sub);
       if (grid.x)
         hipLaunchKernelGGL(anim_list_kernel, grid, dim3(LIST_BLOCK), 0, ctx->stream, codes, mask, len, role, A->list_cnt,
-                           (const uint32_t*)goff, list, 1);
+                           (const uint32_t*)goff, list, 1, qstep);
       if (!role) fresh_refs.push_back(gid);
     }
   }
@@ -249,6 +252,7 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
     n_pairs = fit;
   }
   uint32_t n_units = 2 * n_pairs;
+  const int qstep = frag ? FRAG_QSTEP : SEED_STEP;   // query-strand sampling of the seed lists
   std::vector<int32_t> ref_list;
   std::vector<uint32_t> ref_of_pair(n_pairs);
   for (uint32_t p = 0; p < n_pairs; ++p) {
@@ -324,7 +328,7 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
     std::vector<int32_t> qry_list(qry_ids, qry_ids + n_pairs);
     std::sort(qry_list.begin(), qry_list.end());
     qry_list.erase(std::unique(qry_list.begin(), qry_list.end()), qry_list.end());
-    if ((rc = anim_ensure_lists(ctx, A, ref_list, qry_list))) return rc;
+    if ((rc = anim_ensure_lists(ctx, A, ref_list, qry_list, qstep))) return rc;
   }
   uint32_t max_group = 1;
   for (uint32_t r = 0; r < n_refs; ++r) if (A->gidx[ref_list[r]].ref_max > max_group) max_group = A->gidx[ref_list[r]].ref_max;
@@ -334,7 +338,8 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
     return pg_fail(ctx, PG_E_CAPACITY, "anim seeding: a reference k-mer group does not fit the LDS table (genome too large or too repetitive)");
   std::vector<SeedRef> srefs(n_refs);
   std::vector<SeedQry> sqry(n_pairs);
-  for (uint32_t p = 0; p < n_pairs; ++p) sqry[p] = SeedQry{A->gidx[qry_ids[p]].qry_list, A->gidx[qry_ids[p]].qry_goff};
+  for (uint32_t p = 0; p < n_pairs; ++p)
+    sqry[p] = qstep == 1 ? SeedQry{A->gidx[qry_ids[p]].qry_list1, A->gidx[qry_ids[p]].qry_goff1} : SeedQry{A->gidx[qry_ids[p]].qry_list, A->gidx[qry_ids[p]].qry_goff};
   auto fill_srefs = [&](uint32_t limit) {
     for (uint32_t r = 0; r < n_refs; ++r) srefs[r] = SeedRef{A->gidx[ref_list[r]].ref_list, A->gidx[ref_list[r]].ref_goff, 0, 0};
     for (uint32_t p = 0; p < limit; ++p) {
@@ -365,7 +370,7 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
   uint32_t total = 0, pairs_fit = 0;
   // hit buffer: the matches of the batch budget plus the chance 16-mer hits of unrelated pairs (~1200 per 5 Mb unit)
   {
-    const size_t want = (size_t)max_matches + (size_t)4096 * n_units + 1024;
+    const size_t want = (size_t)max_matches + (size_t)(frag ? 8 * 4096 : 4096) * n_units + 1024;   // (every position sampled: 5 x the chance hits)
     if (want > A->hit_cap) {
       if ((rc = regrow(ctx, A->hits_d, want))) return rc;
       if ((rc = regrow(ctx, A->hits_sorted, want))) return rc;
@@ -383,7 +388,7 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
     pg_prof_begin(ctx, PG_K_ANIM_SEED);
     hipLaunchKernelGGL(anim_seed_kernel, dim3(n_refs, SEED_GROUPS), dim3(SEED_BLOCK), (size_t)slots * 8 + SEED_STAGE_BYTES, ctx->stream,
                        A->refs_d, A->units_d, A->srefs_d, A->sqry_d, A->slice_d, slice_stride, slots - 1, A->hits_d,
-                       (uint32_t)A->hit_cap, A->seed_total + 1, A->hit_count);
+                       (uint32_t)A->hit_cap, A->seed_total + 1, A->hit_count, qstep);
     pg_prof_end(ctx);
     PG_HIP(ctx, hipGetLastError());   // a rejected launch (LDS size) must not surface only at the end of the batch
     pg_prof_begin(ctx, PG_K_ANIM_HIT);
@@ -393,7 +398,7 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
                        (uint32_t)A->hit_cap, A->hoff, A->hit_cursor, A->hits_sorted);
     hipLaunchKernelGGL(anim_hit_kernel, dim3(n_units), dim3(256), 0, ctx->stream, A->refs_d, A->units_d, A->hits_sorted, A->hoff,
                        A->seed_total + 1, (uint32_t)A->hit_cap, A->seedbuf, (uint32_t)A->seed_cap, A->seed_total, A->mem_count,
-                       frag ? FRAG_SEED_MIN : MIN_MATCH);
+                       frag ? FRAG_SEED_MIN : MIN_MATCH, qstep);
     pg_prof_end(ctx);
     PG_HIP(ctx, hipMemcpyAsync(cnt.data(), A->mem_count, n_units * 4, hipMemcpyDeviceToHost, ctx->stream));
     PG_HIP(ctx, hipMemcpyAsync(counts, A->seed_total, 8, hipMemcpyDeviceToHost, ctx->stream));
