@@ -17,6 +17,8 @@ dealt over the ranks (pyani_amd.parallel.anim_row_shard), each rank runs its row
 per step (64 B per pair) puts the step's rows of the result grid on every rank.  No other collective, no sequence traffic.
 
   --workload tetra : the TETRA side alone (C2: 200 genomes, counts + Z + Pearson; N > 1 = weak scaling, 200 genomes per GPU).
+  --workload anib  : C5 (BASELINE.json configs[4]): 500 genomes of 1-12 Mb, pyani's ANIb on the engine's fragment mode
+                     (1020-nt fragments against every other genome); steps of 10 fragmented genomes x 499 subjects.
 
 Rank 0 prints ONE JSON line.
 """
@@ -43,8 +45,9 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICRO
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--workload", choices=["anim", "tetra"], default="anim",
-                    help="anim = C4 (default: the N x N ANIm grid the metric is quoted on); tetra = C2 alone")
+    ap.add_argument("--workload", choices=["anim", "tetra", "anib"], default="anim",
+                    help="anim = C4 (default: the N x N ANIm grid the metric is quoted on); tetra = C2 alone; "
+                         "anib = C5 (mixed-length set, 1020-nt fragment mode)")
     ap.add_argument("--steps", type=int, default=None, help="default 10 (anim: one pass over the grid) / 50 (tetra)")
     ap.add_argument("--warmup", type=int, default=None, help="default 2 (anim) / 5 (tetra)")
     ap.add_argument("--genomes", type=int, default=None, help="anim: genomes of the job (C4: 1000); tetra: genomes per GPU (C2: 200)")
@@ -56,15 +59,17 @@ def parse_args():
     ap.add_argument("--cpu-genomes", type=int, default=2, help="tetra: genomes timed by the CPU leg")
     ap.add_argument("--no-tetra", action="store_true", help="anim: skip the nested C2 TETRA sub-record")
     args = ap.parse_args()
-    anim = args.workload == "anim"
+    w = args.workload
     if args.steps is None:
-        args.steps = 10 if anim else 50
+        args.steps = {"anim": 10, "tetra": 50, "anib": 3}[w]
     if args.warmup is None:
-        args.warmup = 2 if anim else 5
+        args.warmup = {"anim": 2, "tetra": 5, "anib": 1}[w]
     if args.genomes is None:
-        args.genomes = 1000 if anim else 200
+        args.genomes = {"anim": 1000, "tetra": 200, "anib": 500}[w]
     if args.seed is None:
-        args.seed = 20250301 if anim else 20250228
+        args.seed = {"anim": 20250301, "tetra": 20250228, "anib": 20250302}[w]
+    if w == "anib" and args.rows_per_step == 100:
+        args.rows_per_step = 10
     return args
 
 
@@ -361,6 +366,154 @@ def run_anim(args, rank, world, local, dist, torch):
 
 
 # =====================================================================================================================
+# ANIb fragment mode (C5)
+# =====================================================================================================================
+def c5_length(g):
+    """SURVEY.md §8(d) set C5: L_g = 1 000 000 + (g * 22 045 mod 11 000 001)  (1-12 Mb)."""
+    return 1_000_000 + (g * 22_045) % 11_000_001
+
+
+def run_anib(args, rank, world, local, dist, torch):
+    """C5: N = 500 synthetic genomes of 1-12 Mb, pyani's ANIb on the engine's fragment mode: the 1020-nt fragments of every
+    genome against every other genome.  A step = `--rows-per-step` (10) fragmented genomes x all N - 1 subjects; N > 1 = strong
+    scaling of the same steps (rows dealt over the ranks, one all-gather per step), as for ANIm."""
+    from pyani_amd import _lib, parallel, synth
+    from pyani_amd.engine import Engine
+    eng = Engine(local)
+    n, R = args.genomes, max(1, min(args.rows_per_step, args.genomes))
+    K = (n + 24) // 25
+    t_prep = time.perf_counter()
+    with ThreadPoolExecutor(max(1, min(64, (os.cpu_count() or 2) // max(1, world)))) as ex:
+        data = list(ex.map(lambda g: synth.genome(args.seed, n, g, c5_length(g)), range(n)))
+    ids_np = np.asarray([eng.add_genome(s_, o_) for s_, o_ in data], dtype=np.int32)
+    eng.upload()
+    t_prep = time.perf_counter() - t_prep
+    dev = torch.device("cuda", local)
+    lens = np.array([len(d[0]) for d in data], dtype=np.int64)
+
+    def compute(pairs):   # pairs: (fragmented genome, subject genome)
+        return parallel.anib_records_to_tensor(eng.anib_pairs(ids_np[pairs[:, 0]], ids_np[pairs[:, 1]]), dev)
+
+    tiles = {}
+
+    def step(k, keep=False):
+        rows = [(k * R + i) % n for i in range(R)]
+        if world > 1:
+            grid = parallel.anim_allgather(compute, n, dev, rows=rows)
+        else:
+            pairs = parallel.anim_pair_array(n, rows)
+            grid = torch.zeros((len(rows), n, parallel.ANIM_FIELDS), dtype=torch.int64, device=dev)
+            grid[torch.from_numpy(np.repeat(np.arange(len(rows)), n - 1)).to(dev), torch.from_numpy(pairs[:, 1]).to(dev)] = compute(pairs)
+        if keep:
+            tiles[k] = (rows, grid)
+
+    def fence():
+        eng.sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for k in range(args.warmup):
+        step(k)
+    fence()
+    stages = [_lib.K_ANIM_SEED, _lib.K_ANIM_HIT, _lib.K_ANIB_BUCKET, _lib.K_ANIB_FRAG]
+    eng.profile_reset()
+    eng.profile_config(kernel_mask=sum(1 << s_ for s_ in stages), every_n=1)
+    eng.profile_enable(True)
+    t0 = time.perf_counter()
+    for k in range(args.warmup, args.warmup + args.steps):
+        step(k, keep=True)
+    fence()
+    elapsed = time.perf_counter() - t0
+    eng.profile_enable(False)
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    prof = {eng.kernel_name(s_): eng.profile_get(s_) for s_ in stages}
+    if rank == 0:
+        done_rows = [q for k in tiles for q in tiles[k][0]]
+        rowv = np.array(done_rows)
+        g = torch.cat([tiles[k][1] for k in sorted(tiles)]).cpu().numpy()
+        offdiag = rowv[:, None] != np.arange(n)[None, :]
+        related_m = ((rowv[:, None] % K) == (np.arange(n)[None, :] % K)) & offdiag
+        pid = g[:, :, 4].view(np.float64)
+        kept, nfr = g[:, :, 3], g[:, :, 2]
+        pairs_done = int(offdiag.sum())
+        frags_done = int(nfr[offdiag].sum())
+        alg_bytes = float(sum(((lens[q] + 3) // 4 + (lens + 3) // 4 + 32).sum() - ((lens[q] + 3) // 4 * 2 + 32) for q in done_rows))
+        dom = max(prof, key=lambda name: prof[name][0])
+        dom_ms, dom_n = prof[dom]
+        achieved = alg_bytes / world / (dom_ms * 1e-3) / 1e9 if dom_ms else 0.0
+        out = {
+            "metric": "genome-pairs/sec (ordered pairs) for the N x N ANIb matrices: 1020-nt fragments of one genome searched in the "
+                      "other (blastn -task blastn equivalent) + parse_blast_tab, genomes resident in HBM",
+            "value": pairs_done / elapsed, "unit": "genome-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "int32 DP scores and counts, f64 mean identity", "data": "synthetic",
+            "related_pairs_per_s": int(related_m.sum()) / elapsed, "fragments_per_s": frags_done / elapsed,
+            "config": {
+                "workload": f"C5: ANIb fragment mode on {n} synthetic genomes of 1-12 Mb (SURVEY.md §8(d): L_g = 1 000 000 + (g * 22 045 mod "
+                            f"11 000 001), seed {args.seed}), fragment size 1020; a step = {R} fragmented genomes x all {n - 1} subjects",
+                "genomes": n, "rows_per_step": R, "pairs_timed": pairs_done, "related_pairs_timed": int(related_m.sum()),
+                "fragments_timed": frags_done, "grid_pairs": n * (n - 1), "wall_s_grid": elapsed / pairs_done * n * (n - 1),
+                "related_pairs_with_hits": int(((kept > 0) & related_m).sum()), "unrelated_pairs_with_hits": int(((kept > 0) & ~related_m & offdiag).sum()),
+                "identity_related_min_med_max": [float(x) for x in np.percentile(pid[(kept > 0) & related_m], [0, 50, 100])]
+                if ((kept > 0) & related_m).any() else None,
+                "coverage_related_median": float(np.median((g[:, :, 0] / lens[rowv][:, None])[(kept > 0) & related_m]))
+                if ((kept > 0) & related_m).any() else None,
+                "parallelism": f"1 process/GPU x {world}; genomes replicated; each step's rows dealt over the ranks; one RCCL "
+                               f"all-gather per step" if world > 1 else "1 GPU",
+                "host_prep_s": t_prep,
+            },
+            "roofline": {
+                "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None, "launches": int(dom_n), "avg_launch_ms": dom_ms / max(dom_n, 1),
+                "definition": "SURVEY.md §8(d): ceil(Lq/4) + ceil(Ls/4) + 32 B per ordered pair / the HIP-event time of the stage that took "
+                              "longest; the fragment DP is LDS / VALU work, not an HBM stream: the fraction is small by construction",
+                "stage_ms": {name: round(ms, 3) for name, (ms, _) in prof.items()}, "timed_region_ms": round(elapsed * 1e3, 3),
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            sys.path.insert(0, str(ROOT / "oracle"))
+            import anib_cpu
+            threads = os.cpu_count() or 1
+            k = args.cpu_pairs or min(threads, 32)
+            rng = np.random.RandomState(777)
+            rel = [(int(q), int((q + K * int(rng.randint(1, max(2, n // K)))) % n)) for q in rng.randint(0, n, size=k // 2)]
+            rel = [(q, s_) for q, s_ in rel if q != s_ and q % K == s_ % K]
+            unrel = [(int(q), int(s_)) for q, s_ in zip(rng.randint(0, n, size=k), rng.randint(0, n, size=k)) if q % K != s_ % K][: k - len(rel)]
+            sample = rel + unrel
+            t0 = time.perf_counter()
+            with ThreadPoolExecutor(min(threads, len(sample))) as ex:     # ctypes releases the GIL: one pair per thread
+                def one(p):
+                    t1 = time.perf_counter()
+                    rows = anib_cpu.anib_cpu_pair(data[p[0]], data[p[1]])
+                    return time.perf_counter() - t1, anib_cpu.reduce_rows(rows)[:3]
+                got = list(ex.map(one, sample))
+            wall = time.perf_counter() - t0
+            t_rel = float(np.mean([x[0] for x in got[: len(rel)]])) if rel else 0.0
+            t_unrel = float(np.mean([x[0] for x in got[len(rel):]])) if unrel else 0.0
+            n_rel_job = n * (n // K - 1)
+            job_cpu = n_rel_job * t_rel + (n * (n - 1) - n_rel_job) * t_unrel
+            out["cpu_baseline"] = {
+                "value": n * (n - 1) / (job_cpu / threads), "unit": "genome-pairs/s", "cores": threads, "kind": "port",
+                "variant": "own-cpu (oracle/anib_cpu.cpp: host build of the fragment-mode statement; NOT BLAST+)",
+                "sample": f"blastn is not on this box; {len(sample)} ordered pairs ({len(rel)} related, {len(unrel)} unrelated) one per host thread "
+                          f"({wall:.1f} s wall): {t_rel:.1f} s per related, {t_unrel:.1f} s per unrelated pair; extrapolated linearly to the N x N job "
+                          f"on {threads} threads",
+                "job_seconds_extrapolated": job_cpu / threads,
+            }
+            out["cpu_baseline"]["speedup_gpu_over_cpu_job"] = out["value"] / out["cpu_baseline"]["value"]
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    eng.close()
+
+
+# =====================================================================================================================
 # TETRA (C2)
 # =====================================================================================================================
 def tetra_cpu_baseline(eng_z, sample, n_genomes, n_pairs):
@@ -530,6 +683,8 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     if args.workload == "anim":
         return run_anim(args, rank, world, local, dist, torch)
+    if args.workload == "anib":
+        return run_anib(args, rank, world, local, dist, torch)
     return run_tetra(args, rank, world, local, dist, torch)
 
 

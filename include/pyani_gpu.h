@@ -212,7 +212,9 @@ int pg_profile_reset(pg_ctx* ctx);
 #define PG_K_ANIM_EXTLANE 8  /* anim_extdp_lane_kernel */
 #define PG_K_ANIM_EXTEND 9   /* anim_extreq_kernel / anim_extend_kernel / anim_gapreq_kernel / anim_gapdp_kernel */
 #define PG_K_ANIM_FINISH 10  /* anim_finish_kernel */
-#define PG_K__COUNT 11
+#define PG_K_ANIB_BUCKET 11  /* anib_bucket_kernel: seeds clipped to fragments, counting sort by fragment */
+#define PG_K_ANIB_FRAG 12    /* anib_frag_kernel: anchors + X-drop extensions, one wave per (pair, fragment) */
+#define PG_K__COUNT 13
 /* total milliseconds and number of launches of kernel `which` since the last reset (synchronises). */
 int pg_profile_get(pg_ctx* ctx, int which, double* total_ms_out, uint64_t* launches_out);
 const char* pg_kernel_name(int which);

@@ -128,21 +128,28 @@ void run_pair(const Genome& Q, const Genome& S, int32_t fragsize, std::vector<Ro
   for (size_t f = 0; f < frags.size(); ++f) {
     const int32_t fp = frags[f].first, qlen = frags[f].second;
     std::vector<Row> cand;
+    // anchors of both strands first (a weak candidate is dropped when the fragment has a strong one), then the extensions
+    int pick[2][2], nc[2] = {0, 0};
+    int32_t votes[2][2], vmax = 0;
     for (int strand = 0; strand < 2; ++strand) {
       std::vector<FragSeed>& e = seeds[strand][f];
       if (e.empty()) continue;
       std::sort(e.begin(), e.end(), [](const FragSeed& x, const FragSeed& y) { return x.len != y.len ? x.len > y.len : (x.q != y.q ? x.q < y.q : x.s < y.s); });
       if (e.size() > (size_t)FRAG_MAX_SEEDS) e.resize(FRAG_MAX_SEEDS);
-      int pick[2];
-      const int nc = frag_pick_anchors(e.data(), (int)e.size(), pick);
+      nc[strand] = frag_pick_anchors(e.data(), (int)e.size(), pick[strand], votes[strand]);
+      for (int c = 0; c < nc[strand]; ++c) vmax = std::max(vmax, votes[strand][c]);
+    }
+    for (int strand = 0; strand < 2; ++strand) {
+      std::vector<FragSeed>& e = seeds[strand][f];
       auto q_at = [&](int64_t p) -> int {
         if (p < 0 || p >= qlen) return 4;
         const int64_t g = strand ? fp + (qlen - 1 - p) : fp + p;
         if (!QVw.clean(g)) return 4;
         return strand ? 3 - QVw.base(g) : QVw.base(g);
       };
-      for (int c = 0; c < nc; ++c) {
-        const FragSeed& A = e[pick[c]];
+      for (int c = 0; c < nc[strand]; ++c) {
+        if (!frag_keep_candidate(votes[strand][c], vmax)) continue;
+        const FragSeed& A = e[pick[strand][c]];
         const int srec = record_of(S.rec_start.data(), (int)S.rec_start.size() - 1, A.s);
         const int64_t s_lo = S.rec_start[srec], s_hi = S.rec_start[srec + 1] - 1;
         auto s_at = [&](int64_t p) -> int { return (p >= s_lo && p < s_hi && SV.clean(p)) ? SV.base(p) : 5; };

@@ -9,7 +9,8 @@ PG_OK, PG_E_ARG, PG_E_NODEVICE, PG_E_HIP, PG_E_IO, PG_E_NOMEM, PG_E_KEYSET, PG_E
 PG_E_CAPACITY, PG_ANIM_NO_ALIGNMENT = -9, 1
 K_TETRA_COUNT, K_TETRA_FINALIZE, K_TETRA_STATS, K_TETRA_PAIRS = 0, 1, 2, 3
 (K_ANIM_SEED, K_ANIM_HIT, K_ANIM_CLUSTER, K_ANIM_GAPS, K_ANIM_EXTLANE, K_ANIM_EXTEND, K_ANIM_FINISH) = 4, 5, 6, 7, 8, 9, 10
-K_COUNT = 11
+K_ANIB_BUCKET, K_ANIB_FRAG = 11, 12
+K_COUNT = 13
 
 # every symbol declared in include/pyani_gpu.h: (name, restype, argtypes)
 _vp, _i32, _u32, _u64, _int = ctypes.c_void_p, ctypes.c_int32, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_int

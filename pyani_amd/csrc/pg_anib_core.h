@@ -155,7 +155,13 @@ constexpr int FRAG_VOTE_WIN = 16, FRAG_VOTE_FAR = 48, FRAG_MAX_SEEDS = 64, FRAG_
 PG_HD bool frag_seed_before(const FragSeed& a, const FragSeed& o) {      // a is preferred to o at equal votes / as the longer anchor
   return a.len > o.len || (a.len == o.len && (a.q < o.q || (a.q == o.q && a.s < o.s)));
 }
-PG_HD int frag_pick_anchors(const FragSeed* e, int n, int* cand) {
+// votes[] receives each candidate's locus score.  frag_keep_candidate: a candidate whose locus holds fewer than 32 matched bases
+// (one chance 16-mer) is not extended when another candidate of the fragment (either strand) holds at least 64.
+constexpr int FRAG_WEAK_VOTES = 32, FRAG_STRONG_VOTES = 64;
+PG_HD bool frag_keep_candidate(int32_t votes, int32_t best_votes_of_fragment) {
+  return !(votes < FRAG_WEAK_VOTES && best_votes_of_fragment >= FRAG_STRONG_VOTES);
+}
+PG_HD int frag_pick_anchors(const FragSeed* e, int n, int* cand, int32_t* votes_out) {
   int nc = 0;
   int64_t first_diag = 0;
   for (int round = 0; round < 2; ++round) {
@@ -180,6 +186,7 @@ PG_HD int frag_pick_anchors(const FragSeed* e, int n, int* cand) {
       if (round == 1 && (db - first_diag < FRAG_VOTE_FAR && first_diag - db < FRAG_VOTE_FAR)) continue;
       if (frag_seed_before(e[b], e[anchor])) anchor = b;
     }
+    votes_out[nc] = (int32_t)(best_votes > 0x7FFFFFFF ? 0x7FFFFFFF : best_votes);
     cand[nc++] = anchor;
     first_diag = (int64_t)e[anchor].s - e[anchor].q;
   }

@@ -682,11 +682,15 @@ static int anib_frag_stage(pg_ctx* ctx, AnimScratch* A, const int32_t* qry_ids, 
   PG_HIP(ctx, hipMemcpyAsync(A->fr_pairs, fp.data(), n_pairs * sizeof(FragPair), hipMemcpyHostToDevice, ctx->stream));
   if (slots) PG_HIP(ctx, hipMemcpyAsync(A->fr_slot_pair, slot_pair.data(), (size_t)slots * 4, hipMemcpyHostToDevice, ctx->stream));
   PG_HIP(ctx, hipMemcpyAsync(A->fr_ebase, ebase.data(), n_units * 8, hipMemcpyHostToDevice, ctx->stream));
+  pg_prof_begin(ctx, PG_K_ANIB_BUCKET);
   hipLaunchKernelGGL(anib_bucket_kernel, dim3(n_units), dim3(256), 0, ctx->stream, A->units_d, A->fr_pairs, A->mem, A->moff, A->mem_count,
                      A->fr_ebase, F.fragsize, A->fr_off, A->fr_entries);
+  pg_prof_end(ctx);
+  pg_prof_begin(ctx, PG_K_ANIB_FRAG);
   if (slots)
     hipLaunchKernelGGL(anib_frag_kernel, dim3((uint32_t)slots), dim3(64), 0, ctx->stream, A->refs_d, A->units_d, A->fr_pairs, A->fr_slot_pair,
                        A->fr_off, A->fr_entries, A->fr_ebase, A->fr_rows, A->fr_nrows);
+  pg_prof_end(ctx);
   hipLaunchKernelGGL(anib_reduce_pairs_kernel, dim3((n_pairs + 63) / 64), dim3(64), 0, ctx->stream, A->fr_pairs, n_pairs, A->fr_rows, A->fr_nrows,
                      A->fr_out);
   PG_HIP(ctx, hipGetLastError());

@@ -124,6 +124,17 @@ def anim_allgather(compute_pairs: Callable, n_genomes: int, device: torch.device
     return grid
 
 
+def anib_records_to_tensor(recs, device: torch.device) -> torch.Tensor:
+    """Engine.anib_pairs structured array -> int64 [n, ANIM_FIELDS] tensor: aln_length, sim_errors, n_frags, n_kept, mean
+    pident (bit-cast, lossless), status — fragment mode shards and gathers exactly like ANIm (anim_allgather)."""
+    import numpy as np
+    a = np.zeros((len(recs), ANIM_FIELDS), dtype=np.int64)
+    a[:, 0], a[:, 1], a[:, 2], a[:, 3] = recs["aln_length"], recs["sim_errors"], recs["n_frags"], recs["n_kept"]
+    a[:, 4] = recs["pid"].view(np.int64)
+    a[:, 5] = recs["status"]
+    return torch.from_numpy(a).to(device)
+
+
 def anim_records_to_tensor(recs, device: torch.device) -> torch.Tensor:
     """Engine.anim_pairs structured array -> int64 [n, ANIM_FIELDS] tensor (identity bit-cast, lossless)."""
     import numpy as np
