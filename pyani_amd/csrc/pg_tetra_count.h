@@ -27,7 +27,7 @@
 constexpr int K0_H7_BINS = 16384;
 constexpr uint32_t K0_FORCE_FLUSH_TILES = 16384;  // <= 2^30 bases: keeps every u32 bin far from overflow
 
-// LDS layout in words: H7[16384] | S_hi2[1024] | S_lo2[1024] | F4[256] | E3[64] | E2[16]   = 73.3 KiB: two workgroups per CU
+// LDS layout in words: H7[16384] | S_hi2[1024] | S_lo2[1024] | F4[256] | E3[64] | E2[16] | DUMMY[64]   = 73.6 KiB: two workgroups per CU
 struct K0Lds {
   static constexpr int H7 = 0;
   static constexpr int S_HI2 = H7 + K0_H7_BINS;
@@ -35,7 +35,8 @@ struct K0Lds {
   static constexpr int F4 = S_LO2 + 1024;
   static constexpr int E3 = F4 + 256;
   static constexpr int E2 = E3 + 64;
-  static constexpr int WORDS = E2 + 16;
+  static constexpr int DUMMY = E2 + 16;    // 64 words, one per lane (its own bank): where the atomic of a dirty heptamer lands
+  static constexpr int WORDS = DUMMY + 64;
   static_assert(2 * WORDS * 4 <= 160 * 1024, "two workgroups must fit the 160 KiB of one gfx950 CU");
 };
 
@@ -86,29 +87,57 @@ __device__ __forceinline__ void k0_dirty_heptamer(uint32_t m7, uint32_t h, uint3
 }
 
 // 16 heptamers at offsets 0,4,..,60 of the lane's 64 bases (+3 look-ahead), one LDS atomic each.
-// CHECK = false: the whole wave is known clean (no mask work at all).  CHECK = true: every heptamer tests its 7 mask
-// bits and falls back to k0_dirty_heptamer when one is dirty — still one pass, ~1.5x the clean cost for that wave.
+// CHECK = false: the whole wave is known clean (no mask work at all).  CHECK = true (the wave saw a dirty base): still sixteen
+// unconditional atomics per lane, no branch in the hot part — whether a heptamer is clean comes from three shift-and-AND steps
+// per mask word (c7 bit p = mask bits p..p+6 all set) and a dirty heptamer's atomic is redirected to the lane's own dummy word;
+// the dirty heptamers that still hold clean window starts are then classified one by one in a loop only the lanes that have
+// some enter (r01: every heptamer of such a wave tested its mask bits and branched, 3.7 x the clean cost at 3000 N runs per
+// genome — scaffolded drafts look like that).
 template <bool CHECK>
-__device__ __forceinline__ void k0_count_lane(const LaneData& d, uint32_t* lds_h7, uint32_t* F4, uint32_t* E3, uint32_t* E2) {
+__device__ __forceinline__ void k0_count_lane(const LaneData& d, uint32_t* lds_h7, uint32_t* F4, uint32_t* E3, uint32_t* E2,
+                                              uint32_t dummy_byte_off = 0) {
   const uint32_t w[5] = {d.c.x, d.c.y, d.c.z, d.c.w, d.nc};
   // mask bits starting at base 0, 16, 32, 48 (each word holds >= 19 valid bits from there)
   const uint32_t mw[4] = {d.m.x, __builtin_amdgcn_alignbit(d.m.y, d.m.x, 16), d.m.y, __builtin_amdgcn_alignbit(d.nm, d.m.y, 16)};
   char* h7b = reinterpret_cast<char*>(lds_h7);
+  uint32_t need = 0, need_lo = 0;   // CHECK: dirty heptamers that still hold clean window starts (bit 4t + 16 (j & 1), words (0,1) | (2,3))
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const uint32_t lo = w[j], hi = w[j + 1];
     // byte offsets (heptamer << 2) of the four heptamers that start in this code word
     const uint32_t off[4] = {lo << 2, lo >> 6, lo >> 14, __builtin_amdgcn_alignbit(hi, lo, 22)};
+    uint32_t c7 = 0;
+    if (CHECK) {
+      const uint32_t c2 = mw[j] & (mw[j] >> 1), c4 = c2 & (c2 >> 2);
+      c7 = c4 & (c4 >> 3);
+      // heptamers (stride 4: bits 0, 4, 8, 12) that are dirty but whose first four bases hold a clean one
+      const uint32_t a2 = mw[j] | (mw[j] >> 1), a4 = a2 | (a2 >> 2);
+      need |= (a4 & ~c7 & 0x1111u) << (16 * (j & 1));   // words 0 / 1 -> low / high half of a 32-bit word ...
+      if (j == 1) { need_lo = need; need = 0; }                    // ... two such words: (need_lo, need)
+    }
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const uint32_t o = off[t] & 0xFFFCu;
       if (!CHECK) {
         lds_inc(reinterpret_cast<uint32_t*>(h7b + o));
       } else {
-        const uint32_t m7 = (mw[j] >> (4 * t)) & 0x7Fu;
-        if (m7 == 0x7Fu) lds_inc(reinterpret_cast<uint32_t*>(h7b + o));
-        else if (m7 & 0xFu) k0_dirty_heptamer(m7, o >> 2, F4, E3, E2);
+        const bool clean = (c7 >> (4 * t)) & 1u;
+        lds_inc(reinterpret_cast<uint32_t*>(h7b + (clean ? o : dummy_byte_off)));
       }
+    }
+  }
+  if (CHECK) {
+    unsigned long long todo = ((unsigned long long)need << 32) | need_lo;   // bit 16 j + 4 t
+    while (todo) {   // rare: a heptamer that touches the edge of a dirty run
+      const int b = __ffsll(todo) - 1;
+      todo &= todo - 1;
+      const int j = b >> 4, tt = (b >> 2) & 3;
+      // (selects, not w[j]: a dynamically indexed register array would live in scratch memory)
+      const uint32_t lo = j == 0 ? w[0] : j == 1 ? w[1] : j == 2 ? w[2] : w[3];
+      const uint32_t hi = j == 0 ? w[1] : j == 1 ? w[2] : j == 2 ? w[3] : w[4];
+      const uint32_t mj = j == 0 ? mw[0] : j == 1 ? mw[1] : j == 2 ? mw[2] : mw[3];
+      const uint32_t h = (tt == 0 ? lo : tt == 1 ? lo >> 8 : tt == 2 ? lo >> 16 : __builtin_amdgcn_alignbit(hi, lo, 24)) & 0x3FFFu;
+      k0_dirty_heptamer((mj >> (4 * tt)) & 0x7Fu, h, F4, E3, E2);
     }
   }
 }
@@ -129,7 +158,7 @@ __device__ __forceinline__ void k0_process(LaneData d, uint32_t* lds, uint32_t t
   if (__all(all_clean)) {
     k0_count_lane<false>(d, h7, nullptr, nullptr, nullptr);
   } else if (!__all(none_clean)) {
-    if (!none_clean) k0_count_lane<true>(d, h7, lds + L::F4, lds + L::E3, lds + L::E2);
+    if (!none_clean) k0_count_lane<true>(d, h7, lds + L::F4, lds + L::E3, lds + L::E2, (uint32_t)(L::DUMMY + (tid & 63u)) * 4u);
   }
 }
 
