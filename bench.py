@@ -10,8 +10,9 @@ C2 TETRA roofline nested as a sub-record.
 
 ANIm (default).  All genomes are resident in HBM on every GPU (2-bit codes + 1-bit mask; 1.9 GB at C4).  A STEP is one
 pass of the whole pipeline — seed, cluster, extend, 1-to-1 filter, parse_delta reduction, results back on the host — over
-one tile of the ordered-pair grid: `--rows-per-step` reference genomes (default 100) x all 999 queries = 99 900 ordered
-pairs; step k takes rows [k*R, (k+1)*R) modulo N, so 10 steps are exactly one pass over the N x N grid.  `value` = ordered
+one tile of the ordered-pair grid: `--rows-per-step` reference genomes (default 500) x all 999 queries = 499 500 ordered
+pairs; step k takes rows [k*R, (k+1)*R) modulo N, so 2 steps are exactly one pass over the N x N grid (large steps keep every
+rank's launches full-size when the rows are dealt over 8 GPUs).  `value` = ordered
 pairs processed in the K timed steps / wall time.  N > 1 is STRONG scaling of that same job: the rows of every step are
 dealt over the ranks (pyani_amd.parallel.anim_row_shard), each rank runs its rows against all queries, ONE RCCL all-gather
 per step (64 B per pair) puts the step's rows of the result grid on every rank.  No other collective, no sequence traffic.
@@ -48,12 +49,12 @@ def parse_args():
     ap.add_argument("--workload", choices=["anim", "tetra", "anib"], default="anim",
                     help="anim = C4 (default: the N x N ANIm grid the metric is quoted on); tetra = C2 alone; "
                          "anib = C5 (mixed-length set, 1020-nt fragment mode)")
-    ap.add_argument("--steps", type=int, default=None, help="default 10 (anim: one pass over the grid) / 50 (tetra)")
-    ap.add_argument("--warmup", type=int, default=None, help="default 2 (anim) / 5 (tetra)")
+    ap.add_argument("--steps", type=int, default=None, help="default 4 (anim: two passes over the grid) / 50 (tetra) / 3 (anib)")
+    ap.add_argument("--warmup", type=int, default=None, help="default 1 (anim, anib) / 5 (tetra)")
     ap.add_argument("--genomes", type=int, default=None, help="anim: genomes of the job (C4: 1000); tetra: genomes per GPU (C2: 200)")
     ap.add_argument("--length", type=int, default=5_000_000, help="ancestor length in bases (5 Mb)")
     ap.add_argument("--seed", type=int, default=None, help="default: the set's own seed (C4 20250301, C2 20250228)")
-    ap.add_argument("--rows-per-step", type=int, default=100, help="anim: reference genomes (grid rows) per step")
+    ap.add_argument("--rows-per-step", type=int, default=None, help="reference genomes (grid rows) per step: default 500 (anim) / 10 (anib)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=0, help="anim: ordered pairs timed by the CPU leg (0 = one per host thread, <= 128)")
     ap.add_argument("--cpu-genomes", type=int, default=2, help="tetra: genomes timed by the CPU leg")
@@ -61,15 +62,15 @@ def parse_args():
     args = ap.parse_args()
     w = args.workload
     if args.steps is None:
-        args.steps = {"anim": 10, "tetra": 50, "anib": 3}[w]
+        args.steps = {"anim": 4, "tetra": 50, "anib": 3}[w]
     if args.warmup is None:
-        args.warmup = {"anim": 2, "tetra": 5, "anib": 1}[w]
+        args.warmup = {"anim": 1, "tetra": 5, "anib": 1}[w]
     if args.genomes is None:
         args.genomes = {"anim": 1000, "tetra": 200, "anib": 500}[w]
     if args.seed is None:
         args.seed = {"anim": 20250301, "tetra": 20250228, "anib": 20250302}[w]
-    if w == "anib" and args.rows_per_step == 100:
-        args.rows_per_step = 10
+    if args.rows_per_step is None:
+        args.rows_per_step = 10 if w == "anib" else 500
     return args
 
 
@@ -225,6 +226,8 @@ def run_anim(args, rank, world, local, dist, torch):
     from pyani_amd.engine import Engine
     eng = Engine(local)
     n, R = args.genomes, max(1, min(args.rows_per_step, args.genomes))
+    if os.environ.get("PYANI_BENCH_BATCH_PAIRS"):   # development: pairs / matches per internal launch of pg_anim_pairs
+        eng.anim_set_batch_budget(int(os.environ["PYANI_BENCH_BATCH_PAIRS"]), int(os.environ.get("PYANI_BENCH_BATCH_MATCHES", 256 << 20)))
     K = (n + 24) // 25                       # ancestors of the SURVEY.md §8(d) generator: genome g descends from ancestor g mod K
     t_prep = time.perf_counter()
     data = synth_genomes(args.seed, n, args.length, 0, n, world)

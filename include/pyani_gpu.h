@@ -130,9 +130,10 @@ typedef struct {
 int pg_anim_pairs(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_ids, uint64_t n_pairs, int maxmatch,
                   int filter_1to1, pg_anim_result* out);
 
-/* Work-memory budget of one internal launch of pg_anim_pairs: at most max_pairs ordered pairs and max_matches exact
- * matches (about 264 bytes of device scratch each; default 65536 pairs / 256 Mi matches = ~68 GB).  Larger calls are
- * split transparently; results do not depend on the split. */
+/* Work-memory budget of pg_anim_pairs: at most max_pairs ordered pairs and max_matches exact matches in flight (about 264 bytes
+ * of device scratch per match, grown on demand; default 131072 pairs / 512 Mi matches, split over the context's two workers =
+ * launches of up to 65536 pairs / 256 Mi matches, ~68 GB each).  Larger calls are split transparently; results do not depend on
+ * the split. */
 int pg_anim_set_batch_budget(pg_ctx* ctx, uint32_t max_pairs, uint64_t max_matches);
 
 /* The alignment records of ONE ordered pair: the content of the .delta file nucmer would write (kept == 3 marks the

@@ -83,16 +83,19 @@ __device__ __forceinline__ void get16(const uint32_t* __restrict__ codes, const 
 // Scratch lives in the context and only grows.  The per-unit kernels are latency-bound single-thread code, so the
 // batch should be as large as memory allows: thousands of units in flight are what fills the GPU.
 namespace {
+// per-genome seed lists (built once per resident genome and role, dropped by pg_clear_genomes); shared by the two workers of a
+// context: built under ctx->anim_mu and complete (stream synchronised) before the lock is released
+struct GenomeIdx {
+  uint64_t *ref_list = nullptr, *qry_list = nullptr, *qry_list1 = nullptr;   // qry_list1: every position (fragment mode)
+  uint32_t *ref_goff = nullptr, *qry_goff = nullptr, *qry_goff1 = nullptr;
+  uint32_t ref_max = 0;   // largest reference group (sizes the LDS table)
+};
+struct AnimLists { std::vector<GenomeIdx> gidx; };
+thread_local int tls_worker = 0;   // which of the context's two (stream, scratch) sets the calling thread drives
+
 struct AnimScratch {
   size_t units = 0, pairs = 0, refs = 0, recs = 0, wl = 0, matches = 0;
-  // per-genome seed lists (built once per resident genome and role, dropped by pg_clear_genomes)
-  struct GenomeIdx {
-    uint64_t *ref_list = nullptr, *qry_list = nullptr, *qry_list1 = nullptr;   // qry_list1: every position (fragment mode)
-    uint32_t *ref_goff = nullptr, *qry_goff = nullptr, *qry_goff1 = nullptr;
-    uint32_t ref_max = 0;   // largest reference group (sizes the LDS table)
-  };
-  std::vector<GenomeIdx> gidx;
-  uint32_t* list_cnt = nullptr;   // 2 * SEED_GROUPS counters shared by the list builds
+  uint32_t* list_cnt = nullptr;   // 2 * SEED_GROUPS counters used by this worker's list builds
   SeedRef* srefs_d = nullptr;
   SeedQry* sqry_d = nullptr;
   SeedSlice* slice_d = nullptr;   // [SEED_GROUPS][pairs of the batch]
@@ -151,12 +154,23 @@ int regrow(pg_ctx* ctx, T*& p, size_t n) {
 }  // namespace
 
 static AnimScratch* anim_scratch(pg_ctx* ctx) {
-  if (!ctx->anim_scratch) ctx->anim_scratch = new AnimScratch();
-  return static_cast<AnimScratch*>(ctx->anim_scratch);
+  void*& slot = tls_worker ? ctx->anim_scratch2 : ctx->anim_scratch;
+  if (!slot) slot = new AnimScratch();
+  return static_cast<AnimScratch*>(slot);
+}
+static AnimLists* anim_lists(pg_ctx* ctx) {   // (callers hold ctx->anim_mu)
+  if (!ctx->anim_lists) ctx->anim_lists = new AnimLists();
+  return static_cast<AnimLists*>(ctx->anim_lists);
+}
+static hipStream_t cur_stream(pg_ctx* ctx) { return tls_worker ? ctx->stream2 : ctx->stream; }
+void pg_anim_set_worker(pg_ctx* ctx, int worker) {
+  tls_worker = worker ? 1 : 0;
+  pg_tls_stream = cur_stream(ctx);
 }
 
 void pg_anim_drop_lists(pg_ctx* ctx) {
-  AnimScratch* A = static_cast<AnimScratch*>(ctx->anim_scratch);
+  std::lock_guard<std::mutex> lk(ctx->anim_mu);
+  AnimLists* A = static_cast<AnimLists*>(ctx->anim_lists);
   if (!A) return;
   for (auto& g : A->gidx) {
     void* ptrs[] = {g.ref_list, g.qry_list, g.ref_goff, g.qry_goff, g.qry_list1, g.qry_goff1};
@@ -169,12 +183,15 @@ void pg_anim_drop_lists(pg_ctx* ctx) {
 static int anim_ensure_lists(pg_ctx* ctx, AnimScratch* A, const std::vector<int32_t>& ref_genomes, const std::vector<int32_t>& qry_genomes,
                              int qstep) {
   int rc;
-  if (A->gidx.size() < ctx->genomes.size()) A->gidx.resize(ctx->genomes.size());
+  std::lock_guard<std::mutex> lk(ctx->anim_mu);   // one worker builds at a time; a list is complete before anyone else sees it
+  AnimLists* LS = anim_lists(ctx);
+  if (LS->gidx.size() < ctx->genomes.size()) LS->gidx.resize(ctx->genomes.size());
+  bool built = false;
   if (!A->list_cnt && (rc = regrow(ctx, A->list_cnt, (size_t)2 * SEED_GROUPS))) return rc;
   std::vector<int32_t> fresh_refs;
   for (int role = 0; role < 2; ++role) {
     for (int32_t gid : role ? qry_genomes : ref_genomes) {
-      AnimScratch::GenomeIdx& X = A->gidx[gid];
+      GenomeIdx& X = LS->gidx[gid];
       uint64_t*& qlist = qstep == 1 ? X.qry_list1 : X.qry_list;
       uint32_t*& qgoff = qstep == 1 ? X.qry_goff1 : X.qry_goff;
       if (role ? qlist != nullptr : X.ref_list != nullptr) continue;
@@ -190,37 +207,43 @@ static int anim_ensure_lists(pg_ctx* ctx, AnimScratch* A, const std::vector<int3
       const uint32_t* mask = ctx->d_mask + G.arena_start / 32;
       const int32_t n_idx = role ? len / qstep + 1 : len;
       const dim3 grid((uint32_t)(n_idx + LIST_CHUNK - 1) / LIST_CHUNK, role ? 2 : 1);
-      PG_HIP(ctx, hipMemsetAsync(A->list_cnt, 0, (size_t)n_sub * 4, ctx->stream));
+      PG_HIP(ctx, hipMemsetAsync(A->list_cnt, 0, (size_t)n_sub * 4, cur_stream(ctx)));
       if (grid.x)   // (an empty genome still gets its all-zero offset table from the scan)
-        hipLaunchKernelGGL(anim_list_kernel, grid, dim3(LIST_BLOCK), 0, ctx->stream, codes, mask, len, role, A->list_cnt,
+        hipLaunchKernelGGL(anim_list_kernel, grid, dim3(LIST_BLOCK), 0, cur_stream(ctx), codes, mask, len, role, A->list_cnt,
                            (const uint32_t*)nullptr, (uint64_t*)nullptr, 0, qstep);
-      hipLaunchKernelGGL(anim_list_scan_kernel, dim3(1), dim3(64), 0, ctx->stream, A->list_cnt, goff, n_sub);
+      hipLaunchKernelGGL(anim_list_scan_kernel, dim3(1), dim3(64), 0, cur_stream(ctx), A->list_cnt, goff, n_sub);
       if (grid.x)
-        hipLaunchKernelGGL(anim_list_kernel, grid, dim3(LIST_BLOCK), 0, ctx->stream, codes, mask, len, role, A->list_cnt,
+        hipLaunchKernelGGL(anim_list_kernel, grid, dim3(LIST_BLOCK), 0, cur_stream(ctx), codes, mask, len, role, A->list_cnt,
                            (const uint32_t*)goff, list, 1, qstep);
       if (!role) fresh_refs.push_back(gid);
+      built = true;
     }
   }
   PG_HIP(ctx, hipGetLastError());
-  if (!fresh_refs.empty()) {
-    PG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    for (int32_t gid : fresh_refs)
-      PG_HIP(ctx, hipMemcpy(&A->gidx[gid].ref_max, A->gidx[gid].ref_goff + SEED_GROUPS + 1, 4, hipMemcpyDeviceToHost));
-  }
+  if (built) PG_HIP(ctx, hipStreamSynchronize(cur_stream(ctx)));
+  for (int32_t gid : fresh_refs)
+    PG_HIP(ctx, hipMemcpy(&LS->gidx[gid].ref_max, LS->gidx[gid].ref_goff + SEED_GROUPS + 1, 4, hipMemcpyDeviceToHost));
   return PG_OK;
 }
 
+static void anim_free_one(pg_ctx* ctx, void*& slot);
 void pg_anim_free_scratch(pg_ctx* ctx) {
-  AnimScratch* A = static_cast<AnimScratch*>(ctx->anim_scratch);
-  if (!A) return;
   pg_anim_drop_lists(ctx);
+  delete static_cast<AnimLists*>(ctx->anim_lists);
+  ctx->anim_lists = nullptr;
+  anim_free_one(ctx, ctx->anim_scratch);
+  anim_free_one(ctx, ctx->anim_scratch2);
+}
+static void anim_free_one(pg_ctx* ctx, void*& slot) {
+  AnimScratch* A = static_cast<AnimScratch*>(slot);
+  if (!A) return;
   void* ptrs[] = {A->ext_reqs, A->ext_pre, A->ext_dumps, A->ext_wave, A->ext_counts, A->gap_counts, A->task_cls, A->task_lists, A->hits_sorted, A->hit_count, A->hoff, A->hit_cursor, A->hits_d, A->slice_d, A->choff_d, A->list_cnt, A->srefs_d, A->sqry_d, A->recs_d, A->refs_d, A->units_d, A->mem_count, A->moff, A->nch, A->status, A->out, A->mem, A->cm,
                   A->iscratch, A->order, A->prev, A->next, A->alnof, A->chains, A->fw, A->bw, A->S.alns, A->S.a_rrec,
                   A->S.a_qrec, A->S.idx, A->S.from, A->S.sc, A->wl_d, A->seedbuf, A->seed_total, A->tasks_d, A->fr_tables, A->fr_pairs,
                   A->fr_slot_pair, A->fr_off, A->fr_nrows, A->fr_ebase, A->fr_entries, A->fr_rows, A->fr_out};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   delete A;
-  ctx->anim_scratch = nullptr;
+  slot = nullptr;
 }
 
 // One batch of ordered pairs (ref_ids grouped).  The seed pass appends every unit's matches to one buffer and counts them
@@ -319,9 +342,9 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
       U.ref = (int32_t)ref_of_pair[p];
     }
   }
-  PG_HIP(ctx, hipMemcpyAsync(A->recs_d, recs.data(), recs.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-  PG_HIP(ctx, hipMemcpyAsync(A->refs_d, refs.data(), n_refs * sizeof(RefDesc), hipMemcpyHostToDevice, ctx->stream));
-  PG_HIP(ctx, hipMemcpyAsync(A->units_d, units.data(), n_units * sizeof(UnitDesc), hipMemcpyHostToDevice, ctx->stream));
+  PG_HIP(ctx, hipMemcpyAsync(A->recs_d, recs.data(), recs.size() * 4, hipMemcpyHostToDevice, cur_stream(ctx)));
+  PG_HIP(ctx, hipMemcpyAsync(A->refs_d, refs.data(), n_refs * sizeof(RefDesc), hipMemcpyHostToDevice, cur_stream(ctx)));
+  PG_HIP(ctx, hipMemcpyAsync(A->units_d, units.data(), n_units * sizeof(UnitDesc), hipMemcpyHostToDevice, cur_stream(ctx)));
   // seeding: LDS-resident reference groups, streamed query groups; one pass appends (unit, match) records and the
   // per-unit counts it leaves are exact even if the buffer overflowed
   {
@@ -330,8 +353,17 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
     qry_list.erase(std::unique(qry_list.begin(), qry_list.end()), qry_list.end());
     if ((rc = anim_ensure_lists(ctx, A, ref_list, qry_list, qstep))) return rc;
   }
+  // (entries of genomes this batch uses are complete and never change while the genomes are resident; the vector itself may be
+  // resized by the other worker, so take the pointers under the lock)
+  std::vector<GenomeIdx> LSv;
+  {
+    std::lock_guard<std::mutex> lk(ctx->anim_mu);
+    LSv = anim_lists(ctx)->gidx;
+  }
+  struct { std::vector<GenomeIdx>& gidx; } LSref{LSv};
+  auto* LS = &LSref;
   uint32_t max_group = 1;
-  for (uint32_t r = 0; r < n_refs; ++r) if (A->gidx[ref_list[r]].ref_max > max_group) max_group = A->gidx[ref_list[r]].ref_max;
+  for (uint32_t r = 0; r < n_refs; ++r) if (LS->gidx[ref_list[r]].ref_max > max_group) max_group = LS->gidx[ref_list[r]].ref_max;
   uint32_t slots = 256;
   while (slots < 2 * max_group) slots <<= 1;
   if (slots > SEED_MAX_SLOTS)
@@ -339,22 +371,22 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
   std::vector<SeedRef> srefs(n_refs);
   std::vector<SeedQry> sqry(n_pairs);
   for (uint32_t p = 0; p < n_pairs; ++p)
-    sqry[p] = qstep == 1 ? SeedQry{A->gidx[qry_ids[p]].qry_list1, A->gidx[qry_ids[p]].qry_goff1} : SeedQry{A->gidx[qry_ids[p]].qry_list, A->gidx[qry_ids[p]].qry_goff};
+    sqry[p] = qstep == 1 ? SeedQry{LS->gidx[qry_ids[p]].qry_list1, LS->gidx[qry_ids[p]].qry_goff1} : SeedQry{LS->gidx[qry_ids[p]].qry_list, LS->gidx[qry_ids[p]].qry_goff};
   auto fill_srefs = [&](uint32_t limit) {
-    for (uint32_t r = 0; r < n_refs; ++r) srefs[r] = SeedRef{A->gidx[ref_list[r]].ref_list, A->gidx[ref_list[r]].ref_goff, 0, 0};
+    for (uint32_t r = 0; r < n_refs; ++r) srefs[r] = SeedRef{LS->gidx[ref_list[r]].ref_list, LS->gidx[ref_list[r]].ref_goff, 0, 0};
     for (uint32_t p = 0; p < limit; ++p) {
       SeedRef& S = srefs[ref_of_pair[p]];
       if (S.pair_end == 0) S.pair_begin = p;
       S.pair_end = p + 1;
     }
   };
-  PG_HIP(ctx, hipMemcpyAsync(A->sqry_d, sqry.data(), n_pairs * sizeof(SeedQry), hipMemcpyHostToDevice, ctx->stream));
+  PG_HIP(ctx, hipMemcpyAsync(A->sqry_d, sqry.data(), n_pairs * sizeof(SeedQry), hipMemcpyHostToDevice, cur_stream(ctx)));
   if (n_pairs > A->slice_pairs) {
     if ((rc = regrow(ctx, A->slice_d, (size_t)n_pairs * SEED_GROUPS))) return rc;
     A->slice_pairs = n_pairs;
   }
   const uint32_t slice_stride = n_pairs;   // the table is laid out for the whole batch even if only a prefix is seeded again
-  hipLaunchKernelGGL(anim_slice_kernel, dim3(n_pairs), dim3(256), 0, ctx->stream, A->sqry_d, n_pairs, A->slice_d);
+  hipLaunchKernelGGL(anim_slice_kernel, dim3(n_pairs), dim3(256), 0, cur_stream(ctx), A->sqry_d, n_pairs, A->slice_d);
   if (!A->lds_attr_set) {   // per context = per device (the attribute is a property of the function ON a device)
     PG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(anim_seed_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)(SEED_MAX_SLOTS * 8 + SEED_STAGE_BYTES)));
@@ -381,28 +413,28 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
     if (attempt == 8) return pg_fail(ctx, PG_E_CAPACITY, "anim seeding: buffers still overflow after repeated splitting");
     uint32_t counts[2] = {0, 0};   // matches appended, hits recorded
     fill_srefs(n_pairs);
-    PG_HIP(ctx, hipMemcpyAsync(A->srefs_d, srefs.data(), n_refs * sizeof(SeedRef), hipMemcpyHostToDevice, ctx->stream));
-    PG_HIP(ctx, hipMemsetAsync(A->mem_count, 0, n_units * 4, ctx->stream));
-    PG_HIP(ctx, hipMemsetAsync(A->seed_total, 0, 8, ctx->stream));   // [0] matches, [1] hits
-    PG_HIP(ctx, hipMemsetAsync(A->hit_count, 0, n_units * 4, ctx->stream));
+    PG_HIP(ctx, hipMemcpyAsync(A->srefs_d, srefs.data(), n_refs * sizeof(SeedRef), hipMemcpyHostToDevice, cur_stream(ctx)));
+    PG_HIP(ctx, hipMemsetAsync(A->mem_count, 0, n_units * 4, cur_stream(ctx)));
+    PG_HIP(ctx, hipMemsetAsync(A->seed_total, 0, 8, cur_stream(ctx)));   // [0] matches, [1] hits
+    PG_HIP(ctx, hipMemsetAsync(A->hit_count, 0, n_units * 4, cur_stream(ctx)));
     pg_prof_begin(ctx, PG_K_ANIM_SEED);
-    hipLaunchKernelGGL(anim_seed_kernel, dim3(n_refs, SEED_GROUPS), dim3(SEED_BLOCK), (size_t)slots * 8 + SEED_STAGE_BYTES, ctx->stream,
+    hipLaunchKernelGGL(anim_seed_kernel, dim3(n_refs, SEED_GROUPS), dim3(SEED_BLOCK), (size_t)slots * 8 + SEED_STAGE_BYTES, cur_stream(ctx),
                        A->refs_d, A->units_d, A->srefs_d, A->sqry_d, A->slice_d, slice_stride, slots - 1, A->hits_d,
                        (uint32_t)A->hit_cap, A->seed_total + 1, A->hit_count, qstep);
     pg_prof_end(ctx);
     PG_HIP(ctx, hipGetLastError());   // a rejected launch (LDS size) must not surface only at the end of the batch
     pg_prof_begin(ctx, PG_K_ANIM_HIT);
     // hits -> per-unit slices, then one workgroup per unit verifies / extends them
-    hipLaunchKernelGGL(anim_hoff_kernel, dim3(1), dim3(1024), 0, ctx->stream, A->hit_count, n_units, A->hoff, A->hit_cursor);
-    hipLaunchKernelGGL(anim_hit_scatter_kernel, dim3((uint32_t)ctx->num_cu * 8u), dim3(256), 0, ctx->stream, A->hits_d, A->seed_total + 1,
+    hipLaunchKernelGGL(anim_hoff_kernel, dim3(1), dim3(1024), 0, cur_stream(ctx), A->hit_count, n_units, A->hoff, A->hit_cursor);
+    hipLaunchKernelGGL(anim_hit_scatter_kernel, dim3((uint32_t)ctx->num_cu * 8u), dim3(256), 0, cur_stream(ctx), A->hits_d, A->seed_total + 1,
                        (uint32_t)A->hit_cap, A->hoff, A->hit_cursor, A->hits_sorted);
-    hipLaunchKernelGGL(anim_hit_kernel, dim3(n_units), dim3(256), 0, ctx->stream, A->refs_d, A->units_d, A->hits_sorted, A->hoff,
+    hipLaunchKernelGGL(anim_hit_kernel, dim3(n_units), dim3(256), 0, cur_stream(ctx), A->refs_d, A->units_d, A->hits_sorted, A->hoff,
                        A->seed_total + 1, (uint32_t)A->hit_cap, A->seedbuf, (uint32_t)A->seed_cap, A->seed_total, A->mem_count,
                        frag ? FRAG_SEED_MIN : MIN_MATCH, qstep);
     pg_prof_end(ctx);
-    PG_HIP(ctx, hipMemcpyAsync(cnt.data(), A->mem_count, n_units * 4, hipMemcpyDeviceToHost, ctx->stream));
-    PG_HIP(ctx, hipMemcpyAsync(counts, A->seed_total, 8, hipMemcpyDeviceToHost, ctx->stream));
-    PG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    PG_HIP(ctx, hipMemcpyAsync(cnt.data(), A->mem_count, n_units * 4, hipMemcpyDeviceToHost, cur_stream(ctx)));
+    PG_HIP(ctx, hipMemcpyAsync(counts, A->seed_total, 8, hipMemcpyDeviceToHost, cur_stream(ctx)));
+    PG_HIP(ctx, hipStreamSynchronize(cur_stream(ctx)));
     total = counts[0];
     if (counts[1] > A->hit_cap) {   // hits were dropped: the counts are incomplete -> seed half as many pairs
       if (n_pairs == 1) {
@@ -458,13 +490,13 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
     A->matches = cap;
   }
   A->S.aln_of = A->alnof;
-  PG_HIP(ctx, hipMemcpyAsync(A->moff, moff.data(), ((size_t)n_units + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
-  PG_HIP(ctx, hipMemsetAsync(A->mem_count, 0, n_units * 4, ctx->stream));
-  PG_HIP(ctx, hipMemsetAsync(A->status, 0, n_pairs * 4, ctx->stream));
+  PG_HIP(ctx, hipMemcpyAsync(A->moff, moff.data(), ((size_t)n_units + 1) * 4, hipMemcpyHostToDevice, cur_stream(ctx)));
+  PG_HIP(ctx, hipMemsetAsync(A->mem_count, 0, n_units * 4, cur_stream(ctx)));
+  PG_HIP(ctx, hipMemsetAsync(A->status, 0, n_pairs * 4, cur_stream(ctx)));
   ClusterOut O{A->moff, A->cm, A->chains, A->nch, A->order, A->prev, A->next, A->status};
   pg_prof_begin(ctx, PG_K_ANIM_HIT);
   if (total)
-    hipLaunchKernelGGL(anim_scatter_kernel, dim3((total + 255) / 256), dim3(256), 0, ctx->stream, A->seedbuf, total, A->moff, n_units,
+    hipLaunchKernelGGL(anim_scatter_kernel, dim3((total + 255) / 256), dim3(256), 0, cur_stream(ctx), A->seedbuf, total, A->moff, n_units,
                        A->mem_count, A->mem);
   pg_prof_end(ctx);
   if (frag) {   // fragment mode: the matches of every unit are in place; the rest of the batch is the fragment kernels
@@ -473,24 +505,24 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
   }
   pg_prof_begin(ctx, PG_K_ANIM_CLUSTER);
   if (getenv("PYANI_ANIM_SCALAR_CLUSTER") && !maxmatch)   // debugging aid: the one-thread-per-unit statement of the same algorithm
-    hipLaunchKernelGGL(anim_cluster_kernel, dim3((n_units + 63) / 64), dim3(64), 0, ctx->stream, A->refs_d, A->units_d, n_units,
+    hipLaunchKernelGGL(anim_cluster_kernel, dim3((n_units + 63) / 64), dim3(64), 0, cur_stream(ctx), A->refs_d, A->units_d, n_units,
                        A->mem, A->mem_count, A->iscratch, O);
   else if ((n_nonempty > 3000 && !getenv("PYANI_ANIM_SPLIT_CLUSTER")) || getenv("PYANI_ANIM_WAVE_PREP"))
     // thousands of units with matches: one wave per unit already fills the machine, and the radix scatters are bound by
     // HBM's partial-line write rate, which more waves per unit only congest (measured: C3 574 ms vs 724 ms split)
-    hipLaunchKernelGGL(anim_cluster_wave_kernel, dim3(n_units), dim3(64), 0, ctx->stream, A->refs_d, A->units_d, A->mem,
+    hipLaunchKernelGGL(anim_cluster_wave_kernel, dim3(n_units), dim3(64), 0, cur_stream(ctx), A->refs_d, A->units_d, A->mem,
                        A->mem_count, A->iscratch, O, 0, maxmatch);
   else {   // few units: PREP_WAVES waves share each unit's sorts / union-find so that the largest unit is not the launch time
-    hipLaunchKernelGGL(anim_cluster_prep_kernel, dim3(n_units), dim3(PREP_THREADS), 0, ctx->stream, A->refs_d, A->units_d, A->mem,
+    hipLaunchKernelGGL(anim_cluster_prep_kernel, dim3(n_units), dim3(PREP_THREADS), 0, cur_stream(ctx), A->refs_d, A->units_d, A->mem,
                        A->mem_count, A->iscratch, O, maxmatch);
-    hipLaunchKernelGGL(anim_cluster_wave_kernel, dim3(n_units), dim3(64), 0, ctx->stream, A->refs_d, A->units_d, A->mem,
+    hipLaunchKernelGGL(anim_cluster_wave_kernel, dim3(n_units), dim3(64), 0, cur_stream(ctx), A->refs_d, A->units_d, A->mem,
                        A->mem_count, A->iscratch, O, 1, maxmatch);
   }
   pg_prof_end(ctx);
   // work list of (unit, chain): one wave each
   std::vector<int32_t> nch(n_units);
-  PG_HIP(ctx, hipMemcpyAsync(nch.data(), A->nch, n_units * 4, hipMemcpyDeviceToHost, ctx->stream));
-  PG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  PG_HIP(ctx, hipMemcpyAsync(nch.data(), A->nch, n_units * 4, hipMemcpyDeviceToHost, cur_stream(ctx)));
+  PG_HIP(ctx, hipStreamSynchronize(cur_stream(ctx)));
   // (unit, chain) work list, one wave each: offsets by a host prefix over the per-unit chain counts, entries on device
   std::vector<uint32_t> choff((size_t)n_units + 1, 0);
   for (uint32_t u = 0; u < n_units; ++u) choff[u + 1] = choff[u] + (uint32_t)nch[u];
@@ -498,8 +530,8 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
   if (n_wl) {
     if (n_wl > A->wl) { if ((rc = regrow(ctx, A->wl_d, n_wl + n_wl / 2))) return rc; A->wl = n_wl + n_wl / 2; }
     uint32_t* choff_d = A->choff_d;
-    PG_HIP(ctx, hipMemcpyAsync(choff_d, choff.data(), choff.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(anim_wl_kernel, dim3(n_units), dim3(64), 0, ctx->stream, choff_d, A->wl_d);
+    PG_HIP(ctx, hipMemcpyAsync(choff_d, choff.data(), choff.size() * 4, hipMemcpyHostToDevice, cur_stream(ctx)));
+    hipLaunchKernelGGL(anim_wl_kernel, dim3(n_units), dim3(64), 0, cur_stream(ctx), choff_d, A->wl_d);
     // gap tasks: one slot per match (sparse), a class byte per slot, and GAP_CLASSES + 1 slot lists
     const size_t Mp = (M + 15) & ~(size_t)15;
     if (Mp > A->tasks) {
@@ -508,27 +540,27 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
       if ((rc = regrow(ctx, A->task_lists, (GAP_CLASSES + 1) * Mp))) return rc;
       A->tasks = Mp;
     }
-    PG_HIP(ctx, hipMemsetAsync(A->gap_counts, 0, (GAP_CLASSES + 1) * 4, ctx->stream));
-    PG_HIP(ctx, hipMemsetAsync(A->task_cls, 0xFF, Mp, ctx->stream));
+    PG_HIP(ctx, hipMemsetAsync(A->gap_counts, 0, (GAP_CLASSES + 1) * 4, cur_stream(ctx)));
+    PG_HIP(ctx, hipMemsetAsync(A->task_cls, 0xFF, Mp, cur_stream(ctx)));
     pg_prof_begin(ctx, PG_K_ANIM_GAPS);
-    hipLaunchKernelGGL(anim_gaps_kernel, dim3((uint32_t)n_wl), dim3(64), 0, ctx->stream, A->refs_d, A->units_d, O, A->wl_d,
+    hipLaunchKernelGGL(anim_gaps_kernel, dim3((uint32_t)n_wl), dim3(64), 0, cur_stream(ctx), A->refs_d, A->units_d, O, A->wl_d,
                        A->fw, A->tasks_d, A->task_cls);
-    hipLaunchKernelGGL(anim_gapsort_kernel, dim3((uint32_t)ctx->num_cu * 8u), dim3(GAPSORT_BLOCK), 0, ctx->stream, A->task_cls,
+    hipLaunchKernelGGL(anim_gapsort_kernel, dim3((uint32_t)ctx->num_cu * 8u), dim3(GAPSORT_BLOCK), 0, cur_stream(ctx), A->task_cls,
                        (uint32_t)Mp, A->task_lists, A->gap_counts);
     const dim3 lane_grid((uint32_t)ctx->num_cu * 8u);
-    hipLaunchKernelGGL((anim_gapdp_lane_kernel<17, false>), lane_grid, dim3(64), 0, ctx->stream, A->refs_d, A->units_d, O, A->tasks_d,
+    hipLaunchKernelGGL((anim_gapdp_lane_kernel<17, false>), lane_grid, dim3(64), 0, cur_stream(ctx), A->refs_d, A->units_d, O, A->tasks_d,
                        A->task_lists, A->gap_counts, A->fw);
-    hipLaunchKernelGGL((anim_gapdp_lane_kernel<32, false>), lane_grid, dim3(64), 0, ctx->stream, A->refs_d, A->units_d, O, A->tasks_d,
+    hipLaunchKernelGGL((anim_gapdp_lane_kernel<32, false>), lane_grid, dim3(64), 0, cur_stream(ctx), A->refs_d, A->units_d, O, A->tasks_d,
                        A->task_lists + Mp, A->gap_counts + 1, A->fw);
-    hipLaunchKernelGGL((anim_gapdp_lane_kernel<48, true>), lane_grid, dim3(64), 0, ctx->stream, A->refs_d, A->units_d, O, A->tasks_d,
+    hipLaunchKernelGGL((anim_gapdp_lane_kernel<48, true>), lane_grid, dim3(64), 0, cur_stream(ctx), A->refs_d, A->units_d, O, A->tasks_d,
                        A->task_lists + 2 * Mp, A->gap_counts + 2, A->fw);
-    hipLaunchKernelGGL((anim_gapdp_lane_kernel<64, true>), lane_grid, dim3(64), 0, ctx->stream, A->refs_d, A->units_d, O, A->tasks_d,
+    hipLaunchKernelGGL((anim_gapdp_lane_kernel<64, true>), lane_grid, dim3(64), 0, cur_stream(ctx), A->refs_d, A->units_d, O, A->tasks_d,
                        A->task_lists + 3 * Mp, A->gap_counts + 3, A->fw);
     pg_prof_end(ctx);
     // the larger gaps go through the lanes of the extension DP (anim_gapreq_kernel); their number sizes the buffers
     uint32_t gap_counts[GAP_CLASSES + 1];
-    PG_HIP(ctx, hipMemcpyAsync(gap_counts, A->gap_counts, sizeof(gap_counts), hipMemcpyDeviceToHost, ctx->stream));
-    PG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    PG_HIP(ctx, hipMemcpyAsync(gap_counts, A->gap_counts, sizeof(gap_counts), hipMemcpyDeviceToHost, cur_stream(ctx)));
+    PG_HIP(ctx, hipStreamSynchronize(cur_stream(ctx)));
     const size_t n_big = gap_counts[GAP_CLASSES], n_ext = n_wl > n_big ? n_wl : n_big;
     // development / test knobs of the hand-over rule (results do not depend on them: tests/test_anim_gpu.py)
     const int tail_lanes = getenv("PYANI_EXT_TAIL_LANES") ? atoi(getenv("PYANI_EXT_TAIL_LANES")) : EXT_TAIL_LANES;
@@ -545,56 +577,56 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
       A->ext_cap = cap;
     }
     if (n_big) {
-      PG_HIP(ctx, hipMemsetAsync(A->ext_counts, 0, 20, ctx->stream));   // [0], [1] list lengths, [2] hand-out cursor, [4] handed over
+      PG_HIP(ctx, hipMemsetAsync(A->ext_counts, 0, 20, cur_stream(ctx)));   // [0], [1] list lengths, [2] hand-out cursor, [4] handed over
       pg_prof_begin(ctx, PG_K_ANIM_EXTEND);
-      hipLaunchKernelGGL(anim_gapreq_kernel, dim3((uint32_t)((n_big + 255) / 256)), dim3(256), 0, ctx->stream, A->refs_d, A->units_d,
+      hipLaunchKernelGGL(anim_gapreq_kernel, dim3((uint32_t)((n_big + 255) / 256)), dim3(256), 0, cur_stream(ctx), A->refs_d, A->units_d,
                          A->tasks_d, A->task_lists + GAP_CLASSES * Mp, (uint32_t)n_big, A->ext_pre, A->ext_reqs, A->ext_counts);
       pg_prof_end(ctx);
       pg_prof_begin(ctx, PG_K_ANIM_EXTLANE);
-      hipLaunchKernelGGL(anim_extdp_lane_kernel, dim3((uint32_t)ctx->num_cu * 4u), dim3(64), 0, ctx->stream, A->ext_reqs, A->ext_reqs,
+      hipLaunchKernelGGL(anim_extdp_lane_kernel, dim3((uint32_t)ctx->num_cu * 4u), dim3(64), 0, cur_stream(ctx), A->ext_reqs, A->ext_reqs,
                          A->ext_counts, A->ext_counts + 2, A->ext_pre, A->ext_dumps, dump_cap, A->ext_counts + 4, tail_lanes, tail_blocks);
       pg_prof_end(ctx);
       pg_prof_begin(ctx, PG_K_ANIM_EXTEND);
-      hipLaunchKernelGGL(anim_gapdp_kernel, dim3((uint32_t)ctx->num_cu * 32u), dim3(64), 0, ctx->stream, A->refs_d, A->units_d, O,
+      hipLaunchKernelGGL(anim_gapdp_kernel, dim3((uint32_t)ctx->num_cu * 32u), dim3(64), 0, cur_stream(ctx), A->refs_d, A->units_d, O,
                          A->tasks_d, A->task_lists + GAP_CLASSES * Mp, (uint32_t)n_big, A->ext_pre, A->ext_dumps, A->fw);
       pg_prof_end(ctx);
     }
     for (int phase = 0; phase < 2; ++phase) {
       // the first DP calls of every chain: written down, solved one per LANE, then consumed by the wave kernel
-      PG_HIP(ctx, hipMemsetAsync(A->ext_counts + 4, 0, 4, ctx->stream));   // [4] searches handed over mid-way
+      PG_HIP(ctx, hipMemsetAsync(A->ext_counts + 4, 0, 4, cur_stream(ctx)));   // [4] searches handed over mid-way
       for (int round = 0; round < EXT_ROUNDS; ++round) {
-        PG_HIP(ctx, hipMemsetAsync(A->ext_counts, 0, 16, ctx->stream));   // [0], [1] list lengths, [2] hand-out cursor
+        PG_HIP(ctx, hipMemsetAsync(A->ext_counts, 0, 16, cur_stream(ctx)));   // [0], [1] list lengths, [2] hand-out cursor
         pg_prof_begin(ctx, PG_K_ANIM_EXTEND);
-        hipLaunchKernelGGL(anim_extreq_kernel, dim3((uint32_t)((n_wl + 255) / 256)), dim3(256), 0, ctx->stream, A->refs_d, A->units_d, O,
+        hipLaunchKernelGGL(anim_extreq_kernel, dim3((uint32_t)((n_wl + 255) / 256)), dim3(256), 0, cur_stream(ctx), A->refs_d, A->units_d, O,
                            A->wl_d, (uint32_t)n_wl, A->fw, A->bw, phase, round, A->ext_pre, A->ext_reqs, A->ext_reqs + n_wl, A->ext_counts,
                            A->ext_wave);
         pg_prof_end(ctx);
         pg_prof_begin(ctx, PG_K_ANIM_EXTLANE);
-        hipLaunchKernelGGL(anim_extdp_lane_kernel, dim3((uint32_t)ctx->num_cu * 4u), dim3(64), 0, ctx->stream, A->ext_reqs,
+        hipLaunchKernelGGL(anim_extdp_lane_kernel, dim3((uint32_t)ctx->num_cu * 4u), dim3(64), 0, cur_stream(ctx), A->ext_reqs,
                            A->ext_reqs + n_wl, A->ext_counts, A->ext_counts + 2, A->ext_pre + (size_t)round * n_wl, A->ext_dumps,
                            dump_cap, A->ext_counts + 4, tail_lanes, tail_blocks);
         pg_prof_end(ctx);
       }
       // final round: chains whose calls were all answered are finished by a thread each; the others (handed-over searches,
       // third calls, junction rectangles) are listed for the wave kernel
-      PG_HIP(ctx, hipMemsetAsync(A->ext_counts, 0, 12, ctx->stream));   // [0] list length, [2] hand-out cursor
+      PG_HIP(ctx, hipMemsetAsync(A->ext_counts, 0, 12, cur_stream(ctx)));   // [0] list length, [2] hand-out cursor
       pg_prof_begin(ctx, PG_K_ANIM_EXTEND);
-      hipLaunchKernelGGL(anim_extreq_kernel, dim3((uint32_t)((n_wl + 255) / 256)), dim3(256), 0, ctx->stream, A->refs_d, A->units_d, O,
+      hipLaunchKernelGGL(anim_extreq_kernel, dim3((uint32_t)((n_wl + 255) / 256)), dim3(256), 0, cur_stream(ctx), A->refs_d, A->units_d, O,
                          A->wl_d, (uint32_t)n_wl, A->fw, A->bw, phase, EXT_ROUNDS, A->ext_pre, A->ext_reqs, A->ext_reqs + n_wl,
                          A->ext_counts, A->ext_wave);
-      hipLaunchKernelGGL(anim_extend_kernel, dim3((uint32_t)ctx->num_cu * 32u), dim3(64), 0, ctx->stream, A->refs_d, A->units_d, O,
+      hipLaunchKernelGGL(anim_extend_kernel, dim3((uint32_t)ctx->num_cu * 32u), dim3(64), 0, cur_stream(ctx), A->refs_d, A->units_d, O,
                          A->wl_d, A->fw, A->bw, phase, A->ext_pre, (uint32_t)n_wl, A->ext_dumps, A->ext_wave, A->ext_counts,
                          A->ext_counts + 2);
       pg_prof_end(ctx);
     }
   }
   pg_prof_begin(ctx, PG_K_ANIM_FINISH);
-  hipLaunchKernelGGL(anim_finish_kernel, dim3(n_pairs), dim3(64), 0, ctx->stream, A->refs_d, A->units_d, n_pairs,
+  hipLaunchKernelGGL(anim_finish_kernel, dim3(n_pairs), dim3(64), 0, cur_stream(ctx), A->refs_d, A->units_d, n_pairs,
                      O, A->fw, A->bw, A->S, filter_1to1, A->out);
   pg_prof_end(ctx);
   PG_HIP(ctx, hipGetLastError());
-  PG_HIP(ctx, hipMemcpyAsync(out_host, A->out, n_pairs * sizeof(pg_anim_result), hipMemcpyDeviceToHost, ctx->stream));
-  PG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  PG_HIP(ctx, hipMemcpyAsync(out_host, A->out, n_pairs * sizeof(pg_anim_result), hipMemcpyDeviceToHost, cur_stream(ctx)));
+  PG_HIP(ctx, hipStreamSynchronize(cur_stream(ctx)));
 #ifdef PGA_DP_STATS
   {
     unsigned long long st[3][40];
@@ -678,24 +710,24 @@ static int anib_frag_stage(pg_ctx* ctx, AnimScratch* A, const int32_t* qry_ids, 
   uint64_t n_entries = 0;
   for (uint32_t u = 0; u < n_units; ++u) { ebase[u] = n_entries; n_entries += (uint64_t)cnt[u] + (uint64_t)fp[u / 2].n_frags; }
   if (n_entries > A->fr_entries_cap) { if ((rc = regrow(ctx, A->fr_entries, (size_t)n_entries + (size_t)n_entries / 4))) return rc; A->fr_entries_cap = (size_t)n_entries + (size_t)n_entries / 4; }
-  if (!tables.empty()) PG_HIP(ctx, hipMemcpyAsync(A->fr_tables, tables.data(), tables.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-  PG_HIP(ctx, hipMemcpyAsync(A->fr_pairs, fp.data(), n_pairs * sizeof(FragPair), hipMemcpyHostToDevice, ctx->stream));
-  if (slots) PG_HIP(ctx, hipMemcpyAsync(A->fr_slot_pair, slot_pair.data(), (size_t)slots * 4, hipMemcpyHostToDevice, ctx->stream));
-  PG_HIP(ctx, hipMemcpyAsync(A->fr_ebase, ebase.data(), n_units * 8, hipMemcpyHostToDevice, ctx->stream));
+  if (!tables.empty()) PG_HIP(ctx, hipMemcpyAsync(A->fr_tables, tables.data(), tables.size() * 4, hipMemcpyHostToDevice, cur_stream(ctx)));
+  PG_HIP(ctx, hipMemcpyAsync(A->fr_pairs, fp.data(), n_pairs * sizeof(FragPair), hipMemcpyHostToDevice, cur_stream(ctx)));
+  if (slots) PG_HIP(ctx, hipMemcpyAsync(A->fr_slot_pair, slot_pair.data(), (size_t)slots * 4, hipMemcpyHostToDevice, cur_stream(ctx)));
+  PG_HIP(ctx, hipMemcpyAsync(A->fr_ebase, ebase.data(), n_units * 8, hipMemcpyHostToDevice, cur_stream(ctx)));
   pg_prof_begin(ctx, PG_K_ANIB_BUCKET);
-  hipLaunchKernelGGL(anib_bucket_kernel, dim3(n_units), dim3(256), 0, ctx->stream, A->units_d, A->fr_pairs, A->mem, A->moff, A->mem_count,
+  hipLaunchKernelGGL(anib_bucket_kernel, dim3(n_units), dim3(256), 0, cur_stream(ctx), A->units_d, A->fr_pairs, A->mem, A->moff, A->mem_count,
                      A->fr_ebase, F.fragsize, A->fr_off, A->fr_entries);
   pg_prof_end(ctx);
   pg_prof_begin(ctx, PG_K_ANIB_FRAG);
   if (slots)
-    hipLaunchKernelGGL(anib_frag_kernel, dim3((uint32_t)slots), dim3(64), 0, ctx->stream, A->refs_d, A->units_d, A->fr_pairs, A->fr_slot_pair,
+    hipLaunchKernelGGL(anib_frag_kernel, dim3((uint32_t)slots), dim3(64), 0, cur_stream(ctx), A->refs_d, A->units_d, A->fr_pairs, A->fr_slot_pair,
                        A->fr_off, A->fr_entries, A->fr_ebase, A->fr_rows, A->fr_nrows);
   pg_prof_end(ctx);
-  hipLaunchKernelGGL(anib_reduce_pairs_kernel, dim3((n_pairs + 63) / 64), dim3(64), 0, ctx->stream, A->fr_pairs, n_pairs, A->fr_rows, A->fr_nrows,
+  hipLaunchKernelGGL(anib_reduce_pairs_kernel, dim3((n_pairs + 63) / 64), dim3(64), 0, cur_stream(ctx), A->fr_pairs, n_pairs, A->fr_rows, A->fr_nrows,
                      A->fr_out);
   PG_HIP(ctx, hipGetLastError());
-  PG_HIP(ctx, hipMemcpyAsync(F.out, A->fr_out, n_pairs * sizeof(pg_anib_result), hipMemcpyDeviceToHost, ctx->stream));
-  PG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  PG_HIP(ctx, hipMemcpyAsync(F.out, A->fr_out, n_pairs * sizeof(pg_anib_result), hipMemcpyDeviceToHost, cur_stream(ctx)));
+  PG_HIP(ctx, hipStreamSynchronize(cur_stream(ctx)));
   if (F.n_rows_out) {   // the table of pair 0
     const uint32_t nf = (uint32_t)fp[0].n_frags;
     std::vector<uint32_t> nr(nf);
@@ -763,17 +795,17 @@ int pg_anim_reduce_run(pg_ctx* ctx, uint32_t n_pairs, const uint64_t* offsets, c
   AA(d_off, n_pairs + 1); AA(d_a, n + 1); AA(d_rg, n + 1); AA(d_qg, n + 1); AA(d_idx, n + 1); AA(d_from, n + 1); AA(d_sc, n + 1);
   AA(d_out, n_pairs + 1);
 #undef AA
-  hipError_t e = hipMemcpyAsync(d_off, offsets, (n_pairs + 1) * 8, hipMemcpyHostToDevice, ctx->stream);
-  if (e == hipSuccess && n) e = hipMemcpyAsync(d_a, h.data(), n * sizeof(Aln), hipMemcpyHostToDevice, ctx->stream);
-  if (e == hipSuccess && n) e = hipMemcpyAsync(d_rg, rseq, n * 4, hipMemcpyHostToDevice, ctx->stream);
-  if (e == hipSuccess && n) e = hipMemcpyAsync(d_qg, qseq, n * 4, hipMemcpyHostToDevice, ctx->stream);
+  hipError_t e = hipMemcpyAsync(d_off, offsets, (n_pairs + 1) * 8, hipMemcpyHostToDevice, cur_stream(ctx));
+  if (e == hipSuccess && n) e = hipMemcpyAsync(d_a, h.data(), n * sizeof(Aln), hipMemcpyHostToDevice, cur_stream(ctx));
+  if (e == hipSuccess && n) e = hipMemcpyAsync(d_rg, rseq, n * 4, hipMemcpyHostToDevice, cur_stream(ctx));
+  if (e == hipSuccess && n) e = hipMemcpyAsync(d_qg, qseq, n * 4, hipMemcpyHostToDevice, cur_stream(ctx));
   if (e == hipSuccess) {
-    hipLaunchKernelGGL(anim_reduce_kernel, dim3((n_pairs + 63) / 64), dim3(64), 0, ctx->stream, n_pairs, d_off, d_a, d_rg, d_qg,
+    hipLaunchKernelGGL(anim_reduce_kernel, dim3((n_pairs + 63) / 64), dim3(64), 0, cur_stream(ctx), n_pairs, d_off, d_a, d_rg, d_qg,
                        d_idx, d_from, d_sc, apply_filter, d_out);
     e = hipGetLastError();
   }
-  if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, n_pairs * sizeof(pg_anim_result), hipMemcpyDeviceToHost, ctx->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, n_pairs * sizeof(pg_anim_result), hipMemcpyDeviceToHost, cur_stream(ctx));
+  if (e == hipSuccess) e = hipStreamSynchronize(cur_stream(ctx));
   cleanup();
   if (e != hipSuccess) return pg_fail(ctx, PG_E_HIP, std::string("anim reduce: ") + hipGetErrorString(e));
   return PG_OK;
@@ -831,21 +863,21 @@ int pg_anib_reduce_run(pg_ctx* ctx, uint32_t n_pairs, const uint64_t* offsets, c
   AA(d_off, n_pairs + 1); AA(d_foff, n_pairs + 1); AA(d_frag, n + 1); AA(d_len, n + 1); AA(d_mm, n + 1); AA(d_gap, n + 1);
   AA(d_ql, n + 1); AA(d_pid, n + 1); AA(d_first, foff[n_pairs] + 1); AA(d_aln, n_pairs); AA(d_err, n_pairs); AA(d_pout, n_pairs);
 #undef AA
-  hipError_t e = hipMemcpyAsync(d_off, offsets, (n_pairs + 1) * 8, hipMemcpyHostToDevice, ctx->stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(d_foff, foff.data(), (n_pairs + 1) * 8, hipMemcpyHostToDevice, ctx->stream);
+  hipError_t e = hipMemcpyAsync(d_off, offsets, (n_pairs + 1) * 8, hipMemcpyHostToDevice, cur_stream(ctx));
+  if (e == hipSuccess) e = hipMemcpyAsync(d_foff, foff.data(), (n_pairs + 1) * 8, hipMemcpyHostToDevice, cur_stream(ctx));
   const struct { void* d; const void* h; size_t b; } cp[] = {{d_frag, frag, n * 4}, {d_len, length, n * 4}, {d_mm, mismatch, n * 4},
                                                            {d_gap, gaps, n * 4}, {d_ql, qlen, n * 4}, {d_pid, pident, n * 8}};
   for (const auto& c : cp)
-    if (e == hipSuccess && c.b) e = hipMemcpyAsync(c.d, c.h, c.b, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess && c.b) e = hipMemcpyAsync(c.d, c.h, c.b, hipMemcpyHostToDevice, cur_stream(ctx));
   if (e == hipSuccess) {
-    hipLaunchKernelGGL(anib_reduce_kernel, dim3((n_pairs + 63) / 64), dim3(64), 0, ctx->stream, n_pairs, d_off, d_foff, d_frag, d_len,
+    hipLaunchKernelGGL(anib_reduce_kernel, dim3((n_pairs + 63) / 64), dim3(64), 0, cur_stream(ctx), n_pairs, d_off, d_foff, d_frag, d_len,
                        d_mm, d_gap, d_ql, d_pid, d_first, d_aln, d_err, d_pout);
     e = hipGetLastError();
   }
-  if (e == hipSuccess) e = hipMemcpyAsync(aln_out, d_aln, n_pairs * 8, hipMemcpyDeviceToHost, ctx->stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(err_out, d_err, n_pairs * 8, hipMemcpyDeviceToHost, ctx->stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(pid_out, d_pout, n_pairs * 8, hipMemcpyDeviceToHost, ctx->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(aln_out, d_aln, n_pairs * 8, hipMemcpyDeviceToHost, cur_stream(ctx));
+  if (e == hipSuccess) e = hipMemcpyAsync(err_out, d_err, n_pairs * 8, hipMemcpyDeviceToHost, cur_stream(ctx));
+  if (e == hipSuccess) e = hipMemcpyAsync(pid_out, d_pout, n_pairs * 8, hipMemcpyDeviceToHost, cur_stream(ctx));
+  if (e == hipSuccess) e = hipStreamSynchronize(cur_stream(ctx));
   cleanup();
   if (e != hipSuccess) return pg_fail(ctx, PG_E_HIP, std::string("anib reduce: ") + hipGetErrorString(e));
   return PG_OK;

@@ -4,12 +4,13 @@
 #include <cstdio>
 #include <cstring>
 #include <atomic>
+#include <functional>
 #include <thread>
 
 #include "pg_internal.h"
 
 int pg_fail(pg_ctx* ctx, int code, const std::string& msg) {
-  if (ctx) ctx->err = msg;
+  if (ctx) { std::lock_guard<std::mutex> lk(ctx->err_mu); ctx->err = msg; }
   return code;
 }
 
@@ -20,21 +21,28 @@ static const char* const KERNEL_NAMES[PG_K__COUNT] = {"tetra_count_kernel", "tet
                                                       "anib_frag_kernel"};
 
 // ---- profiling ----------------------------------------------------------------------------------------------
+thread_local hipStream_t pg_tls_stream = nullptr;
+namespace { thread_local PgEventPair tls_open_pair; thread_local bool tls_open = false; }
 void pg_prof_begin(pg_ctx* ctx, int which) {
-  ctx->prof_open = false;
+  tls_open = false;
   if (!ctx->profiling || !((ctx->prof_mask >> which) & 1u)) return;
-  if ((ctx->prof_seen[which]++ % ctx->prof_every) != 0) return;
+  {
+    std::lock_guard<std::mutex> lk(ctx->prof_mu);
+    if ((ctx->prof_seen[which]++ % ctx->prof_every) != 0) return;
+  }
   PgEventPair p;
   p.which = which;
   if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return;
-  (void)hipEventRecord(p.a, ctx->stream);
-  ctx->events.push_back(p);
-  ctx->prof_open = true;
+  (void)hipEventRecord(p.a, pg_tls_stream ? pg_tls_stream : ctx->stream);
+  tls_open_pair = p;
+  tls_open = true;
 }
 void pg_prof_end(pg_ctx* ctx) {
-  if (!ctx->prof_open || ctx->events.empty()) return;
-  ctx->prof_open = false;
-  (void)hipEventRecord(ctx->events.back().b, ctx->stream);
+  if (!tls_open) return;
+  tls_open = false;
+  (void)hipEventRecord(tls_open_pair.b, pg_tls_stream ? pg_tls_stream : ctx->stream);
+  std::lock_guard<std::mutex> lk(ctx->prof_mu);
+  ctx->events.push_back(tls_open_pair);
 }
 static void prof_drain(pg_ctx* ctx) {
   for (auto& p : ctx->events) {
@@ -311,10 +319,12 @@ int pg_create(pg_ctx** out, int device) {
   pg_ctx* ctx = new (std::nothrow) pg_ctx();
   if (!ctx) return PG_E_NOMEM;
   ctx->device = device;
-  if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+  if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess) {
     delete ctx;
     return PG_E_HIP;
   }
+  if (const char* w = getenv("PYANI_ANIM_WORKERS")) ctx->anim_workers = atoi(w) >= 2 ? 2 : 1;   // development switch
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
     ctx->num_cu = prop.multiProcessorCount;
@@ -327,6 +337,7 @@ void pg_destroy(pg_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
+  (void)hipStreamSynchronize(ctx->stream2);
   pg_anim_free_scratch(ctx);
   prof_drain(ctx);
   void* dev[] = {ctx->d_codes, ctx->d_mask, ctx->d_quirk, ctx->d_seg_tile0, ctx->d_seg_prefix, ctx->d_batch_gid, ctx->d_acc,
@@ -337,6 +348,7 @@ void pg_destroy(pg_ctx* ctx) {
   for (void* p : host)
     if (p) (void)hipHostFree(p);
   (void)hipStreamDestroy(ctx->stream);
+  (void)hipStreamDestroy(ctx->stream2);
   (void)hipGetLastError();   // teardown errors must not surface in a later context's launch checks
   delete ctx;
 }
@@ -347,6 +359,7 @@ int pg_sync(pg_ctx* ctx) {
   if (!ctx) return PG_E_ARG;
   PG_HIP(ctx, hipSetDevice(ctx->device));
   PG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  PG_HIP(ctx, hipStreamSynchronize(ctx->stream2));
   return PG_OK;
 }
 
@@ -662,6 +675,56 @@ int pg_tetra_corr_rows_dev(pg_ctx* ctx, const double* d_z, const uint8_t* d_pres
 }
 
 // ---- ANIm -------------------------------------------------------------------------------------------------------
+// Ordered pairs grouped by their LDS-table genome are cut into chunks (whole launches); the context's workers (two host
+// threads, each with its own stream and scratch) take chunks in turn, so that one launch's low-occupancy tail overlaps the
+// other's streaming kernels.  run(chunk_begin, chunk_end, worker) processes order[chunk_begin .. chunk_end).
+static int anim_run_chunks(pg_ctx* ctx, const std::vector<std::pair<uint64_t, uint64_t>>& chunks,
+                           const std::function<int(uint64_t, uint64_t, int)>& run) {
+  const int workers = (ctx->anim_workers >= 2 && chunks.size() >= 2) ? 2 : 1;
+  std::atomic<size_t> next{0};
+  std::atomic<int> first_rc{PG_OK};
+  auto body = [&](int w) {
+    (void)hipSetDevice(ctx->device);
+    pg_anim_set_worker(ctx, w);
+    for (size_t c; (c = next++) < chunks.size() && first_rc.load() == PG_OK;) {
+      const int rc = run(chunks[c].first, chunks[c].second, w);
+      int expect = PG_OK;
+      if (rc != PG_OK) first_rc.compare_exchange_strong(expect, rc);
+    }
+    pg_anim_set_worker(ctx, 0);
+    pg_tls_stream = nullptr;
+  };
+  if (workers == 1) {
+    body(0);
+  } else {
+    std::thread other(body, 1);
+    body(0);
+    other.join();
+  }
+  return first_rc.load();
+}
+
+// chunk boundaries over pairs sorted by table genome: at most max_pairs pairs and max_refs distinct table genomes each
+static std::vector<std::pair<uint64_t, uint64_t>> anim_chunks(const int32_t* table_ids, const std::vector<uint64_t>& order, uint64_t max_pairs,
+                                                              uint32_t max_refs) {
+  std::vector<std::pair<uint64_t, uint64_t>> chunks;
+  const uint64_t n = order.size();
+  uint64_t i = 0;
+  while (i < n) {
+    uint64_t j = i;
+    uint32_t nrefs = 0;
+    int32_t last = -1;
+    while (j < n && j - i < max_pairs) {
+      const int32_t rid = table_ids[order[j]];
+      if (rid != last) { if (nrefs == max_refs) break; ++nrefs; last = rid; }
+      ++j;
+    }
+    chunks.push_back({i, j});
+    i = j;
+  }
+  return chunks;
+}
+
 int pg_anim_set_batch_budget(pg_ctx* ctx, uint32_t max_pairs, uint64_t max_matches) {
   if (!ctx || max_pairs == 0 || max_matches < 1024) return pg_fail(ctx, PG_E_ARG, "bad argument");
   ctx->anim_batch_pairs = max_pairs;
@@ -683,30 +746,30 @@ int pg_anim_pairs(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_ids, u
   std::vector<uint64_t> order(n_pairs);
   for (uint64_t i = 0; i < n_pairs; ++i) order[i] = i;
   std::stable_sort(order.begin(), order.end(), [&](uint64_t a, uint64_t b) { return ref_ids[a] < ref_ids[b]; });
-  // batches: as many pairs as the scratch budget allows, at most MAX_REFS distinct references (one 20-mer table each)
-  const uint32_t MAX_PAIRS = ctx->anim_batch_pairs, MAX_REFS = 256;
-  std::vector<int32_t> r, q;
-  std::vector<pg_anim_result> res;
-  uint64_t i = 0;
-  while (i < n_pairs) {
-    uint64_t j = i;
-    uint32_t nrefs = 0;
-    int32_t last = -1;
-    while (j < n_pairs && j - i < MAX_PAIRS) {
-      const int32_t rid = ref_ids[order[j]];
-      if (rid != last) { if (nrefs == MAX_REFS) break; ++nrefs; last = rid; }
-      ++j;
+  // launches: as many pairs as the scratch budget allows, at most MAX_REFS distinct references (one 20-mer table each); with
+  // two workers the launches are half as large and each worker gets half the match budget, so the memory in use is the same
+  const int W = ctx->anim_workers >= 2 && n_pairs >= 4096 ? 2 : 1;
+  const uint32_t MAX_PAIRS = ctx->anim_batch_pairs / W, MAX_REFS = 256;
+  const uint64_t max_matches = ctx->anim_batch_matches / W;
+  // equal chunks, a multiple of W of them, none above the per-launch budget
+  const uint64_t cap = MAX_PAIRS ? MAX_PAIRS : 1;
+  const uint64_t n_chunks = (uint64_t)W * ((n_pairs + (uint64_t)W * cap - 1) / ((uint64_t)W * cap));
+  const auto chunks = anim_chunks(ref_ids, order, n_chunks ? std::min<uint64_t>(cap, (n_pairs + n_chunks - 1) / n_chunks) : cap, MAX_REFS);
+  return anim_run_chunks(ctx, chunks, [&](uint64_t i, uint64_t j, int) -> int {
+    std::vector<int32_t> r, q;
+    std::vector<pg_anim_result> res;
+    while (i < j) {
+      r.clear(); q.clear();
+      for (uint64_t k = i; k < j; ++k) { r.push_back(ref_ids[order[k]]); q.push_back(qry_ids[order[k]]); }
+      res.assign(j - i, pg_anim_result{});
+      uint32_t done = 0;
+      const int rc2 = pg_anim_run_batch(ctx, r.data(), q.data(), (uint32_t)(j - i), filter_1to1, maxmatch != 0, max_matches, res.data(), &done);
+      if (rc2) return rc2;
+      for (uint64_t k = i; k < i + done; ++k) out[order[k]] = res[k - i];
+      i += done;   // pairs beyond the match budget are taken up by the next launch
     }
-    r.clear(); q.clear();
-    for (uint64_t k = i; k < j; ++k) { r.push_back(ref_ids[order[k]]); q.push_back(qry_ids[order[k]]); }
-    res.assign(j - i, pg_anim_result{});
-    uint32_t done = 0;
-    if ((rc = pg_anim_run_batch(ctx, r.data(), q.data(), (uint32_t)(j - i), filter_1to1, maxmatch != 0, ctx->anim_batch_matches, res.data(), &done)))
-      return rc;
-    for (uint64_t k = i; k < i + done; ++k) out[order[k]] = res[k - i];
-    i += done;   // pairs beyond the match budget are taken up by the next batch
-  }
-  return PG_OK;
+    return PG_OK;
+  });
 }
 
 int pg_anim_pair_alignments(pg_ctx* ctx, int32_t ref_id, int32_t qry_id, pg_anim_alignment* out, uint32_t cap, uint32_t* n_out) {
@@ -770,29 +833,27 @@ int pg_anib_pairs(pg_ctx* ctx, const int32_t* qry_ids, const int32_t* sbj_ids, u
   std::vector<uint64_t> order(n_pairs);
   for (uint64_t i = 0; i < n_pairs; ++i) order[i] = i;
   std::stable_sort(order.begin(), order.end(), [&](uint64_t a, uint64_t b) { return sbj_ids[a] < sbj_ids[b]; });
-  const uint32_t MAX_PAIRS = ctx->anim_batch_pairs, MAX_REFS = 256;
-  std::vector<int32_t> s, q;
-  std::vector<pg_anib_result> res;
-  uint64_t i = 0;
-  while (i < n_pairs) {
-    uint64_t j = i;
-    uint32_t nrefs = 0;
-    int32_t last = -1;
-    while (j < n_pairs && j - i < MAX_PAIRS) {
-      const int32_t rid = sbj_ids[order[j]];
-      if (rid != last) { if (nrefs == MAX_REFS) break; ++nrefs; last = rid; }
-      ++j;
+  const int W = ctx->anim_workers >= 2 && n_pairs >= 64 ? 2 : 1;
+  const uint32_t MAX_PAIRS = ctx->anim_batch_pairs / W, MAX_REFS = 256;
+  const uint64_t max_matches = ctx->anim_batch_matches / W, max_slots = ANIB_MAX_SLOTS / W;
+  // (fragment launches are bounded by their (pair, fragment) slots: cut the chunks so that both workers get several)
+  const auto chunks = anim_chunks(sbj_ids, order, std::max<uint64_t>(1, std::min<uint64_t>(MAX_PAIRS, W == 2 ? (n_pairs + 7) / 8 : n_pairs)), MAX_REFS);
+  return anim_run_chunks(ctx, chunks, [&](uint64_t i, uint64_t j, int) -> int {
+    std::vector<int32_t> s, q;
+    std::vector<pg_anib_result> res;
+    while (i < j) {
+      s.clear(); q.clear();
+      for (uint64_t k = i; k < j; ++k) { s.push_back(sbj_ids[order[k]]); q.push_back(qry_ids[order[k]]); }
+      res.assign(j - i, pg_anib_result{});
+      PgFragArgs F{(int32_t)fragsize, res.data(), nullptr, 0, nullptr, max_slots};
+      uint32_t done = 0;
+      const int rc2 = pg_anim_run_batch(ctx, s.data(), q.data(), (uint32_t)(j - i), 0, 1, max_matches, nullptr, &done, &F);
+      if (rc2) return rc2;
+      for (uint64_t k = i; k < i + done; ++k) out[order[k]] = res[k - i];
+      i += done;
     }
-    s.clear(); q.clear();
-    for (uint64_t k = i; k < j; ++k) { s.push_back(sbj_ids[order[k]]); q.push_back(qry_ids[order[k]]); }
-    res.assign(j - i, pg_anib_result{});
-    PgFragArgs F{(int32_t)fragsize, res.data(), nullptr, 0, nullptr, ANIB_MAX_SLOTS};
-    uint32_t done = 0;
-    if ((rc = pg_anim_run_batch(ctx, s.data(), q.data(), (uint32_t)(j - i), 0, 1, ctx->anim_batch_matches, nullptr, &done, &F))) return rc;
-    for (uint64_t k = i; k < i + done; ++k) out[order[k]] = res[k - i];
-    i += done;
-  }
-  return PG_OK;
+    return PG_OK;
+  });
 }
 
 int pg_anib_pair_rows(pg_ctx* ctx, int32_t qry_id, int32_t sbj_id, uint32_t fragsize, pg_anib_row* out, uint32_t cap, uint32_t* n_out) {

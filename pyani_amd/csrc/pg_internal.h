@@ -82,9 +82,16 @@ struct pg_ctx {
   double prof_ms[PG_K__COUNT] = {};
   uint64_t prof_n[PG_K__COUNT] = {};
   int num_cu = 256;
-  void* anim_scratch = nullptr;  // AnimScratch (pg_anim.hip), grows on demand
-  uint32_t anim_batch_pairs = 65536;          // upper bound of ordered pairs per launch (every launch pays its slowest unit once)
-  uint64_t anim_batch_matches = 256ull << 20; // exact matches per launch (~264 B of scratch each: ~68 GB of the 288 GB)
+  void* anim_scratch = nullptr;  // AnimScratch (pg_anim.hip) of worker 0, grows on demand
+  // ANIm / fragment-mode calls are split over two host workers, each with its own stream and scratch: while one worker's
+  // launch is in a low-occupancy tail (one wave per unit, slowest unit = launch time) the other's kernels fill the GPU
+  void* anim_scratch2 = nullptr;   // worker 1
+  hipStream_t stream2 = nullptr;
+  void* anim_lists = nullptr;      // per-genome seed lists, shared by the workers (guarded by anim_mu)
+  std::mutex anim_mu, err_mu, prof_mu;
+  int anim_workers = 2;
+  uint32_t anim_batch_pairs = 131072;         // ordered pairs in flight (split over the two workers: 65536 per launch; every launch pays its slowest unit once)
+  uint64_t anim_batch_matches = 512ull << 20; // exact matches in flight (~264 B of scratch each, grown on demand: at most ~136 GB of the 288 GB)
 };
 
 int pg_fail(pg_ctx* ctx, int code, const std::string& msg);
@@ -95,7 +102,9 @@ int pg_fail(pg_ctx* ctx, int code, const std::string& msg);
       return pg_fail((ctx), PG_E_HIP, std::string(#call) + ": " + hipGetErrorString(_e));                     \
   } while (0)
 
-// profiling helpers (pg_api.cpp)
+// profiling helpers (pg_api.cpp).  Events are recorded on the calling thread's stream: pg_tls_stream when set (the ANIm
+// workers), else the context's.
+extern thread_local hipStream_t pg_tls_stream;
 void pg_prof_begin(pg_ctx* ctx, int which);
 void pg_prof_end(pg_ctx* ctx);
 
@@ -122,6 +131,7 @@ struct PgFragArgs {
 int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_ids, uint32_t n_pairs, int filter_1to1, int maxmatch,
                       uint64_t max_matches, pg_anim_result* out_host, uint32_t* n_done,
                       const PgFragArgs* frag = nullptr);   // ref_ids grouped (equal ids adjacent)
+void pg_anim_set_worker(pg_ctx* ctx, int worker);   // binds the calling thread to worker 0 / 1 (stream + scratch) for run_batch
 void pg_anim_free_scratch(pg_ctx* ctx);
 int pg_anim_fetch_alignments(pg_ctx* ctx, int32_t ref_id, int32_t qry_id, uint32_t n, pg_anim_alignment* out);   // after a 1-pair batch
 void pg_anim_drop_lists(pg_ctx* ctx);   // per-genome seed lists: must go when the genome store is cleared
