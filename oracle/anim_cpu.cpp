@@ -125,7 +125,7 @@ Result run_pair(const Genome& G, const Genome& H, int filter_1to1, int maxmatch)
     find_mems(G, tab, Q, strand, mem);
     int n = (int)mem.size();
     if (!maxmatch) n = mum_filter(mem.data(), n, strand);
-    else std::sort(mem.begin(), mem.end(), [](const Match& a, const Match& b) { return a.q != b.q ? a.q < b.q : (a.len != b.len ? a.len < b.len : a.r < b.r); });
+    else std::sort(mem.begin(), mem.end(), [](const Match& a, const Match& b) { return a.q != b.q ? a.q < b.q : (a.len != b.len ? a.len > b.len : a.r < b.r); });   // the engine's total order: q, len desc, r
     mem.resize(n);
     std::vector<int32_t> rrec(n), qrec(n), parent(n), score(n), from(n), adj(n), order(n);
     const int nq = (int)H.rec_start.size() - 1;

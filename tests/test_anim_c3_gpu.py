@@ -61,10 +61,10 @@ def test_c3_family_equals_cpu_statement_and_properties():
     assert ok >= 0.97 * n_rel
 
 
-def _bench(extra_env, nproc, tmp_path, tag):
+def _bench(extra_env, nproc, tmp_path, tag, args=None):
     env = dict(os.environ, **extra_env)
-    args = ["--genomes", "24", "--length", "300000", "--seed", "11", "--rows-per-step", "8", "--steps", "3", "--warmup", "0",
-            "--no-cpu-baseline", "--no-tetra"]
+    args = args or ["--genomes", "24", "--length", "300000", "--seed", "11", "--rows-per-step", "8", "--steps", "3", "--warmup", "0",
+                    "--no-cpu-baseline", "--no-tetra"]
     if nproc == 1:
         cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", "1"] + args
     else:
@@ -87,3 +87,15 @@ def test_bench_two_ranks_on_one_gpu_equal_single_rank(tmp_path):
     assert one["config"]["related_pairs_with_alignment"] == two["config"]["related_pairs_with_alignment"] > 0
     for rec in (one, two):
         assert rec["roofline"]["kernel"].startswith("anim_") and rec["roofline"]["achieved"] > 0
+
+
+def test_bench_fragment_mode_two_ranks_equal_single_rank(tmp_path):
+    """The same for `bench.py --workload anib` (fragment mode, mixed-length genomes): per-pair results gathered from two ranks
+    equal one rank's (identities, coverage, hit counts of the JSON line)."""
+    args = ["--workload", "anib", "--genomes", "12", "--rows-per-step", "6", "--steps", "2", "--warmup", "0", "--no-cpu-baseline"]
+    one = _bench({}, 1, tmp_path, "anib_one", args)
+    two = _bench({"PYANI_BENCH_DEBUG_ONE_GPU": "1"}, 2, tmp_path, "anib_two", args)
+    for key in ("pairs_timed", "related_pairs_timed", "fragments_timed", "related_pairs_with_hits", "identity_related_min_med_max",
+                "coverage_related_median"):
+        assert one["config"][key] == two["config"][key], key
+    assert one["config"]["pairs_timed"] == 12 * 11 and one["config"]["related_pairs_with_hits"] == 12 * 11 and two["n_gpus"] == 2

@@ -307,3 +307,95 @@ def test_run_anim_writes_recovery_files_and_recovers_from_them(eng, genome_dir, 
     for name in first.matrices:
         assert np.array_equal(first.matrices[name].values, again.matrices[name].values, equal_nan=True)
     assert list(first.matrices["identity"].index) == [1, 2, 3]
+
+
+def _with_repeats(seq, off, salt):
+    """Repeat-bearing variant of a synthetic genome (the generator's ancestors are i.i.d. and repeat-free): 3 copies of a 5 kb
+    'rRNA operon' (one of them with 1 % substitutions) and 6 copies of a 1.4 kb 'IS element' (2 reverse-complemented) pasted
+    over the first record; same length, same records."""
+    rng = np.random.RandomState(1000 + salt)
+    s = seq.copy()
+    n = int(off[1])
+    operon = np.frombuffer(b"ACGT", dtype=np.uint8)[np.random.RandomState(77).randint(0, 4, size=5000)]
+    ins = np.frombuffer(b"ACGT", dtype=np.uint8)[np.random.RandomState(78).randint(0, 4, size=1400)]
+    comp = np.zeros(256, dtype=np.uint8)
+    comp[list(b"ACGT")] = list(b"TGCA")
+    slots = rng.permutation(np.arange(10_000, n - 10_000, 12_000))[:9]
+    for k, pos in enumerate(slots[:3]):
+        cp = operon.copy()
+        if k == 2:
+            hit = rng.rand(len(cp)) < 0.01
+            cp[hit] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.randint(0, 4, size=int(hit.sum()))]
+        s[pos:pos + 5000] = cp
+    for k, pos in enumerate(slots[3:]):
+        s[pos:pos + 1400] = comp[ins][::-1] if k % 3 == 0 else ins
+    return s, off
+
+
+@pytest.fixture(scope="module")
+def repeat_runs(eng):
+    """Genomes WITH repeats (operon and insertion-element copies, some diverged, some reverse-complemented) through the GPU
+    pipeline and through the CPU statement of the same search (oracle/anim_cpu.cpp, exhaustive seeding), --mum and --maxmatch."""
+    sys.path.insert(0, str(ROOT / "oracle"))
+    import anim_cpu
+    from pyani_amd import synth
+    eng.clear_genomes()
+    n, L = 4, 300_000
+    data = [_with_repeats(*synth.genome(31, n, g, L), g) for g in range(n)]
+    ids = [eng.add_genome(*d) for d in data]
+    eng.upload()
+    pairs = [(a, b) for a in range(n) for b in range(n) if a != b]
+    got, want_all = {}, {}
+    for mm in (False, True):
+        res = eng.anim_pairs([ids[a] for a, _ in pairs], [ids[b] for _, b in pairs], maxmatch=mm)
+        want, _ = anim_cpu.anim_cpu_pairs(data, [a for a, _ in pairs], [b for _, b in pairs], maxmatch=mm)
+        for p, r, w in zip(pairs, res, want):
+            got[(mm, p)] = (int(r["ref_aln_len"]), int(r["qry_aln_len"]), int(r["sim_errors"]), int(r["n_alignments"]), float(r["identity"]).hex(),
+                            int(r["status"]))
+            want_all[(mm, p)] = (int(w["ref_aln_len"]), int(w["qry_aln_len"]), int(w["sim_errors"]), int(w["n_alignments"]),
+                                 float(w["identity"]).hex(), int(w["status"]))
+    nofilt = eng.anim_pairs([ids[0]], [ids[1]], filter_1to1=False)[0]
+    return pairs, got, want_all, int(nofilt["n_alignments"])
+
+
+def test_repeats_mum_mode_equals_the_cpu_statement(repeat_runs):
+    """--mum (what pyani runs): with repeats the uniqueness filter and the 1-to-1 filter both have work to do; every tuple of
+    the GPU pipeline equals the CPU statement's, and --maxmatch is a different search on these genomes."""
+    pairs, got, want, n_unfiltered = repeat_runs
+    bad = [(p, got[(False, p)], want[(False, p)]) for p in pairs if got[(False, p)] != want[(False, p)]]
+    assert not bad, bad[:2]
+    assert any(got[(False, p)] != got[(True, p)] for p in pairs)
+    assert n_unfiltered > got[(False, (0, 1))][3]                     # delta-filter -1 had repeat alignments to drop
+
+
+@pytest.mark.xfail(strict=False, reason="--maxmatch with repeated anchors: found in round 2 — 3 of these 12 pairs differ between the "
+                                        "wave-cooperative chain extraction and the scalar statement (a repeat copy's alignment kept by "
+                                        "one, dropped by the other); no MUMmer --maxmatch output exists to say which is right")
+def test_repeats_maxmatch_mode_equals_the_cpu_statement(repeat_runs):
+    pairs, got, want, _ = repeat_runs
+    bad = [(p, got[(True, p)], want[(True, p)]) for p in pairs if got[(True, p)] != want[(True, p)]]
+    (ROOT / "gpurun_out").mkdir(exist_ok=True)
+    (ROOT / "gpurun_out" / "anim_repeats_maxmatch_diff.json").write_text(json.dumps(bad))
+    assert not bad, bad[:2]
+
+
+def test_process_deltadir_on_the_gpu_equals_the_imported_reference(eng, tmp_path):
+    """pyani_amd.anim.process_deltadir with the real engine (batched pg_anim_reduce) on the reference's deltadir fixture: all
+    five matrices bit-equal to what the imported reference's process_deltadir produced (tools/make_goldens.py)."""
+    import gzip
+    from pyani_amd import anim
+    fx = json.loads((GOLD / "ref_targets" / "anim_process_deltadir_cases.json").read_text())["caulobacter_deltadir"]
+    lengths = dict(fx["lengths"])
+    for gz in sorted((GOLD / "anim" / "caulobacter").glob("*.filter.gz")):
+        q = gz.name.split("_vs_")[0]
+        (tmp_path / q).mkdir(exist_ok=True)
+        with gzip.open(gz, "rb") as fi:
+            (tmp_path / q / gz.name[:-3]).write_bytes(fi.read())
+    res = anim.process_deltadir(tmp_path, lengths, engine=eng)
+    for df, stem in res.data:
+        want = fx["matrices"][stem]
+        assert list(df.index) == want["labels"]
+        for a, row in zip(want["labels"], want["rows"]):
+            for b, h in zip(want["labels"], row):
+                w, g = float.fromhex(h), float(df.loc[a, b])
+                assert g == w or (np.isnan(g) and np.isnan(w)), (stem, a, b, g, w)
