@@ -154,7 +154,7 @@ int regrow(pg_ctx* ctx, T*& p, size_t n) {
 }  // namespace
 
 static AnimScratch* anim_scratch(pg_ctx* ctx) {
-  void*& slot = tls_worker ? ctx->anim_scratch2 : ctx->anim_scratch;
+  void*& slot = tls_worker ? ctx->anim_scratch_w[tls_worker] : ctx->anim_scratch;
   if (!slot) slot = new AnimScratch();
   return static_cast<AnimScratch*>(slot);
 }
@@ -162,9 +162,9 @@ static AnimLists* anim_lists(pg_ctx* ctx) {   // (callers hold ctx->anim_mu)
   if (!ctx->anim_lists) ctx->anim_lists = new AnimLists();
   return static_cast<AnimLists*>(ctx->anim_lists);
 }
-static hipStream_t cur_stream(pg_ctx* ctx) { return tls_worker ? ctx->stream2 : ctx->stream; }
+static hipStream_t cur_stream(pg_ctx* ctx) { return tls_worker ? ctx->stream_w[tls_worker] : ctx->stream; }
 void pg_anim_set_worker(pg_ctx* ctx, int worker) {
-  tls_worker = worker ? 1 : 0;
+  tls_worker = worker > 0 && worker < pg_ctx::MAX_WORKERS ? worker : 0;
   pg_tls_stream = cur_stream(ctx);
 }
 
@@ -232,7 +232,7 @@ void pg_anim_free_scratch(pg_ctx* ctx) {
   delete static_cast<AnimLists*>(ctx->anim_lists);
   ctx->anim_lists = nullptr;
   anim_free_one(ctx, ctx->anim_scratch);
-  anim_free_one(ctx, ctx->anim_scratch2);
+  for (int w = 1; w < pg_ctx::MAX_WORKERS; ++w) anim_free_one(ctx, ctx->anim_scratch_w[w]);
 }
 static void anim_free_one(pg_ctx* ctx, void*& slot) {
   AnimScratch* A = static_cast<AnimScratch*>(slot);

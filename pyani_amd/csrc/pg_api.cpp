@@ -319,12 +319,17 @@ int pg_create(pg_ctx** out, int device) {
   pg_ctx* ctx = new (std::nothrow) pg_ctx();
   if (!ctx) return PG_E_NOMEM;
   ctx->device = device;
-  if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
-      hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess) {
+  if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
     delete ctx;
     return PG_E_HIP;
   }
-  if (const char* w = getenv("PYANI_ANIM_WORKERS")) ctx->anim_workers = atoi(w) >= 2 ? 2 : 1;   // development switch
+  for (int w = 1; w < pg_ctx::MAX_WORKERS; ++w)
+    if (hipStreamCreateWithFlags(&ctx->stream_w[w], hipStreamNonBlocking) != hipSuccess) { delete ctx; return PG_E_HIP; }
+  if (const char* w = getenv("PYANI_ANIM_WORKERS")) {   // development switch
+    ctx->anim_workers = atoi(w);
+    if (ctx->anim_workers < 1) ctx->anim_workers = 1;
+    if (ctx->anim_workers > pg_ctx::MAX_WORKERS) ctx->anim_workers = pg_ctx::MAX_WORKERS;
+  }
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
     ctx->num_cu = prop.multiProcessorCount;
@@ -337,7 +342,7 @@ void pg_destroy(pg_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
-  (void)hipStreamSynchronize(ctx->stream2);
+  for (int w = 1; w < pg_ctx::MAX_WORKERS; ++w) (void)hipStreamSynchronize(ctx->stream_w[w]);
   pg_anim_free_scratch(ctx);
   prof_drain(ctx);
   void* dev[] = {ctx->d_codes, ctx->d_mask, ctx->d_quirk, ctx->d_seg_tile0, ctx->d_seg_prefix, ctx->d_batch_gid, ctx->d_acc,
@@ -348,7 +353,7 @@ void pg_destroy(pg_ctx* ctx) {
   for (void* p : host)
     if (p) (void)hipHostFree(p);
   (void)hipStreamDestroy(ctx->stream);
-  (void)hipStreamDestroy(ctx->stream2);
+  for (int w = 1; w < pg_ctx::MAX_WORKERS; ++w) (void)hipStreamDestroy(ctx->stream_w[w]);
   (void)hipGetLastError();   // teardown errors must not surface in a later context's launch checks
   delete ctx;
 }
@@ -359,7 +364,7 @@ int pg_sync(pg_ctx* ctx) {
   if (!ctx) return PG_E_ARG;
   PG_HIP(ctx, hipSetDevice(ctx->device));
   PG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  PG_HIP(ctx, hipStreamSynchronize(ctx->stream2));
+  for (int w = 1; w < pg_ctx::MAX_WORKERS; ++w) PG_HIP(ctx, hipStreamSynchronize(ctx->stream_w[w]));
   return PG_OK;
 }
 
@@ -680,7 +685,7 @@ int pg_tetra_corr_rows_dev(pg_ctx* ctx, const double* d_z, const uint8_t* d_pres
 // other's streaming kernels.  run(chunk_begin, chunk_end, worker) processes order[chunk_begin .. chunk_end).
 static int anim_run_chunks(pg_ctx* ctx, const std::vector<std::pair<uint64_t, uint64_t>>& chunks,
                            const std::function<int(uint64_t, uint64_t, int)>& run) {
-  const int workers = (ctx->anim_workers >= 2 && chunks.size() >= 2) ? 2 : 1;
+  const int workers = (int)std::min<size_t>((size_t)ctx->anim_workers, chunks.size() ? chunks.size() : 1);
   std::atomic<size_t> next{0};
   std::atomic<int> first_rc{PG_OK};
   auto body = [&](int w) {
@@ -694,13 +699,10 @@ static int anim_run_chunks(pg_ctx* ctx, const std::vector<std::pair<uint64_t, ui
     pg_anim_set_worker(ctx, 0);
     pg_tls_stream = nullptr;
   };
-  if (workers == 1) {
-    body(0);
-  } else {
-    std::thread other(body, 1);
-    body(0);
-    other.join();
-  }
+  std::vector<std::thread> others;
+  for (int w = 1; w < workers; ++w) others.emplace_back(body, w);
+  body(0);
+  for (auto& th : others) th.join();
   return first_rc.load();
 }
 
@@ -748,7 +750,7 @@ int pg_anim_pairs(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_ids, u
   std::stable_sort(order.begin(), order.end(), [&](uint64_t a, uint64_t b) { return ref_ids[a] < ref_ids[b]; });
   // launches: as many pairs as the scratch budget allows, at most MAX_REFS distinct references (one 20-mer table each); with
   // two workers the launches are half as large and each worker gets half the match budget, so the memory in use is the same
-  const int W = ctx->anim_workers >= 2 && n_pairs >= 4096 ? 2 : 1;
+  const int W = n_pairs >= 4096 ? ctx->anim_workers : 1;
   const uint32_t MAX_PAIRS = ctx->anim_batch_pairs / W, MAX_REFS = 256;
   const uint64_t max_matches = ctx->anim_batch_matches / W;
   // equal chunks, a multiple of W of them, none above the per-launch budget
@@ -833,11 +835,11 @@ int pg_anib_pairs(pg_ctx* ctx, const int32_t* qry_ids, const int32_t* sbj_ids, u
   std::vector<uint64_t> order(n_pairs);
   for (uint64_t i = 0; i < n_pairs; ++i) order[i] = i;
   std::stable_sort(order.begin(), order.end(), [&](uint64_t a, uint64_t b) { return sbj_ids[a] < sbj_ids[b]; });
-  const int W = ctx->anim_workers >= 2 && n_pairs >= 64 ? 2 : 1;
+  const int W = n_pairs >= 64 ? ctx->anim_workers : 1;
   const uint32_t MAX_PAIRS = ctx->anim_batch_pairs / W, MAX_REFS = 256;
   const uint64_t max_matches = ctx->anim_batch_matches / W, max_slots = ANIB_MAX_SLOTS / W;
   // (fragment launches are bounded by their (pair, fragment) slots: cut the chunks so that both workers get several)
-  const auto chunks = anim_chunks(sbj_ids, order, std::max<uint64_t>(1, std::min<uint64_t>(MAX_PAIRS, W == 2 ? (n_pairs + 7) / 8 : n_pairs)), MAX_REFS);
+  const auto chunks = anim_chunks(sbj_ids, order, std::max<uint64_t>(1, std::min<uint64_t>(MAX_PAIRS, W >= 2 ? (n_pairs + 4 * W - 1) / (4 * W) : n_pairs)), MAX_REFS);
   return anim_run_chunks(ctx, chunks, [&](uint64_t i, uint64_t j, int) -> int {
     std::vector<int32_t> s, q;
     std::vector<pg_anib_result> res;

@@ -85,8 +85,9 @@ struct pg_ctx {
   void* anim_scratch = nullptr;  // AnimScratch (pg_anim.hip) of worker 0, grows on demand
   // ANIm / fragment-mode calls are split over two host workers, each with its own stream and scratch: while one worker's
   // launch is in a low-occupancy tail (one wave per unit, slowest unit = launch time) the other's kernels fill the GPU
-  void* anim_scratch2 = nullptr;   // worker 1
-  hipStream_t stream2 = nullptr;
+  static constexpr int MAX_WORKERS = 4;
+  void* anim_scratch_w[MAX_WORKERS] = {nullptr, nullptr, nullptr, nullptr};   // workers 1.. (index 0 unused: worker 0 = anim_scratch)
+  hipStream_t stream_w[MAX_WORKERS] = {nullptr, nullptr, nullptr, nullptr};   // workers 1.. (index 0 unused: worker 0 = stream)
   void* anim_lists = nullptr;      // per-genome seed lists, shared by the workers (guarded by anim_mu)
   std::mutex anim_mu, err_mu, prof_mu;
   int anim_workers = 2;
@@ -131,7 +132,7 @@ struct PgFragArgs {
 int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_ids, uint32_t n_pairs, int filter_1to1, int maxmatch,
                       uint64_t max_matches, pg_anim_result* out_host, uint32_t* n_done,
                       const PgFragArgs* frag = nullptr);   // ref_ids grouped (equal ids adjacent)
-void pg_anim_set_worker(pg_ctx* ctx, int worker);   // binds the calling thread to worker 0 / 1 (stream + scratch) for run_batch
+void pg_anim_set_worker(pg_ctx* ctx, int worker);   // binds the calling thread to worker 0 .. MAX_WORKERS-1 (stream + scratch) for run_batch
 void pg_anim_free_scratch(pg_ctx* ctx);
 int pg_anim_fetch_alignments(pg_ctx* ctx, int32_t ref_id, int32_t qry_id, uint32_t n, pg_anim_alignment* out);   // after a 1-pair batch
 void pg_anim_drop_lists(pg_ctx* ctx);   // per-genome seed lists: must go when the genome store is cleared

@@ -13,7 +13,7 @@ bench)
   grep '^{' $O/bench_n1.log > $O/bench_n1.json; cut -c1-1500 $O/bench_n1.json; tail -5 $O/bench_n1.err ;;
 prof)
   cd /tmp
-  B="python $R/bench.py --gpus 1 --steps 3 --warmup 1 --no-cpu-baseline --no-tetra"
+  B="python $R/bench.py --gpus 1 --steps 2 --warmup 1 --no-cpu-baseline --no-tetra"
   rm -rf $O/kt $O/pmc_fetch $O/pmc_write
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt -- $B > $O/kt_bench.log 2>&1
   timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o pmc -- $B > $O/pmc_fetch.log 2>&1
