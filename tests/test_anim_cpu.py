@@ -241,226 +241,6 @@ def test_process_deltadir_walk_and_assembly(tmp_path):
     from pyani_amd.engine import Engine
     Rec = namedtuple("Rec", "ref_id qry_id rs re qs qe errors")
 
-    rows = list(csv.reader(open(GOLD / "ref_targets" / "anim_deltadir_result.csv")))
-    names = rows[0][1:]
-    for r in rows[1:]:
-        for s, v in zip(names, r[1:]):
-            if r[0] != s:
-                t = anim_oracle.parse_delta(GOLD / "anim" / "caulobacter" / f"{r[0]}_vs_{s}.filter.gz")
-                assert f"{t[2]:.6f}" == v
-
-
-def test_goldens_file_consistent():
-    gold = json.loads((GOLD / "anim_goldens.json").read_text())
-    assert gold["reference_known_answers"]["test.delta"] == gold["parse_delta"]["test.delta"]
-    for rel, tup in gold["parse_delta"].items():
-        assert list(anim_oracle.parse_delta(GOLD / "anim" / (rel + ".gz"))) == tup
-
-
-def test_legacy_matrix_assembly_overwrite_order():
-    """process_deltadir semantics (anim.py:487-496, pyani_tools.py:108-167): B_vs_A overwrites the mirrored cells."""
-    res = {("A", "B"): (90, 80, 0.9, 5), ("B", "A"): (70, 60, 0.8, 7)}
-    m = anim_oracle.anim_matrices(res, {"A": 100, "B": 200})
-    assert m["alignment_lengths"]["A"]["B"] == 60.0 and m["alignment_lengths"]["B"]["A"] == 70.0
-    assert m["percentage_identity"]["A"]["B"] == 0.9 and m["percentage_identity"]["B"]["A"] == 0.8
-    assert m["similarity_errors"]["A"]["B"] == 7.0
-    assert m["alignment_coverage"]["A"]["B"] == 60 / 100 and m["alignment_coverage"]["B"]["A"] == 70 / 200
-    assert m["alignment_lengths"]["A"]["A"] == 100.0
-
-
-@pytest.fixture(scope="module")
-def filter_check():
-    exe = ROOT / "tools" / "anim_debug" / "filter_check"
-    subprocess.run(["g++", "-O2", "-std=c++17", f"-I{ROOT / 'pyani_amd' / 'csrc'}", str(exe) + ".cpp", "-o", str(exe)], check=True)
-    return exe
-
-
-def test_one_to_one_filter_matches_delta_filter(filter_check):
-    """27 real .delta -> .filter pairs (MUMmer 3.1/3.23 output held by the reference's tests, 12 734 alignments):
-    the engine's filter reproduces every keep/drop decision of delta-filter -1."""
-    total = wrong = exact_files = 0
-    files = [f for f in sorted((GOLD / "anim").glob("*/*.delta.gz")) if Path(str(f).replace(".delta.gz", ".filter.gz")).exists()]
-    assert len(files) == 27
-    for f in files:
-        al, _, _ = anim_oracle.read_delta(f)
-        fl, _, _ = anim_oracle.read_delta(str(f).replace(".delta.gz", ".filter.gz"))
-        inp = "".join(f"{a.ref_id} {a.qry_id} {a.rs} {a.re} {a.qs} {a.qe} {a.errors}\n" for a in al)
-        out = subprocess.run([str(filter_check)], input=inp, capture_output=True, text=True, check=True).stdout
-        mine = {tuple(int(x) for x in ln.split()) for ln in out.splitlines()}
-        want = {(a.rs, a.re, a.qs, a.qe, a.errors) for a in fl}
-        total += len(al)
-        wrong += len(mine ^ want)
-        exact_files += mine == want
-    assert total == 12734 and wrong == 0, (wrong, total)
-    assert exact_files == 27
-
-
-def test_run_matrices_vectorised_equals_cellwise_definition():
-    """assemble_run_matrices (pyani_orm.update_comparison_matrices semantics, vectorised) against the cell-by-cell
-    definition: [q, s] cells only, diagonals 1 / 1 / length / 0 / 1, hadamard = identity * cov_query."""
-    import numpy as np
-    from pyani_amd import anim
-    rng = np.random.default_rng(7)
-    labels = [f"g{k:02d}" for k in rng.permutation(12)]
-    lengths = {g: int(rng.integers(700_000, 6_000_000)) for g in labels}
-    res = {}
-    for q in labels:
-        for s in labels:
-            if q != s and rng.random() < 0.8:          # some pairs have no result (no alignment)
-                res[(q, s)] = (int(rng.integers(1, lengths[q])), int(rng.integers(1, lengths[s])), float(rng.random()),
-                               int(rng.integers(0, 50_000)))
-    m = anim.assemble_run_matrices(res, lengths)
-    order = sorted(labels)
-    for name in ("identity", "coverage", "aln_lengths", "sim_errors", "hadamard"):
-        assert list(m[name].index) == order and list(m[name].columns) == order
-    for q in order:
-        for s in order:
-            if q == s:
-                want = (1.0, 1.0, float(lengths[q]), 0.0, 1.0)
-            elif (q, s) in res:
-                qa, _, pid, err = res[(q, s)]
-                want = (pid, qa / lengths[q], float(qa), float(err), pid * (qa / lengths[q]))
-            else:
-                want = (np.nan,) * 5        # no comparison: the reference's frames start as NaN (pyani_orm.py:627-637)
-            got = tuple(float(m[n].loc[q, s]) for n in ("identity", "coverage", "aln_lengths", "sim_errors", "hadamard"))
-            assert got == want or (all(np.isnan(got)) and all(np.isnan(want))), (q, s)
-    # the form the reference stores: integer genome_id index (sorted), DataFrame.to_json() strings, Comparison rows
-    gids = {g: 100 - k for k, g in enumerate(order)}                      # ids in reverse label order
-    mi = anim.assemble_run_matrices(res, lengths, genome_ids=gids)
-    assert list(mi["identity"].index) == sorted(gids.values()) == list(mi["identity"].columns)
-    for name in m:
-        for q in order:
-            for s in order:
-                a, b = float(m[name].loc[q, s]), float(mi[name].loc[gids[q], gids[s]])
-                assert a == b or (np.isnan(a) and np.isnan(b))
-    js = anim.run_matrices_to_json(mi)
-    assert sorted(js) == ["df_alnlength", "df_coverage", "df_hadamard", "df_identity", "df_simerrors"]
-    import pandas as pd
-    from io import StringIO
-    back = pd.read_json(StringIO(js["df_identity"]))
-    assert js["df_identity"] == mi["identity"].to_json() and back.shape == (12, 12) and "null" in js["df_identity"]
-    rows = anim.comparison_rows(res, lengths, gids, maxmatch=True)
-    assert len(rows) == len(res)
-    (q, s), (qa, sa, pid, err) = next(iter(res.items()))
-    assert rows[0] == {"query_id": gids[q], "subject_id": gids[s], "aln_length": qa, "sim_errs": err, "identity": pid,
-                       "cov_query": qa / lengths[q], "cov_subject": sa / lengths[s], "program": anim.PROGRAM, "version": anim.VERSION,
-                       "fragsize": None, "maxmatch": True, "kmersize": None, "minmatch": None}
-
-
-def test_write_delta_round_trip_and_grammar(tmp_path):
-    """anim.write_delta: MUMmer .delta grammar (path line, NUCMER, '>' blocks, 7-field headers, 0 terminators), record ids
-    and lengths from the FASTA files, filtered / unfiltered variants; the oracle's parse_delta reads the result back."""
-    import numpy as np
-    from pyani_amd import anim
-    from pyani_amd.engine import Engine
-    ref = tmp_path / "r.fna"
-    qry = tmp_path / "q.fna"
-    ref.write_text(">r1 first\n" + "ACGT" * 50 + "\n>r2\n" + "A" * 120 + "\n")
-    qry.write_text(">q1\n" + "ACGT" * 40 + "\n" + "GG" * 5 + "\n")
-    assert anim.fasta_records(ref) == [("r1", 200), ("r2", 120)] and anim.fasta_records(qry) == [("q1", 170)]
-    al = np.zeros(3, dtype=Engine.ALN_DTYPE)
-    al[0] = (0, 0, 1, 160, 1, 160, 2, 3)
-    al[1] = (1, 0, 5, 60, 170, 115, 1, 3)      # reverse strand: qs > qe
-    al[2] = (0, 0, 150, 200, 100, 150, 9, 1)   # dropped by the 1-to-1 filter
-    out = tmp_path / "r_vs_q.filter"
-    assert anim.write_delta(out, ref, qry, al, filtered=True) == 2
-    lines = out.read_text().splitlines()
-    assert lines[1] == "NUCMER" and lines[0].split()[0].endswith("r.fna")
-    assert lines[2] == ">r1 q1 200 170" and lines[3] == "1 160 1 160 2 2 0" and lines[4] == "0"
-    assert lines[5] == ">r2 q1 120 170" and lines[6] == "5 60 170 115 1 1 0"
-    # reference intervals on two sequences: 160 + 56; query intervals 1-160 and 115-170 on one sequence: union 170
-    assert anim_oracle.parse_delta(out) == (160 + 56, 170, (160 * 2 - 4 + 56 * 2 - 2) / (160 * 2 + 56 * 2), 3)
-    out2 = tmp_path / "r_vs_q.delta"
-    assert anim.write_delta(out2, ref, qry, al, filtered=False) == 3
-    assert len(anim_oracle.read_delta(out2)[0]) == 3
-
-
-class OracleEngine:
-    """Engine.anim_reduce restated with the oracle's parse_delta arithmetic (CPU stand-in for the host-logic tests; the GPU
-    reduction itself is compared bit for bit in tests/test_anim_gpu.py)."""
-
-    def anim_reduce(self, files, apply_filter=False):
-        import numpy as np
-        from collections import namedtuple
-        from pyani_amd import _lib
-        from pyani_amd.engine import Engine
-        Rec = namedtuple("Rec", "ref_id qry_id rs re qs qe errors")
-        out = np.zeros(len(files), dtype=Engine.ANIM_DTYPE)
-        for i, recs in enumerate(files):
-            try:
-                t = anim_oracle.parse_delta_records([Rec(*r) for r in recs])
-            except ZeroDivisionError:
-                out[i]["status"] = _lib.PG_ANIM_NO_ALIGNMENT
-                continue
-            out[i]["ref_aln_len"], out[i]["qry_aln_len"], out[i]["identity"], out[i]["sim_errors"] = t
-        return out
-
-
-@pytest.mark.parametrize("case", ["caulobacter_deltadir", "prefix_stems"])
-def test_process_deltadir_equals_the_imported_reference(tmp_path, case):
-    """All five matrices of pyani.anim.process_deltadir, produced by importing the reference (tools/make_goldens.py), on its
-    own deltadir fixture and on a directory whose stems are prefixes of one another (sorted-Path order != sorted-string
-    order: ADVICE r01) with missing directions: bit-equal, NaN where the reference has NaN."""
-    import gzip
-    import json
-    import numpy as np
-    from pyani_amd import anim
-    fx = json.loads((GOLD / "ref_targets" / "anim_process_deltadir_cases.json").read_text())[case]
-    fx["lengths"] = dict(fx["lengths"])      # stored as an ordered list: the dict order is the label order
-    if "files" in fx:
-        for rel, text in fx["files"].items():
-            (tmp_path / rel).parent.mkdir(parents=True, exist_ok=True)
-            (tmp_path / rel).write_text(text)
-    else:
-        for gz in sorted((GOLD / "anim" / "caulobacter").glob("*.filter.gz")):
-            q = gz.name.split("_vs_")[0]
-            (tmp_path / q).mkdir(exist_ok=True)
-            with gzip.open(gz, "rb") as fi:
-                (tmp_path / q / gz.name[:-3]).write_bytes(fi.read())
-    res = anim.process_deltadir(tmp_path, fx["lengths"], engine=OracleEngine())
-    got = dict((stem, df) for df, stem in res.data)
-    assert sorted(got) == sorted(fx["matrices"])
-    for stem, want in fx["matrices"].items():
-        df = got[stem]
-        assert list(df.index) == want["labels"] == list(df.columns)
-        for a, row in zip(want["labels"], want["rows"]):
-            for b, h in zip(want["labels"], row):
-                w, g = float.fromhex(h), float(df.loc[a, b])
-                assert g == w or (np.isnan(g) and np.isnan(w)), (stem, a, b, g, w)
-    # the pair-tuple route (what calculate_anim_pairs feeds) gives the same matrices with the default file order
-    tuples = {tuple(f.stem.split("_vs_")): anim_oracle.parse_delta(f) for f in sorted(tmp_path.glob("*/*.filter"))}
-    again = anim.assemble_legacy_results(tuples, fx["lengths"])
-    for (df, stem), (df2, _) in zip(res.data, again.data):
-        assert df.equals(df2), stem
-
-
-def test_duplicate_stems_are_rejected(tmp_path):
-    """pyani keys every result by Path.stem; two inputs with one stem would silently overwrite each other."""
-    from pyani_amd import anim
-
-    class NoEngine:
-        def genome_count(self):
-            return 0
-    (tmp_path / "a").mkdir(), (tmp_path / "b").mkdir()
-    for d in ("a", "b"):
-        (tmp_path / d / "same.fna").write_text(">x\nACGT\n")
-    with pytest.raises(ValueError, match="share a stem"):
-        anim.calculate_anim_pairs([tmp_path / "a" / "same.fna", tmp_path / "b" / "same.fna"], engine=NoEngine())
-
-
-def test_process_deltadir_walk_and_assembly(tmp_path):
-    """pyani.anim.process_deltadir (anim.py:415-497) mirrored by pyani_amd.anim.process_deltadir: the directory walk, the
-    skipping of foreign files, the overwrite order and the error behaviour, with the pinned oracle standing in for the
-    GPU reduction (the reduction itself is compared on the GPU in tests/test_anim_gpu.py); identities against the
-    reference's deltadir_result.csv (tests/test_anim.py:243-255)."""
-    import gzip
-    import numpy as np
-    from pyani_amd import _lib, anim
-
-    from collections import namedtuple
-    from pyani_amd.engine import Engine
-    Rec = namedtuple("Rec", "ref_id qry_id rs re qs qe errors")
-
     class OracleEngine:   # Engine.anim_reduce restated with the oracle's parse_delta arithmetic
         def anim_reduce(self, files, apply_filter=False):
             out = np.zeros(len(files), dtype=Engine.ANIM_DTYPE)
