@@ -141,7 +141,7 @@ Result run_pair(const Genome& G, const Genome& H, int filter_1to1, int maxmatch)
                  order.data(), chains.data(), n_chains, (int)chains.size(), cm.data(), n_cm, (int)cm.size());
     std::vector<int32_t> co(n_chains);
     for (int i = 0; i < n_chains; ++i) co[i] = i;
-    std::sort(co.begin(), co.end(), [&](int a, int b) { return cm[chains[a].first].r < cm[chains[b].first].r; });
+    std::sort(co.begin(), co.end(), [&](int a, int b) { return chain_before(chains.data(), cm.data(), a, b); });
     std::vector<ChainFwd> fw(n_chains);
     std::vector<ChainBwd> bw(n_chains);
     std::vector<int32_t> prev_of(n_chains, -1), next_of(n_chains, -1), r_lo(n_chains), r_hi(n_chains), q_lo(n_chains), q_hi(n_chains);

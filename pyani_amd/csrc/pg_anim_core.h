@@ -387,6 +387,13 @@ PG_HD void mgaps_strand(const Match* m, int n, int strand, const int32_t* rrec_o
 // preceding alignment as a target — if the target cell is reached before the break criterion fires, the two are
 // fused into one alignment (this is how nucmer bridges ~100-base junk between two clusters), otherwise the chain
 // starts a new alignment at its own best backward cell.
+// Reference order of the chains: by the start of the first match; chains that start on the same reference base (only with
+// --maxmatch: one reference copy anchored by several query copies) in the order they were extracted — a TOTAL order, so
+// that every form of the cluster stage (radix sort of (r, chain), heapsort, std::sort) lists them identically.
+PG_HD bool chain_before(const Chain* chains, const Match* cm, int a, int b) {
+  const int32_t ra = cm[chains[a].first].r, rb = cm[chains[b].first].r;
+  return ra != rb ? ra < rb : a < b;
+}
 // nearest preceding / following chain of the same (ref record, query record) in ref order (looks 8 entries each way)
 PG_HD void chain_neighbours(const Chain* chains, const int32_t* order, int n, int32_t* prev_of, int32_t* next_of) {
   for (int k = 0; k < n; ++k) {

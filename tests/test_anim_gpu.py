@@ -368,10 +368,10 @@ def test_repeats_mum_mode_equals_the_cpu_statement(repeat_runs):
     assert n_unfiltered > got[(False, (0, 1))][3]                     # delta-filter -1 had repeat alignments to drop
 
 
-@pytest.mark.xfail(strict=False, reason="--maxmatch with repeated anchors: found in round 2 — 3 of these 12 pairs differ between the "
-                                        "wave-cooperative chain extraction and the scalar statement (a repeat copy's alignment kept by "
-                                        "one, dropped by the other); no MUMmer --maxmatch output exists to say which is right")
 def test_repeats_maxmatch_mode_equals_the_cpu_statement(repeat_runs):
+    """--maxmatch on the same genomes: several query copies anchor one reference copy, so chains START ON THE SAME REFERENCE
+    BASE — their order is pga::chain_before's total order (start, then extraction order) in every form of the cluster stage
+    (found in round 2: the scalar forms sorted such ties in an unspecified order and 3 of these 12 pairs differed)."""
     pairs, got, want, _ = repeat_runs
     bad = [(p, got[(True, p)], want[(True, p)]) for p in pairs if got[(True, p)] != want[(True, p)]]
     (ROOT / "gpurun_out").mkdir(exist_ok=True)

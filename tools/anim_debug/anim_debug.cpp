@@ -113,7 +113,7 @@ int main(int argc, char** argv) {
     // order chains by first-match ref start; pick forward targets
     std::vector<int32_t> co(n_chains);
     for (int i = 0; i < n_chains; ++i) co[i] = i;
-    std::sort(co.begin(), co.end(), [&](int a, int b) { return cm[chains[a].first].r < cm[chains[b].first].r; });
+    std::sort(co.begin(), co.end(), [&](int a, int b) { return chain_before(chains.data(), cm.data(), a, b); });
     std::vector<ChainFwd> fw(n_chains);
     std::vector<ChainBwd> bw(n_chains);
     std::vector<int32_t> prev_of(n_chains, -1), next_of(n_chains, -1), r_lo(n_chains), r_hi(n_chains), q_lo(n_chains), q_hi(n_chains);
