@@ -10,12 +10,14 @@ C2 TETRA roofline nested as a sub-record.
 
 ANIm (default).  All genomes are resident in HBM on every GPU (2-bit codes + 1-bit mask; 1.9 GB at C4).  A STEP is one
 pass of the whole pipeline — seed, cluster, extend, 1-to-1 filter, parse_delta reduction, results back on the host — over
-one tile of the ordered-pair grid: `--rows-per-step` reference genomes (default 500) x all 999 queries = 499 500 ordered
-pairs; step k takes rows [k*R, (k+1)*R) modulo N, so 2 steps are exactly one pass over the N x N grid (large steps keep every
-rank's launches full-size when the rows are dealt over 8 GPUs).  `value` = ordered
-pairs processed in the K timed steps / wall time.  N > 1 is STRONG scaling of that same job: the rows of every step are
-dealt over the ranks (pyani_amd.parallel.anim_row_shard), each rank runs its rows against all queries, ONE RCCL all-gather
-per step (64 B per pair) puts the step's rows of the result grid on every rank.  No other collective, no sequence traffic.
+one tile of the ordered-pair grid: the UNORDERED pairs owned by `--rows-per-step` genomes (default 500), each in both
+directions (pyani_amd.parallel.anim_pair_array(symmetric=True): {g, h} belongs to the smaller id if g + h is even, else to
+the larger) = ~499 500 ordered pairs; step k takes genomes [k*R, (k+1)*R) modulo N, so 2 steps are exactly one pass over the
+N x N grid.  A pair and its reverse sit in the same call because they have the same maximal exact matches and the engine
+seeds them once (pg_anim.hip "roles"); large steps keep every rank's launches full-size when the rows are dealt over 8 GPUs.
+`value` = ordered pairs processed in the K timed steps / wall time.  N > 1 is STRONG scaling of that same job: the rows of
+every step are dealt over the ranks (pyani_amd.parallel.anim_row_shard), each rank runs the pairs its rows own, ONE RCCL
+all-gather per step (64 B per pair) puts the step's results on every rank.  No other collective, no sequence traffic.
 
   --workload tetra : the TETRA side alone (C2: 200 genomes, counts + Z + Pearson; N > 1 = weak scaling, 200 genomes per GPU).
   --workload anib  : C5 (BASELINE.json configs[4]): 500 genomes of 1-12 Mb, pyani's ANIb on the engine's fragment mode
@@ -249,16 +251,14 @@ def run_anim(args, rank, world, local, dist, torch):
 
     def step(k, keep=False):
         rows = rows_of(k)
+        pairs = parallel.anim_pair_array(n, rows, symmetric=True)   # the rows' unordered pairs, both directions
         if world > 1:
-            grid = parallel.anim_allgather(compute, n, dev, rows=rows)
+            grid = parallel.anim_allgather(compute, n, dev, rows=rows, symmetric=True)
+            vals = grid[torch.from_numpy(pairs[:, 0]).to(dev), torch.from_numpy(pairs[:, 1]).to(dev)]
         else:
-            pairs = parallel.anim_pair_array(n, rows)
             vals = compute(pairs)
-            grid = torch.zeros((len(rows), n, parallel.ANIM_FIELDS), dtype=torch.int64, device=dev)
-            slot = np.repeat(np.arange(len(rows)), n - 1)          # pairs are grouped by row, n - 1 queries each
-            grid[torch.from_numpy(slot).to(dev), torch.from_numpy(pairs[:, 1]).to(dev)] = vals
         if keep:
-            tiles[k] = (rows, grid)
+            tiles[k] = (pairs, vals)
 
     def fence():
         eng.sync()
@@ -288,19 +288,17 @@ def run_anim(args, rank, world, local, dist, torch):
     prof = {eng.kernel_name(s_): eng.profile_get(s_) for s_ in stages}
 
     if rank == 0:
-        done_rows = [q for k in tiles for q in tiles[k][0]]
-        pairs_done = len(done_rows) * (n - 1)
-        g = torch.cat([tiles[k][1] for k in sorted(tiles)]).cpu().numpy()           # [rows, n, FIELDS]
-        rowv = np.array(done_rows)
-        offdiag = rowv[:, None] != np.arange(n)[None, :]
-        related_m = ((rowv[:, None] % K) == (np.arange(n)[None, :] % K)) & offdiag
-        status = g[:, :, 5]
-        ident = g[:, :, 4].view(np.float64)
+        P = np.concatenate([tiles[k][0] for k in sorted(tiles)])                      # [M, 2] (reference, query)
+        g = torch.cat([tiles[k][1] for k in sorted(tiles)]).cpu().numpy()           # [M, FIELDS]
+        pairs_done = len(P)
+        related_m = (P[:, 0] % K) == (P[:, 1] % K)
+        status = g[:, 5]
+        ident = g[:, 4].view(np.float64)
         n_related = int(related_m.sum())
         ok_rel = int(((status == 0) & related_m).sum())
-        unrel_aln = int(((status == 0) & ~related_m & offdiag).sum())
+        unrel_aln = int(((status == 0) & ~related_m).sum())
         step_s = elapsed / args.steps
-        alg_bytes = float(sum(((lens[q] + 3) // 4 + (lens + 3) // 4 + 32).sum() - ((lens[q] + 3) // 4 * 2 + 32) for q in done_rows))
+        alg_bytes = float(((lens[P[:, 0]] + 3) // 4 + (lens[P[:, 1]] + 3) // 4 + 32).sum())
         # the dominant kernel of THIS run, timed live with HIP events on the engine's stream (rank 0's launches)
         dom = max(prof, key=lambda name: prof[name][0])
         dom_ms, dom_n = prof[dom]
@@ -310,11 +308,12 @@ def run_anim(args, rank, world, local, dist, torch):
         pmc = ROOT / "profiles" / "pmc_anim.json"
         if pmc.exists():
             traffic = json.loads(pmc.read_text()).get(dom, {}).get("hbm_bytes_per_launch")
-        # hash of one whole N x N result grid (the last occurrence of every row among the timed steps), if the steps cover it
-        last = {}
-        for pos, q in enumerate(done_rows):
-            last[q] = pos
-        sha = hashlib.sha1(g[[last[q] for q in range(n)]].tobytes()).hexdigest() if len(last) == n else None
+        # hash of one whole N x N result grid (the last occurrence of every cell among the timed steps), if the steps cover it
+        dense = np.zeros((n, n, g.shape[1]), dtype=np.int64)
+        covered = np.zeros((n, n), dtype=bool)
+        dense[P[:, 0], P[:, 1]] = g
+        covered[P[:, 0], P[:, 1]] = True
+        sha = hashlib.sha1(dense.tobytes()).hexdigest() if int(covered.sum()) == n * (n - 1) else None
         out = {
             "metric": "genome-pairs/sec (ordered pairs) + wall-clock for the N x N ANIm grid: nucmer --mum + delta-filter -1 + "
                       "parse_delta equivalent per ordered pair, genomes resident in HBM; vs the CPU path on this box's host cores",
@@ -325,9 +324,10 @@ def run_anim(args, rank, world, local, dist, torch):
             "config": {
                 "workload": f"C4: ANIm N x N grid on {n} synthetic ~{args.length / 1e6:g} Mb genomes (SURVEY.md §8(d) generator, seed "
                             f"{args.seed}; {n * (n - 1)} ordered pairs, {n * (n // K - 1)} of them between descendants of one ancestor); "
-                            f"a step = {R} reference genomes x all {n - 1} queries = {R * (n - 1)} ordered pairs, "
+                            f"a step = the unordered pairs owned by {R} genomes, in both directions (pyani_amd.parallel."
+                            f"anim_pair_array(symmetric=True): ~{R * (n - 1)} ordered pairs), "
                             f"{n // R if n % R == 0 else n / R:g} steps = the whole grid",
-                "genomes": n, "rows_per_step": R, "pairs_per_step": R * (n - 1), "pairs_timed": pairs_done,
+                "genomes": n, "rows_per_step": R, "pairs_per_step": pairs_done / args.steps, "pairs_timed": pairs_done,
                 "related_pairs_timed": n_related, "related_pairs_with_alignment": ok_rel, "unrelated_pairs_with_alignment": unrel_aln,
                 "grid_pairs": n * (n - 1), "wall_s_grid": elapsed / pairs_done * n * (n - 1),
                 "identity_related_min_med_max": [float(x) for x in np.percentile(ident[(status == 0) & related_m], [0, 50, 100])]
@@ -354,10 +354,9 @@ def run_anim(args, rank, world, local, dist, torch):
         }
         if world == 1 and not args.no_cpu_baseline:
             def gpu_lookup(q, s_):
-                hit = np.nonzero(rowv == q)[0]
-                if len(hit) == 0:
+                if not covered[q, s_]:
                     return None
-                c = g[hit[0], s_]
+                c = dense[q, s_]
                 return {"ref_aln_len": c[0], "qry_aln_len": c[1], "sim_errors": c[2], "identity": np.int64(c[4]).view(np.float64), "status": c[5]}
             related_all = ((np.arange(n)[:, None] % K) == (np.arange(n)[None, :] % K))[~np.eye(n, dtype=bool)]
             out["cpu_baseline"] = anim_cpu_baseline(args, data, n, related_all, gpu_lookup)

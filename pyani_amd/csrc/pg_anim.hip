@@ -27,6 +27,7 @@
 // Every kernel has a scalar statement in pg_anim_core.h that compiles for the host (tools/anim_debug); the two are kept
 // in lock-step and compared on the GPU by tests/test_anim_gpu.py.  Limits: genomes up to ~14 Mb (a reference k-mer
 // group must fit a 16384-slot LDS table; PG_E_CAPACITY otherwise), chain scores < 2^24.
+#include <tuple>
 #include "pg_internal.h"
 #include "pg_anim_core.h"
 #include "pg_anib_core.h"
@@ -132,6 +133,11 @@ struct AnimScratch {
   Match* hits_sorted = nullptr;     // the same, dealt into per-unit slices (hoff)
   uint32_t *hit_count = nullptr, *hoff = nullptr, *hit_cursor = nullptr;   // per unit
   size_t hit_cap = 0;
+  int32_t* mirror_d = nullptr;      // per pair: the partner pair (roles swapped) that receives this pair's matches transposed, or -1
+  BigUnit* big_d = nullptr;         // cluster stage: units whose chains are extracted by ranges, the range work items, their counts
+  uint2* ranges_d = nullptr;
+  RangeOut* range_out = nullptr;
+  size_t big_cap = 0, range_cap = 0;
   bool lds_attr_set = false;        // anim_seed_kernel's dynamic-LDS limit has been raised on this context's device
   // fragment mode (ANIb)
   int32_t* fr_tables = nullptr;     // frag_pos | frag_len | rec_frag0 of every distinct query genome of the batch
@@ -237,7 +243,7 @@ void pg_anim_free_scratch(pg_ctx* ctx) {
 static void anim_free_one(pg_ctx* ctx, void*& slot) {
   AnimScratch* A = static_cast<AnimScratch*>(slot);
   if (!A) return;
-  void* ptrs[] = {A->ext_reqs, A->ext_pre, A->ext_dumps, A->ext_wave, A->ext_counts, A->gap_counts, A->task_cls, A->task_lists, A->hits_sorted, A->hit_count, A->hoff, A->hit_cursor, A->hits_d, A->slice_d, A->choff_d, A->list_cnt, A->srefs_d, A->sqry_d, A->recs_d, A->refs_d, A->units_d, A->mem_count, A->moff, A->nch, A->status, A->out, A->mem, A->cm,
+  void* ptrs[] = {A->mirror_d, A->big_d, A->ranges_d, A->range_out, A->ext_reqs, A->ext_pre, A->ext_dumps, A->ext_wave, A->ext_counts, A->gap_counts, A->task_cls, A->task_lists, A->hits_sorted, A->hit_count, A->hoff, A->hit_cursor, A->hits_d, A->slice_d, A->choff_d, A->list_cnt, A->srefs_d, A->sqry_d, A->recs_d, A->refs_d, A->units_d, A->mem_count, A->moff, A->nch, A->status, A->out, A->mem, A->cm,
                   A->iscratch, A->order, A->prev, A->next, A->alnof, A->chains, A->fw, A->bw, A->S.alns, A->S.a_rrec,
                   A->S.a_qrec, A->S.idx, A->S.from, A->S.sc, A->wl_d, A->seedbuf, A->seed_total, A->tasks_d, A->fr_tables, A->fr_pairs,
                   A->fr_slot_pair, A->fr_off, A->fr_nrows, A->fr_ebase, A->fr_entries, A->fr_rows, A->fr_out};
@@ -346,47 +352,92 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
   PG_HIP(ctx, hipMemcpyAsync(A->refs_d, refs.data(), n_refs * sizeof(RefDesc), hipMemcpyHostToDevice, cur_stream(ctx)));
   PG_HIP(ctx, hipMemcpyAsync(A->units_d, units.data(), n_units * sizeof(UnitDesc), hipMemcpyHostToDevice, cur_stream(ctx)));
   // seeding: LDS-resident reference groups, streamed query groups; one pass appends (unit, match) records and the
-  // per-unit counts it leaves are exact even if the buffer overflowed
-  {
-    std::vector<int32_t> qry_list(qry_ids, qry_ids + n_pairs);
-    std::sort(qry_list.begin(), qry_list.end());
-    qry_list.erase(std::unique(qry_list.begin(), qry_list.end()), qry_list.end());
-    if ((rc = anim_ensure_lists(ctx, A, ref_list, qry_list, qstep))) return rc;
-  }
-  // (entries of genomes this batch uses are complete and never change while the genomes are resident; the vector itself may be
-  // resized by the other worker, so take the pointers under the lock)
-  std::vector<GenomeIdx> LSv;
-  {
-    std::lock_guard<std::mutex> lk(ctx->anim_mu);
-    LSv = anim_lists(ctx)->gidx;
-  }
-  struct { std::vector<GenomeIdx>& gidx; } LSref{LSv};
-  auto* LS = &LSref;
-  uint32_t max_group = 1;
-  for (uint32_t r = 0; r < n_refs; ++r) if (LS->gidx[ref_list[r]].ref_max > max_group) max_group = LS->gidx[ref_list[r]].ref_max;
-  uint32_t slots = 256;
-  while (slots < 2 * max_group) slots <<= 1;
-  if (slots > SEED_MAX_SLOTS)
-    return pg_fail(ctx, PG_E_CAPACITY, "anim seeding: a reference k-mer group does not fit the LDS table (genome too large or too repetitive)");
-  std::vector<SeedRef> srefs(n_refs);
+  // per-unit counts it leaves are exact even if the buffer overflowed.
+  // Roles: when the launch holds a pair in BOTH directions, (A, B) and (B, A), only one of them is seeded — the maximal exact
+  // matches of the two are the same set, and anim_hit_kernel appends each match a second time, transposed, for the partner
+  // (`mirror`).  The seeded direction is the one whose reference has more pairs in the launch (longer query streams per LDS
+  // table); equal counts: decided by the ids' parity, so that every genome is the table for half of its partners.
+  std::vector<int32_t> mirror(n_pairs);
+  std::vector<uint8_t> seeded(n_pairs);
+  std::vector<SeedRef> srefs;
   std::vector<SeedQry> sqry(n_pairs);
-  for (uint32_t p = 0; p < n_pairs; ++p)
-    sqry[p] = qstep == 1 ? SeedQry{LS->gidx[qry_ids[p]].qry_list1, LS->gidx[qry_ids[p]].qry_goff1} : SeedQry{LS->gidx[qry_ids[p]].qry_list, LS->gidx[qry_ids[p]].qry_goff};
-  auto fill_srefs = [&](uint32_t limit) {
-    for (uint32_t r = 0; r < n_refs; ++r) srefs[r] = SeedRef{LS->gidx[ref_list[r]].ref_list, LS->gidx[ref_list[r]].ref_goff, 0, 0};
-    for (uint32_t p = 0; p < limit; ++p) {
-      SeedRef& S = srefs[ref_of_pair[p]];
-      if (S.pair_end == 0) S.pair_begin = p;
-      S.pair_end = p + 1;
-    }
-  };
-  PG_HIP(ctx, hipMemcpyAsync(A->sqry_d, sqry.data(), n_pairs * sizeof(SeedQry), hipMemcpyHostToDevice, cur_stream(ctx)));
+  std::vector<GenomeIdx> LSv;
+  uint32_t slots = 256, n_srefs = 0;
   if (n_pairs > A->slice_pairs) {
     if ((rc = regrow(ctx, A->slice_d, (size_t)n_pairs * SEED_GROUPS))) return rc;
+    if ((rc = regrow(ctx, A->mirror_d, n_pairs))) return rc;
     A->slice_pairs = n_pairs;
   }
   const uint32_t slice_stride = n_pairs;   // the table is laid out for the whole batch even if only a prefix is seeded again
-  hipLaunchKernelGGL(anim_slice_kernel, dim3(n_pairs), dim3(256), 0, cur_stream(ctx), A->sqry_d, n_pairs, A->slice_d);
+  const bool use_mirror = !frag && !getenv("PYANI_ANIM_NO_MIRROR");
+  auto prepare = [&](uint32_t limit) -> int {   // roles, seed lists and descriptors for the pairs [0, limit)
+    std::fill(mirror.begin(), mirror.end(), -1);
+    std::fill(seeded.begin(), seeded.end(), (uint8_t)0);
+    std::fill(seeded.begin(), seeded.begin() + limit, (uint8_t)1);
+    if (use_mirror && limit > 1) {
+      std::vector<uint32_t> deg(ctx->genomes.size(), 0);
+      for (uint32_t p = 0; p < limit; ++p) ++deg[ref_ids[p]];
+      std::vector<uint32_t> idx(limit);
+      for (uint32_t p = 0; p < limit; ++p) idx[p] = p;
+      auto key = [&](uint32_t p) {   // unordered pair, then direction, then position: partners end up next to each other
+        const uint32_t a = (uint32_t)ref_ids[p], b = (uint32_t)qry_ids[p];
+        return std::make_tuple(a < b ? a : b, a < b ? b : a, a < b ? 0 : 1, p);
+      };
+      std::sort(idx.begin(), idx.end(), [&](uint32_t x, uint32_t y) { return key(x) < key(y); });
+      for (uint32_t i = 0; i < limit;) {
+        uint32_t j = i;
+        while (j < limit && std::get<0>(key(idx[j])) == std::get<0>(key(idx[i])) && std::get<1>(key(idx[j])) == std::get<1>(key(idx[i]))) ++j;
+        uint32_t m = i;   // [i, m): direction min -> max, [m, j): the other direction (a pair listed twice pairs up once)
+        while (m < j && std::get<2>(key(idx[m])) == 0) ++m;
+        if (ref_ids[idx[i]] != qry_ids[idx[i]])
+          for (uint32_t k = 0; i + k < m && m + k < j; ++k) {
+            const uint32_t p = idx[i + k], p2 = idx[m + k];
+            const uint32_t a = (uint32_t)ref_ids[p], b = (uint32_t)qry_ids[p];
+            const bool first = deg[a] != deg[b] ? deg[a] > deg[b] : ((a < b) != (((a + b) & 1u) != 0));
+            if (first) { mirror[p] = (int32_t)p2; seeded[p2] = 0; } else { mirror[p2] = (int32_t)p; seeded[p] = 0; }
+          }
+        i = j;
+      }
+    }
+    std::vector<int32_t> seed_refs, seed_qrys;
+    for (uint32_t p = 0; p < limit; ++p)
+      if (seeded[p]) {
+        if (seed_refs.empty() || seed_refs.back() != ref_ids[p]) seed_refs.push_back(ref_ids[p]);
+        seed_qrys.push_back(qry_ids[p]);
+      }
+    std::sort(seed_qrys.begin(), seed_qrys.end());
+    seed_qrys.erase(std::unique(seed_qrys.begin(), seed_qrys.end()), seed_qrys.end());
+    int rc2;
+    if ((rc2 = anim_ensure_lists(ctx, A, seed_refs, seed_qrys, qstep))) return rc2;
+    {   // (entries of genomes this batch uses are complete and never change while the genomes are resident; the vector itself
+        // may be resized by another worker, so take the pointers under the lock)
+      std::lock_guard<std::mutex> lk(ctx->anim_mu);
+      LSv = anim_lists(ctx)->gidx;
+    }
+    uint32_t max_group = 1;
+    for (int32_t g : seed_refs) if (LSv[g].ref_max > max_group) max_group = LSv[g].ref_max;
+    slots = 256;
+    while (slots < 2 * max_group) slots <<= 1;
+    if (slots > SEED_MAX_SLOTS)
+      return pg_fail(ctx, PG_E_CAPACITY, "anim seeding: a reference k-mer group does not fit the LDS table (genome too large or too repetitive)");
+    srefs.clear();   // one entry per reference with seeded pairs: [pair_begin, pair_end) spans them (pairs in between that
+                     // are not seeded have empty slices)
+    for (uint32_t p = 0; p < n_pairs; ++p) {
+      sqry[p] = SeedQry{nullptr, nullptr};
+      if (p >= limit || !seeded[p]) continue;
+      const GenomeIdx& X = LSv[qry_ids[p]];
+      sqry[p] = qstep == 1 ? SeedQry{X.qry_list1, X.qry_goff1} : SeedQry{X.qry_list, X.qry_goff};
+      if (srefs.empty() || srefs.back().list != LSv[ref_ids[p]].ref_list)
+        srefs.push_back(SeedRef{LSv[ref_ids[p]].ref_list, LSv[ref_ids[p]].ref_goff, p, p + 1});
+      srefs.back().pair_end = p + 1;
+    }
+    n_srefs = (uint32_t)srefs.size();
+    PG_HIP(ctx, hipMemcpyAsync(A->sqry_d, sqry.data(), n_pairs * sizeof(SeedQry), hipMemcpyHostToDevice, cur_stream(ctx)));
+    PG_HIP(ctx, hipMemcpyAsync(A->mirror_d, mirror.data(), n_pairs * sizeof(int32_t), hipMemcpyHostToDevice, cur_stream(ctx)));
+    if (n_srefs) PG_HIP(ctx, hipMemcpyAsync(A->srefs_d, srefs.data(), n_srefs * sizeof(SeedRef), hipMemcpyHostToDevice, cur_stream(ctx)));
+    hipLaunchKernelGGL(anim_slice_kernel, dim3(n_pairs), dim3(256), 0, cur_stream(ctx), A->sqry_d, slice_stride, A->slice_d);
+    return PG_OK;
+  };
   if (!A->lds_attr_set) {   // per context = per device (the attribute is a property of the function ON a device)
     PG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(anim_seed_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)(SEED_MAX_SLOTS * 8 + SEED_STAGE_BYTES)));
@@ -412,13 +463,13 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
   for (int attempt = 0;; ++attempt) {
     if (attempt == 8) return pg_fail(ctx, PG_E_CAPACITY, "anim seeding: buffers still overflow after repeated splitting");
     uint32_t counts[2] = {0, 0};   // matches appended, hits recorded
-    fill_srefs(n_pairs);
-    PG_HIP(ctx, hipMemcpyAsync(A->srefs_d, srefs.data(), n_refs * sizeof(SeedRef), hipMemcpyHostToDevice, cur_stream(ctx)));
+    if ((rc = prepare(n_pairs))) return rc;   // (again after a split: a pair whose partner left the launch is seeded itself)
     PG_HIP(ctx, hipMemsetAsync(A->mem_count, 0, n_units * 4, cur_stream(ctx)));
     PG_HIP(ctx, hipMemsetAsync(A->seed_total, 0, 8, cur_stream(ctx)));   // [0] matches, [1] hits
     PG_HIP(ctx, hipMemsetAsync(A->hit_count, 0, n_units * 4, cur_stream(ctx)));
     pg_prof_begin(ctx, PG_K_ANIM_SEED);
-    hipLaunchKernelGGL(anim_seed_kernel, dim3(n_refs, SEED_GROUPS), dim3(SEED_BLOCK), (size_t)slots * 8 + SEED_STAGE_BYTES, cur_stream(ctx),
+    if (n_srefs)
+    hipLaunchKernelGGL(anim_seed_kernel, dim3(n_srefs, SEED_GROUPS), dim3(SEED_BLOCK), (size_t)slots * 8 + SEED_STAGE_BYTES, cur_stream(ctx),
                        A->refs_d, A->units_d, A->srefs_d, A->sqry_d, A->slice_d, slice_stride, slots - 1, A->hits_d,
                        (uint32_t)A->hit_cap, A->seed_total + 1, A->hit_count, qstep);
     pg_prof_end(ctx);
@@ -430,7 +481,7 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
                        (uint32_t)A->hit_cap, A->hoff, A->hit_cursor, A->hits_sorted);
     hipLaunchKernelGGL(anim_hit_kernel, dim3(n_units), dim3(256), 0, cur_stream(ctx), A->refs_d, A->units_d, A->hits_sorted, A->hoff,
                        A->seed_total + 1, (uint32_t)A->hit_cap, A->seedbuf, (uint32_t)A->seed_cap, A->seed_total, A->mem_count,
-                       frag ? FRAG_SEED_MIN : MIN_MATCH, qstep);
+                       frag ? FRAG_SEED_MIN : MIN_MATCH, qstep, use_mirror ? A->mirror_d : (const int32_t*)nullptr);
     pg_prof_end(ctx);
     PG_HIP(ctx, hipMemcpyAsync(cnt.data(), A->mem_count, n_units * 4, hipMemcpyDeviceToHost, cur_stream(ctx)));
     PG_HIP(ctx, hipMemcpyAsync(counts, A->seed_total, 8, hipMemcpyDeviceToHost, cur_stream(ctx)));
@@ -464,8 +515,6 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
     if ((rc = regrow(ctx, A->seedbuf, A->seed_cap))) return rc;
   }
   *n_done = n_pairs;
-  uint32_t n_nonempty = 0;
-  for (uint32_t u = 0; u < n_units; ++u) n_nonempty += cnt[u] >= 1024;   // units with real work (unrelated pairs have ~50 chance matches)
   moff.assign((size_t)n_units + 1, 0);
   for (uint32_t u = 0; u < n_units; ++u) moff[u + 1] = moff[u] + ((cnt[u] + 2) & ~1u);   // even slice sizes: 8-byte aligned sub-slices
   const size_t M = moff[n_units];
@@ -503,20 +552,53 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
     PG_HIP(ctx, hipGetLastError());
     return anib_frag_stage(ctx, A, qry_ids, n_pairs, cnt, *frag);
   }
+  // Units with >= split_min matches ("big": pairs of related genomes) get their chains from many waves (pga_cluster.inc,
+  // anim_chain_range_kernel); every other unit is finished by the one wave that filters and clusters it.
+  const int split_min = getenv("PYANI_ANIM_SPLIT_MIN") ? atoi(getenv("PYANI_ANIM_SPLIT_MIN")) : 2048;   // (<= 0: never split)
+  const int range_entries = getenv("PYANI_ANIM_RANGE_ENTRIES") && atoi(getenv("PYANI_ANIM_RANGE_ENTRIES")) > 0
+                                ? atoi(getenv("PYANI_ANIM_RANGE_ENTRIES")) : CHAIN_RANGE_ENTRIES;
+  std::vector<BigUnit> big;
+  std::vector<uint2> ranges;
+  if (split_min > 0 && !getenv("PYANI_ANIM_SCALAR_CLUSTER"))
+    for (uint32_t u = 0; u < n_units; ++u)
+      if (cnt[u] >= (uint32_t)split_min) {
+        uint32_t R = cnt[u] / (uint32_t)range_entries;
+        R = R < 1 ? 1 : (R > (uint32_t)CHAIN_RANGES_MAX ? (uint32_t)CHAIN_RANGES_MAX : R);
+        for (uint32_t r = 0; r < R; ++r) ranges.push_back(make_uint2((uint32_t)big.size(), r));
+        big.push_back(BigUnit{u, (uint32_t)(ranges.size() - R), R, 0});
+      }
+  if (!big.empty()) {
+    if (big.size() > A->big_cap) { if ((rc = regrow(ctx, A->big_d, big.size() + big.size() / 4))) return rc; A->big_cap = big.size() + big.size() / 4; }
+    if (ranges.size() > A->range_cap) {
+      const size_t c = ranges.size() + ranges.size() / 4;
+      if ((rc = regrow(ctx, A->ranges_d, c))) return rc;
+      if ((rc = regrow(ctx, A->range_out, c))) return rc;
+      A->range_cap = c;
+    }
+    PG_HIP(ctx, hipMemcpyAsync(A->big_d, big.data(), big.size() * sizeof(BigUnit), hipMemcpyHostToDevice, cur_stream(ctx)));
+    PG_HIP(ctx, hipMemcpyAsync(A->ranges_d, ranges.data(), ranges.size() * sizeof(uint2), hipMemcpyHostToDevice, cur_stream(ctx)));
+  }
+  const int split_arg = big.empty() ? 0x7fffffff : split_min;
   pg_prof_begin(ctx, PG_K_ANIM_CLUSTER);
   if (getenv("PYANI_ANIM_SCALAR_CLUSTER") && !maxmatch)   // debugging aid: the one-thread-per-unit statement of the same algorithm
     hipLaunchKernelGGL(anim_cluster_kernel, dim3((n_units + 63) / 64), dim3(64), 0, cur_stream(ctx), A->refs_d, A->units_d, n_units,
                        A->mem, A->mem_count, A->iscratch, O);
-  else if ((n_nonempty > 3000 && !getenv("PYANI_ANIM_SPLIT_CLUSTER")) || getenv("PYANI_ANIM_WAVE_PREP"))
-    // thousands of units with matches: one wave per unit already fills the machine, and the radix scatters are bound by
-    // HBM's partial-line write rate, which more waves per unit only congest (measured: C3 574 ms vs 724 ms split)
+  else {
+    // few big units: PREP_WAVES waves share the sorts / union-find of each, so that the largest unit is not the launch time;
+    // thousands of them: one wave per unit already fills the machine, and the radix scatters are bound by HBM's partial-line
+    // write rate, which more waves per unit only congest (measured: C3 574 ms vs 724 ms split)
+    const bool prep = !big.empty() && ((big.size() <= 3000 && !getenv("PYANI_ANIM_WAVE_PREP")) || getenv("PYANI_ANIM_SPLIT_CLUSTER"));
+    if (prep)
+      hipLaunchKernelGGL(anim_cluster_prep_kernel, dim3((uint32_t)big.size()), dim3(PREP_THREADS), 0, cur_stream(ctx), A->refs_d, A->units_d,
+                         A->mem, A->mem_count, A->iscratch, O, maxmatch, A->big_d);
     hipLaunchKernelGGL(anim_cluster_wave_kernel, dim3(n_units), dim3(64), 0, cur_stream(ctx), A->refs_d, A->units_d, A->mem,
-                       A->mem_count, A->iscratch, O, 0, maxmatch);
-  else {   // few units: PREP_WAVES waves share each unit's sorts / union-find so that the largest unit is not the launch time
-    hipLaunchKernelGGL(anim_cluster_prep_kernel, dim3(n_units), dim3(PREP_THREADS), 0, cur_stream(ctx), A->refs_d, A->units_d, A->mem,
-                       A->mem_count, A->iscratch, O, maxmatch);
-    hipLaunchKernelGGL(anim_cluster_wave_kernel, dim3(n_units), dim3(64), 0, cur_stream(ctx), A->refs_d, A->units_d, A->mem,
-                       A->mem_count, A->iscratch, O, 1, maxmatch);
+                       A->mem_count, A->iscratch, O, prep ? 1 : 0, maxmatch, split_arg);
+    if (!big.empty()) {
+      hipLaunchKernelGGL(anim_chain_range_kernel, dim3((uint32_t)ranges.size()), dim3(64), 0, cur_stream(ctx), A->units_d, A->mem, A->iscratch,
+                         O, A->big_d, A->ranges_d, A->range_out);
+      hipLaunchKernelGGL(anim_chain_merge_kernel, dim3((uint32_t)big.size()), dim3(64), 0, cur_stream(ctx), A->iscratch, O, A->big_d,
+                         A->range_out);
+    }
   }
   pg_prof_end(ctx);
   // work list of (unit, chain): one wave each

@@ -744,19 +744,61 @@ int pg_anim_pairs(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_ids, u
       return pg_fail(ctx, PG_E_ARG, "genome id out of range");
   int rc;
   if ((rc = pg_upload(ctx))) return rc;
-  // group the ordered pairs by reference genome: one k-mer table per reference, its queries in chunks
+  // Launch order.  A pair whose reverse (roles swapped) is in the call too shares its seeding with it, if both are in one
+  // launch (pg_anim.hip: roles).  Every pair gets a HUB genome: its reference, or — with the reverse present — the genome
+  // of the two that is the reference of more pairs of the call (ties: by the ids' parity, so that a full grid makes every
+  // genome the hub of half its partners).  A pair and its reverse have the same hub; pairs are ordered by hub, launches are
+  // runs of whole hub groups, and inside a launch the pairs are grouped by reference (one k-mer table per seeded reference).
   std::vector<uint64_t> order(n_pairs);
-  for (uint64_t i = 0; i < n_pairs; ++i) order[i] = i;
-  std::stable_sort(order.begin(), order.end(), [&](uint64_t a, uint64_t b) { return ref_ids[a] < ref_ids[b]; });
-  // launches: as many pairs as the scratch budget allows, at most MAX_REFS distinct references (one 20-mer table each); with
-  // two workers the launches are half as large and each worker gets half the match budget, so the memory in use is the same
+  std::vector<int32_t> hub(n_pairs);
+  {
+    std::vector<uint32_t> deg(ctx->genomes.size(), 0);
+    for (uint64_t i = 0; i < n_pairs; ++i) { order[i] = i; ++deg[ref_ids[i]]; hub[i] = ref_ids[i]; }
+    auto lo = [&](uint64_t i) { return std::min(ref_ids[i], qry_ids[i]); };
+    auto hi = [&](uint64_t i) { return std::max(ref_ids[i], qry_ids[i]); };
+    std::sort(order.begin(), order.end(), [&](uint64_t x, uint64_t y) {
+      return lo(x) != lo(y) ? lo(x) < lo(y) : (hi(x) != hi(y) ? hi(x) < hi(y) : x < y); });
+    for (uint64_t i = 0; i < n_pairs;) {
+      uint64_t j = i;
+      bool fwd = false, rev = false;
+      while (j < n_pairs && lo(order[j]) == lo(order[i]) && hi(order[j]) == hi(order[i])) {
+        (ref_ids[order[j]] <= qry_ids[order[j]] ? fwd : rev) = true;
+        ++j;
+      }
+      if (fwd && rev) {
+        const int32_t a = lo(order[i]), b = hi(order[i]);
+        const int32_t h = deg[a] != deg[b] ? (deg[a] > deg[b] ? a : b) : ((((a + b) & 1) == 0) ? a : b);
+        for (uint64_t k = i; k < j; ++k) hub[order[k]] = h;
+      }
+      i = j;
+    }
+    std::sort(order.begin(), order.end(), [&](uint64_t x, uint64_t y) {
+      return hub[x] != hub[y] ? hub[x] < hub[y] : (ref_ids[x] != ref_ids[y] ? ref_ids[x] < ref_ids[y] : x < y); });
+  }
+  // launches: as many pairs as the scratch budget allows, at most MAX_REFS hubs; with W workers the launches are 1/W as
+  // large and each worker gets 1/W of the match budget, so the memory in use is the same
   const int W = n_pairs >= 4096 ? ctx->anim_workers : 1;
   const uint32_t MAX_PAIRS = ctx->anim_batch_pairs / W, MAX_REFS = 256;
   const uint64_t max_matches = ctx->anim_batch_matches / W;
-  // equal chunks, a multiple of W of them, none above the per-launch budget
+  // about equal launches, a multiple of W of them, none above the per-launch budget
   const uint64_t cap = MAX_PAIRS ? MAX_PAIRS : 1;
-  const uint64_t n_chunks = (uint64_t)W * ((n_pairs + (uint64_t)W * cap - 1) / ((uint64_t)W * cap));
-  const auto chunks = anim_chunks(ref_ids, order, n_chunks ? std::min<uint64_t>(cap, (n_pairs + n_chunks - 1) / n_chunks) : cap, MAX_REFS);
+  const uint64_t n_target = (uint64_t)W * ((n_pairs + (uint64_t)W * cap - 1) / ((uint64_t)W * cap));
+  const uint64_t target = n_target ? std::min<uint64_t>(cap, (n_pairs + n_target - 1) / n_target) : cap;
+  std::vector<std::pair<uint64_t, uint64_t>> chunks;
+  for (uint64_t i = 0; i < n_pairs;) {
+    uint64_t j = i;
+    uint32_t hubs = 0;
+    while (j < n_pairs && hubs < MAX_REFS) {
+      uint64_t g = j;   // the hub group [j, g)
+      while (g < n_pairs && hub[order[g]] == hub[order[j]]) ++g;
+      if (j > i && g - i > target) break;
+      j = g; ++hubs;
+    }
+    if (j - i > cap) j = i + cap;   // one hub with more pairs than a launch holds: cut it (pairs cut off from their reverse are seeded themselves)
+    std::stable_sort(order.begin() + i, order.begin() + j, [&](uint64_t x, uint64_t y) { return ref_ids[x] < ref_ids[y]; });
+    chunks.push_back({i, j});
+    i = j;
+  }
   return anim_run_chunks(ctx, chunks, [&](uint64_t i, uint64_t j, int) -> int {
     std::vector<int32_t> r, q;
     std::vector<pg_anim_result> res;

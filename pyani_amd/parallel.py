@@ -85,28 +85,52 @@ def anim_pair_shard(n_genomes: int, rank: int, world: int, rows: Optional[Sequen
     return [(q, s) for q in anim_row_shard(rows, rank, world) for s in range(n_genomes) if s != q]
 
 
-def anim_pair_array(n_genomes: int, rows: Sequence[int]):
-    """The ordered pairs (q, s), s != q, of the reference rows `rows` as an int64 [m, 2] numpy array (grouped by q)."""
+def anim_pair_array(n_genomes: int, rows: Sequence[int], symmetric: bool = False):
+    """The ordered pairs of the rows `rows` as an int64 [m, 2] numpy array of (reference, query).
+    symmetric = False: row q = reference q against every other genome (grouped by q).
+    symmetric = True: row g = the UNORDERED pairs {g, h} that g owns, each in both directions ((g, h) then, in a second
+    block, (h, g)).  {g, h} is owned by the smaller id when g + h is even, by the larger one otherwise, so every genome owns
+    about half of its pairs and the rows of all genomes together are exactly the N x N grid.  The engine seeds a pair and its
+    reverse once when both are in one call (they have the same maximal exact matches), which is what this layout is for."""
     import numpy as np
     rows = np.asarray(list(rows), dtype=np.int64)
     q = np.repeat(rows, n_genomes)
     s = np.tile(np.arange(n_genomes, dtype=np.int64), len(rows))
     keep = q != s
+    if symmetric:
+        keep &= (((q + s) % 2) == 0) == (q < s)
+        fwd = np.stack([q[keep], s[keep]], axis=1)
+        return np.concatenate([fwd, fwd[:, ::-1]])
     return np.stack([q[keep], s[keep]], axis=1)
 
 
 def anim_allgather(compute_pairs: Callable, n_genomes: int, device: torch.device, group=None,
-                   rows: Optional[Sequence[int]] = None) -> torch.Tensor:
+                   rows: Optional[Sequence[int]] = None, symmetric: bool = False) -> torch.Tensor:
     """compute_pairs(pairs: int64 ndarray [m, 2] of (q, s)) -> int64 tensor [m, ANIM_FIELDS] on `device` (identity as its
     IEEE-754 bit pattern).
-    rows = None: the whole grid -> [n, n, ANIM_FIELDS] on every rank (diagonal zero).  rows = a list of reference genomes
-    (one step of a tiled run): only those rows are computed -> [len(rows), n, ANIM_FIELDS], row i = reference rows[i].
+    rows = None: the whole grid -> [n, n, ANIM_FIELDS] on every rank (diagonal zero).  rows = a list of genomes (one step
+    of a tiled run): only those rows are computed -> [len(rows), n, ANIM_FIELDS], row i = reference rows[i]; with
+    symmetric = True a row is what anim_pair_array(symmetric=True) says and the result is [n, n, ANIM_FIELDS] with the
+    computed cells filled.  Rows are dealt over the ranks by anim_row_shard either way.
     One collective of 64 B per pair (results + the pair's own (q, s), so the gathered block is self-describing)."""
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     all_rows = list(range(n_genomes)) if rows is None else list(rows)
-    mine = anim_pair_array(n_genomes, anim_row_shard(all_rows, rank, world))
-    rows_max = (len(all_rows) + world - 1) // world
-    cap = rows_max * max(n_genomes - 1, 0)
+    shards = [anim_row_shard(all_rows, r, world) for r in range(world)]
+    mine = anim_pair_array(n_genomes, shards[rank], symmetric)
+    if symmetric:   # rows own different numbers of pairs: the padded length is the largest shard's
+        import numpy as np
+        own = np.zeros(n_genomes, dtype=np.int64)
+        g = np.arange(n_genomes, dtype=np.int64)
+        for parity in (0, 1):     # same parity as g: the larger ids; other parity: the smaller ids
+            ids = g[g % 2 == parity]
+            own[ids] += len(ids) - 1 - np.arange(len(ids))
+            other = g[g % 2 != parity]
+            own[ids] += np.searchsorted(other, ids)
+        cap = int(max(2 * own[np.asarray(sh, dtype=np.int64)].sum() if len(sh) else 0 for sh in shards))
+    else:
+        rows_max = (len(all_rows) + world - 1) // world
+        cap = rows_max * max(n_genomes - 1, 0)
+    assert len(mine) <= cap
     loc = torch.zeros((cap, ANIM_FIELDS + 2), dtype=torch.int64, device=device)
     if len(mine):
         vals = compute_pairs(mine)
@@ -115,11 +139,15 @@ def anim_allgather(compute_pairs: Callable, n_genomes: int, device: torch.device
     loc[len(mine):, ANIM_FIELDS] = -1
     allv = torch.zeros((world * cap, ANIM_FIELDS + 2), dtype=torch.int64, device=device)
     dist.all_gather_into_tensor(allv, loc, group=group)
+    valid = allv[:, ANIM_FIELDS] >= 0
+    q, s = allv[valid, ANIM_FIELDS], allv[valid, ANIM_FIELDS + 1]
+    if symmetric:
+        grid = torch.zeros((n_genomes, n_genomes, ANIM_FIELDS), dtype=torch.int64, device=device)
+        grid[q, s] = allv[valid, :ANIM_FIELDS]
+        return grid
     row_slot = torch.full((n_genomes,), -1, dtype=torch.int64, device=device)
     row_slot[torch.tensor(all_rows, dtype=torch.int64, device=device)] = torch.arange(len(all_rows), dtype=torch.int64, device=device)
     grid = torch.zeros((len(all_rows), n_genomes, ANIM_FIELDS), dtype=torch.int64, device=device)
-    valid = allv[:, ANIM_FIELDS] >= 0
-    q, s = allv[valid, ANIM_FIELDS], allv[valid, ANIM_FIELDS + 1]
     grid[row_slot[q], s] = allv[valid, :ANIM_FIELDS]
     return grid
 

@@ -249,6 +249,38 @@ def test_lane_to_wave_hand_over_does_not_change_results(eng, monkeypatch):
         assert eng.anim_pairs(ra, qa).tobytes() == ref.tobytes(), (lanes, blocks, cap)
 
 
+def test_cluster_stage_forms_do_not_change_results(eng, monkeypatch):
+    """The cluster stage finishes small units in one wave and cuts the chain extraction of big units (>= PYANI_ANIM_SPLIT_MIN
+    matches, default 2048) into ranges of whole clusters, one wave each, merged in order (pga_cluster.inc:
+    anim_chain_range_kernel / anim_chain_merge_kernel); the front half of big units runs in one wave or in a 16-wave
+    workgroup.  None of that may show: never split, split everything into single ranges, into many short ranges, with either
+    front half, --mum and --maxmatch, on genomes with repeats (clusters of hundreds of matches) — same records."""
+    from pyani_amd import synth
+    eng.clear_genomes()
+    n, L = 4, 300_000
+    ids = [eng.add_genome(*_with_repeats(*synth.genome(31, n, g, L), g)) for g in range(n)]
+    ids += [eng.add_genome(*synth.genome(11, 3, g, 400_000)) for g in range(3)]
+    eng.upload()
+    pairs = [(a, b) for a in ids[:n] for b in ids[:n] if a != b] + [(a, b) for a in ids[n:] for b in ids[n:] if a != b]
+    ra, qa = [a for a, _ in pairs], [b for _, b in pairs]
+    for var in ("PYANI_ANIM_SPLIT_MIN", "PYANI_ANIM_RANGE_ENTRIES", "PYANI_ANIM_SPLIT_CLUSTER", "PYANI_ANIM_WAVE_PREP"):
+        monkeypatch.delenv(var, raising=False)
+    for mm in (False, True):
+        monkeypatch.setenv("PYANI_ANIM_SPLIT_MIN", "0")          # every unit start to end in its one wave
+        ref = eng.anim_pairs(ra, qa, maxmatch=mm)
+        assert (ref["status"] == 0).sum() == len(pairs) and int(ref["n_alignments"].max()) > 20
+        monkeypatch.delenv("PYANI_ANIM_SPLIT_MIN")
+        assert eng.anim_pairs(ra, qa, maxmatch=mm).tobytes() == ref.tobytes(), ("default", mm)
+        for split_min, entries, front in (("1", "1000000", "PYANI_ANIM_WAVE_PREP"), ("1", "16", "PYANI_ANIM_WAVE_PREP"),
+                                          ("1", "200", "PYANI_ANIM_SPLIT_CLUSTER"), ("500", "64", "PYANI_ANIM_SPLIT_CLUSTER")):
+            monkeypatch.setenv("PYANI_ANIM_SPLIT_MIN", split_min)
+            monkeypatch.setenv("PYANI_ANIM_RANGE_ENTRIES", entries)
+            monkeypatch.setenv(front, "1")
+            assert eng.anim_pairs(ra, qa, maxmatch=mm).tobytes() == ref.tobytes(), (split_min, entries, front, mm)
+            for var in ("PYANI_ANIM_SPLIT_MIN", "PYANI_ANIM_RANGE_ENTRIES", front):
+                monkeypatch.delenv(var)
+
+
 def _resplit(seq, step, salt):
     """Same cutting rule as tools/make_anim_synth_host.py (contig-shaped records, some too short to seed)."""
     cuts, p, k = [0], 0, 0
@@ -259,6 +291,42 @@ def _resplit(seq, step, salt):
         cuts.append(p)
         k += 1
     return np.array(sorted(set(cuts)), dtype=np.uint64)
+
+
+def test_shared_seeding_of_a_pair_and_its_reverse_does_not_change_results(eng, monkeypatch):
+    """(A, B) and (B, A) have the same maximal exact matches, so a launch that holds both seeds one of them and hands the
+    matches, transposed, to the other (pg_anim.hip "roles", pga_seed.inc anim_hit_kernel).  With repeats, reverse-complemented
+    copies, many unequal records and ambiguity symbols in the genomes: the call with both directions == every pair seeded by
+    itself (PYANI_ANIM_NO_MIRROR) == the directions computed in separate calls; pairs listed twice and self pairs included."""
+    from pyani_amd import synth
+    eng.clear_genomes()
+    data = [_with_repeats(*synth.genome(31, 4, g, 300_000), g) for g in range(4)]
+    for g in range(3):
+        seq, _ = synth.genome(17, 3, g, 400_000)
+        seq = seq.copy()
+        seq[1000 * (g + 1): 1000 * (g + 1) + 7] = ord("N")        # ambiguity symbols: dirty positions inside would-be matches
+        seq[200_000 + 13 * g] = ord("n")
+        data.append((seq, _resplit(seq, 3000, g)))
+    ids = [eng.add_genome(*d) for d in data]
+    eng.upload()
+    grid = [(a, b) for a in ids for b in ids if a != b]
+    for mm in (False, True):
+        monkeypatch.setenv("PYANI_ANIM_NO_MIRROR", "1")
+        want = eng.anim_pairs([a for a, _ in grid], [b for _, b in grid], maxmatch=mm)
+        monkeypatch.delenv("PYANI_ANIM_NO_MIRROR")
+        assert (want["status"] == 0).sum() >= 18
+        got = eng.anim_pairs([a for a, _ in grid], [b for _, b in grid], maxmatch=mm)
+        assert got.tobytes() == want.tobytes(), mm
+        upper = [k for k, (a, b) in enumerate(grid) if a < b]     # one direction only: nothing to share
+        one = eng.anim_pairs([grid[k][0] for k in upper], [grid[k][1] for k in upper], maxmatch=mm)
+        assert one.tobytes() == want[upper].tobytes(), mm
+        odd = [grid[0], grid[0], grid[0][::-1], (ids[0], ids[0]), grid[5][::-1], grid[5], grid[0][::-1]]
+        res = eng.anim_pairs([a for a, _ in odd], [b for _, b in odd], maxmatch=mm)
+        index = {p: k for k, p in enumerate(grid)}
+        for p, r in zip(odd, res):
+            if p[0] != p[1]:
+                assert r.tobytes() == want[index[p]].tobytes(), (p, mm)
+        assert res[3].tobytes() == eng.anim_pairs([ids[0]], [ids[0]], maxmatch=mm)[0].tobytes()    # a genome against itself
 
 
 def test_many_records_equal_scalar_host_statement(eng):

@@ -82,6 +82,10 @@ def _anim_worker(rank, world, port, n, out_dir):
 
         grid = parallel.anim_allgather(fake_engine, n, torch.device("cpu")).numpy()
         np.save(os.path.join(out_dir, f"anim{rank}.npy"), grid)
+        # symmetric layout (bench.py's steps): the unordered pairs owned by some genomes, both directions
+        rows = [g for g in range(n) if g != 1]
+        grid = parallel.anim_allgather(fake_engine, n, torch.device("cpu"), rows=rows, symmetric=True).numpy()
+        np.save(os.path.join(out_dir, f"anim_sym{rank}.npy"), grid)
     finally:
         dist.destroy_process_group()
 
@@ -103,3 +107,19 @@ def test_anim_pair_grid_allgather(tmp_path, n):
     # shards partition the ordered-pair grid
     shards = [set(parallel.anim_pair_shard(n, r, 2)) for r in range(2)]
     assert not (shards[0] & shards[1]) and len(shards[0] | shards[1]) == n * (n - 1)
+    # symmetric rows: every unordered pair has one owner; a pair and its reverse are in the same row; the step without
+    # genome 1's row leaves exactly the pairs genome 1 owns empty
+    whole = parallel.anim_pair_array(n, range(n), symmetric=True)
+    assert len(whole) == n * (n - 1) == len(set(map(tuple, whole.tolist())))
+    for g in range(n):
+        row = set(map(tuple, parallel.anim_pair_array(n, [g], symmetric=True).tolist()))
+        assert all((s, q) in row and g in (q, s) for q, s in row)
+    a, b = np.load(tmp_path / "anim_sym0.npy"), np.load(tmp_path / "anim_sym1.npy")
+    assert (a == b).all() and a.shape == (n, n, parallel.ANIM_FIELDS)
+    own1 = set(map(tuple, parallel.anim_pair_array(n, [1], symmetric=True).tolist()))
+    for q in range(n):
+        for s in range(n):
+            if q == s or (q, s) in own1:
+                assert not a[q, s].any()
+            else:
+                assert a[q, s, 0] == 1000 * q + s and a[q, s, 3] == 7
