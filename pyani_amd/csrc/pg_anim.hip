@@ -38,7 +38,6 @@ namespace {
 
 constexpr unsigned long long SLOT_EMPTY = ~0ull;
 constexpr int FRAG_SEED_MIN = 16;   // fragment mode keeps every sampled 16-mer hit (SEED_K)
-constexpr int MAX_HITS = 4096;  // copies of one seed k-mer examined per lookup (a bound for pathological repeats only)
 
 struct RefDesc {
   const uint32_t* codes;
@@ -584,10 +583,10 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
     hipLaunchKernelGGL(anim_cluster_kernel, dim3((n_units + 63) / 64), dim3(64), 0, cur_stream(ctx), A->refs_d, A->units_d, n_units,
                        A->mem, A->mem_count, A->iscratch, O);
   else {
-    // few big units: PREP_WAVES waves share the sorts / union-find of each, so that the largest unit is not the launch time;
-    // thousands of them: one wave per unit already fills the machine, and the radix scatters are bound by HBM's partial-line
-    // write rate, which more waves per unit only congest (measured: C3 574 ms vs 724 ms split)
-    const bool prep = !big.empty() && ((big.size() <= 3000 && !getenv("PYANI_ANIM_WAVE_PREP")) || getenv("PYANI_ANIM_SPLIT_CLUSTER"));
+    // the front half (MUM filter, union-find, grouping) of a big unit is shared by the PREP_WAVES waves of one workgroup: a
+    // single wave needs ~10 ms for the sorts of 50 000 matches, and the launch would wait for the slowest of them (measured
+    // on C4, cluster stage per grid: one wave per big unit 1.95 s, workgroup 0.51 s; PYANI_ANIM_WAVE_PREP=1 forces the former)
+    const bool prep = !big.empty() && !getenv("PYANI_ANIM_WAVE_PREP");
     if (prep)
       hipLaunchKernelGGL(anim_cluster_prep_kernel, dim3((uint32_t)big.size()), dim3(PREP_THREADS), 0, cur_stream(ctx), A->refs_d, A->units_d,
                          A->mem, A->mem_count, A->iscratch, O, maxmatch, A->big_d);

@@ -263,7 +263,7 @@ def test_cluster_stage_forms_do_not_change_results(eng, monkeypatch):
     eng.upload()
     pairs = [(a, b) for a in ids[:n] for b in ids[:n] if a != b] + [(a, b) for a in ids[n:] for b in ids[n:] if a != b]
     ra, qa = [a for a, _ in pairs], [b for _, b in pairs]
-    for var in ("PYANI_ANIM_SPLIT_MIN", "PYANI_ANIM_RANGE_ENTRIES", "PYANI_ANIM_SPLIT_CLUSTER", "PYANI_ANIM_WAVE_PREP"):
+    for var in ("PYANI_ANIM_SPLIT_MIN", "PYANI_ANIM_RANGE_ENTRIES", "PYANI_ANIM_WAVE_PREP"):
         monkeypatch.delenv(var, raising=False)
     for mm in (False, True):
         monkeypatch.setenv("PYANI_ANIM_SPLIT_MIN", "0")          # every unit start to end in its one wave
@@ -271,14 +271,14 @@ def test_cluster_stage_forms_do_not_change_results(eng, monkeypatch):
         assert (ref["status"] == 0).sum() == len(pairs) and int(ref["n_alignments"].max()) > 20
         monkeypatch.delenv("PYANI_ANIM_SPLIT_MIN")
         assert eng.anim_pairs(ra, qa, maxmatch=mm).tobytes() == ref.tobytes(), ("default", mm)
-        for split_min, entries, front in (("1", "1000000", "PYANI_ANIM_WAVE_PREP"), ("1", "16", "PYANI_ANIM_WAVE_PREP"),
-                                          ("1", "200", "PYANI_ANIM_SPLIT_CLUSTER"), ("500", "64", "PYANI_ANIM_SPLIT_CLUSTER")):
+        for split_min, entries, one_wave_front in (("1", "1000000", True), ("1", "16", True), ("1", "200", False), ("500", "64", False)):
             monkeypatch.setenv("PYANI_ANIM_SPLIT_MIN", split_min)
             monkeypatch.setenv("PYANI_ANIM_RANGE_ENTRIES", entries)
-            monkeypatch.setenv(front, "1")
-            assert eng.anim_pairs(ra, qa, maxmatch=mm).tobytes() == ref.tobytes(), (split_min, entries, front, mm)
-            for var in ("PYANI_ANIM_SPLIT_MIN", "PYANI_ANIM_RANGE_ENTRIES", front):
-                monkeypatch.delenv(var)
+            if one_wave_front:
+                monkeypatch.setenv("PYANI_ANIM_WAVE_PREP", "1")
+            assert eng.anim_pairs(ra, qa, maxmatch=mm).tobytes() == ref.tobytes(), (split_min, entries, one_wave_front, mm)
+            for var in ("PYANI_ANIM_SPLIT_MIN", "PYANI_ANIM_RANGE_ENTRIES", "PYANI_ANIM_WAVE_PREP"):
+                monkeypatch.delenv(var, raising=False)
 
 
 def _resplit(seq, step, salt):
