@@ -10,14 +10,14 @@ C2 TETRA roofline nested as a sub-record.
 
 ANIm (default).  All genomes are resident in HBM on every GPU (2-bit codes + 1-bit mask; 1.9 GB at C4).  A STEP is one
 pass of the whole pipeline — seed, cluster, extend, 1-to-1 filter, parse_delta reduction, results back on the host — over
-one tile of the ordered-pair grid: the UNORDERED pairs owned by `--rows-per-step` genomes (default 500), each in both
-directions (pyani_amd.parallel.anim_pair_array(symmetric=True): {g, h} belongs to the smaller id if g + h is even, else to
-the larger) = ~499 500 ordered pairs; step k takes genomes [k*R, (k+1)*R) modulo N, so 2 steps are exactly one pass over the
-N x N grid.  A pair and its reverse sit in the same call because they have the same maximal exact matches and the engine
-seeds them once (pg_anim.hip "roles"); large steps keep every rank's launches full-size when the rows are dealt over 8 GPUs.
-`value` = ordered pairs processed in the K timed steps / wall time.  N > 1 is STRONG scaling of that same job: the rows of
-every step are dealt over the ranks (pyani_amd.parallel.anim_row_shard), each rank runs the pairs its rows own, ONE RCCL
-all-gather per step (64 B per pair) puts the step's results on every rank.  No other collective, no sequence traffic.
+the ordered-pair grid: by default ALL of it, 999 000 ordered pairs per step (`--rows-per-step R` cuts it into tiles: the
+UNORDERED pairs owned by R genomes, each in both directions — pyani_amd.parallel.anim_pair_array(symmetric=True): {g, h}
+belongs to the smaller id if g + h is even, else to the larger; step k then takes genomes [k*R, (k+1)*R) modulo N).  A pair
+and its reverse sit in the same call because they have the same maximal exact matches and the engine seeds them once
+(pg_anim.hip "roles").  `value` = ordered pairs processed in the K timed steps / wall time.  N > 1 is STRONG scaling of that
+same job: the rows of every step are dealt over the ranks (pyani_amd.parallel.anim_row_shard), each rank runs the pairs its
+rows own (whole-grid steps keep every rank's launches full-size at 8 GPUs), ONE RCCL all-gather per step (64 B per pair) puts
+the step's results on every rank.  No other collective, no sequence traffic.
 
   --workload tetra : the TETRA side alone (C2: 200 genomes, counts + Z + Pearson; N > 1 = weak scaling, 200 genomes per GPU).
   --workload anib  : C5 (BASELINE.json configs[4]): 500 genomes of 1-12 Mb, pyani's ANIb on the engine's fragment mode
@@ -51,12 +51,12 @@ def parse_args():
     ap.add_argument("--workload", choices=["anim", "tetra", "anib"], default="anim",
                     help="anim = C4 (default: the N x N ANIm grid the metric is quoted on); tetra = C2 alone; "
                          "anib = C5 (mixed-length set, 1020-nt fragment mode)")
-    ap.add_argument("--steps", type=int, default=None, help="default 4 (anim: two passes over the grid) / 50 (tetra) / 3 (anib)")
+    ap.add_argument("--steps", type=int, default=None, help="default 2 (anim: two passes over the grid) / 50 (tetra) / 3 (anib)")
     ap.add_argument("--warmup", type=int, default=None, help="default 1 (anim, anib) / 5 (tetra)")
     ap.add_argument("--genomes", type=int, default=None, help="anim: genomes of the job (C4: 1000); tetra: genomes per GPU (C2: 200)")
     ap.add_argument("--length", type=int, default=5_000_000, help="ancestor length in bases (5 Mb)")
     ap.add_argument("--seed", type=int, default=None, help="default: the set's own seed (C4 20250301, C2 20250228)")
-    ap.add_argument("--rows-per-step", type=int, default=None, help="reference genomes (grid rows) per step: default 500 (anim) / 10 (anib)")
+    ap.add_argument("--rows-per-step", type=int, default=None, help="genomes (grid rows) per step: default all (anim: a step = the whole grid) / 10 (anib)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=0, help="anim: ordered pairs timed by the CPU leg (0 = one per host thread, <= 128)")
     ap.add_argument("--cpu-genomes", type=int, default=2, help="tetra: genomes timed by the CPU leg")
@@ -64,7 +64,7 @@ def parse_args():
     args = ap.parse_args()
     w = args.workload
     if args.steps is None:
-        args.steps = {"anim": 4, "tetra": 50, "anib": 3}[w]
+        args.steps = {"anim": 2, "tetra": 50, "anib": 3}[w]
     if args.warmup is None:
         args.warmup = {"anim": 1, "tetra": 5, "anib": 1}[w]
     if args.genomes is None:
@@ -72,7 +72,7 @@ def parse_args():
     if args.seed is None:
         args.seed = {"anim": 20250301, "tetra": 20250228, "anib": 20250302}[w]
     if args.rows_per_step is None:
-        args.rows_per_step = 10 if w == "anib" else 500
+        args.rows_per_step = 10 if w == "anib" else args.genomes
     return args
 
 
@@ -249,9 +249,13 @@ def run_anim(args, rank, world, local, dist, torch):
 
     tiles = {}
 
+    pair_cache = {}
+
     def step(k, keep=False):
         rows = rows_of(k)
-        pairs = parallel.anim_pair_array(n, rows, symmetric=True)   # the rows' unordered pairs, both directions
+        if rows[0] not in pair_cache:   # (the job description, not part of the job: built once per tile)
+            pair_cache[rows[0]] = parallel.anim_pair_array(n, rows, symmetric=True)   # the rows' unordered pairs, both directions
+        pairs = pair_cache[rows[0]]
         if world > 1:
             grid = parallel.anim_allgather(compute, n, dev, rows=rows, symmetric=True)
             vals = grid[torch.from_numpy(pairs[:, 0]).to(dev), torch.from_numpy(pairs[:, 1]).to(dev)]
@@ -324,9 +328,10 @@ def run_anim(args, rank, world, local, dist, torch):
             "config": {
                 "workload": f"C4: ANIm N x N grid on {n} synthetic ~{args.length / 1e6:g} Mb genomes (SURVEY.md §8(d) generator, seed "
                             f"{args.seed}; {n * (n - 1)} ordered pairs, {n * (n // K - 1)} of them between descendants of one ancestor); "
-                            f"a step = the unordered pairs owned by {R} genomes, in both directions (pyani_amd.parallel."
-                            f"anim_pair_array(symmetric=True): ~{R * (n - 1)} ordered pairs), "
-                            f"{n // R if n % R == 0 else n / R:g} steps = the whole grid",
+                            + (f"a step = the whole grid" if R == n else
+                               f"a step = the unordered pairs owned by {R} genomes, in both directions (pyani_amd.parallel."
+                               f"anim_pair_array(symmetric=True): ~{R * (n - 1)} ordered pairs), "
+                               f"{n // R if n % R == 0 else n / R:g} steps = the whole grid"),
                 "genomes": n, "rows_per_step": R, "pairs_per_step": pairs_done / args.steps, "pairs_timed": pairs_done,
                 "related_pairs_timed": n_related, "related_pairs_with_alignment": ok_rel, "unrelated_pairs_with_alignment": unrel_aln,
                 "grid_pairs": n * (n - 1), "wall_s_grid": elapsed / pairs_done * n * (n - 1),

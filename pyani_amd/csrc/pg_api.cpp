@@ -756,8 +756,18 @@ int pg_anim_pairs(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_ids, u
     for (uint64_t i = 0; i < n_pairs; ++i) { order[i] = i; ++deg[ref_ids[i]]; hub[i] = ref_ids[i]; }
     auto lo = [&](uint64_t i) { return std::min(ref_ids[i], qry_ids[i]); };
     auto hi = [&](uint64_t i) { return std::max(ref_ids[i], qry_ids[i]); };
-    std::sort(order.begin(), order.end(), [&](uint64_t x, uint64_t y) {
-      return lo(x) != lo(y) ? lo(x) < lo(y) : (hi(x) != hi(y) ? hi(x) < hi(y) : x < y); });
+    // stable counting sorts over the genome ids (a call has up to 10^6 pairs: comparison sorts cost a quarter of a second here)
+    std::vector<uint64_t> tmp(n_pairs);
+    std::vector<uint64_t> start(ctx->genomes.size() + 1);
+    auto sort_by = [&](auto key) {
+      std::fill(start.begin(), start.end(), 0);
+      for (uint64_t i = 0; i < n_pairs; ++i) ++start[(size_t)key(order[i]) + 1];
+      for (size_t g = 0; g + 1 < start.size(); ++g) start[g + 1] += start[g];
+      for (uint64_t i = 0; i < n_pairs; ++i) tmp[start[(size_t)key(order[i])]++] = order[i];
+      order.swap(tmp);
+    };
+    sort_by(hi);
+    sort_by(lo);   // by (lo, hi), the call's order inside
     for (uint64_t i = 0; i < n_pairs;) {
       uint64_t j = i;
       bool fwd = false, rev = false;
@@ -772,8 +782,9 @@ int pg_anim_pairs(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_ids, u
       }
       i = j;
     }
-    std::sort(order.begin(), order.end(), [&](uint64_t x, uint64_t y) {
-      return hub[x] != hub[y] ? hub[x] < hub[y] : (ref_ids[x] != ref_ids[y] ? ref_ids[x] < ref_ids[y] : x < y); });
+    for (uint64_t i = 0; i < n_pairs; ++i) order[i] = i;   // back to the call's order, then by (hub, reference)
+    sort_by([&](uint64_t i) { return ref_ids[i]; });
+    sort_by([&](uint64_t i) { return hub[i]; });
   }
   // launches: as many pairs as the scratch budget allows, at most MAX_REFS hubs; with W workers the launches are 1/W as
   // large and each worker gets 1/W of the match budget, so the memory in use is the same
@@ -795,7 +806,12 @@ int pg_anim_pairs(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_ids, u
       j = g; ++hubs;
     }
     if (j - i > cap) j = i + cap;   // one hub with more pairs than a launch holds: cut it (pairs cut off from their reverse are seeded themselves)
-    std::stable_sort(order.begin() + i, order.begin() + j, [&](uint64_t x, uint64_t y) { return ref_ids[x] < ref_ids[y]; });
+    {   // the launch's pairs grouped by reference (stable counting sort of the range)
+      std::vector<uint64_t> cnt(ctx->genomes.size() + 1, 0), part(order.begin() + i, order.begin() + j);
+      for (uint64_t x : part) ++cnt[(size_t)ref_ids[x] + 1];
+      for (size_t g = 0; g + 1 < cnt.size(); ++g) cnt[g + 1] += cnt[g];
+      for (uint64_t x : part) order[i + cnt[(size_t)ref_ids[x]]++] = x;
+    }
     chunks.push_back({i, j});
     i = j;
   }

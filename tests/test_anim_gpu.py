@@ -153,6 +153,24 @@ def test_gpu_pipeline_equals_scalar_host_statement_on_synthetic_pairs(eng):
         assert not bad, f"{mode}: {len(bad)} of {len(pairs)} pairs differ, first: {bad[0]}"
 
 
+def _delta_data(path):
+    """What pyani.nucmer.DeltaData equality looks at (nucmer.py:47-351): (program, [(header 4-tuple, sorted coordinate
+    4-tuples)] in file order)."""
+    import gzip
+    opener = gzip.open if str(path).endswith(".gz") else open
+    with opener(path, "rt") as fh:
+        fh.readline()
+        program = fh.readline().strip()
+        comparisons = []
+        for line in fh:
+            t = line.split()
+            if line.startswith(">"):
+                comparisons.append(((t[0][1:], t[1], int(t[2]), int(t[3])), []))
+            elif len(t) > 1:
+                comparisons[-1][1].append(tuple(int(x) for x in t[:4]))
+    return program, [(h, sorted(a)) for h, a in comparisons]
+
+
 def test_alignment_records_equal_mummer_delta_and_filter_files(eng, genome_dir, gold, tmp_path):
     """Alignment level, on the GPU, through pg_anim_pair_alignments: for every fixture pair with both genomes the
     engine's records ARE the records of nucmer's .delta file (coordinates and error counts, 505 in all) and the ones
@@ -185,6 +203,10 @@ def test_alignment_records_equal_mummer_delta_and_filter_files(eng, genome_dir, 
             out = tmp_path / f"{a}_vs_{b}.filter"
             assert anim.write_delta(out, paths[a], paths[b], al, filtered=True) == len(want_f)
             assert list(anim_oracle.parse_delta(out)) == gold[f"{grp}/{a}_vs_{b}.filter"]
+            # the reference's own file comparison (tests/tools.py:79-97 assertNucmerEqual = nucmer.DeltaData.__eq__,
+            # nucmer.py:114-122, 154-160, 277-282): program line, per-comparison headers with the sequence lengths, and the
+            # sorted alignment coordinates — our file against MUMmer's
+            assert _delta_data(out) == _delta_data(str(f).replace(".delta.gz", ".filter.gz")), f.name
             n_records += len(want)
             n_pairs += 1
     assert (n_pairs, n_records) == (17, 505)

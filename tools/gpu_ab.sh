@@ -1,7 +1,7 @@
 #!/bin/bash
 # A/B runs of the C4 bench under environment variants: tools/gpu_ab.sh OUTDIR "VAR=1 VAR2=x" "..." ...
 R=$(pwd); O=$R/gpurun_out/$1; shift; mkdir -p $O; export TMPDIR=/tmp
-B="python bench.py --gpus 1 --steps ${AB_STEPS:-4} --warmup 1 --no-cpu-baseline --no-tetra"
+B="python bench.py --gpus 1 --steps ${AB_STEPS:-2} --warmup 1 --no-cpu-baseline --no-tetra"
 for v in "$@"; do
   tag=$(echo "$v" | tr ' =' '__')
   if [ "$v" = default ]; then timeout 600 $B > $O/$tag.json 2> $O/$tag.err; else timeout 600 env $v $B > $O/$tag.json 2> $O/$tag.err; fi
