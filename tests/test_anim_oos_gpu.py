@@ -42,8 +42,10 @@ def oos(genome_dir, tmp_path_factory):
     joined.write_text(">gi|16124256|ref|NC_002696.2| joined\n" + "\n".join(body[i:i + 70] for i in range(0, len(body), 70)) + "\n")
     report = {}
     with Engine(0) as eng:
-        ids = {s: eng.add_fasta(p)[0] for s, p in paths.items()}
-        ids["NC_002696@joined"] = eng.add_fasta(joined)[0]
+        added = {s: eng.add_fasta(p) for s, p in paths.items()}
+        added["NC_002696@joined"] = eng.add_fasta(joined)
+        ids = {s: v[0] for s, v in added.items()}
+        glen = {s: int(v[1]) for s, v in added.items()}          # genome length = sum of the record lengths (pyani_files.py:128-142)
         recs = {s: anim.fasta_records(p) for s, p in paths.items()}
         recs["NC_002696@joined"] = anim.fasta_records(joined)
         for grp in ("caulobacter", "group2", "jspecies"):
@@ -66,7 +68,9 @@ def oos(genome_dir, tmp_path_factory):
                 for name, m, rs in cmp:
                     o = anim_oracle.parse_delta_records(rs)
                     rep[name] = {"mummer": m, "ours": list(o), "identity_abs_diff": abs(m[2] - o[2]),
-                                 "ref_aln_len_rel_diff": abs(m[0] - o[0]) / m[0], "qry_aln_len_rel_diff": abs(m[1] - o[1]) / m[1]}
+                                 "ref_aln_len_rel_diff": abs(m[0] - o[0]) / m[0], "qry_aln_len_rel_diff": abs(m[1] - o[1]) / m[1],
+                                 # coverage as pyani reports it: aligned length / genome length (anim.py:470-480)
+                                 "ref_coverage_abs_diff": abs(m[0] - o[0]) / glen[ka], "qry_coverage_abs_diff": abs(m[1] - o[1]) / glen[kb]}
                 report[f"{grp}/{a}_vs_{b}"] = rep
     out = ROOT / "gpurun_out"
     out.mkdir(exist_ok=True)
@@ -102,8 +106,21 @@ def test_oos_identity_and_coverage_level_reached(oos):
     assert _worst(oos, "ref_aln_len_rel_diff") < 2e-4 and _worst(oos, "qry_aln_len_rel_diff") < 6e-4
 
 
+def test_oos_what_pyani_reports_is_within_the_baseline_bar(oos):
+    """BASELINE.json's bar — identity and coverage within 1e-4 of the reference's — on what pyani computes by default: the
+    tuple of the delta-filter -1 output (identity = 1 - errors / aligned bases, coverage = aligned length / genome length),
+    for all 12 out-of-sample pairs that have a .filter file.  Host build of the same core: identity <= 7.1e-5, coverage
+    <= 7.3e-5.  (The --nofilter path, i.e. the raw .delta tuples, is at 1.4e-4 on one pair: the xfail below.)"""
+    flt = {k: r["filter"] for k, r in oos.items() if "filter" in r}
+    assert len(flt) == 12
+    for name, r in flt.items():
+        assert r["identity_abs_diff"] < 1e-4 and r["ref_coverage_abs_diff"] < 1e-4 and r["qry_coverage_abs_diff"] < 1e-4, (name, r)
+
+
 @pytest.mark.xfail(strict=False, reason="BASELINE.json's bar (identity / coverage within 1e-4) is met for the filtered identity "
-                                        "(7e-5) but not yet for every aligned length (1.7e-4 filtered, 4.9e-4 unfiltered)")
+                                        "(7e-5) and the filtered coverage (7.3e-5: the test above) but not for every aligned length taken "
+                                        "RELATIVE to itself (1.7e-4 filtered, 4.9e-4 unfiltered) nor for the unfiltered coverage (1.4e-4)")
 def test_oos_identity_and_coverage_within_baseline_bar(oos):
     assert _worst(oos, "identity_abs_diff") < 1e-4
+    assert _worst(oos, "ref_coverage_abs_diff") < 1e-4 and _worst(oos, "qry_coverage_abs_diff") < 1e-4
     assert _worst(oos, "ref_aln_len_rel_diff") < 1e-4 and _worst(oos, "qry_aln_len_rel_diff") < 1e-4
