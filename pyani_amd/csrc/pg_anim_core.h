@@ -26,7 +26,19 @@ constexpr int MIN_CLUSTER = 65;      // nucmer -c  (mgaps -l)
 constexpr int MAX_GAP = 90;          // nucmer -g  (mgaps -s)
 constexpr int DIAG_DIFF = 5;         // nucmer -D  (mgaps -d)
 constexpr double DIAG_FACTOR = 0.12; // nucmer -d  (mgaps -f)
+#ifdef PGA_BREAK_LEN
+constexpr int BREAK_LEN = PGA_BREAK_LEN;
+#else
 constexpr int BREAK_LEN = 200;       // nucmer -b  (anti-diagonals without a new high score)
+#endif
+// A target search reaches its target only if the target's anti-diagonal lies fewer than BREAK_LEN - TARGET_SLACK steps past the
+// best cell: out of sample (round 2) MUMmer left every junction unfused whose target sat exactly 199 steps past the best cell
+// and fused the ones at 198 (host sweep over all 25 192 fixture records: slack 0 / 1 / 2 -> 25 006 / 25 022 / 25 014 exact).
+#ifdef PGA_TARGET_SLACK
+constexpr int TARGET_SLACK = PGA_TARGET_SLACK;
+#else
+constexpr int TARGET_SLACK = 1;
+#endif
 constexpr int SC_MATCH = 3, SC_MISMATCH = -7, SC_GAP_OPEN = -10, SC_GAP_EXT = -7;
 constexpr int BAND = 64;             // DP band: diagonal offsets -32 .. +31 around the start diagonal
 
@@ -71,7 +83,7 @@ struct Aln {     // alignment in ref / query-strand coordinates, half-open
 // Free search: the end is the best cell (ties: larger d, then larger k).  Every CHECK_EVERY anti-diagonals the search
 // stops once the best cell lies BREAK_LEN anti-diagonals back (nucmer -b; fitted: ">= 200", a tie at step 201 is too late) or no cell is alive.
 // Target search (tr >= 0): runs to d = tr + tq and reports whether the target cell was reached by a live path,
-// subject to the same break rule on the way.
+// subject to the same break rule on the way (and to TARGET_SLACK at the target itself).
 struct ExtResult {
   int32_t di, dj;      // bases consumed on ref / query at the chosen end
   int32_t score, errors;
@@ -166,7 +178,7 @@ PG_HD ExtResult extend_banded(const RefT& R, const QryT& Q, int64_t r0, int64_t 
     }
     if (targeted && d == d_end) {
       const int l = (tq - tr) - koff + W;
-      if (cur[l].h > NEG_INF / 2) { res.di = tr; res.dj = tq; res.score = cur[l].h; res.errors = cur[l].he; res.reached = 1; return res; }
+      if (cur[l].h > NEG_INF / 2 && d - gbest_d < BREAK_LEN - TARGET_SLACK) { res.di = tr; res.dj = tq; res.score = cur[l].h; res.errors = cur[l].he; res.reached = 1; return res; }
     }
   }
   // best cell: max score, ties -> larger d, then larger k
@@ -540,6 +552,9 @@ PG_HD void bridge_junction(ChainBwd& e, int32_t prev_re, int32_t prev_qe, int32_
   int32_t shift = tq - tr;
   if (shift < 0) shift = -shift;
   if (shift < BAND - 2) return;                            // reachable shifts are decided by the (shifted-band) target search
+#ifdef PGA_BRIDGE_SHIFT_MAX
+  if (shift > PGA_BRIDGE_SHIFT_MAX) return;
+#endif
   const int32_t n = e.rs - prev_re, m = e.qs - prev_qe;
   if (n < 0 || m < 0 || n + m > BREAK_LEN) return;
   const RectResult resid = rect(prev_re, n, prev_qe, m);

@@ -87,7 +87,7 @@ def _worst(report, field):
 def test_oos_record_level_agreement(oos):
     """Every pair: at least 97.5 % of MUMmer's alignment records reproduced coordinate for coordinate with the same error count
     (first unfitted score: 95.5 % over all, 91.7 % on the worst pair; with the X-drop rule for junction bridges, the one rule
-    changed after looking at these files: 99.3 % over all — DESIGN.md §8), the 99.99 % pairs exactly; Group_2 (draft genomes,
+    changed after looking at these files: 99.25 % over all, 99.32 % with the target rule found in the rest — DESIGN.md §8), the 99.99 % pairs exactly; Group_2 (draft genomes,
     never used for any fitting): 27 / 31 and 30 / 32 records."""
     assert len(oos) == 26
     for name, r in oos.items():
@@ -119,7 +119,7 @@ def test_oos_what_pyani_reports_is_within_the_baseline_bar(oos):
 
 @pytest.mark.xfail(strict=False, reason="BASELINE.json's bar (identity / coverage within 1e-4) is met for the filtered identity "
                                         "(7e-5) and the filtered coverage (7.3e-5: the test above) but not for every aligned length taken "
-                                        "RELATIVE to itself (1.7e-4 filtered, 4.9e-4 unfiltered) nor for the unfiltered coverage (1.4e-4)")
+                                        "RELATIVE to itself (1.3e-4 filtered, 4.9e-4 unfiltered) nor for the unfiltered coverage (1.4e-4)")
 def test_oos_identity_and_coverage_within_baseline_bar(oos):
     assert _worst(oos, "identity_abs_diff") < 1e-4
     assert _worst(oos, "ref_coverage_abs_diff") < 1e-4 and _worst(oos, "qry_coverage_abs_diff") < 1e-4

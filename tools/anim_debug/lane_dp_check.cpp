@@ -162,7 +162,7 @@ static ExtResult lane_extend(const SeqView& R, const SeqView& QS, int strand, in
     memcpy(X, nX, sizeof(X)); memcpy(Y, nY, sizeof(Y));
     if (d - (int32_t)(best & 32767u) >= BREAK_LEN) return best_result();
     if (d == d_end) {
-      if (targeted && H[lt] >= K_LIVE) {
+      if (targeted && H[lt] >= K_LIVE && d - (int32_t)(best & 32767u) < BREAK_LEN - TARGET_SLACK) {
         const uint32_t tH = H[lt];
         return ExtResult{tr, tq, (int32_t)(tH >> 15) - 65536, 32767 - (int32_t)(tH & 32767u), 1};
       }

@@ -51,7 +51,7 @@ if f and w:
             fh.write(",".join(str(x) for x in r) + "\n")
     stage_of = {"anim_seed_kernel": "anim_seed_kernel", "anim_cluster_wave_kernel": "anim_cluster_wave_kernel",
                 "anim_extdp_lane_kernel": "anim_extdp_lane_kernel", "anim_finish_kernel": "anim_finish_kernel"}
-    out = {"round": tag, "command": "python bench.py --gpus 1 --steps 2 --warmup 1 --no-cpu-baseline --no-tetra (C4, 499 500 pairs per step; two workers: launches of two streams overlap)",
+    out = {"round": tag, "command": "python bench.py --gpus 1 --steps 2 --warmup 1 --no-cpu-baseline --no-tetra (C4, a step = the whole grid; two workers: launches of two streams overlap)",
            "correction": "FETCH_SIZE doubled (gfx950 rocprofv3 tallies 128-B read requests at 64 B, MI355X_MICROARCH.md §HBM; exact for wide "
                          "coalesced streams, an upper bound for narrower accesses); WRITE_SIZE as reported (uncalibrated)"}
     for k, stage in stage_of.items():
