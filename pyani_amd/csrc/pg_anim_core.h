@@ -194,10 +194,18 @@ PG_HD ExtResult extend_banded(const RefT& R, const QryT& Q, int64_t r0, int64_t 
 // recurrences and tie-breaks as dp_cell.  Used to bridge cluster junctions whose diagonal shift exceeds the band
 // (an indel of 60+ bases between two clusters that nucmer still fuses).  min(n, m) <= THIN_MAX; returns -1 otherwise.
 constexpr int THIN_MAX = 63, THIN_LONG = 511;
+// THIN_WHOLE: the same DP with the shorter side up to two wave strips, for the ERROR COUNT of a bridged junction over the whole
+// junction (between the last match of one chain and the first match of the next); which junctions are bridged is still decided
+// on rectangles of at most THIN_MAX (host sweep, round 2: 63 / 126 / 189 -> 25 022 / 25 038 / 25 034 records exact).
+#ifdef PGA_THIN_WHOLE
+constexpr int THIN_WHOLE = PGA_THIN_WHOLE;
+#else
+constexpr int THIN_WHOLE = 2 * THIN_MAX;
+#endif
 struct RectResult { int32_t score, errors; };   // errors < 0: the rectangle is too large for the thin DP
 template <typename RefT, typename QryT>
-PG_HD RectResult thin_rect_errors(const RefT& R, const QryT& Q, int64_t r0, int32_t n, int64_t q0, int32_t m) {
-  if (n < 0 || m < 0 || n > THIN_LONG || m > THIN_LONG || (n > THIN_MAX && m > THIN_MAX)) return RectResult{NEG_INF, -1};
+PG_HD RectResult thin_rect_errors(const RefT& R, const QryT& Q, int64_t r0, int32_t n, int64_t q0, int32_t m, int32_t max_short = THIN_MAX) {
+  if (n < 0 || m < 0 || n > THIN_LONG || m > THIN_LONG || (n > max_short && m > max_short)) return RectResult{NEG_INF, -1};
   // rows = ref bases, columns = query bases (no transposition: both builds walk the same cells)
   DpCell row[THIN_LONG + 1], nrow[THIN_LONG + 1];
   row[0] = DpCell{0, 0, NEG_INF, 0, NEG_INF, 0};
@@ -545,9 +553,9 @@ constexpr int32_t BRIDGE_XDROP =
 #else
     615;
 #endif
-template <typename RECT>
+template <typename RECT, typename RECTW>
 PG_HD void bridge_junction(ChainBwd& e, int32_t prev_re, int32_t prev_qe, int32_t tr, int32_t tq, int32_t first_r, int32_t first_q,
-                           int32_t prev_lr, int32_t prev_lq, int32_t prev_err_fwd, RECT&& rect) {
+                           int32_t prev_lr, int32_t prev_lq, int32_t prev_err_fwd, RECT&& rect, RECTW&& rect_whole) {
   if (e.reached || prev_re < 0 || tr < 0) return;
   int32_t shift = tq - tr;
   if (shift < 0) shift = -shift;
@@ -562,7 +570,7 @@ PG_HD void bridge_junction(ChainBwd& e, int32_t prev_re, int32_t prev_qe, int32_
   // errors of the fused alignment: prefer the optimal path over the WHOLE junction, from the end of the previous chain's
   // last match to this chain's first match (its free forward extension is then replaced: minus prev_err_fwd); then from the
   // previous forward end; else the residual rectangle behind the free backward search
-  RectResult x = prev_lr >= 0 && prev_lr <= prev_re && prev_lq <= prev_qe ? rect(prev_lr, first_r - prev_lr, prev_lq, first_q - prev_lq)
+  RectResult x = prev_lr >= 0 && prev_lr <= prev_re && prev_lq <= prev_qe ? rect_whole(prev_lr, first_r - prev_lr, prev_lq, first_q - prev_lq)
                                                                            : RectResult{NEG_INF, -1};
   if (x.errors >= 0) { e.err_back = x.errors - prev_err_fwd; }
   else {
@@ -571,6 +579,26 @@ PG_HD void bridge_junction(ChainBwd& e, int32_t prev_re, int32_t prev_qe, int32_
     else { e.err_back += resid.errors; }
   }
   e.rs = prev_re; e.qs = prev_qe; e.reached = 2;
+}
+
+// The backward search of a chain never enters the matches of the chain before it — if that chain is its collinear
+// predecessor: its last match ends before this chain's first match in both sequences, on a diagonal the band can reach.  The
+// chain before it in reference order may just as well belong to another copy of a repeat, hundreds of kilobases away in the
+// query; stopping at ITS matches cut alignments short that MUMmer extends over them (round 2, out of sample: host sweep of
+// the shift bound over 25 192 records, none / 61 / 100 / 1000 / unbounded -> 25 057 / 25 057 / 25 056 / 25 044 / 25 022 exact).
+constexpr int PREV_LIMIT_SHIFT =
+#ifdef PGA_PREV_LIMIT_SHIFT
+    PGA_PREV_LIMIT_SHIFT;
+#else
+    BAND - 3;
+#endif
+PG_HD void limit_backward_by_prev(int32_t first_r, int32_t first_q, int32_t prev_lr, int32_t prev_lq, int32_t& r_lo, int32_t& q_lo) {
+  if (prev_lr > first_r || prev_lq > first_q) return;
+  int32_t sh = (first_q - prev_lq) - (first_r - prev_lr);
+  if (sh < 0) sh = -sh;
+  if (sh > PREV_LIMIT_SHIFT) return;
+  if (prev_lr > r_lo) r_lo = prev_lr;
+  if (prev_lq > q_lo) q_lo = prev_lq;
 }
 
 // prev_re/prev_qe: forward end of the preceding chain (same strand and records), or -1 if there is none;
@@ -591,10 +619,7 @@ PG_HD ChainBwd extend_chain_bwd(const RefT& R, const QryT& Q, int32_t first_r, i
   }
   int32_t tr = -1, tq = -1;
   if (prev_re >= 0 && first_r >= prev_re && first_q >= prev_qe) { tr = first_r - prev_re; tq = first_q - prev_qe; }
-  if (prev_re >= 0 && prev_lr <= first_r && prev_lq <= first_q) {   // collinear predecessor only
-    if (prev_lr > r_lo) r_lo = prev_lr;
-    if (prev_lq > q_lo) q_lo = prev_lq;
-  }
+  if (prev_re >= 0) limit_backward_by_prev(first_r, first_q, prev_lr, prev_lq, r_lo, q_lo);
   ExtResult b = extend_banded(R, Q, first_r, first_q, -1, cap_ext(first_r - r_lo, MAX_EXT_BWD),
                               cap_ext(first_q - q_lo, MAX_EXT_BWD), tr, tq);
   if (tr >= 0 && !b.reached && tr != tq)   // the band was shifted towards an unreachable target: search freely instead
@@ -603,7 +628,8 @@ PG_HD ChainBwd extend_chain_bwd(const RefT& R, const QryT& Q, int32_t first_r, i
   e.rs = first_r - b.di; e.qs = first_q - b.dj; e.err_back = b.errors;
   e.reached = (tr >= 0 && b.reached) ? 1 : 0;
   bridge_junction(e, prev_re, prev_qe, tr, tq, first_r, first_q, prev_lr, prev_lq, prev_err_fwd,
-                  [&](int32_t r0, int32_t n, int32_t q0, int32_t m) { return thin_rect_errors(R, Q, r0, n, q0, m); });
+                  [&](int32_t r0, int32_t n, int32_t q0, int32_t m) { return thin_rect_errors(R, Q, r0, n, q0, m); },
+                  [&](int32_t r0, int32_t n, int32_t q0, int32_t m) { return thin_rect_errors(R, Q, r0, n, q0, m, THIN_WHOLE); });
   return e;
 }
 

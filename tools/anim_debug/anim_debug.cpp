@@ -154,8 +154,8 @@ int main(int argc, char** argv) {
     }
     if (getenv("ANIM_CHAINS")) {
       const int lo = atoi(getenv("ANIM_CHAINS")), hi = getenv("ANIM_CHAINS_HI") ? atoi(getenv("ANIM_CHAINS_HI")) : lo + 4000;
-      for (int k = 0; k < n_chains; ++k) { const int c = co[k]; if (strand == 0 && fw[c].first_r >= lo && fw[c].first_r <= hi)
-        fprintf(stderr, "chain %d: first %d %d last_end %d %d fwd_end %d %d (reached %d) bwd_start %d %d (reached %d) prev %d next %d count %d\n", c, fw[c].first_r, fw[c].first_q, fw[c].lr, fw[c].lq, fw[c].re, fw[c].qe, fw[c].reached, bw[c].rs, bw[c].qs, bw[c].reached, prev_of[c], next_of[c], chains[c].count); }
+      for (int k = 0; k < n_chains; ++k) { const int c = co[k]; if (strand == (getenv("ANIM_CHAINS_STRAND") ? atoi(getenv("ANIM_CHAINS_STRAND")) : 0) && fw[c].first_r >= lo && fw[c].first_r <= hi)
+        fprintf(stderr, "chain %d: first %d %d last_end %d %d fwd_end %d %d (reached %d) bwd_start %d %d (reached %d) prev %d next %d count %d inner %d err_fwd %d err_back %d\n", c, fw[c].first_r, fw[c].first_q, fw[c].lr, fw[c].lq, fw[c].re, fw[c].qe, fw[c].reached, bw[c].rs, bw[c].qs, bw[c].reached, prev_of[c], next_of[c], chains[c].count, fw[c].inner_err, fw[c].err_fwd, bw[c].err_back); }
     }
     std::vector<int32_t> aln_of(n_chains + 1);
     const int before = (int)alns.size();
