@@ -121,23 +121,45 @@ __device__ __forceinline__ void k0_count_lane(const LaneData& d, uint32_t* lds_h
       if (!CHECK) {
         lds_inc(reinterpret_cast<uint32_t*>(h7b + o));
       } else {
-        const bool clean = (c7 >> (4 * t)) & 1u;
-        lds_inc(reinterpret_cast<uint32_t*>(h7b + (clean ? o : dummy_byte_off)));
+        const uint32_t keep = (uint32_t)__builtin_amdgcn_sbfe((int)c7, 4 * t, 1);   // 0 or ~0: one bit-field extract + one v_bfi
+        lds_inc(reinterpret_cast<uint32_t*>(h7b + ((o & keep) | (dummy_byte_off & ~keep))));
       }
     }
   }
   if (CHECK) {
-    unsigned long long todo = ((unsigned long long)need << 32) | need_lo;   // bit 16 j + 4 t
-    while (todo) {   // rare: a heptamer that touches the edge of a dirty run
-      const int b = __ffsll(todo) - 1;
-      todo &= todo - 1;
-      const int j = b >> 4, tt = (b >> 2) & 3;
-      // (selects, not w[j]: a dynamically indexed register array would live in scratch memory)
-      const uint32_t lo = j == 0 ? w[0] : j == 1 ? w[1] : j == 2 ? w[2] : w[3];
-      const uint32_t hi = j == 0 ? w[1] : j == 1 ? w[2] : j == 2 ? w[3] : w[4];
-      const uint32_t mj = j == 0 ? mw[0] : j == 1 ? mw[1] : j == 2 ? mw[2] : mw[3];
-      const uint32_t h = (tt == 0 ? lo : tt == 1 ? lo >> 8 : tt == 2 ? lo >> 16 : __builtin_amdgcn_alignbit(hi, lo, 24)) & 0x3FFFu;
-      k0_dirty_heptamer((mj >> (4 * tt)) & 0x7Fu, h, F4, E3, E2);
+    // Rare: heptamers that touch the edge of a dirty run.  Not a loop per lane (r02 first form: every lane with such a heptamer
+    // walked its own bits, the whole wave waiting through ~300 divergent instructions per dirty base) but wave-wide: the words
+    // of a lane that has some are broadcast, and its <= 16 heptamers x 4 window starts are 64 work items, one per lane.
+    unsigned long long lanes_todo = __ballot((need | need_lo) != 0u);
+    const int lane = (int)(__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)));
+    while (lanes_todo) {   // uniform
+      const int src = __ffsll(lanes_todo) - 1;
+      lanes_todo &= lanes_todo - 1;
+      const uint32_t W0 = __builtin_amdgcn_readlane(w[0], src), W1 = __builtin_amdgcn_readlane(w[1], src),
+                     W2 = __builtin_amdgcn_readlane(w[2], src), W3 = __builtin_amdgcn_readlane(w[3], src),
+                     W4 = __builtin_amdgcn_readlane(w[4], src);
+      const uint32_t M0 = __builtin_amdgcn_readlane(mw[0], src), M1 = __builtin_amdgcn_readlane(mw[1], src),
+                     M2 = __builtin_amdgcn_readlane(mw[2], src), M3 = __builtin_amdgcn_readlane(mw[3], src);
+      unsigned long long T = ((unsigned long long)__builtin_amdgcn_readlane(need, src) << 32) | __builtin_amdgcn_readlane(need_lo, src);
+      int myb = -1;          // bit 16 j + 4 t of the heptamer this lane works on: the (lane >> 2)-th set bit
+      for (int k = 0; T; T &= T - 1, ++k) {   // uniform
+        const int b = __ffsll(T) - 1;
+        myb = (lane >> 2) == k ? b : myb;
+      }
+      if (myb >= 0) {
+        const int j = myb >> 4, tt = (myb >> 2) & 3, q = lane & 3;
+        const uint32_t lo = j == 0 ? W0 : j == 1 ? W1 : j == 2 ? W2 : W3;
+        const uint32_t hi = j == 0 ? W1 : j == 1 ? W2 : j == 2 ? W3 : W4;
+        const uint32_t mj = j == 0 ? M0 : j == 1 ? M1 : j == 2 ? M2 : M3;
+        const uint32_t h = (uint32_t)((((unsigned long long)hi << 32) | lo) >> (8 * tt)) & 0x3FFFu;
+        const uint32_t m7 = (mj >> (4 * tt)) & 0x7Fu;
+        const uint32_t v2 = m7 & (m7 >> 1), v3 = v2 & (m7 >> 2), v4 = v3 & (m7 >> 3);
+        const uint32_t r = h >> (2 * q);
+        // (k0_dirty_heptamer's classification of window start q)
+        if ((v4 >> q) & 1u) lds_inc(&F4[nat4_from_lowfirst(r & 0xFFu)]);
+        else if ((v3 >> q) & 1u) lds_inc(&E3[((r & 3u) << 4) | (r & 0xCu) | ((r >> 4) & 3u)]);
+        else if ((v2 >> q) & 1u) lds_inc(&E2[((r & 3u) << 2) | ((r >> 2) & 3u)]);
+      }
     }
   }
 }
@@ -158,7 +180,9 @@ __device__ __forceinline__ void k0_process(LaneData d, uint32_t* lds, uint32_t t
   if (__all(all_clean)) {
     k0_count_lane<false>(d, h7, nullptr, nullptr, nullptr);
   } else if (!__all(none_clean)) {
-    if (!none_clean) k0_count_lane<true>(d, h7, lds + L::F4, lds + L::E3, lds + L::E2, (uint32_t)(L::DUMMY + (tid & 63u)) * 4u);
+    // every lane takes part (the rare path hands work items to ALL 64 lanes); a lane without a clean base sends its sixteen
+    // atomics to its dummy word and asks for nothing
+    k0_count_lane<true>(d, h7, lds + L::F4, lds + L::E3, lds + L::E2, (uint32_t)(L::DUMMY + (tid & 63u)) * 4u);
   }
 }
 
