@@ -417,6 +417,10 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
     for (int32_t g : seed_refs) if (LSv[g].ref_max > max_group) max_group = LSv[g].ref_max;
     slots = 256;
     while (slots < 2 * max_group) slots <<= 1;
+    if (getenv("PYANI_SEED_SLOTS_MIN")) {   // development: a larger LDS table (lower load, shorter probe sequences, fewer workgroups per CU)
+      const uint32_t want = (uint32_t)atoi(getenv("PYANI_SEED_SLOTS_MIN"));
+      while (slots < want && slots < SEED_MAX_SLOTS) slots <<= 1;
+    }
     if (slots > SEED_MAX_SLOTS)
       return pg_fail(ctx, PG_E_CAPACITY, "anim seeding: a reference k-mer group does not fit the LDS table (genome too large or too repetitive)");
     srefs.clear();   // one entry per reference with seeded pairs: [pair_begin, pair_end) spans them (pairs in between that

@@ -193,7 +193,11 @@ PG_HD ExtResult extend_banded(const RefT& R, const QryT& Q, int64_t r0, int64_t 
 // Full (un-banded) global alignment of a small rectangle: ref [r0, r0+n) x query [q0, q0+m), forward direction, same
 // recurrences and tie-breaks as dp_cell.  Used to bridge cluster junctions whose diagonal shift exceeds the band
 // (an indel of 60+ bases between two clusters that nucmer still fuses).  min(n, m) <= THIN_MAX; returns -1 otherwise.
+#ifdef PGA_THIN_LONG
+constexpr int THIN_MAX = 63, THIN_LONG = PGA_THIN_LONG;
+#else
 constexpr int THIN_MAX = 63, THIN_LONG = 511;
+#endif
 // THIN_WHOLE: the same DP with the shorter side up to two wave strips, for the ERROR COUNT of a bridged junction over the whole
 // junction (between the last match of one chain and the first match of the next); which junctions are bridged is still decided
 // on rectangles of at most THIN_MAX (host sweep, round 2: 63 / 126 / 189 -> 25 022 / 25 038 / 25 034 records exact).
@@ -414,13 +418,25 @@ PG_HD bool chain_before(const Chain* chains, const Match* cm, int a, int b) {
   const int32_t ra = cm[chains[a].first].r, rb = cm[chains[b].first].r;
   return ra != rb ? ra < rb : a < b;
 }
-// nearest preceding / following chain of the same (ref record, query record) in ref order (looks 8 entries each way)
-PG_HD void chain_neighbours(const Chain* chains, const int32_t* order, int n, int32_t* prev_of, int32_t* next_of) {
+// nearest predecessor (chain_is_predecessor) / following chain of the same (ref record, query record) in ref order (looks 8
+// entries each way)
+// Chain p can be the predecessor of chain c (the alignment c's backward search aims at, may fuse with, and must not run into):
+// same records, and p's last match ends before c's first match starts in BOTH sequences, give or take the overlap a target may
+// have (TARGET_TRIM_MAX, as forward_target).  The chain before c in reference order may belong to another copy of a repeat,
+// far ahead in the query: with it as "predecessor" c never met the collinear chain one or two places further back that MUMmer
+// fuses it with (round 2, out of sample: +6 records; the bound itself is not sensitive, 0 / 19 / 100 / 10^5 -> +6 / +6 / +8 / +8).
+PG_HD bool chain_is_predecessor(const Chain* chains, const Match* cm, int p, int c) {
+  if (chains[p].rrec != chains[c].rrec || chains[p].qrec != chains[c].qrec) return false;
+  const Match& l = cm[chains[p].first + chains[p].count - 1];
+  const Match& f = cm[chains[c].first];
+  return l.r + l.len <= f.r + TARGET_TRIM_MAX && l.q + l.len <= f.q + TARGET_TRIM_MAX;
+}
+PG_HD void chain_neighbours(const Chain* chains, const Match* cm, const int32_t* order, int n, int32_t* prev_of, int32_t* next_of) {
   for (int k = 0; k < n; ++k) {
     const int c = order[k];
     int p = -1, q = -1;
     for (int kk = k - 1; kk >= 0 && kk >= k - 8 && p < 0; --kk)
-      if (chains[order[kk]].rrec == chains[c].rrec && chains[order[kk]].qrec == chains[c].qrec) p = order[kk];
+      if (chain_is_predecessor(chains, cm, order[kk], c)) p = order[kk];
     for (int kk = k + 1; kk < n && kk <= k + 8 && q < 0; ++kk)
       if (chains[order[kk]].rrec == chains[c].rrec && chains[order[kk]].qrec == chains[c].qrec) q = order[kk];
     prev_of[c] = p;

@@ -117,7 +117,7 @@ int main(int argc, char** argv) {
     std::vector<ChainFwd> fw(n_chains);
     std::vector<ChainBwd> bw(n_chains);
     std::vector<int32_t> prev_of(n_chains, -1), next_of(n_chains, -1), r_lo(n_chains), r_hi(n_chains), q_lo(n_chains), q_hi(n_chains);
-    chain_neighbours(chains.data(), co.data(), n_chains, prev_of.data(), next_of.data());
+    chain_neighbours(chains.data(), cm.data(), co.data(), n_chains, prev_of.data(), next_of.data());
     for (int c = 0; c < n_chains; ++c) {
       r_lo[c] = G.rec_start[chains[c].rrec]; r_hi[c] = G.rec_start[chains[c].rrec + 1] - 1;
       q_lo[c] = H.rec_start[chains[c].qrec]; q_hi[c] = H.rec_start[chains[c].qrec + 1] - 1;
