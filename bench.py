@@ -256,7 +256,7 @@ def run_anim(args, rank, world, local, dist, torch):
         if rows[0] not in pair_cache:   # (the job description, not part of the job: built once per tile)
             pair_cache[rows[0]] = parallel.anim_pair_array(n, rows, symmetric=True)   # the rows' unordered pairs, both directions
         pairs = pair_cache[rows[0]]
-        if world > 1:
+        if dist is not None:
             grid = parallel.anim_allgather(compute, n, dev, rows=rows, symmetric=True)
             vals = grid[torch.from_numpy(pairs[:, 0]).to(dev), torch.from_numpy(pairs[:, 1]).to(dev)]
         else:
@@ -408,7 +408,7 @@ def run_anib(args, rank, world, local, dist, torch):
 
     def step(k, keep=False):
         rows = [(k * R + i) % n for i in range(R)]
-        if world > 1:
+        if dist is not None:
             grid = parallel.anim_allgather(compute, n, dev, rows=rows)
         else:
             pairs = parallel.anim_pair_array(n, rows)
@@ -685,7 +685,9 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     dist = None
-    if world > 1:
+    # PYANI_BENCH_FORCE_DIST=1 (tests): take the collective path with ONE rank too, so that the RCCL calls themselves run on a
+    # 1-GPU box (launch through torch.distributed.run --nproc-per-node 1)
+    if world > 1 or os.environ.get("PYANI_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
         if one_gpu_debug:
             dist.init_process_group("gloo")

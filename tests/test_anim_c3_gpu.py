@@ -99,3 +99,19 @@ def test_bench_fragment_mode_two_ranks_equal_single_rank(tmp_path):
                 "coverage_related_median"):
         assert one["config"][key] == two["config"][key], key
     assert one["config"]["pairs_timed"] == 12 * 11 and one["config"]["related_pairs_with_hits"] == 12 * 11 and two["n_gpus"] == 2
+
+
+def test_bench_rccl_path_with_one_rank_equals_plain_run(tmp_path):
+    """The collective path of bench.py with its real backend: torch.distributed.run with ONE rank and PYANI_BENCH_FORCE_DIST
+    (init_process_group("nccl"), all_gather_into_tensor of CUDA tensors, barrier, all_reduce) gives the result hash of the plain
+    single-GPU run.  (Two RCCL ranks cannot share one GPU; the two-rank tests above therefore run over gloo.)"""
+    one = _bench({}, 1, tmp_path, "plain")
+    args = ["--genomes", "24", "--length", "300000", "--seed", "11", "--rows-per-step", "8", "--steps", "3", "--warmup", "0",
+            "--no-cpu-baseline", "--no-tetra"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+           "--master-port", "29519", str(ROOT / "bench.py"), "--gpus", "1"] + args
+    r = subprocess.run(cmd, env=dict(os.environ, PYANI_BENCH_FORCE_DIST="1"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    rccl = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert rccl["config"]["results_sha1_full_grid"] == one["config"]["results_sha1_full_grid"]
+    assert rccl["config"]["pairs_timed"] == one["config"]["pairs_timed"] == 24 * 23
