@@ -65,21 +65,33 @@ constexpr int32_t FRAG_NEG = -(1 << 28);
 struct FragCellIn { int32_t h, x, y, hs, xs, ys; };      // stats packed: mismatches << 16 | gap bases
 PG_HD FragCellIn frag_cell(bool has_u, const FragCellIn& u, bool has_l, const FragCellIn& l, bool has_g, const FragCellIn& g, bool ok,
                            int32_t xbest) {
-  FragCellIn c{FRAG_NEG, FRAG_NEG, FRAG_NEG, 0, 0, 0};
-  if (has_u) {                                           // X: gap consuming a query base (ties: extend the open gap)
+  // straight-line: selects and NON-short-circuit logic only (& and | on the flags) — on the device every branch here cost a
+  // round of exec-mask bookkeeping per cell
+  constexpr int32_t LIVE = FRAG_NEG / 2;
+  FragCellIn c;
+  {                                                      // X: gap consuming a query base (ties: extend the open gap)
     const int32_t ho = u.h + FRAG_GAP_OPEN, xo = u.x + FRAG_GAP_EXT;
-    if (u.x > FRAG_NEG / 2 && xo >= ho) { c.x = xo; c.xs = u.xs + 1; } else if (u.h > FRAG_NEG / 2) { c.x = ho; c.xs = u.hs + 1; }
+    const bool ext = (u.x > LIVE) & (xo >= ho), any = has_u & (ext | (u.h > LIVE));
+    c.x = any ? (ext ? xo : ho) : FRAG_NEG;
+    c.xs = any ? (ext ? u.xs : u.hs) + 1 : 0;
   }
-  if (has_l) {                                           // Y: gap consuming a subject base
+  {                                                      // Y: gap consuming a subject base
     const int32_t ho = l.h + FRAG_GAP_OPEN, yo = l.y + FRAG_GAP_EXT;
-    if (l.y > FRAG_NEG / 2 && yo >= ho) { c.y = yo; c.ys = l.ys + 1; } else if (l.h > FRAG_NEG / 2) { c.y = ho; c.ys = l.hs + 1; }
+    const bool ext = (l.y > LIVE) & (yo >= ho), any = has_l & (ext | (l.h > LIVE));
+    c.y = any ? (ext ? yo : ho) : FRAG_NEG;
+    c.ys = any ? (ext ? l.ys : l.hs) + 1 : 0;
   }
-  if (has_g && g.h > FRAG_NEG / 2) { c.h = g.h + (ok ? FRAG_MATCH : FRAG_MISMATCH); c.hs = g.hs + (ok ? 0 : 65536); }
-  if (c.x > c.h) { c.h = c.x; c.hs = c.xs; }
-  if (c.y > c.h) { c.h = c.y; c.hs = c.ys; }
-  if (c.h < xbest - FRAG_XDROP) c.h = FRAG_NEG;
-  if (c.x < xbest - FRAG_XDROP) c.x = FRAG_NEG;
-  if (c.y < xbest - FRAG_XDROP) c.y = FRAG_NEG;
+  const bool diag = has_g & (g.h > LIVE);
+  c.h = diag ? g.h + (ok ? FRAG_MATCH : FRAG_MISMATCH) : FRAG_NEG;
+  c.hs = diag ? g.hs + (ok ? 0 : 65536) : 0;
+  const bool tx = c.x > c.h;
+  c.h = tx ? c.x : c.h; c.hs = tx ? c.xs : c.hs;
+  const bool ty = c.y > c.h;
+  c.h = ty ? c.y : c.h; c.hs = ty ? c.ys : c.hs;
+  const int32_t floor_ = xbest - FRAG_XDROP;
+  c.h = c.h < floor_ ? FRAG_NEG : c.h;
+  c.x = c.x < floor_ ? FRAG_NEG : c.x;
+  c.y = c.y < floor_ ? FRAG_NEG : c.y;
   return c;
 }
 
