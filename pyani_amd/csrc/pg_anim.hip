@@ -661,6 +661,8 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
       if ((rc = regrow(ctx, A->ext_wave, cap))) return rc;
       A->ext_cap = cap;
     }
+    // persistent lane-DP waves per CU: 4 = one per SIMD (the kernel holds its band in 256 VGPRs: two fit a SIMD)
+    const uint32_t ext_waves_per_cu = getenv("PYANI_EXT_WAVES_PER_CU") ? (uint32_t)atoi(getenv("PYANI_EXT_WAVES_PER_CU")) : 4u;
     if (n_big) {
       PG_HIP(ctx, hipMemsetAsync(A->ext_counts, 0, 20, cur_stream(ctx)));   // [0], [1] list lengths, [2] hand-out cursor, [4] handed over
       pg_prof_begin(ctx, PG_K_ANIM_EXTEND);
@@ -668,7 +670,7 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
                          A->tasks_d, A->task_lists + GAP_CLASSES * Mp, (uint32_t)n_big, A->ext_pre, A->ext_reqs, A->ext_counts);
       pg_prof_end(ctx);
       pg_prof_begin(ctx, PG_K_ANIM_EXTLANE);
-      hipLaunchKernelGGL(anim_extdp_lane_kernel, dim3((uint32_t)ctx->num_cu * 4u), dim3(64), 0, cur_stream(ctx), A->ext_reqs, A->ext_reqs,
+      hipLaunchKernelGGL(anim_extdp_lane_kernel, dim3((uint32_t)ctx->num_cu * ext_waves_per_cu), dim3(64), 0, cur_stream(ctx), A->ext_reqs, A->ext_reqs,
                          A->ext_counts, A->ext_counts + 2, A->ext_pre, A->ext_dumps, dump_cap, A->ext_counts + 4, tail_lanes, tail_blocks);
       pg_prof_end(ctx);
       pg_prof_begin(ctx, PG_K_ANIM_EXTEND);
@@ -687,7 +689,7 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
                            A->ext_wave);
         pg_prof_end(ctx);
         pg_prof_begin(ctx, PG_K_ANIM_EXTLANE);
-        hipLaunchKernelGGL(anim_extdp_lane_kernel, dim3((uint32_t)ctx->num_cu * 4u), dim3(64), 0, cur_stream(ctx), A->ext_reqs,
+        hipLaunchKernelGGL(anim_extdp_lane_kernel, dim3((uint32_t)ctx->num_cu * ext_waves_per_cu), dim3(64), 0, cur_stream(ctx), A->ext_reqs,
                            A->ext_reqs + n_wl, A->ext_counts, A->ext_counts + 2, A->ext_pre + (size_t)round * n_wl, A->ext_dumps,
                            dump_cap, A->ext_counts + 4, tail_lanes, tail_blocks);
         pg_prof_end(ctx);
