@@ -39,7 +39,9 @@ class PyaniANImException(Exception):
 
 
 class ANIResults:
-    """Container mirroring pyani.pyani_tools.ANIResults (pyani_tools.py:85-196) for the ANIm mode."""
+    """The five result matrices of a run, under the attribute names pyani's callers read (pyani_tools.py:85-196).  Filled
+    whole by `assemble_legacy_results` (vectorised, last writer wins as in the reference's per-cell loop); there are no
+    per-cell setters."""
 
     def __init__(self, labels: List[str], mode: str = "ANIm"):
         self.alignment_lengths = pd.DataFrame(index=labels, columns=labels, dtype=float)
@@ -48,24 +50,6 @@ class ANIResults:
         self.alignment_coverage = pd.DataFrame(index=labels, columns=labels, dtype=float).fillna(1.0)
         self.zero_error = False
         self.mode = mode
-
-    def add_tot_length(self, qname, sname, qlen, slen=None, sym=True):
-        self.alignment_lengths.loc[qname, sname] = qlen
-        if sym and slen:
-            self.alignment_lengths.loc[sname, qname] = slen
-
-    def add_sim_errors(self, qname, sname, value, sym=True):
-        self.similarity_errors.loc[qname, sname] = value
-        if sym:
-            self.similarity_errors.loc[sname, qname] = value
-
-    def add_pid(self, qname, sname, value, sym=True):
-        self.percentage_identity.loc[qname, sname] = value
-
-    def add_coverage(self, qname, sname, qcover, scover=None):
-        self.alignment_coverage.loc[qname, sname] = qcover
-        if scover:
-            self.alignment_coverage.loc[sname, qname] = scover
 
     @property
     def hadamard(self) -> pd.DataFrame:
