@@ -53,7 +53,12 @@ static long MAX_DIFF = -1;        // trim threshold; -1 = GOOD_SCORE * BREAK_LEN
 static int TRIM_STRICT = 1;       // 1: trim when high - value > MAX_DIFF, 0: >=
 static int FORCED_TRIM = 0;       // forced alignments (FORCED_BIT) neither break nor trim: with trimming 4 of the 43 fixture runs lose their way
 static int STORED_BOUNDS = 1;     // a cell reads neighbours that were computed and then trimmed
+static int EXP_TIE = 0;           // EXPERIMENT (not MUMmer): among equal scores prefer fewer errors (the engine's packed-key rule)
+static int EXP_BAND = 0;          // EXPERIMENT (not MUMmer): confine the band to +-EXP_BAND diagonals (design studies for the GPU engine)
+static int EXP_BAND_SHIFT = 1;    //   ... centred between the start diagonal and the target's (as the engine's shifted band)
 
+static int STATS = 0;
+static long stat_maxw = 0, stat_cells = 0, stat_diags = 0, stat_forced_cells = 0, stat_hist[64];
 static const long NEG = -(1L << 40);
 enum { DELETE = 0, INSERT = 1, MATCH = 2, NONE = 3 };   // DELETE consumes a B base, INSERT an A base
 enum { DIRECTION_BIT = 1, SEARCH_BIT = 2, FORCED_BIT = 4, OPTIMAL_BIT = 8 };
@@ -90,7 +95,10 @@ static bool align_engine(const Seq& A, long Astart, long& Aend, const Seq& B, lo
   const long N = fwd ? Aend - Astart + 1 : Astart - Aend + 1, M = fwd ? Bend - Bstart + 1 : Bstart - Bend + 1;
   auto a_at = [&](long i) { return A.at(fwd ? Astart + i - 1 : Astart - i + 1); };
   auto b_at = [&](long j) { return B.at(fwd ? Bstart + j - 1 : Bstart - j + 1); };
-  const long max_diff = MAX_DIFF >= 0 ? MAX_DIFF : (long)GOOD_SCORE * BREAK_LEN;
+  const long SC = EXP_TIE ? 65536 : 1, ER = EXP_TIE ? 1 : 0;   // EXP_TIE: value = score * 65536 - errors
+  const long max_diff = (MAX_DIFF >= 0 ? MAX_DIFF : (long)GOOD_SCORE * BREAK_LEN) * SC;
+  const long kGOOD = GOOD_SCORE * SC, kBAD = BAD_SCORE * SC - ER, kOPEN = OPEN_GAP_SCORE * SC - ER, kCONT = CONT_GAP_SCORE * SC - ER;
+  auto sc_of = [&](long v) { return EXP_TIE ? ((v + 65535) >> 16) : v; };
   const bool forced = m_o & FORCED_BIT;
   const bool keep_all = !(m_o & SEARCH_BIT);
   std::vector<Diagonal> Diag;
@@ -103,7 +111,15 @@ static bool align_engine(const Seq& A, long Astart, long& Aend, const Seq& B, lo
   for (Dct = 1; Dct <= N + M && (forced || Dct - FinishCt <= BREAK_LEN) && jlo <= jhi; ++Dct) {
     // clip to the matrix
     long lo = std::max(jlo, std::max(0L, Dct - N)), hi = std::min(jhi, std::min(M, Dct));
+    if (EXP_BAND > 0 && !forced) {   // diagonal k = j - i = 2j - Dct within [kc - W, kc + W)
+      long kc = 0;
+      if (EXP_BAND_SHIFT && !(m_o & OPTIMAL_BIT)) { kc = (M - N) / 2; kc = std::max(-(long)EXP_BAND + 2, std::min((long)EXP_BAND - 2, kc)); }
+      const long klo = kc - EXP_BAND, khi = kc + EXP_BAND - 1;
+      lo = std::max(lo, (Dct + klo + 1) >> 1);            // 2j - Dct >= klo
+      hi = std::min(hi, (Dct + khi) >> 1);                // 2j - Dct <= khi
+    }
     if (lo > hi) { break; }
+    if (STATS) { const long w = hi - lo + 1; if (!forced) { if (w > stat_maxw) stat_maxw = w; stat_cells += w; stat_diags += 1; ++stat_hist[std::min(w / 8, 63L)]; } else stat_forced_cells += w; }
     Diag.push_back(Diagonal{lo, hi, std::vector<Node>((size_t)(hi - lo + 1))});
     Diagonal& cur = Diag[Dct];
     const Diagonal& p1 = Diag[Dct - 1];
@@ -114,21 +130,21 @@ static bool align_engine(const Seq& A, long Astart, long& Aend, const Seq& B, lo
       // DELETE: from (i, j-1) on the previous anti-diagonal
       if (j - 1 >= p1.jlo && j - 1 <= p1.jhi && j >= 1) {
         const Node& p = p1.I[j - 1 - p1.jlo];
-        score_edit(c, DELETE, plus(p.v[DELETE], CONT_GAP_SCORE), plus(p.v[INSERT], OPEN_GAP_SCORE), plus(p.v[MATCH], OPEN_GAP_SCORE));
+        score_edit(c, DELETE, plus(p.v[DELETE], kCONT), plus(p.v[INSERT], kOPEN), plus(p.v[MATCH], kOPEN));
       } else { c.v[DELETE] = NEG; c.used[DELETE] = NONE; }
       // INSERT: from (i-1, j)
       if (j >= p1.jlo && j <= p1.jhi && i >= 1) {
         const Node& p = p1.I[j - p1.jlo];
-        score_edit(c, INSERT, plus(p.v[DELETE], OPEN_GAP_SCORE), plus(p.v[INSERT], CONT_GAP_SCORE), plus(p.v[MATCH], OPEN_GAP_SCORE));
+        score_edit(c, INSERT, plus(p.v[DELETE], kOPEN), plus(p.v[INSERT], kCONT), plus(p.v[MATCH], kOPEN));
       } else { c.v[INSERT] = NEG; c.used[INSERT] = NONE; }
       // MATCH: from (i-1, j-1) two anti-diagonals back
       if (p2 && i >= 1 && j >= 1 && j - 1 >= p2->jlo && j - 1 <= p2->jhi) {
         const Node& p = p2->I[j - 1 - p2->jlo];
-        c.v[MATCH] = plus(p.v[p.mx], same_base(a_at(i), b_at(j)) ? GOOD_SCORE : BAD_SCORE);
+        c.v[MATCH] = plus(p.v[p.mx], same_base(a_at(i), b_at(j)) ? kGOOD : kBAD);
         c.used[MATCH] = p.mx;
       } else { c.v[MATCH] = NEG; c.used[MATCH] = NONE; }
       c.mx = max_state(c);
-      if (c.v[c.mx] >= high_score) { high_score = c.v[c.mx]; FinishCt = Dct; FinishJ = j; }
+      if (c.v[c.mx] > NEG / 2 && sc_of(c.v[c.mx]) >= sc_of(high_score)) { high_score = c.v[c.mx]; FinishCt = Dct; FinishJ = j; }
     }
     if (!keep_all && Dct >= 2) { std::vector<Node>().swap(Diag[Dct - 2].I); if (!STORED_BOUNDS) {} }
     // trim hopeless cells from the edges
@@ -501,6 +517,10 @@ int main(int argc, char** argv) {
   if (const char* e = getenv("NUC_TRIM_STRICT")) TRIM_STRICT = atoi(e);
   if (const char* e = getenv("NUC_FORCED_TRIM")) FORCED_TRIM = atoi(e);
   if (const char* e = getenv("NUC_STORED_BOUNDS")) STORED_BOUNDS = atoi(e);
+  if (getenv("NUC_STATS")) STATS = 1;
+  if (const char* e = getenv("NUC_EXP_TIE")) EXP_TIE = atoi(e);
+  if (const char* e = getenv("NUC_EXP_BAND")) EXP_BAND = atoi(e);
+  if (const char* e = getenv("NUC_EXP_BAND_SHIFT")) EXP_BAND_SHIFT = atoi(e);
   if (const char* e = getenv("NUC_OPEN")) OPEN_GAP_SCORE = atoi(e);
   if (const char* e = getenv("NUC_CONT")) CONT_GAP_SCORE = atoi(e);
   std::vector<Rec> ref = load_fasta(argv[1]), qry = load_fasta(argv[2]);
@@ -550,6 +570,11 @@ int main(int argc, char** argv) {
         if (delta) { for (long d : dl) printf("%ld\n", d); printf("0\n"); }
       }
     }
+  }
+  if (STATS) {
+    fprintf(stderr, "STATS max band cells %ld, mean %.1f over %ld anti-diagonals, forced cells %ld (%.1f %% of search cells)\nSTATS width histogram (cells/8):", stat_maxw, (double)stat_cells / (double)std::max(1L, stat_diags), stat_diags, stat_forced_cells, 100.0 * stat_forced_cells / std::max(1L, stat_cells));
+    for (int b = 0; b < 64; ++b) if (stat_hist[b]) fprintf(stderr, " %d:%ld", b * 8, stat_hist[b]);
+    fprintf(stderr, "\n");
   }
   return 0;
 }

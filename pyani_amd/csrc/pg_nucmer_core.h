@@ -1,0 +1,282 @@
+// pg_nucmer_core.h — the extension stage of the ANIm engine as MUMmer 3.23's postnuc defines it: `extendClusters` over the
+// clusters of one (reference, query strand) unit, with the alignment engine (`sw_align`'s anti-diagonal DP: dynamic band that
+// grows by one cell per side and step, trimmed from its edges at breaklen * 3 below the best score, break after breaklen
+// anti-diagonals without a new best, three states per cell with MUMmer's tie order) as a template parameter.
+// Plain C++ that compiles for the device (pg_anim.hip: wave-cooperative engine, pga_postnuc.inc) AND for the host
+// (ScalarEngine below: the statement the GPU must equal; tools/anim_debug, oracle/anim_cpu.cpp).
+//
+// What it restates, and what pins it: pyani runs `nucmer --mum` per ordered pair (pyani/anim.py:240-289); nucmer's extension
+// step is postnuc.  oracle/nucmer_oracle.cpp is an independent restatement of the same published algorithm with traceback and
+// MUMmer's own data structures; it reproduces all 25 192 alignment records (and every indel list) of the MUMmer output files
+// the reference's tests hold.  This file differs from it in form, not in results: stream coordinates, fixed arrays, and error
+// counts that ride along with the scores (every state carries the errors of its chosen path, choices follow MUMmer's tie order,
+// so no traceback is stored) — tests/test_anim_cpu.py holds the two against each other and against the fixtures.
+#pragma once
+#include <stdint.h>
+#include "pg_anim_core.h"
+
+namespace pgn {
+using pga::Chain;
+using pga::Match;
+
+constexpr int32_t GOOD_SCORE = 3, BAD_SCORE = -7, OPEN_GAP_SCORE = -10, CONT_GAP_SCORE = -7;   // sw_alignscore.hh, nucleotides
+constexpr int32_t BREAK_LEN = 200;                       // nucmer -b
+constexpr int32_t MAX_DIFF = GOOD_SCORE * BREAK_LEN;     // a band-edge cell further below the best score is trimmed
+constexpr int32_t MAX_ALIGNMENT_LENGTH = 10000;
+enum : unsigned { DIRECTION_BIT = 1, SEARCH_BIT = 2, FORCED_BIT = 4, OPTIMAL_BIT = 8 };
+constexpr unsigned FORWARD_ALIGN = 1, FORCED_FORWARD_ALIGN = 5, BACKWARD_SEARCH = 2;
+
+// An alignment under construction, MUMmer's coordinates transplanted to the packed streams: positions are stream indices,
+// BOTH ends inclusive (sA = first aligned reference base, eA = last); B in query-STRAND coordinates.
+struct PnAln {
+  int32_t sA, sB, eA, eB;
+  int32_t errors;
+  int32_t chain;   // the chain (cluster) it started from: names the (reference record, query record) it belongs to
+};
+
+// ---- packed DP words ----------------------------------------------------------------------------------------------------
+// One 32-bit word per state: (score + SCORE_BIAS) << 16 | errors.  Scores are compared on the upper half only (MUMmer never
+// looks at errors); 0 = unreachable.  Live scores stay far from both ends of the field: >= best - MAX_DIFF - a few gap steps
+// in a trimmed search, >= -(10 + 7 * 10000) saturating to "unreachable" in a forced one, <= 3 * 10001.
+constexpr uint32_t SCORE_BIAS = 32768u;
+constexpr uint32_t W_HI = 0xFFFF0000u;
+PG_HD uint32_t w_make(int32_t score, uint32_t errors) { return ((uint32_t)(score + (int32_t)SCORE_BIAS) << 16) | errors; }
+PG_HD int32_t w_score(uint32_t w) { return (int32_t)(w >> 16) - (int32_t)SCORE_BIAS; }
+PG_HD uint32_t w_errors(uint32_t w) { return w & 0xFFFFu; }
+PG_HD uint32_t w_gap(uint32_t w, int32_t cost) {   // w + cost (cost < 0), one more error; unreachable stays unreachable
+  const uint32_t c = (uint32_t)(-cost) << 16;
+  return w < c + (1u << 16) ? 0u : w - c + 1u;
+}
+PG_HD uint32_t w_step(uint32_t w, bool same) {     // diagonal step from the best state of (i-1, j-1)
+  if (w < (1u << 16)) return 0u;
+  if (same) return w + ((uint32_t)GOOD_SCORE << 16);
+  const uint32_t c = (uint32_t)(-BAD_SCORE) << 16;
+  return w < c + (1u << 16) ? 0u : w - c + 1u;
+}
+// scoreEdit: the better of continuing this gap / opening it from the other gap state / from the match state; ties: MATCH,
+// then INSERT, then DELETE.  a = from DELETE, b = from INSERT, c = from MATCH (already charged).
+PG_HD uint32_t w_edit(uint32_t del, uint32_t ins, uint32_t mat) {
+  const uint32_t d = del & W_HI, i = ins & W_HI, m = mat & W_HI;
+  if (d > i) return d > m ? del : mat;
+  return i > m ? ins : mat;
+}
+PG_HD uint32_t w_max(uint32_t del, uint32_t ins, uint32_t mat) { return w_edit(del, ins, mat); }   // maxScore: same order
+
+struct Cell { uint32_t D, I, M, X; };   // DELETE (consumes a B base), INSERT (an A base), MATCH, X = the best of the three
+
+// One cell from its three neighbours: L = (i, j-1) and U = (i-1, j) on the previous anti-diagonal, G = best state of (i-1, j-1).
+PG_HD Cell cell_update(bool hasL, const Cell& L, bool hasU, const Cell& U, bool hasG, uint32_t G, bool same) {
+  Cell c;
+  c.D = hasL ? w_edit(w_gap(L.D, CONT_GAP_SCORE), w_gap(L.I, OPEN_GAP_SCORE), w_gap(L.M, OPEN_GAP_SCORE)) : 0u;
+  c.I = hasU ? w_edit(w_gap(U.D, OPEN_GAP_SCORE), w_gap(U.I, CONT_GAP_SCORE), w_gap(U.M, OPEN_GAP_SCORE)) : 0u;
+  c.M = hasG ? w_step(G, same) : 0u;
+  c.X = w_max(c.D, c.I, c.M);
+  return c;
+}
+
+// ---- the scalar engine (host statement; also the definition the wave engine follows cell for cell) -----------------------
+// SEQ: a_ok(p) / a_base(p) / b_ok(p) / b_base(p) on stream positions (b: strand coordinates).
+template <typename RefT, typename QryT>
+struct ScalarEngine {
+  const RefT& R;
+  const QryT& Q;
+  Cell *d0, *d1, *d2;     // three anti-diagonals of capacity cap each (rotating)
+  int32_t cap;
+  int32_t overflow = 0;
+  long cells = 0;
+  PG_HD bool same(int64_t pa, int64_t pb) const { return R.clean(pa) && Q.clean(pb) && R.base(pa) == Q.base(pb); }
+
+  // Aligns A[Astart .. Aend] with B[Bstart .. Bend] (inclusive; walking backwards when DIRECTION_BIT is clear).  Returns whether
+  // the target corner was reached; Aend / Bend = the finish position; errors = errors of the path to it (not in SEARCH mode
+  // — the value is computed anyway and ignored by the callers).
+  PG_HD bool align(int32_t Astart, int32_t& Aend, int32_t Bstart, int32_t& Bend, unsigned m_o, int32_t& errors) {
+    const bool fwd = m_o & DIRECTION_BIT, forced = m_o & FORCED_BIT;
+    const int32_t N = fwd ? Aend - Astart + 1 : Astart - Aend + 1, M = fwd ? Bend - Bstart + 1 : Bstart - Bend + 1;
+    Cell *p2 = d0, *p1 = d1, *cur = d2;
+    int32_t p2lo = 0, p2hi = -1, p1lo = 0, p1hi = 0;
+    p1[0] = Cell{0u, 0u, w_make(0, 0), w_make(0, 0)};
+    int32_t high = -(1 << 30), FinishCt = 0, FinishJ = 0;
+    uint32_t high_w = 0;
+    int32_t jlo = 0, jhi = 1, Dct;
+    for (Dct = 1; Dct <= N + M && (forced || Dct - FinishCt <= BREAK_LEN) && jlo <= jhi; ++Dct) {
+      int32_t lo = jlo, hi = jhi;
+      if (lo < Dct - N) lo = Dct - N;
+      if (lo < 0) lo = 0;
+      if (hi > M) hi = M;
+      if (hi > Dct) hi = Dct;
+      if (lo > hi) break;
+      if (hi - lo + 1 > cap) { overflow = 1; break; }
+      for (int32_t j = lo; j <= hi; ++j) {
+        const int32_t i = Dct - j;
+        const bool hasL = j >= 1 && j - 1 >= p1lo && j - 1 <= p1hi, hasU = i >= 1 && j >= p1lo && j <= p1hi;
+        const bool hasG = i >= 1 && j >= 1 && j - 1 >= p2lo && j - 1 <= p2hi;
+        bool sm = false;
+        if (hasG) sm = same(fwd ? (int64_t)Astart + i - 1 : (int64_t)Astart - i + 1, fwd ? (int64_t)Bstart + j - 1 : (int64_t)Bstart - j + 1);
+        const Cell c = cell_update(hasL, hasL ? p1[j - 1 - p1lo] : Cell{0, 0, 0, 0}, hasU, hasU ? p1[j - p1lo] : Cell{0, 0, 0, 0}, hasG,
+                                   hasG ? p2[j - 1 - p2lo].X : 0u, sm);
+        cur[j - lo] = c;
+        const int32_t s = w_score(c.X);
+        if (s >= high) { high = s; high_w = c.X; FinishCt = Dct; FinishJ = j; }
+      }
+      cells += hi - lo + 1;
+      int32_t tlo = lo, thi = hi;
+      if (!forced) {
+        while (tlo <= thi && high - w_score(cur[tlo - lo].X) > MAX_DIFF) ++tlo;
+        while (thi >= tlo && high - w_score(cur[thi - lo].X) > MAX_DIFF) --thi;
+      }
+      jlo = tlo; jhi = thi + 1;
+      if (tlo > thi) { jlo = 1; jhi = 0; }
+      Cell* t = p2; p2 = p1; p1 = cur; cur = t;
+      p2lo = p1lo; p2hi = p1hi; p1lo = lo; p1hi = hi;
+    }
+    --Dct;
+    bool reached = false;
+    uint32_t fin_w = high_w;
+    if (Dct == N + M && !overflow) {
+      if (!(m_o & OPTIMAL_BIT)) { reached = true; FinishCt = N + M; FinishJ = M; fin_w = p1[M - p1lo].X; }
+      else if (FinishCt == Dct) reached = true;
+    }
+    const int32_t fi = FinishCt - FinishJ, fj = FinishJ;
+    Aend = fwd ? Astart + fi - 1 : Astart - fi + 1;
+    Bend = fwd ? Bstart + fj - 1 : Bstart - fj + 1;
+    errors = (int32_t)w_errors(fin_w);
+    return reached;
+  }
+};
+
+// ---- postnuc: extendClusters ---------------------------------------------------------------------------------------------
+// chains[order[k]], k = 0 .. n-1: the unit's clusters by the reference start of their first match (ties: extraction order);
+// cm: their matches.  BOUNDS(c, r_lo, r_hi, q_lo, q_hi): the records of chain c as half-open stream ranges (q: strand
+// coordinates).  fused[n] / al[max_al]: scratch and output.  Returns the number of alignments (al[] in creation order, as
+// MUMmer prints them), or -1 - count when max_al was too small.
+PG_HD bool pn_close_enough(int32_t a, int32_t b) {
+  const int32_t lesser = a < b ? a : b, greater = a < b ? b : a;
+  return greater < BREAK_LEN || lesser * GOOD_SCORE + (greater - lesser) * CONT_GAP_SCORE >= 0;
+}
+PG_HD bool pn_same_records(const Chain* chains, int a, int b) { return chains[a].rrec == chains[b].rrec && chains[a].qrec == chains[b].qrec; }
+
+template <typename ENG, typename BOUNDS>
+PG_HD int postnuc_unit(ENG& eng, const Chain* chains, const Match* cm, const int32_t* order, int n, BOUNDS&& bounds, uint8_t* fused,
+                       PnAln* al, int max_al) {
+  for (int k = 0; k < n; ++k) fused[k] = 0;
+  int n_al = 0, cura = -1;
+  bool target_reached = false, full = false;
+  int prev = 0, curk = 0, targetk = -1;
+  int32_t targetA = 0, targetB = 0;
+  while (curk < n) {
+    const int c = order[curk];
+    const Chain& C = chains[c];
+    const Match* mm = cm + C.first;
+    const Match& mf = mm[0];
+    const Match& ml = mm[C.count - 1];
+    int32_t r_lo, r_hi, q_lo, q_hi;
+    bounds(c, r_lo, r_hi, q_lo, q_hi);
+    if (!target_reached) {
+      bool skip = fused[curk] != 0;
+      if (!skip) {   // isShadowedCluster: inside an alignment of the same records made so far (from the current one backwards)
+        const int32_t sA = mf.r, eA = ml.r + ml.len - 1, sB = mf.q, eB = ml.q + ml.len - 1;
+        for (int t = cura; t >= 0 && !skip; --t)
+          if (pn_same_records(chains, al[t].chain, c) && al[t].eA >= eA && al[t].eB >= eB && al[t].sA <= sA && al[t].sB <= sB) skip = true;
+      }
+      if (skip) { fused[curk] = 1; curk = ++prev; continue; }
+    }
+    for (int m = 0; m < C.count; ++m) {
+      const Match& Mp = mm[m];
+      if (target_reached) {
+        if (al[cura].eA != Mp.r || al[cura].eB != Mp.q) continue;     // matches of the target cluster before the target match
+        al[cura].eA += Mp.len - 1; al[cura].eB += Mp.len - 1;
+      } else {
+        if (n_al >= max_al) { full = true; break; }
+        al[n_al] = PnAln{Mp.r, Mp.q, Mp.r + Mp.len - 1, Mp.q + Mp.len - 1, 0, c};
+        cura = n_al++;
+        // getReverseTargetAlignment: the latest earlier alignment that ends at or before this start in both sequences and is
+        // close enough; failing that, the one at the smallest distance if that beats the distance to the sequence starts
+        int tgt = -1;
+        {
+          const int32_t sA = al[cura].sA, sB = al[cura].sB;
+          int32_t dist = (sA - r_lo + 1) < (sB - q_lo + 1) ? (sA - r_lo + 1) : (sB - q_lo + 1);
+          for (int t = cura - 1; t >= 0; --t) {
+            if (!pn_same_records(chains, al[t].chain, c)) continue;
+            if (al[t].eA <= sA && al[t].eB <= sB) {
+              int32_t lesser = sA - al[t].eA, greater = sB - al[t].eB;
+              if (lesser > greater) { const int32_t x = lesser; lesser = greater; greater = x; }
+              if (pn_close_enough(lesser, greater)) { tgt = t; break; }
+              if ((greater << 1) - lesser < dist) { tgt = t; dist = (greater << 1) - lesser; }
+            }
+          }
+        }
+        // extendBackward: search back towards the target's end; reached = merge (the gap is re-aligned forwards, forced)
+        {
+          unsigned m_o = BACKWARD_SEARCH;
+          int32_t tA, tB;
+          bool overflow = false;
+          if (tgt >= 0) { tA = al[tgt].eA; tB = al[tgt].eB; } else { tA = r_lo; tB = q_lo; m_o |= OPTIMAL_BIT; }
+          if (al[cura].sA - tA + 1 > MAX_ALIGNMENT_LENGTH) { tA = al[cura].sA - MAX_ALIGNMENT_LENGTH + 1; overflow = true; m_o |= OPTIMAL_BIT; }
+          if (al[cura].sB - tB + 1 > MAX_ALIGNMENT_LENGTH) { tB = al[cura].sB - MAX_ALIGNMENT_LENGTH + 1; if (!overflow) m_o |= OPTIMAL_BIT; overflow = true; }
+          int32_t err = 0;
+          bool reached = eng.align(al[cura].sA, tA, al[cura].sB, tB, m_o | SEARCH_BIT, err);
+          if (overflow || tgt < 0) reached = false;
+          if (reached) {
+            int32_t eA = al[cura].sA, eB = al[cura].sB;
+            eng.align(al[tgt].eA, eA, al[tgt].eB, eB, FORCED_FORWARD_ALIGN, err);
+            al[tgt].errors += err;
+            al[tgt].eA = al[cura].eA; al[tgt].eB = al[cura].eB;
+            --n_al;
+            cura = tgt;
+          } else {
+            if (tA != al[cura].sA || tB != al[cura].sB) {
+              int32_t eA = al[cura].sA, eB = al[cura].sB;
+              eng.align(tA, eA, tB, eB, FORCED_FORWARD_ALIGN, err);
+              al[cura].errors += err;
+            }
+            al[cura].sA = tA; al[cura].sB = tB;
+          }
+        }
+      }
+      // extendForward: to the next match of the cluster, or from its last match towards the target cluster
+      unsigned m_o = FORWARD_ALIGN;
+      if (m + 1 < C.count) { targetA = mm[m + 1].r; targetB = mm[m + 1].q; }
+      else {
+        targetA = r_hi - 1; targetB = q_hi - 1;
+        // getForwardTargetCluster
+        const int32_t sA = ml.r + ml.len - 1, sB = ml.q + ml.len - 1;
+        int32_t dist = (targetA - sA) < (targetB - sB) ? (targetA - sA) : (targetB - sB);
+        targetk = -1;
+        for (int k = curk + 1; k < n; ++k) {
+          const int tc = order[k];
+          if (!pn_same_records(chains, tc, c)) continue;
+          const Match* tm = cm + chains[tc].first;
+          const int tn = chains[tc].count;
+          int32_t eA = tm[0].r, eB = tm[0].q;
+          if ((eA < sA || eB < sB) && tm[tn - 1].r >= sA && tm[tn - 1].q >= sB)
+            for (int x = 0; x < tn && (eA < sA || eB < sB); ++x) { eA = tm[x].r; eB = tm[x].q; }
+          if (eA >= sA && eB >= sB) {
+            int32_t lesser = eA - sA, greater = eB - sB;
+            if (lesser > greater) { const int32_t x = lesser; lesser = greater; greater = x; }
+            if (pn_close_enough(lesser, greater)) { targetk = k; targetA = eA; targetB = eB; break; }
+            if ((greater << 1) - lesser < dist) { targetk = k; targetA = eA; targetB = eB; dist = (greater << 1) - lesser; }
+          }
+        }
+        if (targetk < 0) m_o |= OPTIMAL_BIT;
+      }
+      {
+        bool overflow = false;
+        if (targetA - al[cura].eA + 1 > MAX_ALIGNMENT_LENGTH) { targetA = al[cura].eA + MAX_ALIGNMENT_LENGTH - 1; overflow = true; m_o |= OPTIMAL_BIT; }
+        if (targetB - al[cura].eB + 1 > MAX_ALIGNMENT_LENGTH) { targetB = al[cura].eB + MAX_ALIGNMENT_LENGTH - 1; if (!overflow) m_o |= OPTIMAL_BIT; overflow = true; }
+        int32_t err = 0;
+        bool reached = eng.align(al[cura].eA, targetA, al[cura].eB, targetB, m_o, err);
+        if (reached && overflow) reached = false;
+        al[cura].errors += err;
+        al[cura].eA = targetA; al[cura].eB = targetB;
+        target_reached = reached;
+      }
+    }
+    if (full) break;
+    if (targetk < 0) target_reached = false;
+    fused[curk] = 1;
+    if (!target_reached) curk = ++prev; else curk = targetk;
+  }
+  return full ? -1 - n_al : n_al;
+}
+
+}  // namespace pgn

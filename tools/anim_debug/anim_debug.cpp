@@ -11,6 +11,7 @@
 #include <string>
 #include <vector>
 #include "pg_anim_core.h"
+#include "pg_nucmer_core.h"
 using namespace pga;
 
 struct Genome {
@@ -88,6 +89,9 @@ static int rect_score(const SeqView& R, const QV& Q, int64_t r0, int n, int64_t 
 int main(int argc, char** argv) {
   if (argc < 3) { fprintf(stderr, "usage: anim_debug ref.fna qry.fna [--dump]\n"); return 2; }
   const bool dump = argc > 3 && !strcmp(argv[3], "--dump");
+  bool exact = getenv("ANIM_EXACT") != nullptr;   // the postnuc statement (pg_nucmer_core.h) instead of the banded64 extender
+  for (int i = 3; i < argc; ++i) if (!strcmp(argv[i], "--exact")) exact = true;
+  long exact_cells = 0;
   Genome G = load(argv[1]), H = load(argv[2]);
   const SeqView R = G.view();
   std::vector<Aln> alns;
@@ -114,6 +118,30 @@ int main(int argc, char** argv) {
     std::vector<int32_t> co(n_chains);
     for (int i = 0; i < n_chains; ++i) co[i] = i;
     std::sort(co.begin(), co.end(), [&](int a, int b) { return chain_before(chains.data(), cm.data(), a, b); });
+    if (exact) {
+      const int cap = 1 << 15;
+      std::vector<pgn::Cell> d0(cap), d1(cap), d2(cap);
+      pgn::ScalarEngine<SeqView, StrandView> eng{R, Q, d0.data(), d1.data(), d2.data(), cap};
+      std::vector<uint8_t> fused(n_chains + 1);
+      std::vector<pgn::PnAln> al(n_chains + 1);
+      const int na = pgn::postnuc_unit(eng, chains.data(), cm.data(), co.data(), n_chains,
+          [&](int c, int32_t& rl, int32_t& rh, int32_t& ql, int32_t& qh) {
+            rl = G.rec_start[chains[c].rrec]; rh = G.rec_start[chains[c].rrec + 1] - 1;
+            ql = H.rec_start[chains[c].qrec]; qh = H.rec_start[chains[c].qrec + 1] - 1;
+            if (strand) { const int32_t a = (int32_t)H.len - qh, b = (int32_t)H.len - ql; ql = a; qh = b; } },
+          fused.data(), al.data(), (int)al.size());
+      if (na < 0 || eng.overflow) { fprintf(stderr, "postnuc statement: capacity exceeded\n"); return 3; }
+      exact_cells += eng.cells;
+      for (int i = 0; i < na; ++i) {
+        Aln a; a.rs = al[i].sA; a.re = al[i].eA + 1; a.qs = al[i].sB; a.qe = al[i].eB + 1; a.errors = al[i].errors; a.strand = strand; a.keep = 0;
+        a_rrec.push_back(record_of(G.rec_start.data(), (int)G.rec_start.size() - 1, a.rs));
+        if (strand) { const int32_t qs = (int32_t)H.len - a.qe, qe = (int32_t)H.len - a.qs; a.qs = qs; a.qe = qe; }
+        a_qrec.push_back(record_of(H.rec_start.data(), nq, a.qs));
+        alns.push_back(a);
+      }
+      fprintf(stderr, "strand %d: MEMs->MUMs %d, chains %d, alignments %d (postnuc statement, %ld cells so far)\n", strand, n, n_chains, na, exact_cells);
+      continue;
+    }
     std::vector<ChainFwd> fw(n_chains);
     std::vector<ChainBwd> bw(n_chains);
     std::vector<int32_t> prev_of(n_chains, -1), next_of(n_chains, -1), r_lo(n_chains), r_hi(n_chains), q_lo(n_chains), q_hi(n_chains);
@@ -174,7 +202,8 @@ int main(int argc, char** argv) {
   const int n = (int)alns.size();
   std::vector<int32_t> idx(n + 1), from(n + 1);
   std::vector<double> sc(n + 1);
-  const bool nofilter = argc > 3 && !strcmp(argv[3], "--nofilter");
+  bool nofilter = false;
+  for (int i = 3; i < argc; ++i) if (!strcmp(argv[i], "--nofilter")) nofilter = true;
   if (nofilter) for (auto& a : alns) a.keep = 3;
   else { lis_filter(alns.data(), n, 0, a_rrec.data(), idx.data(), sc.data(), from.data()); lis_filter(alns.data(), n, 1, a_qrec.data(), idx.data(), sc.data(), from.data()); }
   PairResult pr = reduce_pair(alns.data(), n, a_rrec.data(), a_qrec.data(), idx.data());
