@@ -133,6 +133,19 @@ typedef struct {
 int pg_anim_pairs(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_ids, uint64_t n_pairs, int maxmatch,
                   int filter_1to1, pg_anim_result* out);
 
+/* Which extension algorithm pg_anim_pairs / pg_anim_pair_alignments run after seeding and clustering.
+ *   PG_EXTENDER_NUCMER (default)  MUMmer 3.23's own postnuc algorithm (extendClusters + its alignment engine: dynamic
+ *                                 anti-diagonal band trimmed at breaklen * 3 below the best score, backward search + forced
+ *                                 forward re-alignment, MUMmer's tie order).  Reproduces every alignment record (coordinates and
+ *                                 error counts) of the nucmer output files the reference's tests hold; this is what replaces
+ *                                 pyani's `nucmer` job (pyani/anim.py:240-289).
+ *   PG_EXTENDER_BANDED64          the round-1/2 extender: fixed 64-diagonal band, per-chain searches on one LANE each, junction
+ *                                 rules calibrated on fixtures.  ~3 x less DP work, NOT exact: 99.5 % of those records, identity
+ *                                 within 4e-5 on them and up to 3.3e-4 on genomes it was not calibrated on.  Opt-in only. */
+#define PG_EXTENDER_NUCMER 0
+#define PG_EXTENDER_BANDED64 1
+int pg_anim_set_extender(pg_ctx* ctx, int extender);
+
 /* Work-memory budget of pg_anim_pairs: at most max_pairs ordered pairs and max_matches exact matches in flight (about 264 bytes
  * of device scratch per match, grown on demand; default 131072 pairs / 512 Mi matches, split over the context's two workers =
  * launches of up to 65536 pairs / 256 Mi matches, ~68 GB each).  Larger calls are split transparently; results do not depend on

@@ -17,6 +17,7 @@
 #include <thread>
 #include <vector>
 #include "pg_anim_core.h"
+#include "pg_nucmer_core.h"
 using namespace pga;
 
 namespace {
@@ -113,7 +114,8 @@ struct Result {   // = pg_anim_result (include/pyani_gpu.h)
   int32_t reserved;
 };
 
-Result run_pair(const Genome& G, const Genome& H, int filter_1to1, int maxmatch) {
+// extender: 0 = the postnuc statement (pg_nucmer_core.h: MUMmer's own extension algorithm, scalar engine), 1 = banded64
+Result run_pair(const Genome& G, const Genome& H, int filter_1to1, int maxmatch, int extender) {
   const SeqView R = G.view();
   std::vector<Aln> alns;
   std::vector<int32_t> a_rrec, a_qrec;
@@ -142,6 +144,28 @@ Result run_pair(const Genome& G, const Genome& H, int filter_1to1, int maxmatch)
     std::vector<int32_t> co(n_chains);
     for (int i = 0; i < n_chains; ++i) co[i] = i;
     std::sort(co.begin(), co.end(), [&](int a, int b) { return chain_before(chains.data(), cm.data(), a, b); });
+    if (extender == 0) {
+      const int cap = 1 << 14;   // widest anti-diagonal: MAX_ALIGNMENT_LENGTH + 1 cells
+      std::vector<pgn::Cell> d0(cap), d1(cap), d2(cap);
+      pgn::ScalarEngine<SeqView, StrandView> eng{R, Q, d0.data(), d1.data(), d2.data(), cap};
+      std::vector<uint8_t> fused(n_chains + 1);
+      std::vector<pgn::PnAln> al(n_chains + 1);
+      int na = pgn::postnuc_unit(eng, chains.data(), cm.data(), co.data(), n_chains,
+          [&](int c, int32_t& rl, int32_t& rh, int32_t& ql, int32_t& qh) {
+            rl = G.rec_start[chains[c].rrec]; rh = G.rec_start[chains[c].rrec + 1] - 1;
+            ql = H.rec_start[chains[c].qrec]; qh = H.rec_start[chains[c].qrec + 1] - 1;
+            if (strand) { const int32_t a = (int32_t)H.len - qh, b = (int32_t)H.len - ql; ql = a; qh = b; } },
+          fused.data(), al.data(), (int)al.size());
+      if (na < 0) na = -1 - na;
+      for (int i = 0; i < na; ++i) {
+        Aln a{al[i].sA, al[i].eA + 1, al[i].sB, al[i].eB + 1, al[i].errors, strand, 0};
+        a_rrec.push_back(record_of(G.rec_start.data(), (int)G.rec_start.size() - 1, a.rs));
+        if (strand) { const int32_t qs = (int32_t)H.len - a.qe, qe = (int32_t)H.len - a.qs; a.qs = qs; a.qe = qe; }
+        a_qrec.push_back(record_of(H.rec_start.data(), nq, a.qs));
+        alns.push_back(a);
+      }
+      continue;
+    }
     std::vector<ChainFwd> fw(n_chains);
     std::vector<ChainBwd> bw(n_chains);
     std::vector<int32_t> prev_of(n_chains, -1), next_of(n_chains, -1), r_lo(n_chains), r_hi(n_chains), q_lo(n_chains), q_hi(n_chains);
@@ -197,7 +221,7 @@ extern "C" {
 // pyani's runner does it, run_multiprocessing.py:130-144).  Returns 0.
 int anim_cpu_pairs(const uint8_t* const* seqs, const uint64_t* const* rec_offs, const uint32_t* n_recs, uint32_t n_genomes,
                    const int32_t* ref_ids, const int32_t* qry_ids, uint32_t n_pairs, int maxmatch, int filter_1to1, int threads,
-                   Result* out, double* seconds_out) {
+                   int extender, Result* out, double* seconds_out) {
   std::vector<Genome> G(n_genomes);
   std::vector<char> used(n_genomes, 0);
   for (uint32_t i = 0; i < n_pairs; ++i) { used[ref_ids[i]] = 1; used[qry_ids[i]] = 1; }
@@ -216,7 +240,7 @@ int anim_cpu_pairs(const uint8_t* const* seqs, const uint64_t* const* rec_offs, 
     pool.emplace_back([&]() {
       for (uint32_t i; (i = next++) < n_pairs;) {
         const auto t0 = std::chrono::steady_clock::now();
-        out[i] = run_pair(G[ref_ids[i]], G[qry_ids[i]], filter_1to1, maxmatch);
+        out[i] = run_pair(G[ref_ids[i]], G[qry_ids[i]], filter_1to1, maxmatch, extender);
         if (seconds_out) seconds_out[i] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
       }
     });

@@ -33,7 +33,7 @@ def build_oracle(force=False) -> Path:
 def build_anim_cpu(force=False) -> Path:
     core = ROOT / "pyani_amd" / "csrc" / "pg_anim_core.h"
     src = HERE / "anim_cpu.cpp"
-    if force or not _newer(ANIM_CPU_LIB, [src, core]):
+    if force or not _newer(ANIM_CPU_LIB, [src, core, core.with_name("pg_nucmer_core.h")]):
         _run(["g++", "-O2", "-std=c++17", "-pthread", "-fPIC", "-shared", f"-I{core.parent}", "-o", ANIM_CPU_LIB, src])
     return ANIM_CPU_LIB
 

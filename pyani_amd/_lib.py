@@ -11,6 +11,7 @@ K_TETRA_COUNT, K_TETRA_FINALIZE, K_TETRA_STATS, K_TETRA_PAIRS = 0, 1, 2, 3
 (K_ANIM_SEED, K_ANIM_HIT, K_ANIM_CLUSTER, K_ANIM_GAPS, K_ANIM_EXTLANE, K_ANIM_EXTEND, K_ANIM_FINISH) = 4, 5, 6, 7, 8, 9, 10
 K_ANIB_BUCKET, K_ANIB_FRAG = 11, 12
 K_COUNT = 13
+EXTENDER_NUCMER, EXTENDER_BANDED64 = 0, 1
 
 # every symbol declared in include/pyani_gpu.h: (name, restype, argtypes)
 _vp, _i32, _u32, _u64, _int = ctypes.c_void_p, ctypes.c_int32, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_int
@@ -40,6 +41,7 @@ SIGNATURES = {
     "pg_anim_pairs": (_int, [_vp, _vp, _vp, _u64, _int, _int, _vp]),
     "pg_anim_reduce": (_int, [_vp, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _vp]),
     "pg_anim_set_batch_budget": (_int, [_vp, _u32, ctypes.c_uint64]),
+    "pg_anim_set_extender": (_int, [_vp, _int]),
     "pg_anim_pair_alignments": (_int, [_vp, _i32, _i32, _vp, _u32, _P(_u32)]),
     "pg_anib_reduce": (_int, [_vp, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pg_anib_pairs": (_int, [_vp, _vp, _vp, _u64, _u32, _vp]),

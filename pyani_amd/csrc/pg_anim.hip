@@ -30,6 +30,7 @@
 #include <tuple>
 #include "pg_internal.h"
 #include "pg_anim_core.h"
+#include "pg_nucmer_core.h"
 #include "pg_anib_core.h"
 
 using namespace pga;
@@ -73,6 +74,7 @@ __device__ __forceinline__ void get16(const uint32_t* __restrict__ codes, const 
 #include "pga_cluster.inc"
 #include "pga_dp_wave.inc"
 #include "pga_dp_lane.inc"
+#include "pga_postnuc.inc"
 #include "pga_finish.inc"
 #include "pga_frag.inc"
 
@@ -138,6 +140,13 @@ struct AnimScratch {
   RangeOut* range_out = nullptr;
   size_t big_cap = 0, range_cap = 0;
   bool lds_attr_set = false;        // anim_seed_kernel's dynamic-LDS limit has been raised on this context's device
+  // A4x, the postnuc extension stage (pga_postnuc.inc)
+  pgn::PnAln* pn = nullptr;         // per-unit alignment lists, sliced by moff like the per-match arrays
+  uint8_t* pn_fused = nullptr;      // per chain: already extended / fused / shadowed
+  int32_t* pn_n = nullptr;          // per unit: alignments (< 0: capacity)
+  uint32_t* pn_cursor = nullptr;    // unit hand-out counter of the persistent waves
+  uint32_t* pn_gscratch = nullptr;  // [waves][PN_GLOBAL_WORDS] anti-diagonals too wide for LDS
+  size_t pn_cap = 0, pn_units = 0, pn_waves = 0;
   // fragment mode (ANIb)
   int32_t* fr_tables = nullptr;     // frag_pos | frag_len | rec_frag0 of every distinct query genome of the batch
   FragPair* fr_pairs = nullptr;
@@ -612,7 +621,30 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
   std::vector<uint32_t> choff((size_t)n_units + 1, 0);
   for (uint32_t u = 0; u < n_units; ++u) choff[u + 1] = choff[u] + (uint32_t)nch[u];
   const size_t n_wl = choff[n_units];
-  if (n_wl) {
+  const bool postnuc = ctx->anim_extender == PG_EXTENDER_NUCMER;
+  if (postnuc) {
+    // A4x: MUMmer's own extension algorithm, one wave per unit (persistent waves, units handed out longest first would be
+    // better still: a unit's time is ~ its clusters; the cursor takes them in batch order)
+    const size_t Mp = (M + 15) & ~(size_t)15;
+    if (Mp > A->pn_cap) {
+      if ((rc = regrow(ctx, A->pn, Mp))) return rc;
+      if ((rc = regrow(ctx, A->pn_fused, Mp))) return rc;
+      A->pn_cap = Mp;
+    }
+    if (n_units > A->pn_units) { if ((rc = regrow(ctx, A->pn_n, (size_t)n_units + n_units / 2))) return rc; A->pn_units = (size_t)n_units + n_units / 2; }
+    if (!A->pn_cursor && (rc = regrow(ctx, A->pn_cursor, 4))) return rc;
+    const uint32_t pn_waves = (uint32_t)ctx->num_cu * 12u;   // 12 KiB of LDS each: 12 per CU
+    if (pn_waves > A->pn_waves) { if ((rc = regrow(ctx, A->pn_gscratch, (size_t)pn_waves * PN_GLOBAL_WORDS))) return rc; A->pn_waves = pn_waves; }
+    PG_HIP(ctx, hipMemsetAsync(A->pn_cursor, 0, 4, cur_stream(ctx)));
+    pg_prof_begin(ctx, PG_K_ANIM_EXTEND);
+    if (n_wl)
+      hipLaunchKernelGGL(anim_postnuc_kernel, dim3(pn_waves < n_units ? pn_waves : n_units), dim3(64), 0, cur_stream(ctx), A->refs_d, A->units_d,
+                         n_units, O, A->pn_cursor, A->pn, A->pn_fused, A->pn_n, A->pn_gscratch);
+    else
+      PG_HIP(ctx, hipMemsetAsync(A->pn_n, 0, (size_t)n_units * 4, cur_stream(ctx)));
+    pg_prof_end(ctx);
+  }
+  if (n_wl && !postnuc) {
     if (n_wl > A->wl) { if ((rc = regrow(ctx, A->wl_d, n_wl + n_wl / 2))) return rc; A->wl = n_wl + n_wl / 2; }
     uint32_t* choff_d = A->choff_d;
     PG_HIP(ctx, hipMemcpyAsync(choff_d, choff.data(), choff.size() * 4, hipMemcpyHostToDevice, cur_stream(ctx)));
@@ -709,7 +741,7 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
   }
   pg_prof_begin(ctx, PG_K_ANIM_FINISH);
   hipLaunchKernelGGL(anim_finish_kernel, dim3(n_pairs), dim3(64), 0, cur_stream(ctx), A->refs_d, A->units_d, n_pairs,
-                     O, A->fw, A->bw, A->S, filter_1to1, A->out);
+                     O, A->fw, A->bw, postnuc ? A->pn : nullptr, A->pn_n, A->S, filter_1to1, A->out);
   pg_prof_end(ctx);
   PG_HIP(ctx, hipGetLastError());
   PG_HIP(ctx, hipMemcpyAsync(out_host, A->out, n_pairs * sizeof(pg_anim_result), hipMemcpyDeviceToHost, cur_stream(ctx)));

@@ -734,6 +734,12 @@ int pg_anim_set_batch_budget(pg_ctx* ctx, uint32_t max_pairs, uint64_t max_match
   return PG_OK;
 }
 
+int pg_anim_set_extender(pg_ctx* ctx, int extender) {
+  if (!ctx || (extender != PG_EXTENDER_NUCMER && extender != PG_EXTENDER_BANDED64)) return pg_fail(ctx, PG_E_ARG, "bad argument");
+  ctx->anim_extender = extender;
+  return PG_OK;
+}
+
 int pg_anim_pairs(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_ids, uint64_t n_pairs, int maxmatch,
                   int filter_1to1, pg_anim_result* out) {
   if (!ctx || (n_pairs && (!ref_ids || !qry_ids || !out))) return pg_fail(ctx, PG_E_ARG, "bad argument");

@@ -74,6 +74,28 @@ PG_HD Cell cell_update(bool hasL, const Cell& L, bool hasU, const Cell& U, bool 
   return c;
 }
 
+// ---- forced alignments: the whole rectangle, computed as a certified band ------------------------------------------------
+// A FORCED alignment (the forward re-alignment of a backward extension, up to 10 000 x 10 000) is the optimal global path of its
+// rectangle under the tie order above; MUMmer fills the whole rectangle (no trimming, no break).  The same path comes out of
+// the cells within w diagonals of the corner-to-corner span [min(0, M - N), max(0, M - N)] whenever every path that leaves
+// them scores strictly less than the score S_w found inside: such a path spends at least |M - N| + 2 (w + 1) gap bases in at
+// least two runs, so it scores at most  3 (min(N, M) - (w + 1)) - 7 (|M - N| + 2 (w + 1)) - 6.  If S_w beats that bound, the
+// optimal path, every comparison along it (a competitor's banded value is <= its full value, which lost under the same tie
+// order) and therefore the riding error count are those of the full rectangle; otherwise w doubles.  Near-identical genomes
+// certify at w = 32 where the rectangle has 10^8 cells.
+constexpr int32_t FORCED_BAND_FIRST = 32;
+PG_HD int64_t forced_outside_bound(int32_t N, int32_t M, int32_t w) {
+  const int64_t mn = N < M ? N : M, df = N < M ? M - N : N - M;
+  return (int64_t)GOOD_SCORE * (mn - (w + 1)) + (int64_t)CONT_GAP_SCORE * (df + 2 * (int64_t)(w + 1)) + 2 * (OPEN_GAP_SCORE - CONT_GAP_SCORE);
+}
+// band of a forced run in cell coordinates: diagonal k = j - i = 2 j - Dct within [kmin - w, kmax + w]
+PG_HD void forced_band_clip(int32_t Dct, int32_t N, int32_t M, int32_t w, int32_t& lo, int32_t& hi) {
+  const int32_t kmin = (M - N < 0 ? M - N : 0) - w, kmax = (M - N > 0 ? M - N : 0) + w;
+  const int32_t blo = (Dct + kmin + 1) >> 1, bhi = (Dct + kmax) >> 1;   // ceil((Dct + kmin) / 2), floor((Dct + kmax) / 2)
+  if (lo < blo) lo = blo;
+  if (hi > bhi) hi = bhi;
+}
+
 // ---- the scalar engine (host statement; also the definition the wave engine follows cell for cell) -----------------------
 // SEQ: a_ok(p) / a_base(p) / b_ok(p) / b_base(p) on stream positions (b: strand coordinates).
 template <typename RefT, typename QryT>
@@ -90,6 +112,19 @@ struct ScalarEngine {
   // the target corner was reached; Aend / Bend = the finish position; errors = errors of the path to it (not in SEARCH mode
   // — the value is computed anyway and ignored by the callers).
   PG_HD bool align(int32_t Astart, int32_t& Aend, int32_t Bstart, int32_t& Bend, unsigned m_o, int32_t& errors) {
+    if (!(m_o & FORCED_BIT)) return run(Astart, Aend, Bstart, Bend, m_o, -1, errors);
+    const bool fwd = m_o & DIRECTION_BIT;
+    const int32_t N = fwd ? Aend - Astart + 1 : Astart - Aend + 1, M = fwd ? Bend - Bstart + 1 : Bstart - Bend + 1;
+    for (int32_t w = FORCED_BAND_FIRST;; w *= 2) {
+      int32_t a = Aend, b = Bend, score = 0;
+      const bool whole = w >= (N > M ? N : M);
+      const bool reached = run(Astart, a, Bstart, b, m_o, whole ? -1 : w, errors, &score);
+      if (overflow || whole || (reached && (int64_t)score > forced_outside_bound(N, M, w))) { Aend = a; Bend = b; return reached; }
+    }
+  }
+  // band_w < 0: MUMmer's own band (dynamic, trimmed unless forced); >= 0: a forced run confined to the certified band
+  PG_HD bool run(int32_t Astart, int32_t& Aend, int32_t Bstart, int32_t& Bend, unsigned m_o, int32_t band_w, int32_t& errors,
+                 int32_t* score_out = nullptr) {
     const bool fwd = m_o & DIRECTION_BIT, forced = m_o & FORCED_BIT;
     const int32_t N = fwd ? Aend - Astart + 1 : Astart - Aend + 1, M = fwd ? Bend - Bstart + 1 : Bstart - Bend + 1;
     Cell *p2 = d0, *p1 = d1, *cur = d2;
@@ -104,6 +139,7 @@ struct ScalarEngine {
       if (lo < 0) lo = 0;
       if (hi > M) hi = M;
       if (hi > Dct) hi = Dct;
+      if (band_w >= 0) forced_band_clip(Dct, N, M, band_w, lo, hi);
       if (lo > hi) break;
       if (hi - lo + 1 > cap) { overflow = 1; break; }
       for (int32_t j = lo; j <= hi; ++j) {
@@ -140,6 +176,7 @@ struct ScalarEngine {
     Aend = fwd ? Astart + fi - 1 : Astart - fi + 1;
     Bend = fwd ? Bstart + fj - 1 : Bstart - fj + 1;
     errors = (int32_t)w_errors(fin_w);
+    if (score_out) *score_out = w_score(fin_w);
     return reached;
   }
 };

@@ -172,6 +172,11 @@ class Engine:
                                            out.ctypes.data))
         return out
 
+    def anim_set_extender(self, extender: str = "nucmer") -> None:
+        """"nucmer" (default): MUMmer's own postnuc algorithm, exact; "banded64": the approximate fixed-band extender."""
+        which = {"nucmer": _lib.EXTENDER_NUCMER, "banded64": _lib.EXTENDER_BANDED64}[extender]
+        self._check(self.lib.pg_anim_set_extender(self._h, which))
+
     def anim_set_batch_budget(self, max_pairs: int, max_matches: int) -> None:
         self._check(self.lib.pg_anim_set_batch_budget(self._h, int(max_pairs), int(max_matches)))
 

@@ -1,0 +1,77 @@
+"""CPU: the nucmer oracle (oracle/nucmer_oracle.cpp — an independent restatement of MUMmer 3.23's mummer -mum / mgaps / postnuc
+pipeline, with traceback) and the product's scalar statement of the extension stage (pyani_amd/csrc/pg_nucmer_core.h through
+tools/anim_debug/anim_debug --exact: the engine's own seeding and clustering code + pgn::postnuc_unit with riding error counts)
+against the real nucmer output files the reference's tests hold (tests/golden/anim/**):
+
+  * every alignment record of the .delta file — coordinates and error count — and no other record;
+  * for the oracle, every indel offset list too (the body of the .delta file);
+  * oracle == statement, record for record.
+
+A sample of the 43 runs keeps the CPU suite short (the Blochmannia pairs, the two draft genomes of Group_2 in both directions —
+never used for any choice — and the 85 % Caulobacter pair whose forced re-alignments lose their way if the band is trimmed);
+tools/anim_host_fixture_check.py [--oracle] runs all 43: 25 192 of 25 192 records for either program."""
+import gzip
+import subprocess
+import sys
+
+import pytest
+
+from tests.conftest import GOLD, ROOT
+
+sys.path.insert(0, str(ROOT / "oracle"))
+import anim_oracle  # noqa: E402
+
+SAMPLE = [("blochmannia", None), ("group2", None), ("caulobacter", "NC_014100_vs_NC_002696"), ("caulobacter", "NC_002696_vs_NC_011916")]
+
+
+@pytest.fixture(scope="module")
+def programs():
+    oracle = ROOT / "oracle" / "_build" / "nucmer_oracle"
+    oracle.parent.mkdir(exist_ok=True)
+    subprocess.run(["g++", "-O2", "-std=c++17", str(ROOT / "oracle" / "nucmer_oracle.cpp"), "-o", str(oracle)], check=True)
+    stmt = ROOT / "tools" / "anim_debug" / "anim_debug"
+    subprocess.run(["g++", "-O2", "-std=c++17", f"-I{ROOT / 'pyani_amd' / 'csrc'}", str(stmt) + ".cpp", "-o", str(stmt)], check=True)
+    return oracle, stmt
+
+
+def _runs(genome_dir):
+    for grp, only in SAMPLE:
+        for f in sorted((GOLD / "anim" / grp).glob("*.delta.gz")):
+            a, b = f.name[:-len(".delta.gz")].split("_vs_")
+            if only and f.name != only + ".delta.gz":
+                continue
+            if a in genome_dir[grp] and b in genome_dir[grp]:
+                yield grp, f, genome_dir[grp][a], genome_dir[grp][b]
+
+
+def _records(stdout, with_indels=False):
+    recs, cur = {}, None
+    for line in stdout.splitlines():
+        t = line.split()
+        if t and t[0] == "ALN":
+            cur = (t[1], t[2], int(t[3]), int(t[4]), int(t[5]), int(t[6]), int(t[7]))
+            recs[cur] = []
+        elif with_indels and cur is not None and t and t[0] != "0" and len(t) == 1:
+            recs[cur].append(int(t[0]))
+    return recs
+
+
+def test_oracle_and_statement_reproduce_mummer_output(programs, genome_dir):
+    oracle, stmt = programs
+    n_runs = n_records = 0
+    for grp, f, pa, pb in _runs(genome_dir):
+        want = {(x.ref_id, x.qry_id, x.rs, x.re, x.qs, x.qe, x.errors): list(x.indels) for x in anim_oracle.read_delta(f)[0]}
+        got_o = _records(subprocess.run([str(oracle), str(pa), str(pb), "--delta"], capture_output=True, text=True, check=True).stdout, True)
+        assert got_o == want, (f.name, len(got_o), len(want), sorted(set(got_o) ^ set(want))[:4])
+        out = subprocess.run([str(stmt), str(pa), str(pb), "--dump", "--exact"], capture_output=True, text=True, check=True).stdout
+        got_s = _records(out)
+        assert set(got_s) == set(want), (f.name, sorted(set(got_s) ^ set(want))[:4])
+        # the statement also applies the 1-to-1 filter and reduces: its first line is the parse_delta tuple of the .filter file
+        flt = GOLD / "anim" / grp / f.name.replace(".delta.gz", ".filter.gz")
+        if flt.exists():
+            m = anim_oracle.parse_delta(flt)
+            t = out.splitlines()[0].split()
+            assert (int(t[0]), int(t[1]), float(t[2]), int(t[3])) == (m[0], m[1], m[2], m[3]), f.name
+        n_runs += 1
+        n_records += len(want)
+    assert n_runs == 19 and n_records >= 1690

@@ -1,16 +1,15 @@
-"""GPU: the reference's ANIm concordance test (tests/test_concordance.py:168-203) — the three genomes of
-tests/fixtures/concordance against JSpecies' published ANIm values, at the reference's tolerance of 0.1 percentage points.
+"""GPU: the reference's concordance tests (tests/test_concordance.py) — the three genomes of tests/fixtures/concordance
+against JSpecies' published tables (tests/golden/ref_targets/jspecies_output.tab), at the reference's own tolerances:
 
-The reference runs every pair in both directions (anim.py:216-233) and compares all six cells.  The tuples below are those of
-the scalar HOST build of the same core (tools/anim_debug/anim_debug), which the GPU pipeline has to reproduce exactly.
-Against JSpecies: 84.1021 vs 84.11 / 84.09 and 84.5383 vs 84.53 / 84.55 (margins > 0.08); the 98 % pair gives 98.2907 and
-98.2967 against JSpecies' 98.19: 0.1007 and 0.1067, OUTSIDE the reference's tolerance by 0.0007 / 0.0067 points.  Round 1's
-rules gave 98.2803 / 98.2827 (inside); every rule corrected in round 2 on MUMmer output the engine had never seen (DESIGN.md §8
-"Out of sample": records exact 95.5 % -> 99.5 %, identity within 5e-5 = 0.005 points of MUMmer's) moved this pair up, by 0.014
-points in all.  MUMmer's own .delta for these genomes is not among the reference's fixtures, so which side of 98.29 nucmer 3.23
-lands on is not known here — the engine's measured distance to MUMmer (up to 0.005 points on the 85 % pairs it could be measured on) is of the size of its
-distance to the bound.
-The strict criterion is kept as a non-strict xfail and everything that IS known is asserted in the test before it."""
+  ANIm   test_anim_concordance   (:168-203)  six cells of percentage_identity x 100 within 0.1
+  TETRA  test_tetra_concordance  (:290-302)  correlation matrix within 0.1
+  ANIb   test_anib_concordance   (:207-254)  cells >= 90 within 0.2, cells below within 5
+
+These genomes are the engine's HOLD-OUT: no constant of the search was chosen with them.  The ANIm tuples below
+are those of the scalar host statement of MUMmer's algorithm (tools/anim_debug/anim_debug --exact), which the GPU has to
+reproduce exactly; against JSpecies the 98 % pair gives 98.2580 / 98.2605 vs 98.19 (0.068 / 0.071 inside the 0.1).  Round 2's
+banded64 extender gave 98.2907 / 98.2967 there — outside the tolerance, and 3.3e-4 away from what MUMmer's own algorithm
+computes: the reason the extension stage was rebuilt as a restatement of postnuc instead of being fitted further."""
 import csv
 
 import pytest
@@ -19,21 +18,22 @@ from tests.conftest import GOLD
 
 pytestmark = pytest.mark.gpu
 
-TOLERANCE_ANIM = 0.1   # tests/test_concordance.py:157-159
+TOLERANCE_ANIM, TOLERANCE_TETRA = 0.1, 0.1                                   # tests/test_concordance.py:156-165
+TOLERANCE_ANIB_HI, TOLERANCE_ANIB_LO, THRESHOLD_ANIB_LO_HI = 0.2, 5, 90     # tests/test_concordance.py:118-153
 A, B, C = ("GCF_000011325.1_ASM1132v1_genomic", "GCF_000227605.2_ASM22760v2_genomic", "GCF_002243555.1_ASM224355v1_genomic")
-HOST_STATEMENT = {     # (nucmer reference, nucmer query) -> parse_delta tuple from the host build
+HOST_STATEMENT = {     # (nucmer reference, nucmer query) -> parse_delta tuple of the host statement
     (A, B): (37213, 37174, 0.8410206084396468, 5913),
     (B, A): (37174, 37213, 0.8410206084396468, 5913),
-    (A, C): (2862006, 2864368, 0.9829068370569779, 49260),
-    (C, A): (2861836, 2859532, 0.9829666693787248, 49512),
+    (A, C): (2862738, 2864818, 0.982580474824455, 49912),
+    (C, A): (2864687, 2862679, 0.9826050264283885, 49840),
     (B, C): (38970, 39016, 0.8453825045520991, 6029),
     (C, B): (39016, 38970, 0.8453825045520991, 6029),
 }
 
 
-def _jspecies_anim():
+def _jspecies(block):
     rows = list(csv.reader(open(GOLD / "ref_targets" / "jspecies_output.tab"), delimiter="\t"))
-    start = next(i for i, r in enumerate(rows) if r and r[0].strip() == "ANIm")
+    start = next(i for i, r in enumerate(rows) if r and r[0].strip() == block)
     names = [n[:-4] for n in rows[start + 1][1:] if n]
     want = {}
     for r in rows[start + 2: start + 2 + len(names)]:
@@ -44,33 +44,60 @@ def _jspecies_anim():
 
 
 @pytest.fixture(scope="module")
-def concordance_run(genome_dir):
-    from pyani_amd import anim
+def engine():
     from pyani_amd.engine import Engine
     eng = Engine(0)
-    try:
-        return anim.calculate_anim_pairs(list(genome_dir["concordance"].values()), engine=eng)
-    finally:
-        eng.close()
+    yield eng
+    eng.close()
 
 
-def test_anim_concordance_tuples_and_margins(concordance_run):
+@pytest.fixture(scope="module")
+def concordance_run(genome_dir, engine):
+    from pyani_amd import anim
+    return anim.calculate_anim_pairs(list(genome_dir["concordance"].values()), engine=engine)
+
+
+def test_anim_concordance_tuples(concordance_run):
     res, lengths = concordance_run
-    want = _jspecies_anim()
-    assert len(want) == 6 and set(res) == set(want) == set(HOST_STATEMENT)
+    assert set(res) == set(HOST_STATEMENT)
     for pair, tup in HOST_STATEMENT.items():
         assert tuple(res[pair][:2]) == tup[:2] and res[pair][3] == tup[3], (pair, res[pair])
-        assert res[pair][2] == pytest.approx(tup[2], abs=1e-12)
-    off = {pair: abs(100.0 * res[pair][2] - pid) for pair, pid in want.items()}
-    assert sum(d <= TOLERANCE_ANIM for d in off.values()) == 4 and max(off.values()) < 0.108, off
-    assert sorted(p for p, d in off.items() if d > TOLERANCE_ANIM) == [(A, C), (C, A)]
+        assert res[pair][2] == tup[2], (pair, res[pair])
 
 
-@pytest.mark.xfail(strict=False, reason="the reference's criterion on all six cells: the 98 % pair is 98.2907 / 98.2967 against JSpecies' 98.19 "
-                                        "= 0.1007 / 0.1067 > 0.1 (see the module docstring); the other four cells are inside")
 def test_anim_concordance_with_jspecies(concordance_run):
+    """The reference's criterion, on the matrix the reference's test compares (legacy assembly: anim.py:415-497)."""
     from pyani_amd import anim
     res, lengths = concordance_run
-    results = anim.assemble_legacy_results(res, lengths)   # the matrix the reference test compares
-    for (q, s), pid in _jspecies_anim().items():
+    want = _jspecies("ANIm")
+    assert len(want) == 6
+    results = anim.assemble_legacy_results(res, lengths)
+    for (q, s), pid in want.items():
         assert abs(100.0 * float(results.percentage_identity.loc[q, s]) - pid) <= TOLERANCE_ANIM, (q, s)
+    # and every ordered comparison on its own (the v0.3 run matrices keep both directions)
+    for (q, s), pid in want.items():
+        assert abs(100.0 * res[(q, s)][2] - pid) <= TOLERANCE_ANIM, (q, s, res[(q, s)][2])
+
+
+def test_tetra_concordance(genome_dir, engine):
+    from pyani_amd import tetra
+    files = list(genome_dir["concordance"].values())
+    corr = tetra.calculate_correlations(tetra.calculate_tetra_zscores(files, engine=engine), engine=engine)
+    want = _jspecies("Tetra")
+    assert len(want) == 6
+    for (q, s), r in want.items():
+        assert abs(float(corr.loc[q, s]) - r) <= TOLERANCE_TETRA, (q, s, float(corr.loc[q, s]))
+
+
+def test_anib_concordance(genome_dir, engine):
+    from pyani_amd import anib
+    res, lengths = anib.calculate_anib_pairs(list(genome_dir["concordance"].values()), engine=engine)
+    pid = anib.process_blast_results(res, lengths)["percentage_identity"] * 100.0
+    want = _jspecies("ANIb")
+    assert len(want) == 6
+    for (q, s), target in want.items():
+        got = float(pid.loc[q, s])
+        # the reference masks result and target by the threshold separately: a cell counts as "high" only where both are
+        lo_r, hi_r = (got, 0.0) if got < THRESHOLD_ANIB_LO_HI else (0.0, got)
+        lo_t, hi_t = (target, 0.0) if target < THRESHOLD_ANIB_LO_HI else (0.0, target)
+        assert abs(lo_r - lo_t) <= TOLERANCE_ANIB_LO and abs(hi_r - hi_t) <= TOLERANCE_ANIB_HI, (q, s, got, target)

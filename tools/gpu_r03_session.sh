@@ -1,0 +1,38 @@
+#!/bin/bash
+# Round-3 GPU session steps (everything under gpurun_out/r03/).  Usage: tools/gpu_r03_session.sh step...
+#   exact   the exactness tests of the postnuc extender (fixtures, concordance, synthetic statement)
+#   tests   the whole -m gpu suite
+#   c3 / c4 bench lines (C3: 200 genomes; C4: the driver's default, few steps)
+#   bench   the driver's command
+#   prof    rocprofv3 kernel trace + FETCH_SIZE / WRITE_SIZE passes of the bench command (short)
+R=$(pwd); O=$R/gpurun_out/r03; mkdir -p $O; export TMPDIR=/tmp
+for w in "$@"; do
+case $w in
+exact)
+  timeout 1500 python -m pytest tests/test_anim_oos_gpu.py tests/test_zz_concordance_gpu.py tests/test_anim_gpu.py -m gpu -q --timeout 900 > $O/pytest_exact.log 2>&1
+  echo "pytest rc=$?" >> $O/pytest_exact.log; tail -25 $O/pytest_exact.log ;;
+tests)
+  timeout 2400 python -m pytest tests -m gpu -q --timeout 1200 > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.log
+  tail -25 $O/pytest_gpu.log ;;
+c3)
+  timeout 900 python bench.py --gpus 1 --genomes 200 --seed 20250228 --steps 3 --warmup 1 --no-tetra > $O/bench_c3.log 2> $O/bench_c3.err; echo "c3 rc=$?"
+  grep '^{' $O/bench_c3.log > $O/bench_c3.json; cut -c1-2500 $O/bench_c3.json; tail -5 $O/bench_c3.err ;;
+c4)
+  timeout 1200 python bench.py --gpus 1 --steps 2 --warmup 1 --no-tetra --no-cpu-baseline > $O/bench_c4.log 2> $O/bench_c4.err; echo "c4 rc=$?"
+  grep '^{' $O/bench_c4.log > $O/bench_c4.json; cut -c1-2500 $O/bench_c4.json; tail -5 $O/bench_c4.err ;;
+bench)
+  timeout 1500 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_n1.log 2> $O/bench_n1.err; echo "bench rc=$?"
+  grep '^{' $O/bench_n1.log > $O/bench_n1.json; cut -c1-3000 $O/bench_n1.json; tail -5 $O/bench_n1.err ;;
+prof)
+  cd /tmp
+  B="python $R/bench.py --gpus 1 --steps 2 --warmup 1 --no-cpu-baseline --no-tetra"
+  rm -rf $O/kt $O/pmc_fetch $O/pmc_write
+  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt -- $B > $O/kt_bench.log 2>&1
+  timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o pmc -- $B > $O/pmc_fetch.log 2>&1
+  timeout 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o pmc -- $B > $O/pmc_write.log 2>&1
+  cd $R
+  python tools/summarize_anim_profiles.py r03 2>&1 | tail -40
+  find $O -name "*counter_collection.csv" -size +20M -delete; find $O -name "*kernel_trace.csv" -size +20M -delete ;;
+esac
+done
+du -sh $O
