@@ -72,11 +72,19 @@ def _tuple(rec) -> Tuple[int, int, float, int]:
 
 
 def calculate_anim_pairs(infiles: Iterable, engine: Engine = None, nofilter: bool = False, skip_zero: bool = False,
-                         maxmatch: bool = False
+                         maxmatch: bool = False, devices=None, workers=None
                          ) -> Tuple[Dict[Tuple[str, str], Tuple[int, int, float, int]], Dict[str, int]]:
     """All ordered comparisons between the FASTA files (what generate_nucmer_jobs + run_dependency_graph + parse_delta
     produce, anim.py:155-235).  Key (q, s): q is nucmer's reference / pyani's query genome.  Returns (results,
-    genome lengths keyed by stem)."""
+    genome lengths keyed by stem).  devices / workers: several GPUs of this node through a work queue (pyani_amd/multi.py)."""
+    if engine is None and (devices is not None or workers):
+        from . import multi
+        eng = multi.engine_for(devices, workers)
+        try:
+            return calculate_anim_pairs(infiles, eng, nofilter, skip_zero, maxmatch)
+        finally:
+            if isinstance(eng, multi.MultiEngine):
+                eng.close()
     eng = engine or default_engine()
     files = sorted(Path(f) for f in infiles)
     stems = [f.stem for f in files]

@@ -35,42 +35,44 @@ struct PnAln {
 };
 
 // ---- packed DP words ----------------------------------------------------------------------------------------------------
-// One 32-bit word per state: (score + SCORE_BIAS) << 16 | errors.  Scores are compared on the upper half only (MUMmer never
-// looks at errors); 0 = unreachable.  Live scores stay far from both ends of the field: >= best - MAX_DIFF - a few gap steps
-// in a trimmed search, >= -(10 + 7 * 10000) saturating to "unreachable" in a forced one, <= 3 * 10001.
-constexpr uint32_t SCORE_BIAS = 32768u;
-constexpr uint32_t W_HI = 0xFFFF0000u;
-PG_HD uint32_t w_make(int32_t score, uint32_t errors) { return ((uint32_t)(score + (int32_t)SCORE_BIAS) << 16) | errors; }
-PG_HD int32_t w_score(uint32_t w) { return (int32_t)(w >> 16) - (int32_t)SCORE_BIAS; }
-PG_HD uint32_t w_errors(uint32_t w) { return w & 0xFFFFu; }
-PG_HD uint32_t w_gap(uint32_t w, int32_t cost) {   // w + cost (cost < 0), one more error; unreachable stays unreachable
-  const uint32_t c = (uint32_t)(-cost) << 16;
-  return w < c + (1u << 16) ? 0u : w - c + 1u;
+// One 32-bit word per state:  (score + SCORE_BIAS) << 17 | state << 15 | errors.
+// MUMmer compares scores only and breaks ties by state (scoreEdit and maxScore alike: MATCH, then INSERT, then DELETE).  With the
+// state of ORIGIN in the two bits under the score, one unsigned max over the three candidates is exactly that rule — the three
+// candidates of a choice always come from three different states, so the error bits below never decide — and the errors of the
+// chosen path ride along for free.  After a choice the word is re-labelled with the state it now belongs to.
+// A word whose score field is 0 is UNREACHABLE (any low bits).  Fields: 15 bits of score, bias 1024: a trimmed search keeps its
+// live cells within MAX_DIFF + a few gap steps of the best score, which starts at 3, and an alignment of at most 10 001 x 10 001
+// bases cannot score above 30 003; a forced run may push cells below -1024, where they saturate to unreachable (they are
+// thousands of points under the optimum: never on its path).  15 bits of errors: one call aligns at most 20 002 bases.
+constexpr uint32_t SCORE_BIAS = 1024u, SCORE_SHIFT = 17u;
+constexpr uint32_t W_ONE = 1u << SCORE_SHIFT;                 // one score point; also: the smallest live word
+constexpr uint32_t W_STATE = 3u << 15, W_ERR = 0x7FFFu;
+enum : uint32_t { ST_DELETE = 0u << 15, ST_INSERT = 1u << 15, ST_MATCH = 2u << 15 };   // DELETE consumes a B base, INSERT an A base
+PG_HD uint32_t w_make(int32_t score, uint32_t errors, uint32_t state) { return ((uint32_t)(score + (int32_t)SCORE_BIAS) << SCORE_SHIFT) | state | errors; }
+PG_HD int32_t w_score(uint32_t w) { return (int32_t)(w >> SCORE_SHIFT) - (int32_t)SCORE_BIAS; }
+PG_HD uint32_t w_errors(uint32_t w) { return w & W_ERR; }
+PG_HD uint32_t w_relabel(uint32_t w, uint32_t state) { return (w & ~W_STATE) | state; }
+PG_HD uint32_t w_gap(uint32_t w, int32_t cost) {   // w + cost (cost < 0) and one more error; unreachable stays unreachable
+  const uint32_t c = (uint32_t)(-cost) << SCORE_SHIFT;
+  return w >= c + W_ONE ? w - c + 1u : 0u;
 }
 PG_HD uint32_t w_step(uint32_t w, bool same) {     // diagonal step from the best state of (i-1, j-1)
-  if (w < (1u << 16)) return 0u;
-  if (same) return w + ((uint32_t)GOOD_SCORE << 16);
-  const uint32_t c = (uint32_t)(-BAD_SCORE) << 16;
-  return w < c + (1u << 16) ? 0u : w - c + 1u;
+  const uint32_t c = (uint32_t)(-BAD_SCORE) << SCORE_SHIFT;
+  const uint32_t hit = w + ((uint32_t)GOOD_SCORE << SCORE_SHIFT), miss = w >= c + W_ONE ? w - c + 1u : 0u;
+  return w >= W_ONE ? (same ? hit : miss) : 0u;
 }
-// scoreEdit: the better of continuing this gap / opening it from the other gap state / from the match state; ties: MATCH,
-// then INSERT, then DELETE.  a = from DELETE, b = from INSERT, c = from MATCH (already charged).
-PG_HD uint32_t w_edit(uint32_t del, uint32_t ins, uint32_t mat) {
-  const uint32_t d = del & W_HI, i = ins & W_HI, m = mat & W_HI;
-  if (d > i) return d > m ? del : mat;
-  return i > m ? ins : mat;
-}
-PG_HD uint32_t w_max(uint32_t del, uint32_t ins, uint32_t mat) { return w_edit(del, ins, mat); }   // maxScore: same order
+PG_HD uint32_t w_max3(uint32_t a, uint32_t b, uint32_t c) { const uint32_t m = a > b ? a : b; return m > c ? m : c; }
 
-struct Cell { uint32_t D, I, M, X; };   // DELETE (consumes a B base), INSERT (an A base), MATCH, X = the best of the three
+struct Cell { uint32_t D, I, M, X; };   // the three states and X = the best of them (labelled with the winner's state)
 
-// One cell from its three neighbours: L = (i, j-1) and U = (i-1, j) on the previous anti-diagonal, G = best state of (i-1, j-1).
-PG_HD Cell cell_update(bool hasL, const Cell& L, bool hasU, const Cell& U, bool hasG, uint32_t G, bool same) {
+// One cell from its three neighbours: L = (i, j-1) and U = (i-1, j) on the previous anti-diagonal, G = best state of (i-1, j-1);
+// a neighbour that does not exist (outside its anti-diagonal's computed range, or the matrix) is all zeros.
+PG_HD Cell cell_update(const Cell& L, const Cell& U, uint32_t G, bool same) {
   Cell c;
-  c.D = hasL ? w_edit(w_gap(L.D, CONT_GAP_SCORE), w_gap(L.I, OPEN_GAP_SCORE), w_gap(L.M, OPEN_GAP_SCORE)) : 0u;
-  c.I = hasU ? w_edit(w_gap(U.D, OPEN_GAP_SCORE), w_gap(U.I, CONT_GAP_SCORE), w_gap(U.M, OPEN_GAP_SCORE)) : 0u;
-  c.M = hasG ? w_step(G, same) : 0u;
-  c.X = w_max(c.D, c.I, c.M);
+  c.D = w_relabel(w_max3(w_gap(L.D, CONT_GAP_SCORE), w_gap(L.I, OPEN_GAP_SCORE), w_gap(L.M, OPEN_GAP_SCORE)), ST_DELETE);
+  c.I = w_relabel(w_max3(w_gap(U.D, OPEN_GAP_SCORE), w_gap(U.I, CONT_GAP_SCORE), w_gap(U.M, OPEN_GAP_SCORE)), ST_INSERT);
+  c.M = w_relabel(w_step(G, same), ST_MATCH);
+  c.X = w_max3(c.D, c.I, c.M);
   return c;
 }
 
@@ -129,7 +131,7 @@ struct ScalarEngine {
     const int32_t N = fwd ? Aend - Astart + 1 : Astart - Aend + 1, M = fwd ? Bend - Bstart + 1 : Bstart - Bend + 1;
     Cell *p2 = d0, *p1 = d1, *cur = d2;
     int32_t p2lo = 0, p2hi = -1, p1lo = 0, p1hi = 0;
-    p1[0] = Cell{0u, 0u, w_make(0, 0), w_make(0, 0)};
+    p1[0] = Cell{0u, 0u, w_make(0, 0, ST_MATCH), w_make(0, 0, ST_MATCH)};
     int32_t high = -(1 << 30), FinishCt = 0, FinishJ = 0;
     uint32_t high_w = 0;
     int32_t jlo = 0, jhi = 1, Dct;
@@ -148,7 +150,7 @@ struct ScalarEngine {
         const bool hasG = i >= 1 && j >= 1 && j - 1 >= p2lo && j - 1 <= p2hi;
         bool sm = false;
         if (hasG) sm = same(fwd ? (int64_t)Astart + i - 1 : (int64_t)Astart - i + 1, fwd ? (int64_t)Bstart + j - 1 : (int64_t)Bstart - j + 1);
-        const Cell c = cell_update(hasL, hasL ? p1[j - 1 - p1lo] : Cell{0, 0, 0, 0}, hasU, hasU ? p1[j - p1lo] : Cell{0, 0, 0, 0}, hasG,
+        const Cell c = cell_update(hasL ? p1[j - 1 - p1lo] : Cell{0, 0, 0, 0}, hasU ? p1[j - p1lo] : Cell{0, 0, 0, 0},
                                    hasG ? p2[j - 1 - p2lo].X : 0u, sm);
         cur[j - lo] = c;
         const int32_t s = w_score(c.X);

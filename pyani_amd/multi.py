@@ -1,0 +1,215 @@
+"""MultiEngine — one process, several GPUs: the in-product answer to pyani's `--workers` (SURVEY.md §8 e).
+
+pyani spreads its nucmer / blastn jobs over `--workers` CPU cores with a multiprocessing pool
+(`scripts/subcommands/subcmd_anim.py:392-396` -> `run_multiprocessing.run_dependency_graph(jobs, workers=...)`,
+`run_multiprocessing.py:113-152`): independent jobs, handed out as workers fall idle.  Here a "worker" is a GPU: one Engine (one
+libpyani_gpu context) per device, every genome resident on every device (1.9 GB for 1000 x 5 Mb of the 288 GB each has), and the
+ordered-pair list cut into chunks that the devices PULL from a shared queue — one host thread per device, the ctypes calls release
+the GIL — so a device that drew cheap chunks (unrelated pairs cost microseconds, related ones milliseconds: ~60 x apart) simply
+comes back for more.  No data-path collective: results are merged on the host in the caller's order.  The multi-process RCCL
+path (`pyani_amd/parallel.py`, `bench.py --gpus N`: one process per GPU, one all-gather per step) stays what the driver's scaling
+run measures; this class is what `run_anim(..., devices=[...])` and the module functions use.
+
+A chunk keeps a pair and its reverse together (they share their seeding inside one `pg_anim_pairs` call, DESIGN.md §8 "Roles") and
+keeps the pairs of one reference genome together (its seed table is built once per call).  Results do not depend on the number of
+devices or on which device ran what (tests/test_parallel_multi_gpu.py: two engines on GPU 0 == one).
+"""
+import threading
+from collections import defaultdict
+from typing import Iterable, List, Optional, Sequence
+
+import numpy as np
+
+from .engine import Engine
+
+
+def _chunks_by_hub(a: np.ndarray, b: np.ndarray, target: int) -> List[np.ndarray]:
+    """Indices of the pair list grouped so that (x, y) and (y, x) share a chunk and the pairs of one hub genome stay together;
+    chunks of about `target` pairs, heaviest first is not knowable, so: in hub order."""
+    n = len(a)
+    lo, hi = np.minimum(a, b), np.maximum(a, b)
+    # the hub of an unordered pair {lo, hi}: lo when lo + hi is even, hi otherwise — every genome hubs half of its partners
+    hub = np.where(((lo + hi) & 1) == 0, lo, hi)
+    order = np.argsort(hub, kind="stable")
+    bounds = np.flatnonzero(np.diff(hub[order])) + 1
+    groups = np.split(order, bounds)
+    out, cur, size = [], [], 0
+    for g in groups:
+        cur.append(g)
+        size += len(g)
+        if size >= target:
+            out.append(np.concatenate(cur)); cur, size = [], 0
+    if cur:
+        out.append(np.concatenate(cur))
+    assert sum(len(c) for c in out) == n
+    return out
+
+
+class MultiEngine:
+    """Engines on several devices behind the Engine calls the module functions use (genome store, anim_pairs, anib_pairs)."""
+
+    def __init__(self, devices: Sequence[int], chunk_pairs: int = 0):
+        if not devices:
+            raise ValueError("MultiEngine needs at least one device")
+        self.devices = list(devices)
+        self.engines = [Engine(d) for d in self.devices]
+        self.chunk_pairs = int(chunk_pairs)
+        self.last_chunks_per_engine: List[int] = []
+
+    # -- plumbing -------------------------------------------------------------------------------------------------------
+    def close(self):
+        for e in self.engines:
+            e.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _all(self, fn):
+        """fn(engine) on every engine, one thread each; returns the results in engine order, re-raises the first error."""
+        out, err = [None] * len(self.engines), []
+
+        def run(k):
+            try:
+                out[k] = fn(self.engines[k])
+            except BaseException as e:  # noqa: BLE001 — re-raised below
+                err.append(e)
+        ts = [threading.Thread(target=run, args=(k,)) for k in range(len(self.engines))]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        if err:
+            raise err[0]
+        return out
+
+    # -- genome store: replicated ---------------------------------------------------------------------------------------
+    def add_genome(self, seq, rec_off) -> int:
+        ids = [e.add_genome(seq, rec_off) for e in self.engines]
+        assert len(set(ids)) == 1
+        return ids[0]
+
+    def add_fasta(self, path):
+        res = [e.add_fasta(path) for e in self.engines]
+        assert len({r[0] for r in res}) == 1
+        return res[0]
+
+    def add_fasta_batch(self, paths, threads: int = 0):
+        paths = list(paths)
+        res = self._all(lambda e: e.add_fasta_batch(paths, threads))
+        assert all(r == res[0] for r in res)
+        return res[0]
+
+    def genome_count(self) -> int:
+        return self.engines[0].genome_count()
+
+    def genome_length(self, gid: int):
+        return self.engines[0].genome_length(gid)
+
+    def clear_genomes(self):
+        self._all(lambda e: e.clear_genomes())
+
+    def upload(self):
+        self._all(lambda e: e.upload())
+
+    def anim_set_extender(self, extender: str = "nucmer"):
+        for e in self.engines:
+            e.anim_set_extender(extender)
+
+    # -- the work queue ----------------------------------------------------------------------------------------------------
+    def _pull(self, chunks: List[np.ndarray], run_chunk, out: np.ndarray):
+        lock = threading.Lock()
+        nxt = [0]
+        taken = defaultdict(int)
+
+        def worker(e):
+            while True:
+                with lock:
+                    k = nxt[0]
+                    nxt[0] += 1
+                if k >= len(chunks):
+                    return
+                idx = chunks[k]
+                out[idx] = run_chunk(e, idx)
+                taken[id(e)] += 1
+        self._all(worker)
+        self.last_chunks_per_engine = [taken[id(e)] for e in self.engines]
+
+    def _target(self, n: int) -> int:
+        if self.chunk_pairs > 0:
+            return self.chunk_pairs
+        # ~24 chunks per device so that the tail is short, but never launches so small that the GPU idles inside them
+        return max(2048, n // (24 * len(self.engines)) + 1)
+
+    def anim_pairs(self, ref_ids, qry_ids, filter_1to1: bool = True, maxmatch: bool = False) -> np.ndarray:
+        r = np.ascontiguousarray(list(ref_ids), dtype=np.int32)
+        q = np.ascontiguousarray(list(qry_ids), dtype=np.int32)
+        if len(r) != len(q):
+            raise ValueError("ref_ids and qry_ids must have the same length")
+        out = np.zeros(len(r), dtype=Engine.ANIM_DTYPE)
+        if len(r):
+            self._pull(_chunks_by_hub(r, q, self._target(len(r))),
+                       lambda e, idx: e.anim_pairs(r[idx], q[idx], filter_1to1=filter_1to1, maxmatch=maxmatch), out)
+        return out
+
+    def anib_pairs(self, qry_ids, sbj_ids, fragsize: int = 1020) -> np.ndarray:
+        qa = np.ascontiguousarray(list(qry_ids), dtype=np.int32)
+        sa = np.ascontiguousarray(list(sbj_ids), dtype=np.int32)
+        if len(qa) != len(sa):
+            raise ValueError("qry_ids and sbj_ids must have the same length")
+        out = np.zeros(len(qa), dtype=Engine.ANIB_DTYPE)
+        if len(qa):
+            # fragment mode: the fragmented (query) genome is the expensive side to set up — keep its pairs together
+            order = np.argsort(qa, kind="stable")
+            bounds = np.flatnonzero(np.diff(qa[order])) + 1
+            groups, chunks, cur, size = np.split(order, bounds), [], [], 0
+            target = max(64, len(qa) // (24 * len(self.engines)) + 1) if self.chunk_pairs <= 0 else self.chunk_pairs
+            for g in groups:
+                cur.append(g); size += len(g)
+                if size >= target:
+                    chunks.append(np.concatenate(cur)); cur, size = [], 0
+            if cur:
+                chunks.append(np.concatenate(cur))
+            self._pull(chunks, lambda e, idx: e.anib_pairs(qa[idx], sa[idx], fragsize), out)
+        return out
+
+    # -- single-device calls go to the first engine ------------------------------------------------------------------------
+    def anim_pair_alignments(self, ref_id: int, qry_id: int):
+        return self.engines[0].anim_pair_alignments(ref_id, qry_id)
+
+    def anib_pair_rows(self, qry_id: int, sbj_id: int, fragsize: int = 1020):
+        return self.engines[0].anib_pair_rows(qry_id, sbj_id, fragsize)
+
+    def anim_reduce(self, pairs, apply_filter: bool = False):
+        return self.engines[0].anim_reduce(pairs, apply_filter)
+
+    def anib_reduce(self, pairs):
+        return self.engines[0].anib_reduce(pairs)
+
+    def tetra_matrix(self, ids):
+        return self.engines[0].tetra_matrix(ids)
+
+    def tetra_counts(self, ids):
+        return self.engines[0].tetra_counts(ids)
+
+
+def engine_for(devices: Optional[Iterable[int]] = None, workers: Optional[int] = None):
+    """The engine a caller should use: `devices` as given; else `workers` GPUs starting at 0 (pyani's --workers, capped at the
+    GPUs present); else the process-wide single engine."""
+    from .engine import default_engine
+    if devices is None and workers:
+        import ctypes
+        n = ctypes.c_int(0)
+        try:
+            hip = ctypes.CDLL("libamdhip64.so")
+            if hip.hipGetDeviceCount(ctypes.byref(n)) != 0:
+                n.value = 0
+        except OSError:
+            n.value = 0
+        devices = list(range(max(1, min(int(workers), n.value or 1))))
+    if devices is None:
+        return default_engine()
+    devices = list(devices)
+    return MultiEngine(devices) if len(devices) > 1 or devices != [0] else default_engine()

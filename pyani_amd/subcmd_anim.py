@@ -43,9 +43,26 @@ def outfile_path(outdir: Path, qstem: str, sstem: str, nofilter: bool = False) -
 
 
 def run_anim(indir, outdir=None, recovery: bool = False, nofilter: bool = False, maxmatch: bool = False,
-             write_output: bool = False, skip_zero: bool = False, engine: Optional[Engine] = None) -> AnimRun:
-    """ANIm over every FASTA file of `indir`.  outdir is needed for recovery / write_output only."""
-    eng = engine or default_engine()
+             write_output: bool = False, skip_zero: bool = False, engine: Optional[Engine] = None,
+             devices: Optional[List[int]] = None, workers: Optional[int] = None) -> AnimRun:
+    """ANIm over every FASTA file of `indir`.  outdir is needed for recovery / write_output only.
+    devices / workers: run on several GPUs of this node (pyani's `--workers`, subcmd_anim.py:392-396, counts GPUs here): the
+    comparisons are pulled from a work queue by one engine per device (pyani_amd/multi.py); ignored when `engine` is given."""
+    if write_output and outdir is None:
+        raise ValueError("write_output needs an output directory")     # before any work is done
+    own = None
+    if engine is None and (devices is not None or workers):
+        from . import multi
+        engine = multi.engine_for(devices, workers)
+        own = engine if isinstance(engine, multi.MultiEngine) else None
+    try:
+        return _run_anim(indir, outdir, recovery, nofilter, maxmatch, write_output, skip_zero, engine or default_engine())
+    finally:
+        if own is not None:
+            own.close()
+
+
+def _run_anim(indir, outdir, recovery, nofilter, maxmatch, write_output, skip_zero, eng) -> AnimRun:
     paths = files.get_fasta_paths(Path(indir))
     stems = [p.stem for p in paths]
     if len(set(stems)) != len(stems):
