@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 #include <vector>
@@ -79,6 +80,59 @@ void sampled_matches(const Genome& S, const std::vector<std::pair<uint32_t, int3
   }
 }
 
+// ---- the word tier (blastn's word size): fragments the 16-mer seeds leave without a reportable HSP ------------------------------
+// pyani asks for `-task blastn`, whose seeds are 11-mers (anib.py:465-471); at 70-80 % identity a 1020-nt fragment holds an exact
+// 16-mer with probability 0.6-0.99 but an exact 11-mer almost surely.  For such a fragment every 11-mer of either strand is looked
+// up in the subject's word index; a hit becomes a seed if its neighbourhood looks like an alignment — at least WORD_FLANK_MIN of
+// the WORD_FLANK bases on its left or on its right match on the same diagonal (chance: 8 +- 2.4 of 32) — and is reported once, as
+// the maximal exact match around it.  The pair is only searched this way if the 16-mer tier found it related at all (one
+// reportable fragment): unrelated genomes have ~10^4 chance word hits per fragment and nothing to find.
+struct WordIndex { std::vector<uint32_t> start; std::vector<int32_t> pos; };
+void build_word_index(const SeqView& SV, WordIndex& W) {
+  const uint32_t NB = 1u << (2 * WORD_K);
+  W.start.assign((size_t)NB + 1, 0);
+  uint32_t v = 0; int run = 0;
+  for (int64_t p = 0; p < SV.len; ++p) {
+    if (!SV.clean(p)) { run = 0; v = 0; continue; }
+    v = ((v << 2) | (uint32_t)SV.base(p)) & (NB - 1);
+    if (++run >= WORD_K) ++W.start[v + 1];
+  }
+  for (size_t b = 0; b < NB; ++b) W.start[b + 1] += W.start[b];
+  W.pos.assign(W.start[NB], 0);
+  std::vector<uint32_t> fill(W.start.begin(), W.start.end() - 1);
+  v = 0; run = 0;
+  for (int64_t p = 0; p < SV.len; ++p) {
+    if (!SV.clean(p)) { run = 0; v = 0; continue; }
+    v = ((v << 2) | (uint32_t)SV.base(p)) & (NB - 1);
+    if (++run >= WORD_K) W.pos[fill[v]++] = (int32_t)(p - WORD_K + 1);
+  }
+}
+// Seeds of the word tier for one (fragment, strand): q_at(p) = base of the fragment's searched strand (4 outside / dirty),
+// s_at(p) = subject base (5 outside / dirty).  Appends FragSeeds (maximal exact matches >= WORD_K clipped to the fragment).
+template <typename QA, typename SA>
+void word_tier_seeds(QA&& q_at, int32_t qlen, SA&& s_at, const WordIndex& W, std::vector<FragSeed>& out) {
+  const uint32_t NB = 1u << (2 * WORD_K);
+  uint32_t v = 0; int run = 0;
+  for (int32_t e = 0; e < qlen; ++e) {
+    const int c = q_at(e);
+    if (c > 3) { run = 0; v = 0; continue; }
+    v = ((v << 2) | (uint32_t)c) & (NB - 1);
+    if (++run < WORD_K) continue;
+    const int32_t i = e - WORD_K + 1;
+    for (uint32_t t = W.start[v]; t < W.start[v + 1]; ++t) {
+      const int64_t p = W.pos[t];
+      if (i > 0 && q_at(i - 1) == s_at(p - 1)) continue;          // not the first word of its exact match inside the fragment
+      int left = 0, right = 0;
+      for (int k = 1; k <= WORD_FLANK; ++k) left += q_at(i - k) == s_at(p - k);
+      for (int k = 0; k < WORD_FLANK; ++k) right += q_at(i + WORD_K + k) == s_at(p + WORD_K + k);
+      if (left < WORD_FLANK_MIN && right < WORD_FLANK_MIN) continue;
+      int32_t L = WORD_K;
+      while (i + L < qlen && q_at(i + L) == s_at(p + L)) ++L;
+      out.push_back(FragSeed{(int32_t)p, i, L});
+    }
+  }
+}
+
 void run_pair(const Genome& Q, const Genome& S, int32_t fragsize, std::vector<Row>& rows) {
   const SeqView SV = S.view(), QVw = Q.view();
   std::vector<std::pair<uint32_t, int32_t>> tab;
@@ -125,9 +179,9 @@ void run_pair(const Genome& Q, const Genome& S, int32_t fragsize, std::vector<Ro
       }
     }
   }
-  for (size_t f = 0; f < frags.size(); ++f) {
+  // rows of one fragment from its seed lists (both strands): anchors, extensions, e-value
+  auto fragment_rows = [&](size_t f, std::vector<Row>& cand) {
     const int32_t fp = frags[f].first, qlen = frags[f].second;
-    std::vector<Row> cand;
     // anchors of both strands first (a weak candidate is dropped when the fragment has a strong one), then the extensions
     int pick[2][2], nc[2] = {0, 0};
     int32_t votes[2][2], vmax = 0;
@@ -163,10 +217,50 @@ void run_pair(const Genome& Q, const Genome& S, int32_t fragsize, std::vector<Ro
         cand.push_back(r);
       }
     }
-    // table order: best score first (ties: plus strand first, then the first candidate) — what the reduction walks
     std::stable_sort(cand.begin(), cand.end(), [](const Row& x, const Row& y) { return x.score > y.score; });
-    for (const Row& r : cand) rows.push_back(r);
+  };
+  auto reportable = [](const std::vector<Row>& cand) {   // parse_blast_tab's test (anib.py:641-649) on any row of the fragment
+    for (const Row& r : cand) {
+      const int32_t alnlen = r.length - r.gaps;
+      if ((double)alnlen / r.qlen > 0.7 && (double)(alnlen - r.mismatch) / r.qlen > 0.3) return true;
+    }
+    return false;
+  };
+  std::vector<std::vector<Row>> per_frag(frags.size());
+  size_t n_reportable = 0;
+  for (size_t f = 0; f < frags.size(); ++f) { fragment_rows(f, per_frag[f]); n_reportable += reportable(per_frag[f]); }
+  if (n_reportable > 0 && n_reportable < frags.size() && !getenv("ANIB_NO_WORD_TIER")) {
+    WordIndex W;
+    build_word_index(SV, W);
+    for (size_t f = 0; f < frags.size(); ++f) {
+      if (reportable(per_frag[f])) continue;
+      const int32_t fp = frags[f].first, qlen = frags[f].second;
+      bool added = false;
+      for (int strand = 0; strand < 2; ++strand) {
+        auto q_at = [&](int64_t p) -> int {
+          if (p < 0 || p >= qlen) return 4;
+          const int64_t g = strand ? fp + (qlen - 1 - p) : fp + p;
+          if (!QVw.clean(g)) return 4;
+          return strand ? 3 - QVw.base(g) : QVw.base(g);
+        };
+        auto s_at = [&](int64_t p) -> int { return (p >= 0 && p < SV.len && SV.clean(p)) ? SV.base(p) : 5; };
+        std::vector<FragSeed> extra;
+        word_tier_seeds(q_at, qlen, s_at, W, extra);
+        std::vector<FragSeed> fresh;     // not a piece of one of the fragment's own (at most FRAG_MAX_SEEDS) seeds
+        for (const FragSeed& x : extra) {
+          bool dup = false;
+          for (const FragSeed& y : seeds[strand][f]) if (y.s - y.q == x.s - x.q && x.q >= y.q && x.q + x.len <= y.q + y.len) dup = true;
+          if (!dup) fresh.push_back(x);
+        }
+        if (fresh.empty() || fresh.size() > (size_t)(WORD_MAX_SEEDS - FRAG_MAX_SEEDS)) continue;   // (a repeat family: left as it is)
+        seeds[strand][f].insert(seeds[strand][f].end(), fresh.begin(), fresh.end());
+        added = true;
+      }
+      if (added) { per_frag[f].clear(); fragment_rows(f, per_frag[f]); }
+    }
   }
+  for (size_t f = 0; f < frags.size(); ++f)
+    for (const Row& r : per_frag[f]) rows.push_back(r);
 }
 }  // namespace
 

@@ -91,6 +91,8 @@ struct GenomeIdx {
   uint64_t *ref_list = nullptr, *qry_list = nullptr, *qry_list1 = nullptr;   // qry_list1: every position (fragment mode)
   uint32_t *ref_goff = nullptr, *qry_goff = nullptr, *qry_goff1 = nullptr;
   uint32_t ref_max = 0;   // largest reference group (sizes the LDS table)
+  uint32_t* word_start = nullptr;   // fragment mode, word tier: 4^11 + 1 bucket offsets of the genome's 11-mers ...
+  int32_t* word_pos = nullptr;      // ... and their positions
 };
 struct AnimLists { std::vector<GenomeIdx> gidx; };
 thread_local int tls_worker = 0;   // which of the context's two (stream, scratch) sets the calling thread drives
@@ -155,6 +157,9 @@ struct AnimScratch {
   FragSeed* fr_entries = nullptr;
   FragRow* fr_rows = nullptr;
   pg_anib_result* fr_out = nullptr;
+  uint32_t *fr_list = nullptr, *fr_nlist = nullptr, *fr_wtmp = nullptr;   // word tier: slots to search again, their number, scan scratch
+  WordIdx* fr_widx = nullptr;
+  size_t fr_list_cap = 0, fr_widx_cap = 0;
   size_t fr_tables_cap = 0, fr_pairs_cap = 0, fr_slots_cap = 0, fr_off_cap = 0, fr_units_cap = 0, fr_entries_cap = 0;
 };
 
@@ -187,7 +192,7 @@ void pg_anim_drop_lists(pg_ctx* ctx) {
   AnimLists* A = static_cast<AnimLists*>(ctx->anim_lists);
   if (!A) return;
   for (auto& g : A->gidx) {
-    void* ptrs[] = {g.ref_list, g.qry_list, g.ref_goff, g.qry_goff, g.qry_list1, g.qry_goff1};
+    void* ptrs[] = {g.ref_list, g.qry_list, g.ref_goff, g.qry_goff, g.qry_list1, g.qry_goff1, g.word_start, g.word_pos};
     for (void* p : ptrs) if (p) (void)hipFree(p);
   }
   A->gidx.clear();
@@ -254,7 +259,8 @@ static void anim_free_one(pg_ctx* ctx, void*& slot) {
   void* ptrs[] = {A->mirror_d, A->big_d, A->ranges_d, A->range_out, A->ext_reqs, A->ext_pre, A->ext_dumps, A->ext_wave, A->ext_counts, A->gap_counts, A->task_cls, A->task_lists, A->hits_sorted, A->hit_count, A->hoff, A->hit_cursor, A->hits_d, A->slice_d, A->choff_d, A->list_cnt, A->srefs_d, A->sqry_d, A->recs_d, A->refs_d, A->units_d, A->mem_count, A->moff, A->nch, A->status, A->out, A->mem, A->cm,
                   A->iscratch, A->order, A->prev, A->next, A->alnof, A->chains, A->fw, A->bw, A->S.alns, A->S.a_rrec,
                   A->S.a_qrec, A->S.idx, A->S.from, A->S.sc, A->wl_d, A->seedbuf, A->seed_total, A->tasks_d, A->fr_tables, A->fr_pairs,
-                  A->fr_slot_pair, A->fr_off, A->fr_nrows, A->fr_ebase, A->fr_entries, A->fr_rows, A->fr_out};
+                  A->fr_slot_pair, A->fr_off, A->fr_nrows, A->fr_ebase, A->fr_entries, A->fr_rows, A->fr_out, A->fr_list, A->fr_nlist, A->fr_wtmp, A->fr_widx,
+                  A->pn, A->pn_fused, A->pn_n, A->pn_cursor, A->pn_gscratch};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   delete A;
   slot = nullptr;
@@ -266,7 +272,7 @@ static void anim_free_one(pg_ctx* ctx, void*& slot) {
 // If the batch needs more than max_matches, only its first n_done pairs are processed (the caller continues from there).
 static_assert(sizeof(FragRow) == sizeof(pg_anib_row), "FragRow is pg_anib_row");
 static int anib_frag_stage(pg_ctx* ctx, AnimScratch* A, const int32_t* qry_ids, uint32_t n_pairs, const std::vector<uint32_t>& cnt,
-                           const PgFragArgs& F);
+                           const PgFragArgs& F, const std::vector<int32_t>& ref_list, const std::vector<uint32_t>& ref_of_pair);
 
 int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_ids, uint32_t n_pairs, int filter_1to1, int maxmatch,
                       uint64_t max_matches, pg_anim_result* out_host, uint32_t* n_done, const PgFragArgs* frag) {
@@ -562,7 +568,7 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
   pg_prof_end(ctx);
   if (frag) {   // fragment mode: the matches of every unit are in place; the rest of the batch is the fragment kernels
     PG_HIP(ctx, hipGetLastError());
-    return anib_frag_stage(ctx, A, qry_ids, n_pairs, cnt, *frag);
+    return anib_frag_stage(ctx, A, qry_ids, n_pairs, cnt, *frag, ref_list, ref_of_pair);
   }
   // Units with >= split_min matches ("big": pairs of related genomes) get their chains from many waves (pga_cluster.inc,
   // anim_chain_range_kernel); every other unit is finished by the one wave that filters and clusters it.
@@ -643,6 +649,14 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
     else
       PG_HIP(ctx, hipMemsetAsync(A->pn_n, 0, (size_t)n_units * 4, cur_stream(ctx)));
     pg_prof_end(ctx);
+    if (getenv("PYANI_PN_STATS")) {   // development: what the engines did in this launch
+      PG_HIP(ctx, hipStreamSynchronize(cur_stream(ctx)));
+      unsigned long long st[16], zero[16] = {0};
+      PG_HIP(ctx, hipMemcpyFromSymbol(st, HIP_SYMBOL(g_pn_stats), sizeof(st)));
+      PG_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_pn_stats), zero, sizeof(zero)));
+      fprintf(stderr, "[pn-stats] units %llu clusters %llu | regs: calls %llu steps %llu cells %llu moves %llu overflows %llu | lds: calls %llu steps %llu cells %llu | "
+                      "global: calls %llu steps %llu cells %llu\n", st[11], st[12], st[0], st[1], st[2], st[9], st[10], st[3], st[4], st[5], st[6], st[7], st[8]);
+    }
   }
   if (n_wl && !postnuc) {
     if (n_wl > A->wl) { if ((rc = regrow(ctx, A->wl_d, n_wl + n_wl / 2))) return rc; A->wl = n_wl + n_wl / 2; }
@@ -770,8 +784,42 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
 // Fragment mode after seeding: A->mem / A->moff / A->mem_count hold every unit's exact matches (>= 16, sampled), A->units_d /
 // A->refs_d the descriptors.  Builds the fragment tables of the batch's query genomes, runs F1-F3 (pga_frag.inc), returns
 // the pair results (and, optionally, the rows of pair 0).
+// The word index of one genome (pga_frag.inc), built once and kept with its seed lists.
+static int anib_ensure_word_index(pg_ctx* ctx, AnimScratch* A, int32_t gid) {
+  int rc;
+  std::lock_guard<std::mutex> lk(ctx->anim_mu);
+  AnimLists* LS = anim_lists(ctx);
+  if (LS->gidx.size() < ctx->genomes.size()) LS->gidx.resize(ctx->genomes.size());
+  GenomeIdx& X = LS->gidx[gid];
+  if (X.word_start) return PG_OK;
+  const PgGenome& G = ctx->genomes[gid];
+  const int32_t len = (int32_t)G.stream_len;
+  const uint32_t* codes = ctx->d_codes + G.arena_start / 16;
+  const uint32_t* mask = ctx->d_mask + G.arena_start / 32;
+  uint32_t* start = nullptr;
+  int32_t* pos = nullptr;
+  if (!A->fr_wtmp && (rc = regrow(ctx, A->fr_wtmp, (size_t)WORD_BUCKETS + 1024 + 16))) return rc;   // fill cursors | block sums
+  if ((rc = regrow(ctx, start, (size_t)WORD_BUCKETS + 1))) return rc;
+  if ((rc = regrow(ctx, pos, (size_t)(len > 0 ? len : 1)))) { (void)hipFree(start); return rc; }
+  hipStream_t st = cur_stream(ctx);
+  const uint32_t grid = (uint32_t)((len + 255) / 256);
+  hipError_t e = hipMemsetAsync(start, 0, ((size_t)WORD_BUCKETS + 1) * 4, st);
+  if (e == hipSuccess && grid) hipLaunchKernelGGL(anib_word_count_kernel, dim3(grid), dim3(256), 0, st, codes, mask, len, start, pos, 0);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(anib_word_scan1_kernel, dim3(WORD_BUCKETS / 4096u), dim3(1024), 0, st, start, A->fr_wtmp + WORD_BUCKETS);
+    hipLaunchKernelGGL(anib_word_scan2_kernel, dim3(1), dim3(1024), 0, st, A->fr_wtmp + WORD_BUCKETS, WORD_BUCKETS / 4096u, start + WORD_BUCKETS);
+    hipLaunchKernelGGL(anib_word_scan3_kernel, dim3(WORD_BUCKETS / 1024u), dim3(1024), 0, st, start, A->fr_wtmp + WORD_BUCKETS, A->fr_wtmp);
+    if (grid) hipLaunchKernelGGL(anib_word_count_kernel, dim3(grid), dim3(256), 0, st, codes, mask, len, A->fr_wtmp, pos, 1);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  if (e != hipSuccess) { (void)hipFree(start); (void)hipFree(pos); return pg_fail(ctx, PG_E_HIP, hipGetErrorString(e)); }
+  X.word_start = start; X.word_pos = pos;     // published complete
+  return PG_OK;
+}
+
 static int anib_frag_stage(pg_ctx* ctx, AnimScratch* A, const int32_t* qry_ids, uint32_t n_pairs, const std::vector<uint32_t>& cnt,
-                           const PgFragArgs& F) {
+                           const PgFragArgs& F, const std::vector<int32_t>& ref_list, const std::vector<uint32_t>& ref_of_pair) {
   int rc;
   const uint32_t n_units = 2 * n_pairs;
   // fragment tables, one per distinct query genome
@@ -840,13 +888,51 @@ static int anib_frag_stage(pg_ctx* ctx, AnimScratch* A, const int32_t* qry_ids, 
   pg_prof_begin(ctx, PG_K_ANIB_FRAG);
   if (slots)
     hipLaunchKernelGGL(anib_frag_kernel, dim3((uint32_t)slots), dim3(64), 0, cur_stream(ctx), A->refs_d, A->units_d, A->fr_pairs, A->fr_slot_pair,
-                       A->fr_off, A->fr_entries, A->fr_ebase, A->fr_rows, A->fr_nrows);
+                       A->fr_off, A->fr_entries, A->fr_ebase, A->fr_rows, A->fr_nrows, (const uint32_t*)nullptr, (const WordIdx*)nullptr);
   pg_prof_end(ctx);
   hipLaunchKernelGGL(anib_reduce_pairs_kernel, dim3((n_pairs + 63) / 64), dim3(64), 0, cur_stream(ctx), A->fr_pairs, n_pairs, A->fr_rows, A->fr_nrows,
                      A->fr_out);
   PG_HIP(ctx, hipGetLastError());
   PG_HIP(ctx, hipMemcpyAsync(F.out, A->fr_out, n_pairs * sizeof(pg_anib_result), hipMemcpyDeviceToHost, cur_stream(ctx)));
   PG_HIP(ctx, hipStreamSynchronize(cur_stream(ctx)));
+  // ---- word tier (pga_frag.inc): pairs with some, but not all, fragments reportable get their other fragments searched again
+  // with blastn-sized seeds; the subjects' word indices are built on first use
+  if (slots && ctx->anib_word_tier) {
+    std::vector<WordIdx> widx(ref_list.size(), WordIdx{nullptr, nullptr});
+    bool any = false;
+    for (uint32_t p = 0; p < n_pairs; ++p) {
+      if (!(F.out[p].n_kept > 0 && F.out[p].n_kept < F.out[p].n_frags)) continue;
+      const uint32_t r = ref_of_pair[p];
+      if (widx[r].start) continue;
+      if ((rc = anib_ensure_word_index(ctx, A, ref_list[r]))) return rc;
+      const GenomeIdx& X = anim_lists(ctx)->gidx[ref_list[r]];
+      widx[r] = WordIdx{X.word_start, X.word_pos};
+      any = true;
+    }
+    if (any) {
+      if (widx.size() > A->fr_widx_cap) { if ((rc = regrow(ctx, A->fr_widx, widx.size() + 16))) return rc; A->fr_widx_cap = widx.size() + 16; }
+      if ((size_t)slots > A->fr_list_cap) { if ((rc = regrow(ctx, A->fr_list, (size_t)slots + (size_t)slots / 4))) return rc; A->fr_list_cap = (size_t)slots + (size_t)slots / 4; }
+      if (!A->fr_nlist && (rc = regrow(ctx, A->fr_nlist, 4))) return rc;
+      PG_HIP(ctx, hipMemcpyAsync(A->fr_widx, widx.data(), widx.size() * sizeof(WordIdx), hipMemcpyHostToDevice, cur_stream(ctx)));
+      PG_HIP(ctx, hipMemsetAsync(A->fr_nlist, 0, 4, cur_stream(ctx)));
+      hipLaunchKernelGGL(anib_failed_kernel, dim3((uint32_t)((slots + 255) / 256)), dim3(256), 0, cur_stream(ctx), A->fr_pairs, A->fr_slot_pair,
+                         (uint32_t)slots, A->fr_rows, A->fr_nrows, A->fr_out, A->fr_widx, A->units_d, A->fr_list, A->fr_nlist);
+      uint32_t n_list = 0;
+      PG_HIP(ctx, hipMemcpyAsync(&n_list, A->fr_nlist, 4, hipMemcpyDeviceToHost, cur_stream(ctx)));
+      PG_HIP(ctx, hipStreamSynchronize(cur_stream(ctx)));
+      if (n_list) {
+        pg_prof_begin(ctx, PG_K_ANIB_FRAG);
+        hipLaunchKernelGGL(anib_frag_kernel, dim3(n_list), dim3(64), 0, cur_stream(ctx), A->refs_d, A->units_d, A->fr_pairs, A->fr_slot_pair,
+                           A->fr_off, A->fr_entries, A->fr_ebase, A->fr_rows, A->fr_nrows, (const uint32_t*)A->fr_list, (const WordIdx*)A->fr_widx);
+        pg_prof_end(ctx);
+        hipLaunchKernelGGL(anib_reduce_pairs_kernel, dim3((n_pairs + 63) / 64), dim3(64), 0, cur_stream(ctx), A->fr_pairs, n_pairs, A->fr_rows,
+                           A->fr_nrows, A->fr_out);
+        PG_HIP(ctx, hipGetLastError());
+        PG_HIP(ctx, hipMemcpyAsync(F.out, A->fr_out, n_pairs * sizeof(pg_anib_result), hipMemcpyDeviceToHost, cur_stream(ctx)));
+        PG_HIP(ctx, hipStreamSynchronize(cur_stream(ctx)));
+      }
+    }
+  }
   if (F.n_rows_out) {   // the table of pair 0
     const uint32_t nf = (uint32_t)fp[0].n_frags;
     std::vector<uint32_t> nr(nf);

@@ -76,6 +76,75 @@ PG_HD Cell cell_update(const Cell& L, const Cell& U, uint32_t G, bool same) {
   return c;
 }
 
+// ---- the scans of extendClusters ---------------------------------------------------------------------------------------------
+PG_HD bool pn_close_enough(int32_t a, int32_t b) {
+  const int32_t lesser = a < b ? a : b, greater = a < b ? b : a;
+  return greater < BREAK_LEN || lesser * GOOD_SCORE + (greater - lesser) * CONT_GAP_SCORE >= 0;
+}
+PG_HD bool pn_same_records(const Chain* chains, int a, int b) { return chains[a].rrec == chains[b].rrec && chains[a].qrec == chains[b].qrec; }
+
+// The three scans of extendClusters, one candidate at a time (the scalar engines walk them in MUMmer's order; the GPU's wave
+// engine evaluates 64 candidates per step and reduces to the same answer — the selection rules are order-free once stated as
+// "the first close-enough candidate in scan order, else the smallest distance, ties to the earlier one in scan order").
+struct PnCand { bool valid, close; int32_t dist, a, b; };
+// isShadowedCluster: alignment x (same records) contains the cluster [sA, eA] x [sB, eB]
+PG_HD bool pn_shadow_hit(const Chain* chains, const PnAln& x, int c, int32_t sA, int32_t eA, int32_t sB, int32_t eB) {
+  return pn_same_records(chains, x.chain, c) && x.eA >= eA && x.eB >= eB && x.sA <= sA && x.sB <= sB;
+}
+// getReverseTargetAlignment: alignment x as the target of a backward search that starts at (sA, sB)
+PG_HD PnCand pn_reverse_cand(const Chain* chains, const PnAln& x, int c, int32_t sA, int32_t sB) {
+  PnCand r{false, false, 0, x.eA, x.eB};
+  if (!pn_same_records(chains, x.chain, c) || !(x.eA <= sA && x.eB <= sB)) return r;
+  int32_t lesser = sA - x.eA, greater = sB - x.eB;
+  if (lesser > greater) { const int32_t t = lesser; lesser = greater; greater = t; }
+  r.valid = true; r.close = pn_close_enough(lesser, greater); r.dist = (greater << 1) - lesser;
+  return r;
+}
+// getForwardTargetCluster: cluster tc as the target of a forward extension off a cluster that ends at (sA, sB); if its first
+// match overlaps that end but its last one does not, the target is its first match that starts at or after the end in both
+PG_HD PnCand pn_forward_cand(const Chain* chains, const Match* cm, int tc, int c, int32_t sA, int32_t sB) {
+  PnCand r{false, false, 0, 0, 0};
+  if (!pn_same_records(chains, tc, c)) return r;
+  const Match* tm = cm + chains[tc].first;
+  const int tn = chains[tc].count;
+  int32_t eA = tm[0].r, eB = tm[0].q;
+  if ((eA < sA || eB < sB) && tm[tn - 1].r >= sA && tm[tn - 1].q >= sB)
+    for (int x = 0; x < tn && (eA < sA || eB < sB); ++x) { eA = tm[x].r; eB = tm[x].q; }
+  if (!(eA >= sA && eB >= sB)) return r;
+  int32_t lesser = eA - sA, greater = eB - sB;
+  if (lesser > greater) { const int32_t t = lesser; lesser = greater; greater = t; }
+  r.valid = true; r.close = pn_close_enough(lesser, greater); r.dist = (greater << 1) - lesser; r.a = eA; r.b = eB;
+  return r;
+}
+// the scans in MUMmer's own order (what ScalarEngine / DiagEngine use; PnWaveEngine has lane-parallel forms of the same three)
+struct PnScalarScans {
+  PG_HD bool shadowed(const Chain* chains, const PnAln* al, int from, int c, int32_t sA, int32_t eA, int32_t sB, int32_t eB) const {
+    for (int t = from; t >= 0; --t) if (pn_shadow_hit(chains, al[t], c, sA, eA, sB, eB)) return true;
+    return false;
+  }
+  PG_HD int reverse_target(const Chain* chains, const PnAln* al, int cura, int c, int32_t sA, int32_t sB, int32_t dist) const {
+    int tgt = -1;
+    for (int t = cura - 1; t >= 0; --t) {
+      const PnCand x = pn_reverse_cand(chains, al[t], c, sA, sB);
+      if (!x.valid) continue;
+      if (x.close) { tgt = t; break; }
+      if (x.dist < dist) { tgt = t; dist = x.dist; }
+    }
+    return tgt;
+  }
+  PG_HD int forward_target(const Chain* chains, const Match* cm, const int32_t* order, int n, int curk, int c, int32_t sA, int32_t sB,
+                           int32_t dist, int32_t& targetA, int32_t& targetB) const {
+    int targetk = -1;
+    for (int k = curk + 1; k < n; ++k) {
+      const PnCand x = pn_forward_cand(chains, cm, order[k], c, sA, sB);
+      if (!x.valid) continue;
+      if (x.close) { targetk = k; targetA = x.a; targetB = x.b; break; }
+      if (x.dist < dist) { targetk = k; targetA = x.a; targetB = x.b; dist = x.dist; }
+    }
+    return targetk;
+  }
+};
+
 // ---- forced alignments: the whole rectangle, computed as a certified band ------------------------------------------------
 // A FORCED alignment (the forward re-alignment of a backward extension, up to 10 000 x 10 000) is the optimal global path of its
 // rectangle under the tie order above; MUMmer fills the whole rectangle (no trimming, no break).  The same path comes out of
@@ -108,6 +177,14 @@ struct ScalarEngine {
   int32_t cap;
   int32_t overflow = 0;
   long cells = 0;
+  // the scans of extendClusters in MUMmer's own order
+  PG_HD bool shadowed(const Chain* chains, const PnAln* al, int from, int c, int32_t sA, int32_t eA, int32_t sB, int32_t eB) const {
+    return PnScalarScans().shadowed(chains, al, from, c, sA, eA, sB, eB); }
+  PG_HD int reverse_target(const Chain* chains, const PnAln* al, int cura, int c, int32_t sA, int32_t sB, int32_t dist) const {
+    return PnScalarScans().reverse_target(chains, al, cura, c, sA, sB, dist); }
+  PG_HD int forward_target(const Chain* chains, const Match* cm, const int32_t* order, int n, int curk, int c, int32_t sA, int32_t sB,
+                           int32_t dist, int32_t& targetA, int32_t& targetB) const {
+    return PnScalarScans().forward_target(chains, cm, order, n, curk, c, sA, sB, dist, targetA, targetB); }
   PG_HD bool same(int64_t pa, int64_t pb) const { return R.clean(pa) && Q.clean(pb) && R.base(pa) == Q.base(pb); }
 
   // Aligns A[Astart .. Aend] with B[Bstart .. Bend] (inclusive; walking backwards when DIRECTION_BIT is clear).  Returns whether
@@ -183,17 +260,151 @@ struct ScalarEngine {
   }
 };
 
+// ---- the same engine laid out by DIAGONAL (the statement of the quad-lane kernel, pga_postnuc_quad.inc) ---------------------
+// Cell (i, j) lives on diagonal k = j - i, slot l = k + DIAG_HALF of a fixed window of DIAG_WINDOW diagonals around the start
+// cell; anti-diagonal Dct touches the slots of its own parity.  Per slot: X = best-state word of the latest cell on that
+// diagonal (two anti-diagonals old when the slot's turn comes: the diagonal neighbour G), D / I = the gap states of that cell
+// (read once, by the neighbours l - 1 / l + 1 on the next anti-diagonal).  The gap states need only two candidates each:
+//   DELETE = max(D(left) + CONT, X(left) + OPEN),  INSERT = max(I(up) + CONT, X(up) + OPEN)
+// — the third candidate of MUMmer's scoreEdit is dominated (a gap state re-opened from itself costs OPEN < CONT) and the state
+// labels settle every tie as before.  A slot whose turn comes while it is outside the anti-diagonal's range is zeroed, which
+// is what "not computed" means to its later readers.  A range that would leave the window makes the call start over in the
+// general engine (overflow = true): MUMmer's band is 150-190 diagonals wide wherever two sequences align and follows the
+// alignment's net indels, so 256 diagonals hold it unless an extension drifts more than ~40 diagonals off its start.
+constexpr int32_t DIAG_WINDOW = 256, DIAG_HALF = 128;
+struct DiagSlot { uint32_t X, D, I; };
+PG_HD void diag_cell(const DiagSlot& left, const DiagSlot& up, uint32_t G, bool same, DiagSlot& out) {
+  const uint32_t dc = w_gap(left.D, CONT_GAP_SCORE), dx = w_gap(left.X, OPEN_GAP_SCORE);
+  const uint32_t ic = w_gap(up.I, CONT_GAP_SCORE), ix = w_gap(up.X, OPEN_GAP_SCORE);
+  const uint32_t d = w_relabel(dc > dx ? dc : dx, ST_DELETE), i = w_relabel(ic > ix ? ic : ix, ST_INSERT);
+  const uint32_t m = w_relabel(w_step(G, same), ST_MATCH);
+  out.D = d; out.I = i; out.X = w_max3(d, i, m);
+}
+
+template <typename RefT, typename QryT>
+struct DiagScalarEngine {
+  const RefT& R;
+  const QryT& Q;
+  int32_t overflow = 0;
+  long cells = 0, fallbacks = 0;
+  PG_HD bool same(int64_t pa, int64_t pb) const { return R.clean(pa) && Q.clean(pb) && R.base(pa) == Q.base(pb); }
+  // false: the band left the window (nothing is returned)
+  PG_HD bool run(int32_t Astart, int32_t& Aend, int32_t Bstart, int32_t& Bend, unsigned m_o, int32_t band_w, int32_t& errors,
+                 int32_t& score, bool& reached) {
+    const bool fwd = m_o & DIRECTION_BIT, forced = m_o & FORCED_BIT;
+    const int32_t N = fwd ? Aend - Astart + 1 : Astart - Aend + 1, M = fwd ? Bend - Bstart + 1 : Bstart - Bend + 1;
+    DiagSlot S[DIAG_WINDOW];
+    for (int l = 0; l < DIAG_WINDOW; ++l) S[l] = DiagSlot{0u, 0u, 0u};
+    S[DIAG_HALF].X = w_make(0, 0, ST_MATCH);
+    int32_t high = -(1 << 30), FinishCt = 0, FinishK = 0;
+    uint32_t high_w = 0;
+    int32_t ka = 0, kb = 0;     // surviving diagonals of the latest anti-diagonal
+    bool empty = false;
+    int32_t Dct;
+    for (Dct = 1; Dct <= N + M && (forced || Dct - FinishCt <= BREAK_LEN) && !empty; ++Dct) {
+      int32_t lo = ka - 1, hi = kb + 1;                 // k range; cells exist on k == Dct (mod 2): ka / kb had parity Dct - 1
+      const int32_t c1 = -Dct > Dct - 2 * N ? -Dct : Dct - 2 * N, c2 = 2 * M - Dct < Dct ? 2 * M - Dct : Dct;
+      if (lo < c1) lo = c1;
+      if (hi > c2) hi = c2;
+      if (band_w >= 0) {
+        const int32_t kmin = (M - N < 0 ? M - N : 0) - band_w, kmax = (M - N > 0 ? M - N : 0) + band_w;
+        if (lo < kmin) lo = kmin;
+        if (hi > kmax) hi = kmax;
+      }
+      if ((lo + Dct) & 1) ++lo;
+      if ((hi + Dct) & 1) --hi;
+      if (lo > hi) break;
+      if (lo < -DIAG_HALF || hi >= DIAG_HALF) return false;
+      DiagSlot nw[DIAG_WINDOW / 2];
+      const int par = Dct & 1;                           // slots l = k + DIAG_HALF have the parity of k (DIAG_HALF is even)
+      int32_t bestk = -(1 << 30), best_l = -1; uint32_t bestw = 0;
+      for (int l = par; l < DIAG_WINDOW; l += 2) {
+        const int32_t k = l - DIAG_HALF;
+        DiagSlot out{0u, 0u, 0u};
+        if (k >= lo && k <= hi) {
+          const int32_t i = (Dct - k) / 2, j = (Dct + k) / 2;
+          const DiagSlot zero{0u, 0u, 0u};
+          const DiagSlot& left = l >= 1 ? S[l - 1] : zero;
+          const DiagSlot& up = l + 1 < DIAG_WINDOW ? S[l + 1] : zero;
+          bool sm = false;
+          if (i >= 1 && j >= 1) sm = same(fwd ? (int64_t)Astart + i - 1 : (int64_t)Astart - i + 1, fwd ? (int64_t)Bstart + j - 1 : (int64_t)Bstart - j + 1);
+          diag_cell(j >= 1 ? left : zero, i >= 1 ? up : zero, (i >= 1 && j >= 1) ? S[l].X : 0u, sm, out);
+          ++cells;
+          const int32_t sc = w_score(out.X);
+          if (sc >= bestk) { bestk = sc; best_l = l; bestw = out.X; }
+        }
+        nw[l >> 1] = out;
+      }
+      for (int l = par; l < DIAG_WINDOW; l += 2) S[l] = nw[l >> 1];
+      if (best_l >= 0 && bestk >= high) { high = bestk; high_w = bestw; FinishCt = Dct; FinishK = best_l - DIAG_HALF; }
+      int32_t ta = lo, tb = hi;
+      if (!forced) {
+        while (ta <= tb && high - w_score(S[ta + DIAG_HALF].X) > MAX_DIFF) ta += 2;
+        while (tb >= ta && high - w_score(S[tb + DIAG_HALF].X) > MAX_DIFF) tb -= 2;
+      }
+      ka = ta; kb = tb;
+      if (ta > tb) empty = true;
+    }
+    --Dct;
+    reached = false;
+    uint32_t fin_w = high_w;
+    if (Dct == N + M) {
+      if (!(m_o & OPTIMAL_BIT)) { reached = true; FinishCt = N + M; FinishK = M - N; fin_w = S[M - N + DIAG_HALF].X; }
+      else if (FinishCt == Dct) reached = true;
+    }
+    const int32_t fi = (FinishCt - FinishK) / 2, fj = (FinishCt + FinishK) / 2;
+    Aend = fwd ? Astart + fi - 1 : Astart - fi + 1;
+    Bend = fwd ? Bstart + fj - 1 : Bstart - fj + 1;
+    errors = (int32_t)w_errors(fin_w);
+    score = w_score(fin_w);
+    return true;
+  }
+};
+
+// The diagonal-window engine with the general one behind it: what the GPU's quad-lane kernel + wave-engine fallback compute.
+template <typename RefT, typename QryT>
+struct DiagEngine {
+  DiagScalarEngine<RefT, QryT> fast;
+  ScalarEngine<RefT, QryT> slow;
+  // the scans of extendClusters in MUMmer's own order
+  PG_HD bool shadowed(const Chain* chains, const PnAln* al, int from, int c, int32_t sA, int32_t eA, int32_t sB, int32_t eB) const {
+    return PnScalarScans().shadowed(chains, al, from, c, sA, eA, sB, eB); }
+  PG_HD int reverse_target(const Chain* chains, const PnAln* al, int cura, int c, int32_t sA, int32_t sB, int32_t dist) const {
+    return PnScalarScans().reverse_target(chains, al, cura, c, sA, sB, dist); }
+  PG_HD int forward_target(const Chain* chains, const Match* cm, const int32_t* order, int n, int curk, int c, int32_t sA, int32_t sB,
+                           int32_t dist, int32_t& targetA, int32_t& targetB) const {
+    return PnScalarScans().forward_target(chains, cm, order, n, curk, c, sA, sB, dist, targetA, targetB); }
+  long stat_cells[16] = {0}, stat_calls[16] = {0};   // by class: 0 trimmed search / alignment, 1 + log2(w / 32) forced band, 15 whole
+  PG_HD bool run(int32_t Astart, int32_t& Aend, int32_t Bstart, int32_t& Bend, unsigned m_o, int32_t band_w, int32_t& errors, int32_t& score) {
+    int32_t a = Aend, b = Bend;
+    bool reached = false;
+    const long c0 = fast.cells + slow.cells;
+    int cls = 0;
+    if (m_o & FORCED_BIT) { cls = 15; for (int t = 0; t < 12; ++t) if (band_w == (FORCED_BAND_FIRST << t)) cls = 1 + t; }
+    struct Tally { DiagEngine* e; int cls; long c0; ~Tally() { e->stat_cells[cls] += e->fast.cells + e->slow.cells - c0; e->stat_calls[cls] += 1; } } tally{this, cls, c0};
+    if (fast.run(Astart, a, Bstart, b, m_o, band_w, errors, score, reached)) { Aend = a; Bend = b; return reached; }
+    ++fast.fallbacks;
+    return slow.run(Astart, Aend, Bstart, Bend, m_o, band_w, errors, &score);
+  }
+  PG_HD bool align(int32_t Astart, int32_t& Aend, int32_t Bstart, int32_t& Bend, unsigned m_o, int32_t& errors) {
+    int32_t score = 0;
+    if (!(m_o & FORCED_BIT)) return run(Astart, Aend, Bstart, Bend, m_o, -1, errors, score);
+    const bool fwd = m_o & DIRECTION_BIT;
+    const int32_t N = fwd ? Aend - Astart + 1 : Astart - Aend + 1, M = fwd ? Bend - Bstart + 1 : Bstart - Bend + 1;
+    for (int32_t w = FORCED_BAND_FIRST;; w *= 2) {
+      int32_t a = Aend, b = Bend;
+      const bool whole = w >= (N > M ? N : M);
+      const bool reached = run(Astart, a, Bstart, b, m_o, whole ? -1 : w, errors, score);
+      if (slow.overflow || whole || (reached && (int64_t)score > forced_outside_bound(N, M, w))) { Aend = a; Bend = b; return reached; }
+    }
+  }
+};
+
 // ---- postnuc: extendClusters ---------------------------------------------------------------------------------------------
 // chains[order[k]], k = 0 .. n-1: the unit's clusters by the reference start of their first match (ties: extraction order);
 // cm: their matches.  BOUNDS(c, r_lo, r_hi, q_lo, q_hi): the records of chain c as half-open stream ranges (q: strand
 // coordinates).  fused[n] / al[max_al]: scratch and output.  Returns the number of alignments (al[] in creation order, as
 // MUMmer prints them), or -1 - count when max_al was too small.
-PG_HD bool pn_close_enough(int32_t a, int32_t b) {
-  const int32_t lesser = a < b ? a : b, greater = a < b ? b : a;
-  return greater < BREAK_LEN || lesser * GOOD_SCORE + (greater - lesser) * CONT_GAP_SCORE >= 0;
-}
-PG_HD bool pn_same_records(const Chain* chains, int a, int b) { return chains[a].rrec == chains[b].rrec && chains[a].qrec == chains[b].qrec; }
-
 template <typename ENG, typename BOUNDS>
 PG_HD int postnuc_unit(ENG& eng, const Chain* chains, const Match* cm, const int32_t* order, int n, BOUNDS&& bounds, uint8_t* fused,
                        PnAln* al, int max_al) {
@@ -212,11 +423,8 @@ PG_HD int postnuc_unit(ENG& eng, const Chain* chains, const Match* cm, const int
     bounds(c, r_lo, r_hi, q_lo, q_hi);
     if (!target_reached) {
       bool skip = fused[curk] != 0;
-      if (!skip) {   // isShadowedCluster: inside an alignment of the same records made so far (from the current one backwards)
-        const int32_t sA = mf.r, eA = ml.r + ml.len - 1, sB = mf.q, eB = ml.q + ml.len - 1;
-        for (int t = cura; t >= 0 && !skip; --t)
-          if (pn_same_records(chains, al[t].chain, c) && al[t].eA >= eA && al[t].eB >= eB && al[t].sA <= sA && al[t].sB <= sB) skip = true;
-      }
+      if (!skip)     // isShadowedCluster: inside an alignment of the same records made so far (from the current one backwards)
+        skip = eng.shadowed(chains, al, cura, c, mf.r, ml.r + ml.len - 1, mf.q, ml.q + ml.len - 1);
       if (skip) { fused[curk] = 1; curk = ++prev; continue; }
     }
     for (int m = 0; m < C.count; ++m) {
@@ -230,20 +438,8 @@ PG_HD int postnuc_unit(ENG& eng, const Chain* chains, const Match* cm, const int
         cura = n_al++;
         // getReverseTargetAlignment: the latest earlier alignment that ends at or before this start in both sequences and is
         // close enough; failing that, the one at the smallest distance if that beats the distance to the sequence starts
-        int tgt = -1;
-        {
-          const int32_t sA = al[cura].sA, sB = al[cura].sB;
-          int32_t dist = (sA - r_lo + 1) < (sB - q_lo + 1) ? (sA - r_lo + 1) : (sB - q_lo + 1);
-          for (int t = cura - 1; t >= 0; --t) {
-            if (!pn_same_records(chains, al[t].chain, c)) continue;
-            if (al[t].eA <= sA && al[t].eB <= sB) {
-              int32_t lesser = sA - al[t].eA, greater = sB - al[t].eB;
-              if (lesser > greater) { const int32_t x = lesser; lesser = greater; greater = x; }
-              if (pn_close_enough(lesser, greater)) { tgt = t; break; }
-              if ((greater << 1) - lesser < dist) { tgt = t; dist = (greater << 1) - lesser; }
-            }
-          }
-        }
+        const int32_t d0 = (al[cura].sA - r_lo + 1) < (al[cura].sB - q_lo + 1) ? (al[cura].sA - r_lo + 1) : (al[cura].sB - q_lo + 1);
+        const int tgt = eng.reverse_target(chains, al, cura, c, al[cura].sA, al[cura].sB, d0);
         // extendBackward: search back towards the target's end; reached = merge (the gap is re-aligned forwards, forced)
         {
           unsigned m_o = BACKWARD_SEARCH;
@@ -279,23 +475,8 @@ PG_HD int postnuc_unit(ENG& eng, const Chain* chains, const Match* cm, const int
         targetA = r_hi - 1; targetB = q_hi - 1;
         // getForwardTargetCluster
         const int32_t sA = ml.r + ml.len - 1, sB = ml.q + ml.len - 1;
-        int32_t dist = (targetA - sA) < (targetB - sB) ? (targetA - sA) : (targetB - sB);
-        targetk = -1;
-        for (int k = curk + 1; k < n; ++k) {
-          const int tc = order[k];
-          if (!pn_same_records(chains, tc, c)) continue;
-          const Match* tm = cm + chains[tc].first;
-          const int tn = chains[tc].count;
-          int32_t eA = tm[0].r, eB = tm[0].q;
-          if ((eA < sA || eB < sB) && tm[tn - 1].r >= sA && tm[tn - 1].q >= sB)
-            for (int x = 0; x < tn && (eA < sA || eB < sB); ++x) { eA = tm[x].r; eB = tm[x].q; }
-          if (eA >= sA && eB >= sB) {
-            int32_t lesser = eA - sA, greater = eB - sB;
-            if (lesser > greater) { const int32_t x = lesser; lesser = greater; greater = x; }
-            if (pn_close_enough(lesser, greater)) { targetk = k; targetA = eA; targetB = eB; break; }
-            if ((greater << 1) - lesser < dist) { targetk = k; targetA = eA; targetB = eB; dist = (greater << 1) - lesser; }
-          }
-        }
+        const int32_t d0 = (targetA - sA) < (targetB - sB) ? (targetA - sA) : (targetB - sB);
+        targetk = eng.forward_target(chains, cm, order, n, curk, c, sA, sB, d0, targetA, targetB);
         if (targetk < 0) m_o |= OPTIMAL_BIT;
       }
       {

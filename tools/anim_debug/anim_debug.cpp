@@ -124,14 +124,22 @@ int main(int argc, char** argv) {
       pgn::ScalarEngine<SeqView, StrandView> eng{R, Q, d0.data(), d1.data(), d2.data(), cap};
       std::vector<uint8_t> fused(n_chains + 1);
       std::vector<pgn::PnAln> al(n_chains + 1);
-      const int na = pgn::postnuc_unit(eng, chains.data(), cm.data(), co.data(), n_chains,
+      pgn::DiagEngine<SeqView, StrandView> deng{pgn::DiagScalarEngine<SeqView, StrandView>{R, Q}, eng};
+      auto bounds_of = [&](int c, int32_t& rl, int32_t& rh, int32_t& ql, int32_t& qh) {
+            rl = G.rec_start[chains[c].rrec]; rh = G.rec_start[chains[c].rrec + 1] - 1;
+            ql = H.rec_start[chains[c].qrec]; qh = H.rec_start[chains[c].qrec + 1] - 1;
+            if (strand) { const int32_t a = (int32_t)H.len - qh, b = (int32_t)H.len - ql; ql = a; qh = b; } };
+      const int na = getenv("ANIM_DIAG") ? pgn::postnuc_unit(deng, chains.data(), cm.data(), co.data(), n_chains, bounds_of, fused.data(), al.data(), (int)al.size())
+                                         : pgn::postnuc_unit(eng, chains.data(), cm.data(), co.data(), n_chains,
           [&](int c, int32_t& rl, int32_t& rh, int32_t& ql, int32_t& qh) {
             rl = G.rec_start[chains[c].rrec]; rh = G.rec_start[chains[c].rrec + 1] - 1;
             ql = H.rec_start[chains[c].qrec]; qh = H.rec_start[chains[c].qrec + 1] - 1;
             if (strand) { const int32_t a = (int32_t)H.len - qh, b = (int32_t)H.len - ql; ql = a; qh = b; } },
           fused.data(), al.data(), (int)al.size());
-      if (na < 0 || eng.overflow) { fprintf(stderr, "postnuc statement: capacity exceeded\n"); return 3; }
-      exact_cells += eng.cells;
+      if (na < 0 || eng.overflow || deng.slow.overflow) { fprintf(stderr, "postnuc statement: capacity exceeded\n"); return 3; }
+      exact_cells += eng.cells + deng.fast.cells + deng.slow.cells;
+      if (getenv("ANIM_DIAG")) { fprintf(stderr, "calls / cells by class (0 = trimmed, 1.. = forced w 32, 64, ..., 15 = whole):"); for (int t = 0; t < 16; ++t) if (deng.stat_calls[t]) fprintf(stderr, " [%d] %ld / %ld", t, deng.stat_calls[t], deng.stat_cells[t]); fprintf(stderr, "\n"); }
+      if (getenv("ANIM_DIAG")) fprintf(stderr, "diagonal-window engine: %ld cells, %ld calls fell back to the general engine (%ld cells)\n", deng.fast.cells, deng.fast.fallbacks, deng.slow.cells);
       for (int i = 0; i < na; ++i) {
         Aln a; a.rs = al[i].sA; a.re = al[i].eA + 1; a.qs = al[i].sB; a.qe = al[i].eB + 1; a.errors = al[i].errors; a.strand = strand; a.keep = 0;
         a_rrec.push_back(record_of(G.rec_start.data(), (int)G.rec_start.size() - 1, a.rs));

@@ -14,6 +14,12 @@ exact)
 tests)
   timeout 2400 python -m pytest tests -m gpu -q --timeout 1200 > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.log
   tail -25 $O/pytest_gpu.log ;;
+stats)   # one C3 grid with the engines' counters (PYANI_PN_STATS) and one worker, so that the launch times are not overlapped
+  PYANI_PN_STATS=1 PYANI_ANIM_WORKERS=1 timeout 900 python bench.py --gpus 1 --genomes 200 --seed 20250228 --steps 1 --warmup 0 --no-tetra --no-cpu-baseline > $O/bench_c3_stats.log 2> $O/bench_c3_stats.err; echo "stats rc=$?"
+  grep '^{' $O/bench_c3_stats.log | cut -c1-1500; grep "pn-stats" $O/bench_c3_stats.err | tail -8 ;;
+anib)
+  timeout 1200 python -m pytest tests/test_anib_gpu.py tests/test_zz_concordance_gpu.py -m gpu -q --timeout 900 > $O/pytest_anib.log 2>&1; echo "pytest rc=$?" >> $O/pytest_anib.log
+  tail -30 $O/pytest_anib.log; cp gpurun_out/anib_blast_agreement.json $O/ 2>/dev/null ;;
 c3)
   timeout 900 python bench.py --gpus 1 --genomes 200 --seed 20250228 --steps 3 --warmup 1 --no-tetra > $O/bench_c3.log 2> $O/bench_c3.err; echo "c3 rc=$?"
   grep '^{' $O/bench_c3.log > $O/bench_c3.json; cut -c1-2500 $O/bench_c3.json; tail -5 $O/bench_c3.err ;;
