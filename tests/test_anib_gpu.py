@@ -108,10 +108,13 @@ def test_real_pair_equals_cpu_statement(eng, caulobacter, genome_dir):
 def test_agreement_with_blast_plus_tables(eng, caulobacter):
     """All 12 ordered Caulobacter pairs against the BLAST+ tables and blastn_result.csv of the reference's tests.  The two
     99.99 % pairs: aligned length, similarity errors and mean identity EQUAL BLAST+'s (incl. the reference's known answer
-    4 016 551 / 93 / 99.99769357705, tests/test_anib.py:387-391).  The ten 78-84 % pairs: mean identity within 0.2 percentage
-    points (measured 0.09-0.16; the reference's own concordance tolerance is 5 below 90 % identity and 0.2 above), aligned
-    length within 2 % (measured -0.8 ... -1.4 %: BLAST+'s 11-mer words find a few per cent more low-identity fragments than
-    16-mer seeds do).  Per pair the level reached goes to gpurun_out/anib_blast_agreement.json."""
+    4 016 551 / 93 / 99.99769357705, tests/test_anib.py:387-391).  The ten 78-84 % pairs: mean identity within 0.04 percentage
+    points and aligned length within 0.25 % (measured on MI355X, round 3, with the word tier — blastn's 11-mer seeds for the
+    fragments the 16-mer seeds leave without a reportable HSP: identity -0.026 ... +0.026 pp, aligned length -0.15 ... +0.17 %,
+    profiles/r03_anib_blast_agreement.json; round 2 without it: +0.09 ... +0.16 pp and -0.8 ... -1.4 %).  BLAST+ itself is a
+    heuristic whose tables cannot be reproduced row for row without restating all of blastn; the reference's own concordance
+    tolerances for this mode are 0.2 / 5 points (tests/test_zz_concordance_gpu.py holds them on genomes not used here).
+    Per pair the level reached goes to gpurun_out/anib_blast_agreement.json."""
     ids, res = caulobacter
     rows = list(csv.reader(open(GOLD / "ref_targets" / "anib_blastn_result.csv")))
     names = rows[0][1:]
@@ -129,7 +132,7 @@ def test_agreement_with_blast_plus_tables(eng, caulobacter):
         if rep["blast"][2] > 99.0:
             assert rep["ours"][:2] == rep["blast"][:2] and abs(rep["identity_pp_diff"]) < 1e-9, (name, rep)
         else:
-            assert abs(rep["identity_pp_diff"]) < 0.2 and abs(rep["aln_length_rel_diff"]) < 0.02, (name, rep)
+            assert abs(rep["identity_pp_diff"]) < 0.04 and abs(rep["aln_length_rel_diff"]) < 0.0025, (name, rep)
     near = report["NC_002696_vs_NC_011916"]
     assert near["ours"][:2] == [4016551, 93] and abs(near["ours"][2] - 99.997693577050029) < 1e-9   # the reference's known answer
 
