@@ -148,7 +148,8 @@ struct AnimScratch {
   int32_t* pn_n = nullptr;          // per unit: alignments (< 0: capacity)
   uint32_t* pn_cursor = nullptr;    // unit hand-out counter of the persistent waves
   uint32_t* pn_gscratch = nullptr;  // [waves][PN_GLOBAL_WORDS] anti-diagonals too wide for LDS
-  size_t pn_cap = 0, pn_units = 0, pn_waves = 0;
+  PnForcedReq* pn_reqs = nullptr;   // the launch's deferred forced runs (at most one per alignment started: <= chains)
+  size_t pn_cap = 0, pn_units = 0, pn_waves = 0, pn_req_cap = 0;
   // fragment mode (ANIb)
   int32_t* fr_tables = nullptr;     // frag_pos | frag_len | rec_frag0 of every distinct query genome of the batch
   FragPair* fr_pairs = nullptr;
@@ -260,7 +261,7 @@ static void anim_free_one(pg_ctx* ctx, void*& slot) {
                   A->iscratch, A->order, A->prev, A->next, A->alnof, A->chains, A->fw, A->bw, A->S.alns, A->S.a_rrec,
                   A->S.a_qrec, A->S.idx, A->S.from, A->S.sc, A->wl_d, A->seedbuf, A->seed_total, A->tasks_d, A->fr_tables, A->fr_pairs,
                   A->fr_slot_pair, A->fr_off, A->fr_nrows, A->fr_ebase, A->fr_entries, A->fr_rows, A->fr_out, A->fr_list, A->fr_nlist, A->fr_wtmp, A->fr_widx,
-                  A->pn, A->pn_fused, A->pn_n, A->pn_cursor, A->pn_gscratch};
+                  A->pn, A->pn_fused, A->pn_n, A->pn_cursor, A->pn_gscratch, A->pn_reqs};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   delete A;
   slot = nullptr;
@@ -638,16 +639,23 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
       A->pn_cap = Mp;
     }
     if (n_units > A->pn_units) { if ((rc = regrow(ctx, A->pn_n, (size_t)n_units + n_units / 2))) return rc; A->pn_units = (size_t)n_units + n_units / 2; }
-    if (!A->pn_cursor && (rc = regrow(ctx, A->pn_cursor, 4))) return rc;
+    if (!A->pn_cursor && (rc = regrow(ctx, A->pn_cursor, 8))) return rc;
     const uint32_t pn_waves = (uint32_t)ctx->num_cu * 12u;   // 12 KiB of LDS each: 12 per CU
     if (pn_waves > A->pn_waves) { if ((rc = regrow(ctx, A->pn_gscratch, (size_t)pn_waves * PN_GLOBAL_WORDS))) return rc; A->pn_waves = pn_waves; }
-    PG_HIP(ctx, hipMemsetAsync(A->pn_cursor, 0, 4, cur_stream(ctx)));
+    const size_t req_cap = n_wl + 16;
+    if (req_cap > A->pn_req_cap) { if ((rc = regrow(ctx, A->pn_reqs, req_cap + req_cap / 2))) return rc; A->pn_req_cap = req_cap + req_cap / 2; }
+    PG_HIP(ctx, hipMemsetAsync(A->pn_cursor, 0, 16, cur_stream(ctx)));   // [0] unit cursor, [1] forced runs recorded, [2] forced-run cursor
     pg_prof_begin(ctx, PG_K_ANIM_EXTEND);
     if (n_wl)
       hipLaunchKernelGGL(anim_postnuc_kernel, dim3(pn_waves < n_units ? pn_waves : n_units), dim3(64), 0, cur_stream(ctx), A->refs_d, A->units_d,
-                         n_units, O, A->pn_cursor, A->pn, A->pn_fused, A->pn_n, A->pn_gscratch);
+                         n_units, O, A->pn_cursor, A->pn, A->pn_fused, A->pn_n, A->pn_gscratch, A->pn_reqs, A->pn_cursor + 1, (uint32_t)req_cap);
     else
       PG_HIP(ctx, hipMemsetAsync(A->pn_n, 0, (size_t)n_units * 4, cur_stream(ctx)));
+    pg_prof_end(ctx);
+    pg_prof_begin(ctx, PG_K_ANIM_EXTLANE);     // (the forced re-alignments, deferred: pga_postnuc.inc)
+    if (n_wl)
+      hipLaunchKernelGGL(anim_postnuc_forced_kernel, dim3(pn_waves), dim3(64), 0, cur_stream(ctx), A->refs_d, A->units_d, A->pn_reqs,
+                         A->pn_cursor + 1, (uint32_t)req_cap, A->pn_cursor + 2, A->pn_n, A->pn_gscratch);
     pg_prof_end(ctx);
     if (getenv("PYANI_PN_STATS")) {   // development: what the engines did in this launch
       PG_HIP(ctx, hipStreamSynchronize(cur_stream(ctx)));

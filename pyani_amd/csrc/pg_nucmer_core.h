@@ -154,7 +154,10 @@ struct PnScalarScans {
 // optimal path, every comparison along it (a competitor's banded value is <= its full value, which lost under the same tie
 // order) and therefore the riding error count are those of the full rectangle; otherwise w doubles.  Near-identical genomes
 // certify at w = 32 where the rectangle has 10^8 cells.
-constexpr int32_t FORCED_BAND_FIRST = 32;
+// Band sequence: w = 28, 60, 124, 252, 508, 1020, then the whole rectangle (band cells = w + |M - N| / 2 + 2: chosen so that
+// successive bands fill the GPU's register engines of 127 / 255 / 511 / 1023 cells).
+constexpr int32_t FORCED_BAND_FIRST = 28;
+PG_HD int32_t forced_band_next(int32_t w) { return 2 * w + 4; }
 PG_HD int64_t forced_outside_bound(int32_t N, int32_t M, int32_t w) {
   const int64_t mn = N < M ? N : M, df = N < M ? M - N : N - M;
   return (int64_t)GOOD_SCORE * (mn - (w + 1)) + (int64_t)CONT_GAP_SCORE * (df + 2 * (int64_t)(w + 1)) + 2 * (OPEN_GAP_SCORE - CONT_GAP_SCORE);
@@ -177,6 +180,12 @@ struct ScalarEngine {
   int32_t cap;
   int32_t overflow = 0;
   long cells = 0;
+  // a forced alignment between two known corners: its error count (see the call sites in postnuc_unit)
+  PG_HD int32_t forced_errors(int32_t A0, int32_t A1, int32_t B0, int32_t B1, PnAln*) {
+    int32_t err = 0, a = A1, b = B1;
+    align(A0, a, B0, b, FORCED_FORWARD_ALIGN, err);
+    return err;
+  }
   // the scans of extendClusters in MUMmer's own order
   PG_HD bool shadowed(const Chain* chains, const PnAln* al, int from, int c, int32_t sA, int32_t eA, int32_t sB, int32_t eB) const {
     return PnScalarScans().shadowed(chains, al, from, c, sA, eA, sB, eB); }
@@ -194,7 +203,7 @@ struct ScalarEngine {
     if (!(m_o & FORCED_BIT)) return run(Astart, Aend, Bstart, Bend, m_o, -1, errors);
     const bool fwd = m_o & DIRECTION_BIT;
     const int32_t N = fwd ? Aend - Astart + 1 : Astart - Aend + 1, M = fwd ? Bend - Bstart + 1 : Bstart - Bend + 1;
-    for (int32_t w = FORCED_BAND_FIRST;; w *= 2) {
+    for (int32_t w = FORCED_BAND_FIRST;; w = forced_band_next(w)) {
       int32_t a = Aend, b = Bend, score = 0;
       const bool whole = w >= (N > M ? N : M);
       const bool reached = run(Astart, a, Bstart, b, m_o, whole ? -1 : w, errors, &score);
@@ -366,6 +375,12 @@ template <typename RefT, typename QryT>
 struct DiagEngine {
   DiagScalarEngine<RefT, QryT> fast;
   ScalarEngine<RefT, QryT> slow;
+  // a forced alignment between two known corners: its error count (see the call sites in postnuc_unit)
+  PG_HD int32_t forced_errors(int32_t A0, int32_t A1, int32_t B0, int32_t B1, PnAln*) {
+    int32_t err = 0, a = A1, b = B1;
+    align(A0, a, B0, b, FORCED_FORWARD_ALIGN, err);
+    return err;
+  }
   // the scans of extendClusters in MUMmer's own order
   PG_HD bool shadowed(const Chain* chains, const PnAln* al, int from, int c, int32_t sA, int32_t eA, int32_t sB, int32_t eB) const {
     return PnScalarScans().shadowed(chains, al, from, c, sA, eA, sB, eB); }
@@ -380,7 +395,7 @@ struct DiagEngine {
     bool reached = false;
     const long c0 = fast.cells + slow.cells;
     int cls = 0;
-    if (m_o & FORCED_BIT) { cls = 15; for (int t = 0; t < 12; ++t) if (band_w == (FORCED_BAND_FIRST << t)) cls = 1 + t; }
+    if (m_o & FORCED_BIT) { cls = 15; int32_t w = FORCED_BAND_FIRST; for (int t = 0; t < 12; ++t, w = forced_band_next(w)) if (band_w == w) cls = 1 + t; }
     struct Tally { DiagEngine* e; int cls; long c0; ~Tally() { e->stat_cells[cls] += e->fast.cells + e->slow.cells - c0; e->stat_calls[cls] += 1; } } tally{this, cls, c0};
     if (fast.run(Astart, a, Bstart, b, m_o, band_w, errors, score, reached)) { Aend = a; Bend = b; return reached; }
     ++fast.fallbacks;
@@ -391,7 +406,7 @@ struct DiagEngine {
     if (!(m_o & FORCED_BIT)) return run(Astart, Aend, Bstart, Bend, m_o, -1, errors, score);
     const bool fwd = m_o & DIRECTION_BIT;
     const int32_t N = fwd ? Aend - Astart + 1 : Astart - Aend + 1, M = fwd ? Bend - Bstart + 1 : Bstart - Bend + 1;
-    for (int32_t w = FORCED_BAND_FIRST;; w *= 2) {
+    for (int32_t w = FORCED_BAND_FIRST;; w = forced_band_next(w)) {
       int32_t a = Aend, b = Bend;
       const bool whole = w >= (N > M ? N : M);
       const bool reached = run(Astart, a, Bstart, b, m_o, whole ? -1 : w, errors, score);
@@ -452,18 +467,15 @@ PG_HD int postnuc_unit(ENG& eng, const Chain* chains, const Match* cm, const int
           bool reached = eng.align(al[cura].sA, tA, al[cura].sB, tB, m_o | SEARCH_BIT, err);
           if (overflow || tgt < 0) reached = false;
           if (reached) {
-            int32_t eA = al[cura].sA, eB = al[cura].sB;
-            eng.align(al[tgt].eA, eA, al[tgt].eB, eB, FORCED_FORWARD_ALIGN, err);
-            al[tgt].errors += err;
+            // forced re-alignments only contribute their error count (the corner is reached by definition): the engine may
+            // return it now (scalar engines) or add it to the alignment later (the GPU defers them to a kernel of their own)
+            al[tgt].errors += eng.forced_errors(al[tgt].eA, al[cura].sA, al[tgt].eB, al[cura].sB, al + tgt);
             al[tgt].eA = al[cura].eA; al[tgt].eB = al[cura].eB;
             --n_al;
             cura = tgt;
           } else {
-            if (tA != al[cura].sA || tB != al[cura].sB) {
-              int32_t eA = al[cura].sA, eB = al[cura].sB;
-              eng.align(tA, eA, tB, eB, FORCED_FORWARD_ALIGN, err);
-              al[cura].errors += err;
-            }
+            if (tA != al[cura].sA || tB != al[cura].sB)
+              al[cura].errors += eng.forced_errors(tA, al[cura].sA, tB, al[cura].sB, al + cura);
             al[cura].sA = tA; al[cura].sB = tB;
           }
         }
