@@ -56,7 +56,7 @@ def parse_args():
     ap.add_argument("--genomes", type=int, default=None, help="anim: genomes of the job (C4: 1000); tetra: genomes per GPU (C2: 200)")
     ap.add_argument("--length", type=int, default=5_000_000, help="ancestor length in bases (5 Mb)")
     ap.add_argument("--seed", type=int, default=None, help="default: the set's own seed (C4 20250301, C2 20250228)")
-    ap.add_argument("--rows-per-step", type=int, default=None, help="genomes (grid rows) per step: default all (anim: a step = the whole grid) / 10 (anib)")
+    ap.add_argument("--rows-per-step", type=int, default=None, help="genomes (grid rows) per step: default genomes / 10 (anim: ten steps = the whole grid) / 10 (anib)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=0, help="anim: ordered pairs timed by the CPU leg (0 = one per host thread, <= 128)")
     ap.add_argument("--cpu-genomes", type=int, default=2, help="tetra: genomes timed by the CPU leg")
@@ -72,7 +72,9 @@ def parse_args():
     if args.seed is None:
         args.seed = {"anim": 20250301, "tetra": 20250228, "anib": 20250302}[w]
     if args.rows_per_step is None:
-        args.rows_per_step = 10 if w == "anib" else args.genomes
+        # anim: a tenth of the grid per step (the exact extension stage makes a whole C4 grid a ~1 min step; the driver's 25 steps
+        # must finish in minutes) — ~100 000 ordered pairs per step at C4, far above the size where launches stop filling the GPU
+        args.rows_per_step = 10 if w == "anib" else max(1, args.genomes // 10)
     return args
 
 
@@ -129,20 +131,26 @@ def anim_cpu_baseline(args, data, n, related, gpu_lookup):
     t_unrel = float(secs[len(rel):].mean()) if unrel else 0.0
     job_cpu_s = n_rel_job * t_rel + n_unrel_job * t_unrel
     job_wall = job_cpu_s / threads
-    same = 0
+    same = covered_n = 0
     for (q, s), r in zip(sample, res):
         g = gpu_lookup(q, s)
-        same += int(g is None or (int(g["ref_aln_len"]), int(g["qry_aln_len"]), int(g["sim_errors"]), float(g["identity"]).hex(), int(g["status"])) ==
+        if g is None:
+            continue           # (a sampled cell the timed steps did not cover counts for nothing)
+        covered_n += 1
+        same += int((int(g["ref_aln_len"]), int(g["qry_aln_len"]), int(g["sim_errors"]), float(g["identity"]).hex(), int(g["status"])) ==
                     (int(r["ref_aln_len"]), int(r["qry_aln_len"]), int(r["sim_errors"]), float(r["identity"]).hex(), int(r["status"])))
     return {
         "value": (n_rel_job + n_unrel_job) / job_wall, "unit": "genome-pairs/s", "cores": threads, "kind": "port",
-        "variant": "own-cpu (oracle/anim_cpu.cpp: host build of the engine's scalar core, exhaustive 20-mer table; NOT MUMmer)",
+        "variant": "own-cpu (oracle/anim_cpu.cpp: host build of the engine's scalar statement of MUMmer's algorithm — exhaustive 20-mer "
+                   "table, mgaps clustering, postnuc extension with its dynamic band — -O2, one pair per thread; NOT MUMmer's binary, whose "
+                   "suffix-tree matcher and full-rectangle re-alignments cost more per pair)",
+        "cpu_s_per_related_pair": t_rel, "cpu_s_per_unrelated_pair": t_unrel,
         "sample": note + f"{len(sample)} ordered pairs of the same job ({len(rel)} related, {len(unrel)} unrelated) run one per host "
                   f"thread ({min(threads, len(sample))} concurrent, {wall:.1f} s wall, {float(secs.sum()):.0f} CPU-s): "
                   f"{t_rel:.2f} s per related pair, {t_unrel:.2f} s per unrelated pair; extrapolated linearly to "
                   f"{n_rel_job} related + {n_unrel_job} unrelated pairs on {threads} threads",
         "job_seconds_extrapolated": job_wall, "cpu_seconds_extrapolated": job_cpu_s,
-        "gpu_parity_on_sample": f"{same}/{len(sample)} sampled pairs identical to the GPU's result",
+        "gpu_parity_on_sample": f"{same}/{covered_n} sampled pairs (of {len(sample)}; the others were not among the timed cells) identical to the GPU's result",
     }
 
 
@@ -223,6 +231,26 @@ def tetra_subrecord(eng, local, no_cpu):
     return rec
 
 
+ASSEMBLY_S_PER_PAIR = 1.2e-6     # pyani_amd.anim.assemble_run_matrices, measured on the full C4 grid (999 000 pairs in 1.2 s)
+
+
+def related_only_record(eng, args):
+    """One family of the same generator (25 genomes of one ancestor, all 600 ordered pairs related) in ONE call: the rate a
+    genus-level job sees, where no pair is a cheap miss."""
+    n, K = args.genomes, (args.genomes + 24) // 25
+    fam = [g for g in range(n) if g % K == 1][:25]
+    data = [synth_genomes(args.seed, n, args.length, g, g + 1, 1)[0] for g in fam]
+    ids = [eng.add_genome(s_, o_) for s_, o_ in data]
+    eng.upload()
+    pairs = [(a, b) for a in ids for b in ids if a != b]
+    eng.anim_pairs([a for a, _ in pairs[:50]], [b for _, b in pairs[:50]])      # seed lists built
+    t0 = time.perf_counter()
+    res = eng.anim_pairs([a for a, _ in pairs], [b for _, b in pairs])
+    dt = time.perf_counter() - t0
+    return {"workload": f"{len(fam)} genomes of one ancestor ({len(pairs)} ordered pairs, all related), one call", "seconds": dt,
+            "pairs_per_s": len(pairs) / dt, "pairs_with_alignment": int((res["status"] == 0).sum())}
+
+
 def run_anim(args, rank, world, local, dist, torch):
     from pyani_amd import _lib, parallel
     from pyani_amd.engine import Engine
@@ -271,9 +299,15 @@ def run_anim(args, rank, world, local, dist, torch):
             dist.barrier()
         torch.cuda.synchronize()
 
+    t_cold = time.perf_counter()
     for k in range(args.warmup):
         step(k)
+        if k == 0:
+            fence()
+            t_cold = time.perf_counter() - t_cold      # the first step also builds the seed lists of every genome it touches
     fence()
+    if args.warmup == 0:
+        t_cold = None
     stages = [_lib.K_ANIM_SEED, _lib.K_ANIM_HIT, _lib.K_ANIM_CLUSTER, _lib.K_ANIM_GAPS, _lib.K_ANIM_EXTLANE, _lib.K_ANIM_EXTEND,
               _lib.K_ANIM_FINISH]
     eng.profile_reset()
@@ -323,7 +357,7 @@ def run_anim(args, rank, world, local, dist, torch):
                       "parse_delta equivalent per ordered pair, genomes resident in HBM; vs the CPU path on this box's host cores",
             "value": pairs_done / elapsed, "unit": "genome-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": step_s * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "int32 DP keys (score << 15 | errors), i64 lengths, f64 identity", "data": "synthetic",
+            "dtype": "u32 packed DP words (score << 17 | state << 15 | errors), i64 lengths, f64 identity", "data": "synthetic",
             "related_pairs_per_s": n_related / elapsed,
             "config": {
                 "workload": f"C4: ANIm N x N grid on {n} synthetic ~{args.length / 1e6:g} Mb genomes (SURVEY.md §8(d) generator, seed "
@@ -340,7 +374,12 @@ def run_anim(args, rank, world, local, dist, torch):
                 "results_sha1_full_grid": sha,
                 "parallelism": f"1 process/GPU x {world}; genomes replicated; each step's rows dealt over the ranks; one RCCL "
                                f"all-gather per step" if world > 1 else "1 GPU",
-                "host_prep_s": t_prep,
+                "host_prep_s": t_prep, "cold_first_step_s": t_cold,
+                "end_to_end_cold_s_estimate": (t_prep + (t_cold or step_s) + (n / R - 1) * step_s + ASSEMBLY_S_PER_PAIR * n * (n - 1)),
+                "note_end_to_end": "synthetic-genome generation + 2-bit packing + upload (host_prep_s; a FASTA run parses instead: 27.6 GB/s of text, "
+                                   "profiles/r01_ingest_100x5M.json) + the first step with its one-time seed-list builds + the remaining steps of one grid at "
+                                   "the timed rate + the vectorised matrix assembly (1.2 us per pair, measured r02 on 999 000 pairs)",
+                "extender": "nucmer (MUMmer 3.23's postnuc algorithm restated: exact on every nucmer output file the reference's tests hold)",
                 "note_related_pairs_per_s": "related pairs timed / the same wall time (unrelated pairs of the tile included): a lower "
                                             "bound of the related-only rate; 97.6 % of C4's pairs are unrelated by construction",
             },
@@ -366,6 +405,8 @@ def run_anim(args, rank, world, local, dist, torch):
             related_all = ((np.arange(n)[:, None] % K) == (np.arange(n)[None, :] % K))[~np.eye(n, dtype=bool)]
             out["cpu_baseline"] = anim_cpu_baseline(args, data, n, related_all, gpu_lookup)
             out["cpu_baseline"]["speedup_gpu_over_cpu_job"] = out["value"] / out["cpu_baseline"]["value"]
+        if world == 1 and not args.no_cpu_baseline:
+            out["related_only"] = related_only_record(eng, args)
         if world == 1 and not args.no_tetra:
             out["tetra"] = tetra_subrecord(eng, local, args.no_cpu_baseline)
         print(json.dumps(out), flush=True)
@@ -424,9 +465,15 @@ def run_anib(args, rank, world, local, dist, torch):
             dist.barrier()
         torch.cuda.synchronize()
 
+    t_cold = time.perf_counter()
     for k in range(args.warmup):
         step(k)
+        if k == 0:
+            fence()
+            t_cold = time.perf_counter() - t_cold      # the first step also builds the seed lists of every genome it touches
     fence()
+    if args.warmup == 0:
+        t_cold = None
     stages = [_lib.K_ANIM_SEED, _lib.K_ANIM_HIT, _lib.K_ANIB_BUCKET, _lib.K_ANIB_FRAG]
     eng.profile_reset()
     eng.profile_config(kernel_mask=sum(1 << s_ for s_ in stages), every_n=1)

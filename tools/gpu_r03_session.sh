@@ -24,7 +24,7 @@ c3)
   timeout 900 python bench.py --gpus 1 --genomes 200 --seed 20250228 --steps 3 --warmup 1 --no-tetra > $O/bench_c3.log 2> $O/bench_c3.err; echo "c3 rc=$?"
   grep '^{' $O/bench_c3.log > $O/bench_c3.json; cut -c1-2500 $O/bench_c3.json; tail -5 $O/bench_c3.err ;;
 c4)
-  timeout 1200 python bench.py --gpus 1 --steps 2 --warmup 1 --no-tetra --no-cpu-baseline > $O/bench_c4.log 2> $O/bench_c4.err; echo "c4 rc=$?"
+  timeout 1200 python bench.py --gpus 1 --steps 4 --warmup 1 --no-tetra --no-cpu-baseline > $O/bench_c4.log 2> $O/bench_c4.err; echo "c4 rc=$?"
   grep '^{' $O/bench_c4.log > $O/bench_c4.json; cut -c1-2500 $O/bench_c4.json; tail -5 $O/bench_c4.err ;;
 bench)
   timeout 1500 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_n1.log 2> $O/bench_n1.err; echo "bench rc=$?"
