@@ -149,6 +149,7 @@ struct AnimScratch {
   uint32_t* pn_cursor = nullptr;    // unit hand-out counter of the persistent waves
   uint32_t* pn_gscratch = nullptr;  // [waves][PN_GLOBAL_WORDS] anti-diagonals too wide for LDS
   PnForcedReq* pn_reqs = nullptr;   // the launch's deferred forced runs (at most one per alignment started: <= chains)
+  pgn::PnGap* pn_gaps = nullptr;    // match-to-match alignments by match slot
   size_t pn_cap = 0, pn_units = 0, pn_waves = 0, pn_req_cap = 0;
   // fragment mode (ANIb)
   int32_t* fr_tables = nullptr;     // frag_pos | frag_len | rec_frag0 of every distinct query genome of the batch
@@ -261,7 +262,7 @@ static void anim_free_one(pg_ctx* ctx, void*& slot) {
                   A->iscratch, A->order, A->prev, A->next, A->alnof, A->chains, A->fw, A->bw, A->S.alns, A->S.a_rrec,
                   A->S.a_qrec, A->S.idx, A->S.from, A->S.sc, A->wl_d, A->seedbuf, A->seed_total, A->tasks_d, A->fr_tables, A->fr_pairs,
                   A->fr_slot_pair, A->fr_off, A->fr_nrows, A->fr_ebase, A->fr_entries, A->fr_rows, A->fr_out, A->fr_list, A->fr_nlist, A->fr_wtmp, A->fr_widx,
-                  A->pn, A->pn_fused, A->pn_n, A->pn_cursor, A->pn_gscratch, A->pn_reqs};
+                  A->pn, A->pn_fused, A->pn_n, A->pn_cursor, A->pn_gscratch, A->pn_reqs, A->pn_gaps};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   delete A;
   slot = nullptr;
@@ -636,6 +637,7 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
     if (Mp > A->pn_cap) {
       if ((rc = regrow(ctx, A->pn, Mp))) return rc;
       if ((rc = regrow(ctx, A->pn_fused, Mp))) return rc;
+      if ((rc = regrow(ctx, A->pn_gaps, Mp))) return rc;
       A->pn_cap = Mp;
     }
     if (n_units > A->pn_units) { if ((rc = regrow(ctx, A->pn_n, (size_t)n_units + n_units / 2))) return rc; A->pn_units = (size_t)n_units + n_units / 2; }
@@ -645,10 +647,20 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
     const size_t req_cap = n_wl + 16;
     if (req_cap > A->pn_req_cap) { if ((rc = regrow(ctx, A->pn_reqs, req_cap + req_cap / 2))) return rc; A->pn_req_cap = req_cap + req_cap / 2; }
     PG_HIP(ctx, hipMemsetAsync(A->pn_cursor, 0, 16, cur_stream(ctx)));   // [0] unit cursor, [1] forced runs recorded, [2] forced-run cursor
+    if (n_wl) {     // the (unit, chain) work list, then every cluster's match-to-match alignments
+      if (n_wl > A->wl) { if ((rc = regrow(ctx, A->wl_d, n_wl + n_wl / 2))) return rc; A->wl = n_wl + n_wl / 2; }
+      PG_HIP(ctx, hipMemcpyAsync(A->choff_d, choff.data(), choff.size() * 4, hipMemcpyHostToDevice, cur_stream(ctx)));
+      hipLaunchKernelGGL(anim_wl_kernel, dim3(n_units), dim3(64), 0, cur_stream(ctx), A->choff_d, A->wl_d);
+      pg_prof_begin(ctx, PG_K_ANIM_GAPS);
+      hipLaunchKernelGGL(anim_postnuc_gap_kernel, dim3(pn_waves), dim3(64), 0, cur_stream(ctx), A->refs_d, A->units_d, O, A->wl_d, (uint32_t)n_wl,
+                         A->pn_cursor + 3, A->pn_gaps, A->pn_gscratch);
+      pg_prof_end(ctx);
+    }
     pg_prof_begin(ctx, PG_K_ANIM_EXTEND);
     if (n_wl)
       hipLaunchKernelGGL(anim_postnuc_kernel, dim3(pn_waves < n_units ? pn_waves : n_units), dim3(64), 0, cur_stream(ctx), A->refs_d, A->units_d,
-                         n_units, O, A->pn_cursor, A->pn, A->pn_fused, A->pn_n, A->pn_gscratch, A->pn_reqs, A->pn_cursor + 1, (uint32_t)req_cap);
+                         n_units, O, A->pn_cursor, A->pn, A->pn_fused, A->pn_n, A->pn_gscratch, A->pn_reqs, A->pn_cursor + 1, (uint32_t)req_cap,
+                         A->pn_gaps);
     else
       PG_HIP(ctx, hipMemsetAsync(A->pn_n, 0, (size_t)n_units * 4, cur_stream(ctx)));
     pg_prof_end(ctx);

@@ -34,6 +34,9 @@ struct PnAln {
   int32_t chain;   // the chain (cluster) it started from: names the (reference record, query record) it belongs to
 };
 
+// The forward alignment from a cluster's match to its next one, computed ahead of the unit's walk (pga_postnuc.inc).
+struct PnGap { int32_t eA, eB, errors, reached; };
+
 // ---- packed DP words ----------------------------------------------------------------------------------------------------
 // One 32-bit word per state:  (score + SCORE_BIAS) << 17 | state << 15 | errors.
 // MUMmer compares scores only and breaks ties by state (scoreEdit and maxScore alike: MATCH, then INSERT, then DELETE).  With the
@@ -180,6 +183,7 @@ struct ScalarEngine {
   int32_t cap;
   int32_t overflow = 0;
   long cells = 0;
+  PG_HD bool gap_ready(int32_t, PnGap&) const { return false; }     // (scalar engines align match to match as they go)
   // a forced alignment between two known corners: its error count (see the call sites in postnuc_unit)
   PG_HD int32_t forced_errors(int32_t A0, int32_t A1, int32_t B0, int32_t B1, PnAln*) {
     int32_t err = 0, a = A1, b = B1;
@@ -375,6 +379,7 @@ template <typename RefT, typename QryT>
 struct DiagEngine {
   DiagScalarEngine<RefT, QryT> fast;
   ScalarEngine<RefT, QryT> slow;
+  PG_HD bool gap_ready(int32_t, PnGap&) const { return false; }     // (scalar engines align match to match as they go)
   // a forced alignment between two known corners: its error count (see the call sites in postnuc_unit)
   PG_HD int32_t forced_errors(int32_t A0, int32_t A1, int32_t B0, int32_t B1, PnAln*) {
     int32_t err = 0, a = A1, b = B1;
@@ -482,8 +487,17 @@ PG_HD int postnuc_unit(ENG& eng, const Chain* chains, const Match* cm, const int
       }
       // extendForward: to the next match of the cluster, or from its last match towards the target cluster
       unsigned m_o = FORWARD_ALIGN;
-      if (m + 1 < C.count) { targetA = mm[m + 1].r; targetB = mm[m + 1].q; }
-      else {
+      if (m + 1 < C.count) {
+        targetA = mm[m + 1].r; targetB = mm[m + 1].q;
+        // match to match inside a cluster: the call depends on the two matches only (the alignment ends on this match's last
+        // base), so an engine may have it ready (the GPU runs all of them in a pass of their own before the units)
+        PnGap g;
+        if (eng.gap_ready(C.first + m, g)) {
+          al[cura].errors += g.errors; al[cura].eA = g.eA; al[cura].eB = g.eB;
+          target_reached = g.reached != 0;
+          continue;
+        }
+      } else {
         targetA = r_hi - 1; targetB = q_hi - 1;
         // getForwardTargetCluster
         const int32_t sA = ml.r + ml.len - 1, sB = ml.q + ml.len - 1;
