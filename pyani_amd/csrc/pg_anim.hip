@@ -70,6 +70,27 @@ __device__ __forceinline__ void get16(const uint32_t* __restrict__ codes, const 
   m = (uint32_t)(ml >> ms) & 0xFFFFu;
 }
 
+// 2-bit codes / clean bits of the n <= 32 stream positions p0 .. p0 + n - 1 of a packed genome (positions outside are not clean)
+__device__ __forceinline__ void packed_window(const uint32_t* __restrict__ codes, const uint32_t* __restrict__ mask, int32_t len, int64_t p0,
+                                              uint64_t& c, uint32_t& ok) {
+  c = 0; ok = 0;
+  if (p0 >= len || p0 + 32 <= 0) return;
+  const int64_t q0 = p0 < 0 ? 0 : p0;                 // first position actually read
+  const int sh = (int)(q0 - p0);                      // it lands at window slot sh
+  const int32_t w = (int32_t)(q0 >> 4), lastw = (len - 1) >> 4;
+  const uint32_t c0 = codes[w], c1 = codes[w + 1 <= lastw ? w + 1 : lastw], c2 = codes[w + 2 <= lastw ? w + 2 : lastw];
+  const int cs = 2 * (int)(q0 & 15);
+  uint64_t lo = ((uint64_t)c1 << 32) | c0;
+  uint64_t win = cs ? ((lo >> cs) | ((uint64_t)c2 << (64 - cs))) : lo;
+  const int32_t mw = (int32_t)(q0 >> 5), lastm = (len - 1) >> 5;
+  const uint64_t m = ((uint64_t)mask[mw + 1 <= lastm ? mw + 1 : lastm] << 32) | mask[mw];
+  uint32_t okw = (uint32_t)(m >> (q0 & 31));
+  const int64_t avail = len - q0;                      // positions from q0 that exist
+  if (avail < 32) okw &= (avail <= 0 ? 0u : ((1u << avail) - 1u));
+  c = sh ? (win << (2 * sh)) : win;
+  ok = sh ? (okw << sh) : okw;
+}
+
 #include "pga_seed.inc"
 #include "pga_cluster.inc"
 #include "pga_dp_wave.inc"
@@ -150,6 +171,8 @@ struct AnimScratch {
   uint32_t* pn_gscratch = nullptr;  // [waves][PN_GLOBAL_WORDS] anti-diagonals too wide for LDS
   PnForcedReq* pn_reqs = nullptr;   // the launch's deferred forced runs (at most one per alignment started: <= chains)
   pgn::PnGap* pn_gaps = nullptr;    // match-to-match alignments by match slot
+  PnGapTask* pn_tasks = nullptr;    // [3 size classes][pn_cap] small gaps for the lane kernel
+  uint32_t* pn_order = nullptr;     // units by descending cluster count
   size_t pn_cap = 0, pn_units = 0, pn_waves = 0, pn_req_cap = 0;
   // fragment mode (ANIb)
   int32_t* fr_tables = nullptr;     // frag_pos | frag_len | rec_frag0 of every distinct query genome of the batch
@@ -262,7 +285,7 @@ static void anim_free_one(pg_ctx* ctx, void*& slot) {
                   A->iscratch, A->order, A->prev, A->next, A->alnof, A->chains, A->fw, A->bw, A->S.alns, A->S.a_rrec,
                   A->S.a_qrec, A->S.idx, A->S.from, A->S.sc, A->wl_d, A->seedbuf, A->seed_total, A->tasks_d, A->fr_tables, A->fr_pairs,
                   A->fr_slot_pair, A->fr_off, A->fr_nrows, A->fr_ebase, A->fr_entries, A->fr_rows, A->fr_out, A->fr_list, A->fr_nlist, A->fr_wtmp, A->fr_widx,
-                  A->pn, A->pn_fused, A->pn_n, A->pn_cursor, A->pn_gscratch, A->pn_reqs, A->pn_gaps};
+                  A->pn, A->pn_fused, A->pn_n, A->pn_cursor, A->pn_gscratch, A->pn_reqs, A->pn_gaps, A->pn_tasks, A->pn_order};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   delete A;
   slot = nullptr;
@@ -638,29 +661,50 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
       if ((rc = regrow(ctx, A->pn, Mp))) return rc;
       if ((rc = regrow(ctx, A->pn_fused, Mp))) return rc;
       if ((rc = regrow(ctx, A->pn_gaps, Mp))) return rc;
+      if ((rc = regrow(ctx, A->pn_tasks, 3 * Mp))) return rc;
       A->pn_cap = Mp;
     }
-    if (n_units > A->pn_units) { if ((rc = regrow(ctx, A->pn_n, (size_t)n_units + n_units / 2))) return rc; A->pn_units = (size_t)n_units + n_units / 2; }
-    if (!A->pn_cursor && (rc = regrow(ctx, A->pn_cursor, 8))) return rc;
+    if (n_units > A->pn_units) {
+      if ((rc = regrow(ctx, A->pn_n, (size_t)n_units + n_units / 2))) return rc;
+      if ((rc = regrow(ctx, A->pn_order, (size_t)n_units + n_units / 2))) return rc;
+      A->pn_units = (size_t)n_units + n_units / 2;
+    }
+    {
+      std::vector<uint32_t> uorder(n_units);
+      for (uint32_t u = 0; u < n_units; ++u) uorder[u] = u;
+      std::stable_sort(uorder.begin(), uorder.end(), [&](uint32_t a, uint32_t b) { return nch[a] > nch[b]; });
+      PG_HIP(ctx, hipMemcpyAsync(A->pn_order, uorder.data(), (size_t)n_units * 4, hipMemcpyHostToDevice, cur_stream(ctx)));
+      PG_HIP(ctx, hipStreamSynchronize(cur_stream(ctx)));     // (uorder is a local)
+    }
+    if (!A->pn_cursor && (rc = regrow(ctx, A->pn_cursor, 16))) return rc;
     const uint32_t pn_waves = (uint32_t)ctx->num_cu * 12u;   // 12 KiB of LDS each: 12 per CU
     if (pn_waves > A->pn_waves) { if ((rc = regrow(ctx, A->pn_gscratch, (size_t)pn_waves * PN_GLOBAL_WORDS))) return rc; A->pn_waves = pn_waves; }
     const size_t req_cap = n_wl + 16;
     if (req_cap > A->pn_req_cap) { if ((rc = regrow(ctx, A->pn_reqs, req_cap + req_cap / 2))) return rc; A->pn_req_cap = req_cap + req_cap / 2; }
-    PG_HIP(ctx, hipMemsetAsync(A->pn_cursor, 0, 16, cur_stream(ctx)));   // [0] unit cursor, [1] forced runs recorded, [2] forced-run cursor
+    PG_HIP(ctx, hipMemsetAsync(A->pn_cursor, 0, 64, cur_stream(ctx)));   // [0] unit cursor, [1] forced runs recorded ([7]: the long ones), [2] forced-run cursor, [3] chain cursor, [4..6] small gaps
     if (n_wl) {     // the (unit, chain) work list, then every cluster's match-to-match alignments
       if (n_wl > A->wl) { if ((rc = regrow(ctx, A->wl_d, n_wl + n_wl / 2))) return rc; A->wl = n_wl + n_wl / 2; }
       PG_HIP(ctx, hipMemcpyAsync(A->choff_d, choff.data(), choff.size() * 4, hipMemcpyHostToDevice, cur_stream(ctx)));
       hipLaunchKernelGGL(anim_wl_kernel, dim3(n_units), dim3(64), 0, cur_stream(ctx), A->choff_d, A->wl_d);
       pg_prof_begin(ctx, PG_K_ANIM_GAPS);
+      const int lane_small = ctx->anim_gap_lanes;
+      if (lane_small) {     // small gaps: one LANE each, by size class
+        hipLaunchKernelGGL(anim_postnuc_gaplist_kernel, dim3((uint32_t)((n_wl + 255) / 256)), dim3(256), 0, cur_stream(ctx), A->units_d, O, A->wl_d,
+                           (uint32_t)n_wl, A->pn_tasks, A->pn_cap, A->pn_cursor + 4);
+        const dim3 lg((uint32_t)ctx->num_cu * 8u);
+        hipLaunchKernelGGL((anim_postnuc_gaplane_kernel<16>), lg, dim3(64), 0, cur_stream(ctx), A->refs_d, A->units_d, O, A->pn_tasks, A->pn_cursor + 4, A->pn_gaps);
+        hipLaunchKernelGGL((anim_postnuc_gaplane_kernel<32>), lg, dim3(64), 0, cur_stream(ctx), A->refs_d, A->units_d, O, A->pn_tasks + A->pn_cap, A->pn_cursor + 5, A->pn_gaps);
+        hipLaunchKernelGGL((anim_postnuc_gaplane_kernel<PN_SMALL>), lg, dim3(64), 0, cur_stream(ctx), A->refs_d, A->units_d, O, A->pn_tasks + 2 * A->pn_cap, A->pn_cursor + 6, A->pn_gaps);
+      }
       hipLaunchKernelGGL(anim_postnuc_gap_kernel, dim3(pn_waves), dim3(64), 0, cur_stream(ctx), A->refs_d, A->units_d, O, A->wl_d, (uint32_t)n_wl,
-                         A->pn_cursor + 3, A->pn_gaps, A->pn_gscratch);
+                         A->pn_cursor + 3, A->pn_gaps, A->pn_gscratch, lane_small);
       pg_prof_end(ctx);
     }
     pg_prof_begin(ctx, PG_K_ANIM_EXTEND);
     if (n_wl)
       hipLaunchKernelGGL(anim_postnuc_kernel, dim3(pn_waves < n_units ? pn_waves : n_units), dim3(64), 0, cur_stream(ctx), A->refs_d, A->units_d,
                          n_units, O, A->pn_cursor, A->pn, A->pn_fused, A->pn_n, A->pn_gscratch, A->pn_reqs, A->pn_cursor + 1, (uint32_t)req_cap,
-                         A->pn_gaps);
+                         A->pn_gaps, A->pn_order);
     else
       PG_HIP(ctx, hipMemsetAsync(A->pn_n, 0, (size_t)n_units * 4, cur_stream(ctx)));
     pg_prof_end(ctx);

@@ -161,6 +161,16 @@ struct PnScalarScans {
 // successive bands fill the GPU's register engines of 127 / 255 / 511 / 1023 cells).
 constexpr int32_t FORCED_BAND_FIRST = 28;
 PG_HD int32_t forced_band_next(int32_t w) { return 2 * w + 4; }
+// The band to try after band w gave score S without a certificate: a wider band can only score higher, so the first band of the
+// sequence with  17 (w' + 1) > 3 min(N, M) - 7 |M - N| - 6 - S  is certain to certify — the ones before it are skipped (a run
+// over divergent sequence would otherwise be repeated at every size on its way up to the whole rectangle).
+PG_HD int32_t forced_band_after(int32_t w, int32_t N, int32_t M, int32_t S) {
+  const int64_t mn = N < M ? N : M, df = N < M ? M - N : N - M;
+  const int64_t need = ((int64_t)GOOD_SCORE * mn + (int64_t)CONT_GAP_SCORE * df + 2 * (OPEN_GAP_SCORE - CONT_GAP_SCORE) - S) / (GOOD_SCORE - 2 * CONT_GAP_SCORE);
+  int32_t nw = forced_band_next(w);
+  while (nw < need && nw < (N > M ? N : M)) nw = forced_band_next(nw);
+  return nw;
+}
 PG_HD int64_t forced_outside_bound(int32_t N, int32_t M, int32_t w) {
   const int64_t mn = N < M ? N : M, df = N < M ? M - N : N - M;
   return (int64_t)GOOD_SCORE * (mn - (w + 1)) + (int64_t)CONT_GAP_SCORE * (df + 2 * (int64_t)(w + 1)) + 2 * (OPEN_GAP_SCORE - CONT_GAP_SCORE);
@@ -207,11 +217,12 @@ struct ScalarEngine {
     if (!(m_o & FORCED_BIT)) return run(Astart, Aend, Bstart, Bend, m_o, -1, errors);
     const bool fwd = m_o & DIRECTION_BIT;
     const int32_t N = fwd ? Aend - Astart + 1 : Astart - Aend + 1, M = fwd ? Bend - Bstart + 1 : Bstart - Bend + 1;
-    for (int32_t w = FORCED_BAND_FIRST;; w = forced_band_next(w)) {
+    for (int32_t w = FORCED_BAND_FIRST;;) {
       int32_t a = Aend, b = Bend, score = 0;
       const bool whole = w >= (N > M ? N : M);
       const bool reached = run(Astart, a, Bstart, b, m_o, whole ? -1 : w, errors, &score);
       if (overflow || whole || (reached && (int64_t)score > forced_outside_bound(N, M, w))) { Aend = a; Bend = b; return reached; }
+      w = forced_band_after(w, N, M, score);
     }
   }
   // band_w < 0: MUMmer's own band (dynamic, trimmed unless forced); >= 0: a forced run confined to the certified band
@@ -411,11 +422,12 @@ struct DiagEngine {
     if (!(m_o & FORCED_BIT)) return run(Astart, Aend, Bstart, Bend, m_o, -1, errors, score);
     const bool fwd = m_o & DIRECTION_BIT;
     const int32_t N = fwd ? Aend - Astart + 1 : Astart - Aend + 1, M = fwd ? Bend - Bstart + 1 : Bstart - Bend + 1;
-    for (int32_t w = FORCED_BAND_FIRST;; w = forced_band_next(w)) {
+    for (int32_t w = FORCED_BAND_FIRST;;) {
       int32_t a = Aend, b = Bend;
       const bool whole = w >= (N > M ? N : M);
       const bool reached = run(Astart, a, Bstart, b, m_o, whole ? -1 : w, errors, score);
       if (slow.overflow || whole || (reached && (int64_t)score > forced_outside_bound(N, M, w))) { Aend = a; Bend = b; return reached; }
+      w = forced_band_after(w, N, M, score);
     }
   }
 };

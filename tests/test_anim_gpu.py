@@ -287,6 +287,25 @@ def test_lane_to_wave_hand_over_does_not_change_results(eng, monkeypatch):
             assert eng.anim_pairs(ra, qa).tobytes() == ref.tobytes(), (lanes, blocks, cap)
 
 
+def test_gap_forms_and_extenders_of_the_postnuc_stage_agree(monkeypatch):
+    """The match-to-match alignments of a cluster run on one LANE each when their rectangle is small enough to rule out trimming
+    and the break rule (pga_postnuc.inc, PN_SMALL) and on the wave engine otherwise: switching the lane form off
+    (PYANI_ANIM_GAP_LANES=0, read when a context is created) must not change a single result."""
+    from pyani_amd import synth
+    from pyani_amd.engine import Engine
+    n, L = 10, 250_000
+    data = [synth.genome(5, n, g, L) for g in range(n)]
+    out = {}
+    for lanes in ("1", "0"):
+        monkeypatch.setenv("PYANI_ANIM_GAP_LANES", lanes)
+        with Engine(0) as e:
+            ids = [e.add_genome(*d) for d in data]
+            pairs = [(a, b) for a in ids for b in ids if a != b]
+            out[lanes] = e.anim_pairs([a for a, _ in pairs], [b for _, b in pairs])
+    assert (out["1"]["status"] == 0).sum() >= 40
+    assert out["1"].tobytes() == out["0"].tobytes()
+
+
 def test_cluster_stage_forms_do_not_change_results(eng, monkeypatch):
     """The cluster stage finishes small units in one wave and cuts the chain extraction of big units (>= PYANI_ANIM_SPLIT_MIN
     matches, default 2048) into ranges of whole clusters, one wave each, merged in order (pga_cluster.inc:
