@@ -55,14 +55,20 @@ PG_HD uint32_t w_make(int32_t score, uint32_t errors, uint32_t state) { return (
 PG_HD int32_t w_score(uint32_t w) { return (int32_t)(w >> SCORE_SHIFT) - (int32_t)SCORE_BIAS; }
 PG_HD uint32_t w_errors(uint32_t w) { return w & W_ERR; }
 PG_HD uint32_t w_relabel(uint32_t w, uint32_t state) { return (w & ~W_STATE) | state; }
-PG_HD uint32_t w_gap(uint32_t w, int32_t cost) {   // w + cost (cost < 0) and one more error; unreachable stays unreachable
-  const uint32_t c = (uint32_t)(-cost) << SCORE_SHIFT;
-  return w >= c + W_ONE ? w - c + 1u : 0u;
+// Saturating unsigned subtraction (one v_sub_u32 with clamp on the device).
+PG_HD uint32_t w_sat_sub(uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_elementwise_sub_sat(a, b);
+#else
+  return a > b ? a - b : 0u;
+#endif
 }
+// w + cost (cost < 0) and one more error.  A word that falls to score field 0 is unreachable whatever its low bits hold (they
+// cannot carry into the field: at most 20 002 + 3 * 32768 < 2^17), so the subtraction may simply saturate — no test, no select.
+PG_HD uint32_t w_gap(uint32_t w, int32_t cost) { return w_sat_sub(w, ((uint32_t)(-cost) << SCORE_SHIFT) - 1u); }
 PG_HD uint32_t w_step(uint32_t w, bool same) {     // diagonal step from the best state of (i-1, j-1)
-  const uint32_t c = (uint32_t)(-BAD_SCORE) << SCORE_SHIFT;
-  const uint32_t hit = w + ((uint32_t)GOOD_SCORE << SCORE_SHIFT), miss = w >= c + W_ONE ? w - c + 1u : 0u;
-  return w >= W_ONE ? (same ? hit : miss) : 0u;
+  const uint32_t hit = w + ((uint32_t)GOOD_SCORE << SCORE_SHIFT), miss = w_sat_sub(w, ((uint32_t)(-BAD_SCORE) << SCORE_SHIFT) - 1u);
+  return w >= W_ONE ? (same ? hit : miss) : 0u;    // (an unreachable word must stay one: matches would lift it back into the field)
 }
 PG_HD uint32_t w_max3(uint32_t a, uint32_t b, uint32_t c) { const uint32_t m = a > b ? a : b; return m > c ? m : c; }
 

@@ -20,6 +20,15 @@ stats)   # one C3 grid with the engines' counters (PYANI_PN_STATS) and one worke
 anib)
   timeout 1200 python -m pytest tests/test_anib_gpu.py tests/test_zz_concordance_gpu.py -m gpu -q --timeout 900 > $O/pytest_anib.log 2>&1; echo "pytest rc=$?" >> $O/pytest_anib.log
   tail -30 $O/pytest_anib.log; cp gpurun_out/anib_blast_agreement.json $O/ 2>/dev/null ;;
+steps)   # C4 at two step sizes: how much a smaller step (shorter launches) costs
+  for R in 100 250; do
+    timeout 900 python bench.py --gpus 1 --rows-per-step $R --steps 2 --warmup 1 --no-tetra --no-cpu-baseline > $O/bench_c4_R$R.log 2> $O/bench_c4_R$R.err; echo "R=$R rc=$?"
+    python - <<PY
+import json
+d=json.loads([l for l in open("$O/bench_c4_R$R.log") if l.startswith("{")][-1])
+print("R=$R", "pairs/s", round(d["value"]), "ms/step", round(d["ms_per_step"]), "grid s", round(d["config"]["wall_s_grid"],1), "cold first step s", d["config"]["cold_first_step_s"], d["roofline"]["stage_ms"])
+PY
+  done ;;
 c3)
   timeout 900 python bench.py --gpus 1 --genomes 200 --seed 20250228 --steps 3 --warmup 1 --no-tetra > $O/bench_c3.log 2> $O/bench_c3.err; echo "c3 rc=$?"
   grep '^{' $O/bench_c3.log > $O/bench_c3.json; cut -c1-2500 $O/bench_c3.json; tail -5 $O/bench_c3.err ;;
