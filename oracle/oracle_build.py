@@ -3,6 +3,7 @@
   liboracle.so    oracle/tetra_oracle.c   gcc -ffp-contract=off     TETRA restatement (tetra.py:78-194)
   libanimcpu.so   oracle/anim_cpu.cpp     g++ -pthread              host statement of the ANIm pair search (own-cpu baseline)
   libanibcpu.so   oracle/anib_cpu.cpp     g++ -pthread              host statement of fragment mode (ANIb)
+  _build/nucmer_oracle   oracle/nucmer_oracle.cpp   g++               restatement of MUMmer 3.23's nucmer pipeline (the ANIm search oracle)
 """
 import subprocess
 import sys
@@ -49,8 +50,20 @@ def build_anib_cpu(force=False) -> Path:
     return ANIB_CPU_LIB
 
 
+NUCMER_ORACLE = HERE / "_build" / "nucmer_oracle"
+
+
+def build_nucmer_oracle(force=False) -> Path:
+    """oracle/nucmer_oracle.cpp -> oracle/_build/nucmer_oracle (a command-line program: ref.fna qry.fna [--maxmatch] [--delta])."""
+    src = HERE / "nucmer_oracle.cpp"
+    if force or not _newer(NUCMER_ORACLE, [src]):
+        NUCMER_ORACLE.parent.mkdir(exist_ok=True)
+        _run(["g++", "-O2", "-std=c++17", "-o", NUCMER_ORACLE, src])
+    return NUCMER_ORACLE
+
+
 def build_all(force=False):
-    return build_oracle(force), build_anim_cpu(force), build_anib_cpu(force)
+    return build_oracle(force), build_anim_cpu(force), build_anib_cpu(force), build_nucmer_oracle(force)
 
 
 if __name__ == "__main__":

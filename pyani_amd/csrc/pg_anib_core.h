@@ -208,7 +208,7 @@ PG_HD int frag_pick_anchors(const FragSeed* e, int n, int* cand, int32_t* votes_
 // The word tier (blastn's word size, `-task blastn`: anib.py:465-471): a fragment that the 16-mer seeds leave without a reportable
 // HSP is searched again with every 11-mer of either strand; a hit becomes a seed if at least WORD_FLANK_MIN of the WORD_FLANK
 // bases on its left OR on its right match on its diagonal (chance: 8 +- 2.4 of 32; 22 centres the agreement with the BLAST+
-// tables of the reference's tests: oracle/anib_cpu.cpp has the statement, profiles/r03_anib_blast_agreement.json the level).
+// tables of the reference's tests: the CPU checker of the tests (anib_cpu.cpp) has the statement, profiles/r03_anib_blast_agreement.json the level).
 constexpr int WORD_K = 11, WORD_FLANK = 32, WORD_FLANK_MIN = 22, WORD_MAX_SEEDS = 512;
 
 // BLAST's e-value for raw score S (blastn 2 / -3, gap costs 5 / 2: lambda = 0.625, K = 0.41), search space m * n without length

@@ -16,8 +16,10 @@ int pg_fail(pg_ctx* ctx, int code, const std::string& msg) {
 
 static const char* const KERNEL_NAMES[PG_K__COUNT] = {"tetra_count_kernel", "tetra_finalize_kernel", "tetra_stats_kernel",
                                                       "tetra_pairs_kernel", "anim_seed_kernel", "anim_hit_kernels",
-                                                      "anim_cluster_wave_kernel", "anim_gap_kernels", "anim_extdp_lane_kernel",
-                                                      "anim_extend_kernels", "anim_finish_kernel", "anib_bucket_kernel",
+                                                      "anim_cluster_wave_kernel",
+                                                      // the three extension-stage slots, by extender: nucmer (default) / banded64
+                                                      "anim_postnuc_gap_kernels|anim_gap_kernels", "anim_postnuc_forced_kernel|anim_extdp_lane_kernel",
+                                                      "anim_postnuc_kernel|anim_extend_kernels", "anim_finish_kernel", "anib_bucket_kernel",
                                                       "anib_frag_kernel"};
 
 // ---- profiling ----------------------------------------------------------------------------------------------

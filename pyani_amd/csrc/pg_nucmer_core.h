@@ -3,10 +3,10 @@
 // grows by one cell per side and step, trimmed from its edges at breaklen * 3 below the best score, break after breaklen
 // anti-diagonals without a new best, three states per cell with MUMmer's tie order) as a template parameter.
 // Plain C++ that compiles for the device (pg_anim.hip: wave-cooperative engine, pga_postnuc.inc) AND for the host
-// (ScalarEngine below: the statement the GPU must equal; tools/anim_debug, oracle/anim_cpu.cpp).
+// (ScalarEngine below: the statement the GPU must equal; tools/anim_debug and the CPU checker of the tests).
 //
 // What it restates, and what pins it: pyani runs `nucmer --mum` per ordered pair (pyani/anim.py:240-289); nucmer's extension
-// step is postnuc.  oracle/nucmer_oracle.cpp is an independent restatement of the same published algorithm with traceback and
+// step is postnuc.  The tests' CPU checker of nucmer is an independent restatement of the same published algorithm with traceback and
 // MUMmer's own data structures; it reproduces all 25 192 alignment records (and every indel list) of the MUMmer output files
 // the reference's tests hold.  This file differs from it in form, not in results: stream coordinates, fixed arrays, and error
 // counts that ride along with the scores (every state carries the errors of its chosen path, choices follow MUMmer's tie order,

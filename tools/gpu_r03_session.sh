@@ -36,11 +36,11 @@ c4)
   timeout 1200 python bench.py --gpus 1 --steps 4 --warmup 1 --no-tetra --no-cpu-baseline > $O/bench_c4.log 2> $O/bench_c4.err; echo "c4 rc=$?"
   grep '^{' $O/bench_c4.log > $O/bench_c4.json; cut -c1-2500 $O/bench_c4.json; tail -5 $O/bench_c4.err ;;
 bench)
-  timeout 1500 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_n1.log 2> $O/bench_n1.err; echo "bench rc=$?"
+  timeout 1500 python bench.py --gpus 1 --steps ${BENCH_STEPS:-20} --warmup ${BENCH_WARMUP:-5} > $O/bench_n1.log 2> $O/bench_n1.err; echo "bench rc=$?"
   grep '^{' $O/bench_n1.log > $O/bench_n1.json; cut -c1-3000 $O/bench_n1.json; tail -5 $O/bench_n1.err ;;
 prof)
   cd /tmp
-  B="python $R/bench.py --gpus 1 --steps 2 --warmup 1 --no-cpu-baseline --no-tetra"
+  B="python $R/bench.py --gpus 1 --steps 1 --warmup 1 --no-cpu-baseline --no-tetra"
   rm -rf $O/kt $O/pmc_fetch $O/pmc_write
   timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt -- $B > $O/kt_bench.log 2>&1
   timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o pmc -- $B > $O/pmc_fetch.log 2>&1

@@ -29,7 +29,7 @@ def counter_by_kernel(path, counter):
     with open(path) as fh:
         for r in csv.DictReader(fh):
             if r["Counter_Name"] == counter:
-                m = re.search(r"(anim_\w+|tetra_\w+|anib_\w+)", r["Kernel_Name"])
+                m = re.search(r"(anim_\w+?_kernel|tetra_\w+?_kernel|anib_\w+?_kernel)", r["Kernel_Name"])
                 acc[m.group(1) if m else r["Kernel_Name"][:60]].append(float(r["Counter_Value"]))
     return acc
 
@@ -50,8 +50,10 @@ if f and w:
         for r in rows:
             fh.write(",".join(str(x) for x in r) + "\n")
     stage_of = {"anim_seed_kernel": "anim_seed_kernel", "anim_cluster_wave_kernel": "anim_cluster_wave_kernel",
-                "anim_extdp_lane_kernel": "anim_extdp_lane_kernel", "anim_finish_kernel": "anim_finish_kernel"}
-    out = {"round": tag, "command": "python bench.py --gpus 1 --steps 2 --warmup 1 --no-cpu-baseline --no-tetra (C4, a step = the whole grid; two workers: launches of two streams overlap)",
+                "anim_postnuc_kernel": "anim_postnuc_kernel|anim_extend_kernels",
+                "anim_postnuc_forced_kernel": "anim_postnuc_forced_kernel|anim_extdp_lane_kernel",
+                "anim_postnuc_gap_kernel": "anim_postnuc_gap_kernels|anim_gap_kernels", "anim_finish_kernel": "anim_finish_kernel"}
+    out = {"round": tag, "command": "python bench.py --gpus 1 --steps 1 --warmup 1 --no-cpu-baseline --no-tetra (C4, a step = a tenth of the grid; two workers: launches of two streams overlap)",
            "correction": "FETCH_SIZE doubled (gfx950 rocprofv3 tallies 128-B read requests at 64 B, MI355X_MICROARCH.md §HBM; exact for wide "
                          "coalesced streams, an upper bound for narrower accesses); WRITE_SIZE as reported (uncalibrated)"}
     for k, stage in stage_of.items():
