@@ -171,6 +171,7 @@ struct AnimScratch {
   uint32_t* pn_gscratch = nullptr;  // [waves][PN_GLOBAL_WORDS] anti-diagonals too wide for LDS
   PnForcedReq* pn_reqs = nullptr;   // the launch's deferred forced runs (at most one per alignment started: <= chains)
   pgn::PnGap* pn_gaps = nullptr;    // match-to-match alignments by match slot
+  pgn::PnFwd* pn_fwd = nullptr;     // forward extensions by cluster (moff-relative position in the unit's order)
   PnGapTask* pn_tasks = nullptr;    // [3 size classes][pn_cap] small gaps for the lane kernel
   uint32_t* pn_order = nullptr;     // units by descending cluster count
   size_t pn_cap = 0, pn_units = 0, pn_waves = 0, pn_req_cap = 0;
@@ -285,7 +286,7 @@ static void anim_free_one(pg_ctx* ctx, void*& slot) {
                   A->iscratch, A->order, A->prev, A->next, A->alnof, A->chains, A->fw, A->bw, A->S.alns, A->S.a_rrec,
                   A->S.a_qrec, A->S.idx, A->S.from, A->S.sc, A->wl_d, A->seedbuf, A->seed_total, A->tasks_d, A->fr_tables, A->fr_pairs,
                   A->fr_slot_pair, A->fr_off, A->fr_nrows, A->fr_ebase, A->fr_entries, A->fr_rows, A->fr_out, A->fr_list, A->fr_nlist, A->fr_wtmp, A->fr_widx,
-                  A->pn, A->pn_fused, A->pn_n, A->pn_cursor, A->pn_gscratch, A->pn_reqs, A->pn_gaps, A->pn_tasks, A->pn_order};
+                  A->pn, A->pn_fused, A->pn_n, A->pn_cursor, A->pn_gscratch, A->pn_reqs, A->pn_gaps, A->pn_fwd, A->pn_tasks, A->pn_order};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   delete A;
   slot = nullptr;
@@ -661,6 +662,7 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
       if ((rc = regrow(ctx, A->pn, Mp))) return rc;
       if ((rc = regrow(ctx, A->pn_fused, Mp))) return rc;
       if ((rc = regrow(ctx, A->pn_gaps, Mp))) return rc;
+      if ((rc = regrow(ctx, A->pn_fwd, Mp))) return rc;
       if ((rc = regrow(ctx, A->pn_tasks, 3 * Mp))) return rc;
       A->pn_cap = Mp;
     }
@@ -681,7 +683,7 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
     if (pn_waves > A->pn_waves) { if ((rc = regrow(ctx, A->pn_gscratch, (size_t)pn_waves * PN_GLOBAL_WORDS))) return rc; A->pn_waves = pn_waves; }
     const size_t req_cap = n_wl + 16;
     if (req_cap > A->pn_req_cap) { if ((rc = regrow(ctx, A->pn_reqs, req_cap + req_cap / 2))) return rc; A->pn_req_cap = req_cap + req_cap / 2; }
-    PG_HIP(ctx, hipMemsetAsync(A->pn_cursor, 0, 64, cur_stream(ctx)));   // [0] unit cursor, [1] forced runs recorded ([7]: the long ones), [2] forced-run cursor, [3] chain cursor, [4..6] small gaps
+    PG_HIP(ctx, hipMemsetAsync(A->pn_cursor, 0, 64, cur_stream(ctx)));   // [0] unit cursor, [1] forced runs recorded ([7]: the long ones), [2] forced-run cursor, [3] chain cursor, [4..6] small gaps, [8] cluster cursor of the forward extensions
     if (n_wl) {     // the (unit, chain) work list, then every cluster's match-to-match alignments
       if (n_wl > A->wl) { if ((rc = regrow(ctx, A->wl_d, n_wl + n_wl / 2))) return rc; A->wl = n_wl + n_wl / 2; }
       PG_HIP(ctx, hipMemcpyAsync(A->choff_d, choff.data(), choff.size() * 4, hipMemcpyHostToDevice, cur_stream(ctx)));
@@ -698,13 +700,15 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
       }
       hipLaunchKernelGGL(anim_postnuc_gap_kernel, dim3(pn_waves), dim3(64), 0, cur_stream(ctx), A->refs_d, A->units_d, O, A->wl_d, (uint32_t)n_wl,
                          A->pn_cursor + 3, A->pn_gaps, A->pn_gscratch, lane_small);
+      hipLaunchKernelGGL(anim_postnuc_fwd_kernel, dim3(pn_waves), dim3(64), 0, cur_stream(ctx), A->refs_d, A->units_d, O, A->wl_d, (uint32_t)n_wl,
+                         A->pn_cursor + 8, A->pn_fwd, A->pn_gscratch);
       pg_prof_end(ctx);
     }
     pg_prof_begin(ctx, PG_K_ANIM_EXTEND);
     if (n_wl)
       hipLaunchKernelGGL(anim_postnuc_kernel, dim3(pn_waves < n_units ? pn_waves : n_units), dim3(64), 0, cur_stream(ctx), A->refs_d, A->units_d,
                          n_units, O, A->pn_cursor, A->pn, A->pn_fused, A->pn_n, A->pn_gscratch, A->pn_reqs, A->pn_cursor + 1, (uint32_t)req_cap,
-                         A->pn_gaps, A->pn_order);
+                         A->pn_gaps, A->pn_fwd, A->pn_order);
     else
       PG_HIP(ctx, hipMemsetAsync(A->pn_n, 0, (size_t)n_units * 4, cur_stream(ctx)));
     pg_prof_end(ctx);
@@ -715,11 +719,15 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
     pg_prof_end(ctx);
     if (getenv("PYANI_PN_STATS")) {   // development: what the engines did in this launch
       PG_HIP(ctx, hipStreamSynchronize(cur_stream(ctx)));
-      unsigned long long st[16], zero[16] = {0};
+      unsigned long long st[24], zero[24] = {0};
       PG_HIP(ctx, hipMemcpyFromSymbol(st, HIP_SYMBOL(g_pn_stats), sizeof(st)));
       PG_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_pn_stats), zero, sizeof(zero)));
       fprintf(stderr, "[pn-stats] units %llu clusters %llu | regs: calls %llu steps %llu cells %llu moves %llu overflows %llu | lds: calls %llu steps %llu cells %llu | "
                       "global: calls %llu steps %llu cells %llu\n", st[11], st[12], st[0], st[1], st[2], st[9], st[10], st[3], st[4], st[5], st[6], st[7], st[8]);
+      fprintf(stderr, "[pn-stats] searches of the gap + units kernels: %llu calls, %.1f ms inside the engine (summed over waves)\n", st[22], st[21] / 1e5);
+      for (int k = 13; k <= 17; k += 4)      // ticks of the 100 MHz wall clock -> ms
+        fprintf(stderr, "[pn-stats] %s: busy %.1f ms summed over waves, span %.1f ms, longest item %.1f ms (size %llu)\n", k == 13 ? "units" : "forced",
+                st[k] / 1e5, st[k + 2] ? (st[k + 2] - ~st[k + 3]) / 1e5 : 0.0, (st[k + 1] >> 20) / 1e5, st[k + 1] & 0xFFFFFull);
     }
   }
   if (n_wl && !postnuc) {

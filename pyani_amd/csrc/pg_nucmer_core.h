@@ -36,6 +36,11 @@ struct PnAln {
 
 // The forward alignment from a cluster's match to its next one, computed ahead of the unit's walk (pga_postnuc.inc).
 struct PnGap { int32_t eA, eB, errors, reached; };
+// The forward extension off a cluster's last match (towards its forward target cluster): a function of the unit's clusters alone —
+// getForwardTargetCluster looks at the clusters' matches, not at what has been aligned or fused so far, and the extension starts on
+// the last base of the cluster's last match whichever way the walk came to it — so an engine may have all of them ready
+// (postnuc_forward: the GPU runs one wave per cluster before the units' sequential walks).
+struct PnFwd { int32_t eA, eB, errors, targetk, reached; };
 
 // ---- packed DP words ----------------------------------------------------------------------------------------------------
 // One 32-bit word per state:  (score + SCORE_BIAS) << 17 | state << 15 | errors.
@@ -200,6 +205,8 @@ struct ScalarEngine {
   int32_t overflow = 0;
   long cells = 0;
   PG_HD bool gap_ready(int32_t, PnGap&) const { return false; }     // (scalar engines align match to match as they go)
+  const PnFwd* fwd = nullptr;      // forward extensions computed beforehand (postnuc_forward_all), by position in `order`
+  PG_HD bool fwd_ready(int k, PnFwd& f) const { if (!fwd) return false; f = fwd[k]; return true; }
   // a forced alignment between two known corners: its error count (see the call sites in postnuc_unit)
   PG_HD int32_t forced_errors(int32_t A0, int32_t A1, int32_t B0, int32_t B1, PnAln*) {
     int32_t err = 0, a = A1, b = B1;
@@ -397,6 +404,8 @@ struct DiagEngine {
   DiagScalarEngine<RefT, QryT> fast;
   ScalarEngine<RefT, QryT> slow;
   PG_HD bool gap_ready(int32_t, PnGap&) const { return false; }     // (scalar engines align match to match as they go)
+  const PnFwd* fwd = nullptr;      // forward extensions computed beforehand (postnuc_forward_all), by position in `order`
+  PG_HD bool fwd_ready(int k, PnFwd& f) const { if (!fwd) return false; f = fwd[k]; return true; }
   // a forced alignment between two known corners: its error count (see the call sites in postnuc_unit)
   PG_HD int32_t forced_errors(int32_t A0, int32_t A1, int32_t B0, int32_t B1, PnAln*) {
     int32_t err = 0, a = A1, b = B1;
@@ -443,6 +452,29 @@ struct DiagEngine {
 // cm: their matches.  BOUNDS(c, r_lo, r_hi, q_lo, q_hi): the records of chain c as half-open stream ranges (q: strand
 // coordinates).  fused[n] / al[max_al]: scratch and output.  Returns the number of alignments (al[] in creation order, as
 // MUMmer prints them), or -1 - count when max_al was too small.
+// extendForward off the last match of cluster order[curk]: target search (getForwardTargetCluster), clamps, alignment
+template <typename ENG, typename BOUNDS>
+PG_HD PnFwd postnuc_forward(ENG& eng, const Chain* chains, const Match* cm, const int32_t* order, int n, int curk, BOUNDS&& bounds) {
+  const int c = order[curk];
+  const Chain& C = chains[c];
+  const Match& ml = cm[C.first + C.count - 1];
+  int32_t r_lo, r_hi, q_lo, q_hi;
+  bounds(c, r_lo, r_hi, q_lo, q_hi);
+  unsigned m_o = FORWARD_ALIGN;
+  int32_t targetA = r_hi - 1, targetB = q_hi - 1;
+  const int32_t sA = ml.r + ml.len - 1, sB = ml.q + ml.len - 1;
+  const int32_t d0 = (targetA - sA) < (targetB - sB) ? (targetA - sA) : (targetB - sB);
+  const int targetk = eng.forward_target(chains, cm, order, n, curk, c, sA, sB, d0, targetA, targetB);
+  if (targetk < 0) m_o |= OPTIMAL_BIT;
+  bool overflow = false;
+  if (targetA - sA + 1 > MAX_ALIGNMENT_LENGTH) { targetA = sA + MAX_ALIGNMENT_LENGTH - 1; overflow = true; m_o |= OPTIMAL_BIT; }
+  if (targetB - sB + 1 > MAX_ALIGNMENT_LENGTH) { targetB = sB + MAX_ALIGNMENT_LENGTH - 1; if (!overflow) m_o |= OPTIMAL_BIT; overflow = true; }
+  int32_t err = 0;
+  bool reached = eng.align(sA, targetA, sB, targetB, m_o, err);
+  if (reached && overflow) reached = false;
+  return PnFwd{targetA, targetB, err, targetk, reached ? 1 : 0};
+}
+
 template <typename ENG, typename BOUNDS>
 PG_HD int postnuc_unit(ENG& eng, const Chain* chains, const Match* cm, const int32_t* order, int n, BOUNDS&& bounds, uint8_t* fused,
                        PnAln* al, int max_al) {
@@ -504,7 +536,6 @@ PG_HD int postnuc_unit(ENG& eng, const Chain* chains, const Match* cm, const int
         }
       }
       // extendForward: to the next match of the cluster, or from its last match towards the target cluster
-      unsigned m_o = FORWARD_ALIGN;
       if (m + 1 < C.count) {
         targetA = mm[m + 1].r; targetB = mm[m + 1].q;
         // match to match inside a cluster: the call depends on the two matches only (the alignment ends on this match's last
@@ -515,16 +546,8 @@ PG_HD int postnuc_unit(ENG& eng, const Chain* chains, const Match* cm, const int
           target_reached = g.reached != 0;
           continue;
         }
-      } else {
-        targetA = r_hi - 1; targetB = q_hi - 1;
-        // getForwardTargetCluster
-        const int32_t sA = ml.r + ml.len - 1, sB = ml.q + ml.len - 1;
-        const int32_t d0 = (targetA - sA) < (targetB - sB) ? (targetA - sA) : (targetB - sB);
-        targetk = eng.forward_target(chains, cm, order, n, curk, c, sA, sB, d0, targetA, targetB);
-        if (targetk < 0) m_o |= OPTIMAL_BIT;
-      }
-      {
         bool overflow = false;
+        unsigned m_o = FORWARD_ALIGN;
         if (targetA - al[cura].eA + 1 > MAX_ALIGNMENT_LENGTH) { targetA = al[cura].eA + MAX_ALIGNMENT_LENGTH - 1; overflow = true; m_o |= OPTIMAL_BIT; }
         if (targetB - al[cura].eB + 1 > MAX_ALIGNMENT_LENGTH) { targetB = al[cura].eB + MAX_ALIGNMENT_LENGTH - 1; if (!overflow) m_o |= OPTIMAL_BIT; overflow = true; }
         int32_t err = 0;
@@ -533,6 +556,13 @@ PG_HD int postnuc_unit(ENG& eng, const Chain* chains, const Match* cm, const int
         al[cura].errors += err;
         al[cura].eA = targetA; al[cura].eB = targetB;
         target_reached = reached;
+      } else {
+        // off the last match (the alignment ends on its last base here, however the walk entered the cluster): PnFwd
+        PnFwd f;
+        if (!eng.fwd_ready(curk, f)) f = postnuc_forward(eng, chains, cm, order, n, curk, bounds);
+        targetk = f.targetk;
+        al[cura].errors += f.errors; al[cura].eA = f.eA; al[cura].eB = f.eB;
+        target_reached = f.reached != 0;
       }
     }
     if (full) break;

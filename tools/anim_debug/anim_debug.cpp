@@ -129,6 +129,13 @@ int main(int argc, char** argv) {
             rl = G.rec_start[chains[c].rrec]; rh = G.rec_start[chains[c].rrec + 1] - 1;
             ql = H.rec_start[chains[c].qrec]; qh = H.rec_start[chains[c].qrec + 1] - 1;
             if (strand) { const int32_t a = (int32_t)H.len - qh, b = (int32_t)H.len - ql; ql = a; qh = b; } };
+      // ANIM_HOIST: every cluster's forward extension first (what the GPU's pre-pass does), the walk then only reads them
+      std::vector<pgn::PnFwd> fw;
+      if (getenv("ANIM_HOIST")) {
+        fw.resize(n_chains);
+        for (int k = 0; k < n_chains; ++k) fw[k] = pgn::postnuc_forward(eng, chains.data(), cm.data(), co.data(), n_chains, k, bounds_of);
+        eng.fwd = fw.data();
+      }
       const int na = getenv("ANIM_DIAG") ? pgn::postnuc_unit(deng, chains.data(), cm.data(), co.data(), n_chains, bounds_of, fused.data(), al.data(), (int)al.size())
                                          : pgn::postnuc_unit(eng, chains.data(), cm.data(), co.data(), n_chains,
           [&](int c, int32_t& rl, int32_t& rh, int32_t& ql, int32_t& qh) {

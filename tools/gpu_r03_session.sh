@@ -17,6 +17,9 @@ tests)
 stats)   # one C3 grid with the engines' counters (PYANI_PN_STATS) and one worker, so that the launch times are not overlapped
   PYANI_PN_STATS=1 PYANI_ANIM_WORKERS=1 timeout 900 python bench.py --gpus 1 --genomes 200 --seed 20250228 --rows-per-step 200 --steps 1 --warmup 0 --no-tetra --no-cpu-baseline > $O/bench_c3_stats.log 2> $O/bench_c3_stats.err; echo "stats rc=$?"
   grep '^{' $O/bench_c3_stats.log | cut -c1-1500; grep "pn-stats" $O/bench_c3_stats.err | tail -8 ;;
+stats4)  # one C4 step (the driver's step: 100 rows) with the counters and the per-item clocks of the units / forced kernels
+  PYANI_PN_STATS=1 PYANI_ANIM_WORKERS=1 timeout 900 python bench.py --gpus 1 --steps 1 --warmup 0 --no-tetra --no-cpu-baseline > $O/bench_c4_stats.log 2> $O/bench_c4_stats.err; echo "stats4 rc=$?"
+  grep '^{' $O/bench_c4_stats.log | cut -c1-1500; grep "pn-stats" $O/bench_c4_stats.err | tail -16 ;;
 anib)
   timeout 1200 python -m pytest tests/test_anib_gpu.py tests/test_zz_concordance_gpu.py -m gpu -q --timeout 900 > $O/pytest_anib.log 2>&1; echo "pytest rc=$?" >> $O/pytest_anib.log
   tail -30 $O/pytest_anib.log; cp gpurun_out/anib_blast_agreement.json $O/ 2>/dev/null ;;
