@@ -719,12 +719,14 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
     pg_prof_end(ctx);
     if (getenv("PYANI_PN_STATS")) {   // development: what the engines did in this launch
       PG_HIP(ctx, hipStreamSynchronize(cur_stream(ctx)));
-      unsigned long long st[24], zero[24] = {0};
+      unsigned long long st[32], zero[32] = {0};
       PG_HIP(ctx, hipMemcpyFromSymbol(st, HIP_SYMBOL(g_pn_stats), sizeof(st)));
       PG_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_pn_stats), zero, sizeof(zero)));
       fprintf(stderr, "[pn-stats] units %llu clusters %llu | regs: calls %llu steps %llu cells %llu moves %llu overflows %llu | lds: calls %llu steps %llu cells %llu | "
                       "global: calls %llu steps %llu cells %llu\n", st[11], st[12], st[0], st[1], st[2], st[9], st[10], st[3], st[4], st[5], st[6], st[7], st[8]);
       fprintf(stderr, "[pn-stats] searches of the gap + units kernels: %llu calls, %.1f ms inside the engine (summed over waves)\n", st[22], st[21] / 1e5);
+      fprintf(stderr, "[pn-stats] forced passes by engine (127 / 255 / 511 cells / strips): %llu %llu %llu %llu passes, %.1f %.1f %.1f %.1f ms summed over waves\n",
+              st[27], st[28], st[29], st[30], st[23] / 1e5, st[24] / 1e5, st[25] / 1e5, st[26] / 1e5);
       for (int k = 13; k <= 17; k += 4)      // ticks of the 100 MHz wall clock -> ms
         fprintf(stderr, "[pn-stats] %s: busy %.1f ms summed over waves, span %.1f ms, longest item %.1f ms (size %llu)\n", k == 13 ? "units" : "forced",
                 st[k] / 1e5, st[k + 2] ? (st[k + 2] - ~st[k + 3]) / 1e5 : 0.0, (st[k + 1] >> 20) / 1e5, st[k + 1] & 0xFFFFFull);
