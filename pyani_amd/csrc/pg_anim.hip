@@ -679,8 +679,9 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
       PG_HIP(ctx, hipStreamSynchronize(cur_stream(ctx)));     // (uorder is a local)
     }
     if (!A->pn_cursor && (rc = regrow(ctx, A->pn_cursor, 16))) return rc;
-    const uint32_t pn_waves = (uint32_t)ctx->num_cu * 12u;   // 12 KiB of LDS each: 12 per CU
-    if (pn_waves > A->pn_waves) { if ((rc = regrow(ctx, A->pn_gscratch, (size_t)pn_waves * PN_GLOBAL_WORDS))) return rc; A->pn_waves = pn_waves; }
+    const uint32_t pn_waves = (uint32_t)ctx->num_cu * 12u;   // units / forced kernels: 12 KiB of LDS each: 12 per CU
+    const uint32_t pn_waves_pre = (uint32_t)ctx->num_cu * 20u;   // gap / forward pre-passes: no LDS, < 104 registers: 5 per SIMD
+    if (pn_waves_pre > A->pn_waves) { if ((rc = regrow(ctx, A->pn_gscratch, (size_t)pn_waves_pre * PN_GLOBAL_WORDS))) return rc; A->pn_waves = pn_waves_pre; }
     const size_t req_cap = n_wl + 16;
     if (req_cap > A->pn_req_cap) { if ((rc = regrow(ctx, A->pn_reqs, req_cap + req_cap / 2))) return rc; A->pn_req_cap = req_cap + req_cap / 2; }
     PG_HIP(ctx, hipMemsetAsync(A->pn_cursor, 0, 64, cur_stream(ctx)));   // [0] unit cursor, [1] forced runs recorded ([7]: the long ones), [2] forced-run cursor, [3] chain cursor, [4..6] small gaps, [8] cluster cursor of the forward extensions
@@ -698,9 +699,9 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
         hipLaunchKernelGGL((anim_postnuc_gaplane_kernel<32>), lg, dim3(64), 0, cur_stream(ctx), A->refs_d, A->units_d, O, A->pn_tasks + A->pn_cap, A->pn_cursor + 5, A->pn_gaps);
         hipLaunchKernelGGL((anim_postnuc_gaplane_kernel<PN_SMALL>), lg, dim3(64), 0, cur_stream(ctx), A->refs_d, A->units_d, O, A->pn_tasks + 2 * A->pn_cap, A->pn_cursor + 6, A->pn_gaps);
       }
-      hipLaunchKernelGGL(anim_postnuc_gap_kernel, dim3(pn_waves), dim3(64), 0, cur_stream(ctx), A->refs_d, A->units_d, O, A->wl_d, (uint32_t)n_wl,
+      hipLaunchKernelGGL(anim_postnuc_gap_kernel, dim3(pn_waves_pre), dim3(64), 0, cur_stream(ctx), A->refs_d, A->units_d, O, A->wl_d, (uint32_t)n_wl,
                          A->pn_cursor + 3, A->pn_gaps, A->pn_gscratch, lane_small);
-      hipLaunchKernelGGL(anim_postnuc_fwd_kernel, dim3(pn_waves), dim3(64), 0, cur_stream(ctx), A->refs_d, A->units_d, O, A->wl_d, (uint32_t)n_wl,
+      hipLaunchKernelGGL(anim_postnuc_fwd_kernel, dim3(pn_waves_pre), dim3(64), 0, cur_stream(ctx), A->refs_d, A->units_d, O, A->wl_d, (uint32_t)n_wl,
                          A->pn_cursor + 8, A->pn_fwd, A->pn_gscratch);
       pg_prof_end(ctx);
     }

@@ -41,6 +41,13 @@ c4)
 bench)
   timeout 1500 python bench.py --gpus 1 --steps ${BENCH_STEPS:-20} --warmup ${BENCH_WARMUP:-5} > $O/bench_n1.log 2> $O/bench_n1.err; echo "bench rc=$?"
   grep '^{' $O/bench_n1.log > $O/bench_n1.json; cut -c1-3000 $O/bench_n1.json; tail -5 $O/bench_n1.err ;;
+kt)      # kernel trace only, one worker (launches not overlapped): per-kernel durations of one C4 step
+  cd /tmp
+  rm -rf $O/kt1
+  PYANI_ANIM_WORKERS=1 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt1 -o kt -- python $R/bench.py --gpus 1 --steps 1 --warmup 0 --no-cpu-baseline --no-tetra > $O/kt1_bench.log 2>&1
+  cd $R
+  f=$(find $O/kt1 -name "*kernel_stats.csv" | head -1); head -25 $f | cut -c1-200
+  find $O/kt1 -name "*kernel_trace.csv" -size +20M -delete ;;
 prof)
   cd /tmp
   B="python $R/bench.py --gpus 1 --steps 1 --warmup 1 --no-cpu-baseline --no-tetra"
