@@ -41,6 +41,18 @@ c4)
 bench)
   timeout 1500 python bench.py --gpus 1 --steps ${BENCH_STEPS:-20} --warmup ${BENCH_WARMUP:-5} > $O/bench_n1.log 2> $O/bench_n1.err; echo "bench rc=$?"
   grep '^{' $O/bench_n1.log > $O/bench_n1.json; cut -c1-3000 $O/bench_n1.json; tail -5 $O/bench_n1.err ;;
+c5)      # C5 fragment mode (word tier on)
+  timeout 900 python bench.py --gpus 1 --workload anib > $O/bench_c5.log 2> $O/bench_c5.err; echo "c5 rc=$?"
+  grep '^{' $O/bench_c5.log > $O/bench_c5.json; cut -c1-2500 $O/bench_c5.json; tail -3 $O/bench_c5.err ;;
+workers) # C4 steps with 2 and 4 host workers (streams): how much of a launch's sequential tail the others' kernels cover
+  for W in 2 4; do
+    PYANI_ANIM_WORKERS=$W timeout 600 python bench.py --gpus 1 --steps 3 --warmup 1 --no-tetra --no-cpu-baseline > $O/bench_c4_W$W.log 2> $O/bench_c4_W$W.err; echo "W=$W rc=$?"
+    python - <<PY2
+import json
+d=json.loads([l for l in open("$O/bench_c4_W$W.log") if l.startswith("{")][-1])
+print("W=$W", "pairs/s", round(d["value"]), "ms/step", round(d["ms_per_step"]), "cold first step s", d["config"]["cold_first_step_s"])
+PY2
+  done ;;
 kt)      # kernel trace only, one worker (launches not overlapped): per-kernel durations of one C4 step
   cd /tmp
   rm -rf $O/kt1
