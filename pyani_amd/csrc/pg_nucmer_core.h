@@ -90,6 +90,68 @@ PG_HD Cell cell_update(const Cell& L, const Cell& U, uint32_t G, bool same) {
   return c;
 }
 
+// ---- traceback (the .delta indel lists; optional: pg_anim_alignments_batch) ------------------------------------------------
+// The riding error counts make a traceback unnecessary for ANI; MUMmer's .delta files also hold each alignment's path as
+// indel offsets.  For those, a run of the scalar engine can store one byte per computed cell — the state of ORIGIN of each of
+// the cell's three states (the two state bits of the winning candidate word BEFORE it is re-labelled: that is what the word
+// format keeps them for) and the state of the cell's best word — anti-diagonal after anti-diagonal, and walk back from the
+// finish cell: MATCH steps to (i - 1, j - 1), INSERT to (i - 1, j), DELETE to (i, j - 1), each into the recorded state of origin.
+struct PnTrace {
+  uint8_t* bp;         // [bp_cap] one byte per computed cell: origin of D | origin of I << 2 | origin of M << 4 | state of X << 6
+  uint64_t bp_cap;
+  uint32_t* doff;      // [dcap] offset of anti-diagonal d's first cell in bp (doff[last + 1] = cells used)
+  int32_t* dlo;        // [dcap] its lowest column
+  int32_t dcap;
+  uint64_t used;
+  int32_t finish_ct, finish_j, overflow;
+};
+PG_HD Cell cell_update_bp(const Cell& L, const Cell& U, uint32_t G, bool same, uint8_t& bp) {
+  const uint32_t d = w_max3(w_gap(L.D, CONT_GAP_SCORE), w_gap(L.I, OPEN_GAP_SCORE), w_gap(L.M, OPEN_GAP_SCORE));
+  const uint32_t i = w_max3(w_gap(U.D, OPEN_GAP_SCORE), w_gap(U.I, CONT_GAP_SCORE), w_gap(U.M, OPEN_GAP_SCORE));
+  const uint32_t m = w_step(G, same);
+  Cell c;
+  c.D = w_relabel(d, ST_DELETE); c.I = w_relabel(i, ST_INSERT); c.M = w_relabel(m, ST_MATCH);
+  c.X = w_max3(c.D, c.I, c.M);
+  bp = (uint8_t)(((d >> 15) & 3u) | (((i >> 15) & 3u) << 2) | (((m >> 15) & 3u) << 4) | (((c.X >> 15) & 3u) << 6));
+  return c;
+}
+// The path from the finish cell back to the start, run-length coded in REVERSE order: entry = op << 28 | count, op 0 = DELETE
+// (a B base alone), 1 = INSERT (an A base alone), 2 = MATCH column.  Returns the number of entries, -1 if `cap` is too small or
+// the trace is broken.  The first and last columns are the two corner base pairs (or gap ops standing in for them).
+PG_HD int32_t pn_trace_back(const PnTrace& tr, uint32_t* rle, int32_t cap) {
+  int32_t d = tr.finish_ct, j = tr.finish_j, n = 0;
+  if (d <= 0) return 0;
+  if (j < tr.dlo[d] || (uint32_t)(j - tr.dlo[d]) >= tr.doff[d + 1] - tr.doff[d]) return -1;
+  uint32_t st = tr.bp[tr.doff[d] + (uint32_t)(j - tr.dlo[d])] >> 6;
+  uint32_t cur_op = 3u, cur_n = 0u;
+  while (d > 0) {
+    if (j < tr.dlo[d] || (uint32_t)(j - tr.dlo[d]) >= tr.doff[d + 1] - tr.doff[d] || st > 2u) return -1;
+    const uint8_t b = tr.bp[tr.doff[d] + (uint32_t)(j - tr.dlo[d])];
+    const uint32_t from = (b >> (2u * st)) & 3u;
+    if (st != cur_op || cur_n == 0x0FFFFFFFu) {
+      if (cur_n) { if (n >= cap) return -1; rle[n++] = (cur_op << 28) | cur_n; }
+      cur_op = st; cur_n = 0u;
+    }
+    ++cur_n;
+    if (st == 2u) { d -= 2; j -= 1; } else if (st == 1u) { d -= 1; } else { d -= 1; j -= 1; }
+    st = from;
+  }
+  if (cur_n) { if (n >= cap) return -1; rle[n++] = (cur_op << 28) | cur_n; }
+  return d == 0 && j == 0 ? n : -1;
+}
+
+// A piece of an alignment's path, in the order the walk lays them down (postnuc_unit, `eng.piece`): an exact match, a search /
+// alignment of the engine from (A0, B0) towards the target (tA, tB) that ended on (A1, B1), or a forced run between two corners.
+enum : uint32_t { PIECE_MATCH = 0, PIECE_SEARCH = 1, PIECE_FORCED = 2 };
+struct PnPiece {
+  int32_t aln;                 // the alignment (index in the unit's al[]) it belongs to
+  uint32_t kind, m_o;
+  int32_t A0, B0, A1, B1;      // first and last base pair (inclusive corners; A1/B1 = where the engine finished)
+  int32_t tA, tB;              // PIECE_SEARCH: the target the engine was given
+  uint32_t cells, wmax;        // engine bookkeeping of the call (cells computed, widest anti-diagonal): sizes the traceback store
+  uint32_t aux;                // PIECE_FORCED on the GPU: the slot of its deferred request (the band it certified with is found there)
+};
+
 // ---- the scans of extendClusters ---------------------------------------------------------------------------------------------
 PG_HD bool pn_close_enough(int32_t a, int32_t b) {
   const int32_t lesser = a < b ? a : b, greater = a < b ? b : a;
@@ -207,6 +269,15 @@ struct ScalarEngine {
   PG_HD bool gap_ready(int32_t, PnGap&) const { return false; }     // (scalar engines align match to match as they go)
   const PnFwd* fwd = nullptr;      // forward extensions computed beforehand (postnuc_forward_all), by position in `order`
   PG_HD bool fwd_ready(int k, PnFwd& f) const { if (!fwd) return false; f = fwd[k]; return true; }
+  PnTrace* trace = nullptr;        // set: the next run() stores its backpointers there
+  PnPiece* pieces = nullptr;       // set: the walk's pieces are listed here (piece_cap entries; n_pieces counts on past it)
+  int32_t piece_cap = 0, n_pieces = 0;
+  uint32_t last_cells = 0, last_wmax = 0;    // of the latest run()
+  PG_HD void piece(uint32_t kind, int32_t aln, int32_t A0, int32_t B0, int32_t A1, int32_t B1, int32_t tA, int32_t tB, unsigned m_o) {
+    if (!pieces) return;
+    if (n_pieces < piece_cap) pieces[n_pieces] = PnPiece{aln, kind, m_o, A0, B0, A1, B1, tA, tB, last_cells, last_wmax, 0u};
+    ++n_pieces;
+  }
   // a forced alignment between two known corners: its error count (see the call sites in postnuc_unit)
   PG_HD int32_t forced_errors(int32_t A0, int32_t A1, int32_t B0, int32_t B1, PnAln*) {
     int32_t err = 0, a = A1, b = B1;
@@ -249,6 +320,10 @@ struct ScalarEngine {
     int32_t high = -(1 << 30), FinishCt = 0, FinishJ = 0;
     uint32_t high_w = 0;
     int32_t jlo = 0, jhi = 1, Dct;
+    PnTrace* const tr = trace;
+    uint32_t wmax = 0;
+    uint64_t ncells = 0;
+    if (tr) { tr->used = 0; tr->overflow = 0; tr->doff[0] = 0; tr->dlo[0] = 0; if (tr->dcap > 1) tr->doff[1] = 0; }
     for (Dct = 1; Dct <= N + M && (forced || Dct - FinishCt <= BREAK_LEN) && jlo <= jhi; ++Dct) {
       int32_t lo = jlo, hi = jhi;
       if (lo < Dct - N) lo = Dct - N;
@@ -258,18 +333,29 @@ struct ScalarEngine {
       if (band_w >= 0) forced_band_clip(Dct, N, M, band_w, lo, hi);
       if (lo > hi) break;
       if (hi - lo + 1 > cap) { overflow = 1; break; }
+      if ((uint32_t)(hi - lo + 1) > wmax) wmax = (uint32_t)(hi - lo + 1);
+      ncells += (uint64_t)(hi - lo + 1);
+      if (tr) {
+        if (Dct + 2 > tr->dcap || tr->used + (uint64_t)(hi - lo + 1) > tr->bp_cap) { tr->overflow = 1; overflow = 1; break; }
+        tr->doff[Dct] = (uint32_t)tr->used; tr->dlo[Dct] = lo;
+      }
       for (int32_t j = lo; j <= hi; ++j) {
         const int32_t i = Dct - j;
         const bool hasL = j >= 1 && j - 1 >= p1lo && j - 1 <= p1hi, hasU = i >= 1 && j >= p1lo && j <= p1hi;
         const bool hasG = i >= 1 && j >= 1 && j - 1 >= p2lo && j - 1 <= p2hi;
         bool sm = false;
         if (hasG) sm = same(fwd ? (int64_t)Astart + i - 1 : (int64_t)Astart - i + 1, fwd ? (int64_t)Bstart + j - 1 : (int64_t)Bstart - j + 1);
-        const Cell c = cell_update(hasL ? p1[j - 1 - p1lo] : Cell{0, 0, 0, 0}, hasU ? p1[j - p1lo] : Cell{0, 0, 0, 0},
-                                   hasG ? p2[j - 1 - p2lo].X : 0u, sm);
+        uint8_t bp = 0;
+        const Cell c = tr ? cell_update_bp(hasL ? p1[j - 1 - p1lo] : Cell{0, 0, 0, 0}, hasU ? p1[j - p1lo] : Cell{0, 0, 0, 0},
+                                           hasG ? p2[j - 1 - p2lo].X : 0u, sm, bp)
+                          : cell_update(hasL ? p1[j - 1 - p1lo] : Cell{0, 0, 0, 0}, hasU ? p1[j - p1lo] : Cell{0, 0, 0, 0},
+                                        hasG ? p2[j - 1 - p2lo].X : 0u, sm);
+        if (tr) tr->bp[tr->used + (uint64_t)(j - lo)] = bp;
         cur[j - lo] = c;
         const int32_t s = w_score(c.X);
         if (s >= high) { high = s; high_w = c.X; FinishCt = Dct; FinishJ = j; }
       }
+      if (tr) { tr->used += (uint64_t)(hi - lo + 1); tr->doff[Dct + 1] = (uint32_t)tr->used; }
       cells += hi - lo + 1;
       int32_t tlo = lo, thi = hi;
       if (!forced) {
@@ -293,6 +379,8 @@ struct ScalarEngine {
     Bend = fwd ? Bstart + fj - 1 : Bstart - fj + 1;
     errors = (int32_t)w_errors(fin_w);
     if (score_out) *score_out = w_score(fin_w);
+    last_cells = ncells > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)ncells; last_wmax = wmax;
+    if (tr) { tr->finish_ct = FinishCt; tr->finish_j = FinishJ; }
     return reached;
   }
 };
@@ -404,6 +492,7 @@ struct DiagEngine {
   DiagScalarEngine<RefT, QryT> fast;
   ScalarEngine<RefT, QryT> slow;
   PG_HD bool gap_ready(int32_t, PnGap&) const { return false; }     // (scalar engines align match to match as they go)
+  PG_HD void piece(uint32_t, int32_t, int32_t, int32_t, int32_t, int32_t, int32_t, int32_t, unsigned) {}
   const PnFwd* fwd = nullptr;      // forward extensions computed beforehand (postnuc_forward_all), by position in `order`
   PG_HD bool fwd_ready(int k, PnFwd& f) const { if (!fwd) return false; f = fwd[k]; return true; }
   // a forced alignment between two known corners: its error count (see the call sites in postnuc_unit)
@@ -454,7 +543,8 @@ struct DiagEngine {
 // MUMmer prints them), or -1 - count when max_al was too small.
 // extendForward off the last match of cluster order[curk]: target search (getForwardTargetCluster), clamps, alignment
 template <typename ENG, typename BOUNDS>
-PG_HD PnFwd postnuc_forward(ENG& eng, const Chain* chains, const Match* cm, const int32_t* order, int n, int curk, BOUNDS&& bounds) {
+PG_HD PnFwd postnuc_forward(ENG& eng, const Chain* chains, const Match* cm, const int32_t* order, int n, int curk, BOUNDS&& bounds,
+                            int aln = -1) {
   const int c = order[curk];
   const Chain& C = chains[c];
   const Match& ml = cm[C.first + C.count - 1];
@@ -470,7 +560,9 @@ PG_HD PnFwd postnuc_forward(ENG& eng, const Chain* chains, const Match* cm, cons
   if (targetA - sA + 1 > MAX_ALIGNMENT_LENGTH) { targetA = sA + MAX_ALIGNMENT_LENGTH - 1; overflow = true; m_o |= OPTIMAL_BIT; }
   if (targetB - sB + 1 > MAX_ALIGNMENT_LENGTH) { targetB = sB + MAX_ALIGNMENT_LENGTH - 1; if (!overflow) m_o |= OPTIMAL_BIT; overflow = true; }
   int32_t err = 0;
+  const int32_t tA = targetA, tB = targetB;
   bool reached = eng.align(sA, targetA, sB, targetB, m_o, err);
+  if (aln >= 0) eng.piece(PIECE_SEARCH, aln, sA, sB, targetA, targetB, tA, tB, m_o);
   if (reached && overflow) reached = false;
   return PnFwd{targetA, targetB, err, targetk, reached ? 1 : 0};
 }
@@ -502,6 +594,7 @@ PG_HD int postnuc_unit(ENG& eng, const Chain* chains, const Match* cm, const int
       if (target_reached) {
         if (al[cura].eA != Mp.r || al[cura].eB != Mp.q) continue;     // matches of the target cluster before the target match
         al[cura].eA += Mp.len - 1; al[cura].eB += Mp.len - 1;
+        eng.piece(PIECE_MATCH, cura, Mp.r, Mp.q, Mp.r + Mp.len - 1, Mp.q + Mp.len - 1, 0, 0, 0u);
       } else {
         if (n_al >= max_al) { full = true; break; }
         al[n_al] = PnAln{Mp.r, Mp.q, Mp.r + Mp.len - 1, Mp.q + Mp.len - 1, 0, c};
@@ -525,15 +618,19 @@ PG_HD int postnuc_unit(ENG& eng, const Chain* chains, const Match* cm, const int
             // forced re-alignments only contribute their error count (the corner is reached by definition): the engine may
             // return it now (scalar engines) or add it to the alignment later (the GPU defers them to a kernel of their own)
             al[tgt].errors += eng.forced_errors(al[tgt].eA, al[cura].sA, al[tgt].eB, al[cura].sB, al + tgt);
+            eng.piece(PIECE_FORCED, tgt, al[tgt].eA, al[tgt].eB, al[cura].sA, al[cura].sB, 0, 0, FORCED_FORWARD_ALIGN);
             al[tgt].eA = al[cura].eA; al[tgt].eB = al[cura].eB;
             --n_al;
             cura = tgt;
           } else {
-            if (tA != al[cura].sA || tB != al[cura].sB)
+            if (tA != al[cura].sA || tB != al[cura].sB) {
               al[cura].errors += eng.forced_errors(tA, al[cura].sA, tB, al[cura].sB, al + cura);
+              eng.piece(PIECE_FORCED, cura, tA, tB, al[cura].sA, al[cura].sB, 0, 0, FORCED_FORWARD_ALIGN);
+            }
             al[cura].sA = tA; al[cura].sB = tB;
           }
         }
+        eng.piece(PIECE_MATCH, cura, Mp.r, Mp.q, Mp.r + Mp.len - 1, Mp.q + Mp.len - 1, 0, 0, 0u);
       }
       // extendForward: to the next match of the cluster, or from its last match towards the target cluster
       if (m + 1 < C.count) {
@@ -551,7 +648,9 @@ PG_HD int postnuc_unit(ENG& eng, const Chain* chains, const Match* cm, const int
         if (targetA - al[cura].eA + 1 > MAX_ALIGNMENT_LENGTH) { targetA = al[cura].eA + MAX_ALIGNMENT_LENGTH - 1; overflow = true; m_o |= OPTIMAL_BIT; }
         if (targetB - al[cura].eB + 1 > MAX_ALIGNMENT_LENGTH) { targetB = al[cura].eB + MAX_ALIGNMENT_LENGTH - 1; if (!overflow) m_o |= OPTIMAL_BIT; overflow = true; }
         int32_t err = 0;
+        const int32_t tA = targetA, tB = targetB;
         bool reached = eng.align(al[cura].eA, targetA, al[cura].eB, targetB, m_o, err);
+        eng.piece(PIECE_SEARCH, cura, al[cura].eA, al[cura].eB, targetA, targetB, tA, tB, m_o);
         if (reached && overflow) reached = false;
         al[cura].errors += err;
         al[cura].eA = targetA; al[cura].eB = targetB;
@@ -559,7 +658,7 @@ PG_HD int postnuc_unit(ENG& eng, const Chain* chains, const Match* cm, const int
       } else {
         // off the last match (the alignment ends on its last base here, however the walk entered the cluster): PnFwd
         PnFwd f;
-        if (!eng.fwd_ready(curk, f)) f = postnuc_forward(eng, chains, cm, order, n, curk, bounds);
+        if (!eng.fwd_ready(curk, f)) f = postnuc_forward(eng, chains, cm, order, n, curk, bounds, cura);
         targetk = f.targetk;
         al[cura].errors += f.errors; al[cura].eA = f.eA; al[cura].eB = f.eB;
         target_reached = f.reached != 0;

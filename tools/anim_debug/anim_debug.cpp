@@ -12,6 +12,7 @@
 #include <vector>
 #include "pg_anim_core.h"
 #include "pg_nucmer_core.h"
+#include "pg_anim_trace.h"
 using namespace pga;
 
 struct Genome {
@@ -92,6 +93,9 @@ int main(int argc, char** argv) {
   bool exact = getenv("ANIM_EXACT") != nullptr;   // the postnuc statement (pg_nucmer_core.h) instead of the banded64 extender
   for (int i = 3; i < argc; ++i) if (!strcmp(argv[i], "--exact")) exact = true;
   long exact_cells = 0;
+  bool want_delta = false;        // --delta (with --exact): every alignment's .delta indel list after its ALN line
+  for (int i = 3; i < argc; ++i) if (!strcmp(argv[i], "--delta")) want_delta = true;
+  std::vector<std::vector<int64_t>> deltas_all;
   Genome G = load(argv[1]), H = load(argv[2]);
   const SeqView R = G.view();
   std::vector<Aln> alns;
@@ -129,6 +133,8 @@ int main(int argc, char** argv) {
             rl = G.rec_start[chains[c].rrec]; rh = G.rec_start[chains[c].rrec + 1] - 1;
             ql = H.rec_start[chains[c].qrec]; qh = H.rec_start[chains[c].qrec + 1] - 1;
             if (strand) { const int32_t a = (int32_t)H.len - qh, b = (int32_t)H.len - ql; ql = a; qh = b; } };
+      std::vector<pgn::PnPiece> pieces;
+      if (want_delta) { pieces.resize((size_t)3 * n_cm + (size_t)4 * n_chains + 16); eng.pieces = pieces.data(); eng.piece_cap = (int32_t)pieces.size(); }
       // ANIM_HOIST: every cluster's forward extension first (what the GPU's pre-pass does), the walk then only reads them
       std::vector<pgn::PnFwd> fw;
       if (getenv("ANIM_HOIST")) {
@@ -145,6 +151,35 @@ int main(int argc, char** argv) {
           fused.data(), al.data(), (int)al.size());
       if (na < 0 || eng.overflow || deng.slow.overflow) { fprintf(stderr, "postnuc statement: capacity exceeded\n"); return 3; }
       exact_cells += eng.cells + deng.fast.cells + deng.slow.cells;
+      if (want_delta) {
+        // the paths of the walk's search / forced pieces, by the scalar engine with its traceback store (on the GPU: anim_trace_kernel)
+        if (eng.n_pieces > eng.piece_cap) { fprintf(stderr, "piece list too small\n"); return 3; }
+        eng.pieces = nullptr;
+        std::vector<std::vector<uint32_t>> rle((size_t)eng.n_pieces);
+        for (int p = 0; p < eng.n_pieces; ++p) {
+          const pgn::PnPiece& P = pieces[p];
+          if (P.kind == pgn::PIECE_MATCH) continue;
+          const int32_t N = P.kind == pgn::PIECE_FORCED ? P.A1 - P.A0 + 1 : P.tA - P.A0 + 1, M = P.kind == pgn::PIECE_FORCED ? P.B1 - P.B0 + 1 : P.tB - P.B0 + 1;
+          std::vector<uint8_t> bp((size_t)P.cells + 1);
+          std::vector<uint32_t> doff((size_t)N + M + 4);
+          std::vector<int32_t> dlo((size_t)N + M + 4);
+          pgn::PnTrace tr{bp.data(), (uint64_t)P.cells, doff.data(), dlo.data(), (int32_t)doff.size(), 0, 0, 0, 0};
+          eng.trace = &tr;
+          int32_t a = P.kind == pgn::PIECE_FORCED ? P.A1 : P.tA, b = P.kind == pgn::PIECE_FORCED ? P.B1 : P.tB, err = 0;
+          eng.align(P.A0, a, P.B0, b, P.m_o, err);
+          eng.trace = nullptr;
+          if (tr.overflow || eng.overflow || a != P.A1 || b != P.B1) { fprintf(stderr, "trace: piece %d does not repeat (%d %d vs %d %d, overflow %d)\n", p, a, b, P.A1, P.B1, tr.overflow); return 3; }
+          rle[p].resize((size_t)N + M + 4);
+          const int32_t cnt = pgn::pn_trace_back(tr, rle[p].data(), (int32_t)rle[p].size());
+          if (cnt < 0) { fprintf(stderr, "trace: broken path at piece %d\n", p); return 3; }
+          rle[p].resize((size_t)cnt);
+        }
+        std::vector<std::vector<int64_t>> deltas;
+        std::string why;
+        if (!pgt::unit_deltas(pieces.data(), eng.n_pieces, al.data(), na, [&](int32_t p, int32_t& cnt) { cnt = (int32_t)rle[p].size(); return rle[p].data(); }, deltas, &why)) {
+          fprintf(stderr, "trace: %s\n", why.c_str()); return 3; }
+        for (auto& d : deltas) deltas_all.push_back(std::move(d));
+      }
       if (getenv("ANIM_DIAG")) { fprintf(stderr, "calls / cells by class (0 = trimmed, 1.. = forced w 32, 64, ..., 15 = whole):"); for (int t = 0; t < 16; ++t) if (deng.stat_calls[t]) fprintf(stderr, " [%d] %ld / %ld", t, deng.stat_calls[t], deng.stat_cells[t]); fprintf(stderr, "\n"); }
       if (getenv("ANIM_DIAG")) fprintf(stderr, "diagonal-window engine: %ld cells, %ld calls fell back to the general engine (%ld cells)\n", deng.fast.cells, deng.fast.fallbacks, deng.slow.cells);
       for (int i = 0; i < na; ++i) {
@@ -230,6 +265,7 @@ int main(int argc, char** argv) {
       const int32_t ro = G.rec_start[a_rrec[i]], qo = H.rec_start[a_qrec[i]];
       printf("ALN %s %s %d %d %d %d %d keep=%d\n", G.ids[a_rrec[i]].c_str(), H.ids[a_qrec[i]].c_str(), a.rs - ro + 1, a.re - ro,
              a.strand ? a.qe - qo : a.qs - qo + 1, a.strand ? a.qs - qo + 1 : a.qe - qo, a.errors, a.keep);
+      if (want_delta && (size_t)i < deltas_all.size()) { for (int64_t d : deltas_all[i]) printf("%lld\n", (long long)d); printf("0\n"); }
     }
   return 0;
 }

@@ -24,6 +24,7 @@ ap.add_argument("--diff", action="store_true", help="print the records that diff
 ap.add_argument("--json", default="", help="write the per-pair report (records + parse_delta tuples) here")
 ap.add_argument("--oracle", action="store_true", help="run oracle/nucmer_oracle.cpp (the restatement of MUMmer's own algorithm) instead of the engine's host build")
 ap.add_argument("--groups", default="blochmannia,caulobacter,group2,jspecies")
+ap.add_argument("--delta", action="store_true", help="also compare every alignment's indel offset list with the .delta file's (host build: needs ANIM_EXACT=1)")
 args = ap.parse_args()
 import os
 import shlex
@@ -60,12 +61,21 @@ for grp in args.groups.split(","):
 def run(job):
     f, a, b, grp = job
     pa, pb = (joined if grp == "jspecies" and s == "NC_002696" else paths[s] for s in (a, b))
-    r = subprocess.run([str(exe), str(pa), str(pb), "--dump"], capture_output=True, text=True)
-    got, kept = set(), []
+    r = subprocess.run([str(exe), str(pa), str(pb), "--dump"] + (["--delta"] if args.delta else []), capture_output=True, text=True)
+    if r.returncode != 0:
+        print("FAILED", f.name, r.stderr[-300:], flush=True)
+    got, kept, lists, cur = set(), [], {}, None
     for line in r.stdout.splitlines():
+        if args.delta and cur is not None and not line.startswith("ALN "):
+            t = line.split()
+            if len(t) == 1 and t[0] != "0":
+                lists[cur].append(int(t[0]))
+            continue
         if line.startswith("ALN "):
             t = line.split()
             got.add((t[1], t[2], int(t[3]), int(t[4]), int(t[5]), int(t[6]), int(t[7])))
+            cur = (t[1], t[2], int(t[3]), int(t[4]), int(t[5]), int(t[6]), int(t[7]))
+            lists[cur] = []
             if len(t) > 8 and t[8] == "keep=3":
                 kept.append(anim_oracle.Aln(t[1], t[2], int(t[3]), int(t[4]), int(t[5]), int(t[6]), int(t[7]), int(t[7]), 0, ()))
     want = {(x.ref_id, x.qry_id, x.rs, x.re, x.qs, x.qe, x.errors) for x in anim_oracle.read_delta(f)[0]}
@@ -74,6 +84,11 @@ def run(job):
         for w in sorted(want - got): print("  MUMMER", w, flush=True)
         for g in sorted(got - want): print("  OURS  ", g, flush=True)
     rep = {"mummer_records": len(want), "exact": len(want & got), "same_coordinates": len(coords), "ours": len(got)}
+    if args.delta:
+        wl = {(x.ref_id, x.qry_id, x.rs, x.re, x.qs, x.qe, x.errors): list(x.indels) for x in anim_oracle.read_delta(f)[0]}
+        rep["indel_lists"] = len(wl)
+        rep["indel_lists_equal"] = sum(1 for k, v in wl.items() if lists.get(k) == v)
+        DELTA_TOTALS[0] += rep["indel_lists"]; DELTA_TOTALS[1] += rep["indel_lists_equal"]
     allrecs = [anim_oracle.Aln(*g, g[6], 0, ()) for g in got]
     rep["delta_tuple_mummer"] = list(anim_oracle.parse_delta(f))
     rep["delta_tuple_ours"] = list(anim_oracle.parse_delta_records(allrecs)) if allrecs else None
@@ -92,12 +107,15 @@ def run(job):
 
 
 report = {}
+DELTA_TOTALS = [0, 0]
 tot_w = tot_e = tot_c = 0
 with ThreadPoolExecutor(args.j) as ex:
     for name, nw, ne, nc, ng, first in ex.map(run, jobs):
         tot_w += nw; tot_e += ne; tot_c += nc
         print(f"{name[:70]:70s} mummer {nw:4d}  exact {ne:4d}  coords-only {nc:4d}  ours {ng:4d}", flush=True)
 print(f"TOTAL records {tot_w}  exact {tot_e}  same coordinates {tot_c}")
+if args.delta:
+    print(f"TOTAL indel lists {DELTA_TOTALS[0]}  equal {DELTA_TOTALS[1]}")
 if args.json:
     import json
     worst = {k: max((r.get(k, 0.0) for r in report.values()), default=0.0) for k in
