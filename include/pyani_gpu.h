@@ -31,7 +31,8 @@ extern "C" {
 #define PG_E_KEYSET (-6)   /* genomes have different observed-tetramer key sets: pyani raises AssertionError (tetra.py:174-175) */
 #define PG_E_EMPTY (-7)    /* empty key set: pyani raises ZeroDivisionError (tetra.py:181) */
 #define PG_E_RNA (-8)      /* sequence contains U/u: Biopython complements it asymmetrically (U->A); unsupported */
-#define PG_E_CAPACITY (-9) /* a per-pair work buffer overflowed (pg_anim_result.status only) */
+#define PG_E_CAPACITY (-9) /* a per-pair work buffer overflowed (pg_anim_result.status; pg_anim_alignments_batch) */
+#define PG_E_INTERNAL (-10) /* an internal consistency check failed (traceback pass), see pg_last_error */
 
 typedef struct pg_ctx pg_ctx;
 
@@ -165,6 +166,20 @@ typedef struct {
   int32_t kept;   /* 3 = survives delta-filter -1 (bit 0: reference-side LIS, bit 1: query-side LIS) */
 } pg_anim_alignment;
 int pg_anim_pair_alignments(pg_ctx* ctx, int32_t ref_id, int32_t qry_id, pg_anim_alignment* out, uint32_t cap, uint32_t* n_out);
+
+/* The same for MANY ordered pairs in one call — what pyani's nucmer jobs leave on disk for a whole run (the .delta files of
+ * pyani/anim.py:240-289, one per pair; kept == 3 marks the records of the .filter files), without running the search once per
+ * pair.  aln_offsets[n_pairs + 1]: pair i owns records [aln_offsets[i], aln_offsets[i + 1]) of the result, in MUMmer's output
+ * order (forward-strand alignments of the pair, then reverse-strand ones, each in the order postnuc creates them).
+ * with_indels != 0 adds a traceback pass on the GPU (one thread per search / forced piece of the alignments' paths, scalar engine
+ * with a backpointer store) and yields every record's .delta indel offset list (pyani/nucmer.py:170-290 parses them: positive =
+ * a reference base facing a gap, negative = a query base facing a gap, distances between consecutive indels; the terminating 0
+ * is not stored); *n_indels = how many numbers all lists hold together.  Needs the default extender (PG_EXTENDER_NUCMER).
+ * The result stays in the context until the next call; pg_anim_alignments_read copies it out: out[aln_offsets[n_pairs]],
+ * indel_offsets[n_alignments + 1] and indels[*n_indels] (both may be NULL). */
+int pg_anim_alignments_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_ids, uint64_t n_pairs, int maxmatch, int with_indels,
+                             uint64_t* aln_offsets, uint64_t* n_indels);
+int pg_anim_alignments_read(pg_ctx* ctx, pg_anim_alignment* out, uint64_t* indel_offsets, int64_t* indels);
 
 /* The reduction alone, on alignment records supplied by the caller (e.g. parsed from existing MUMmer .delta/.filter
  * files — pyani's --recovery mode): replaces delta-filter -1 (apply_filter != 0; scripts/delta_filter_wrapper.py:70-93)

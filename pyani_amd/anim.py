@@ -141,28 +141,34 @@ def fasta_records(path) -> List[Tuple[str, int]]:
     return [(i, n) for i, n in out]
 
 
-def write_delta(path, ref_fasta, qry_fasta, alignments, filtered: bool = True) -> int:
-    """Write one pair's alignment records (Engine.anim_pair_alignments) as a MUMmer .filter (filtered=True: only the
-    records delta-filter -1 keeps) or .delta file: the file nucmer / delta_filter_wrapper leave in
+def write_delta(path, ref_fasta, qry_fasta, alignments, filtered: bool = True, indels=None) -> int:
+    """Write one pair's alignment records (Engine.anim_alignments_batch / anim_pair_alignments) as a MUMmer .filter
+    (filtered=True: only the records delta-filter -1 keeps) or .delta file: the file nucmer / delta_filter_wrapper leave in
     <outdir>/nucmer_output/<stem1>/<stem1>_vs_<stem2>.{filter,delta} (anim.py:271-288) and pyani's --recovery mode
-    reads back with parse_delta.  Header lines follow pyani/nucmer.py:292-351.  The indel offset lists of a real
-    .delta are NOT written (no traceback in the engine; parse_delta ignores them): every alignment is its 7-field
-    header followed by the terminating 0, so the file is exact for pyani and for coordinate-level tools, but tools that
-    replay the alignment (show-aligns, dnadiff's SNP calls) cannot use it.  Returns the number of records written."""
+    reads back with parse_delta.  Header lines follow pyani/nucmer.py:292-351.
+    indels: one sequence of indel offsets per record (anim_alignments_batch(with_indels=True)) — then every alignment header is
+    followed by its offsets and the terminating 0, as in MUMmer's own file, and the records keep the order they came in
+    (MUMmer's output order inside each sequence pair).  Without them every alignment is its header followed by the 0 alone (exact
+    for pyani, whose parse_delta ignores the lists; tools that replay alignments need them) and records are sorted by start.
+    Returns the number of records written."""
     rrec, qrec = fasta_records(ref_fasta), fasta_records(qry_fasta)
     blocks = {}
-    for a in alignments:
+    for k, a in enumerate(alignments):
         if filtered and int(a["kept"]) != 3:
             continue
-        blocks.setdefault((int(a["ref_rec"]), int(a["qry_rec"])), []).append(a)
+        blocks.setdefault((int(a["ref_rec"]), int(a["qry_rec"])), []).append((a, None if indels is None else indels[k]))
     n = 0
     with open(path, "w") as fh:
         fh.write(f"{Path(ref_fasta).resolve()} {Path(qry_fasta).resolve()}\nNUCMER\n")
         for (r, q) in sorted(blocks):
             fh.write(f">{rrec[r][0]} {qrec[q][0]} {rrec[r][1]} {qrec[q][1]}\n")
-            for a in sorted(blocks[(r, q)], key=lambda x: (int(x["rs"]), int(x["qs"]))):
+            recs = blocks[(r, q)] if indels is not None else sorted(blocks[(r, q)], key=lambda x: (int(x[0]["rs"]), int(x[0]["qs"])))
+            for a, ind in recs:
                 e = int(a["errors"])
-                fh.write(f"{int(a['rs'])} {int(a['re'])} {int(a['qs'])} {int(a['qe'])} {e} {e} 0\n0\n")
+                fh.write(f"{int(a['rs'])} {int(a['re'])} {int(a['qs'])} {int(a['qe'])} {e} {e} 0\n")
+                if ind is not None and len(ind):
+                    fh.write("\n".join(str(int(v)) for v in ind) + "\n")
+                fh.write("0\n")
                 n += 1
     return n
 

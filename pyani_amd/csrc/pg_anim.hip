@@ -32,6 +32,7 @@
 #include "pg_anim_core.h"
 #include "pg_nucmer_core.h"
 #include "pg_anib_core.h"
+#include "pg_anim_trace.h"
 
 using namespace pga;
 
@@ -116,6 +117,7 @@ struct GenomeIdx {
   int32_t* word_pos = nullptr;      // ... and their positions
 };
 struct AnimLists { std::vector<GenomeIdx> gidx; };
+thread_local PgAlnSink* tls_sink = nullptr;      // set by pg_anim_alignments_batch around its run_batch calls
 thread_local int tls_worker = 0;   // which of the context's two (stream, scratch) sets the calling thread drives
 
 struct AnimScratch {
@@ -172,6 +174,15 @@ struct AnimScratch {
   PnForcedReq* pn_reqs = nullptr;   // the launch's deferred forced runs (at most one per alignment started: <= chains)
   pgn::PnGap* pn_gaps = nullptr;    // match-to-match alignments by match slot
   pgn::PnFwd* pn_fwd = nullptr;     // forward extensions by cluster (moff-relative position in the unit's order)
+  pgn::PnPiece* pn_pieces = nullptr; // traceback runs: the walks' pieces (pn_piece_base)
+  uint32_t* pn_npieces = nullptr;    // per unit
+  size_t pn_piece_cap = 0, pn_npieces_cap = 0;
+  uint8_t* tr_arena = nullptr;       // traceback pass: the jobs' slabs
+  uint32_t* tr_out = nullptr;        // ... their paths (run-length coded)
+  PnTraceJob* tr_jobs = nullptr;
+  unsigned long long *tr_off = nullptr, *tr_cursor = nullptr;
+  int32_t* tr_cnt = nullptr;
+  size_t tr_arena_cap = 0, tr_out_cap = 0, tr_jobs_cap = 0;
   PnGapTask* pn_tasks = nullptr;    // [3 size classes][pn_cap] small gaps for the lane kernel
   uint32_t* pn_order = nullptr;     // units by descending cluster count
   size_t pn_cap = 0, pn_units = 0, pn_waves = 0, pn_req_cap = 0;
@@ -212,6 +223,8 @@ void pg_anim_set_worker(pg_ctx* ctx, int worker) {
   tls_worker = worker > 0 && worker < pg_ctx::MAX_WORKERS ? worker : 0;
   pg_tls_stream = cur_stream(ctx);
 }
+
+void pg_anim_set_sink(PgAlnSink* sink) { tls_sink = sink; }
 
 void pg_anim_drop_lists(pg_ctx* ctx) {
   std::lock_guard<std::mutex> lk(ctx->anim_mu);
@@ -286,7 +299,7 @@ static void anim_free_one(pg_ctx* ctx, void*& slot) {
                   A->iscratch, A->order, A->prev, A->next, A->alnof, A->chains, A->fw, A->bw, A->S.alns, A->S.a_rrec,
                   A->S.a_qrec, A->S.idx, A->S.from, A->S.sc, A->wl_d, A->seedbuf, A->seed_total, A->tasks_d, A->fr_tables, A->fr_pairs,
                   A->fr_slot_pair, A->fr_off, A->fr_nrows, A->fr_ebase, A->fr_entries, A->fr_rows, A->fr_out, A->fr_list, A->fr_nlist, A->fr_wtmp, A->fr_widx,
-                  A->pn, A->pn_fused, A->pn_n, A->pn_cursor, A->pn_gscratch, A->pn_reqs, A->pn_gaps, A->pn_fwd, A->pn_tasks, A->pn_order};
+                  A->pn, A->pn_fused, A->pn_n, A->pn_cursor, A->pn_gscratch, A->pn_reqs, A->pn_gaps, A->pn_fwd, A->pn_tasks, A->pn_order, A->pn_pieces, A->pn_npieces, A->tr_arena, A->tr_out, A->tr_jobs, A->tr_off, A->tr_cursor, A->tr_cnt};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   delete A;
   slot = nullptr;
@@ -299,6 +312,179 @@ static void anim_free_one(pg_ctx* ctx, void*& slot) {
 static_assert(sizeof(FragRow) == sizeof(pg_anib_row), "FragRow is pg_anib_row");
 static int anib_frag_stage(pg_ctx* ctx, AnimScratch* A, const int32_t* qry_ids, uint32_t n_pairs, const std::vector<uint32_t>& cnt,
                            const PgFragArgs& F, const std::vector<int32_t>& ref_list, const std::vector<uint32_t>& ref_of_pair);
+
+// The alignment records of a finished batch -> the caller's sink; with_indels: the traceback pass (anim_trace_kernel: one
+// search / forced piece of the walks per thread, the scalar engine with its backpointer store) and the .delta lists
+// (pg_anim_trace.h).  Host work here is list management: sizing the jobs' slabs from the wave engine's own bookkeeping,
+// batching them into the arena, stitching the pieces' paths.
+static int anim_collect(pg_ctx* ctx, AnimScratch* A, const int32_t* ref_ids, const int32_t* qry_ids, uint32_t n_pairs, const pg_anim_result* res,
+                        const std::vector<uint32_t>& choff, bool postnuc, PgAlnSink& sink) {
+  const uint32_t n_units = 2 * n_pairs;
+  int rc;
+  std::vector<uint32_t> moff((size_t)n_units + 1);
+  PG_HIP(ctx, hipMemcpy(moff.data(), A->moff, moff.size() * 4, hipMemcpyDeviceToHost));
+  const size_t total = moff[n_units];
+  std::vector<Aln> al(total ? total : 1);
+  std::vector<int32_t> rr(total ? total : 1), qr(total ? total : 1);
+  if (total) {
+    PG_HIP(ctx, hipMemcpy(al.data(), A->S.alns, total * sizeof(Aln), hipMemcpyDeviceToHost));
+    PG_HIP(ctx, hipMemcpy(rr.data(), A->S.a_rrec, total * 4, hipMemcpyDeviceToHost));
+    PG_HIP(ctx, hipMemcpy(qr.data(), A->S.a_qrec, total * 4, hipMemcpyDeviceToHost));
+  }
+  const size_t first_aln = sink.alns.size();
+  std::vector<size_t> pair_first(n_pairs);
+  for (uint32_t p = 0; p < n_pairs; ++p) {
+    if (res[p].status == PG_E_CAPACITY) return pg_fail(ctx, PG_E_CAPACITY, "anim: work buffers overflowed for a pair of the batch");
+    const PgGenome& G = ctx->genomes[ref_ids[p]];
+    const PgGenome& H = ctx->genomes[qry_ids[p]];
+    const uint32_t n = (uint32_t)res[p].reserved;
+    pair_first[p] = sink.alns.size();
+    for (uint32_t i = 0; i < n; ++i) {
+      const Aln& a = al[moff[2 * p] + i];            // forward stream coordinates, half-open
+      const int32_t r_ = rr[moff[2 * p] + i], q_ = qr[moff[2 * p] + i], ro = G.rec_start[r_], qo = H.rec_start[q_];
+      pg_anim_alignment x;
+      x.ref_rec = r_; x.qry_rec = q_;
+      x.rs = a.rs - ro + 1; x.re = a.re - ro;
+      x.qs = a.strand ? a.qe - qo : a.qs - qo + 1;
+      x.qe = a.strand ? a.qs - qo + 1 : a.qe - qo;
+      x.errors = a.errors; x.kept = a.keep;
+      sink.alns.push_back(x);
+    }
+    sink.pair_count.push_back(n);
+  }
+  if (!sink.with_indels) return PG_OK;
+  if (!postnuc) return pg_fail(ctx, PG_E_ARG, "indel lists need the nucmer extender (pg_anim_set_extender)");
+  sink.indels.resize(sink.alns.size());
+  if (!total) return PG_OK;
+  // ---- the walks' pieces
+  const size_t n_wl = choff[n_units];
+  std::vector<pgn::PnAln> pn(total);
+  std::vector<int32_t> pn_n(n_units);
+  std::vector<uint32_t> npieces(n_units);
+  const size_t piece_total = pn_piece_base(total, (uint32_t)n_wl, n_units);
+  std::vector<pgn::PnPiece> pieces(piece_total ? piece_total : 1);
+  PG_HIP(ctx, hipMemcpy(pn.data(), A->pn, total * sizeof(pgn::PnAln), hipMemcpyDeviceToHost));
+  PG_HIP(ctx, hipMemcpy(pn_n.data(), A->pn_n, (size_t)n_units * 4, hipMemcpyDeviceToHost));
+  PG_HIP(ctx, hipMemcpy(npieces.data(), A->pn_npieces, (size_t)n_units * 4, hipMemcpyDeviceToHost));
+  PG_HIP(ctx, hipMemcpy(pieces.data(), A->pn_pieces, piece_total * sizeof(pgn::PnPiece), hipMemcpyDeviceToHost));
+  const size_t req_cap = n_wl + 16;
+  std::vector<PnForcedReq> reqs(req_cap);
+  PG_HIP(ctx, hipMemcpy(reqs.data(), A->pn_reqs, req_cap * sizeof(PnForcedReq), hipMemcpyDeviceToHost));
+  // ---- one job per search / forced piece
+  struct JobRef { uint32_t unit; uint32_t piece; uint64_t bytes; };      // piece: index in the unit's list
+  std::vector<PnTraceJob> jobs;
+  std::vector<JobRef> refs_;
+  for (uint32_t u = 0; u < n_units; ++u) {
+    const size_t pb = pn_piece_base(moff[u], choff[u], u);
+    if (pn_n[u] < 0 || npieces[u] > pn_piece_cap((size_t)moff[u + 1] - moff[u], choff[u + 1] - choff[u]))
+      return pg_fail(ctx, PG_E_CAPACITY, "anim traceback: a unit's piece list overflowed");
+    for (uint32_t k = 0; k < npieces[u]; ++k) {
+      const pgn::PnPiece& P = pieces[pb + k];
+      if (P.kind == pgn::PIECE_MATCH || P.kind == pgn::PIECE_VISIT) continue;
+      PnTraceJob J{};
+      J.unit = u; J.m_o = P.m_o; J.A0 = P.A0; J.B0 = P.B0; J.A1 = P.A1; J.B1 = P.B1;
+      uint64_t cells = P.cells;
+      uint32_t wmax = P.wmax;
+      if (P.kind == pgn::PIECE_FORCED) {
+        J.tA = P.A1; J.tB = P.B1;
+        if (P.aux >= req_cap) return pg_fail(ctx, PG_E_INTERNAL, "anim traceback: forced piece without its request");
+        J.band_w = reqs[P.aux].w;
+        const int32_t N = P.A1 - P.A0 + 1, M_ = P.B1 - P.B0 + 1;
+        cells = 0; wmax = 0;
+        for (int32_t d = 1; d <= N + M_; ++d) {      // the cells of the certified band, as the engine clips them
+          int32_t lo = d - N > 0 ? d - N : 0, hi = d < M_ ? d : M_;
+          if (J.band_w >= 0) pgn::forced_band_clip(d, N, M_, J.band_w, lo, hi);
+          if (hi >= lo) { cells += (uint64_t)(hi - lo + 1); if ((uint32_t)(hi - lo + 1) > wmax) wmax = (uint32_t)(hi - lo + 1); }
+        }
+      } else {
+        J.tA = P.tA; J.tB = P.tB; J.band_w = -1;
+        if (P.cells == 0xFFFFFFFFu) return pg_fail(ctx, PG_E_CAPACITY, "anim traceback: a search outgrew the register engine");
+      }
+      const int32_t N = J.tA - J.A0 + 1, M_ = J.tB - J.B0 + 1;
+      J.cap = wmax + 2; J.dcap = (uint32_t)(N + M_ + 4); J.rle_cap = (uint32_t)(N + M_ + 4); J.bp_cap = cells;
+      const uint64_t bytes = (uint64_t)J.cap * 3 * sizeof(pgn::Cell) + (uint64_t)J.dcap * 8 + (uint64_t)J.rle_cap * 4 + ((cells + 15) & ~15ull) + 16;
+      jobs.push_back(J);
+      refs_.push_back(JobRef{u, k, (bytes + 15) & ~15ull});
+    }
+  }
+  // ---- batches that fit the arena (largest jobs first: threads of a wave get pieces of similar size)
+  std::vector<uint32_t> order(jobs.size());
+  for (uint32_t i = 0; i < order.size(); ++i) order[i] = i;
+  std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return refs_[a].bytes > refs_[b].bytes; });
+  std::vector<std::vector<uint32_t>> rle(jobs.size());
+  const uint64_t ARENA = 6ull << 30, OUT_MAX = 192ull << 20;      // bytes of slabs / path entries per launch
+  if (!A->tr_cursor && (rc = regrow(ctx, A->tr_cursor, 2))) return rc;
+  for (size_t b0 = 0; b0 < order.size();) {
+    uint64_t bytes = 0, outs = 0;
+    size_t b1 = b0;
+    while (b1 < order.size() && (b1 == b0 || (bytes + refs_[order[b1]].bytes <= ARENA && outs + jobs[order[b1]].rle_cap <= OUT_MAX))) {
+      bytes += refs_[order[b1]].bytes; outs += jobs[order[b1]].rle_cap; ++b1;
+    }
+    const size_t nb = b1 - b0;
+    std::vector<PnTraceJob> hj(nb);
+    uint64_t at = 0;
+    for (size_t k = 0; k < nb; ++k) { hj[k] = jobs[order[b0 + k]]; hj[k].slab = at; at += refs_[order[b0 + k]].bytes; }
+    if (bytes > A->tr_arena_cap) { if ((rc = regrow(ctx, A->tr_arena, (size_t)bytes))) return rc; A->tr_arena_cap = (size_t)bytes; }
+    if (outs > A->tr_out_cap) { if ((rc = regrow(ctx, A->tr_out, (size_t)outs))) return rc; A->tr_out_cap = (size_t)outs; }
+    if (nb > A->tr_jobs_cap) {
+      if ((rc = regrow(ctx, A->tr_jobs, nb))) return rc;
+      if ((rc = regrow(ctx, A->tr_off, nb))) return rc;
+      if ((rc = regrow(ctx, A->tr_cnt, nb))) return rc;
+      A->tr_jobs_cap = nb;
+    }
+    PG_HIP(ctx, hipMemcpyAsync(A->tr_jobs, hj.data(), nb * sizeof(PnTraceJob), hipMemcpyHostToDevice, cur_stream(ctx)));
+    PG_HIP(ctx, hipMemsetAsync(A->tr_cursor, 0, 8, cur_stream(ctx)));
+    hipLaunchKernelGGL(anim_trace_kernel, dim3((uint32_t)((nb + 63) / 64)), dim3(64), 0, cur_stream(ctx), A->refs_d, A->units_d, A->tr_jobs, (uint32_t)nb,
+                       A->tr_arena, A->tr_out, (unsigned long long)outs, A->tr_cursor, A->tr_off, A->tr_cnt);
+    PG_HIP(ctx, hipGetLastError());
+    std::vector<unsigned long long> off(nb);
+    std::vector<int32_t> cnt(nb);
+    unsigned long long used = 0;
+    PG_HIP(ctx, hipMemcpyAsync(off.data(), A->tr_off, nb * 8, hipMemcpyDeviceToHost, cur_stream(ctx)));
+    PG_HIP(ctx, hipMemcpyAsync(cnt.data(), A->tr_cnt, nb * 4, hipMemcpyDeviceToHost, cur_stream(ctx)));
+    PG_HIP(ctx, hipMemcpyAsync(&used, A->tr_cursor, 8, hipMemcpyDeviceToHost, cur_stream(ctx)));
+    PG_HIP(ctx, hipStreamSynchronize(cur_stream(ctx)));
+    std::vector<uint32_t> out((size_t)used ? (size_t)used : 1);
+    if (used) PG_HIP(ctx, hipMemcpy(out.data(), A->tr_out, (size_t)used * 4, hipMemcpyDeviceToHost));
+    for (size_t k = 0; k < nb; ++k) {
+      if (cnt[k] < 0) return pg_fail(ctx, PG_E_INTERNAL, "anim traceback: a piece did not repeat in the scalar engine");
+      rle[order[b0 + k]].assign(out.begin() + (size_t)off[k], out.begin() + (size_t)off[k] + (size_t)cnt[k]);
+    }
+    b0 = b1;
+  }
+  // ---- stitch: per unit, the paths of its alignments; then the pair's records in MUMmer's print order (PIECE_VISIT)
+  size_t job_at = 0;
+  for (uint32_t p = 0; p < n_pairs; ++p) {
+    const size_t n_rec = (size_t)pn_n[2 * p] + (size_t)pn_n[2 * p + 1];
+    if (n_rec != sink.pair_count[sink.pair_count.size() - n_pairs + p]) return pg_fail(ctx, PG_E_INTERNAL, "anim traceback: record counts differ");
+    std::vector<std::vector<int64_t>> lists(n_rec);
+    std::vector<std::tuple<int32_t, int32_t, int32_t>> key(n_rec);      // (visit, strand, index in the unit)
+    for (uint32_t u = 2 * p; u < 2 * p + 2; ++u) {
+      const size_t pb = pn_piece_base(moff[u], choff[u], u);
+      std::vector<int32_t> job_of(npieces[u], -1);
+      for (uint32_t k = 0; k < npieces[u]; ++k)
+        if (pieces[pb + k].kind == pgn::PIECE_SEARCH || pieces[pb + k].kind == pgn::PIECE_FORCED) job_of[k] = (int32_t)job_at++;
+      std::vector<std::vector<int64_t>> deltas;
+      std::vector<int32_t> visit;
+      std::string why;
+      static const uint32_t none = 0;
+      if (!pgt::unit_deltas(pieces.data() + pb, (int32_t)npieces[u], pn.data() + moff[u], pn_n[u],
+                            [&](int32_t k, int32_t& c) -> const uint32_t* { const auto& v = rle[(size_t)job_of[k]]; c = (int32_t)v.size(); return v.empty() ? &none : v.data(); },
+                            deltas, visit, &why))
+        return pg_fail(ctx, PG_E_INTERNAL, "anim traceback: " + why);
+      const size_t base = (u & 1) ? (size_t)pn_n[u - 1] : 0;
+      for (int32_t i = 0; i < pn_n[u]; ++i) { lists[base + (size_t)i] = std::move(deltas[(size_t)i]); key[base + (size_t)i] = std::make_tuple(visit[(size_t)i], (int32_t)(u & 1), i); }
+    }
+    std::vector<size_t> perm(n_rec);
+    for (size_t i = 0; i < n_rec; ++i) perm[i] = i;
+    std::stable_sort(perm.begin(), perm.end(), [&](size_t a, size_t b) { return key[a] < key[b]; });
+    std::vector<pg_anim_alignment> recs(n_rec);
+    for (size_t i = 0; i < n_rec; ++i) recs[i] = sink.alns[pair_first[p] + perm[i]];
+    for (size_t i = 0; i < n_rec; ++i) { sink.alns[pair_first[p] + i] = recs[i]; sink.indels[pair_first[p] + i] = std::move(lists[perm[i]]); }
+  }
+  (void)first_aln;
+  return PG_OK;
+}
 
 int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_ids, uint32_t n_pairs, int filter_1to1, int maxmatch,
                       uint64_t max_matches, pg_anim_result* out_host, uint32_t* n_done, const PgFragArgs* frag) {
@@ -682,10 +868,17 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
     const uint32_t pn_waves = (uint32_t)ctx->num_cu * 12u;   // units / forced kernels: 12 KiB of LDS each: 12 per CU
     const uint32_t pn_waves_pre = (uint32_t)ctx->num_cu * 20u;   // gap / forward pre-passes: no LDS, < 104 registers: 5 per SIMD
     if (pn_waves_pre > A->pn_waves) { if ((rc = regrow(ctx, A->pn_gscratch, (size_t)pn_waves_pre * PN_GLOBAL_WORDS))) return rc; A->pn_waves = pn_waves_pre; }
+    const bool trace = tls_sink && tls_sink->with_indels;      // the walks list their pieces and align everything themselves
+    if (trace) {
+      const size_t need = pn_piece_base(Mp, (uint32_t)n_wl, n_units) + 16;
+      if (need > A->pn_piece_cap) { if ((rc = regrow(ctx, A->pn_pieces, need))) return rc; A->pn_piece_cap = need; }
+      if (n_units > A->pn_npieces_cap) { if ((rc = regrow(ctx, A->pn_npieces, (size_t)n_units + 16))) return rc; A->pn_npieces_cap = (size_t)n_units + 16; }
+    }
     const size_t req_cap = n_wl + 16;
     if (req_cap > A->pn_req_cap) { if ((rc = regrow(ctx, A->pn_reqs, req_cap + req_cap / 2))) return rc; A->pn_req_cap = req_cap + req_cap / 2; }
     PG_HIP(ctx, hipMemsetAsync(A->pn_cursor, 0, 64, cur_stream(ctx)));   // [0] unit cursor, [1] forced runs recorded ([7]: the long ones), [2] forced-run cursor, [3] chain cursor, [4..6] small gaps, [8] cluster cursor of the forward extensions
-    if (n_wl) {     // the (unit, chain) work list, then every cluster's match-to-match alignments
+    if (n_wl && trace) PG_HIP(ctx, hipMemcpyAsync(A->choff_d, choff.data(), choff.size() * 4, hipMemcpyHostToDevice, cur_stream(ctx)));
+    if (n_wl && !trace) {     // the (unit, chain) work list, then every cluster's match-to-match alignments
       if (n_wl > A->wl) { if ((rc = regrow(ctx, A->wl_d, n_wl + n_wl / 2))) return rc; A->wl = n_wl + n_wl / 2; }
       PG_HIP(ctx, hipMemcpyAsync(A->choff_d, choff.data(), choff.size() * 4, hipMemcpyHostToDevice, cur_stream(ctx)));
       hipLaunchKernelGGL(anim_wl_kernel, dim3(n_units), dim3(64), 0, cur_stream(ctx), A->choff_d, A->wl_d);
@@ -709,7 +902,7 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
     if (n_wl)
       hipLaunchKernelGGL(anim_postnuc_kernel, dim3(pn_waves < n_units ? pn_waves : n_units), dim3(64), 0, cur_stream(ctx), A->refs_d, A->units_d,
                          n_units, O, A->pn_cursor, A->pn, A->pn_fused, A->pn_n, A->pn_gscratch, A->pn_reqs, A->pn_cursor + 1, (uint32_t)req_cap,
-                         A->pn_gaps, A->pn_fwd, A->pn_order);
+                         trace ? nullptr : A->pn_gaps, trace ? nullptr : A->pn_fwd, A->pn_order, trace ? A->pn_pieces : nullptr, A->pn_npieces, A->choff_d);
     else
       PG_HIP(ctx, hipMemsetAsync(A->pn_n, 0, (size_t)n_units * 4, cur_stream(ctx)));
     pg_prof_end(ctx);
@@ -835,6 +1028,7 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
   PG_HIP(ctx, hipGetLastError());
   PG_HIP(ctx, hipMemcpyAsync(out_host, A->out, n_pairs * sizeof(pg_anim_result), hipMemcpyDeviceToHost, cur_stream(ctx)));
   PG_HIP(ctx, hipStreamSynchronize(cur_stream(ctx)));
+  if (tls_sink && (rc = anim_collect(ctx, A, ref_ids, qry_ids, n_pairs, out_host, choff, postnuc, *tls_sink))) return rc;
 #ifdef PGA_DP_STATS
   {
     unsigned long long st[3][40];

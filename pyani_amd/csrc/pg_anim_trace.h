@@ -68,15 +68,20 @@ inline void delta_of(const OpRuns& ops, std::vector<int64_t>& out, int64_t& a_ba
 // One unit: pieces in walk order (n of them), rle_of(p, n_out) -> the reverse RLE of piece p (search / forced pieces).
 // Fills, for alignment a of the unit (index in al[]), its indel list.  Returns false on an inconsistent plan (a piece that does
 // not start where its alignment ends, a path whose base counts differ from the alignment's extent).
+// visit_key[a] = the reference start of the cluster the walk had arrived at when alignment a was created (PIECE_VISIT).
 template <typename RLE>
 bool unit_deltas(const pgn::PnPiece* pieces, int32_t n, const pgn::PnAln* al, int32_t n_al, RLE&& rle_of,
-                 std::vector<std::vector<int64_t>>& deltas, std::string* why = nullptr) {
+                 std::vector<std::vector<int64_t>>& deltas, std::vector<int32_t>& visit_key, std::string* why = nullptr) {
   std::vector<OpRuns> ops((size_t)n_al);
+  visit_key.assign((size_t)n_al, -1);
+  int32_t visit = -1;
   const auto fail = [&](const char* w, int32_t p) { if (why) *why = std::string(w) + " at piece " + std::to_string(p); return false; };
   for (int32_t p = 0; p < n; ++p) {
     const pgn::PnPiece& P = pieces[p];
+    if (P.kind == pgn::PIECE_VISIT) { visit = P.A0; continue; }
     if (P.aln < 0 || P.aln >= n_al) continue;      // (an alignment that was merged away later never gets here: see postnuc_unit)
     OpRuns& O = ops[(size_t)P.aln];
+    if (O.empty() && visit_key[(size_t)P.aln] < 0) visit_key[(size_t)P.aln] = visit;
     if (P.kind == pgn::PIECE_MATCH) {
       // a match: its first base pair may already be the path's last column (the target of the piece before it)
       uint64_t len = (uint64_t)(P.A1 - P.A0 + 1);

@@ -860,6 +860,71 @@ int pg_anim_pair_alignments(pg_ctx* ctx, int32_t ref_id, int32_t qry_id, pg_anim
   return PG_OK;
 }
 
+int pg_anim_alignments_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_ids, uint64_t n_pairs, int maxmatch, int with_indels,
+                             uint64_t* aln_offsets, uint64_t* n_indels) {
+  if (!ctx || !aln_offsets || (n_pairs && (!ref_ids || !qry_ids))) return pg_fail(ctx, PG_E_ARG, "bad argument");
+  for (uint64_t i = 0; i < n_pairs; ++i)
+    if (ref_ids[i] < 0 || (size_t)ref_ids[i] >= ctx->genomes.size() || qry_ids[i] < 0 || (size_t)qry_ids[i] >= ctx->genomes.size())
+      return pg_fail(ctx, PG_E_ARG, "genome id out of range");
+  if (with_indels && ctx->anim_extender != PG_EXTENDER_NUCMER) return pg_fail(ctx, PG_E_ARG, "indel lists need the nucmer extender (pg_anim_set_extender)");
+  PG_HIP(ctx, hipSetDevice(ctx->device));
+  int rc;
+  if ((rc = pg_upload(ctx))) return rc;
+  ctx->aln_store.clear(); ctx->aln_indel_off.assign(1, 0); ctx->aln_indels.clear();
+  // launches: the call's pairs grouped by reference genome (its seed table is built once per launch), a bounded number each
+  std::vector<uint64_t> order(n_pairs);
+  for (uint64_t i = 0; i < n_pairs; ++i) order[i] = i;
+  std::stable_sort(order.begin(), order.end(), [&](uint64_t a, uint64_t b) { return ref_ids[a] < ref_ids[b]; });
+  const uint64_t LAUNCH = with_indels ? 64 : 1024;      // (a traceback launch keeps its walks' pieces and their paths on the host)
+  PgAlnSink sink;
+  sink.with_indels = with_indels != 0;
+  pg_anim_set_sink(&sink);
+  std::vector<int32_t> r, q;
+  std::vector<pg_anim_result> res;
+  rc = PG_OK;
+  for (uint64_t i = 0; i < n_pairs && rc == PG_OK;) {
+    uint64_t j = std::min<uint64_t>(n_pairs, i + LAUNCH);
+    r.clear(); q.clear();
+    for (uint64_t k = i; k < j; ++k) { r.push_back(ref_ids[order[k]]); q.push_back(qry_ids[order[k]]); }
+    res.assign(j - i, pg_anim_result{});
+    uint32_t done = 0;
+    rc = pg_anim_run_batch(ctx, r.data(), q.data(), (uint32_t)(j - i), 1, maxmatch != 0, ctx->anim_batch_matches, res.data(), &done);
+    i += done;
+  }
+  pg_anim_set_sink(nullptr);
+  if (rc) return rc;
+  // back to the caller's order
+  std::vector<uint64_t> first(n_pairs + 1, 0), at_sorted(n_pairs + 1, 0);
+  for (uint64_t k = 0; k < n_pairs; ++k) at_sorted[k + 1] = at_sorted[k] + sink.pair_count[k];
+  for (uint64_t k = 0; k < n_pairs; ++k) first[order[k] + 1] = sink.pair_count[k];
+  for (uint64_t i = 0; i < n_pairs; ++i) first[i + 1] += first[i];
+  ctx->aln_store.resize(sink.alns.size());
+  std::vector<uint64_t> src_of(sink.alns.size());
+  for (uint64_t k = 0; k < n_pairs; ++k)
+    for (uint64_t t = 0; t < sink.pair_count[k]; ++t) { ctx->aln_store[first[order[k]] + t] = sink.alns[at_sorted[k] + t]; src_of[first[order[k]] + t] = at_sorted[k] + t; }
+  uint64_t total = 0;
+  if (with_indels) {
+    ctx->aln_indel_off.assign(sink.alns.size() + 1, 0);
+    for (uint64_t a = 0; a < sink.alns.size(); ++a) { total += sink.indels[src_of[a]].size(); ctx->aln_indel_off[a + 1] = total; }
+    ctx->aln_indels.reserve(total);
+    for (uint64_t a = 0; a < sink.alns.size(); ++a) ctx->aln_indels.insert(ctx->aln_indels.end(), sink.indels[src_of[a]].begin(), sink.indels[src_of[a]].end());
+  }
+  for (uint64_t i = 0; i <= n_pairs; ++i) aln_offsets[i] = first[i];
+  if (n_indels) *n_indels = total;
+  return PG_OK;
+}
+
+int pg_anim_alignments_read(pg_ctx* ctx, pg_anim_alignment* out, uint64_t* indel_offsets, int64_t* indels) {
+  if (!ctx || (!out && !ctx->aln_store.empty())) return pg_fail(ctx, PG_E_ARG, "bad argument");
+  for (size_t i = 0; i < ctx->aln_store.size(); ++i) out[i] = ctx->aln_store[i];
+  if (indel_offsets) {
+    if (ctx->aln_indel_off.size() != ctx->aln_store.size() + 1) return pg_fail(ctx, PG_E_ARG, "the stored result has no indel lists (with_indels was 0)");
+    for (size_t i = 0; i < ctx->aln_indel_off.size(); ++i) indel_offsets[i] = ctx->aln_indel_off[i];
+  }
+  if (indels) for (size_t i = 0; i < ctx->aln_indels.size(); ++i) indels[i] = ctx->aln_indels[i];
+  return PG_OK;
+}
+
 int pg_anim_reduce(pg_ctx* ctx, uint32_t n_pairs, const uint64_t* offsets, const int32_t* rseq, const int32_t* qseq,
                    const int32_t* rs, const int32_t* re, const int32_t* qs, const int32_t* qe, const int32_t* errors,
                    int apply_filter, pg_anim_result* out) {

@@ -85,6 +85,10 @@ struct pg_ctx {
   void* anim_scratch = nullptr;  // AnimScratch (pg_anim.hip) of worker 0, grows on demand
   // ANIm / fragment-mode calls are split over two host workers, each with its own stream and scratch: while one worker's
   // launch is in a low-occupancy tail (one wave per unit, slowest unit = launch time) the other's kernels fill the GPU
+  // result of the latest pg_anim_alignments_batch (caller's pair order)
+  std::vector<pg_anim_alignment> aln_store;
+  std::vector<uint64_t> aln_indel_off;
+  std::vector<int64_t> aln_indels;
   static constexpr int MAX_WORKERS = 4;
   void* anim_scratch_w[MAX_WORKERS] = {nullptr, nullptr, nullptr, nullptr};   // workers 1.. (index 0 unused: worker 0 = anim_scratch)
   hipStream_t stream_w[MAX_WORKERS] = {nullptr, nullptr, nullptr, nullptr};   // workers 1.. (index 0 unused: worker 0 = stream)
@@ -138,6 +142,15 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
 void pg_anim_set_worker(pg_ctx* ctx, int worker);   // binds the calling thread to worker 0 .. MAX_WORKERS-1 (stream + scratch) for run_batch
 void pg_anim_free_scratch(pg_ctx* ctx);
 int pg_anim_fetch_alignments(pg_ctx* ctx, int32_t ref_id, int32_t qry_id, uint32_t n, pg_anim_alignment* out);   // after a 1-pair batch
+// Where pg_anim_run_batch leaves the alignment records of its pairs when the calling thread has set one (pg_anim_alignments_batch):
+// appended pair after pair in the order of the call's arrays; with_indels adds the traceback pass and every alignment's .delta list.
+struct PgAlnSink {
+  bool with_indels = false;
+  std::vector<pg_anim_alignment> alns;
+  std::vector<uint32_t> pair_count;               // alignments of each pair, in arrival order
+  std::vector<std::vector<int64_t>> indels;       // parallel to alns (with_indels)
+};
+void pg_anim_set_sink(PgAlnSink* sink);           // thread-local; nullptr = none
 void pg_anim_drop_lists(pg_ctx* ctx);   // per-genome seed lists: must go when the genome store is cleared
 int pg_anib_reduce_run(pg_ctx* ctx, uint32_t n_pairs, const uint64_t* offsets, const uint32_t* n_frags, const int32_t* frag,
                        const int32_t* length, const int32_t* mismatch, const int32_t* gaps, const int32_t* qlen,

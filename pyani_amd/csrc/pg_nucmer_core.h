@@ -142,7 +142,10 @@ PG_HD int32_t pn_trace_back(const PnTrace& tr, uint32_t* rle, int32_t cap) {
 
 // A piece of an alignment's path, in the order the walk lays them down (postnuc_unit, `eng.piece`): an exact match, a search /
 // alignment of the engine from (A0, B0) towards the target (tA, tB) that ended on (A1, B1), or a forced run between two corners.
-enum : uint32_t { PIECE_MATCH = 0, PIECE_SEARCH = 1, PIECE_FORCED = 2 };
+// PIECE_VISIT (aln = -1) marks the walk arriving at the next cluster in reference order (A0 = the reference start of its first
+// match): MUMmer walks the clusters of BOTH strands of a sequence pair in one list sorted by that start and prints alignments in
+// the order it creates them, so an alignment's place in the .delta file is (the visit it was created in, forward strand first).
+enum : uint32_t { PIECE_MATCH = 0, PIECE_SEARCH = 1, PIECE_FORCED = 2, PIECE_VISIT = 3 };
 struct PnPiece {
   int32_t aln;                 // the alignment (index in the unit's al[]) it belongs to
   uint32_t kind, m_o;
@@ -584,6 +587,7 @@ PG_HD int postnuc_unit(ENG& eng, const Chain* chains, const Match* cm, const int
     int32_t r_lo, r_hi, q_lo, q_hi;
     bounds(c, r_lo, r_hi, q_lo, q_hi);
     if (!target_reached) {
+      eng.piece(PIECE_VISIT, -1, mf.r, mf.q, 0, 0, 0, 0, 0u);
       bool skip = fused[curk] != 0;
       if (!skip)     // isShadowedCluster: inside an alignment of the same records made so far (from the current one backwards)
         skip = eng.shadowed(chains, al, cura, c, mf.r, ml.r + ml.len - 1, mf.q, ml.q + ml.len - 1);

@@ -193,6 +193,27 @@ class Engine:
             self._check(self.lib.pg_anim_pair_alignments(self._h, int(ref_id), int(qry_id), out.ctypes.data, len(out), ctypes.byref(n)))
         return out[:n.value].copy()
 
+    def anim_alignments_batch(self, ref_ids, qry_ids, maxmatch: bool = False, with_indels: bool = False):
+        """Alignment records of MANY ordered pairs in one call (pg_anim_alignments_batch): what pyani's nucmer jobs leave in
+        their .delta files for a whole run (anim.py:240-289).  Returns (offsets, records, indel_offsets, indels): pair i owns
+        records[offsets[i]:offsets[i + 1]] (ALN_DTYPE; kept == 3: survives delta-filter -1); with_indels=True adds the GPU
+        traceback pass: record k's .delta indel offset list is indels[indel_offsets[k]:indel_offsets[k + 1]] (without the
+        terminating 0) and the records of a pair come in MUMmer's own output order; else the last two are None."""
+        r = np.ascontiguousarray(list(ref_ids), dtype=np.int32)
+        q = np.ascontiguousarray(list(qry_ids), dtype=np.int32)
+        if len(r) != len(q):
+            raise ValueError("ref_ids and qry_ids must have the same length")
+        offsets = np.zeros(len(r) + 1, dtype=np.uint64)
+        n_ind = ctypes.c_uint64(0)
+        self._check(self.lib.pg_anim_alignments_batch(self._h, r.ctypes.data, q.ctypes.data, len(r), int(bool(maxmatch)), int(bool(with_indels)),
+                                                      offsets.ctypes.data, ctypes.byref(n_ind)))
+        recs = np.zeros(int(offsets[-1]), dtype=self.ALN_DTYPE)
+        ioff = np.zeros(len(recs) + 1, dtype=np.uint64) if with_indels else None
+        ind = np.zeros(int(n_ind.value), dtype=np.int64) if with_indels else None
+        self._check(self.lib.pg_anim_alignments_read(self._h, recs.ctypes.data if len(recs) else None, ioff.ctypes.data if with_indels else None,
+                                                     ind.ctypes.data if with_indels and len(ind) else None))
+        return offsets, recs, ioff, ind
+
     def anim_reduce(self, pairs, apply_filter: bool = False) -> np.ndarray:
         """pairs: list of per-pair record lists [(rseq, qseq, rs, re, qs, qe, errors), ...] in MUMmer coordinates
         (1-based closed, qs > qe on the reverse strand; rseq/qseq = sequence ordinals within the pair)."""

@@ -179,6 +179,9 @@ class MultiEngine:
     def anim_pair_alignments(self, ref_id: int, qry_id: int):
         return self.engines[0].anim_pair_alignments(ref_id, qry_id)
 
+    def anim_alignments_batch(self, ref_ids, qry_ids, maxmatch: bool = False, with_indels: bool = False):
+        return self.engines[0].anim_alignments_batch(ref_ids, qry_ids, maxmatch=maxmatch, with_indels=with_indels)
+
     def anib_pair_rows(self, qry_id: int, sbj_id: int, fragsize: int = 1020):
         return self.engines[0].anib_pair_rows(qry_id, sbj_id, fragsize)
 

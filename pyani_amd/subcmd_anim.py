@@ -37,6 +37,9 @@ class AnimRun(NamedTuple):
     written: List[Path]                                         # output files written by this run
 
 
+WRITE_CHUNK = 256      # ordered pairs per pg_anim_alignments_batch call of write_output (its result is held on the host)
+
+
 def outfile_path(outdir: Path, qstem: str, sstem: str, nofilter: bool = False) -> Path:
     """anim.py:271-288: suffixes are appended as strings (stems may contain dots)."""
     return Path(outdir) / ALIGNDIR / qstem / (f"{qstem}_vs_{sstem}" + (".delta" if nofilter else ".filter"))
@@ -106,13 +109,18 @@ def _run_anim(indir, outdir, recovery, nofilter, maxmatch, write_output, skip_ze
                     if not skip_zero:
                         raise
             if write_output:
-                if outdir is None or maxmatch:
-                    raise ValueError("write_output needs an output directory (and is not available with maxmatch yet)")
-                for q, s in todo:
-                    f = outfile_path(outdir, q, s, nofilter)
-                    f.parent.mkdir(parents=True, exist_ok=True)
-                    anim.write_delta(f, by_stem[q], by_stem[s], eng.anim_pair_alignments(ids[q], ids[s]), filtered=not nofilter)
-                    written.append(f)
+                # the files nucmer / delta-filter would have left, indel lists included: batched calls, a traceback pass on the GPU each
+                for c0 in range(0, len(todo), WRITE_CHUNK):
+                    part = todo[c0:c0 + WRITE_CHUNK]
+                    off, recs, ioff, ind = eng.anim_alignments_batch([ids[q] for q, _ in part], [ids[s] for _, s in part],
+                                                                     maxmatch=maxmatch, with_indels=True)
+                    for k, (q, s) in enumerate(part):
+                        f = outfile_path(outdir, q, s, nofilter)
+                        f.parent.mkdir(parents=True, exist_ok=True)
+                        lo, hi = int(off[k]), int(off[k + 1])
+                        anim.write_delta(f, by_stem[q], by_stem[s], recs[lo:hi], filtered=not nofilter,
+                                         indels=[ind[int(ioff[a]):int(ioff[a + 1])] for a in range(lo, hi)])
+                        written.append(f)
     finally:
         if scratch_store:
             eng.clear_genomes()

@@ -96,6 +96,7 @@ int main(int argc, char** argv) {
   bool want_delta = false;        // --delta (with --exact): every alignment's .delta indel list after its ALN line
   for (int i = 3; i < argc; ++i) if (!strcmp(argv[i], "--delta")) want_delta = true;
   std::vector<std::vector<int64_t>> deltas_all;
+  std::vector<int32_t> visit_all;       // per alignment: the PIECE_VISIT key (MUMmer's print order: by visit, forward strand first)
   Genome G = load(argv[1]), H = load(argv[2]);
   const SeqView R = G.view();
   std::vector<Aln> alns;
@@ -158,7 +159,7 @@ int main(int argc, char** argv) {
         std::vector<std::vector<uint32_t>> rle((size_t)eng.n_pieces);
         for (int p = 0; p < eng.n_pieces; ++p) {
           const pgn::PnPiece& P = pieces[p];
-          if (P.kind == pgn::PIECE_MATCH) continue;
+          if (P.kind == pgn::PIECE_MATCH || P.kind == pgn::PIECE_VISIT) continue;
           const int32_t N = P.kind == pgn::PIECE_FORCED ? P.A1 - P.A0 + 1 : P.tA - P.A0 + 1, M = P.kind == pgn::PIECE_FORCED ? P.B1 - P.B0 + 1 : P.tB - P.B0 + 1;
           std::vector<uint8_t> bp((size_t)P.cells + 1);
           std::vector<uint32_t> doff((size_t)N + M + 4);
@@ -175,10 +176,12 @@ int main(int argc, char** argv) {
           rle[p].resize((size_t)cnt);
         }
         std::vector<std::vector<int64_t>> deltas;
+        std::vector<int32_t> visit;
         std::string why;
-        if (!pgt::unit_deltas(pieces.data(), eng.n_pieces, al.data(), na, [&](int32_t p, int32_t& cnt) { cnt = (int32_t)rle[p].size(); return rle[p].data(); }, deltas, &why)) {
+        if (!pgt::unit_deltas(pieces.data(), eng.n_pieces, al.data(), na, [&](int32_t p, int32_t& cnt) { cnt = (int32_t)rle[p].size(); return rle[p].data(); }, deltas, visit, &why)) {
           fprintf(stderr, "trace: %s\n", why.c_str()); return 3; }
         for (auto& d : deltas) deltas_all.push_back(std::move(d));
+        for (int i = 0; i < na; ++i) visit_all.push_back(visit[(size_t)i]);
       }
       if (getenv("ANIM_DIAG")) { fprintf(stderr, "calls / cells by class (0 = trimmed, 1.. = forced w 32, 64, ..., 15 = whole):"); for (int t = 0; t < 16; ++t) if (deng.stat_calls[t]) fprintf(stderr, " [%d] %ld / %ld", t, deng.stat_calls[t], deng.stat_cells[t]); fprintf(stderr, "\n"); }
       if (getenv("ANIM_DIAG")) fprintf(stderr, "diagonal-window engine: %ld cells, %ld calls fell back to the general engine (%ld cells)\n", deng.fast.cells, deng.fast.fallbacks, deng.slow.cells);
@@ -265,7 +268,7 @@ int main(int argc, char** argv) {
       const int32_t ro = G.rec_start[a_rrec[i]], qo = H.rec_start[a_qrec[i]];
       printf("ALN %s %s %d %d %d %d %d keep=%d\n", G.ids[a_rrec[i]].c_str(), H.ids[a_qrec[i]].c_str(), a.rs - ro + 1, a.re - ro,
              a.strand ? a.qe - qo : a.qs - qo + 1, a.strand ? a.qs - qo + 1 : a.qe - qo, a.errors, a.keep);
-      if (want_delta && (size_t)i < deltas_all.size()) { for (int64_t d : deltas_all[i]) printf("%lld\n", (long long)d); printf("0\n"); }
+      if (want_delta && (size_t)i < deltas_all.size()) { printf("VISIT %d %d\n", visit_all[i], a.strand); for (int64_t d : deltas_all[i]) printf("%lld\n", (long long)d); printf("0\n"); }
     }
   return 0;
 }

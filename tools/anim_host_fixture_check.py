@@ -64,18 +64,21 @@ def run(job):
     r = subprocess.run([str(exe), str(pa), str(pb), "--dump"] + (["--delta"] if args.delta else []), capture_output=True, text=True)
     if r.returncode != 0:
         print("FAILED", f.name, r.stderr[-300:], flush=True)
-    got, kept, lists, cur = set(), [], {}, None
+    got, kept, lists, cur, visits, seq = set(), [], {}, None, {}, []
     for line in r.stdout.splitlines():
         if args.delta and cur is not None and not line.startswith("ALN "):
             t = line.split()
             if len(t) == 1 and t[0] != "0":
                 lists[cur].append(int(t[0]))
+            elif t and t[0] == "VISIT":
+                visits[cur] = (int(t[1]), int(t[2]))
             continue
         if line.startswith("ALN "):
             t = line.split()
             got.add((t[1], t[2], int(t[3]), int(t[4]), int(t[5]), int(t[6]), int(t[7])))
             cur = (t[1], t[2], int(t[3]), int(t[4]), int(t[5]), int(t[6]), int(t[7]))
             lists[cur] = []
+            seq.append(cur)
             if len(t) > 8 and t[8] == "keep=3":
                 kept.append(anim_oracle.Aln(t[1], t[2], int(t[3]), int(t[4]), int(t[5]), int(t[6]), int(t[7]), int(t[7]), 0, ()))
     want = {(x.ref_id, x.qry_id, x.rs, x.re, x.qs, x.qe, x.errors) for x in anim_oracle.read_delta(f)[0]}
@@ -89,6 +92,17 @@ def run(job):
         rep["indel_lists"] = len(wl)
         rep["indel_lists_equal"] = sum(1 for k, v in wl.items() if lists.get(k) == v)
         DELTA_TOTALS[0] += rep["indel_lists"]; DELTA_TOTALS[1] += rep["indel_lists_equal"]
+        # MUMmer's print order inside each (reference record, query record) block: by the visit the alignment was created in, forward strand first
+        file_seq = [(x.ref_id, x.qry_id, x.rs, x.re, x.qs, x.qe, x.errors) for x in anim_oracle.read_delta(f)[0]]
+        blocks_file, blocks_ours = {}, {}
+        for k in file_seq:
+            blocks_file.setdefault(k[:2], []).append(k)
+        for i, k in enumerate(seq):
+            blocks_ours.setdefault(k[:2], []).append((visits.get(k, (0, 0)), i, k))
+        same = sum(1 for b, v in blocks_file.items() if [k for _, _, k in sorted(blocks_ours.get(b, []))] == v)
+        rep["blocks"] = len(blocks_file); rep["blocks_in_mummer_order"] = same
+        rep["block_sequence_equal"] = list(dict.fromkeys(k[:2] for k in file_seq)) == list(dict.fromkeys(k[:2] for k in seq))
+        DELTA_TOTALS[2] += len(blocks_file); DELTA_TOTALS[3] += same; DELTA_TOTALS[4] += int(rep["block_sequence_equal"]); DELTA_TOTALS[5] += 1
     allrecs = [anim_oracle.Aln(*g, g[6], 0, ()) for g in got]
     rep["delta_tuple_mummer"] = list(anim_oracle.parse_delta(f))
     rep["delta_tuple_ours"] = list(anim_oracle.parse_delta_records(allrecs)) if allrecs else None
@@ -107,7 +121,7 @@ def run(job):
 
 
 report = {}
-DELTA_TOTALS = [0, 0]
+DELTA_TOTALS = [0, 0, 0, 0, 0, 0]
 tot_w = tot_e = tot_c = 0
 with ThreadPoolExecutor(args.j) as ex:
     for name, nw, ne, nc, ng, first in ex.map(run, jobs):
@@ -115,7 +129,7 @@ with ThreadPoolExecutor(args.j) as ex:
         print(f"{name[:70]:70s} mummer {nw:4d}  exact {ne:4d}  coords-only {nc:4d}  ours {ng:4d}", flush=True)
 print(f"TOTAL records {tot_w}  exact {tot_e}  same coordinates {tot_c}")
 if args.delta:
-    print(f"TOTAL indel lists {DELTA_TOTALS[0]}  equal {DELTA_TOTALS[1]}")
+    print(f"TOTAL indel lists {DELTA_TOTALS[0]}  equal {DELTA_TOTALS[1]};  blocks {DELTA_TOTALS[2]}, alignments in MUMmer's order inside {DELTA_TOTALS[3]} of them;  files whose block sequence is ours (by record ordinal) {DELTA_TOTALS[4]} of {DELTA_TOTALS[5]}")
 if args.json:
     import json
     worst = {k: max((r.get(k, 0.0) for r in report.values()), default=0.0) for k in
