@@ -155,7 +155,7 @@ int pg_anim_set_batch_budget(pg_ctx* ctx, uint32_t max_pairs, uint64_t max_match
 
 /* The alignment records of ONE ordered pair: the content of the .delta file nucmer would write (kept == 3 marks the
  * records delta-filter -1 keeps, i.e. the .filter file), minus the indel offset lists, which parse_delta ignores
- * (anim.py:374-393) and this engine does not trace back.  Coordinates as in MUMmer's alignment header lines
+ * (anim.py:374-393); pg_anim_alignments_batch below returns them too.  Coordinates as in MUMmer's alignment header lines
  * (pyani/nucmer.py:333-351): 1-based, closed, relative to the record, qs > qe on the reverse strand; ref_rec / qry_rec
  * = ordinal of the FASTA record (the '>' line names the ids).  At most `cap` records are written, *n_out = how many
  * there are.  Used for alignment-level parity tests and to write recovery files (pyani_amd.anim.write_delta). */

@@ -426,6 +426,15 @@ def test_run_anim_writes_recovery_files_and_recovers_from_them(eng, genome_dir, 
         rel = f"blochmannia/{q}_vs_{s}.filter"
         if rel in gold:
             assert list(t) == gold[rel], rel
+    # the files themselves (one batched call + the GPU traceback pass): MUMmer's own .filter files but for their first line (the paths)
+    import gzip
+    same = 0
+    for f in first.written:
+        g = GOLD / "anim" / "blochmannia" / (f.name + ".gz")
+        if g.exists():
+            assert f.read_text().splitlines()[1:] == gzip.open(g, "rt").read().splitlines()[1:], f.name
+            same += 1
+    assert same >= 3
     first.written[2].unlink()
     again = subcmd_anim.run_anim(indir, outdir, recovery=True, engine=eng)
     assert len(again.recovered) == 5 and again.results == first.results and again.comparisons and again.json == first.json
