@@ -205,15 +205,20 @@ int pg_anib_reduce(pg_ctx* ctx, uint32_t n_pairs, const uint64_t* offsets, const
  * `fragsize`-nt fragments of the query genome, anib.py:164-203, searched with blastn -task blastn against the subject
  * genome) followed by parse_blast_tab (anib.py:569-667).  One result per ORDERED pair (qry_ids[i] = the fragmented genome,
  * sbj_ids[i] = the BLAST database genome):  aln_length = sum of (length - gaps), sim_errors = sum of (mismatch + gaps),
- * pid = mean pident over the fragments whose best hit has coverage > 0.7 and identity > 0.3 — the tuple parse_blast_tab
+ * pid = mean pident, each over the FIRST row of every fragment among the rows with coverage > 0.7 and identity > 0.3 (rows in
+ * BLAST's order: best score first; anib.py:640-660 filters, then drops duplicates keeping the first) — the tuple parse_blast_tab
  * returns.  BLAST+ is third-party and absent from the reference tree; the search is a restatement of its documented
- * behaviour for this command line (blastn scoring 2 / -3 / 5 / 2, X-drop 150 bits, e-value 1e-15), calibrated on the BLAST+
- * tables the reference's tests hold (level of agreement per fixture). */
+ * behaviour for this command line (blastn scoring 2 / -3 / 5 / 2, X-drop 150 bits, e-value 1e-15; seeds: exact 16-mers, then
+ * blastn's 11-mer words for fragments those leave without a reportable hit), checked against the BLAST+ tables the reference's
+ * tests hold (level of agreement per fixture).
+ * Limits: fragsize <= 1020 (pyani's default and maximum in practice; larger values are rejected with PG_E_ARG — the fragment's
+ * DP lives in LDS); a query genome of more than 15 872 fragments (16.1 Mb at 1020 nt) cannot be searched: its pairs come back
+ * with status = PG_E_CAPACITY (n_frags set, everything else 0) and the call goes on with the others. */
 typedef struct {
   int64_t aln_length, sim_errors;
   double pid;
   int32_t n_frags, n_kept;   /* fragments of the query genome / fragments that contributed */
-  int32_t status, reserved;  /* 0 = ok, PG_E_CAPACITY = a work buffer overflowed for this pair */
+  int32_t status, reserved;  /* 0 = ok, PG_E_CAPACITY = the query genome has more fragments than a launch can hold (see above) */
 } pg_anib_result;
 int pg_anib_pairs(pg_ctx* ctx, const int32_t* qry_ids, const int32_t* sbj_ids, uint64_t n_pairs, uint32_t fragsize, pg_anib_result* out);
 /* The table of ONE ordered pair, row for row as pyani reads it (anib.py:609-624): at most 4 rows per fragment (2 strands x

@@ -240,10 +240,14 @@ void pg_anim_drop_lists(pg_ctx* ctx) {
 // Build the seed lists the batch needs and does not have yet: reference role for `ref_genomes`, query role for `qry_genomes`.
 static int anim_ensure_lists(pg_ctx* ctx, AnimScratch* A, const std::vector<int32_t>& ref_genomes, const std::vector<int32_t>& qry_genomes,
                              int qstep) {
-  int rc;
   std::lock_guard<std::mutex> lk(ctx->anim_mu);   // one worker builds at a time; a list is complete before anyone else sees it
   AnimLists* LS = anim_lists(ctx);
   if (LS->gidx.size() < ctx->genomes.size()) LS->gidx.resize(ctx->genomes.size());
+  // A list counts as built when its pointer is set, and it outlives this call (shared by the workers): whatever this call
+  // allocated is taken back if anything after the allocation fails, so that no later call seeds from a half-built list.
+  std::vector<std::pair<uint64_t**, uint32_t**>> mine;
+  const int rc_all = [&]() -> int {
+  int rc;
   bool built = false;
   if (!A->list_cnt && (rc = regrow(ctx, A->list_cnt, (size_t)2 * SEED_GROUPS))) return rc;
   std::vector<int32_t> fresh_refs;
@@ -259,6 +263,7 @@ static int anim_ensure_lists(pg_ctx* ctx, AnimScratch* A, const std::vector<int3
       const size_t bound = role ? 2 * ((size_t)len / qstep + 1) : (size_t)len + 1;
       uint64_t*& list = role ? qlist : X.ref_list;
       uint32_t*& goff = role ? qgoff : X.ref_goff;
+      mine.emplace_back(&list, &goff);
       if ((rc = regrow(ctx, list, bound))) return rc;
       if ((rc = regrow(ctx, goff, (size_t)n_sub + 2))) return rc;
       const uint32_t* codes = ctx->d_codes + G.arena_start / 16;
@@ -282,6 +287,15 @@ static int anim_ensure_lists(pg_ctx* ctx, AnimScratch* A, const std::vector<int3
   for (int32_t gid : fresh_refs)
     PG_HIP(ctx, hipMemcpy(&LS->gidx[gid].ref_max, LS->gidx[gid].ref_goff + SEED_GROUPS + 1, 4, hipMemcpyDeviceToHost));
   return PG_OK;
+  }();
+  if (rc_all != PG_OK) {
+    (void)hipStreamSynchronize(cur_stream(ctx));      // nothing of this call may still be writing into them
+    for (auto& pr : mine) {
+      if (*pr.first) { (void)hipFree(*pr.first); *pr.first = nullptr; }
+      if (*pr.second) { (void)hipFree(*pr.second); *pr.second = nullptr; }
+    }
+  }
+  return rc_all;
 }
 
 static void anim_free_one(pg_ctx* ctx, void*& slot);
@@ -673,17 +687,26 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
                                     (int)(SEED_MAX_SLOTS * 8 + SEED_STAGE_BYTES)));
     A->lds_attr_set = true;
   }
-  if (!A->seedbuf) {
-    A->seed_cap = (size_t)max_matches + 1024;   // the whole batch budget (2.4 GB by default): no overflow re-runs
-    if ((rc = regrow(ctx, A->seedbuf, A->seed_cap))) return rc;
+  // The append buffer of the seed pass and the hit buffers hold the batch budget for a large call (no overflow re-runs), but no more
+  // than the call can produce: a pair of genomes cannot have more maximal matches than a quarter of its bases (a one-pair call
+  // — smoke(), pg_anim_pair_alignments — used to reserve 3 x 8 GB for a few MB of matches).  Both grow on overflow (below).
+  size_t call_bound = 0;
+  for (uint32_t p = 0; p < n_pairs && call_bound <= max_matches; ++p)
+    call_bound += (size_t)(ctx->genomes[ref_ids[p]].stream_len + ctx->genomes[qry_ids[p]].stream_len) / 4 + 8192;
+  const size_t budget = call_bound < max_matches ? call_bound : (size_t)max_matches;
+  if (!A->seed_total) {
     if ((rc = regrow(ctx, A->seed_total, 2))) return rc;
     if ((rc = regrow(ctx, A->gap_counts, GAP_CLASSES + 1))) return rc;
   }
+  if (budget + 1024 > A->seed_cap) {
+    A->seed_cap = budget + 1024;
+    if ((rc = regrow(ctx, A->seedbuf, A->seed_cap))) return rc;
+  }
   std::vector<uint32_t> cnt(n_units), moff;
   uint32_t total = 0, pairs_fit = 0;
-  // hit buffer: the matches of the batch budget plus the chance 16-mer hits of unrelated pairs (~1200 per 5 Mb unit)
+  // hit buffer: the matches of the budget plus the chance 16-mer hits of unrelated pairs (~1200 per 5 Mb unit)
   {
-    const size_t want = (size_t)max_matches + (size_t)(frag ? 8 * 4096 : 4096) * n_units + 1024;   // (every position sampled: 5 x the chance hits)
+    const size_t want = budget + (size_t)(frag ? 8 * 4096 : 4096) * n_units + 1024;   // (every position sampled: 5 x the chance hits)
     if (want > A->hit_cap) {
       if ((rc = regrow(ctx, A->hits_d, want))) return rc;
       if ((rc = regrow(ctx, A->hits_sorted, want))) return rc;

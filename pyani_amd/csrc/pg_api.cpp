@@ -5,6 +5,7 @@
 #include <cstring>
 #include <atomic>
 #include <functional>
+#include <new>
 #include <thread>
 
 #include "pg_internal.h"
@@ -695,7 +696,10 @@ static int anim_run_chunks(pg_ctx* ctx, const std::vector<std::pair<uint64_t, ui
     (void)hipSetDevice(ctx->device);
     pg_anim_set_worker(ctx, w);
     for (size_t c; (c = next++) < chunks.size() && first_rc.load() == PG_OK;) {
-      const int rc = run(chunks[c].first, chunks[c].second, w);
+      int rc;
+      try { rc = run(chunks[c].first, chunks[c].second, w); }      // (a worker thread must not let an exception escape: std::terminate)
+      catch (const std::bad_alloc&) { rc = pg_fail(ctx, PG_E_NOMEM, "out of host memory in an ANIm worker"); }
+      catch (const std::exception& e) { rc = pg_fail(ctx, PG_E_HIP, std::string("ANIm worker: ") + e.what()); }
       int expect = PG_OK;
       if (rc != PG_OK) first_rc.compare_exchange_strong(expect, rc);
     }
@@ -963,9 +967,28 @@ int pg_anib_pairs(pg_ctx* ctx, const int32_t* qry_ids, const int32_t* sbj_ids, u
       return pg_fail(ctx, PG_E_ARG, "genome id out of range");
   int rc;
   if ((rc = pg_upload(ctx))) return rc;
+  // A query genome with more fragments than a launch's per-genome counters hold (15 872: 16.1 Mb at 1020 nt) cannot be searched:
+  // its pairs get status = PG_E_CAPACITY, the others are computed (the call does not fail for them).
+  std::vector<uint64_t> order;
+  order.reserve(n_pairs);
+  {
+    std::vector<int64_t> nfrag(ctx->genomes.size(), -1);
+    for (uint64_t i = 0; i < n_pairs; ++i) {
+      int64_t& nf = nfrag[(size_t)qry_ids[i]];
+      if (nf < 0) {
+        const PgGenome& Q = ctx->genomes[(size_t)qry_ids[i]];
+        nf = 0;
+        for (uint32_t r = 0; r < Q.n_rec; ++r) nf += ((int64_t)(Q.rec_start[r + 1] - 1 - Q.rec_start[r]) + fragsize - 1) / fragsize;
+      }
+      if (nf > (int64_t)PG_FRAG_MAX_FRAGS) {
+        out[i] = pg_anib_result{};
+        out[i].n_frags = (int32_t)nf;
+        out[i].status = PG_E_CAPACITY;
+      } else order.push_back(i);
+    }
+  }
+  n_pairs = order.size();      // (pairs are addressed through order[] from here on)
   // grouped by subject genome (the LDS-table role of the seeding stage), then in chunks the launch budgets allow
-  std::vector<uint64_t> order(n_pairs);
-  for (uint64_t i = 0; i < n_pairs; ++i) order[i] = i;
   std::stable_sort(order.begin(), order.end(), [&](uint64_t a, uint64_t b) { return sbj_ids[a] < sbj_ids[b]; });
   const int W = n_pairs >= 64 ? ctx->anim_workers : 1;
   const uint32_t MAX_PAIRS = ctx->anim_batch_pairs / W, MAX_REFS = 256;

@@ -144,6 +144,7 @@ void pg_anim_free_scratch(pg_ctx* ctx);
 int pg_anim_fetch_alignments(pg_ctx* ctx, int32_t ref_id, int32_t qry_id, uint32_t n, pg_anim_alignment* out);   // after a 1-pair batch
 // Where pg_anim_run_batch leaves the alignment records of its pairs when the calling thread has set one (pg_anim_alignments_batch):
 // appended pair after pair in the order of the call's arrays; with_indels adds the traceback pass and every alignment's .delta list.
+constexpr uint32_t PG_FRAG_MAX_FRAGS = 15872;      // fragments per query genome in fragment mode (pga_frag.inc: LDS counters)
 struct PgAlnSink {
   bool with_indels = false;
   std::vector<pg_anim_alignment> alns;

@@ -84,6 +84,13 @@ def test_edge_inputs(eng):
     aln, err, pid, kept = anib_cpu.reduce_rows(want)       # (a record's last few bases make a fragment too short for any hit)
     assert (int(half["aln_length"]), int(half["sim_errors"]), int(half["n_kept"])) == (aln, 0, len(kept)) and total - 40 < aln <= total
     assert int(half["n_frags"]) > int(me["n_frags"])
+    # a query genome with more fragments than a launch can hold (15 872): ITS pairs report PG_E_CAPACITY, the others are computed
+    big = synth.genome(6, 4, 1, 500_000)
+    b = eng.add_genome(*big)
+    mixed = eng.anib_pairs([b, a, b], [a, a, b], fragsize=30)
+    assert [int(r["status"]) for r in mixed] == [-9, 0, -9] and int(mixed[0]["n_frags"]) > 15872 and int(mixed[0]["n_kept"]) == 0
+    again = eng.anib_pairs([a], [a], fragsize=30)[0]
+    assert tuple(mixed[1]) == tuple(again) and int(again["n_frags"]) >= 2000
 
 
 @pytest.fixture(scope="module")
