@@ -609,7 +609,7 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
     A->slice_pairs = n_pairs;
   }
   const uint32_t slice_stride = n_pairs;   // the table is laid out for the whole batch even if only a prefix is seeded again
-  const bool use_mirror = !frag && !getenv("PYANI_ANIM_NO_MIRROR");
+  const bool use_mirror = !frag && !pg_dev_env("PYANI_ANIM_NO_MIRROR");
   auto prepare = [&](uint32_t limit) -> int {   // roles, seed lists and descriptors for the pairs [0, limit)
     std::fill(mirror.begin(), mirror.end(), -1);
     std::fill(seeded.begin(), seeded.end(), (uint8_t)0);
@@ -658,8 +658,8 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
     for (int32_t g : seed_refs) if (LSv[g].ref_max > max_group) max_group = LSv[g].ref_max;
     slots = 256;
     while (slots < 2 * max_group) slots <<= 1;
-    if (getenv("PYANI_SEED_SLOTS_MIN")) {   // development: a larger LDS table (lower load, shorter probe sequences, fewer workgroups per CU)
-      const uint32_t want = (uint32_t)atoi(getenv("PYANI_SEED_SLOTS_MIN"));
+    if (pg_dev_env("PYANI_SEED_SLOTS_MIN")) {   // development: a larger LDS table (lower load, shorter probe sequences, fewer workgroups per CU)
+      const uint32_t want = (uint32_t)atoi(pg_dev_env("PYANI_SEED_SLOTS_MIN"));
       while (slots < want && slots < SEED_MAX_SLOTS) slots <<= 1;
     }
     if (slots > SEED_MAX_SLOTS)
@@ -807,12 +807,12 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
   }
   // Units with >= split_min matches ("big": pairs of related genomes) get their chains from many waves (pga_cluster.inc,
   // anim_chain_range_kernel); every other unit is finished by the one wave that filters and clusters it.
-  const int split_min = getenv("PYANI_ANIM_SPLIT_MIN") ? atoi(getenv("PYANI_ANIM_SPLIT_MIN")) : 2048;   // (<= 0: never split)
-  const int range_entries = getenv("PYANI_ANIM_RANGE_ENTRIES") && atoi(getenv("PYANI_ANIM_RANGE_ENTRIES")) > 0
-                                ? atoi(getenv("PYANI_ANIM_RANGE_ENTRIES")) : CHAIN_RANGE_ENTRIES;
+  const int split_min = pg_dev_env("PYANI_ANIM_SPLIT_MIN") ? atoi(pg_dev_env("PYANI_ANIM_SPLIT_MIN")) : 2048;   // (<= 0: never split)
+  const int range_entries = pg_dev_env("PYANI_ANIM_RANGE_ENTRIES") && atoi(pg_dev_env("PYANI_ANIM_RANGE_ENTRIES")) > 0
+                                ? atoi(pg_dev_env("PYANI_ANIM_RANGE_ENTRIES")) : CHAIN_RANGE_ENTRIES;
   std::vector<BigUnit> big;
   std::vector<uint2> ranges;
-  if (split_min > 0 && !getenv("PYANI_ANIM_SCALAR_CLUSTER"))
+  if (split_min > 0 && !pg_dev_env("PYANI_ANIM_SCALAR_CLUSTER"))
     for (uint32_t u = 0; u < n_units; ++u)
       if (cnt[u] >= (uint32_t)split_min) {
         uint32_t R = cnt[u] / (uint32_t)range_entries;
@@ -833,14 +833,14 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
   }
   const int split_arg = big.empty() ? 0x7fffffff : split_min;
   pg_prof_begin(ctx, PG_K_ANIM_CLUSTER);
-  if (getenv("PYANI_ANIM_SCALAR_CLUSTER") && !maxmatch)   // debugging aid: the one-thread-per-unit statement of the same algorithm
+  if (pg_dev_env("PYANI_ANIM_SCALAR_CLUSTER") && !maxmatch)   // debugging aid: the one-thread-per-unit statement of the same algorithm
     hipLaunchKernelGGL(anim_cluster_kernel, dim3((n_units + 63) / 64), dim3(64), 0, cur_stream(ctx), A->refs_d, A->units_d, n_units,
                        A->mem, A->mem_count, A->iscratch, O);
   else {
     // the front half (MUM filter, union-find, grouping) of a big unit is shared by the PREP_WAVES waves of one workgroup: a
     // single wave needs ~10 ms for the sorts of 50 000 matches, and the launch would wait for the slowest of them (measured
     // on C4, cluster stage per grid: one wave per big unit 1.95 s, workgroup 0.51 s; PYANI_ANIM_WAVE_PREP=1 forces the former)
-    const bool prep = !big.empty() && !getenv("PYANI_ANIM_WAVE_PREP");
+    const bool prep = !big.empty() && !pg_dev_env("PYANI_ANIM_WAVE_PREP");
     if (prep)
       hipLaunchKernelGGL(anim_cluster_prep_kernel, dim3((uint32_t)big.size()), dim3(PREP_THREADS), 0, cur_stream(ctx), A->refs_d, A->units_d,
                          A->mem, A->mem_count, A->iscratch, O, maxmatch, A->big_d);
@@ -934,7 +934,7 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
       hipLaunchKernelGGL(anim_postnuc_forced_kernel, dim3(pn_waves), dim3(64), 0, cur_stream(ctx), A->refs_d, A->units_d, A->pn_reqs,
                          A->pn_cursor + 1, (uint32_t)req_cap, A->pn_cursor + 2, A->pn_n, A->pn_gscratch);
     pg_prof_end(ctx);
-    if (getenv("PYANI_PN_STATS")) {   // development: what the engines did in this launch
+    if (pg_dev_env("PYANI_PN_STATS")) {   // development: what the engines did in this launch
       PG_HIP(ctx, hipStreamSynchronize(cur_stream(ctx)));
       unsigned long long st[32], zero[32] = {0};
       PG_HIP(ctx, hipMemcpyFromSymbol(st, HIP_SYMBOL(g_pn_stats), sizeof(st)));
@@ -985,10 +985,10 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
     PG_HIP(ctx, hipStreamSynchronize(cur_stream(ctx)));
     const size_t n_big = gap_counts[GAP_CLASSES], n_ext = n_wl > n_big ? n_wl : n_big;
     // development / test knobs of the hand-over rule (results do not depend on them: tests/test_anim_gpu.py)
-    const int tail_lanes = getenv("PYANI_EXT_TAIL_LANES") ? atoi(getenv("PYANI_EXT_TAIL_LANES")) : EXT_TAIL_LANES;
-    const int tail_blocks = getenv("PYANI_EXT_TAIL_BLOCKS") ? atoi(getenv("PYANI_EXT_TAIL_BLOCKS")) : EXT_TAIL_BLOCKS;
+    const int tail_lanes = pg_dev_env("PYANI_EXT_TAIL_LANES") ? atoi(pg_dev_env("PYANI_EXT_TAIL_LANES")) : EXT_TAIL_LANES;
+    const int tail_blocks = pg_dev_env("PYANI_EXT_TAIL_BLOCKS") ? atoi(pg_dev_env("PYANI_EXT_TAIL_BLOCKS")) : EXT_TAIL_BLOCKS;
     uint32_t dump_cap = EXT_DUMP_CAP;
-    if (getenv("PYANI_EXT_DUMP_CAP") && (uint32_t)atoi(getenv("PYANI_EXT_DUMP_CAP")) < dump_cap) dump_cap = (uint32_t)atoi(getenv("PYANI_EXT_DUMP_CAP"));
+    if (pg_dev_env("PYANI_EXT_DUMP_CAP") && (uint32_t)atoi(pg_dev_env("PYANI_EXT_DUMP_CAP")) < dump_cap) dump_cap = (uint32_t)atoi(pg_dev_env("PYANI_EXT_DUMP_CAP"));
     if (!A->ext_dumps && (rc = regrow(ctx, A->ext_dumps, EXT_DUMP_CAP))) return rc;
     if (!A->ext_counts && (rc = regrow(ctx, A->ext_counts, 8))) return rc;
     if (n_ext > A->ext_cap) {
@@ -999,7 +999,7 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
       A->ext_cap = cap;
     }
     // persistent lane-DP waves per CU: 4 = one per SIMD (the kernel holds its band in 256 VGPRs: two fit a SIMD)
-    const uint32_t ext_waves_per_cu = getenv("PYANI_EXT_WAVES_PER_CU") ? (uint32_t)atoi(getenv("PYANI_EXT_WAVES_PER_CU")) : 4u;
+    const uint32_t ext_waves_per_cu = pg_dev_env("PYANI_EXT_WAVES_PER_CU") ? (uint32_t)atoi(pg_dev_env("PYANI_EXT_WAVES_PER_CU")) : 4u;
     if (n_big) {
       PG_HIP(ctx, hipMemsetAsync(A->ext_counts, 0, 20, cur_stream(ctx)));   // [0], [1] list lengths, [2] hand-out cursor, [4] handed over
       pg_prof_begin(ctx, PG_K_ANIM_EXTEND);

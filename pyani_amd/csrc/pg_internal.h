@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <array>
 #include <cstdint>
+#include <cstdlib>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -144,6 +145,13 @@ void pg_anim_free_scratch(pg_ctx* ctx);
 int pg_anim_fetch_alignments(pg_ctx* ctx, int32_t ref_id, int32_t qry_id, uint32_t n, pg_anim_alignment* out);   // after a 1-pair batch
 // Where pg_anim_run_batch leaves the alignment records of its pairs when the calling thread has set one (pg_anim_alignments_batch):
 // appended pair after pair in the order of the call's arrays; with_indels adds the traceback pass and every alignment's .delta list.
+// Development knobs (launch shapes, alternative code paths that must give the same results, counters): environment variables
+// honoured ONLY under PYANI_DEV_KNOBS=1 — the test suite sets it — so that a stray variable in a production environment cannot
+// change what the library launches.
+inline const char* pg_dev_env(const char* name) {
+  const char* on = getenv("PYANI_DEV_KNOBS");
+  return on && on[0] == '1' ? getenv(name) : nullptr;
+}
 constexpr uint32_t PG_FRAG_MAX_FRAGS = 15872;      // fragments per query genome in fragment mode (pga_frag.inc: LDS counters)
 struct PgAlnSink {
   bool with_indels = false;

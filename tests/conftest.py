@@ -15,6 +15,10 @@ GOLD = ROOT / "tests" / "golden"
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the library's development knobs (PYANI_ANIM_*, PYANI_EXT_*: alternative launch shapes that must give the same results) are
+    # honoured only under this switch (pg_internal.h, pg_dev_env); the tests that use them run in this process and its children
+    import os
+    os.environ.setdefault("PYANI_DEV_KNOBS", "1")
 
 
 @pytest.fixture(scope="session")

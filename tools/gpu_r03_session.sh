@@ -6,6 +6,7 @@
 #   bench   the driver's command
 #   prof    rocprofv3 kernel trace + FETCH_SIZE / WRITE_SIZE passes of the bench command (short)
 R=$(pwd); O=$R/gpurun_out/r03; mkdir -p $O; export TMPDIR=/tmp
+export PYANI_DEV_KNOBS=1      # the library honours its development variables (PYANI_PN_STATS, PYANI_ANIM_WORKERS) only under this switch
 for w in "$@"; do
 case $w in
 exact)
