@@ -10,14 +10,15 @@ C2 TETRA roofline nested as a sub-record.
 
 ANIm (default).  All genomes are resident in HBM on every GPU (2-bit codes + 1-bit mask; 1.9 GB at C4).  A STEP is one
 pass of the whole pipeline — seed, cluster, extend, 1-to-1 filter, parse_delta reduction, results back on the host — over
-the ordered-pair grid: by default ALL of it, 999 000 ordered pairs per step (`--rows-per-step R` cuts it into tiles: the
-UNORDERED pairs owned by R genomes, each in both directions — pyani_amd.parallel.anim_pair_array(symmetric=True): {g, h}
+a TILE of the ordered-pair grid: the UNORDERED pairs owned by R genomes (default: a tenth of the genomes per GPU = ~99 900
+ordered pairs at C4; `--rows-per-step R`), each in both directions — pyani_amd.parallel.anim_pair_array(symmetric=True): {g, h}
 belongs to the smaller id if g + h is even, else to the larger; step k then takes genomes [k*R, (k+1)*R) modulo N).  A pair
 and its reverse sit in the same call because they have the same maximal exact matches and the engine seeds them once
-(pg_anim.hip "roles").  `value` = ordered pairs processed in the K timed steps / wall time.  N > 1 is STRONG scaling of that
-same job: the rows of every step are dealt over the ranks (pyani_amd.parallel.anim_row_shard), each rank runs the pairs its
-rows own (whole-grid steps keep every rank's launches full-size at 8 GPUs), ONE RCCL all-gather per step (64 B per pair) puts
-the step's results on every rank.  No other collective, no sequence traffic.
+(pg_anim.hip "roles").  `value` = ordered pairs processed in the K timed steps / wall time.  N > 1: the rows of every step
+are dealt over the ranks (pyani_amd.parallel.anim_row_shard), each rank runs the pairs its rows own, ONE RCCL all-gather per step
+(64 B per pair) puts the step's results on every rank.  No other collective, no sequence traffic.  By default a step has
+genomes / 10 rows PER GPU (weak scaling: every rank's launches keep their N = 1 size); with --rows-per-step R it has R rows
+whatever N is (strong scaling of that step).
 
   --workload tetra : the TETRA side alone (C2: 200 genomes, counts + Z + Pearson; N > 1 = weak scaling, 200 genomes per GPU).
   --workload anib  : C5 (BASELINE.json configs[4]): 500 genomes of 1-12 Mb, pyani's ANIb on the engine's fragment mode
@@ -56,7 +57,7 @@ def parse_args():
     ap.add_argument("--genomes", type=int, default=None, help="anim: genomes of the job (C4: 1000); tetra: genomes per GPU (C2: 200)")
     ap.add_argument("--length", type=int, default=5_000_000, help="ancestor length in bases (5 Mb)")
     ap.add_argument("--seed", type=int, default=None, help="default: the set's own seed (C4 20250301, C2 20250228)")
-    ap.add_argument("--rows-per-step", type=int, default=None, help="genomes (grid rows) per step: default genomes / 10 (anim: ten steps = the whole grid) / 10 (anib)")
+    ap.add_argument("--rows-per-step", type=int, default=None, help="genomes (grid rows) per step: default genomes / 10 per GPU (anim: ten steps = the whole grid at N = 1) / 10 (anib)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=0, help="anim: ordered pairs timed by the CPU leg (0 = one per host thread, <= 128)")
     ap.add_argument("--cpu-genomes", type=int, default=2, help="tetra: genomes timed by the CPU leg")
@@ -71,10 +72,15 @@ def parse_args():
         args.genomes = {"anim": 1000, "tetra": 200, "anib": 500}[w]
     if args.seed is None:
         args.seed = {"anim": 20250301, "tetra": 20250228, "anib": 20250302}[w]
+    args.rows_default = args.rows_per_step is None
     if args.rows_per_step is None:
-        # anim: a tenth of the grid per step (the exact extension stage makes a whole C4 grid a ~1 min step; the driver's 25 steps
-        # must finish in minutes) — ~100 000 ordered pairs per step at C4, far above the size where launches stop filling the GPU
-        args.rows_per_step = 10 if w == "anib" else max(1, args.genomes // 10)
+        # anim: a tenth of the grid PER GPU per step (the exact extension stage makes a whole C4 grid a ~1 min step; the driver's 25
+        # steps must finish in minutes) — ~100 000 ordered pairs per GPU and step at C4, where launches still fill the GPU and a
+        # launch's sequential tail (its longest unit walk, ~2.4 s) stays a fraction of it.  Per-GPU work is fixed as N grows: the
+        # default series is WEAK scaling (8 GPUs: 800 rows per step, 10 steps = 8 grids); an explicit --rows-per-step R keeps R rows
+        # per step whatever N is (strong scaling of that step).
+        world = int(os.environ.get("WORLD_SIZE", "1")) if args.gpus > 1 else 1
+        args.rows_per_step = 10 if w == "anib" else max(1, min(args.genomes, (args.genomes // 10) * max(1, world)))
     return args
 
 
@@ -356,7 +362,7 @@ def run_anim(args, rank, world, local, dist, torch):
             "metric": "genome-pairs/sec (ordered pairs) + wall-clock for the N x N ANIm grid: nucmer --mum + delta-filter -1 + "
                       "parse_delta equivalent per ordered pair, genomes resident in HBM; vs the CPU path on this box's host cores",
             "value": pairs_done / elapsed, "unit": "genome-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": step_s * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "ms_per_step": step_s * 1e3, "higher_is_better": True, "scaling": "weak" if args.rows_default else "strong", "vs_baseline": None,
             "dtype": "u32 packed DP words (score << 17 | state << 15 | errors), i64 lengths, f64 identity", "data": "synthetic",
             "related_pairs_per_s": n_related / elapsed,
             "config": {
