@@ -148,7 +148,7 @@ def anim_cpu_baseline(args, data, n, related, gpu_lookup):
     return {
         "value": (n_rel_job + n_unrel_job) / job_wall, "unit": "genome-pairs/s", "cores": threads, "kind": "port",
         "variant": "own-cpu (oracle/anim_cpu.cpp: host build of the engine's scalar statement of MUMmer's algorithm — exhaustive 20-mer "
-                   "table, mgaps clustering, postnuc extension with its dynamic band — -O2, one pair per thread; NOT MUMmer's binary, whose "
+                   "table, mgaps clustering, postnuc extension with its dynamic band — g++ -O3 -mavx2, one pair per thread; NOT MUMmer's binary, whose "
                    "suffix-tree matcher and full-rectangle re-alignments cost more per pair)",
         "cpu_s_per_related_pair": t_rel, "cpu_s_per_unrelated_pair": t_unrel,
         "sample": note + f"{len(sample)} ordered pairs of the same job ({len(rel)} related, {len(unrel)} unrelated) run one per host "
