@@ -575,96 +575,107 @@ PG_HD int postnuc_unit(ENG& eng, const Chain* chains, const Match* cm, const int
                        PnAln* al, int max_al) {
   for (int k = 0; k < n; ++k) fused[k] = 0;
   int n_al = 0, cura = -1;
+  // The current alignment lives in A (registers) and is written to al[cura] only when something is about to read al[] or the
+  // walk moves on to another alignment: with every field update a read-modify-write of global memory, a unit of 50 000 matches
+  // spent ~50 us per match waiting on its own stores (the longest unit of a launch took 2.4 s with all its DP work done ahead).
+  PnAln A{0, 0, 0, 0, 0, 0};
   bool target_reached = false, full = false;
   int prev = 0, curk = 0, targetk = -1;
   int32_t targetA = 0, targetB = 0;
   while (curk < n) {
     const int c = order[curk];
-    const Chain& C = chains[c];
+    const Chain C = chains[c];
     const Match* mm = cm + C.first;
-    const Match& mf = mm[0];
-    const Match& ml = mm[C.count - 1];
+    const Match mf = mm[0];
+    const Match ml = mm[C.count - 1];
     int32_t r_lo, r_hi, q_lo, q_hi;
     bounds(c, r_lo, r_hi, q_lo, q_hi);
     if (!target_reached) {
       eng.piece(PIECE_VISIT, -1, mf.r, mf.q, 0, 0, 0, 0, 0u);
       bool skip = fused[curk] != 0;
-      if (!skip)     // isShadowedCluster: inside an alignment of the same records made so far (from the current one backwards)
+      if (!skip) {   // isShadowedCluster: inside an alignment of the same records made so far (from the current one backwards)
+        if (cura >= 0) al[cura] = A;
         skip = eng.shadowed(chains, al, cura, c, mf.r, ml.r + ml.len - 1, mf.q, ml.q + ml.len - 1);
+      }
       if (skip) { fused[curk] = 1; curk = ++prev; continue; }
     }
     for (int m = 0; m < C.count; ++m) {
-      const Match& Mp = mm[m];
+      const Match Mp = mm[m];
       if (target_reached) {
-        if (al[cura].eA != Mp.r || al[cura].eB != Mp.q) continue;     // matches of the target cluster before the target match
-        al[cura].eA += Mp.len - 1; al[cura].eB += Mp.len - 1;
+        if (A.eA != Mp.r || A.eB != Mp.q) continue;     // matches of the target cluster before the target match
+        A.eA += Mp.len - 1; A.eB += Mp.len - 1;
         eng.piece(PIECE_MATCH, cura, Mp.r, Mp.q, Mp.r + Mp.len - 1, Mp.q + Mp.len - 1, 0, 0, 0u);
       } else {
         if (n_al >= max_al) { full = true; break; }
-        al[n_al] = PnAln{Mp.r, Mp.q, Mp.r + Mp.len - 1, Mp.q + Mp.len - 1, 0, c};
+        if (cura >= 0) al[cura] = A;      // (the one the walk leaves; the scan below reads the alignments made so far)
+        A = PnAln{Mp.r, Mp.q, Mp.r + Mp.len - 1, Mp.q + Mp.len - 1, 0, c};
         cura = n_al++;
         // getReverseTargetAlignment: the latest earlier alignment that ends at or before this start in both sequences and is
         // close enough; failing that, the one at the smallest distance if that beats the distance to the sequence starts
-        const int32_t d0 = (al[cura].sA - r_lo + 1) < (al[cura].sB - q_lo + 1) ? (al[cura].sA - r_lo + 1) : (al[cura].sB - q_lo + 1);
-        const int tgt = eng.reverse_target(chains, al, cura, c, al[cura].sA, al[cura].sB, d0);
+        const int32_t d0 = (A.sA - r_lo + 1) < (A.sB - q_lo + 1) ? (A.sA - r_lo + 1) : (A.sB - q_lo + 1);
+        const int tgt = eng.reverse_target(chains, al, cura, c, A.sA, A.sB, d0);
         // extendBackward: search back towards the target's end; reached = merge (the gap is re-aligned forwards, forced)
         {
           unsigned m_o = BACKWARD_SEARCH;
           int32_t tA, tB;
           bool overflow = false;
-          if (tgt >= 0) { tA = al[tgt].eA; tB = al[tgt].eB; } else { tA = r_lo; tB = q_lo; m_o |= OPTIMAL_BIT; }
-          if (al[cura].sA - tA + 1 > MAX_ALIGNMENT_LENGTH) { tA = al[cura].sA - MAX_ALIGNMENT_LENGTH + 1; overflow = true; m_o |= OPTIMAL_BIT; }
-          if (al[cura].sB - tB + 1 > MAX_ALIGNMENT_LENGTH) { tB = al[cura].sB - MAX_ALIGNMENT_LENGTH + 1; if (!overflow) m_o |= OPTIMAL_BIT; overflow = true; }
+          PnAln T{0, 0, 0, 0, 0, 0};
+          if (tgt >= 0) { T = al[tgt]; tA = T.eA; tB = T.eB; } else { tA = r_lo; tB = q_lo; m_o |= OPTIMAL_BIT; }
+          if (A.sA - tA + 1 > MAX_ALIGNMENT_LENGTH) { tA = A.sA - MAX_ALIGNMENT_LENGTH + 1; overflow = true; m_o |= OPTIMAL_BIT; }
+          if (A.sB - tB + 1 > MAX_ALIGNMENT_LENGTH) { tB = A.sB - MAX_ALIGNMENT_LENGTH + 1; if (!overflow) m_o |= OPTIMAL_BIT; overflow = true; }
           int32_t err = 0;
-          bool reached = eng.align(al[cura].sA, tA, al[cura].sB, tB, m_o | SEARCH_BIT, err);
+          bool reached = eng.align(A.sA, tA, A.sB, tB, m_o | SEARCH_BIT, err);
           if (overflow || tgt < 0) reached = false;
           if (reached) {
             // forced re-alignments only contribute their error count (the corner is reached by definition): the engine may
-            // return it now (scalar engines) or add it to the alignment later (the GPU defers them to a kernel of their own)
-            al[tgt].errors += eng.forced_errors(al[tgt].eA, al[cura].sA, al[tgt].eB, al[cura].sB, al + tgt);
-            eng.piece(PIECE_FORCED, tgt, al[tgt].eA, al[tgt].eB, al[cura].sA, al[cura].sB, 0, 0, FORCED_FORWARD_ALIGN);
-            al[tgt].eA = al[cura].eA; al[tgt].eB = al[cura].eB;
+            // return it now (scalar engines) or add it to the alignment later (the GPU defers them to a kernel of their own,
+            // which runs after this walk has written al[tgt] for the last time)
+            T.errors += eng.forced_errors(T.eA, A.sA, T.eB, A.sB, al + tgt);
+            eng.piece(PIECE_FORCED, tgt, T.eA, T.eB, A.sA, A.sB, 0, 0, FORCED_FORWARD_ALIGN);
+            T.eA = A.eA; T.eB = A.eB;
             --n_al;
             cura = tgt;
+            A = T;
           } else {
-            if (tA != al[cura].sA || tB != al[cura].sB) {
-              al[cura].errors += eng.forced_errors(tA, al[cura].sA, tB, al[cura].sB, al + cura);
-              eng.piece(PIECE_FORCED, cura, tA, tB, al[cura].sA, al[cura].sB, 0, 0, FORCED_FORWARD_ALIGN);
+            if (tA != A.sA || tB != A.sB) {
+              A.errors += eng.forced_errors(tA, A.sA, tB, A.sB, al + cura);
+              eng.piece(PIECE_FORCED, cura, tA, tB, A.sA, A.sB, 0, 0, FORCED_FORWARD_ALIGN);
             }
-            al[cura].sA = tA; al[cura].sB = tB;
+            A.sA = tA; A.sB = tB;
           }
         }
         eng.piece(PIECE_MATCH, cura, Mp.r, Mp.q, Mp.r + Mp.len - 1, Mp.q + Mp.len - 1, 0, 0, 0u);
       }
       // extendForward: to the next match of the cluster, or from its last match towards the target cluster
       if (m + 1 < C.count) {
-        targetA = mm[m + 1].r; targetB = mm[m + 1].q;
         // match to match inside a cluster: the call depends on the two matches only (the alignment ends on this match's last
         // base), so an engine may have it ready (the GPU runs all of them in a pass of their own before the units)
         PnGap g;
         if (eng.gap_ready(C.first + m, g)) {
-          al[cura].errors += g.errors; al[cura].eA = g.eA; al[cura].eB = g.eB;
+          A.errors += g.errors; A.eA = g.eA; A.eB = g.eB;
           target_reached = g.reached != 0;
           continue;
         }
+        const Match Mn = mm[m + 1];
+        targetA = Mn.r; targetB = Mn.q;
         bool overflow = false;
         unsigned m_o = FORWARD_ALIGN;
-        if (targetA - al[cura].eA + 1 > MAX_ALIGNMENT_LENGTH) { targetA = al[cura].eA + MAX_ALIGNMENT_LENGTH - 1; overflow = true; m_o |= OPTIMAL_BIT; }
-        if (targetB - al[cura].eB + 1 > MAX_ALIGNMENT_LENGTH) { targetB = al[cura].eB + MAX_ALIGNMENT_LENGTH - 1; if (!overflow) m_o |= OPTIMAL_BIT; overflow = true; }
+        if (targetA - A.eA + 1 > MAX_ALIGNMENT_LENGTH) { targetA = A.eA + MAX_ALIGNMENT_LENGTH - 1; overflow = true; m_o |= OPTIMAL_BIT; }
+        if (targetB - A.eB + 1 > MAX_ALIGNMENT_LENGTH) { targetB = A.eB + MAX_ALIGNMENT_LENGTH - 1; if (!overflow) m_o |= OPTIMAL_BIT; overflow = true; }
         int32_t err = 0;
         const int32_t tA = targetA, tB = targetB;
-        bool reached = eng.align(al[cura].eA, targetA, al[cura].eB, targetB, m_o, err);
-        eng.piece(PIECE_SEARCH, cura, al[cura].eA, al[cura].eB, targetA, targetB, tA, tB, m_o);
+        bool reached = eng.align(A.eA, targetA, A.eB, targetB, m_o, err);
+        eng.piece(PIECE_SEARCH, cura, A.eA, A.eB, targetA, targetB, tA, tB, m_o);
         if (reached && overflow) reached = false;
-        al[cura].errors += err;
-        al[cura].eA = targetA; al[cura].eB = targetB;
+        A.errors += err;
+        A.eA = targetA; A.eB = targetB;
         target_reached = reached;
       } else {
         // off the last match (the alignment ends on its last base here, however the walk entered the cluster): PnFwd
         PnFwd f;
         if (!eng.fwd_ready(curk, f)) f = postnuc_forward(eng, chains, cm, order, n, curk, bounds, cura);
         targetk = f.targetk;
-        al[cura].errors += f.errors; al[cura].eA = f.eA; al[cura].eB = f.eB;
+        A.errors += f.errors; A.eA = f.eA; A.eB = f.eB;
         target_reached = f.reached != 0;
       }
     }
@@ -673,6 +684,7 @@ PG_HD int postnuc_unit(ENG& eng, const Chain* chains, const Match* cm, const int
     fused[curk] = 1;
     if (!target_reached) curk = ++prev; else curk = targetk;
   }
+  if (cura >= 0) al[cura] = A;
   return full ? -1 - n_al : n_al;
 }
 
