@@ -155,6 +155,32 @@ def test_write_delta_round_trip_and_grammar(tmp_path):
     assert len(anim_oracle.read_delta(out2)[0]) == 3
 
 
+def test_write_delta_with_indel_lists_reproduces_mummer_files(tmp_path, genome_dir):
+    """anim.write_delta(indels=...): fed with the records and indel lists of MUMmer's own files (read back by the oracle's parser),
+    it writes those files again line for line — .delta and .filter, single- and multi-record genomes (what the GPU test
+    tests/test_anim_delta_gpu.py then checks is only where the records and lists come from)."""
+    import gzip
+    import numpy as np
+    from pyani_amd import anim
+    from pyani_amd.engine import Engine
+    cases = [("blochmannia", "GCF_000011745.1_ASM1174v1_genomic_vs_GCF_000043285.1_ASM4328v1_genomic", "delta"),
+             ("blochmannia", "GCF_000011745.1_ASM1174v1_genomic_vs_GCF_000043285.1_ASM4328v1_genomic", "filter"),
+             ("caulobacter", "NC_011916_vs_NC_002696", "delta")]
+    for grp, name, ext in cases:
+        gold = GOLD / "anim" / grp / f"{name}.{ext}.gz"
+        a, b = name.split("_vs_")
+        fa, fb = genome_dir[grp][a], genome_dir[grp][b]
+        ra = {rid: k for k, (rid, _) in enumerate(anim.fasta_records(fa))}
+        rb = {rid: k for k, (rid, _) in enumerate(anim.fasta_records(fb))}
+        recs = anim_oracle.read_delta(gold)[0]
+        al = np.zeros(len(recs), dtype=Engine.ALN_DTYPE)
+        for k, x in enumerate(recs):
+            al[k] = (ra[x.ref_id], rb[x.qry_id], x.rs, x.re, x.qs, x.qe, x.errors, 3)
+        out = tmp_path / f"{name}.{ext}"
+        assert anim.write_delta(out, fa, fb, al, filtered=(ext == "filter"), indels=[list(x.indels) for x in recs]) == len(recs)
+        assert out.read_text().splitlines()[1:] == gzip.open(gold, "rt").read().splitlines()[1:], (grp, name, ext)
+
+
 class OracleEngine:
     """Engine.anim_reduce restated with the oracle's parse_delta arithmetic (CPU stand-in for the host-logic tests; the GPU
     reduction itself is compared bit for bit in tests/test_anim_gpu.py)."""
