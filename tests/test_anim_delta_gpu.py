@@ -114,3 +114,49 @@ def test_batch_records_equal_the_per_pair_call(genome_dir):
             got = recs[int(off[k]):int(off[k + 1])]
             assert [tuple(x) for x in got] == [tuple(x) for x in one]
             assert sorted(tuple(x) for x in recs2[int(off2[k]):int(off2[k + 1])]) == sorted(tuple(x) for x in one)
+
+
+def test_maxmatch_and_mum_lists_on_repeat_genomes_equal_the_nucmer_oracle(tmp_path):
+    """Genomes WITH repeats (tests/test_anim_gpu.py::_with_repeats), --mum and --maxmatch: the records AND indel lists of the batched
+    call with the traceback pass equal those of oracle/nucmer_oracle.cpp (the restatement of MUMmer's pipeline that reproduces
+    every fixture file) run on the same FASTA files — the check behind run_anim(write_output=True, maxmatch=True)."""
+    import subprocess
+    from pyani_amd import anim, synth
+    from pyani_amd.engine import Engine
+    from tests.conftest import ROOT
+    from tests.test_anim_gpu import _with_repeats
+    oracle = ROOT / "oracle" / "_build" / "nucmer_oracle"
+    if not oracle.exists():
+        oracle.parent.mkdir(exist_ok=True)
+        subprocess.run(["g++", "-O2", "-std=c++17", str(ROOT / "oracle" / "nucmer_oracle.cpp"), "-o", str(oracle)], check=True)
+    n, L = 4, 300_000
+    files = []
+    for g in (0, 1):
+        seq, off = _with_repeats(*synth.genome(31, n, g, L), g)
+        f = tmp_path / f"rep{g}.fna"
+        synth.write_fasta(f, seq, off, f"rep{g}")
+        files.append(f)
+    with Engine(0) as eng:
+        ids = [eng.add_fasta(f)[0] for f in files]
+        recs_of = [anim.fasta_records(f) for f in files]
+        for mm in (False, True):
+            off, recs, ioff, ind = eng.anim_alignments_batch([ids[0], ids[1]], [ids[1], ids[0]], maxmatch=mm, with_indels=True)
+            for k, (a, b) in enumerate(((0, 1), (1, 0))):
+                out = subprocess.run([str(oracle), str(files[a]), str(files[b]), "--delta"] + (["--maxmatch"] if mm else []),
+                                     capture_output=True, text=True, check=True).stdout
+                want, cur = {}, None
+                for line in out.splitlines():
+                    t = line.split()
+                    if t and t[0] == "ALN":
+                        cur = (t[1], t[2], int(t[3]), int(t[4]), int(t[5]), int(t[6]), int(t[7]))
+                        want[cur] = []
+                    elif cur is not None and len(t) == 1 and t[0] != "0":
+                        want[cur].append(int(t[0]))
+                got = {}
+                for x in range(int(off[k]), int(off[k + 1])):
+                    r = recs[x]
+                    key = (recs_of[a][int(r["ref_rec"])][0], recs_of[b][int(r["qry_rec"])][0], int(r["rs"]), int(r["re"]), int(r["qs"]), int(r["qe"]),
+                           int(r["errors"]))
+                    got[key] = [int(v) for v in ind[int(ioff[x]):int(ioff[x + 1])]]
+                assert got == want, (mm, a, b, len(got), len(want), sorted(set(got) ^ set(want))[:3])
+                assert len(got) > 10
