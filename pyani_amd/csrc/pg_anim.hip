@@ -369,9 +369,9 @@ static int anim_collect(pg_ctx* ctx, AnimScratch* A, const int32_t* ref_ids, con
   if (!sink.with_indels) return PG_OK;
   if (!postnuc) return pg_fail(ctx, PG_E_ARG, "indel lists need the nucmer extender (pg_anim_set_extender)");
   sink.indels.resize(sink.alns.size());
-  if (!total) return PG_OK;
-  // ---- the walks' pieces
   const size_t n_wl = choff[n_units];
+  if (!total || !n_wl) return PG_OK;      // no clusters at all: no alignments, nothing to trace
+  // ---- the walks' pieces
   std::vector<pgn::PnAln> pn(total);
   std::vector<int32_t> pn_n(n_units);
   std::vector<uint32_t> npieces(n_units);
@@ -896,6 +896,7 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
       const size_t need = pn_piece_base(Mp, (uint32_t)n_wl, n_units) + 16;
       if (need > A->pn_piece_cap) { if ((rc = regrow(ctx, A->pn_pieces, need))) return rc; A->pn_piece_cap = need; }
       if (n_units > A->pn_npieces_cap) { if ((rc = regrow(ctx, A->pn_npieces, (size_t)n_units + 16))) return rc; A->pn_npieces_cap = (size_t)n_units + 16; }
+      PG_HIP(ctx, hipMemsetAsync(A->pn_npieces, 0, (size_t)n_units * 4, cur_stream(ctx)));
     }
     const size_t req_cap = n_wl + 16;
     if (req_cap > A->pn_req_cap) { if ((rc = regrow(ctx, A->pn_reqs, req_cap + req_cap / 2))) return rc; A->pn_req_cap = req_cap + req_cap / 2; }
