@@ -174,6 +174,7 @@ struct AnimScratch {
   PnForcedReq* pn_reqs = nullptr;   // the launch's deferred forced runs (at most one per alignment started: <= chains)
   pgn::PnGap* pn_gaps = nullptr;    // match-to-match alignments by match slot
   pgn::PnFwd* pn_fwd = nullptr;     // forward extensions by cluster (moff-relative position in the unit's order)
+  pgn::PnBwd* pn_bwd = nullptr;      // backward searches run ahead of the walks, by cluster (as pn_fwd)
   pgn::PnPiece* pn_pieces = nullptr; // traceback runs: the walks' pieces (pn_piece_base)
   uint32_t* pn_npieces = nullptr;    // per unit
   size_t pn_piece_cap = 0, pn_npieces_cap = 0;
@@ -313,7 +314,7 @@ static void anim_free_one(pg_ctx* ctx, void*& slot) {
                   A->iscratch, A->order, A->prev, A->next, A->alnof, A->chains, A->fw, A->bw, A->S.alns, A->S.a_rrec,
                   A->S.a_qrec, A->S.idx, A->S.from, A->S.sc, A->wl_d, A->seedbuf, A->seed_total, A->tasks_d, A->fr_tables, A->fr_pairs,
                   A->fr_slot_pair, A->fr_off, A->fr_nrows, A->fr_ebase, A->fr_entries, A->fr_rows, A->fr_out, A->fr_list, A->fr_nlist, A->fr_wtmp, A->fr_widx,
-                  A->pn, A->pn_fused, A->pn_n, A->pn_cursor, A->pn_gscratch, A->pn_reqs, A->pn_gaps, A->pn_fwd, A->pn_tasks, A->pn_order, A->pn_pieces, A->pn_npieces, A->tr_arena, A->tr_out, A->tr_jobs, A->tr_off, A->tr_cursor, A->tr_cnt};
+                  A->pn, A->pn_fused, A->pn_n, A->pn_cursor, A->pn_gscratch, A->pn_reqs, A->pn_gaps, A->pn_fwd, A->pn_bwd, A->pn_tasks, A->pn_order, A->pn_pieces, A->pn_npieces, A->tr_arena, A->tr_out, A->tr_jobs, A->tr_off, A->tr_cursor, A->tr_cnt};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   delete A;
   slot = nullptr;
@@ -872,6 +873,7 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
       if ((rc = regrow(ctx, A->pn_fused, Mp))) return rc;
       if ((rc = regrow(ctx, A->pn_gaps, Mp))) return rc;
       if ((rc = regrow(ctx, A->pn_fwd, Mp))) return rc;
+      if ((rc = regrow(ctx, A->pn_bwd, Mp))) return rc;
       if ((rc = regrow(ctx, A->pn_tasks, 3 * Mp))) return rc;
       A->pn_cap = Mp;
     }
@@ -892,6 +894,7 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
     const uint32_t pn_waves_pre = (uint32_t)ctx->num_cu * 20u;   // gap / forward pre-passes: no LDS, < 104 registers: 5 per SIMD
     if (pn_waves_pre > A->pn_waves) { if ((rc = regrow(ctx, A->pn_gscratch, (size_t)pn_waves_pre * PN_GLOBAL_WORDS))) return rc; A->pn_waves = pn_waves_pre; }
     const bool trace = tls_sink && tls_sink->with_indels;      // the walks list their pieces and align everything themselves
+    const bool bwd_ahead = ctx->anim_bwd_ahead != 0;
     if (trace) {
       const size_t need = pn_piece_base(Mp, (uint32_t)n_wl, n_units) + 16;
       if (need > A->pn_piece_cap) { if ((rc = regrow(ctx, A->pn_pieces, need))) return rc; A->pn_piece_cap = need; }
@@ -900,7 +903,7 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
     }
     const size_t req_cap = n_wl + 16;
     if (req_cap > A->pn_req_cap) { if ((rc = regrow(ctx, A->pn_reqs, req_cap + req_cap / 2))) return rc; A->pn_req_cap = req_cap + req_cap / 2; }
-    PG_HIP(ctx, hipMemsetAsync(A->pn_cursor, 0, 64, cur_stream(ctx)));   // [0] unit cursor, [1] forced runs recorded ([7]: the long ones), [2] forced-run cursor, [3] chain cursor, [4..6] small gaps, [8] cluster cursor of the forward extensions
+    PG_HIP(ctx, hipMemsetAsync(A->pn_cursor, 0, 64, cur_stream(ctx)));   // [0] unit cursor, [1] forced runs recorded ([7]: the long ones), [2] forced-run cursor, [3] chain cursor, [4..6] small gaps, [8] cluster cursor of the forward extensions, [9] unit cursor of the rehearsal, [10] cluster cursor of the backward searches
     if (n_wl && trace) PG_HIP(ctx, hipMemcpyAsync(A->choff_d, choff.data(), choff.size() * 4, hipMemcpyHostToDevice, cur_stream(ctx)));
     if (n_wl && !trace) {     // the (unit, chain) work list, then every cluster's match-to-match alignments
       if (n_wl > A->wl) { if ((rc = regrow(ctx, A->wl_d, n_wl + n_wl / 2))) return rc; A->wl = n_wl + n_wl / 2; }
@@ -920,13 +923,21 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
                          A->pn_cursor + 3, A->pn_gaps, A->pn_gscratch, lane_small);
       hipLaunchKernelGGL(anim_postnuc_fwd_kernel, dim3(pn_waves_pre), dim3(64), 0, cur_stream(ctx), A->refs_d, A->units_d, O, A->wl_d, (uint32_t)n_wl,
                          A->pn_cursor + 8, A->pn_fwd, A->pn_gscratch);
+      if (bwd_ahead) {     // the walks rehearsed without their backward searches, then the searches they predict, one wave each
+        PG_HIP(ctx, hipMemsetAsync(A->pn_bwd, 0, (size_t)M * sizeof(pgn::PnBwd), cur_stream(ctx)));
+        hipLaunchKernelGGL(anim_postnuc_rehearse_kernel, dim3(pn_waves < n_units ? pn_waves : n_units), dim3(64), 0, cur_stream(ctx), A->refs_d,
+                           A->units_d, n_units, O, A->pn_cursor + 9, A->pn, A->pn_fused, A->pn_gscratch, A->pn_gaps, A->pn_fwd, A->pn_order, A->pn_bwd);
+        hipLaunchKernelGGL(anim_postnuc_bwd_kernel, dim3(pn_waves_pre), dim3(64), 0, cur_stream(ctx), A->refs_d, A->units_d, O, A->wl_d, (uint32_t)n_wl,
+                           A->pn_cursor + 10, A->pn_bwd, A->pn_gscratch);
+      }
       pg_prof_end(ctx);
     }
     pg_prof_begin(ctx, PG_K_ANIM_EXTEND);
     if (n_wl)
       hipLaunchKernelGGL(anim_postnuc_kernel, dim3(pn_waves < n_units ? pn_waves : n_units), dim3(64), 0, cur_stream(ctx), A->refs_d, A->units_d,
                          n_units, O, A->pn_cursor, A->pn, A->pn_fused, A->pn_n, A->pn_gscratch, A->pn_reqs, A->pn_cursor + 1, (uint32_t)req_cap,
-                         trace ? nullptr : A->pn_gaps, trace ? nullptr : A->pn_fwd, A->pn_order, trace ? A->pn_pieces : nullptr, A->pn_npieces, A->choff_d);
+                         trace ? nullptr : A->pn_gaps, trace ? nullptr : A->pn_fwd, A->pn_order, trace ? A->pn_pieces : nullptr, A->pn_npieces, A->choff_d,
+                         bwd_ahead && !trace ? A->pn_bwd : nullptr);
     else
       PG_HIP(ctx, hipMemsetAsync(A->pn_n, 0, (size_t)n_units * 4, cur_stream(ctx)));
     pg_prof_end(ctx);

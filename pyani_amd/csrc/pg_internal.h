@@ -97,7 +97,8 @@ struct pg_ctx {
   std::mutex anim_mu, err_mu, prof_mu;
   int anib_word_tier = 1;      // fragment mode: search failed fragments again with blastn-sized (11-mer) seeds
   int anim_gap_lanes = 1;      // postnuc: small match-to-match gaps on one lane each (0: all gaps on the wave engine; tests compare the two)
-  int anim_extender = 0;       // PG_EXTENDER_NUCMER (pg_anim_set_extender)
+  int anim_extender = 0;
+  int anim_bwd_ahead = 1;      // backward searches ahead of the units' walks (pga_postnuc.inc); PYANI_ANIM_BWD_AHEAD=0 (development switch): inside them       // PG_EXTENDER_NUCMER (pg_anim_set_extender)
   int anim_workers = 2;
   uint32_t anim_batch_pairs = 131072;         // ordered pairs in flight (split over the two workers: 65536 per launch; every launch pays its slowest unit once)
   uint64_t anim_batch_matches = 512ull << 20; // exact matches in flight (~264 B of scratch each, grown on demand: at most ~136 GB of the 288 GB)

@@ -41,6 +41,12 @@ struct PnGap { int32_t eA, eB, errors, reached; };
 // the last base of the cluster's last match whichever way the walk came to it — so an engine may have all of them ready
 // (postnuc_forward: the GPU runs one wave per cluster before the units' sequential walks).
 struct PnFwd { int32_t eA, eB, errors, targetk, reached; };
+// A backward search run AHEAD of the walk (one per cluster, for the alignment that starts on its first match): its arguments as
+// a DP-free rehearsal of the walk predicted them (postnuc_rehearse: the walk with every backward search answered "found
+// nothing" — alignment ENDS do not depend on backward searches, only starts and merges do, so the targets come out right almost
+// always) and its result.  The real walk takes the result only if its own arguments are these (else it searches itself):
+// a wrong prediction costs time, never a result.  state: 0 = no search predicted, 1 = predicted, 2 = result present.
+struct PnBwd { int32_t sA, sB, tA, tB; uint32_t m_o; int32_t rA, rB, reached, state; };
 
 // ---- packed DP words ----------------------------------------------------------------------------------------------------
 // One 32-bit word per state:  (score + SCORE_BIAS) << 17 | state << 15 | errors.
@@ -272,6 +278,10 @@ struct ScalarEngine {
   PG_HD bool gap_ready(int32_t, PnGap&) const { return false; }     // (scalar engines align match to match as they go)
   const PnFwd* fwd = nullptr;      // forward extensions computed beforehand (postnuc_forward_all), by position in `order`
   PG_HD bool fwd_ready(int k, PnFwd& f) const { if (!fwd) return false; f = fwd[k]; return true; }
+  const PnBwd* bwd = nullptr;      // backward searches run ahead (postnuc_rehearse + one align per predicted call), by position in `order`
+  PG_HD bool bwd_ready(int k, PnBwd& b) const { if (!bwd) return false; b = bwd[k]; return b.state == 2; }
+  PG_HD void bwd_key(int, int32_t, int32_t, int32_t, int32_t, unsigned) {}
+  long searches = 0, search_cells = 0;      // backward searches this engine ran itself (host experiments)
   PnTrace* trace = nullptr;        // set: the next run() stores its backpointers there
   PnPiece* pieces = nullptr;       // set: the walk's pieces are listed here (piece_cap entries; n_pieces counts on past it)
   int32_t piece_cap = 0, n_pieces = 0;
@@ -301,7 +311,11 @@ struct ScalarEngine {
   // the target corner was reached; Aend / Bend = the finish position; errors = errors of the path to it (not in SEARCH mode
   // — the value is computed anyway and ignored by the callers).
   PG_HD bool align(int32_t Astart, int32_t& Aend, int32_t Bstart, int32_t& Bend, unsigned m_o, int32_t& errors) {
-    if (!(m_o & FORCED_BIT)) return run(Astart, Aend, Bstart, Bend, m_o, -1, errors);
+    if (!(m_o & FORCED_BIT)) {
+      const bool r = run(Astart, Aend, Bstart, Bend, m_o, -1, errors);
+      if (m_o & SEARCH_BIT) { ++searches; search_cells += last_cells; }
+      return r;
+    }
     const bool fwd = m_o & DIRECTION_BIT;
     const int32_t N = fwd ? Aend - Astart + 1 : Astart - Aend + 1, M = fwd ? Bend - Bstart + 1 : Bstart - Bend + 1;
     for (int32_t w = FORCED_BAND_FIRST;;) {
@@ -496,6 +510,8 @@ struct DiagEngine {
   ScalarEngine<RefT, QryT> slow;
   PG_HD bool gap_ready(int32_t, PnGap&) const { return false; }     // (scalar engines align match to match as they go)
   PG_HD void piece(uint32_t, int32_t, int32_t, int32_t, int32_t, int32_t, int32_t, int32_t, unsigned) {}
+  PG_HD bool bwd_ready(int, PnBwd&) const { return false; }
+  PG_HD void bwd_key(int, int32_t, int32_t, int32_t, int32_t, unsigned) {}
   const PnFwd* fwd = nullptr;      // forward extensions computed beforehand (postnuc_forward_all), by position in `order`
   PG_HD bool fwd_ready(int k, PnFwd& f) const { if (!fwd) return false; f = fwd[k]; return true; }
   // a forced alignment between two known corners: its error count (see the call sites in postnuc_unit)
@@ -544,6 +560,36 @@ struct DiagEngine {
 // cm: their matches.  BOUNDS(c, r_lo, r_hi, q_lo, q_hi): the records of chain c as half-open stream ranges (q: strand
 // coordinates).  fused[n] / al[max_al]: scratch and output.  Returns the number of alignments (al[] in creation order, as
 // MUMmer prints them), or -1 - count when max_al was too small.
+// The walk rehearsed without its backward searches: every other call goes to the real engine (which has them ready: the match-to-match
+// and forward pre-passes ran before), a backward search is noted (bwd[k] = its arguments) and answered "found nothing".
+template <typename ENG>
+struct PnRehearsal {
+  ENG& e;
+  PnBwd* out;
+  PG_HD bool gap_ready(int32_t slot, PnGap& g) const { return e.gap_ready(slot, g); }
+  PG_HD bool fwd_ready(int k, PnFwd& f) const { return e.fwd_ready(k, f); }
+  PG_HD bool bwd_ready(int, PnBwd&) const { return false; }
+  PG_HD void bwd_key(int k, int32_t sA, int32_t sB, int32_t tA, int32_t tB, unsigned m_o) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if ((threadIdx.x & 63) != 0) return;      // (a wave rehearses as one: every lane holds the same values)
+#endif
+    out[k] = PnBwd{sA, sB, tA, tB, m_o, 0, 0, 0, 1};
+  }
+  PG_HD void piece(uint32_t, int32_t, int32_t, int32_t, int32_t, int32_t, int32_t, int32_t, unsigned) {}
+  PG_HD int32_t forced_errors(int32_t, int32_t, int32_t, int32_t, PnAln*) { return 0; }
+  PG_HD bool shadowed(const Chain* chains, const PnAln* al, int from, int c, int32_t sA, int32_t eA, int32_t sB, int32_t eB) const {
+    return e.shadowed(chains, al, from, c, sA, eA, sB, eB); }
+  PG_HD int reverse_target(const Chain* chains, const PnAln* al, int cura, int c, int32_t sA, int32_t sB, int32_t dist) const {
+    return e.reverse_target(chains, al, cura, c, sA, sB, dist); }
+  PG_HD int forward_target(const Chain* chains, const Match* cm, const int32_t* order, int n, int curk, int c, int32_t sA, int32_t sB,
+                           int32_t dist, int32_t& targetA, int32_t& targetB) const {
+    return e.forward_target(chains, cm, order, n, curk, c, sA, sB, dist, targetA, targetB); }
+  PG_HD bool align(int32_t Astart, int32_t& Aend, int32_t Bstart, int32_t& Bend, unsigned m_o, int32_t& errors) {
+    if (m_o & SEARCH_BIT) { Aend = Astart; Bend = Bstart; errors = 0; return false; }
+    return e.align(Astart, Aend, Bstart, Bend, m_o, errors);
+  }
+};
+
 // extendForward off the last match of cluster order[curk]: target search (getForwardTargetCluster), clamps, alignment
 template <typename ENG, typename BOUNDS>
 PG_HD PnFwd postnuc_forward(ENG& eng, const Chain* chains, const Match* cm, const int32_t* order, int n, int curk, BOUNDS&& bounds,
@@ -624,7 +670,13 @@ PG_HD int postnuc_unit(ENG& eng, const Chain* chains, const Match* cm, const int
           if (A.sA - tA + 1 > MAX_ALIGNMENT_LENGTH) { tA = A.sA - MAX_ALIGNMENT_LENGTH + 1; overflow = true; m_o |= OPTIMAL_BIT; }
           if (A.sB - tB + 1 > MAX_ALIGNMENT_LENGTH) { tB = A.sB - MAX_ALIGNMENT_LENGTH + 1; if (!overflow) m_o |= OPTIMAL_BIT; overflow = true; }
           int32_t err = 0;
-          bool reached = eng.align(A.sA, tA, A.sB, tB, m_o | SEARCH_BIT, err);
+          bool reached;
+          PnBwd bw;
+          if (m == 0) eng.bwd_key(curk, A.sA, A.sB, tA, tB, m_o | SEARCH_BIT);      // (a rehearsal notes what it was asked)
+          if (m == 0 && eng.bwd_ready(curk, bw) && bw.sA == A.sA && bw.sB == A.sB && bw.tA == tA && bw.tB == tB && bw.m_o == (m_o | SEARCH_BIT)) {
+            tA = bw.rA; tB = bw.rB; reached = bw.reached != 0;      // searched ahead of the walk with exactly these arguments
+          } else
+            reached = eng.align(A.sA, tA, A.sB, tB, m_o | SEARCH_BIT, err);
           if (overflow || tgt < 0) reached = false;
           if (reached) {
             // forced re-alignments only contribute their error count (the corner is reached by definition): the engine may

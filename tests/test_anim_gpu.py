@@ -304,6 +304,15 @@ def test_gap_forms_and_extenders_of_the_postnuc_stage_agree(monkeypatch):
             out[lanes] = e.anim_pairs([a for a, _ in pairs], [b for _, b in pairs])
     assert (out["1"]["status"] == 0).sum() >= 40
     assert out["1"].tobytes() == out["0"].tobytes()
+    # the backward searches run ahead of the units' walks (rehearsal + one wave per predicted search; results are taken only when
+    # the walk repeats the predicted arguments) or inside them (PYANI_ANIM_BWD_AHEAD=0): not a single result may differ
+    monkeypatch.setenv("PYANI_ANIM_GAP_LANES", "1")
+    monkeypatch.setenv("PYANI_ANIM_BWD_AHEAD", "0")
+    with Engine(0) as e:
+        ids = [e.add_genome(*d) for d in data]
+        pairs = [(a, b) for a in ids for b in ids if a != b]
+        inside = e.anim_pairs([a for a, _ in pairs], [b for _, b in pairs])
+    assert inside.tobytes() == out["1"].tobytes()
 
 
 def test_cluster_stage_forms_do_not_change_results(eng, monkeypatch):

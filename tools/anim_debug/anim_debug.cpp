@@ -143,6 +143,26 @@ int main(int argc, char** argv) {
         for (int k = 0; k < n_chains; ++k) fw[k] = pgn::postnuc_forward(eng, chains.data(), cm.data(), co.data(), n_chains, k, bounds_of);
         eng.fwd = fw.data();
       }
+      // ANIM_BWD_AHEAD (with ANIM_HOIST): the walk rehearsed without its backward searches, the searches it predicts run ahead, the real
+      // walk takes those whose arguments it repeats — what the GPU's backward pre-pass does (results must not change; the rate is printed)
+      std::vector<pgn::PnBwd> bwd;
+      if (getenv("ANIM_BWD_AHEAD") && !fw.empty()) {
+        bwd.assign(n_chains, pgn::PnBwd{0, 0, 0, 0, 0u, 0, 0, 0, 0});
+        std::vector<uint8_t> fused2(n_chains + 1);
+        std::vector<pgn::PnAln> al2(n_chains + 1);
+        pgn::PnRehearsal<pgn::ScalarEngine<SeqView, StrandView>> dry{eng, bwd.data()};
+        pgn::postnuc_unit(dry, chains.data(), cm.data(), co.data(), n_chains, bounds_of, fused2.data(), al2.data(), (int)al2.size());
+        long predicted = 0;
+        for (auto& b : bwd) if (b.state == 1) {
+          int32_t a = b.tA, q = b.tB, err = 0;
+          b.reached = eng.align(b.sA, a, b.sB, q, b.m_o, err) ? 1 : 0;
+          b.rA = a; b.rB = q; b.state = 2; ++predicted;
+        }
+        const long ahead_cells = eng.search_cells;
+        eng.searches = 0; eng.search_cells = 0;
+        eng.bwd = bwd.data();
+        fprintf(stderr, "backward searches run ahead: %ld (%ld cells); ", predicted, ahead_cells);
+      }
       const int na = getenv("ANIM_DIAG") ? pgn::postnuc_unit(deng, chains.data(), cm.data(), co.data(), n_chains, bounds_of, fused.data(), al.data(), (int)al.size())
                                          : pgn::postnuc_unit(eng, chains.data(), cm.data(), co.data(), n_chains,
           [&](int c, int32_t& rl, int32_t& rh, int32_t& ql, int32_t& qh) {
@@ -152,6 +172,7 @@ int main(int argc, char** argv) {
           fused.data(), al.data(), (int)al.size());
       if (na < 0 || eng.overflow || deng.slow.overflow) { fprintf(stderr, "postnuc statement: capacity exceeded\n"); return 3; }
       exact_cells += eng.cells + deng.fast.cells + deng.slow.cells;
+      if (!bwd.empty()) fprintf(stderr, "the walk still ran %ld itself (%ld cells)\n", eng.searches, eng.search_cells);
       if (want_delta) {
         // the paths of the walk's search / forced pieces, by the scalar engine with its traceback store (on the GPU: anim_trace_kernel)
         if (eng.n_pieces > eng.piece_cap) { fprintf(stderr, "piece list too small\n"); return 3; }
