@@ -314,8 +314,8 @@ def run_anim(args, rank, world, local, dist, torch):
     fence()
     if args.warmup == 0:
         t_cold = None
-    stages = [_lib.K_ANIM_SEED, _lib.K_ANIM_HIT, _lib.K_ANIM_CLUSTER, _lib.K_ANIM_GAPS, _lib.K_ANIM_EXTLANE, _lib.K_ANIM_EXTEND,
-              _lib.K_ANIM_FINISH]
+    stages = [_lib.K_ANIM_SEED, _lib.K_ANIM_HIT, _lib.K_ANIM_CLUSTER, _lib.K_ANIM_GAPS, _lib.K_ANIM_FWD, _lib.K_ANIM_BWD, _lib.K_ANIM_EXTEND,
+              _lib.K_ANIM_EXTLANE, _lib.K_ANIM_FINISH]
     eng.profile_reset()
     eng.profile_config(kernel_mask=sum(1 << s_ for s_ in stages), every_n=1)   # ms-scale launches: an event pair costs nothing here
     eng.profile_enable(True)

@@ -245,13 +245,15 @@ int pg_profile_reset(pg_ctx* ctx);
 #define PG_K_ANIM_SEED 4     /* anim_seed_kernel: LDS-resident reference groups, streamed query lists */
 #define PG_K_ANIM_HIT 5      /* anim_hoff_kernel + anim_hit_scatter_kernel + anim_hit_kernel + anim_scatter_kernel */
 #define PG_K_ANIM_CLUSTER 6  /* anim_cluster_wave_kernel (one launch; + anim_cluster_prep_kernel when few units) */
-#define PG_K_ANIM_GAPS 7     /* anim_gaps_kernel + anim_gapsort_kernel + the four anim_gapdp_lane_kernel launches */
-#define PG_K_ANIM_EXTLANE 8  /* anim_extdp_lane_kernel */
-#define PG_K_ANIM_EXTEND 9   /* anim_extreq_kernel / anim_extend_kernel / anim_gapreq_kernel / anim_gapdp_kernel */
+#define PG_K_ANIM_GAPS 7     /* nucmer extender: anim_postnuc_gaplist / gaplane<16,32,59> / gap kernels (match-to-match alignments); banded64: anim_gaps_kernel + anim_gapsort_kernel + the four anim_gapdp_lane_kernel launches */
+#define PG_K_ANIM_EXTLANE 8  /* nucmer extender: anim_postnuc_forced_kernel; banded64: anim_extdp_lane_kernel */
+#define PG_K_ANIM_EXTEND 9   /* nucmer extender: anim_postnuc_kernel (the units' walks); banded64: anim_extreq_kernel / anim_extend_kernel / anim_gapreq_kernel / anim_gapdp_kernel */
 #define PG_K_ANIM_FINISH 10  /* anim_finish_kernel */
 #define PG_K_ANIB_BUCKET 11  /* anib_bucket_kernel: seeds clipped to fragments, counting sort by fragment */
 #define PG_K_ANIB_FRAG 12    /* anib_frag_kernel: anchors + X-drop extensions, one wave per (pair, fragment) */
-#define PG_K__COUNT 13
+#define PG_K_ANIM_FWD 13     /* anim_postnuc_fwd_kernel: the forward extension off every cluster, ahead of the units' walks */
+#define PG_K_ANIM_BWD 14     /* anim_postnuc_rehearse_kernel + anim_postnuc_bwd_kernel: the walks rehearsed, their backward searches run ahead */
+#define PG_K__COUNT 15
 /* total milliseconds and number of launches of kernel `which` since the last reset (synchronises). */
 int pg_profile_get(pg_ctx* ctx, int which, double* total_ms_out, uint64_t* launches_out);
 const char* pg_kernel_name(int which);

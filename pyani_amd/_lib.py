@@ -10,7 +10,8 @@ PG_E_CAPACITY, PG_ANIM_NO_ALIGNMENT = -9, 1
 K_TETRA_COUNT, K_TETRA_FINALIZE, K_TETRA_STATS, K_TETRA_PAIRS = 0, 1, 2, 3
 (K_ANIM_SEED, K_ANIM_HIT, K_ANIM_CLUSTER, K_ANIM_GAPS, K_ANIM_EXTLANE, K_ANIM_EXTEND, K_ANIM_FINISH) = 4, 5, 6, 7, 8, 9, 10
 K_ANIB_BUCKET, K_ANIB_FRAG = 11, 12
-K_COUNT = 13
+K_ANIM_FWD, K_ANIM_BWD = 13, 14
+K_COUNT = 15
 EXTENDER_NUCMER, EXTENDER_BANDED64 = 0, 1
 
 # every symbol declared in include/pyani_gpu.h: (name, restype, argtypes)

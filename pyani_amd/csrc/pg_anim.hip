@@ -921,8 +921,12 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
       }
       hipLaunchKernelGGL(anim_postnuc_gap_kernel, dim3(pn_waves_pre), dim3(64), 0, cur_stream(ctx), A->refs_d, A->units_d, O, A->wl_d, (uint32_t)n_wl,
                          A->pn_cursor + 3, A->pn_gaps, A->pn_gscratch, lane_small);
+      pg_prof_end(ctx);
+      pg_prof_begin(ctx, PG_K_ANIM_FWD);
       hipLaunchKernelGGL(anim_postnuc_fwd_kernel, dim3(pn_waves_pre), dim3(64), 0, cur_stream(ctx), A->refs_d, A->units_d, O, A->wl_d, (uint32_t)n_wl,
                          A->pn_cursor + 8, A->pn_fwd, A->pn_gscratch);
+      pg_prof_end(ctx);
+      pg_prof_begin(ctx, PG_K_ANIM_BWD);
       if (bwd_ahead) {     // the walks rehearsed without their backward searches, then the searches they predict, one wave each
         PG_HIP(ctx, hipMemsetAsync(A->pn_bwd, 0, (size_t)M * sizeof(pgn::PnBwd), cur_stream(ctx)));
         hipLaunchKernelGGL(anim_postnuc_rehearse_kernel, dim3(pn_waves < n_units ? pn_waves : n_units), dim3(64), 0, cur_stream(ctx), A->refs_d,

@@ -52,7 +52,8 @@ if f and w:
     stage_of = {"anim_seed_kernel": "anim_seed_kernel", "anim_cluster_wave_kernel": "anim_cluster_wave_kernel",
                 "anim_postnuc_kernel": "anim_postnuc_kernel|anim_extend_kernels",
                 "anim_postnuc_forced_kernel": "anim_postnuc_forced_kernel|anim_extdp_lane_kernel",
-                "anim_postnuc_gap_kernel": "anim_postnuc_gap_kernels|anim_gap_kernels", "anim_finish_kernel": "anim_finish_kernel"}
+                "anim_postnuc_gap_kernel": "anim_postnuc_gap_kernels|anim_gap_kernels", "anim_finish_kernel": "anim_finish_kernel",
+                "anim_postnuc_fwd_kernel": "anim_postnuc_fwd_kernel", "anim_postnuc_bwd_kernel": "anim_postnuc_rehearse_kernel+anim_postnuc_bwd_kernel"}
     out = {"round": tag, "command": "python bench.py --gpus 1 --steps 1 --warmup 1 --no-cpu-baseline --no-tetra (C4, a step = a tenth of the grid; two workers: launches of two streams overlap)",
            "correction": "FETCH_SIZE doubled (gfx950 rocprofv3 tallies 128-B read requests at 64 B, MI355X_MICROARCH.md §HBM; exact for wide "
                          "coalesced streams, an upper bound for narrower accesses); WRITE_SIZE as reported (uncalibrated)"}
