@@ -77,3 +77,22 @@ def test_oracle_and_statement_reproduce_mummer_output(programs, genome_dir):
         n_runs += 1
         n_records += len(want)
     assert n_runs == 19 and n_records >= 1690
+
+
+def test_pre_pass_forms_of_the_statement_give_the_same_records(programs, genome_dir):
+    """The forms the GPU runs the walk in — forward extensions computed for every cluster beforehand (ANIM_HOIST) and backward
+    searches predicted by a rehearsal of the walk and run ahead of it (ANIM_BWD_AHEAD; a result is taken only when the walk repeats
+    the predicted arguments) — must not change a record: host statement on the Blochmannia runs and one divergent Caulobacter pair."""
+    import os
+    _, stmt = programs
+    env = dict(os.environ, ANIM_HOIST="1", ANIM_BWD_AHEAD="1")
+    n = 0
+    for grp, f, pa, pb in _runs(genome_dir):
+        if grp == "group2":
+            continue
+        want = {(x.ref_id, x.qry_id, x.rs, x.re, x.qs, x.qe, x.errors) for x in anim_oracle.read_delta(f)[0]}
+        r = subprocess.run([str(stmt), str(pa), str(pb), "--dump", "--exact"], capture_output=True, text=True, check=True, env=env)
+        assert set(_records(r.stdout)) == want, f.name
+        assert "backward searches run ahead" in r.stderr
+        n += 1
+    assert n >= 16
