@@ -850,8 +850,8 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
     if (!big.empty()) {
       hipLaunchKernelGGL(anim_chain_range_kernel, dim3((uint32_t)ranges.size()), dim3(64), 0, cur_stream(ctx), A->units_d, A->mem, A->iscratch,
                          O, A->big_d, A->ranges_d, A->range_out);
-      hipLaunchKernelGGL(anim_chain_merge_kernel, dim3((uint32_t)big.size()), dim3(64), 0, cur_stream(ctx), A->iscratch, O, A->big_d,
-                         A->range_out);
+      hipLaunchKernelGGL(anim_chain_merge_kernel, dim3((uint32_t)big.size()), dim3(64), 0, cur_stream(ctx), A->refs_d, A->units_d, A->iscratch, O,
+                         A->big_d, A->range_out);
     }
   }
   pg_prof_end(ctx);

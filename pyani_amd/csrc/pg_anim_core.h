@@ -290,11 +290,17 @@ PG_HD int record_of(const int32_t* rec_start, int n_rec, int32_t p) {
 
 // MUM filter (`mummer -mum`): keep maximal matches whose string occurs once in the reference and once in the query
 // strand.  A match is NOT unique in the reference iff another match (other ref position) covers its whole query
-// interval, and NOT unique in the query iff another match covers its whole ref interval.  m[0..n) of ONE strand; the
-// `strand` field is used as scratch flag and restored.  Returns the new count (order: by q).
-PG_HD int mum_filter(Match* m, int n, int strand) {
+// interval, and NOT unique in the query iff another match OF THE SAME QUERY RECORD covers its whole ref interval: `mummer`
+// indexes the whole reference file (all records) and streams the query file one sequence and strand at a time, so
+// mumuniqueinquery never sees the candidates of another query record — a repeat that sits once in each of two contigs of a
+// draft assembly is unique in either (round 4: the filter used to scan the strand stream of all records as one sequence and
+// lost those matches; found by fuzzing against oracle/nucmer_oracle.cpp, tools/anim_fuzz_multirecord.py).
+// m[0..n) of ONE strand; the `strand` field is used as scratch flag and restored.  QREC(strand position) -> query record
+// (any monotone labelling: only equality is used).  Returns the new count (order: by q).
+template <typename QREC>
+PG_HD int mum_filter(Match* m, int n, int strand, QREC&& qrec_of) {
   for (int i = 0; i < n; ++i) m[i].strand = 0;
-  // query-interval containment
+  // query-interval containment (a query interval lies inside one record: the candidates of other records cannot cover it)
   heapsort(m, n, [](const Match& a, const Match& b) { return a.q < b.q || (a.q == b.q && a.len > b.len); });
   int32_t maxend = -1;
   for (int i = 0; i < n; ++i) {
@@ -303,13 +309,17 @@ PG_HD int mum_filter(Match* m, int n, int strand) {
     else if (i + 1 < n && m[i + 1].q == m[i].q && m[i + 1].len == m[i].len) m[i].strand = 1;
     if (e > maxend) maxend = e;
   }
-  // ref-interval containment
-  heapsort(m, n, [](const Match& a, const Match& b) { return a.r < b.r || (a.r == b.r && a.len > b.len); });
+  // ref-interval containment, per query record
+  heapsort(m, n, [&](const Match& a, const Match& b) {
+    const int32_t ra = qrec_of(a.q), rb = qrec_of(b.q);
+    return ra != rb ? ra < rb : (a.r < b.r || (a.r == b.r && a.len > b.len)); });
   maxend = -1;
+  int32_t seg = -1;
   for (int i = 0; i < n; ++i) {
-    const int32_t e = m[i].r + m[i].len;
+    const int32_t e = m[i].r + m[i].len, rec = qrec_of(m[i].q);
+    if (rec != seg) { seg = rec; maxend = -1; }
     if (e <= maxend) m[i].strand = 1;
-    else if (i + 1 < n && m[i + 1].r == m[i].r && m[i + 1].len == m[i].len) m[i].strand = 1;
+    else if (i + 1 < n && m[i + 1].r == m[i].r && m[i + 1].len == m[i].len && qrec_of(m[i + 1].q) == rec) m[i].strand = 1;
     if (e > maxend) maxend = e;
   }
   int k = 0;
@@ -330,7 +340,10 @@ constexpr int CHAIN_LOOKBACK = 64;  // mgaps scans all earlier matches of the cl
 
 // mgaps: union-find clustering of one strand's MUMs (sorted by q) + best-chain extraction.
 // scratch: parent[n], score[n], from[n], adj[n], used[n] (int32 each).  Appends chains to chains[]/cm[].
-// Matches of different (ref record, query record) never join.
+// Matches of different QUERY records never join (mummer / mgaps run per query sequence).  The reference is ONE text to them —
+// nucmer's prenuc joins the reference records with a separator, exactly the stream layout here — so a cluster may hold matches
+// of two reference records (a query contig that runs across the junction of two adjacent reference contigs); postnuc then cuts
+// such a cluster where the record changes: split_chains_by_ref_record below, applied after the -l 65 test on the whole.
 PG_HD void mgaps_strand(const Match* m, int n, int strand, const int32_t* rrec_of, const int32_t* qrec_of,
                         int32_t* parent, int32_t* score, int32_t* from, int32_t* adj, int32_t* order,
                         Chain* chains, int& n_chains, int max_chains, Match* cm, int& n_cm, int max_cm) {
@@ -344,7 +357,7 @@ PG_HD void mgaps_strand(const Match* m, int n, int strand, const int32_t* rrec_o
     for (int j = i + 1; j < n; ++j) {
       const int32_t sep = m[j].q - iend;
       if (sep > MAX_GAP) break;
-      if (rrec_of[i] != rrec_of[j] || qrec_of[i] != qrec_of[j]) continue;
+      if (qrec_of[i] != qrec_of[j]) continue;
       int32_t dd = (m[j].q - m[j].r) - idiag;
       if (dd < 0) dd = -dd;
       int32_t lim = (int32_t)(DIAG_FACTOR * sep);
@@ -369,6 +382,7 @@ PG_HD void mgaps_strand(const Match* m, int n, int strand, const int32_t* rrec_o
         if (from[i] == -2) continue;
         score[i] = m[i].len; from[i] = -1; adj[i] = 0;
         int seen = 0;
+        int32_t bc = NEG_INF, bj = -1, bol = 0;   // best predecessor; equal scores: the EARLIEST one (mgaps scans j = 0 .. i-1 with a strict >)
         for (int kk = k - 1; kk >= g0 && seen < CHAIN_LOOKBACK; --kk) {
           const int j = order[kk];
           if (from[j] == -2) continue;
@@ -380,8 +394,9 @@ PG_HD void mgaps_strand(const Match* m, int n, int strand, const int32_t* rrec_o
           int32_t dd = (m[i].q - m[i].r) - (m[j].q - m[j].r);
           if (dd < 0) dd = -dd;
           const int32_t cand = score[j] + m[i].len - (ol + dd);
-          if (cand > score[i]) { score[i] = cand; from[i] = j; adj[i] = ol; }
+          if (cand >= bc) { bc = cand; bj = j; bol = ol; }
         }
+        if (bc > score[i]) { score[i] = bc; from[i] = bj; adj[i] = bol; }
         if (best < 0 || score[i] > score[best]) best = i;
       }
       // walk the chain
@@ -403,6 +418,33 @@ PG_HD void mgaps_strand(const Match* m, int n, int strand, const int32_t* rrec_o
     }
     g0 = g1;
   }
+}
+
+// postnuc reads mgaps' clusters in joined-reference coordinates and maps every match back to its record: a cluster whose
+// matches lie in more than one reference record becomes one cluster per run of matches of the same record (the -l 65 test was
+// applied to the whole by mgaps).  In place: the chains keep their order, the pieces of a cut chain take consecutive slots
+// (chains[] must have room for one chain per match).  RREC(ref stream position) -> reference record.  Returns the new count.
+template <typename RREC>
+PG_HD int split_chains_by_ref_record(Chain* chains, int n_chains, const Match* cm, RREC&& rrec_of) {
+  int extra = 0;
+  for (int c = 0; c < n_chains; ++c)
+    for (int k = 1; k < chains[c].count; ++k)
+      if (rrec_of(cm[chains[c].first + k].r) != rrec_of(cm[chains[c].first + k - 1].r)) ++extra;
+  if (!extra) return n_chains;
+  int w = n_chains + extra;
+  for (int c = n_chains - 1; c >= 0; --c) {        // from the back: a chain's pieces land at slots >= its own
+    const Chain C = chains[c];
+    int end = C.first + C.count;
+    for (int k = C.count - 1; k >= 0; --k) {
+      const bool cut = k == 0 || rrec_of(cm[C.first + k].r) != rrec_of(cm[C.first + k - 1].r);
+      if (!cut) continue;
+      Chain p = C;
+      p.first = C.first + k; p.count = end - p.first; p.rrec = rrec_of(cm[p.first].r);
+      chains[--w] = p;
+      end = p.first;
+    }
+  }
+  return n_chains + extra;
 }
 
 // ---- chains -> alignments -------------------------------------------------------------------------------------------

@@ -105,10 +105,16 @@ int main(int argc, char** argv) {
     StrandView Q{H.view(), strand};
     std::vector<Match> mem;
     find_mems(G, Q, strand, mem);
-    int n = mum_filter(mem.data(), (int)mem.size(), strand);
+    const int nq = (int)H.rec_start.size() - 1;
+    int n = (int)mem.size();
+    bool maxmatch = false;
+    for (int i = 3; i < argc; ++i) if (!strcmp(argv[i], "--maxmatch")) maxmatch = true;
+    if (!maxmatch)
+      n = mum_filter(mem.data(), n, strand, [&](int32_t q) { return record_of(H.rec_start.data(), nq, strand ? (int32_t)(H.len - 1 - q) : q); });
+    else
+      std::sort(mem.begin(), mem.end(), [](const Match& a, const Match& b) { return a.q != b.q ? a.q < b.q : (a.len != b.len ? a.len > b.len : a.r < b.r); });
     mem.resize(n);
     std::vector<int32_t> rrec(n), qrec(n), parent(n), score(n), from(n), adj(n), order(n);
-    const int nq = (int)H.rec_start.size() - 1;
     for (int i = 0; i < n; ++i) {
       rrec[i] = record_of(G.rec_start.data(), (int)G.rec_start.size() - 1, mem[i].r);
       const int32_t qf = strand ? (int32_t)(H.len - 1 - mem[i].q) : mem[i].q;
@@ -119,6 +125,7 @@ int main(int argc, char** argv) {
     int n_chains = 0, n_cm = 0;
     mgaps_strand(mem.data(), n, strand, rrec.data(), qrec.data(), parent.data(), score.data(), from.data(), adj.data(),
                  order.data(), chains.data(), n_chains, (int)chains.size(), cm.data(), n_cm, (int)cm.size());
+    n_chains = split_chains_by_ref_record(chains.data(), n_chains, cm.data(), [&](int32_t r) { return record_of(G.rec_start.data(), (int)G.rec_start.size() - 1, r); });
     // order chains by first-match ref start; pick forward targets
     std::vector<int32_t> co(n_chains);
     for (int i = 0; i < n_chains; ++i) co[i] = i;
