@@ -186,7 +186,7 @@ struct AnimScratch {
   size_t tr_arena_cap = 0, tr_out_cap = 0, tr_jobs_cap = 0;
   PnGapTask* pn_tasks = nullptr;    // [3 size classes][pn_cap] small gaps for the lane kernel
   uint32_t* pn_order = nullptr;     // units by descending cluster count
-  size_t pn_cap = 0, pn_units = 0, pn_waves = 0, pn_req_cap = 0;
+  size_t pn_cap = 0, pn_units = 0, pn_waves = 0, pn_req_cap = 0, pn_req_n = 0;   // pn_req_n: slots of pn_reqs the latest launch used (its req_cap)
   // fragment mode (ANIb)
   int32_t* fr_tables = nullptr;     // frag_pos | frag_len | rec_frag0 of every distinct query genome of the batch
   FragPair* fr_pairs = nullptr;
@@ -382,7 +382,7 @@ static int anim_collect(pg_ctx* ctx, AnimScratch* A, const int32_t* ref_ids, con
   PG_HIP(ctx, hipMemcpy(pn_n.data(), A->pn_n, (size_t)n_units * 4, hipMemcpyDeviceToHost));
   PG_HIP(ctx, hipMemcpy(npieces.data(), A->pn_npieces, (size_t)n_units * 4, hipMemcpyDeviceToHost));
   PG_HIP(ctx, hipMemcpy(pieces.data(), A->pn_pieces, piece_total * sizeof(pgn::PnPiece), hipMemcpyDeviceToHost));
-  const size_t req_cap = n_wl + 16;
+  const size_t req_cap = A->pn_req_n;      // as the launch laid the two request lists out
   std::vector<PnForcedReq> reqs(req_cap);
   PG_HIP(ctx, hipMemcpy(reqs.data(), A->pn_reqs, req_cap * sizeof(PnForcedReq), hipMemcpyDeviceToHost));
   // ---- one job per search / forced piece
@@ -901,7 +901,8 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
       if (n_units > A->pn_npieces_cap) { if ((rc = regrow(ctx, A->pn_npieces, (size_t)n_units + 16))) return rc; A->pn_npieces_cap = (size_t)n_units + 16; }
       PG_HIP(ctx, hipMemsetAsync(A->pn_npieces, 0, (size_t)n_units * 4, cur_stream(ctx)));
     }
-    const size_t req_cap = n_wl + 16;
+    const size_t req_cap = Mp + 16;      // one slot per match slot: a walk records at most one forced run per alignment it starts, and starts at most one per match
+    A->pn_req_n = req_cap;
     if (req_cap > A->pn_req_cap) { if ((rc = regrow(ctx, A->pn_reqs, req_cap + req_cap / 2))) return rc; A->pn_req_cap = req_cap + req_cap / 2; }
     PG_HIP(ctx, hipMemsetAsync(A->pn_cursor, 0, 64, cur_stream(ctx)));   // [0] unit cursor, [1] forced runs recorded ([7]: the long ones), [2] forced-run cursor, [3] chain cursor, [4..6] small gaps, [8] cluster cursor of the forward extensions, [9] unit cursor of the rehearsal, [10] cluster cursor of the backward searches
     if (n_wl && trace) PG_HIP(ctx, hipMemcpyAsync(A->choff_d, choff.data(), choff.size() * 4, hipMemcpyHostToDevice, cur_stream(ctx)));

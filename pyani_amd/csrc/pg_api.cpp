@@ -865,8 +865,19 @@ int pg_anim_pair_alignments(pg_ctx* ctx, int32_t ref_id, int32_t qry_id, pg_anim
   return PG_OK;
 }
 
+static int anim_alignments_batch_body(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_ids, uint64_t n_pairs, int maxmatch, int with_indels,
+                                      uint64_t* aln_offsets, uint64_t* n_indels);
+// No exception may cross the C ABI (the call grows host vectors: sink, indel lists, the stored result), and the thread's sink must
+// not outlive the call whichever way it ends.
 int pg_anim_alignments_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_ids, uint64_t n_pairs, int maxmatch, int with_indels,
                              uint64_t* aln_offsets, uint64_t* n_indels) {
+  struct SinkReset { ~SinkReset() { pg_anim_set_sink(nullptr); } } reset;
+  try { return anim_alignments_batch_body(ctx, ref_ids, qry_ids, n_pairs, maxmatch, with_indels, aln_offsets, n_indels); }
+  catch (const std::bad_alloc&) { return pg_fail(ctx, PG_E_NOMEM, "out of host memory while collecting alignment records"); }
+  catch (const std::exception& e) { return pg_fail(ctx, PG_E_INTERNAL, std::string("pg_anim_alignments_batch: ") + e.what()); }
+}
+static int anim_alignments_batch_body(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_ids, uint64_t n_pairs, int maxmatch, int with_indels,
+                                      uint64_t* aln_offsets, uint64_t* n_indels) {
   if (!ctx || !aln_offsets || (n_pairs && (!ref_ids || !qry_ids))) return pg_fail(ctx, PG_E_ARG, "bad argument");
   for (uint64_t i = 0; i < n_pairs; ++i)
     if (ref_ids[i] < 0 || (size_t)ref_ids[i] >= ctx->genomes.size() || qry_ids[i] < 0 || (size_t)qry_ids[i] >= ctx->genomes.size())
