@@ -1,0 +1,360 @@
+// pg_nucmer_diag.h — MUMmer's alignment engine (pg_nucmer_core.h: ScalarEngine / DiagScalarEngine) laid out BY DIAGONAL for a
+// 64-lane wave: lane l holds DPL consecutive diagonals (slots g = DPL l .. DPL l + DPL - 1 of a window of W = 64 DPL diagonals),
+// per slot the best-state word X of the latest cell on that diagonal and its gap states D / I.  Anti-diagonal Dct has cells on the
+// diagonals of its own parity, so a lane computes DPL / 2 cells per step; a cell's left / up neighbours are the adjacent slots
+// (the cells of anti-diagonal Dct - 1), its diagonal neighbour is the slot's own previous word — everything but one slot per step
+// is in the lane's own registers (the column layout of round 3, pga_postnuc.inc pn_align_regs, needs five cross-lane moves per
+// cell and slides its window every other step: ~190 wave instructions per anti-diagonal of ~100 live cells against ~70 here).
+// The base comparisons come from per-slot MATCH WINDOWS: along a diagonal the cells compare a[i + t] with b[j + t], so one XOR
+// of two packed 16-base windows yields the next 16 cells' match bits; they are refilled every 32 anti-diagonals.
+// The band may drift (net indels): when it comes near the window's edge the window is re-centred by whole lanes.
+//
+// This header holds everything that is not a cross-lane operation — the per-lane cell code, the per-step control (ranges, best
+// cell, trimming, finish) and the window bookkeeping — as plain C++ for the device (pga_postnuc_diag.inc: DPP / ballots around
+// it) AND for the host (DiagWaveEmu below: the same code over an array of 64 emulated lanes; tools/anim_debug --diagwave and
+// tests/test_anim_cpu.py hold it against ScalarEngine on the MUMmer fixtures, so the layout is checked before it meets a GPU).
+// Results are those of pgn::ScalarEngine word for word: same cells (MUMmer's dynamic band: grows by one cell per side and
+// anti-diagonal, trimmed at MAX_DIFF below the best, trimmed cells stay readable), same tie order, same riding error counts.
+#pragma once
+#include <stdint.h>
+#include "pg_nucmer_core.h"
+
+namespace pgd {
+using namespace pgn;
+
+template <int DPL> struct DiagRegs { uint32_t X[DPL], D[DPL], I[DPL], mw[DPL]; };   // one lane; mw: match bits of the next 16 cells (bit 2 t)
+
+PG_HD uint32_t spread16(uint32_t m) {      // bit t (t < 16) -> bit 2 t
+  m &= 0xFFFFu;
+  m = (m | (m << 8)) & 0x00FF00FFu;
+  m = (m | (m << 4)) & 0x0F0F0F0Fu;
+  m = (m | (m << 2)) & 0x33333333u;
+  m = (m | (m << 1)) & 0x55555555u;
+  return m;
+}
+
+// ---- per-lane code -------------------------------------------------------------------------------------------------------
+// The cells of one lane on an anti-diagonal of parity PAR: slots s = PAR, PAR + 2, ...  nbX / nbG: the X word and the D (PAR = 0:
+// left neighbour = slot DPL - 1 of the lane below) or I (PAR = 1: up neighbour = slot 0 of the lane above) word that slot needs
+// from the neighbouring lane.  g0 = DPL * lane; slots in [glo, glo + gspan] are computed, the others of this parity are zeroed
+// ("not computed": what their later readers must see).  key / keyw: the lane's best cell as (score field | slot) and its word —
+// ties go to the larger slot = larger column, as MUMmer's ">=" scan does (TRACK = false: forced runs track nothing).
+template <int DPL, int PAR, bool TRACK>
+PG_HD void diag_lane_step(DiagRegs<DPL>& T, uint32_t nbX, uint32_t nbG, uint32_t g0, uint32_t glo, uint32_t gspan, uint32_t& key, uint32_t& keyw) {
+  key = 0u; keyw = 0u;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+  for (int s = PAR; s < DPL; s += 2) {
+    const uint32_t lX = s == 0 ? nbX : T.X[s == 0 ? 0 : s - 1], lD = s == 0 ? nbG : T.D[s == 0 ? 0 : s - 1];
+    const uint32_t uX = s == DPL - 1 ? nbX : T.X[s == DPL - 1 ? s : s + 1], uI = s == DPL - 1 ? nbG : T.I[s == DPL - 1 ? s : s + 1];
+    const uint32_t dc = w_gap(lD, CONT_GAP_SCORE), dx = w_gap(lX, OPEN_GAP_SCORE);
+    const uint32_t ic = w_gap(uI, CONT_GAP_SCORE), ix = w_gap(uX, OPEN_GAP_SCORE);
+    const uint32_t d = w_relabel(dc > dx ? dc : dx, ST_DELETE), i = w_relabel(ic > ix ? ic : ix, ST_INSERT);
+    const uint32_t m = w_relabel(w_step(T.X[s], (T.mw[s] & 1u) != 0u), ST_MATCH);
+    T.mw[s] >>= 2;
+    const uint32_t x = w_max3(d, i, m);
+    const bool in = (uint32_t)(g0 + (uint32_t)s - glo) <= gspan;
+    T.X[s] = in ? x : 0u; T.D[s] = in ? d : 0u; T.I[s] = in ? i : 0u;
+    if (TRACK) {
+      const uint32_t k = in ? ((x & ~(W_ONE - 1u)) | (g0 + (uint32_t)s)) : 0u;
+      if (k >= key) { key = k; keyw = x; }
+    }
+  }
+}
+// which of the lane's cells of this parity survive the trimming (bit s): X >= thr, thr = the word of score high - MAX_DIFF
+template <int DPL, int PAR>
+PG_HD uint32_t diag_lane_alive(const DiagRegs<DPL>& T, uint32_t thr) {
+  uint32_t bits = 0u;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+  for (int s = PAR; s < DPL; s += 2) bits |= (T.X[s] >= thr ? 1u : 0u) << s;
+  return bits;
+}
+// The match windows of one lane, refilled at an anti-diagonal of parity PAR.  Slot s is next computed on anti-diagonal
+// Dct + ((s ^ PAR) & 1); with u = Dct - k0 (k0 = the lane's first diagonal: even) its next cell is row i_s = (u - s + e_s) / 2,
+// e_s = (s ^ PAR) & 1, column j_s = i_s + k0 + s.  ca / oka: the codes (2 bits each) / clean bits of the 32 A rows from row
+// i_{DPL-1} on (field f = row i_{DPL-1} + f: the caller has undone direction and strand), cb / okb: the 32 B columns from column
+// j_0 on.  The offsets of slot s inside the two windows are compile-time constants.
+template <int DPL, int PAR>
+PG_HD void diag_lane_refill(DiagRegs<DPL>& T, uint64_t ca, uint32_t oka, uint64_t cb, uint32_t okb) {
+  constexpr int e_last = ((DPL - 1) ^ PAR) & 1, e_0 = PAR & 1;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+  for (int s = 0; s < DPL; ++s) {
+    const int e_s = (s ^ PAR) & 1;
+    const int oa = (DPL - 1 - s + e_s - e_last) / 2, ob = (s + e_s - e_0) / 2;      // both numerators are even and >= 0
+    const uint32_t a16 = (uint32_t)(ca >> (2 * oa)), b16 = (uint32_t)(cb >> (2 * ob));
+    const uint32_t x = a16 ^ b16;
+    const uint32_t eq = ~(x | (x >> 1)) & 0x55555555u;
+    T.mw[s] = eq & spread16((oka >> oa) & (okb >> ob));
+  }
+}
+// first A row / first B column of the windows diag_lane_refill wants, for a lane whose first diagonal is k0
+template <int DPL, int PAR>
+PG_HD void diag_refill_origin(int32_t Dct, int32_t k0, int32_t& ia0, int32_t& jb0) {
+  constexpr int e_last = ((DPL - 1) ^ PAR) & 1, e_0 = PAR & 1;
+  const int32_t u = Dct - k0;
+  ia0 = (u - (DPL - 1) + e_last) >> 1;      // (even numerators: exact for negative values too)
+  jb0 = ((u + e_0) >> 1) + k0;
+}
+
+// ---- per-step control (wave-uniform) ---------------------------------------------------------------------------------------
+// One engine call: its uniform state and the decisions of every anti-diagonal, as pgn::DiagScalarEngine::run makes them.
+struct DiagCtl {
+  int32_t N, M, band_w, kmin, kmax;
+  bool fwd, forced, optimal;
+  int32_t Dct, ka, kb;              // survivors of the latest anti-diagonal (diagonals)
+  int32_t lo, hi;                   // range of the current one
+  int32_t shiftk;                   // diagonal of slot g: k = g - HALF + shiftk
+  int32_t high, FinishCt, FinishK;
+  uint32_t high_w;
+  unsigned long long cells;
+  int32_t wmax;
+  int32_t next_refill;
+  PG_HD void init(int32_t N_, int32_t M_, unsigned m_o, int32_t band_w_) {
+    N = N_; M = M_; band_w = band_w_;
+    fwd = m_o & DIRECTION_BIT; forced = m_o & FORCED_BIT; optimal = m_o & OPTIMAL_BIT;
+    kmin = (M - N < 0 ? M - N : 0) - band_w; kmax = (M - N > 0 ? M - N : 0) + band_w;
+    Dct = 1; ka = 0; kb = 0; lo = 0; hi = 0; shiftk = 0;
+    high = -(1 << 30); FinishCt = 0; FinishK = 0; high_w = 0u; cells = 0; wmax = 0; next_refill = 1;
+  }
+  // 0: compute anti-diagonal Dct (lo / hi set); 1: the run is over (end of the matrix, break length, band trimmed away);
+  // 2: the band is empty after clipping
+  PG_HD int begin_step() {
+    if (!(Dct <= N + M && (forced || Dct - FinishCt <= BREAK_LEN) && ka <= kb)) return 1;
+    lo = ka - 1; hi = kb + 1;
+    const int32_t c1 = -Dct > Dct - 2 * N ? -Dct : Dct - 2 * N, c2 = 2 * M - Dct < Dct ? 2 * M - Dct : Dct;
+    if (lo < c1) lo = c1;
+    if (hi > c2) hi = c2;
+    if (band_w >= 0) { if (lo < kmin) lo = kmin; if (hi > kmax) hi = kmax; }
+    if ((lo + Dct) & 1) ++lo;
+    if ((hi + Dct) & 1) --hi;
+    return lo > hi ? 2 : 0;
+  }
+  // Slots of the range; returns how many LANES the window has to move (0: fine; INT32_MIN: the band does not fit the window).
+  // The slots lo - 1 and hi + 1 are read, so two slots of margin are kept on either side.
+  template <int DPL>
+  PG_HD int32_t window_check(uint32_t& glo, uint32_t& gspan) const {
+    constexpr int32_t W = 64 * DPL, HALF = W / 2;
+    const int32_t a = lo - shiftk + HALF, b = hi - shiftk + HALF;
+    glo = (uint32_t)a; gspan = (uint32_t)(b - a);
+    if (a >= 2 && b <= W - 3) return 0;
+    if (b - a + 5 > W) return INT32_MIN;
+    int32_t n = ((a + b) / 2 - HALF) / DPL;
+    if (n == 0) n = a < 2 ? -1 : 1;
+    // after the move: a - DPL n >= 2 and b - DPL n <= W - 3 ?
+    if (a - DPL * n < 2 || b - DPL * n > W - 3) return INT32_MIN;
+    return n;
+  }
+  PG_HD void note_cells() {
+    const int32_t w = (hi - lo) / 2 + 1;
+    cells += (unsigned long long)w;
+    if (w > wmax) wmax = w;
+  }
+  // the wave's best cell of this anti-diagonal: gk = (score field | slot), gw its word
+  template <int DPL>
+  PG_HD void update_best(uint32_t gk, uint32_t gw) {
+    constexpr int32_t HALF = 32 * DPL;
+    const int32_t sc = w_score(gk);
+    if (gk != 0u && sc >= high) { high = sc; high_w = gw; FinishCt = Dct; FinishK = (int32_t)(gk & (W_ONE - 1u)) - HALF + shiftk; }
+  }
+  // the word a cell must reach to survive the trimming (cells more than MAX_DIFF below the best score go)
+  PG_HD uint32_t trim_threshold() const {
+    const int32_t t = high - MAX_DIFF + (int32_t)SCORE_BIAS;
+    return t <= 0 ? 0u : ((uint32_t)t << SCORE_SHIFT);
+  }
+  // survivors: the lowest / highest surviving slot (any = false: none)
+  template <int DPL>
+  PG_HD void end_step(bool any, uint32_t gmin, uint32_t gmax) {
+    constexpr int32_t HALF = 32 * DPL;
+    if (forced || trim_threshold() == 0u) { ka = lo; kb = hi; }      // (threshold 0: nothing can be trimmed — and zero words would pass the lanes' test)
+    else if (any) { ka = (int32_t)gmin - HALF + shiftk; kb = (int32_t)gmax - HALF + shiftk; }
+    else { ka = 1; kb = 0; }
+    ++Dct;
+  }
+  // after the loop: where the call finished.  corner_slot: the slot of the target corner (its X word is needed when the corner
+  // counts as reached); returns whether the caller has to deliver that word (finish2) or the best cell's word stands.
+  template <int DPL>
+  PG_HD bool finish1(bool& reached, uint32_t& corner_slot) {
+    constexpr int32_t HALF = 32 * DPL;
+    reached = false;
+    const int32_t last = Dct - 1;
+    corner_slot = 0u;
+    if (last == N + M) {
+      if (!optimal) { reached = true; FinishCt = N + M; FinishK = M - N; corner_slot = (uint32_t)(M - N - shiftk + HALF); return true; }
+      if (FinishCt == last) reached = true;
+    }
+    return false;
+  }
+  PG_HD void finish2(uint32_t fin_w, int32_t Astart, int32_t Bstart, int32_t& Aend, int32_t& Bend, int32_t& errors, int32_t& score) const {
+    const int32_t fi = (FinishCt - FinishK) / 2, fj = (FinishCt + FinishK) / 2;
+    Aend = fwd ? Astart + fi - 1 : Astart - fi + 1;
+    Bend = fwd ? Bstart + fj - 1 : Bstart - fj + 1;
+    errors = (int32_t)w_errors(fin_w);
+    score = w_score(fin_w);
+  }
+};
+
+// ---- host emulation of the wave (the statement of pga_postnuc_diag.inc) ---------------------------------------------------------
+#if !defined(__HIP_DEVICE_COMPILE__)
+template <int DPL, typename RefT, typename QryT>
+struct DiagWaveEmu {
+  static constexpr int W = 64 * DPL, HALF = W / 2;
+  const RefT& R;
+  const QryT& Q;
+  long cells = 0, calls = 0, moves = 0, fails = 0;
+  uint32_t last_cells = 0, last_wmax = 0;
+  DiagRegs<DPL> T[64];
+  template <int PAR>
+  void refill(const DiagCtl& C, int32_t Astart, int32_t Bstart) {
+    for (int l = 0; l < 64; ++l) {
+      const int32_t k0 = DPL * l - HALF + C.shiftk;
+      int32_t ia0, jb0;
+      diag_refill_origin<DPL, PAR>(C.Dct, k0, ia0, jb0);
+      uint64_t ca = 0, cb = 0; uint32_t oka = 0, okb = 0;
+      for (int f = 0; f < 32; ++f) {
+        const int64_t pa = C.fwd ? (int64_t)Astart + (ia0 + f) - 1 : (int64_t)Astart - (ia0 + f) + 1;
+        const int64_t pb = C.fwd ? (int64_t)Bstart + (jb0 + f) - 1 : (int64_t)Bstart - (jb0 + f) + 1;
+        if (R.clean(pa)) { ca |= (uint64_t)R.base(pa) << (2 * f); oka |= 1u << f; }
+        if (Q.clean(pb)) { cb |= (uint64_t)Q.base(pb) << (2 * f); okb |= 1u << f; }
+      }
+      diag_lane_refill<DPL, PAR>(T[l], ca, oka, cb, okb);
+    }
+  }
+  template <int PAR, bool TRACK>
+  void step(DiagCtl& C, uint32_t glo, uint32_t gspan) {
+    uint32_t nbX[64], nbG[64], key[64], keyw[64];
+    for (int l = 0; l < 64; ++l) {
+      if (PAR == 0) { nbX[l] = l > 0 ? T[l - 1].X[DPL - 1] : 0u; nbG[l] = l > 0 ? T[l - 1].D[DPL - 1] : 0u; }
+      else { nbX[l] = l < 63 ? T[l + 1].X[0] : 0u; nbG[l] = l < 63 ? T[l + 1].I[0] : 0u; }
+    }
+    for (int l = 0; l < 64; ++l) diag_lane_step<DPL, PAR, TRACK>(T[l], nbX[l], nbG[l], (uint32_t)(DPL * l), glo, gspan, key[l], keyw[l]);
+    if (TRACK) {
+      uint32_t gk = 0, gw = 0;
+      for (int l = 0; l < 64; ++l) if (key[l] > gk) { gk = key[l]; gw = keyw[l]; }      // (keys are unique: they carry the slot)
+      C.template update_best<DPL>(gk, gw);
+    }
+    bool any = false; uint32_t gmin = 0, gmax = 0;
+    if (!C.forced) {
+      const uint32_t thr = C.trim_threshold();
+      for (int l = 0; l < 64; ++l) {
+        const uint32_t bits = diag_lane_alive<DPL, PAR>(T[l], thr);
+        for (int s = PAR; s < DPL; s += 2)
+          if ((bits >> s) & 1u) { const uint32_t g = (uint32_t)(DPL * l + s); if (!any) { gmin = g; any = true; } gmax = g; }
+      }
+    }
+    C.template end_step<DPL>(any, gmin, gmax);
+  }
+  // as pgn::ScalarEngine::run (band_w < 0: MUMmer's own band).  false: the band did not fit the window (nothing is returned).
+  bool run(int32_t Astart, int32_t& Aend, int32_t Bstart, int32_t& Bend, unsigned m_o, int32_t band_w, int32_t& errors, int32_t& score, bool& reached) {
+    DiagCtl C;
+    const bool fwd = m_o & DIRECTION_BIT;
+    C.init(fwd ? Aend - Astart + 1 : Astart - Aend + 1, fwd ? Bend - Bstart + 1 : Bstart - Bend + 1, m_o, band_w);
+    for (int l = 0; l < 64; ++l) for (int s = 0; s < DPL; ++s) { T[l].X[s] = 0u; T[l].D[s] = 0u; T[l].I[s] = 0u; T[l].mw[s] = 0u; }
+    T[HALF / DPL].X[0] = w_make(0, 0, ST_MATCH);
+    ++calls;
+    for (;;) {
+      const int why = C.begin_step();
+      if (why) break;
+      uint32_t glo, gspan;
+      int32_t n = C.template window_check<DPL>(glo, gspan);
+      if (n == INT32_MIN) { ++fails; return false; }
+      if (n != 0) {
+        DiagRegs<DPL> Z;
+        for (int s = 0; s < DPL; ++s) { Z.X[s] = 0u; Z.D[s] = 0u; Z.I[s] = 0u; Z.mw[s] = 0u; }
+        DiagRegs<DPL> U[64];
+        for (int l = 0; l < 64; ++l) U[l] = (l + n >= 0 && l + n < 64) ? T[l + n] : Z;
+        for (int l = 0; l < 64; ++l) T[l] = U[l];
+        C.shiftk += DPL * n;
+        C.next_refill = C.Dct;
+        ++moves;
+        n = C.template window_check<DPL>(glo, gspan);
+        if (n != 0) { ++fails; return false; }
+      }
+      if (C.Dct == C.next_refill) { if (C.Dct & 1) refill<1>(C, Astart, Bstart); else refill<0>(C, Astart, Bstart); C.next_refill = C.Dct + 32; }
+      C.note_cells();
+      if (C.Dct & 1) { if (C.forced) step<1, false>(C, glo, gspan); else step<1, true>(C, glo, gspan); }
+      else { if (C.forced) step<0, false>(C, glo, gspan); else step<0, true>(C, glo, gspan); }
+    }
+    uint32_t corner = 0, fin_w = C.high_w;
+    if (C.template finish1<DPL>(reached, corner)) fin_w = T[corner / DPL].X[corner % DPL];
+    C.finish2(fin_w, Astart, Bstart, Aend, Bend, errors, score);
+    cells += (long)C.cells;
+    last_cells = C.cells > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)C.cells; last_wmax = (uint32_t)C.wmax;
+    return true;
+  }
+};
+
+// The engine postnuc_unit is given when the host statement runs on the emulated wave engines: trimmed searches / alignments on
+// the 256-diagonal window, forced runs on the window that holds their certified band (256 ... 2048 diagonals), anything that
+// does not fit on pgn::ScalarEngine — the dispatch of the GPU's PnWaveEngine (pga_postnuc.inc).
+template <typename RefT, typename QryT>
+struct DiagWaveEngine {
+  ScalarEngine<RefT, QryT> slow;
+  DiagWaveEmu<4, RefT, QryT> e4;
+  DiagWaveEmu<8, RefT, QryT> e8;
+  DiagWaveEmu<16, RefT, QryT> e16;
+  DiagWaveEmu<32, RefT, QryT> e32;
+  long fallbacks = 0;
+  DiagWaveEngine(const RefT& R, const QryT& Q, Cell* d0, Cell* d1, Cell* d2, int32_t cap)
+      : slow{R, Q, d0, d1, d2, cap}, e4{R, Q}, e8{R, Q}, e16{R, Q}, e32{R, Q} {}
+  bool gap_ready(int32_t, PnGap&) const { return false; }
+  void piece(uint32_t, int32_t, int32_t, int32_t, int32_t, int32_t, int32_t, int32_t, unsigned) {}
+  bool bwd_ready(int, PnBwd&) const { return false; }
+  void bwd_key(int, int32_t, int32_t, int32_t, int32_t, unsigned) {}
+  bool fwd_ready(int, PnFwd&) const { return false; }
+  int32_t forced_errors(int32_t A0, int32_t A1, int32_t B0, int32_t B1, PnAln*) {
+    int32_t err = 0, a = A1, b = B1;
+    align(A0, a, B0, b, FORCED_FORWARD_ALIGN, err);
+    return err;
+  }
+  bool shadowed(const Chain* chains, const PnAln* al, int from, int c, int32_t sA, int32_t eA, int32_t sB, int32_t eB) const {
+    return PnScalarScans().shadowed(chains, al, from, c, sA, eA, sB, eB); }
+  int reverse_target(const Chain* chains, const PnAln* al, int cura, int c, int32_t sA, int32_t sB, int32_t dist) const {
+    return PnScalarScans().reverse_target(chains, al, cura, c, sA, sB, dist); }
+  int forward_target(const Chain* chains, const Match* cm, const int32_t* order, int n, int curk, int c, int32_t sA, int32_t sB,
+                     int32_t dist, int32_t& targetA, int32_t& targetB) const {
+    return PnScalarScans().forward_target(chains, cm, order, n, curk, c, sA, sB, dist, targetA, targetB); }
+  // diagonals a run needs in its window (band_w < 0: MUMmer's own band -> the narrow window)
+  static int window_for(int32_t N, int32_t M, unsigned m_o, int32_t band_w) {
+    if (!(m_o & FORCED_BIT)) return 256;
+    const int32_t df = N < M ? M - N : N - M;
+    const int64_t span = band_w >= 0 ? (int64_t)df + 2 * (int64_t)band_w + 1 : (int64_t)N + M + 1;
+    return span + 5 <= 256 ? 256 : span + 5 <= 512 ? 512 : span + 5 <= 1024 ? 1024 : span + 5 <= 2048 ? 2048 : 0;
+  }
+  bool run(int32_t Astart, int32_t& Aend, int32_t Bstart, int32_t& Bend, unsigned m_o, int32_t band_w, int32_t& errors, int32_t& score) {
+    const bool fwd = m_o & DIRECTION_BIT;
+    const int32_t N = fwd ? Aend - Astart + 1 : Astart - Aend + 1, M = fwd ? Bend - Bstart + 1 : Bstart - Bend + 1;
+    int32_t a = Aend, b = Bend;
+    bool reached = false, done = false;
+    switch (window_for(N, M, m_o, band_w)) {
+      case 256: done = e4.run(Astart, a, Bstart, b, m_o, band_w, errors, score, reached); break;
+      case 512: done = e8.run(Astart, a, Bstart, b, m_o, band_w, errors, score, reached); break;
+      case 1024: done = e16.run(Astart, a, Bstart, b, m_o, band_w, errors, score, reached); break;
+      case 2048: done = e32.run(Astart, a, Bstart, b, m_o, band_w, errors, score, reached); break;
+      default: break;
+    }
+    if (done) { Aend = a; Bend = b; return reached; }
+    ++fallbacks;
+    return slow.run(Astart, Aend, Bstart, Bend, m_o, band_w, errors, &score);
+  }
+  bool align(int32_t Astart, int32_t& Aend, int32_t Bstart, int32_t& Bend, unsigned m_o, int32_t& errors) {
+    int32_t score = 0;
+    if (!(m_o & FORCED_BIT)) return run(Astart, Aend, Bstart, Bend, m_o, -1, errors, score);
+    const bool fwd = m_o & DIRECTION_BIT;
+    const int32_t N = fwd ? Aend - Astart + 1 : Astart - Aend + 1, M = fwd ? Bend - Bstart + 1 : Bstart - Bend + 1;
+    for (int32_t w = FORCED_BAND_FIRST;;) {
+      int32_t a = Aend, b = Bend;
+      const bool whole = w >= (N > M ? N : M);
+      const bool reached = run(Astart, a, Bstart, b, m_o, whole ? -1 : w, errors, score);
+      if (slow.overflow || whole || (reached && (int64_t)score > forced_outside_bound(N, M, w))) { Aend = a; Bend = b; return reached; }
+      w = forced_band_after(w, N, M, score);
+    }
+  }
+};
+#endif
+
+}  // namespace pgd

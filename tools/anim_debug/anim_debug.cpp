@@ -12,6 +12,7 @@
 #include <vector>
 #include "pg_anim_core.h"
 #include "pg_nucmer_core.h"
+#include "pg_nucmer_diag.h"
 #include "pg_anim_trace.h"
 using namespace pga;
 
@@ -170,14 +171,21 @@ int main(int argc, char** argv) {
         eng.bwd = bwd.data();
         fprintf(stderr, "backward searches run ahead: %ld (%ld cells); ", predicted, ahead_cells);
       }
-      const int na = getenv("ANIM_DIAG") ? pgn::postnuc_unit(deng, chains.data(), cm.data(), co.data(), n_chains, bounds_of, fused.data(), al.data(), (int)al.size())
+      // ANIM_DIAGWAVE: the diagonal-layout wave engines of the GPU (pg_nucmer_diag.h), emulated lane by lane, under the same walk
+      pgd::DiagWaveEngine<SeqView, StrandView> weng(R, Q, d0.data(), d1.data(), d2.data(), cap);
+      const int na = getenv("ANIM_DIAGWAVE") ? pgn::postnuc_unit(weng, chains.data(), cm.data(), co.data(), n_chains, bounds_of, fused.data(), al.data(), (int)al.size())
+                   : getenv("ANIM_DIAG") ? pgn::postnuc_unit(deng, chains.data(), cm.data(), co.data(), n_chains, bounds_of, fused.data(), al.data(), (int)al.size())
                                          : pgn::postnuc_unit(eng, chains.data(), cm.data(), co.data(), n_chains,
           [&](int c, int32_t& rl, int32_t& rh, int32_t& ql, int32_t& qh) {
             rl = G.rec_start[chains[c].rrec]; rh = G.rec_start[chains[c].rrec + 1] - 1;
             ql = H.rec_start[chains[c].qrec]; qh = H.rec_start[chains[c].qrec + 1] - 1;
             if (strand) { const int32_t a = (int32_t)H.len - qh, b = (int32_t)H.len - ql; ql = a; qh = b; } },
           fused.data(), al.data(), (int)al.size());
-      if (na < 0 || eng.overflow || deng.slow.overflow) { fprintf(stderr, "postnuc statement: capacity exceeded\n"); return 3; }
+      if (getenv("ANIM_DIAGWAVE"))
+        fprintf(stderr, "diag-wave engines: calls %ld / %ld / %ld / %ld (256 / 512 / 1024 / 2048 diagonals), window moves %ld, did not fit %ld, fell back to the scalar engine %ld, cells %ld + %ld\n",
+                weng.e4.calls, weng.e8.calls, weng.e16.calls, weng.e32.calls, weng.e4.moves + weng.e8.moves + weng.e16.moves + weng.e32.moves,
+                weng.e4.fails + weng.e8.fails + weng.e16.fails + weng.e32.fails, weng.fallbacks, weng.e4.cells + weng.e8.cells + weng.e16.cells + weng.e32.cells, weng.slow.cells);
+      if (na < 0 || eng.overflow || deng.slow.overflow || weng.slow.overflow) { fprintf(stderr, "postnuc statement: capacity exceeded\n"); return 3; }
       exact_cells += eng.cells + deng.fast.cells + deng.slow.cells;
       if (!bwd.empty()) fprintf(stderr, "the walk still ran %ld itself (%ld cells)\n", eng.searches, eng.search_cells);
       if (want_delta) {
