@@ -31,6 +31,7 @@
 #include "pg_internal.h"
 #include "pg_anim_core.h"
 #include "pg_nucmer_core.h"
+#include "pg_nucmer_diag.h"
 #include "pg_anib_core.h"
 #include "pg_anim_trace.h"
 

@@ -24,6 +24,18 @@ using namespace pgn;
 
 template <int DPL> struct DiagRegs { uint32_t X[DPL], D[DPL], I[DPL], mw[DPL]; };   // one lane; mw: match bits of the next 16 cells (bit 2 t)
 
+PG_HD uint32_t rev16_fields(uint32_t x) {      // the sixteen 2-bit fields of x in reverse order
+#if defined(__HIP_DEVICE_COMPILE__)
+  x = __brev(x);
+#else
+  x = ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);
+  x = ((x >> 2) & 0x33333333u) | ((x & 0x33333333u) << 2);
+  x = ((x >> 4) & 0x0F0F0F0Fu) | ((x & 0x0F0F0F0Fu) << 4);
+  x = ((x >> 8) & 0x00FF00FFu) | ((x & 0x00FF00FFu) << 8);
+  x = (x >> 16) | (x << 16);
+#endif
+  return ((x & 0x55555555u) << 1) | ((x >> 1) & 0x55555555u);
+}
 PG_HD uint32_t spread16(uint32_t m) {      // bit t (t < 16) -> bit 2 t
   m &= 0xFFFFu;
   m = (m | (m << 8)) & 0x00FF00FFu;
@@ -38,10 +50,15 @@ PG_HD uint32_t spread16(uint32_t m) {      // bit t (t < 16) -> bit 2 t
 // left neighbour = slot DPL - 1 of the lane below) or I (PAR = 1: up neighbour = slot 0 of the lane above) word that slot needs
 // from the neighbouring lane.  g0 = DPL * lane; slots in [glo, glo + gspan] are computed, the others of this parity are zeroed
 // ("not computed": what their later readers must see).  key / keyw: the lane's best cell as (score field | slot) and its word —
-// ties go to the larger slot = larger column, as MUMmer's ">=" scan does (TRACK = false: forced runs track nothing).
+// ties go to the larger slot = larger column, as MUMmer's ">=" scan does (TRACK = false: forced runs track nothing).  A slot
+// outside the range has a zero word, i.e. key = its slot number with score field 0: below every reachable cell's key.
+// relmask = ~W_STATE, handed in so that the device keeps it in a scalar register (v_and_or_b32 takes one literal, not two).
+// The match bit of a slot's next cell is the TOP bit of its window (tested as a sign), the window moves up two bits per cell.
 template <int DPL, int PAR, bool TRACK>
-PG_HD void diag_lane_step(DiagRegs<DPL>& T, uint32_t nbX, uint32_t nbG, uint32_t g0, uint32_t glo, uint32_t gspan, uint32_t& key, uint32_t& keyw) {
+PG_HD void diag_lane_step(DiagRegs<DPL>& T, uint32_t nbX, uint32_t nbG, uint32_t g0, uint32_t glo, uint32_t gspan, uint32_t relmask,
+                          uint32_t& key, uint32_t& keyw) {
   key = 0u; keyw = 0u;
+  const uint32_t rel = g0 - glo;
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
@@ -50,15 +67,15 @@ PG_HD void diag_lane_step(DiagRegs<DPL>& T, uint32_t nbX, uint32_t nbG, uint32_t
     const uint32_t uX = s == DPL - 1 ? nbX : T.X[s == DPL - 1 ? s : s + 1], uI = s == DPL - 1 ? nbG : T.I[s == DPL - 1 ? s : s + 1];
     const uint32_t dc = w_gap(lD, CONT_GAP_SCORE), dx = w_gap(lX, OPEN_GAP_SCORE);
     const uint32_t ic = w_gap(uI, CONT_GAP_SCORE), ix = w_gap(uX, OPEN_GAP_SCORE);
-    const uint32_t d = w_relabel(dc > dx ? dc : dx, ST_DELETE), i = w_relabel(ic > ix ? ic : ix, ST_INSERT);
-    const uint32_t m = w_relabel(w_step(T.X[s], (T.mw[s] & 1u) != 0u), ST_MATCH);
-    T.mw[s] >>= 2;
+    const uint32_t d = ((dc > dx ? dc : dx) & relmask) | ST_DELETE, i = ((ic > ix ? ic : ix) & relmask) | ST_INSERT;
+    const uint32_t m = (w_step(T.X[s], (int32_t)T.mw[s] < 0) & relmask) | ST_MATCH;
+    T.mw[s] <<= 2;
     const uint32_t x = w_max3(d, i, m);
-    const bool in = (uint32_t)(g0 + (uint32_t)s - glo) <= gspan;
+    const bool in = (uint32_t)(rel + (uint32_t)s) <= gspan;
     T.X[s] = in ? x : 0u; T.D[s] = in ? d : 0u; T.I[s] = in ? i : 0u;
     if (TRACK) {
-      const uint32_t k = in ? ((x & ~(W_ONE - 1u)) | (g0 + (uint32_t)s)) : 0u;
-      if (k >= key) { key = k; keyw = x; }
+      const uint32_t k = (T.X[s] & ~(W_ONE - 1u)) | (g0 + (uint32_t)s);
+      if (k >= key) { key = k; keyw = T.X[s]; }
     }
   }
 }
@@ -66,9 +83,6 @@ PG_HD void diag_lane_step(DiagRegs<DPL>& T, uint32_t nbX, uint32_t nbG, uint32_t
 template <int DPL, int PAR>
 PG_HD uint32_t diag_lane_alive(const DiagRegs<DPL>& T, uint32_t thr) {
   uint32_t bits = 0u;
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
   for (int s = PAR; s < DPL; s += 2) bits |= (T.X[s] >= thr ? 1u : 0u) << s;
   return bits;
 }
@@ -89,7 +103,8 @@ PG_HD void diag_lane_refill(DiagRegs<DPL>& T, uint64_t ca, uint32_t oka, uint64_
     const uint32_t a16 = (uint32_t)(ca >> (2 * oa)), b16 = (uint32_t)(cb >> (2 * ob));
     const uint32_t x = a16 ^ b16;
     const uint32_t eq = ~(x | (x >> 1)) & 0x55555555u;
-    T.mw[s] = eq & spread16((oka >> oa) & (okb >> ob));
+    // cell t of the slot at bit 31 - 2 t: the fields in reverse order, one bit up
+    T.mw[s] = rev16_fields((eq & spread16((oka >> oa) & (okb >> ob)))) << 1;
   }
 }
 // first A row / first B column of the windows diag_lane_refill wants, for a lane whose first diagonal is k0
@@ -122,16 +137,26 @@ struct DiagCtl {
     high = -(1 << 30); FinishCt = 0; FinishK = 0; high_w = 0u; cells = 0; wmax = 0; next_refill = 1;
   }
   // 0: compute anti-diagonal Dct (lo / hi set); 1: the run is over (end of the matrix, break length, band trimmed away);
-  // 2: the band is empty after clipping
+  // 2: the band is empty after clipping.  FORCED is a template argument so that a search's step carries none of the band
+  // arithmetic (the per-step control is scalar code, and a CU has ONE scalar unit for its four SIMDs: with the cells down to
+  // ~80 vector instructions per step, 130 scalar ones per step were the bound).
+  // The band grows by one diagonal per side and anti-diagonal from the single cell of anti-diagonal 0, so it can never overtake
+  // the matrix's near corner (lo >= -Dct, hi <= Dct hold by themselves): only the far sides clip, at Dct - 2 N and 2 M - Dct —
+  // which have the parity of Dct, as ka - 1 and kb + 1 do: a search's range needs no parity fix; a forced band's limits do.
+  template <bool FORCED>
   PG_HD int begin_step() {
-    if (!(Dct <= N + M && (forced || Dct - FinishCt <= BREAK_LEN) && ka <= kb)) return 1;
+    if (FORCED) { if (Dct > N + M) return 1; }
+    else if (!(Dct <= N + M && Dct - FinishCt <= BREAK_LEN && ka <= kb)) return 1;
     lo = ka - 1; hi = kb + 1;
-    const int32_t c1 = -Dct > Dct - 2 * N ? -Dct : Dct - 2 * N, c2 = 2 * M - Dct < Dct ? 2 * M - Dct : Dct;
+    const int32_t c1 = Dct - 2 * N, c2 = 2 * M - Dct;
     if (lo < c1) lo = c1;
     if (hi > c2) hi = c2;
-    if (band_w >= 0) { if (lo < kmin) lo = kmin; if (hi > kmax) hi = kmax; }
-    if ((lo + Dct) & 1) ++lo;
-    if ((hi + Dct) & 1) --hi;
+    if (FORCED && band_w >= 0) {
+      if (lo < kmin) lo = kmin;
+      if (hi > kmax) hi = kmax;
+      if ((lo + Dct) & 1) ++lo;
+      if ((hi + Dct) & 1) --hi;
+    }
     return lo > hi ? 2 : 0;
   }
   // Slots of the range; returns how many LANES the window has to move (0: fine; INT32_MIN: the band does not fit the window).
@@ -149,11 +174,14 @@ struct DiagCtl {
     if (a - DPL * n < 2 || b - DPL * n > W - 3) return INT32_MIN;
     return n;
   }
+  // bookkeeping of the call (cells computed, widest anti-diagonal: what a traceback of the same call has to store).  `cells` holds
+  // the sum of (hi - lo) until cells_total() folds the step count in: two scalar instructions per step.
+  template <bool WIDEST>
   PG_HD void note_cells() {
-    const int32_t w = (hi - lo) / 2 + 1;
-    cells += (unsigned long long)w;
-    if (w > wmax) wmax = w;
+    cells += (unsigned long long)(uint32_t)(hi - lo);
+    if (WIDEST) { const int32_t w = (hi - lo) / 2 + 1; if (w > wmax) wmax = w; }
   }
+  PG_HD unsigned long long cells_total(int32_t steps) const { return cells / 2 + (unsigned long long)steps; }
   // the wave's best cell of this anti-diagonal: gk = (score field | slot), gw its word
   template <int DPL>
   PG_HD void update_best(uint32_t gk, uint32_t gw) {
@@ -162,15 +190,14 @@ struct DiagCtl {
     if (gk != 0u && sc >= high) { high = sc; high_w = gw; FinishCt = Dct; FinishK = (int32_t)(gk & (W_ONE - 1u)) - HALF + shiftk; }
   }
   // the word a cell must reach to survive the trimming (cells more than MAX_DIFF below the best score go)
-  PG_HD uint32_t trim_threshold() const {
-    const int32_t t = high - MAX_DIFF + (int32_t)SCORE_BIAS;
-    return t <= 0 ? 0u : ((uint32_t)t << SCORE_SHIFT);
-  }
+  // (high >= -10 after the first anti-diagonal of a search — its cells are one step from the origin — and never falls: the
+  // threshold is a positive word, so a zero word, i.e. a slot outside the computed range, never counts as a survivor)
+  PG_HD uint32_t trim_threshold() const { return (uint32_t)(high - MAX_DIFF + (int32_t)SCORE_BIAS) << SCORE_SHIFT; }
   // survivors: the lowest / highest surviving slot (any = false: none)
-  template <int DPL>
+  template <int DPL, bool FORCED>
   PG_HD void end_step(bool any, uint32_t gmin, uint32_t gmax) {
     constexpr int32_t HALF = 32 * DPL;
-    if (forced || trim_threshold() == 0u) { ka = lo; kb = hi; }      // (threshold 0: nothing can be trimmed — and zero words would pass the lanes' test)
+    if (FORCED) { ka = lo; kb = hi; }
     else if (any) { ka = (int32_t)gmin - HALF + shiftk; kb = (int32_t)gmax - HALF + shiftk; }
     else { ka = 1; kb = 0; }
     ++Dct;
@@ -231,7 +258,7 @@ struct DiagWaveEmu {
       if (PAR == 0) { nbX[l] = l > 0 ? T[l - 1].X[DPL - 1] : 0u; nbG[l] = l > 0 ? T[l - 1].D[DPL - 1] : 0u; }
       else { nbX[l] = l < 63 ? T[l + 1].X[0] : 0u; nbG[l] = l < 63 ? T[l + 1].I[0] : 0u; }
     }
-    for (int l = 0; l < 64; ++l) diag_lane_step<DPL, PAR, TRACK>(T[l], nbX[l], nbG[l], (uint32_t)(DPL * l), glo, gspan, key[l], keyw[l]);
+    for (int l = 0; l < 64; ++l) diag_lane_step<DPL, PAR, TRACK>(T[l], nbX[l], nbG[l], (uint32_t)(DPL * l), glo, gspan, ~W_STATE, key[l], keyw[l]);
     if (TRACK) {
       uint32_t gk = 0, gw = 0;
       for (int l = 0; l < 64; ++l) if (key[l] > gk) { gk = key[l]; gw = keyw[l]; }      // (keys are unique: they carry the slot)
@@ -246,7 +273,7 @@ struct DiagWaveEmu {
           if ((bits >> s) & 1u) { const uint32_t g = (uint32_t)(DPL * l + s); if (!any) { gmin = g; any = true; } gmax = g; }
       }
     }
-    C.template end_step<DPL>(any, gmin, gmax);
+    if (C.forced) C.template end_step<DPL, true>(any, gmin, gmax); else C.template end_step<DPL, false>(any, gmin, gmax);
   }
   // as pgn::ScalarEngine::run (band_w < 0: MUMmer's own band).  false: the band did not fit the window (nothing is returned).
   bool run(int32_t Astart, int32_t& Aend, int32_t Bstart, int32_t& Bend, unsigned m_o, int32_t band_w, int32_t& errors, int32_t& score, bool& reached) {
@@ -256,8 +283,9 @@ struct DiagWaveEmu {
     for (int l = 0; l < 64; ++l) for (int s = 0; s < DPL; ++s) { T[l].X[s] = 0u; T[l].D[s] = 0u; T[l].I[s] = 0u; T[l].mw[s] = 0u; }
     T[HALF / DPL].X[0] = w_make(0, 0, ST_MATCH);
     ++calls;
+    int32_t steps_done = 0;
     for (;;) {
-      const int why = C.begin_step();
+      const int why = C.forced ? C.template begin_step<true>() : C.template begin_step<false>();
       if (why) break;
       uint32_t glo, gspan;
       int32_t n = C.template window_check<DPL>(glo, gspan);
@@ -275,15 +303,17 @@ struct DiagWaveEmu {
         if (n != 0) { ++fails; return false; }
       }
       if (C.Dct == C.next_refill) { if (C.Dct & 1) refill<1>(C, Astart, Bstart); else refill<0>(C, Astart, Bstart); C.next_refill = C.Dct + 32; }
-      C.note_cells();
+      C.template note_cells<true>();
+      ++steps_done;
       if (C.Dct & 1) { if (C.forced) step<1, false>(C, glo, gspan); else step<1, true>(C, glo, gspan); }
       else { if (C.forced) step<0, false>(C, glo, gspan); else step<0, true>(C, glo, gspan); }
     }
     uint32_t corner = 0, fin_w = C.high_w;
     if (C.template finish1<DPL>(reached, corner)) fin_w = T[corner / DPL].X[corner % DPL];
     C.finish2(fin_w, Astart, Bstart, Aend, Bend, errors, score);
-    cells += (long)C.cells;
-    last_cells = C.cells > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)C.cells; last_wmax = (uint32_t)C.wmax;
+    const unsigned long long nc = C.cells_total(steps_done);
+    cells += (long)nc;
+    last_cells = nc > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)nc; last_wmax = (uint32_t)C.wmax;
     return true;
   }
 };
