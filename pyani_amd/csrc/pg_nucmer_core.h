@@ -243,15 +243,17 @@ struct PnScalarScans {
 // successive bands fill the GPU's register engines of 127 / 255 / 511 / 1023 cells).
 constexpr int32_t FORCED_BAND_FIRST = 28;
 PG_HD int32_t forced_band_next(int32_t w) { return 2 * w + 4; }
-// The band to try after band w gave score S without a certificate: a wider band can only score higher, so the first band of the
-// sequence with  17 (w' + 1) > 3 min(N, M) - 7 |M - N| - 6 - S  is certain to certify — the ones before it are skipped (a run
-// over divergent sequence would otherwise be repeated at every size on its way up to the whole rectangle).
+// The band to try after band w gave score S without a certificate: a wider band can only score higher, so the first width w'
+// with  17 (w' + 1) > 3 min(N, M) - 7 |M - N| - 6 - S  is CERTAIN to certify — and nothing wider is needed: the run's cells grow
+// with w'.  (Rounds 1-3 went up a doubling sequence 28, 60, 124, ... to fill fixed register engines: a run that needed w = 1100
+// was computed at 2044.  The diagonal-window engines of round 4 take any width.)
 PG_HD int32_t forced_band_after(int32_t w, int32_t N, int32_t M, int32_t S) {
   const int64_t mn = N < M ? N : M, df = N < M ? M - N : N - M;
   const int64_t need = ((int64_t)GOOD_SCORE * mn + (int64_t)CONT_GAP_SCORE * df + 2 * (OPEN_GAP_SCORE - CONT_GAP_SCORE) - S) / (GOOD_SCORE - 2 * CONT_GAP_SCORE);
-  int32_t nw = forced_band_next(w);
-  while (nw < need && nw < (N > M ? N : M)) nw = forced_band_next(nw);
-  return nw;
+  const int64_t mx = N > M ? N : M;
+  int64_t nw = need > (int64_t)w + 1 ? need : (int64_t)w + 1;
+  nw = (nw + 3) & ~(int64_t)3;
+  return (int32_t)(nw < mx ? nw : mx);
 }
 PG_HD int64_t forced_outside_bound(int32_t N, int32_t M, int32_t w) {
   const int64_t mn = N < M ? N : M, df = N < M ? M - N : N - M;

@@ -52,13 +52,16 @@ PG_HD uint32_t spread16(uint32_t m) {      // bit t (t < 16) -> bit 2 t
 // ("not computed": what their later readers must see).  key / keyw: the lane's best cell as (score field | slot) and its word —
 // ties go to the larger slot = larger column, as MUMmer's ">=" scan does (TRACK = false: forced runs track nothing).  A slot
 // outside the range has a zero word, i.e. key = its slot number with score field 0: below every reachable cell's key.
-// relmask = ~W_STATE, handed in so that the device keeps it in a scalar register (v_and_or_b32 takes one literal, not two).
+// rel = {~W_STATE, ST_INSERT, ST_MATCH} handed in as values: on the device the mask sits in a scalar register and the two labels
+// in vector registers, so that a re-labelling is ONE v_and_or_b32 (a VOP3 instruction of this ISA takes no literal and reads the
+// constant bus once; as literals the compiler needs v_and + v_or).
 // The match bit of a slot's next cell is the TOP bit of its window (tested as a sign), the window moves up two bits per cell.
+struct DiagRelabel { uint32_t mask, st_insert, st_match; };
 template <int DPL, int PAR, bool TRACK>
-PG_HD void diag_lane_step(DiagRegs<DPL>& T, uint32_t nbX, uint32_t nbG, uint32_t g0, uint32_t glo, uint32_t gspan, uint32_t relmask,
+PG_HD void diag_lane_step(DiagRegs<DPL>& T, uint32_t nbX, uint32_t nbG, uint32_t g0, uint32_t glo, uint32_t gspan, const DiagRelabel& rel,
                           uint32_t& key, uint32_t& keyw) {
   key = 0u; keyw = 0u;
-  const uint32_t rel = g0 - glo;
+  const uint32_t gofs = g0 - glo;
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
@@ -67,11 +70,11 @@ PG_HD void diag_lane_step(DiagRegs<DPL>& T, uint32_t nbX, uint32_t nbG, uint32_t
     const uint32_t uX = s == DPL - 1 ? nbX : T.X[s == DPL - 1 ? s : s + 1], uI = s == DPL - 1 ? nbG : T.I[s == DPL - 1 ? s : s + 1];
     const uint32_t dc = w_gap(lD, CONT_GAP_SCORE), dx = w_gap(lX, OPEN_GAP_SCORE);
     const uint32_t ic = w_gap(uI, CONT_GAP_SCORE), ix = w_gap(uX, OPEN_GAP_SCORE);
-    const uint32_t d = ((dc > dx ? dc : dx) & relmask) | ST_DELETE, i = ((ic > ix ? ic : ix) & relmask) | ST_INSERT;
-    const uint32_t m = (w_step(T.X[s], (int32_t)T.mw[s] < 0) & relmask) | ST_MATCH;
+    const uint32_t d = (dc > dx ? dc : dx) & rel.mask /* | ST_DELETE = 0 */, i = ((ic > ix ? ic : ix) & rel.mask) | rel.st_insert;
+    const uint32_t m = (w_step(T.X[s], (int32_t)T.mw[s] < 0) & rel.mask) | rel.st_match;
     T.mw[s] <<= 2;
     const uint32_t x = w_max3(d, i, m);
-    const bool in = (uint32_t)(rel + (uint32_t)s) <= gspan;
+    const bool in = (uint32_t)(gofs + (uint32_t)s) <= gspan;
     T.X[s] = in ? x : 0u; T.D[s] = in ? d : 0u; T.I[s] = in ? i : 0u;
     if (TRACK) {
       const uint32_t k = (T.X[s] & ~(W_ONE - 1u)) | (g0 + (uint32_t)s);
@@ -117,106 +120,117 @@ PG_HD void diag_refill_origin(int32_t Dct, int32_t k0, int32_t& ia0, int32_t& jb
 }
 
 // ---- per-step control (wave-uniform) ---------------------------------------------------------------------------------------
-// One engine call: its uniform state and the decisions of every anti-diagonal, as pgn::DiagScalarEngine::run makes them.
+// One engine call: its uniform state and the decisions of every anti-diagonal, as pgn::DiagScalarEngine::run makes them.  This is
+// SCALAR code on the GPU, and a CU has one scalar unit for its four SIMDs: with the cells down to ~80 vector instructions per
+// anti-diagonal, ~100 scalar ones per step were the bound (round 4, SQ_INSTS_SALU > SQ_INSTS_VALU).  Hence: everything in SLOT
+// coordinates of the window (no conversion per step; a window move shifts the few values that live in them), the matrix clips
+// kept as two counters, one comparison for "is the run over" (Dend = the last anti-diagonal the break rule and the matrix allow,
+// updated when the best cell moves; -1 once the band has been trimmed away), FORCED a template argument (a search carries none
+// of the band arithmetic).  The band grows by one diagonal per side and step from the single cell of anti-diagonal 0, so it can
+// never overtake the matrix's near sides (k >= -Dct, k <= Dct hold by themselves): only the far sides clip, at Dct - 2 N and
+// 2 M - Dct — which have the parity of Dct, as ka - 1 and kb + 1 do: a search's range needs no parity fix; a forced band's does.
 struct DiagCtl {
-  int32_t N, M, band_w, kmin, kmax;
-  bool fwd, forced, optimal;
-  int32_t Dct, ka, kb;              // survivors of the latest anti-diagonal (diagonals)
-  int32_t lo, hi;                   // range of the current one
+  int32_t N, M, NM;
+  bool fwd, forced, optimal, banded;
+  int32_t Dct, Dend;
+  int32_t ga, gb;                   // survivors of the latest anti-diagonal (slots)
+  int32_t lo, hi;                   // range of the current one (slots)
+  int32_t c1g, c2g;                 // the matrix's far sides on the current anti-diagonal: diagonals Dct - 2 N and 2 M - Dct, as slots
+  int32_t kming, kmaxg;             // a forced run's band (slots)
   int32_t shiftk;                   // diagonal of slot g: k = g - HALF + shiftk
-  int32_t high, FinishCt, FinishK;
-  uint32_t high_w;
-  unsigned long long cells;
-  int32_t wmax;
+  uint32_t high_f, high_w;          // best score so far as a score FIELD (score + SCORE_BIAS) and its word
+  int32_t FinishCt, FinishG, FinishShift;
+  uint32_t span_sum;                // sum of (hi - lo) over the steps: cells = span_sum / 2 + steps
+  int32_t steps, wmax;
   int32_t next_refill;
-  PG_HD void init(int32_t N_, int32_t M_, unsigned m_o, int32_t band_w_) {
-    N = N_; M = M_; band_w = band_w_;
-    fwd = m_o & DIRECTION_BIT; forced = m_o & FORCED_BIT; optimal = m_o & OPTIMAL_BIT;
-    kmin = (M - N < 0 ? M - N : 0) - band_w; kmax = (M - N > 0 ? M - N : 0) + band_w;
-    Dct = 1; ka = 0; kb = 0; lo = 0; hi = 0; shiftk = 0;
-    high = -(1 << 30); FinishCt = 0; FinishK = 0; high_w = 0u; cells = 0; wmax = 0; next_refill = 1;
+  template <int DPL>
+  PG_HD void init(int32_t N_, int32_t M_, unsigned m_o, int32_t band_w) {
+    constexpr int32_t HALF = 32 * DPL;
+    N = N_; M = M_; NM = N_ + M_;
+    fwd = m_o & DIRECTION_BIT; forced = m_o & FORCED_BIT; optimal = m_o & OPTIMAL_BIT; banded = band_w >= 0;
+    kming = (M - N < 0 ? M - N : 0) - band_w + HALF; kmaxg = (M - N > 0 ? M - N : 0) + band_w + HALF;
+    Dct = 1; Dend = forced ? NM : (NM < BREAK_LEN ? NM : BREAK_LEN);      // (FinishCt = 0: the break rule allows BREAK_LEN steps)
+    ga = HALF; gb = HALF; lo = HALF; hi = HALF; shiftk = 0;
+    c1g = 1 - 2 * N + HALF; c2g = 2 * M - 1 + HALF;
+    high_f = 0u; high_w = 0u; FinishCt = 0; FinishG = HALF; FinishShift = 0;
+    span_sum = 0u; steps = 0; wmax = 0; next_refill = 1;
   }
   // 0: compute anti-diagonal Dct (lo / hi set); 1: the run is over (end of the matrix, break length, band trimmed away);
-  // 2: the band is empty after clipping.  FORCED is a template argument so that a search's step carries none of the band
-  // arithmetic (the per-step control is scalar code, and a CU has ONE scalar unit for its four SIMDs: with the cells down to
-  // ~80 vector instructions per step, 130 scalar ones per step were the bound).
-  // The band grows by one diagonal per side and anti-diagonal from the single cell of anti-diagonal 0, so it can never overtake
-  // the matrix's near corner (lo >= -Dct, hi <= Dct hold by themselves): only the far sides clip, at Dct - 2 N and 2 M - Dct —
-  // which have the parity of Dct, as ka - 1 and kb + 1 do: a search's range needs no parity fix; a forced band's limits do.
+  // 2: the band is empty after clipping
   template <bool FORCED>
   PG_HD int begin_step() {
-    if (FORCED) { if (Dct > N + M) return 1; }
-    else if (!(Dct <= N + M && Dct - FinishCt <= BREAK_LEN && ka <= kb)) return 1;
-    lo = ka - 1; hi = kb + 1;
-    const int32_t c1 = Dct - 2 * N, c2 = 2 * M - Dct;
-    if (lo < c1) lo = c1;
-    if (hi > c2) hi = c2;
-    if (FORCED && band_w >= 0) {
-      if (lo < kmin) lo = kmin;
-      if (hi > kmax) hi = kmax;
+    if (Dct > Dend) return 1;
+    lo = ga - 1; hi = gb + 1;
+    if (lo < c1g) lo = c1g;
+    if (hi > c2g) hi = c2g;
+    if (FORCED && banded) {
+      if (lo < kming) lo = kming;
+      if (hi > kmaxg) hi = kmaxg;
       if ((lo + Dct) & 1) ++lo;
       if ((hi + Dct) & 1) --hi;
     }
     return lo > hi ? 2 : 0;
   }
-  // Slots of the range; returns how many LANES the window has to move (0: fine; INT32_MIN: the band does not fit the window).
-  // The slots lo - 1 and hi + 1 are read, so two slots of margin are kept on either side.
+  // How many LANES the window has to move before this step (0: fine; INT32_MIN: the band does not fit the window).  The slots
+  // lo - 1 and hi + 1 are read, so two slots of margin are kept on either side.
   template <int DPL>
-  PG_HD int32_t window_check(uint32_t& glo, uint32_t& gspan) const {
+  PG_HD int32_t window_check() const {
     constexpr int32_t W = 64 * DPL, HALF = W / 2;
-    const int32_t a = lo - shiftk + HALF, b = hi - shiftk + HALF;
-    glo = (uint32_t)a; gspan = (uint32_t)(b - a);
-    if (a >= 2 && b <= W - 3) return 0;
-    if (b - a + 5 > W) return INT32_MIN;
-    int32_t n = ((a + b) / 2 - HALF) / DPL;
-    if (n == 0) n = a < 2 ? -1 : 1;
-    // after the move: a - DPL n >= 2 and b - DPL n <= W - 3 ?
-    if (a - DPL * n < 2 || b - DPL * n > W - 3) return INT32_MIN;
+    if (lo >= 2 && hi <= W - 3) return 0;
+    if (hi - lo + 5 > W) return INT32_MIN;
+    int32_t n = ((lo + hi) / 2 - HALF) / DPL;
+    if (n == 0) n = lo < 2 ? -1 : 1;
+    if (lo - DPL * n < 2 || hi - DPL * n > W - 3) return INT32_MIN;
     return n;
   }
-  // bookkeeping of the call (cells computed, widest anti-diagonal: what a traceback of the same call has to store).  `cells` holds
-  // the sum of (hi - lo) until cells_total() folds the step count in: two scalar instructions per step.
+  template <int DPL>
+  PG_HD void window_move(int32_t n) {      // the lanes' registers have moved n lanes down: every slot coordinate follows
+    const int32_t d = DPL * n;
+    shiftk += d; lo -= d; hi -= d; ga -= d; gb -= d; c1g -= d; c2g -= d; kming -= d; kmaxg -= d;
+    next_refill = Dct;
+  }
   template <bool WIDEST>
   PG_HD void note_cells() {
-    cells += (unsigned long long)(uint32_t)(hi - lo);
+    span_sum += (uint32_t)(hi - lo); ++steps;
     if (WIDEST) { const int32_t w = (hi - lo) / 2 + 1; if (w > wmax) wmax = w; }
   }
-  PG_HD unsigned long long cells_total(int32_t steps) const { return cells / 2 + (unsigned long long)steps; }
-  // the wave's best cell of this anti-diagonal: gk = (score field | slot), gw its word
-  template <int DPL>
+  PG_HD unsigned long long cells_total() const { return (unsigned long long)(span_sum / 2u) + (unsigned long long)steps; }
+  // the wave's best cell of this anti-diagonal: gk = (score field | slot), gw its word; ties move the finish forward (">=")
   PG_HD void update_best(uint32_t gk, uint32_t gw) {
-    constexpr int32_t HALF = 32 * DPL;
-    const int32_t sc = w_score(gk);
-    if (gk != 0u && sc >= high) { high = sc; high_w = gw; FinishCt = Dct; FinishK = (int32_t)(gk & (W_ONE - 1u)) - HALF + shiftk; }
+    const uint32_t f = gk >> SCORE_SHIFT;
+    if (f >= high_f) {
+      high_f = f; high_w = gw; FinishCt = Dct; FinishG = (int32_t)(gk & (W_ONE - 1u)); FinishShift = shiftk;
+      Dend = Dct + BREAK_LEN < NM ? Dct + BREAK_LEN : NM;
+    }
   }
-  // the word a cell must reach to survive the trimming (cells more than MAX_DIFF below the best score go)
-  // (high >= -10 after the first anti-diagonal of a search — its cells are one step from the origin — and never falls: the
-  // threshold is a positive word, so a zero word, i.e. a slot outside the computed range, never counts as a survivor)
-  PG_HD uint32_t trim_threshold() const { return (uint32_t)(high - MAX_DIFF + (int32_t)SCORE_BIAS) << SCORE_SHIFT; }
+  // the word a cell must reach to survive the trimming (cells more than MAX_DIFF below the best score go).  high >= -10 after the
+  // first anti-diagonal of a search (its cells are one step from the origin) and never falls: the threshold is a positive word, so
+  // a zero word — a slot outside the computed range — never counts as a survivor.
+  PG_HD uint32_t trim_threshold() const { return (high_f - (uint32_t)MAX_DIFF) << SCORE_SHIFT; }
   // survivors: the lowest / highest surviving slot (any = false: none)
-  template <int DPL, bool FORCED>
+  template <bool FORCED>
   PG_HD void end_step(bool any, uint32_t gmin, uint32_t gmax) {
-    constexpr int32_t HALF = 32 * DPL;
-    if (FORCED) { ka = lo; kb = hi; }
-    else if (any) { ka = (int32_t)gmin - HALF + shiftk; kb = (int32_t)gmax - HALF + shiftk; }
-    else { ka = 1; kb = 0; }
-    ++Dct;
+    if (FORCED) { ga = lo; gb = hi; }
+    else if (any) { ga = (int32_t)gmin; gb = (int32_t)gmax; }
+    else { ga = 1; gb = 0; Dend = -1; }
+    ++Dct; ++c1g; --c2g;
   }
   // after the loop: where the call finished.  corner_slot: the slot of the target corner (its X word is needed when the corner
   // counts as reached); returns whether the caller has to deliver that word (finish2) or the best cell's word stands.
   template <int DPL>
-  PG_HD bool finish1(bool& reached, uint32_t& corner_slot) {
+  PG_HD bool finish1(bool& reached, uint32_t& corner_slot, int32_t& FinishK) {
     constexpr int32_t HALF = 32 * DPL;
     reached = false;
     const int32_t last = Dct - 1;
     corner_slot = 0u;
-    if (last == N + M) {
-      if (!optimal) { reached = true; FinishCt = N + M; FinishK = M - N; corner_slot = (uint32_t)(M - N - shiftk + HALF); return true; }
+    FinishK = FinishG - HALF + FinishShift;
+    if (last == NM) {
+      if (!optimal) { reached = true; FinishCt = NM; FinishK = M - N; corner_slot = (uint32_t)(M - N - shiftk + HALF); return true; }
       if (FinishCt == last) reached = true;
     }
     return false;
   }
-  PG_HD void finish2(uint32_t fin_w, int32_t Astart, int32_t Bstart, int32_t& Aend, int32_t& Bend, int32_t& errors, int32_t& score) const {
+  PG_HD void finish2(uint32_t fin_w, int32_t FinishK, int32_t Astart, int32_t Bstart, int32_t& Aend, int32_t& Bend, int32_t& errors, int32_t& score) const {
     const int32_t fi = (FinishCt - FinishK) / 2, fj = (FinishCt + FinishK) / 2;
     Aend = fwd ? Astart + fi - 1 : Astart - fi + 1;
     Bend = fwd ? Bstart + fj - 1 : Bstart - fj + 1;
@@ -251,21 +265,20 @@ struct DiagWaveEmu {
       diag_lane_refill<DPL, PAR>(T[l], ca, oka, cb, okb);
     }
   }
-  template <int PAR, bool TRACK>
-  void step(DiagCtl& C, uint32_t glo, uint32_t gspan) {
+  template <int PAR, bool FORCED>
+  void step(DiagCtl& C) {
     uint32_t nbX[64], nbG[64], key[64], keyw[64];
     for (int l = 0; l < 64; ++l) {
       if (PAR == 0) { nbX[l] = l > 0 ? T[l - 1].X[DPL - 1] : 0u; nbG[l] = l > 0 ? T[l - 1].D[DPL - 1] : 0u; }
       else { nbX[l] = l < 63 ? T[l + 1].X[0] : 0u; nbG[l] = l < 63 ? T[l + 1].I[0] : 0u; }
     }
-    for (int l = 0; l < 64; ++l) diag_lane_step<DPL, PAR, TRACK>(T[l], nbX[l], nbG[l], (uint32_t)(DPL * l), glo, gspan, ~W_STATE, key[l], keyw[l]);
-    if (TRACK) {
+    for (int l = 0; l < 64; ++l)
+      diag_lane_step<DPL, PAR, !FORCED>(T[l], nbX[l], nbG[l], (uint32_t)(DPL * l), (uint32_t)C.lo, (uint32_t)(C.hi - C.lo), DiagRelabel{~W_STATE, ST_INSERT, ST_MATCH}, key[l], keyw[l]);
+    bool any = false; uint32_t gmin = 0, gmax = 0;
+    if (!FORCED) {
       uint32_t gk = 0, gw = 0;
       for (int l = 0; l < 64; ++l) if (key[l] > gk) { gk = key[l]; gw = keyw[l]; }      // (keys are unique: they carry the slot)
-      C.template update_best<DPL>(gk, gw);
-    }
-    bool any = false; uint32_t gmin = 0, gmax = 0;
-    if (!C.forced) {
+      C.update_best(gk, gw);
       const uint32_t thr = C.trim_threshold();
       for (int l = 0; l < 64; ++l) {
         const uint32_t bits = diag_lane_alive<DPL, PAR>(T[l], thr);
@@ -273,22 +286,19 @@ struct DiagWaveEmu {
           if ((bits >> s) & 1u) { const uint32_t g = (uint32_t)(DPL * l + s); if (!any) { gmin = g; any = true; } gmax = g; }
       }
     }
-    if (C.forced) C.template end_step<DPL, true>(any, gmin, gmax); else C.template end_step<DPL, false>(any, gmin, gmax);
+    C.template end_step<FORCED>(any, gmin, gmax);
   }
-  // as pgn::ScalarEngine::run (band_w < 0: MUMmer's own band).  false: the band did not fit the window (nothing is returned).
-  bool run(int32_t Astart, int32_t& Aend, int32_t Bstart, int32_t& Bend, unsigned m_o, int32_t band_w, int32_t& errors, int32_t& score, bool& reached) {
+  template <bool FORCED>
+  bool run_(int32_t Astart, int32_t& Aend, int32_t Bstart, int32_t& Bend, unsigned m_o, int32_t band_w, int32_t& errors, int32_t& score, bool& reached) {
     DiagCtl C;
     const bool fwd = m_o & DIRECTION_BIT;
-    C.init(fwd ? Aend - Astart + 1 : Astart - Aend + 1, fwd ? Bend - Bstart + 1 : Bstart - Bend + 1, m_o, band_w);
+    C.template init<DPL>(fwd ? Aend - Astart + 1 : Astart - Aend + 1, fwd ? Bend - Bstart + 1 : Bstart - Bend + 1, m_o, band_w);
     for (int l = 0; l < 64; ++l) for (int s = 0; s < DPL; ++s) { T[l].X[s] = 0u; T[l].D[s] = 0u; T[l].I[s] = 0u; T[l].mw[s] = 0u; }
     T[HALF / DPL].X[0] = w_make(0, 0, ST_MATCH);
     ++calls;
-    int32_t steps_done = 0;
     for (;;) {
-      const int why = C.forced ? C.template begin_step<true>() : C.template begin_step<false>();
-      if (why) break;
-      uint32_t glo, gspan;
-      int32_t n = C.template window_check<DPL>(glo, gspan);
+      if (C.template begin_step<FORCED>()) break;
+      const int32_t n = C.template window_check<DPL>();
       if (n == INT32_MIN) { ++fails; return false; }
       if (n != 0) {
         DiagRegs<DPL> Z;
@@ -296,28 +306,31 @@ struct DiagWaveEmu {
         DiagRegs<DPL> U[64];
         for (int l = 0; l < 64; ++l) U[l] = (l + n >= 0 && l + n < 64) ? T[l + n] : Z;
         for (int l = 0; l < 64; ++l) T[l] = U[l];
-        C.shiftk += DPL * n;
-        C.next_refill = C.Dct;
+        C.template window_move<DPL>(n);
         ++moves;
-        n = C.template window_check<DPL>(glo, gspan);
-        if (n != 0) { ++fails; return false; }
       }
       if (C.Dct == C.next_refill) { if (C.Dct & 1) refill<1>(C, Astart, Bstart); else refill<0>(C, Astart, Bstart); C.next_refill = C.Dct + 32; }
       C.template note_cells<true>();
-      ++steps_done;
-      if (C.Dct & 1) { if (C.forced) step<1, false>(C, glo, gspan); else step<1, true>(C, glo, gspan); }
-      else { if (C.forced) step<0, false>(C, glo, gspan); else step<0, true>(C, glo, gspan); }
+      if (C.Dct & 1) step<1, FORCED>(C); else step<0, FORCED>(C);
     }
     uint32_t corner = 0, fin_w = C.high_w;
-    if (C.template finish1<DPL>(reached, corner)) fin_w = T[corner / DPL].X[corner % DPL];
-    C.finish2(fin_w, Astart, Bstart, Aend, Bend, errors, score);
-    const unsigned long long nc = C.cells_total(steps_done);
+    int32_t FinishK = 0;
+    if (C.template finish1<DPL>(reached, corner, FinishK)) fin_w = T[corner / DPL].X[corner % DPL];
+    C.finish2(fin_w, FinishK, Astart, Bstart, Aend, Bend, errors, score);
+    const unsigned long long nc = C.cells_total();
     cells += (long)nc;
     last_cells = nc > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)nc; last_wmax = (uint32_t)C.wmax;
     return true;
   }
+  // as pgn::ScalarEngine::run (band_w < 0: MUMmer's own band).  false: the band did not fit the window (nothing is returned).
+  bool run(int32_t Astart, int32_t& Aend, int32_t Bstart, int32_t& Bend, unsigned m_o, int32_t band_w, int32_t& errors, int32_t& score, bool& reached) {
+    return (m_o & FORCED_BIT) ? run_<true>(Astart, Aend, Bstart, Bend, m_o, band_w, errors, score, reached)
+                              : run_<false>(Astart, Aend, Bstart, Bend, m_o, band_w, errors, score, reached);
+  }
 };
+#endif
 
+#if !defined(__HIP_DEVICE_COMPILE__)
 // The engine postnuc_unit is given when the host statement runs on the emulated wave engines: trimmed searches / alignments on
 // the 256-diagonal window, forced runs on the window that holds their certified band (256 ... 2048 diagonals), anything that
 // does not fit on pgn::ScalarEngine — the dispatch of the GPU's PnWaveEngine (pga_postnuc.inc).
