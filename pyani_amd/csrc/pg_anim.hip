@@ -172,6 +172,7 @@ struct AnimScratch {
   int32_t* pn_n = nullptr;          // per unit: alignments (< 0: capacity)
   uint32_t* pn_cursor = nullptr;    // unit hand-out counter of the persistent waves
   uint32_t* pn_gscratch = nullptr;  // [waves][PN_GLOBAL_WORDS] anti-diagonals too wide for LDS
+  uint32_t* pn_wide = nullptr;      // request slots handed from the narrow forced kernel to the wide one
   PnForcedReq* pn_reqs = nullptr;   // the launch's deferred forced runs (at most one per alignment started: <= chains)
   pgn::PnGap* pn_gaps = nullptr;    // match-to-match alignments by match slot
   pgn::PnFwd* pn_fwd = nullptr;     // forward extensions by cluster (moff-relative position in the unit's order)
@@ -315,7 +316,7 @@ static void anim_free_one(pg_ctx* ctx, void*& slot) {
                   A->iscratch, A->order, A->prev, A->next, A->alnof, A->chains, A->fw, A->bw, A->S.alns, A->S.a_rrec,
                   A->S.a_qrec, A->S.idx, A->S.from, A->S.sc, A->wl_d, A->seedbuf, A->seed_total, A->tasks_d, A->fr_tables, A->fr_pairs,
                   A->fr_slot_pair, A->fr_off, A->fr_nrows, A->fr_ebase, A->fr_entries, A->fr_rows, A->fr_out, A->fr_list, A->fr_nlist, A->fr_wtmp, A->fr_widx,
-                  A->pn, A->pn_fused, A->pn_n, A->pn_cursor, A->pn_gscratch, A->pn_reqs, A->pn_gaps, A->pn_fwd, A->pn_bwd, A->pn_tasks, A->pn_order, A->pn_pieces, A->pn_npieces, A->tr_arena, A->tr_out, A->tr_jobs, A->tr_off, A->tr_cursor, A->tr_cnt};
+                  A->pn, A->pn_fused, A->pn_n, A->pn_cursor, A->pn_gscratch, A->pn_reqs, A->pn_wide, A->pn_gaps, A->pn_fwd, A->pn_bwd, A->pn_tasks, A->pn_order, A->pn_pieces, A->pn_npieces, A->tr_arena, A->tr_out, A->tr_jobs, A->tr_off, A->tr_cursor, A->tr_cnt};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   delete A;
   slot = nullptr;
@@ -875,7 +876,7 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
       if ((rc = regrow(ctx, A->pn_gaps, Mp))) return rc;
       if ((rc = regrow(ctx, A->pn_fwd, Mp))) return rc;
       if ((rc = regrow(ctx, A->pn_bwd, Mp))) return rc;
-      if ((rc = regrow(ctx, A->pn_tasks, 3 * Mp))) return rc;
+      if ((rc = regrow(ctx, A->pn_tasks, 4 * Mp))) return rc;      // three lane classes + the wave engine's list
       A->pn_cap = Mp;
     }
     if (n_units > A->pn_units) {
@@ -904,8 +905,8 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
     }
     const size_t req_cap = Mp + 16;      // one slot per match slot: a walk records at most one forced run per alignment it starts, and starts at most one per match
     A->pn_req_n = req_cap;
-    if (req_cap > A->pn_req_cap) { if ((rc = regrow(ctx, A->pn_reqs, req_cap + req_cap / 2))) return rc; A->pn_req_cap = req_cap + req_cap / 2; }
-    PG_HIP(ctx, hipMemsetAsync(A->pn_cursor, 0, 64, cur_stream(ctx)));   // [0] unit cursor, [1] forced runs recorded ([7]: the long ones), [2] forced-run cursor, [3] chain cursor, [4..6] small gaps, [8] cluster cursor of the forward extensions, [9] unit cursor of the rehearsal, [10] cluster cursor of the backward searches
+    if (req_cap > A->pn_req_cap) { if ((rc = regrow(ctx, A->pn_reqs, req_cap + req_cap / 2))) return rc; if ((rc = regrow(ctx, A->pn_wide, req_cap + req_cap / 2))) return rc; A->pn_req_cap = req_cap + req_cap / 2; }
+    PG_HIP(ctx, hipMemsetAsync(A->pn_cursor, 0, 64, cur_stream(ctx)));   // [0] unit cursor, [1] forced runs recorded ([7]: the long ones), [2] forced-run cursor, [3] chain / big-gap cursor, [4..6] small gaps by class ([11]: gaps left to the wave engine), [8] cluster cursor of the forward extensions, [9] unit cursor of the rehearsal, [10] cluster cursor of the backward searches
     if (n_wl && trace) PG_HIP(ctx, hipMemcpyAsync(A->choff_d, choff.data(), choff.size() * 4, hipMemcpyHostToDevice, cur_stream(ctx)));
     if (n_wl && !trace) {     // the (unit, chain) work list, then every cluster's match-to-match alignments
       if (n_wl > A->wl) { if ((rc = regrow(ctx, A->wl_d, n_wl + n_wl / 2))) return rc; A->wl = n_wl + n_wl / 2; }
@@ -921,8 +922,12 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
         hipLaunchKernelGGL((anim_postnuc_gaplane_kernel<32>), lg, dim3(64), 0, cur_stream(ctx), A->refs_d, A->units_d, O, A->pn_tasks + A->pn_cap, A->pn_cursor + 5, A->pn_gaps);
         hipLaunchKernelGGL((anim_postnuc_gaplane_kernel<PN_SMALL>), lg, dim3(64), 0, cur_stream(ctx), A->refs_d, A->units_d, O, A->pn_tasks + 2 * A->pn_cap, A->pn_cursor + 6, A->pn_gaps);
       }
-      hipLaunchKernelGGL(anim_postnuc_gap_kernel, dim3(pn_waves_pre), dim3(64), 0, cur_stream(ctx), A->refs_d, A->units_d, O, A->wl_d, (uint32_t)n_wl,
-                         A->pn_cursor + 3, A->pn_gaps, A->pn_gscratch, lane_small);
+      if (lane_small)
+        hipLaunchKernelGGL(anim_postnuc_gapbig_kernel, dim3(pn_waves_pre), dim3(64), 0, cur_stream(ctx), A->refs_d, A->units_d, O, A->pn_cursor + 3,
+                           A->pn_gaps, A->pn_gscratch, A->pn_tasks + 3 * A->pn_cap, A->pn_cursor + 11);
+      else
+        hipLaunchKernelGGL(anim_postnuc_gap_kernel, dim3(pn_waves_pre), dim3(64), 0, cur_stream(ctx), A->refs_d, A->units_d, O, A->wl_d, (uint32_t)n_wl,
+                           A->pn_cursor + 3, A->pn_gaps, A->pn_gscratch);
       pg_prof_end(ctx);
       pg_prof_begin(ctx, PG_K_ANIM_FWD);
       hipLaunchKernelGGL(anim_postnuc_fwd_kernel, dim3(pn_waves_pre), dim3(64), 0, cur_stream(ctx), A->refs_d, A->units_d, O, A->wl_d, (uint32_t)n_wl,
@@ -948,9 +953,12 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
       PG_HIP(ctx, hipMemsetAsync(A->pn_n, 0, (size_t)n_units * 4, cur_stream(ctx)));
     pg_prof_end(ctx);
     pg_prof_begin(ctx, PG_K_ANIM_EXTLANE);     // (the forced re-alignments, deferred: pga_postnuc.inc)
-    if (n_wl)
-      hipLaunchKernelGGL(anim_postnuc_forced_kernel, dim3(pn_waves), dim3(64), 0, cur_stream(ctx), A->refs_d, A->units_d, A->pn_reqs,
-                         A->pn_cursor + 1, (uint32_t)req_cap, A->pn_cursor + 2, A->pn_n, A->pn_gscratch);
+    if (n_wl) {      // narrow bands first (five waves per SIMD), then the runs that asked for a wide one (pga_postnuc.inc, pn_forced_wave)
+      hipLaunchKernelGGL(anim_postnuc_forced_kernel, dim3(pn_waves_pre), dim3(64), 0, cur_stream(ctx), A->refs_d, A->units_d, A->pn_reqs,
+                         A->pn_cursor + 1, (uint32_t)req_cap, A->pn_cursor + 2, A->pn_n, A->pn_wide, A->pn_cursor + 12);
+      hipLaunchKernelGGL(anim_postnuc_forced_wide_kernel, dim3(pn_waves), dim3(64), 0, cur_stream(ctx), A->refs_d, A->units_d, A->pn_reqs,
+                         A->pn_cursor + 1, (uint32_t)req_cap, A->pn_cursor + 13, A->pn_n, A->pn_gscratch, A->pn_wide, A->pn_cursor + 12);
+    }
     pg_prof_end(ctx);
     if (pg_dev_env("PYANI_PN_STATS")) {   // development: what the engines did in this launch
       PG_HIP(ctx, hipStreamSynchronize(cur_stream(ctx)));
