@@ -893,8 +893,9 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
     }
     if (!A->pn_cursor && (rc = regrow(ctx, A->pn_cursor, 16))) return rc;
     const uint32_t pn_waves = (uint32_t)ctx->num_cu * 12u;   // units / forced kernels: 12 KiB of LDS each: 12 per CU
-    const uint32_t pn_waves_pre = (uint32_t)ctx->num_cu * 20u;   // gap / forward pre-passes: no LDS, < 104 registers: 5 per SIMD
-    if (pn_waves_pre > A->pn_waves) { if ((rc = regrow(ctx, A->pn_gscratch, (size_t)pn_waves_pre * PN_GLOBAL_WORDS))) return rc; A->pn_waves = pn_waves_pre; }
+    const uint32_t pn_waves_pre = (uint32_t)ctx->num_cu * 32u;   // gap / forward / backward pre-passes and the narrow forced kernel: no LDS, diagonal engine only, <= 64 registers: 8 per SIMD
+    const uint32_t pn_waves_scr = ctx->anim_gap_lanes ? pn_waves : pn_waves_pre;      // (only the walks, the wide forced kernel and the all-gaps form of the gap kernel use the global scratch)
+    if (pn_waves_scr > A->pn_waves) { if ((rc = regrow(ctx, A->pn_gscratch, (size_t)pn_waves_scr * PN_GLOBAL_WORDS))) return rc; A->pn_waves = pn_waves_scr; }
     const bool trace = tls_sink && tls_sink->with_indels;      // the walks list their pieces and align everything themselves
     const bool bwd_ahead = ctx->anim_bwd_ahead != 0;
     if (trace) {
@@ -924,7 +925,7 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
       }
       if (lane_small)
         hipLaunchKernelGGL(anim_postnuc_gapbig_kernel, dim3(pn_waves_pre), dim3(64), 0, cur_stream(ctx), A->refs_d, A->units_d, O, A->pn_cursor + 3,
-                           A->pn_gaps, A->pn_gscratch, A->pn_tasks + 3 * A->pn_cap, A->pn_cursor + 11);
+                           A->pn_gaps, A->pn_tasks + 3 * A->pn_cap, A->pn_cursor + 11);
       else
         hipLaunchKernelGGL(anim_postnuc_gap_kernel, dim3(pn_waves_pre), dim3(64), 0, cur_stream(ctx), A->refs_d, A->units_d, O, A->wl_d, (uint32_t)n_wl,
                            A->pn_cursor + 3, A->pn_gaps, A->pn_gscratch);
