@@ -971,6 +971,14 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
       fprintf(stderr, "[pn-stats] searches of the gap + units kernels: %llu calls, %.1f ms inside the engine (summed over waves)\n", st[22], st[21] / 1e5);
       fprintf(stderr, "[pn-stats] forced passes by engine (127 / 255 / 511 cells / strips): %llu %llu %llu %llu passes, %.1f %.1f %.1f %.1f ms summed over waves\n",
               st[27], st[28], st[29], st[30], st[23] / 1e5, st[24] / 1e5, st[25] / 1e5, st[26] / 1e5);
+      {
+        unsigned long long ks[32], kz[32] = {0};
+        PG_HIP(ctx, hipMemcpyFromSymbol(ks, HIP_SYMBOL(g_pn_kstats), sizeof(ks)));
+        PG_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_pn_kstats), kz, sizeof(kz)));
+        const char* kn[7] = {"gaps", "forward", "backward-ahead", "walks", "forced narrow", "forced 512-1024", "forced 2048"};
+        for (int k = 0; k < 7; ++k)
+          fprintf(stderr, "[pn-stats] diagonal engine in %-16s: %llu calls, %llu anti-diagonals, %llu cells\n", kn[k], ks[4 * k], ks[4 * k + 1], ks[4 * k + 2]);
+      }
       for (int k = 13; k <= 17; k += 4)      // ticks of the 100 MHz wall clock -> ms
         fprintf(stderr, "[pn-stats] %s: busy %.1f ms summed over waves, span %.1f ms, longest item %.1f ms (size %llu)\n", k == 13 ? "units" : "forced",
                 st[k] / 1e5, st[k + 2] ? (st[k + 2] - ~st[k + 3]) / 1e5 : 0.0, (st[k + 1] >> 20) / 1e5, st[k + 1] & 0xFFFFFull);
