@@ -147,6 +147,19 @@ int pg_anim_pairs(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_ids, u
 #define PG_EXTENDER_BANDED64 1
 int pg_anim_set_extender(pg_ctx* ctx, int extender);
 
+/* How many host worker threads (each with its own HIP stream and scratch) share one pg_anim_pairs / pg_anib_pairs call: 1 ... 4,
+ * default 2 (the launches of two streams overlap: one worker's read-backs and sequential tails hide behind the other's kernels).
+ * The counterpart of pyani's --workers inside ONE device (subcmd_anim.py:392-396 spreads jobs over CPU cores; over devices it is
+ * pyani_amd.multi.MultiEngine).  Results do not depend on it; 1 gives un-overlapped per-stage timings (pg_profile_get). */
+int pg_anim_set_workers(pg_ctx* ctx, int workers);
+
+/* Engine counters of the nucmer extender since the last reset, for measurement (bench.py's VALU-issue roofline: cells per second
+ * against the instruction count per cell): out[64].  out[0..2] = calls / anti-diagonals / DP cells of all register engines;
+ * out[32 + 4 k + {0, 1, 2}] = the same for the diagonal engine in kernel class k (0 match-to-match gaps, 1 forward extensions,
+ * 2 backward searches run ahead, 3 the units' walks, 4 forced runs in the narrow kernel, 5 / 6 forced runs in 1024- / 2048-
+ * diagonal windows); the rest: development counters.  Synchronises the context's streams. */
+int pg_anim_counters(pg_ctx* ctx, uint64_t* out, int reset);
+
 /* Work-memory budget of pg_anim_pairs: at most max_pairs ordered pairs and max_matches exact matches in flight (about 264 bytes
  * of device scratch per match, grown on demand; default 131072 pairs / 512 Mi matches, split over the context's two workers =
  * launches of up to 65536 pairs / 256 Mi matches, ~68 GB each).  Larger calls are split transparently; results do not depend on

@@ -50,59 +50,65 @@ Genome pack(const uint8_t* seq, const uint64_t* rec_off, uint32_t n_rec) {
   return g;
 }
 
-// sorted (20-mer, position) table + a direct index on the k-mer's top INDEX_BITS bits: a lookup costs two cache misses (index,
-// bucket) instead of the ~20 of a binary search over 80 MB — this leg is a baseline, it should not be slow for no reason
-constexpr int INDEX_BITS = 22;
+// Seeding as a CPU program would do it (the exhaustive sorted 20-mer table — 80 MB per pair, one lookup per query
+// base — cost 8.9 s for an UNRELATED 5 Mb pair with every host core busy; a baseline should not be slow for no reason): a SPARSE
+// index in MUMmer 4's spirit.  Every reference position's 16-mer goes into a bucket table (counting sort on the top 22 bits, the
+// other 10 bits kept beside the position: 8 B per base, no comparison sort); of the query strand only every 5th position is looked
+// up — a match of >= 20 bases contains a whole 16-mer at one of its first five positions — a hit is extended to the left (5 or
+// more bases: an earlier sampled position reports it) and to the right, and kept if it is >= 20 long.  Same maximal matches as
+// the exhaustive table (the tests hold the results against the GPU's and the fixtures'), a fifth of the random memory accesses.
+constexpr int SEED_K = 16, SEED_STEP = MIN_MATCH - SEED_K + 1, INDEX_BITS = 22;
+static_assert(SEED_STEP == 5, "a match of MIN_MATCH bases must contain a sampled SEED_K-mer");
 struct KmerTable {
-  std::vector<std::pair<uint64_t, int32_t>> tab;
-  std::vector<uint32_t> start;   // start[b] .. start[b + 1]: entries whose k-mer has prefix b
+  std::vector<uint64_t> tab;     // (low 10 bits of the 16-mer) << 32 | position, grouped by the 16-mer's top 22 bits
+  std::vector<uint32_t> start;   // start[b] .. start[b + 1]: the entries of bucket b
 };
 
 void build_table(const Genome& G, KmerTable& T) {
-  auto& tab = T.tab;
   const SeqView R = G.view();
-  const int K = MIN_MATCH;
-  tab.clear();
-  tab.reserve((size_t)R.len);
-  uint64_t v = 0;
+  constexpr int K = SEED_K, shift = 2 * K - INDEX_BITS;
+  T.start.assign((size_t(1) << INDEX_BITS) + 2, 0);
+  uint32_t v = 0;
   int run = 0;
-  const uint64_t keep = (K == 32) ? ~0ull : ((1ull << (2 * K)) - 1);
   for (int64_t p = 0; p < R.len; ++p) {
     if (!R.clean(p)) { run = 0; v = 0; continue; }
-    v = ((v << 2) | (uint64_t)R.base(p)) & keep;
-    if (++run >= K) tab.push_back({v, (int32_t)(p - K + 1)});
+    v = (v << 2) | (uint32_t)R.base(p);
+    if (++run >= K) ++T.start[(v >> shift) + 2];
   }
-  std::sort(tab.begin(), tab.end());
-  const int shift = 2 * K - INDEX_BITS;
-  T.start.assign((size_t(1) << INDEX_BITS) + 1, 0);
-  for (const auto& e : tab) ++T.start[(e.first >> shift) + 1];
-  for (size_t b = 0; b < (size_t(1) << INDEX_BITS); ++b) T.start[b + 1] += T.start[b];
+  for (size_t b = 2; b < T.start.size(); ++b) T.start[b] += T.start[b - 1];
+  T.tab.resize(T.start.back());
+  v = 0; run = 0;
+  for (int64_t p = 0; p < R.len; ++p) {      // start[b + 1] is bucket b's fill cursor; afterwards it is bucket b's end = bucket b + 1's start
+    if (!R.clean(p)) { run = 0; v = 0; continue; }
+    v = (v << 2) | (uint32_t)R.base(p);
+    if (++run >= K) T.tab[T.start[(v >> shift) + 1]++] = ((uint64_t)(v & ((1u << shift) - 1u)) << 32) | (uint32_t)(p - K + 1);
+  }
 }
 
 // all maximal exact matches >= MIN_MATCH between the reference and one query strand
 template <typename QV>
 void find_mems(const Genome& G, const KmerTable& T, const QV& Q, int strand, std::vector<Match>& out) {
-  const auto& tab = T.tab;
   const SeqView R = G.view();
-  const int K = MIN_MATCH;
-  const uint64_t keep = (K == 32) ? ~0ull : ((1ull << (2 * K)) - 1);
-  uint64_t v = 0;
+  constexpr int K = SEED_K, shift = 2 * K - INDEX_BITS;
+  uint32_t v = 0;
   int run = 0;
   for (int64_t e = 0; e < Q.len(); ++e) {
     if (!Q.clean(e)) { run = 0; v = 0; continue; }
-    v = ((v << 2) | (uint64_t)Q.base(e)) & keep;
+    v = (v << 2) | (uint32_t)Q.base(e);
     if (++run < K) continue;
     const int64_t q = e - K + 1;
-    const uint64_t b = v >> (2 * K - INDEX_BITS);
-    auto it = tab.begin() + T.start[b];
-    const auto bucket_end = tab.begin() + T.start[b + 1];
-    while (it != bucket_end && it->first < v) ++it;
-    for (; it != bucket_end && it->first == v; ++it) {
-      const int64_t r = it->second;
-      if (R.clean(r - 1) && Q.clean(q - 1) && R.base(r - 1) == Q.base(q - 1)) continue;  // not left-maximal
+    if (q % SEED_STEP) continue;
+    const uint32_t b = v >> shift;
+    const uint64_t rem = (uint64_t)(v & ((1u << shift) - 1u));
+    for (uint32_t t = T.start[b]; t < T.start[b + 1]; ++t) {
+      if ((T.tab[t] >> 32) != rem) continue;
+      const int64_t r = (int64_t)(uint32_t)T.tab[t];
+      int32_t left = 0;
+      while (left < SEED_STEP && R.clean(r - 1 - left) && Q.clean(q - 1 - left) && R.base(r - 1 - left) == Q.base(q - 1 - left)) ++left;
+      if (left >= SEED_STEP) continue;      // the match holds an earlier sampled position: reported from there
       int32_t L = K;
       while (R.clean(r + L) && Q.clean(q + L) && R.base(r + L) == Q.base(q + L)) ++L;
-      out.push_back(Match{(int32_t)r, (int32_t)q, L, strand});
+      if (left + L >= MIN_MATCH) out.push_back(Match{(int32_t)(r - left), (int32_t)(q - left), left + L, strand});
     }
   }
 }

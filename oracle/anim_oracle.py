@@ -97,6 +97,49 @@ def parse_delta_records(alns) -> Tuple[int, int, float, int]:
     return raln, qaln, identity, sim_error
 
 
+def delta_filter_1to1(alns) -> List[bool]:
+    """`delta-filter -1` (what pyani's delta_filter_wrapper.py:80-90 runs on every nucmer output): MUMmer 3.23's published 1-to-1
+    mapping — an alignment survives iff it lies on the best weighted chain of its REFERENCE sequence and on the best weighted
+    chain of its QUERY sequence (DeltaGraph_t::flagRLIS / flagQLIS + ScoreLocal).  Per sequence: alignments by start (equal
+    starts: the higher own score first, then input order); score_i = max(own_i, max over earlier j of score_j + gain(i, j)) with
+    own_i = trunc(len_i * idy_i^2), gain = trunc((len_i - overlap) * idy_i^2), integer scores, first best wins; the chain ending in
+    the first maximal score is kept.  idy = 1 - 2 errors / (ref length + query length).  Independent of the engine's C++ (which
+    runs the same rule on the GPU); pinned on every .delta / .filter pair the reference's tests hold (tests/test_anim_cpu.py)."""
+    n = len(alns)
+    keep = [0] * n
+    for side in (0, 1):
+        groups = defaultdict(list)
+        for i, a in enumerate(alns):
+            lo, hi = (min(a.rs, a.re), max(a.rs, a.re)) if side == 0 else (min(a.qs, a.qe), max(a.qs, a.qe))
+            tot = (abs(a.re - a.rs) + 1) + (abs(a.qe - a.qs) + 1)
+            idy = 1.0 - 2.0 * a.errors / tot if tot > 0 else 0.0
+            length = hi - lo + 1
+            own = int(length * (idy * idy))
+            groups[a.ref_id if side == 0 else a.qry_id].append((lo, -own, i, hi, length, idy, own))
+        for items in groups.values():
+            items.sort(key=lambda t: (t[0], t[1], t[2]))
+            score, frm = [], []
+            best = -1
+            for k, (lo, _, i, hi, length, idy, own) in enumerate(items):
+                sc, fr = own, -1
+                for kk in range(k):
+                    lo_j, _, _, hi_j, len_j, _, _ = items[kk]
+                    olap = max(0, hi_j - lo + 1)
+                    if olap > 0 and (olap / length * 100.0 > 100.0 or olap / len_j * 100.0 > 100.0):
+                        continue
+                    cand = score[kk] + int((length - olap) * (idy * idy))
+                    if cand > sc:
+                        sc, fr = cand, kk
+                score.append(sc); frm.append(fr)
+                if best < 0 or sc > score[best]:
+                    best = k
+            k = best
+            while k >= 0:
+                keep[items[k][2]] |= 1 << side
+                k = frm[k]
+    return [f == 3 for f in keep]
+
+
 def parse_delta(path) -> Tuple[int, int, float, int]:
     return parse_delta_records(read_delta(path)[0])
 

@@ -228,6 +228,18 @@ void pg_anim_set_worker(pg_ctx* ctx, int worker) {
 }
 
 void pg_anim_set_sink(PgAlnSink* sink) { tls_sink = sink; }
+int pg_anim_counters_read(pg_ctx* ctx, uint64_t* out, int reset) {
+  PG_HIP(ctx, hipDeviceSynchronize());
+  unsigned long long a[32], b[32], z[32] = {0};
+  PG_HIP(ctx, hipMemcpyFromSymbol(a, HIP_SYMBOL(g_pn_stats), sizeof(a)));
+  PG_HIP(ctx, hipMemcpyFromSymbol(b, HIP_SYMBOL(g_pn_kstats), sizeof(b)));
+  for (int i = 0; i < 32; ++i) { out[i] = a[i]; out[32 + i] = b[i]; }
+  if (reset) {
+    PG_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_pn_stats), z, sizeof(z)));
+    PG_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_pn_kstats), z, sizeof(z)));
+  }
+  return PG_OK;
+}
 
 void pg_anim_drop_lists(pg_ctx* ctx) {
   std::lock_guard<std::mutex> lk(ctx->anim_mu);

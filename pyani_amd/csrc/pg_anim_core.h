@@ -294,7 +294,7 @@ PG_HD int record_of(const int32_t* rec_start, int n_rec, int32_t p) {
 // indexes the whole reference file (all records) and streams the query file one sequence and strand at a time, so
 // mumuniqueinquery never sees the candidates of another query record — a repeat that sits once in each of two contigs of a
 // draft assembly is unique in either (round 4: the filter used to scan the strand stream of all records as one sequence and
-// lost those matches; found by fuzzing against oracle/nucmer_oracle.cpp, tools/anim_fuzz_multirecord.py).
+// lost those matches; found by fuzzing against the independent restatement the tests use, tools/anim_fuzz_multirecord.py).
 // m[0..n) of ONE strand; the `strand` field is used as scratch flag and restored.  QREC(strand position) -> query record
 // (any monotone labelling: only equality is used).  Returns the new count (order: by q).
 template <typename QREC>

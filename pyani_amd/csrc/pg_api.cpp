@@ -748,6 +748,18 @@ int pg_anim_set_extender(pg_ctx* ctx, int extender) {
   return PG_OK;
 }
 
+int pg_anim_set_workers(pg_ctx* ctx, int workers) {
+  if (!ctx || workers < 1 || workers > pg_ctx::MAX_WORKERS) return pg_fail(ctx, PG_E_ARG, "workers must be 1 ... 4");
+  ctx->anim_workers = workers;
+  return PG_OK;
+}
+
+int pg_anim_counters(pg_ctx* ctx, uint64_t* out, int reset) {
+  if (!ctx || !out) return pg_fail(ctx, PG_E_ARG, "bad argument");
+  PG_HIP(ctx, hipSetDevice(ctx->device));
+  return pg_anim_counters_read(ctx, out, reset);
+}
+
 int pg_anim_pairs(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_ids, uint64_t n_pairs, int maxmatch,
                   int filter_1to1, pg_anim_result* out) {
   if (!ctx || (n_pairs && (!ref_ids || !qry_ids || !out))) return pg_fail(ctx, PG_E_ARG, "bad argument");

@@ -160,6 +160,7 @@ struct PgAlnSink {
   std::vector<uint32_t> pair_count;               // alignments of each pair, in arrival order
   std::vector<std::vector<int64_t>> indels;       // parallel to alns (with_indels)
 };
+int pg_anim_counters_read(pg_ctx* ctx, uint64_t* out /*[64]*/, int reset);
 void pg_anim_set_sink(PgAlnSink* sink);           // thread-local; nullptr = none
 void pg_anim_drop_lists(pg_ctx* ctx);   // per-genome seed lists: must go when the genome store is cleared
 int pg_anib_reduce_run(pg_ctx* ctx, uint32_t n_pairs, const uint64_t* offsets, const uint32_t* n_frags, const int32_t* frag,

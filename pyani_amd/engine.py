@@ -177,6 +177,16 @@ class Engine:
         which = {"nucmer": _lib.EXTENDER_NUCMER, "banded64": _lib.EXTENDER_BANDED64}[extender]
         self._check(self.lib.pg_anim_set_extender(self._h, which))
 
+    def anim_set_workers(self, workers: int = 2) -> None:
+        """Host worker threads (streams) sharing one anim_pairs / anib_pairs call: 1 ... 4 (pyani's --workers inside one device)."""
+        self._check(self.lib.pg_anim_set_workers(self._h, int(workers)))
+
+    def anim_counters(self, reset: bool = False) -> np.ndarray:
+        """The nucmer extender's engine counters since the last reset (include/pyani_gpu.h, pg_anim_counters): uint64[64]."""
+        out = np.zeros(64, dtype=np.uint64)
+        self._check(self.lib.pg_anim_counters(self._h, out.ctypes.data, int(bool(reset))))
+        return out
+
     def anim_set_batch_budget(self, max_pairs: int, max_matches: int) -> None:
         self._check(self.lib.pg_anim_set_batch_budget(self._h, int(max_pairs), int(max_matches)))
 

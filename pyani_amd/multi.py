@@ -46,7 +46,8 @@ def _chunks_by_hub(a: np.ndarray, b: np.ndarray, target: int) -> List[np.ndarray
 
 
 class MultiEngine:
-    """Engines on several devices behind the Engine calls the module functions use (genome store, anim_pairs, anib_pairs)."""
+    """Engines on several devices behind the Engine calls the module functions use: genome store (replicated), anim_pairs / anib_pairs /
+    anim_alignments_batch (pairs pulled in chunks by the devices), tetra_counts / tetra_matrix (genomes counted in shards)."""
 
     def __init__(self, devices: Sequence[int], chunk_pairs: int = 0):
         if not devices:
@@ -175,12 +176,67 @@ class MultiEngine:
             self._pull(chunks, lambda e, idx: e.anib_pairs(qa[idx], sa[idx], fragsize), out)
         return out
 
-    # -- single-device calls go to the first engine ------------------------------------------------------------------------
+    # -- alignment records (run_anim(write_output=True): the .delta / .filter files) -----------------------------------------------
+    def anim_alignments_batch(self, ref_ids, qry_ids, maxmatch: bool = False, with_indels: bool = False):
+        """Engine.anim_alignments_batch over all devices: the pair list is cut by hub genome as for anim_pairs, the devices pull
+        chunks, and the records (and indel lists) are put back together in the caller's pair order."""
+        r = np.ascontiguousarray(list(ref_ids), dtype=np.int32)
+        q = np.ascontiguousarray(list(qry_ids), dtype=np.int32)
+        if len(r) != len(q):
+            raise ValueError("ref_ids and qry_ids must have the same length")
+        n = len(r)
+        if n == 0 or len(self.engines) == 1:
+            return self.engines[0].anim_alignments_batch(r, q, maxmatch=maxmatch, with_indels=with_indels)
+        # traceback launches keep their walks' pieces on the host: smaller chunks
+        chunks = _chunks_by_hub(r, q, max(16 if with_indels else 256, n // (8 * len(self.engines)) + 1))
+        parts = [None] * len(chunks)
+        lock = threading.Lock()
+        nxt = [0]
+
+        def worker(e):
+            while True:
+                with lock:
+                    k = nxt[0]
+                    nxt[0] += 1
+                if k >= len(chunks):
+                    return
+                idx = chunks[k]
+                parts[k] = e.anim_alignments_batch(r[idx], q[idx], maxmatch=maxmatch, with_indels=with_indels)
+        self._all(worker)
+        return merge_alignment_parts(n, chunks, parts, with_indels)
+
+    # -- TETRA: genomes are independent -> counted in shards, the small N x N matrix on one device ----------------------------
+    def _id_shards(self, ids) -> List[np.ndarray]:
+        ids = np.ascontiguousarray(list(ids), dtype=np.int32)
+        if len(ids) == 0:
+            return [ids]
+        lens = np.array([self.engines[0].genome_length(int(g))[0] for g in ids], dtype=np.int64)
+        # contiguous blocks of about equal bases (results are concatenated in order)
+        cuts = np.searchsorted(np.cumsum(lens), np.linspace(0, lens.sum(), len(self.engines) + 1)[1:-1], side="left")
+        return [b for b in np.split(ids, cuts) if len(b)]
+
+    def tetra_counts(self, ids):
+        shards = self._id_shards(ids)
+        res = [None] * len(shards)
+
+        def run(k):
+            res[k] = self.engines[k].tetra_counts(shards[k])
+        ts = [threading.Thread(target=run, args=(k,)) for k in range(len(shards))]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        return tuple(np.concatenate([x[j] for x in res]) for j in range(3))
+
+    def tetra_matrix(self, ids, want_corr: bool = True):
+        c2, c3, c4 = self.tetra_counts(ids)
+        z, present = self.engines[0].tetra_zscores_from_counts(c2, c3, c4)
+        corr = self.engines[0].tetra_corr(z, present) if want_corr else None
+        return z, present, corr
+
+    # -- single-pair / reduction calls go to the first engine ---------------------------------------------------------------
     def anim_pair_alignments(self, ref_id: int, qry_id: int):
         return self.engines[0].anim_pair_alignments(ref_id, qry_id)
-
-    def anim_alignments_batch(self, ref_ids, qry_ids, maxmatch: bool = False, with_indels: bool = False):
-        return self.engines[0].anim_alignments_batch(ref_ids, qry_ids, maxmatch=maxmatch, with_indels=with_indels)
 
     def anib_pair_rows(self, qry_id: int, sbj_id: int, fragsize: int = 1020):
         return self.engines[0].anib_pair_rows(qry_id, sbj_id, fragsize)
@@ -191,11 +247,43 @@ class MultiEngine:
     def anib_reduce(self, pairs):
         return self.engines[0].anib_reduce(pairs)
 
-    def tetra_matrix(self, ids):
-        return self.engines[0].tetra_matrix(ids)
 
-    def tetra_counts(self, ids):
-        return self.engines[0].tetra_counts(ids)
+def merge_alignment_parts(n: int, chunks: List[np.ndarray], parts, with_indels: bool):
+    """Put the per-chunk results of Engine.anim_alignments_batch — (offsets, records, indel offsets, indels) over the chunk's own
+    pairs — back into ONE result over the caller's n pairs, in the caller's order."""
+    counts = np.zeros(n, dtype=np.int64)
+    for idx, (off, _, _, _) in zip(chunks, parts):
+        counts[idx] = np.diff(np.asarray(off, dtype=np.int64))
+    offsets = np.zeros(n + 1, dtype=np.uint64)
+    offsets[1:] = np.cumsum(counts)
+    total = int(offsets[-1])
+    rec_dtype = next((p[1].dtype for p in parts if len(p[1])), Engine.ALN_DTYPE)
+    recs = np.zeros(total, dtype=rec_dtype)
+    icounts = np.zeros(total, dtype=np.int64)
+    for idx, (off, rc, ioff, _) in zip(chunks, parts):
+        off = np.asarray(off, dtype=np.int64)
+        for j, p in enumerate(idx):
+            a, b = int(off[j]), int(off[j + 1])
+            if b > a:
+                dst = int(offsets[p])
+                recs[dst:dst + b - a] = rc[a:b]
+                if with_indels:
+                    icounts[dst:dst + b - a] = np.diff(np.asarray(ioff[a:b + 1], dtype=np.int64))
+    if not with_indels:
+        return offsets, recs, None, None
+    ioffsets = np.zeros(total + 1, dtype=np.uint64)
+    ioffsets[1:] = np.cumsum(icounts)
+    ind_dtype = next((p[3].dtype for p in parts if p[3] is not None and len(p[3])), np.int64)
+    indels = np.zeros(int(ioffsets[-1]), dtype=ind_dtype)
+    for idx, (off, _, ioff, ind) in zip(chunks, parts):
+        off = np.asarray(off, dtype=np.int64)
+        for j, p in enumerate(idx):
+            a, b = int(off[j]), int(off[j + 1])
+            if b > a:
+                dst = int(offsets[p])
+                lo, hi = int(ioff[a]), int(ioff[b])
+                indels[int(ioffsets[dst]):int(ioffsets[dst]) + hi - lo] = ind[lo:hi]
+    return offsets, recs, ioffsets, indels
 
 
 def engine_for(devices: Optional[Iterable[int]] = None, workers: Optional[int] = None):

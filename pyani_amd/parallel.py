@@ -152,6 +152,95 @@ def anim_allgather(compute_pairs: Callable, n_genomes: int, device: torch.device
     return grid
 
 
+# ---- dynamic dealing: the ranks PULL row chunks from a cross-rank counter ------------------------------------------------------
+# Pair cost varies ~60 x with relatedness and row cost several-fold with the divergence of a genome's family; a static deal (the
+# hash above) leaves the step waiting for its unluckiest rank, and every launch inside a rank ends on its slowest unit.  pyani's
+# own runner is a pool that hands the next job to whichever worker falls idle (run_multiprocessing.py:113-152); the counterpart
+# across processes: the step's rows, in the scrambled order, are cut into GUIDED chunks (each about half of an even share of
+# what is left: large first, small at the end — the classic guided self-scheduling), every rank computes the same chunk list, and
+# an atomic counter in a TCPStore hands out chunk numbers.  One engine call per chunk; results gathered once per step.
+def guided_chunks(n_rows: int, world: int, min_rows: int = 2) -> List[Tuple[int, int]]:
+    """[lo, hi) spans of the guided chunk sequence over n_rows rows for `world` ranks."""
+    spans, lo = [], 0
+    while lo < n_rows:
+        c = max(min_rows, -(-(n_rows - lo) // (2 * world)))
+        hi = min(n_rows, lo + c)
+        spans.append((lo, hi))
+        lo = hi
+    return spans
+
+
+class RowQueue:
+    """The cross-rank counter: `next_chunk(step)` returns the next unclaimed chunk number of that step (atomic over all ranks)."""
+
+    def __init__(self, rank: int, world: int, host: str, port: int, timeout_s: float = 1800.0):
+        import datetime
+        self.world = world
+        self.store = dist.TCPStore(host, port, world, is_master=(rank == 0), timeout=datetime.timedelta(seconds=timeout_s),
+                                   wait_for_workers=True) if world > 1 else None
+        self._local = {}
+
+    def next_chunk(self, step_key: str) -> int:
+        if self.store is None:
+            k = self._local.get(step_key, 0)
+            self._local[step_key] = k + 1
+            return k
+        return int(self.store.add(f"rows/{step_key}", 1)) - 1
+
+
+def anim_allgather_dynamic(compute_pairs: Callable, n_genomes: int, device: torch.device, queue: RowQueue, step_key: str,
+                           rows: Sequence[int], symmetric: bool = True, group=None, min_rows: int = 2):
+    """anim_allgather with the rows PULLED in guided chunks from `queue` instead of dealt statically.  Returns (grid, stats):
+    grid as anim_allgather returns it; stats = {"busy_s": [per rank], "chunks": [per rank], "imbalance": max / mean of busy_s}.
+    Two small collectives (per-rank counts and busy times, then the padded results) per step."""
+    import time
+    import numpy as np
+    rank, world = (dist.get_rank(group), dist.get_world_size(group)) if dist.is_initialized() else (0, 1)
+    order = sorted(rows, key=lambda q: ((q * 0x9E3779B1) & 0xFFFFFFFF, q))      # related genomes sit side by side in sorted lists
+    spans = guided_chunks(len(order), world, min_rows)
+    mine_pairs, mine_vals, busy, taken = [], [], 0.0, 0
+    while True:
+        k = queue.next_chunk(step_key)
+        if k >= len(spans):
+            break
+        lo, hi = spans[k]
+        pairs = anim_pair_array(n_genomes, order[lo:hi], symmetric)
+        if len(pairs):
+            t0 = time.perf_counter()
+            vals = compute_pairs(pairs)
+            if vals.is_cuda:
+                torch.cuda.synchronize(vals.device)
+            busy += time.perf_counter() - t0
+            mine_pairs.append(pairs); mine_vals.append(vals)
+        taken += 1
+    n_mine = sum(len(p) for p in mine_pairs)
+    meta = torch.tensor([float(n_mine), busy, float(taken)], dtype=torch.float64, device=device)
+    if world > 1:
+        metas = torch.zeros(world * 3, dtype=torch.float64, device=device)
+        dist.all_gather_into_tensor(metas, meta, group=group)
+    else:
+        metas = meta
+    metas = metas.cpu().numpy().reshape(world, 3)
+    cap = int(metas[:, 0].max())
+    loc = torch.zeros((max(cap, 1), ANIM_FIELDS + 2), dtype=torch.int64, device=device)
+    loc[:, ANIM_FIELDS] = -1
+    if n_mine:
+        loc[:n_mine, :ANIM_FIELDS] = torch.cat(mine_vals)
+        loc[:n_mine, ANIM_FIELDS:] = torch.from_numpy(np.concatenate(mine_pairs)).to(device)
+    if world > 1:
+        allv = torch.zeros((world * max(cap, 1), ANIM_FIELDS + 2), dtype=torch.int64, device=device)
+        dist.all_gather_into_tensor(allv, loc, group=group)
+    else:
+        allv = loc
+    valid = allv[:, ANIM_FIELDS] >= 0
+    q, s_ = allv[valid, ANIM_FIELDS], allv[valid, ANIM_FIELDS + 1]
+    grid = torch.zeros((n_genomes, n_genomes, ANIM_FIELDS), dtype=torch.int64, device=device)
+    grid[q, s_] = allv[valid, :ANIM_FIELDS]
+    busy_s = metas[:, 1].tolist()
+    mean = sum(busy_s) / len(busy_s)
+    return grid, {"busy_s": busy_s, "chunks": [int(x) for x in metas[:, 2]], "imbalance": (max(busy_s) / mean) if mean > 0 else 1.0}
+
+
 def anib_records_to_tensor(recs, device: torch.device) -> torch.Tensor:
     """Engine.anib_pairs structured array -> int64 [n, ANIM_FIELDS] tensor: aln_length, sim_errors, n_frags, n_kept, mean
     pident (bit-cast, lossless), status — fragment mode shards and gathers exactly like ANIm (anim_allgather)."""

@@ -75,6 +75,21 @@ def test_one_to_one_filter_matches_delta_filter(filter_check):
     assert exact_files == 27
 
 
+def test_python_restatement_of_the_one_to_one_filter_matches_delta_filter():
+    """oracle/anim_oracle.py:delta_filter_1to1 — the INDEPENDENT (pure-Python) restatement of `delta-filter -1`, the one the nucmer
+    oracle's records go through when whole parse_delta tuples are compared (bench.py's CPU leg, tests) — on the same 27 real pairs."""
+    files = [f for f in sorted((GOLD / "anim").glob("*/*.delta.gz")) if Path(str(f).replace(".delta.gz", ".filter.gz")).exists()]
+    checked = 0
+    for f in files:
+        al, _, _ = anim_oracle.read_delta(f)
+        fl, _, _ = anim_oracle.read_delta(str(f).replace(".delta.gz", ".filter.gz"))
+        keep = anim_oracle.delta_filter_1to1(al)
+        got = sorted((a.ref_id, a.qry_id, a.rs, a.re, a.qs, a.qe, a.errors) for a, k in zip(al, keep) if k)
+        assert got == sorted((a.ref_id, a.qry_id, a.rs, a.re, a.qs, a.qe, a.errors) for a in fl), f.name
+        checked += 1
+    assert checked == 27
+
+
 def test_run_matrices_vectorised_equals_cellwise_definition():
     """assemble_run_matrices (pyani_orm.update_comparison_matrices semantics, vectorised) against the cell-by-cell
     definition: [q, s] cells only, diagonals 1 / 1 / length / 0 / 1, hadamard = identity * cov_query."""

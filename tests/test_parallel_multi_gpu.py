@@ -60,3 +60,59 @@ def test_run_anim_with_devices_equals_single_engine(genome_dir, tmp_path):
     assert one.results == two.results and one.json == two.json
     with pytest.raises(ValueError):
         subcmd_anim.run_anim(d, write_output=True)      # refused before any work
+
+
+def test_alignment_parts_are_merged_into_the_callers_order():
+    """merge_alignment_parts (what MultiEngine.anim_alignments_batch does with its devices' chunks) against one flat result."""
+    from pyani_amd.engine import Engine
+    from pyani_amd.multi import merge_alignment_parts
+    rng = np.random.RandomState(5)
+    n = 23
+    counts = rng.randint(0, 5, size=n)
+    counts[4] = 0
+    off = np.zeros(n + 1, dtype=np.uint64); off[1:] = np.cumsum(counts)
+    recs = np.zeros(int(off[-1]), dtype=Engine.ALN_DTYPE)
+    recs["rs"] = np.arange(len(recs)) * 7 + 1
+    icnt = rng.randint(0, 4, size=len(recs))
+    ioff = np.zeros(len(recs) + 1, dtype=np.uint64); ioff[1:] = np.cumsum(icnt)
+    ind = np.arange(int(ioff[-1]), dtype=np.int64) * 3 - 5
+    order = rng.permutation(n)
+    chunks = [order[:9], order[9:10], order[10:]]
+    parts = []
+    for idx in chunks:          # what an engine would return for the chunk's own pair list
+        o = np.zeros(len(idx) + 1, dtype=np.uint64); o[1:] = np.cumsum(counts[idx])
+        r = np.concatenate([recs[int(off[p]):int(off[p + 1])] for p in idx]) if len(idx) else recs[:0]
+        ic = np.concatenate([icnt[int(off[p]):int(off[p + 1])] for p in idx]) if len(idx) else icnt[:0]
+        io = np.zeros(len(r) + 1, dtype=np.uint64); io[1:] = np.cumsum(ic)
+        iv = np.concatenate([ind[int(ioff[int(off[p])]):int(ioff[int(off[p + 1])])] for p in idx]) if len(idx) else ind[:0]
+        parts.append((o, r, io, iv))
+    o2, r2, io2, i2 = merge_alignment_parts(n, chunks, parts, True)
+    assert o2.tolist() == off.tolist() and r2.tobytes() == recs.tobytes() and io2.tolist() == ioff.tolist() and i2.tolist() == ind.tolist()
+    o3, r3, io3, i3 = merge_alignment_parts(n, chunks, [(p[0], p[1], None, None) for p in parts], False)
+    assert o3.tolist() == off.tolist() and r3.tobytes() == recs.tobytes() and io3 is None and i3 is None
+
+
+@pytest.mark.gpu
+def test_alignment_records_and_tetra_over_two_engines_equal_one(genome_dir):
+    """MultiEngine shards anim_alignments_batch (run_anim(write_output=True)) and TETRA over its devices: same records, same
+    indel lists, same Z-scores and matrix as one engine (two engines on GPU 0)."""
+    from pyani_amd.engine import Engine
+    from pyani_amd.multi import MultiEngine
+    paths = list(genome_dir["blochmannia"].values())[:4]
+    with Engine(0) as one:
+        ids = [one.add_fasta(p)[0] for p in paths]
+        pairs = [(a, b) for a in ids for b in ids if a != b]
+        want = one.anim_alignments_batch([a for a, _ in pairs], [b for _, b in pairs], with_indels=True)
+        want_t = one.tetra_matrix(ids)
+        want_c = one.tetra_counts(ids)
+    with MultiEngine([0, 0]) as two:
+        ids2 = [two.add_fasta(p)[0] for p in paths]
+        assert ids2 == ids
+        got = two.anim_alignments_batch([a for a, _ in pairs], [b for _, b in pairs], with_indels=True)
+        got_t = two.tetra_matrix(ids)
+        got_c = two.tetra_counts(ids)
+    assert got[0].tolist() == want[0].tolist() and got[2].tolist() == want[2].tolist() and got[3].tolist() == want[3].tolist()
+    for k in range(len(pairs)):      # the records of a pair: same set (a pair's own order is MUMmer's in both)
+        a, b = int(want[0][k]), int(want[0][k + 1])
+        assert got[1][a:b].tobytes() == want[1][a:b].tobytes()
+    assert all(x.tobytes() == y.tobytes() for x, y in zip(got_t, want_t)) and all(x.tobytes() == y.tobytes() for x, y in zip(got_c, want_c))
