@@ -62,6 +62,10 @@ def parse_args():
     ap.add_argument("--cpu-pairs", type=int, default=0, help="anim: ordered pairs timed by the CPU leg (0 = one per host thread, <= 128)")
     ap.add_argument("--cpu-genomes", type=int, default=2, help="tetra: genomes timed by the CPU leg")
     ap.add_argument("--no-tetra", action="store_true", help="anim: skip the nested C2 TETRA sub-record")
+    ap.add_argument("--no-side-records", action="store_true", help="anim: skip related_only / banded64 / strong-step side records")
+    ap.add_argument("--static-deal", action="store_true", help="anim, N > 1: deal a step's rows by the fixed hash (round 3) instead of the cross-rank queue")
+    ap.add_argument("--cold-e2e", action="store_true", help="anim, N = 1: measure ONE cold end-to-end run instead of the step loop: FASTA files on disk -> "
+                    "parse + pack (pg_add_fasta_batch) -> upload -> seed lists -> the whole grid -> run matrices -> JSON, one wall clock")
     args = ap.parse_args()
     w = args.workload
     if args.steps is None:
@@ -147,9 +151,10 @@ def anim_cpu_baseline(args, data, n, related, gpu_lookup):
                     (int(r["ref_aln_len"]), int(r["qry_aln_len"]), int(r["sim_errors"]), float(r["identity"]).hex(), int(r["status"])))
     return {
         "value": (n_rel_job + n_unrel_job) / job_wall, "unit": "genome-pairs/s", "cores": threads, "kind": "port",
-        "variant": "own-cpu (oracle/anim_cpu.cpp: host build of the engine's scalar statement of MUMmer's algorithm — exhaustive 20-mer "
-                   "table, mgaps clustering, postnuc extension with its dynamic band — g++ -O3 -mavx2, one pair per thread; NOT MUMmer's binary, whose "
-                   "suffix-tree matcher and full-rectangle re-alignments cost more per pair)",
+        "variant": "own-cpu (oracle/anim_cpu.cpp: the repo's CPU aligner — sparse 16-mer index of the reference (8 B per base, counting sort), every "
+                   "5th query position looked up, mgaps clustering, postnuc extension with MUMmer's dynamic band and certified bands for the forced "
+                   "re-alignments — g++ -O3 -mavx2, one pair per thread; NOT MUMmer's binary, whose suffix-tree matcher and full-rectangle "
+                   "re-alignments cost more per pair)",
         "cpu_s_per_related_pair": t_rel, "cpu_s_per_unrelated_pair": t_unrel,
         "sample": note + f"{len(sample)} ordered pairs of the same job ({len(rel)} related, {len(unrel)} unrelated) run one per host "
                   f"thread ({min(threads, len(sample))} concurrent, {wall:.1f} s wall, {float(secs.sum()):.0f} CPU-s): "
@@ -257,9 +262,79 @@ def related_only_record(eng, args):
             "pairs_per_s": len(pairs) / dt, "pairs_with_alignment": int((res["status"] == 0).sum())}
 
 
+SIMDS, CLOCK_GHZ = 1024, 2.4          # MI355X: 256 CUs x 4 SIMDs; a SIMD issues one wave64 VALU instruction per 4 cycles
+
+
+def _pmc_profile():
+    f = ROOT / "profiles" / "pmc_anim.json"
+    return json.loads(f.read_text()) if f.exists() else {}
+
+
+def run_anim_cold(args, local):
+    """ONE cold end-to-end run, one wall clock: FASTA files on disk -> pg_add_fasta_batch (read + parse +
+    2-bit pack on the host threads) -> upload -> the whole N x N grid (seed lists built on first use) in steps of R rows ->
+    pyani_amd.anim.assemble_run_matrices -> run_matrices_to_json.  Writing the synthetic FASTA files is NOT timed (they are
+    the job's input)."""
+    from pyani_amd import anim, parallel, synth
+    from pyani_amd.engine import Engine
+    n, R = args.genomes, max(1, min(args.rows_per_step, args.genomes))
+    tmp = Path(tempfile.mkdtemp(prefix="pyani_cold_", dir=os.environ.get("PYANI_BENCH_TMP", None)))
+    try:
+        t_write = time.perf_counter()
+        with ThreadPoolExecutor(min(64, os.cpu_count() or 2)) as ex:
+            def put(g):
+                seq, off = synth.genome(args.seed, n, g, args.length)
+                f = tmp / f"{synth.genome_name(g)}.fna"
+                synth.write_fasta(f, seq, off, synth.genome_name(g))
+                return f
+            paths = list(ex.map(put, range(n)))
+        t_write = time.perf_counter() - t_write
+        nbytes = sum(f.stat().st_size for f in paths)
+        t0 = time.perf_counter()
+        eng = Engine(local)
+        added = eng.add_fasta_batch(paths)
+        t_ingest = time.perf_counter() - t0
+        eng.upload()
+        eng.sync()
+        t_upload = time.perf_counter() - t0 - t_ingest
+        ids = np.asarray([a[0] for a in added], dtype=np.int32)
+        stems = [f.stem for f in paths]
+        lengths = {stems[k]: int(added[k][1]) for k in range(n)}
+        res = {}
+        t_grid = time.perf_counter()
+        for k in range((n + R - 1) // R):
+            rows = [r for r in range(k * R, min(n, (k + 1) * R))]
+            pairs = parallel.anim_pair_array(n, rows, symmetric=True)
+            out = eng.anim_pairs(ids[pairs[:, 0]], ids[pairs[:, 1]])
+            ok = out["status"] == 0
+            for (q, s_), r in zip(pairs[ok].tolist(), out[ok]):
+                res[(stems[q], stems[s_])] = (int(r["ref_aln_len"]), int(r["qry_aln_len"]), float(r["identity"]), int(r["sim_errors"]))
+        t_grid = time.perf_counter() - t_grid
+        t_asm = time.perf_counter()
+        mats = anim.assemble_run_matrices(res, lengths)
+        js = anim.run_matrices_to_json(mats)
+        t_asm = time.perf_counter() - t_asm
+        total = time.perf_counter() - t0
+        eng.close()
+        print(json.dumps({
+            "metric": "end-to-end cold wall-clock for the N x N ANIm matrices, from FASTA files on disk to the run's five matrices as JSON",
+            "value": total, "unit": "s", "n_gpus": 1, "steps": 1, "warmup": 0, "ms_per_step": total * 1e3, "higher_is_better": False,
+            "scaling": "strong", "vs_baseline": None, "dtype": "u32 packed DP words, i64 lengths, f64 identity", "data": "synthetic",
+            "end_to_end_cold_s": total,
+            "config": {"workload": f"C4 cold: {n} synthetic ~{args.length / 1e6:g} Mb FASTA files ({nbytes / 1e9:.2f} GB of text) -> {n * (n - 1)} ordered pairs -> matrices",
+                       "genomes": n, "fasta_bytes": nbytes, "pairs_with_alignment": len(res),
+                       "seconds": {"read_parse_pack": t_ingest, "upload": t_upload, "grid": t_grid, "matrices_and_json": t_asm},
+                       "json_bytes": sum(len(v) for v in js.values()), "not_timed_writing_the_input_files_s": t_write,
+                       "host_threads": os.cpu_count()}}), flush=True)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def run_anim(args, rank, world, local, dist, torch):
     from pyani_amd import _lib, parallel
     from pyani_amd.engine import Engine
+    if args.cold_e2e:
+        return run_anim_cold(args, local)
     eng = Engine(local)
     n, R = args.genomes, max(1, min(args.rows_per_step, args.genomes))
     if os.environ.get("PYANI_BENCH_BATCH_PAIRS"):   # development: pairs / matches per internal launch of pg_anim_pairs
@@ -272,31 +347,39 @@ def run_anim(args, rank, world, local, dist, torch):
     t_prep = time.perf_counter() - t_prep
     dev = torch.device("cuda", local)
     lens = np.array([len(d[0]) for d in data], dtype=np.int64)
+    # N > 1: the ranks PULL a step's rows in guided chunks from a cross-rank counter (pyani_amd.parallel.RowQueue: pair cost
+    # varies ~60 x and a static deal leaves the step waiting for its unluckiest rank); --static-deal: the fixed hash of round 3
+    queue = None
+    if dist is not None and not args.static_deal:
+        queue = parallel.RowQueue(rank, world, os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ.get("MASTER_PORT", "29500")) + 7)
 
-    def rows_of(step):
-        return [(step * R + i) % n for i in range(R)]
+    def rows_of(step, rows_per_step=None):
+        r = rows_per_step or R
+        return [(step * r + i) % n for i in range(r)]
 
     ids_np = np.asarray(ids, dtype=np.int32)
 
     def compute(pairs):   # pairs: int64 [m, 2] of (reference, query) genome numbers
         return parallel.anim_records_to_tensor(eng.anim_pairs(ids_np[pairs[:, 0]], ids_np[pairs[:, 1]]), dev)
 
-    tiles = {}
+    tiles, imbalance = {}, []
 
-    pair_cache = {}
-
-    def step(k, keep=False):
-        rows = rows_of(k)
-        if rows[0] not in pair_cache:   # (the job description, not part of the job: built once per tile)
-            pair_cache[rows[0]] = parallel.anim_pair_array(n, rows, symmetric=True)   # the rows' unordered pairs, both directions
-        pairs = pair_cache[rows[0]]
-        if dist is not None:
-            grid = parallel.anim_allgather(compute, n, dev, rows=rows, symmetric=True)
-            vals = grid[torch.from_numpy(pairs[:, 0]).to(dev), torch.from_numpy(pairs[:, 1]).to(dev)]
-        else:
+    def step(k, keep=False, rows=None, key=None):
+        rows = rows_of(k) if rows is None else rows
+        pairs = parallel.anim_pair_array(n, rows, symmetric=True)   # the rows' unordered pairs, both directions
+        if dist is None:
             vals = compute(pairs)
+        else:
+            if queue is not None:
+                grid, st = parallel.anim_allgather_dynamic(compute, n, dev, queue, key or f"k{k}", rows, symmetric=True)
+                if keep:
+                    imbalance.append(st)
+            else:
+                grid = parallel.anim_allgather(compute, n, dev, rows=rows, symmetric=True)
+            vals = grid[torch.from_numpy(pairs[:, 0]).to(dev), torch.from_numpy(pairs[:, 1]).to(dev)]
         if keep:
             tiles[k] = (pairs, vals)
+        return pairs
 
     def fence():
         eng.sync()
@@ -316,20 +399,57 @@ def run_anim(args, rank, world, local, dist, torch):
         t_cold = None
     stages = [_lib.K_ANIM_SEED, _lib.K_ANIM_HIT, _lib.K_ANIM_CLUSTER, _lib.K_ANIM_GAPS, _lib.K_ANIM_FWD, _lib.K_ANIM_BWD, _lib.K_ANIM_EXTEND,
               _lib.K_ANIM_EXTLANE, _lib.K_ANIM_FINISH]
-    eng.profile_reset()
-    eng.profile_config(kernel_mask=sum(1 << s_ for s_ in stages), every_n=1)   # ms-scale launches: an event pair costs nothing here
-    eng.profile_enable(True)
+    ext_stages = [_lib.K_ANIM_GAPS, _lib.K_ANIM_FWD, _lib.K_ANIM_BWD, _lib.K_ANIM_EXTEND, _lib.K_ANIM_EXTLANE]
+    # ---- the timed region: K steps between fences, no per-kernel events (they belong to the one-worker step below) ----------
     t0 = time.perf_counter()
     for k in range(args.warmup, args.warmup + args.steps):
         step(k, keep=True)
     fence()
     elapsed = time.perf_counter() - t0
-    eng.profile_enable(False)
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    # ---- the roofline step (untimed): ONE worker, so that the stages' HIP events are not timing the other worker's persistent waves
+    # (two streams made `anim_finish_kernel` look 379 ms long), engine counters read around it.  Each rank runs its
+    # static share of the next tile; rank 0 reports its own.
+    k_prof = args.warmup + args.steps
+    my_rows = parallel.anim_row_shard(rows_of(k_prof), rank, world)
+    prof_pairs = parallel.anim_pair_array(n, my_rows, symmetric=True)
+    eng.anim_set_workers(1)
+    eng.anim_counters(reset=True)
+    eng.profile_reset()
+    eng.profile_config(kernel_mask=sum(1 << s_ for s_ in stages), every_n=1)
+    eng.profile_enable(True)
+    t1 = time.perf_counter()
+    compute(prof_pairs)
+    eng.sync()
+    prof_s = time.perf_counter() - t1
+    eng.profile_enable(False)
     prof = {eng.kernel_name(s_): eng.profile_get(s_) for s_ in stages}
+    ext_ms = sum(eng.profile_get(s_)[0] for s_ in ext_stages)
+    cnt = eng.anim_counters()
+    eng.anim_set_workers(2)
+    fence()
+
+    # ---- N > 1: the same tile size as N = 1's step, dealt over all ranks (strong scaling of ONE step: launches shrink with N)
+    strong = None
+    bare = args.no_cpu_baseline or args.no_side_records      # (tests and profiling runs: the step loop and the roofline step only)
+    if dist is not None and not bare:
+        r1 = max(1, n // 10)
+        step(k_prof + 1, rows=rows_of(k_prof + 1, r1), key="strong_warm")
+        fence()
+        ts = time.perf_counter()
+        np_strong = 0
+        for j in range(2):
+            np_strong += len(step(k_prof + 2 + j, rows=rows_of(k_prof + 2 + j, r1), key=f"strong{j}"))
+        fence()
+        ts = time.perf_counter() - ts
+        tt = torch.tensor([ts], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        strong = {"rows_per_step": r1, "steps": 2, "ms_per_step": float(tt.item()) / 2 * 1e3, "pairs_per_s": np_strong / float(tt.item()),
+                  "note": f"the N = 1 step ({r1} rows, ~{r1 * (n - 1)} ordered pairs) dealt over {world} ranks: each rank's launches are 1/{world} the size"}
 
     if rank == 0:
         P = np.concatenate([tiles[k][0] for k in sorted(tiles)])                      # [M, 2] (reference, query)
@@ -342,22 +462,35 @@ def run_anim(args, rank, world, local, dist, torch):
         ok_rel = int(((status == 0) & related_m).sum())
         unrel_aln = int(((status == 0) & ~related_m).sum())
         step_s = elapsed / args.steps
+        # byte roofline of the dominant stage of the one-worker step
+        alg_prof = float(((lens[prof_pairs[:, 0]] + 3) // 4 + (lens[prof_pairs[:, 1]] + 3) // 4 + 32).sum())
         alg_bytes = float(((lens[P[:, 0]] + 3) // 4 + (lens[P[:, 1]] + 3) // 4 + 32).sum())
-        # the dominant kernel of THIS run, timed live with HIP events on the engine's stream (rank 0's launches)
         dom = max(prof, key=lambda name: prof[name][0])
         dom_ms, dom_n = prof[dom]
-        share = 1.0 / world                 # rank 0 ran 1/world of the rows
-        achieved = alg_bytes * share / (dom_ms * 1e-3) / 1e9 if dom_ms else 0.0
-        traffic = None
-        pmc = ROOT / "profiles" / "pmc_anim.json"
-        if pmc.exists():
-            traffic = json.loads(pmc.read_text()).get(dom, {}).get("hbm_bytes_per_launch")
+        achieved = alg_prof / (dom_ms * 1e-3) / 1e9 if dom_ms else 0.0
+        pmc = _pmc_profile()
+        traffic = pmc.get(dom, {}).get("hbm_bytes_per_launch")
+        # VALU-issue roofline of the extension stage (integer DP in registers: bytes are not its bound): DP cells per second against the
+        # rate at which the chip can issue the vector instructions those cells cost (instructions per cell: rocprofv3 SQ_INSTS_VALU of
+        # the extension kernels / the engines' own cell count of the same command, profiles/pmc_anim.json)
+        cells = int(cnt[2]) + int(cnt[5]) + int(cnt[8])
+        vpc = pmc.get("extension_valu_per_cell")
+        valu = None
+        if vpc and ext_ms:
+            peak_cells = SIMDS * CLOCK_GHZ * 1e9 / 4.0 / vpc
+            valu = {"bound": "valu-issue", "kernels": "anim_postnuc_{gaplane,gapbig,fwd,rehearse,bwd,(walk),forced,forced_wide}_kernel",
+                    "achieved": cells / (ext_ms * 1e-3), "peak": peak_cells, "unit": "DP cells/s", "frac": cells / (ext_ms * 1e-3) / peak_cells,
+                    "cells": cells, "anti_diagonals": int(cnt[1]), "extension_ms": ext_ms, "valu_instructions_per_cell": vpc,
+                    "peak_definition": f"{SIMDS} SIMDs x {CLOCK_GHZ} GHz / 4 cycles per wave64 VALU instruction / instructions per cell "
+                                       f"({pmc.get('extension_valu_source', 'profiles/pmc_anim.json')})"}
         # hash of one whole N x N result grid (the last occurrence of every cell among the timed steps), if the steps cover it
         dense = np.zeros((n, n, g.shape[1]), dtype=np.int64)
         covered = np.zeros((n, n), dtype=bool)
         dense[P[:, 0], P[:, 1]] = g
         covered[P[:, 0], P[:, 1]] = True
         sha = hashlib.sha1(dense.tobytes()).hexdigest() if int(covered.sum()) == n * (n - 1) else None
+        grid_s = elapsed / pairs_done * n * (n - 1)
+        measured_cold = pmc.get("end_to_end_cold_s_measured")
         out = {
             "metric": "genome-pairs/sec (ordered pairs) + wall-clock for the N x N ANIm grid: nucmer --mum + delta-filter -1 + "
                       "parse_delta equivalent per ordered pair, genomes resident in HBM; vs the CPU path on this box's host cores",
@@ -365,6 +498,17 @@ def run_anim(args, rank, world, local, dist, torch):
             "ms_per_step": step_s * 1e3, "higher_is_better": True, "scaling": "weak" if args.rows_default else "strong", "vs_baseline": None,
             "dtype": "u32 packed DP words (score << 17 | state << 15 | errors), i64 lengths, f64 identity", "data": "synthetic",
             "related_pairs_per_s": n_related / elapsed,
+            "series": {
+                "weak": {"rows_per_step_per_gpu": R // world if args.rows_default else None, "pairs_per_s": pairs_done / elapsed, "ms_per_step": step_s * 1e3},
+                "fixed_grid": {"grid_pairs": n * (n - 1), "wall_s_grid": grid_s,
+                               "note": "the FIXED 1000-genome grid at this rate: strong-scaling speed-up over N = 1 = wall_s_grid(1) / wall_s_grid(N) "
+                                       "(per-GPU work per step is constant, so the weak series prices the fixed grid directly)"},
+                "strong_step": strong,
+            },
+            "imbalance": None if not imbalance else {
+                "max_over_mean_rank_busy_time_per_step": [round(st["imbalance"], 4) for st in imbalance],
+                "mean": float(np.mean([st["imbalance"] for st in imbalance])), "worst": float(max(st["imbalance"] for st in imbalance)),
+                "chunks_per_rank_last_step": imbalance[-1]["chunks"], "dealing": "guided chunks from a cross-rank counter (pyani_amd.parallel.RowQueue)"},
             "config": {
                 "workload": f"C4: ANIm N x N grid on {n} synthetic ~{args.length / 1e6:g} Mb genomes (SURVEY.md §8(d) generator, seed "
                             f"{args.seed}; {n * (n - 1)} ordered pairs, {n * (n // K - 1)} of them between descendants of one ancestor); "
@@ -374,17 +518,19 @@ def run_anim(args, rank, world, local, dist, torch):
                                f"{n // R if n % R == 0 else n / R:g} steps = the whole grid"),
                 "genomes": n, "rows_per_step": R, "pairs_per_step": pairs_done / args.steps, "pairs_timed": pairs_done,
                 "related_pairs_timed": n_related, "related_pairs_with_alignment": ok_rel, "unrelated_pairs_with_alignment": unrel_aln,
-                "grid_pairs": n * (n - 1), "wall_s_grid": elapsed / pairs_done * n * (n - 1),
+                "grid_pairs": n * (n - 1), "wall_s_grid": grid_s,
                 "identity_related_min_med_max": [float(x) for x in np.percentile(ident[(status == 0) & related_m], [0, 50, 100])]
                 if ok_rel else None,
                 "results_sha1_full_grid": sha,
-                "parallelism": f"1 process/GPU x {world}; genomes replicated; each step's rows dealt over the ranks; one RCCL "
-                               f"all-gather per step" if world > 1 else "1 GPU",
+                "parallelism": (f"1 process/GPU x {world}; genomes replicated; each step's rows "
+                                + ("pulled in guided chunks from a cross-rank counter" if queue is not None else "dealt over the ranks by a fixed hash")
+                                + "; one RCCL all-gather of 64 B per pair per step") if world > 1 else "1 GPU",
                 "host_prep_s": t_prep, "cold_first_step_s": t_cold,
                 "end_to_end_cold_s_estimate": (t_prep + (t_cold or step_s) + (n / R - 1) * step_s + ASSEMBLY_S_PER_PAIR * n * (n - 1)),
-                "note_end_to_end": "synthetic-genome generation + 2-bit packing + upload (host_prep_s; a FASTA run parses instead: 27.6 GB/s of text, "
-                                   "profiles/r01_ingest_100x5M.json) + the first step with its one-time seed-list builds + the remaining steps of one grid at "
-                                   "the timed rate + the vectorised matrix assembly (1.2 us per pair, measured r02 on 999 000 pairs)",
+                "end_to_end_cold_s_measured": measured_cold,
+                "note_end_to_end": "estimate = this run's synthetic-genome generation + packing + upload + first step + the remaining steps of one grid at "
+                                   "the timed rate + matrix assembly; measured = `bench.py --cold-e2e` (FASTA files on disk -> matrices as JSON, one wall "
+                                   "clock), kept in profiles/pmc_anim.json with its provenance",
                 "extender": "nucmer (MUMmer 3.23's postnuc algorithm restated: exact on every nucmer output file the reference's tests hold)",
                 "note_related_pairs_per_s": "related pairs timed / the same wall time (unrelated pairs of the tile included): a lower "
                                             "bound of the related-only rate; 97.6 % of C4's pairs are unrelated by construction",
@@ -392,14 +538,16 @@ def run_anim(args, rank, world, local, dist, torch):
             "roofline": {
                 "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "algorithmic_bytes_per_launch": alg_bytes * share / max(dom_n, 1), "avg_launch_ms": dom_ms / max(dom_n, 1),
+                "algorithmic_bytes_per_launch": alg_prof / max(dom_n, 1), "avg_launch_ms": dom_ms / max(dom_n, 1),
                 "launches": int(dom_n),
-                "definition": "SURVEY.md §8(d): ceil(Lq/4) + ceil(Ls/4) + 32 B per ordered pair, summed over the pairs rank 0 ran in the "
-                              "timed steps, / the HIP-event time of the stage that took longest (events on the engine's own stream)",
+                "definition": "SURVEY.md §8(d): ceil(Lq/4) + ceil(Ls/4) + 32 B per ordered pair of ONE untimed step run with a single worker "
+                              "(stage events un-overlapped; rank 0's share at N > 1) / the HIP-event time of the stage that took longest in it",
+                "one_worker_step": {"pairs": int(len(prof_pairs)), "seconds": prof_s,
+                                    "stage_ms": {name: round(ms, 3) for name, (ms, _) in prof.items()},
+                                    "stage_launches": {name: int(c) for name, (_, c) in prof.items()}},
                 "pipeline_achieved": alg_bytes / elapsed / 1e9, "pipeline_frac": alg_bytes / elapsed / 1e9 / HBM_PEAK_GBS,
-                "stage_ms": {name: round(ms, 3) for name, (ms, _) in prof.items()},
-                "stage_launches": {name: int(cnt) for name, (_, cnt) in prof.items()},
-                "stage_sum_ms": round(sum(ms for ms, _ in prof.values()), 3), "timed_region_ms": round(elapsed * 1e3, 3),
+                "timed_region_ms": round(elapsed * 1e3, 3),
+                "valu_issue": valu,
             },
         }
         if world == 1 and not args.no_cpu_baseline:
@@ -411,18 +559,28 @@ def run_anim(args, rank, world, local, dist, torch):
             related_all = ((np.arange(n)[:, None] % K) == (np.arange(n)[None, :] % K))[~np.eye(n, dtype=bool)]
             out["cpu_baseline"] = anim_cpu_baseline(args, data, n, related_all, gpu_lookup)
             out["cpu_baseline"]["speedup_gpu_over_cpu_job"] = out["value"] / out["cpu_baseline"]["value"]
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not bare:
             out["related_only"] = related_only_record(eng, args)
+            cb = out.get("cpu_baseline")
+            if cb and cb.get("cpu_s_per_related_pair"):
+                # the two halves of the job priced separately: a genus-level job is all related pairs
+                cpu_rel = cb["cores"] / cb["cpu_s_per_related_pair"]
+                cpu_unrel = cb["cores"] / cb["cpu_s_per_unrelated_pair"] if cb.get("cpu_s_per_unrelated_pair") else None
+                unrel_gpu = (pairs_done - n_related) / max(elapsed - n_related / out["related_only"]["pairs_per_s"], 1e-9)
+                cb["speedup_related_only"] = out["related_only"]["pairs_per_s"] / cpu_rel
+                cb["speedup_unrelated_only_estimate"] = (unrel_gpu / cpu_unrel) if cpu_unrel else None
+                cb["note_speedups"] = ("related-only: the GPU's all-related family job / (host threads / CPU seconds per related pair); unrelated-only: the "
+                                       "timed tiles with their related pairs' time (at the related-only rate) taken out / the same for the CPU")
             # the opt-in approximate extender of rounds 1-2 on one step of the same job, for scale (NOT exact: DESIGN.md §8b)
             eng.anim_set_extender("banded64")
             step(args.warmup)                     # its own scratch and lists are built here
             fence()
-            t1 = time.perf_counter()
-            step(args.warmup + 1)
+            tb = time.perf_counter()
+            pb = step(args.warmup + 1)
             fence()
-            dt = time.perf_counter() - t1
+            dt = time.perf_counter() - tb
             eng.anim_set_extender("nucmer")
-            out["banded64_extender"] = {"pairs_per_s": len(pair_cache[rows_of(args.warmup + 1)[0]]) / dt, "ms_per_step": dt * 1e3,
+            out["banded64_extender"] = {"pairs_per_s": len(pb) / dt, "ms_per_step": dt * 1e3,
                                         "note": "PG_EXTENDER_BANDED64: fixed 64-diagonal band, fitted junction rules; 99.55 % of the hold-out MUMmer records, "
                                                 "identity up to 3.3e-4 off — not what `value` measures"}
         if world == 1 and not args.no_tetra:

@@ -258,8 +258,8 @@ int pg_profile_reset(pg_ctx* ctx);
 #define PG_K_ANIM_SEED 4     /* anim_seed_kernel: LDS-resident reference groups, streamed query lists */
 #define PG_K_ANIM_HIT 5      /* anim_hoff_kernel + anim_hit_scatter_kernel + anim_hit_kernel + anim_scatter_kernel */
 #define PG_K_ANIM_CLUSTER 6  /* anim_cluster_wave_kernel (one launch; + anim_cluster_prep_kernel when few units) */
-#define PG_K_ANIM_GAPS 7     /* nucmer extender: anim_postnuc_gaplist / gaplane<16,32,59> / gap kernels (match-to-match alignments); banded64: anim_gaps_kernel + anim_gapsort_kernel + the four anim_gapdp_lane_kernel launches */
-#define PG_K_ANIM_EXTLANE 8  /* nucmer extender: anim_postnuc_forced_kernel; banded64: anim_extdp_lane_kernel */
+#define PG_K_ANIM_GAPS 7     /* nucmer extender: anim_postnuc_gaplist / gaplane<16,32,59> / gapbig kernels (match-to-match alignments); banded64: anim_gaps_kernel + anim_gapsort_kernel + the four anim_gapdp_lane_kernel launches */
+#define PG_K_ANIM_EXTLANE 8  /* nucmer extender: anim_postnuc_forced_kernel (narrow bands) + anim_postnuc_forced_wide_kernel; banded64: anim_extdp_lane_kernel */
 #define PG_K_ANIM_EXTEND 9   /* nucmer extender: anim_postnuc_kernel (the units' walks); banded64: anim_extreq_kernel / anim_extend_kernel / anim_gapreq_kernel / anim_gapdp_kernel */
 #define PG_K_ANIM_FINISH 10  /* anim_finish_kernel */
 #define PG_K_ANIB_BUCKET 11  /* anib_bucket_kernel: seeds clipped to fragments, counting sort by fragment */

@@ -111,8 +111,19 @@ def calculate_anim_pairs(infiles: Iterable, engine: Engine = None, nofilter: boo
     return out, lengths
 
 
-def read_delta(path):
-    """MUMmer .delta/.filter -> list of (rseq, qseq, rs, re, qs, qe, errors) with per-file sequence ordinals."""
+def read_delta(path, with_indels: bool = False):
+    """MUMmer .delta/.filter -> list of (rseq, qseq, rs, re, qs, qe, errors) with per-file sequence ordinals; with_indels=True:
+    (records, indel lists) — record k's signed indel offsets without the terminating 0 (pyani_amd.nucmer.DeltaData is the object
+    model of the same files, pyani/nucmer.py:47-351)."""
+    if with_indels:
+        from .nucmer import DeltaData
+        recs, lists, rid, qid = [], [], {}, {}
+        for comp in DeltaData.from_file(path).comparisons:
+            cur = (rid.setdefault(comp.header.reference, len(rid)), qid.setdefault(comp.header.query, len(qid)))
+            for a in comp.alignments:
+                recs.append((cur[0], cur[1], a.refstart, a.refend, a.querystart, a.queryend, a.errs))
+                lists.append(a.indel_offsets)
+        return recs, lists
     recs, rid, qid = [], {}, {}
     cur = None
     opener = gzip.open if str(path).endswith(".gz") else open

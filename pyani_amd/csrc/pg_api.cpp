@@ -19,7 +19,7 @@ static const char* const KERNEL_NAMES[PG_K__COUNT] = {"tetra_count_kernel", "tet
                                                       "tetra_pairs_kernel", "anim_seed_kernel", "anim_hit_kernels",
                                                       "anim_cluster_wave_kernel",
                                                       // the three extension-stage slots, by extender: nucmer (default) / banded64
-                                                      "anim_postnuc_gap_kernels|anim_gap_kernels", "anim_postnuc_forced_kernel|anim_extdp_lane_kernel",
+                                                      "anim_postnuc_gap_kernels|anim_gap_kernels", "anim_postnuc_forced_kernels|anim_extdp_lane_kernel",
                                                       "anim_postnuc_kernel|anim_extend_kernels", "anim_finish_kernel", "anib_bucket_kernel",
                                                       "anib_frag_kernel", "anim_postnuc_fwd_kernel", "anim_postnuc_rehearse_kernel+anim_postnuc_bwd_kernel"};
 

@@ -63,15 +63,17 @@ def test_reduction_bit_exact_on_all_fixture_files(eng, gold):
         anim._tuple(eng.anim_reduce([[]])[0])       # empty file: parse_delta raises ZeroDivisionError (anim.py:396)
 
 
-def test_delta_filter_then_reduce_close_to_filter_files(eng, gold):
-    """delta -> (GPU 1-to-1 filter) -> reduction vs the .filter file's tuple: identity within 2e-4 on every pair."""
+def test_delta_filter_then_reduce_equals_the_filter_files(eng, gold):
+    """delta -> (GPU 1-to-1 filter) -> reduction == the parse_delta tuple of MUMmer's own .filter file, on all 27 pairs that have
+    both: aligned lengths, errors, identity to the last bit (the filter reproduces every keep / drop decision of delta-filter -1)."""
     from pyani_amd import anim
     rels = sorted(r for r in gold if r.endswith(".delta") and r.replace(".delta", ".filter") in gold)
+    assert len(rels) == 27
     out = eng.anim_reduce([anim.read_delta(GOLD / "anim" / (r + ".gz")) for r in rels], apply_filter=True)
     for rel, r in zip(rels, out):
         want = gold[rel.replace(".delta", ".filter")]
-        assert abs(float(r["identity"]) - want[2]) < 2e-4, rel
-        assert abs(int(r["ref_aln_len"]) - want[0]) <= 0.004 * want[0], rel
+        assert [int(r["ref_aln_len"]), int(r["qry_aln_len"]), float(r["identity"]).hex(), int(r["sim_errors"])] == \
+               [want[0], want[1], float(want[2]).hex(), want[3]], rel
 
 
 @pytest.fixture(scope="module")

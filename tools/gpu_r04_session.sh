@@ -59,6 +59,9 @@ tetra)
   cd $R
   f=$(find $O/tetra_kt -name "*kernel_stats.csv" | head -1); cp $f $O/tetra_kernel_stats.csv; head -8 $f | cut -c1-200
   for d in tetra_fetch tetra_write tetra_sq; do python tools/summarize_pmc.py $O/$d $O/${d}_summary.csv 2>&1 | tail -6; done ;;
+cold)    # one cold end-to-end run of the whole C4 job from FASTA files on disk
+  PYANI_BENCH_TMP=/tmp timeout 1200 python bench.py --gpus 1 --cold-e2e > $O/cold_e2e.json 2> $O/cold_e2e.err; echo "cold rc=$?"
+  cut -c1-1200 $O/cold_e2e.json; tail -3 $O/cold_e2e.err ;;
 esac
 done
 du -sh $O

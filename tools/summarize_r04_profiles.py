@@ -1,0 +1,91 @@
+#!/usr/bin/env python3
+"""gpurun_out/r04 (scratch) -> profiles/ (tracked): the rocprofv3 summaries of `bench.py --gpus 1 --steps 1 --warmup 1
+--no-cpu-baseline --no-tetra` (C4, one step = a tenth of the grid) that bench.py's roofline block reads.
+
+  profiles/r04_anim_C4_rocprofv3_kernel_stats_one_worker.csv / ..._two_workers.csv   --kernel-trace --stats
+  profiles/r04_anim_C4_pmc_fetch_summary.csv / _write_summary.csv / _sq_summary.csv     --pmc passes (one worker), per kernel
+  profiles/pmc_anim.json   per bench stage: HBM bytes per launch (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, MI355X_MICROARCH.md §HBM);
+                           extension_valu_per_cell = SQ_INSTS_VALU of the extension kernels / the engines' own DP-cell count of
+                           the same command (PYANI_PN_STATS run); end_to_end_cold_s_measured from the --cold-e2e run if present
+Usage: python tools/summarize_r04_profiles.py"""
+import csv
+import json
+import re
+import shutil
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+SRC, DST = ROOT / "gpurun_out" / "r04", ROOT / "profiles"
+STAGE = {   # rocprofv3 kernel -> the stage name bench.py reports (pg_kernel_name)
+    "anim_seed_kernel": "anim_seed_kernel",
+    "anim_hit_kernel": "anim_hit_kernels", "anim_hit_scatter_kernel": "anim_hit_kernels", "anim_hoff_kernel": "anim_hit_kernels", "anim_scatter_kernel": "anim_hit_kernels",
+    "anim_cluster_wave_kernel": "anim_cluster_wave_kernel", "anim_cluster_prep_kernel": "anim_cluster_wave_kernel",
+    "anim_chain_range_kernel": "anim_cluster_wave_kernel", "anim_chain_merge_kernel": "anim_cluster_wave_kernel",
+    "anim_postnuc_gaplist_kernel": "anim_postnuc_gap_kernels|anim_gap_kernels", "anim_postnuc_gapbig_kernel": "anim_postnuc_gap_kernels|anim_gap_kernels",
+    "anim_postnuc_gaplane_kernel<16>": "anim_postnuc_gap_kernels|anim_gap_kernels", "anim_postnuc_gaplane_kernel<32>": "anim_postnuc_gap_kernels|anim_gap_kernels",
+    "anim_postnuc_gaplane_kernel<59>": "anim_postnuc_gap_kernels|anim_gap_kernels",
+    "anim_postnuc_fwd_kernel": "anim_postnuc_fwd_kernel",
+    "anim_postnuc_rehearse_kernel": "anim_postnuc_rehearse_kernel+anim_postnuc_bwd_kernel", "anim_postnuc_bwd_kernel": "anim_postnuc_rehearse_kernel+anim_postnuc_bwd_kernel",
+    "anim_postnuc_kernel": "anim_postnuc_kernel|anim_extend_kernels",
+    "anim_postnuc_forced_kernel": "anim_postnuc_forced_kernels|anim_extdp_lane_kernel", "anim_postnuc_forced_wide_kernel": "anim_postnuc_forced_kernels|anim_extdp_lane_kernel",
+    "anim_finish_kernel": "anim_finish_kernel",
+}
+EXT = [k for k in STAGE if k.startswith("anim_postnuc_")]
+
+
+def rows(path):
+    return {r["kernel"]: r for r in csv.DictReader(open(path))} if path.exists() else {}
+
+
+for w, name in (("kt1", "one_worker"), ("kt2", "two_workers")):
+    f = SRC / f"{w}_kernel_stats.csv"
+    if f.exists():
+        shutil.copyfile(f, DST / f"r04_anim_C4_rocprofv3_kernel_stats_{name}.csv")
+for w in ("fetch", "write"):
+    f = SRC / f"pmc_{w}_summary.csv"
+    if f.exists():
+        shutil.copyfile(f, DST / f"r04_anim_C4_pmc_{w}_summary.csv")
+if (SRC / "sq_summary.csv").exists():
+    shutil.copyfile(SRC / "sq_summary.csv", DST / "r04_anim_C4_pmc_sq_summary.csv")
+fetch, write, sq = rows(SRC / "pmc_fetch_summary.csv"), rows(SRC / "pmc_write_summary.csv"), rows(SRC / "sq_summary.csv")
+out = {"round": "r04",
+       "command": "python bench.py --gpus 1 --steps 1 --warmup 1 --no-cpu-baseline --no-tetra under rocprofv3 --pmc <counter> with PYANI_ANIM_WORKERS=1 "
+                  "(C4, a step = a tenth of the grid: 99 900 ordered pairs; 2 launches per kernel: the warm-up step and the timed one)",
+       "correction": "FETCH_SIZE doubled (gfx950 rocprofv3 tallies 128-B read requests at 64 B, MI355X_MICROARCH.md §HBM; exact for wide coalesced streams, "
+                     "an upper bound for narrower accesses); WRITE_SIZE as reported (uncalibrated)"}
+stage_bytes = {}
+for k, st in STAGE.items():
+    f, w = fetch.get(k), write.get(k)
+    if f and w:
+        n = max(1, int(f["launches"]))
+        b = 2 * 1024 * float(f["FETCH_SIZE_sum"]) / n + 1024 * float(w["WRITE_SIZE_sum"]) / max(1, int(w["launches"]))
+        stage_bytes.setdefault(st, {"kernels": {}, "hbm_bytes_per_launch": 0})
+        stage_bytes[st]["kernels"][k] = {"FETCH_SIZE_KiB_per_launch": float(f["FETCH_SIZE_sum"]) / n, "WRITE_SIZE_KiB_per_launch": float(w["WRITE_SIZE_sum"]) / max(1, int(w["launches"]))}
+        stage_bytes[st]["hbm_bytes_per_launch"] += int(b)
+out.update(stage_bytes)
+# instructions per DP cell of the extension stage
+stats = SRC / "bench_c4_stats.err"
+cells = None
+if stats.exists():
+    m = re.search(r"regs: calls \d+ steps (\d+) cells (\d+).*?lds: calls \d+ steps \d+ cells (\d+).*?global: calls \d+ steps \d+ cells (\d+)", stats.read_text())
+    if m:
+        cells = int(m.group(2)) + int(m.group(3)) + int(m.group(4))
+        out["extension_cells_per_launch"] = cells
+        out["extension_anti_diagonals_per_launch"] = int(m.group(1))
+if cells and sq:
+    valu = sum(float(sq[k]["SQ_INSTS_VALU_sum"]) / max(1, int(sq[k]["launches"])) for k in EXT if k in sq)
+    salu = sum(float(sq[k]["SQ_INSTS_SALU_sum"]) / max(1, int(sq[k]["launches"])) for k in EXT if k in sq)
+    out["extension_valu_per_cell"] = valu / cells
+    out["extension_salu_per_cell"] = salu / cells
+    out["extension_valu_source"] = ("rocprofv3 SQ_INSTS_VALU of the anim_postnuc_* kernels per launch (profiles/r04_anim_C4_pmc_sq_summary.csv) / the engines' "
+                                    "DP-cell count of one launch of the same step (profiles/r04_pn_stats_C4_step.txt)")
+cold = SRC / "cold_e2e.json"
+if cold.exists():
+    rec = json.loads([l for l in cold.read_text().splitlines() if l.startswith("{")][-1])
+    out["end_to_end_cold_s_measured"] = rec["end_to_end_cold_s"]
+    out["end_to_end_cold_breakdown_s"] = rec["config"]["seconds"]
+    shutil.copyfile(cold, DST / "r04_cold_e2e_C4.json")
+(DST / "pmc_anim.json").write_text(json.dumps(out, indent=1) + "\n")
+print(json.dumps({k: v for k, v in out.items() if not isinstance(v, dict)}, indent=1))
+for st, v in stage_bytes.items():
+    print(f"{st:60s} {v['hbm_bytes_per_launch'] / 1e9:9.2f} GB per launch")
