@@ -918,8 +918,8 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
     }
     const size_t req_cap = Mp + 16;      // one slot per match slot: a walk records at most one forced run per alignment it starts, and starts at most one per match
     A->pn_req_n = req_cap;
-    if (req_cap > A->pn_req_cap) { if ((rc = regrow(ctx, A->pn_reqs, req_cap + req_cap / 2))) return rc; if ((rc = regrow(ctx, A->pn_wide, req_cap + req_cap / 2))) return rc; A->pn_req_cap = req_cap + req_cap / 2; }
-    PG_HIP(ctx, hipMemsetAsync(A->pn_cursor, 0, 64, cur_stream(ctx)));   // [0] unit cursor, [1] forced runs recorded ([7]: the long ones), [2] forced-run cursor, [3] chain / big-gap cursor, [4..6] small gaps by class ([11]: gaps left to the wave engine), [8] cluster cursor of the forward extensions, [9] unit cursor of the rehearsal, [10] cluster cursor of the backward searches
+    if (req_cap > A->pn_req_cap) { if ((rc = regrow(ctx, A->pn_reqs, req_cap + req_cap / 2))) return rc; if ((rc = regrow(ctx, A->pn_wide, 2 * (req_cap + req_cap / 2)))) return rc; A->pn_req_cap = req_cap + req_cap / 2; }
+    PG_HIP(ctx, hipMemsetAsync(A->pn_cursor, 0, 64, cur_stream(ctx)));   // [0] unit cursor, [1] forced runs recorded ([7]: the long ones), [2] forced-run cursor, [3] chain / big-gap cursor, [4..6] small gaps by class ([11]: gaps left to the wave engine), [8] cluster cursor of the forward extensions, [9] unit cursor of the rehearsal, [10] cluster cursor of the backward searches, [12] / [13] wide forced runs: count / cursor, [14] / [15] huge ones
     if (n_wl && trace) PG_HIP(ctx, hipMemcpyAsync(A->choff_d, choff.data(), choff.size() * 4, hipMemcpyHostToDevice, cur_stream(ctx)));
     if (n_wl && !trace) {     // the (unit, chain) work list, then every cluster's match-to-match alignments
       if (n_wl > A->wl) { if ((rc = regrow(ctx, A->wl_d, n_wl + n_wl / 2))) return rc; A->wl = n_wl + n_wl / 2; }
@@ -970,7 +970,11 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
       hipLaunchKernelGGL(anim_postnuc_forced_kernel, dim3(pn_waves_pre), dim3(64), 0, cur_stream(ctx), A->refs_d, A->units_d, A->pn_reqs,
                          A->pn_cursor + 1, (uint32_t)req_cap, A->pn_cursor + 2, A->pn_n, A->pn_wide, A->pn_cursor + 12);
       hipLaunchKernelGGL(anim_postnuc_forced_wide_kernel, dim3(pn_waves), dim3(64), 0, cur_stream(ctx), A->refs_d, A->units_d, A->pn_reqs,
-                         A->pn_cursor + 1, (uint32_t)req_cap, A->pn_cursor + 13, A->pn_n, A->pn_gscratch, A->pn_wide, A->pn_cursor + 12);
+                         A->pn_cursor + 1, (uint32_t)req_cap, A->pn_cursor + 13, A->pn_n, A->pn_gscratch, A->pn_wide, A->pn_cursor + 12,
+                         A->pn_wide + req_cap, A->pn_cursor + 14);
+      // runs whose band spans more than one wave's 2048 diagonals: a workgroup of four waves each (2 workgroups per CU)
+      hipLaunchKernelGGL(anim_postnuc_forced_huge_kernel, dim3((uint32_t)ctx->num_cu * 2u), dim3(64 * PN_HUGE_WAVES), 0, cur_stream(ctx), A->refs_d,
+                         A->units_d, A->pn_reqs, A->pn_cursor + 15, A->pn_n, A->pn_gscratch, A->pn_wide + req_cap, A->pn_cursor + 14);
     }
     pg_prof_end(ctx);
     if (pg_dev_env("PYANI_PN_STATS")) {   // development: what the engines did in this launch
@@ -987,8 +991,8 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
         unsigned long long ks[32], kz[32] = {0};
         PG_HIP(ctx, hipMemcpyFromSymbol(ks, HIP_SYMBOL(g_pn_kstats), sizeof(ks)));
         PG_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_pn_kstats), kz, sizeof(kz)));
-        const char* kn[7] = {"gaps", "forward", "backward-ahead", "walks", "forced narrow", "forced 512-1024", "forced 2048"};
-        for (int k = 0; k < 7; ++k)
+        const char* kn[8] = {"gaps", "forward", "backward-ahead", "walks", "forced narrow", "forced 512-1024", "forced 2048", "forced group 8192"};
+        for (int k = 0; k < 8; ++k)
           fprintf(stderr, "[pn-stats] diagonal engine in %-16s: %llu calls, %llu anti-diagonals, %llu cells\n", kn[k], ks[4 * k], ks[4 * k + 1], ks[4 * k + 2]);
       }
       for (int k = 13; k <= 17; k += 4)      // ticks of the 100 MHz wall clock -> ms

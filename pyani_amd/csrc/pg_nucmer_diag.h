@@ -184,8 +184,8 @@ struct DiagCtl {
     return n;
   }
   template <int DPL>
-  PG_HD void window_move(int32_t n) {      // the lanes' registers have moved n lanes down: every slot coordinate follows
-    const int32_t d = DPL * n;
+  PG_HD void window_move(int32_t n) { window_shift(DPL * n); }      // the lanes' registers have moved n lanes down
+  PG_HD void window_shift(int32_t d) {      // slot g now holds diagonal g - HALF + shiftk + d (d even): every slot coordinate follows
     shiftk += d; lo -= d; hi -= d; ga -= d; gb -= d; c1g -= d; c2g -= d; kming -= d; kmaxg -= d;
     next_refill = Dct;
   }
