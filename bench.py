@@ -245,21 +245,46 @@ def tetra_subrecord(eng, local, no_cpu):
 ASSEMBLY_S_PER_PAIR = 1.2e-6     # pyani_amd.anim.assemble_run_matrices, measured on the full C4 grid (999 000 pairs in 1.2 s)
 
 
-def related_only_record(eng, args):
+def related_only_record(eng, args, stages=()):
     """One family of the same generator (25 genomes of one ancestor, all 600 ordered pairs related) in ONE call: the rate a
-    genus-level job sees, where no pair is a cheap miss."""
+    genus-level job sees, where no pair is a cheap miss.  `steady`: four families (2400 related pairs) in one call — the same
+    work with the launch tails of one call (the last forced run alone on the chip) amortised, as a 24 000-related-pair C4 grid
+    sees them.  `stage_ms`: the 600-pair call once more with ONE worker and the stages' HIP events on (untimed)."""
     n, K = args.genomes, (args.genomes + 24) // 25
-    fam = [g for g in range(n) if g % K == 1][:25]
-    data = [synth_genomes(args.seed, n, args.length, g, g + 1, 1)[0] for g in fam]
-    ids = [eng.add_genome(s_, o_) for s_, o_ in data]
+    fams = [[g for g in range(n) if g % K == f][:25] for f in (1, 2, 3, 4) if f < K]
+    ids = []
+    for fam in fams:
+        data = [synth_genomes(args.seed, n, args.length, g, g + 1, 1)[0] for g in fam]
+        ids.append([eng.add_genome(s_, o_) for s_, o_ in data])
     eng.upload()
-    pairs = [(a, b) for a in ids for b in ids if a != b]
-    eng.anim_pairs([a for a, _ in pairs[:50]], [b for _, b in pairs[:50]])      # seed lists built
+    pairs = [(a, b) for a in ids[0] for b in ids[0] if a != b]
+    many = [(a, b) for fam in ids for a in fam for b in fam if a != b]
+    every = [(a, b) for fam in ids for a, b in zip(fam, fam[1:] + fam[:1])]
+    eng.anim_pairs([a for a, _ in every], [b for _, b in every])      # seed lists built
     t0 = time.perf_counter()
     res = eng.anim_pairs([a for a, _ in pairs], [b for _, b in pairs])
     dt = time.perf_counter() - t0
-    return {"workload": f"{len(fam)} genomes of one ancestor ({len(pairs)} ordered pairs, all related), one call", "seconds": dt,
-            "pairs_per_s": len(pairs) / dt, "pairs_with_alignment": int((res["status"] == 0).sum())}
+    rec = {"workload": f"{len(fams[0])} genomes of one ancestor ({len(pairs)} ordered pairs, all related), one call", "seconds": dt,
+           "pairs_per_s": len(pairs) / dt, "pairs_with_alignment": int((res["status"] == 0).sum())}
+    if len(fams) > 1:
+        t0 = time.perf_counter()
+        eng.anim_pairs([a for a, _ in many], [b for _, b in many])
+        dt = time.perf_counter() - t0
+        rec["steady"] = {"workload": f"{len(fams)} such families in one call ({len(many)} ordered pairs, all related)", "seconds": dt,
+                         "pairs_per_s": len(many) / dt}
+    if stages:
+        eng.anim_set_workers(1)
+        eng.profile_reset()
+        eng.profile_config(kernel_mask=sum(1 << s_ for s_ in stages), every_n=1)
+        eng.profile_enable(True)
+        t0 = time.perf_counter()
+        eng.anim_pairs([a for a, _ in pairs], [b for _, b in pairs])
+        eng.sync()
+        rec["one_worker_seconds"] = time.perf_counter() - t0
+        eng.profile_enable(False)
+        rec["stage_ms"] = {eng.kernel_name(s_): round(eng.profile_get(s_)[0], 3) for s_ in stages}
+        eng.anim_set_workers(2)
+    return rec
 
 
 def unrelated_only_record(eng, args, ids):
@@ -576,7 +601,7 @@ def run_anim(args, rank, world, local, dist, torch):
             out["cpu_baseline"] = anim_cpu_baseline(args, data, n, related_all, gpu_lookup)
             out["cpu_baseline"]["speedup_gpu_over_cpu_job"] = out["value"] / out["cpu_baseline"]["value"]
         if world == 1 and not bare:
-            out["related_only"] = related_only_record(eng, args)
+            out["related_only"] = related_only_record(eng, args, stages)
             out["unrelated_only"] = unrelated_only_record(eng, args, ids)
             cb = out.get("cpu_baseline")
             if cb and cb.get("cpu_s_per_related_pair"):

@@ -330,20 +330,28 @@ struct DiagWaveEmu {
 };
 #endif
 
+// A fixed band of `span` diagonals (its 5 margin slots included) is sure to fit a window of 64 DPL diagonals: the window moves by
+// whole lanes towards the band's centre (DiagCtl::window_check: the quotient is truncated), so up to DPL - 1 diagonals of either
+// margin are lost to the placement.
+PG_HD bool diag_window_holds(int64_t span, int dpl) { return span <= 64 * (int64_t)dpl - 2 * (int64_t)dpl + 2; }
 #if !defined(__HIP_DEVICE_COMPILE__)
 // The engine postnuc_unit is given when the host statement runs on the emulated wave engines: trimmed searches / alignments on
-// the 256-diagonal window, forced runs on the window that holds their certified band (256 ... 2048 diagonals), anything that
+// the 256-diagonal window, forced runs on the smallest window that holds their certified band (256, 384, 512 ... 2048 diagonals), anything that
 // does not fit on pgn::ScalarEngine — the dispatch of the GPU's PnWaveEngine (pga_postnuc.inc).
 template <typename RefT, typename QryT>
 struct DiagWaveEngine {
   ScalarEngine<RefT, QryT> slow;
   DiagWaveEmu<4, RefT, QryT> e4;
+  DiagWaveEmu<6, RefT, QryT> e6;
   DiagWaveEmu<8, RefT, QryT> e8;
+  DiagWaveEmu<12, RefT, QryT> e12;
   DiagWaveEmu<16, RefT, QryT> e16;
+  DiagWaveEmu<24, RefT, QryT> e24;
   DiagWaveEmu<32, RefT, QryT> e32;
   long fallbacks = 0;
+  void (*fallback_log)(int32_t N, int32_t M, unsigned m_o, int32_t band_w) = nullptr;      // development: what did not fit
   DiagWaveEngine(const RefT& R, const QryT& Q, Cell* d0, Cell* d1, Cell* d2, int32_t cap)
-      : slow{R, Q, d0, d1, d2, cap}, e4{R, Q}, e8{R, Q}, e16{R, Q}, e32{R, Q} {}
+      : slow{R, Q, d0, d1, d2, cap}, e4{R, Q}, e6{R, Q}, e8{R, Q}, e12{R, Q}, e16{R, Q}, e24{R, Q}, e32{R, Q} {}
   bool gap_ready(int32_t, PnGap&) const { return false; }
   void piece(uint32_t, int32_t, int32_t, int32_t, int32_t, int32_t, int32_t, int32_t, unsigned) {}
   bool bwd_ready(int, PnBwd&) const { return false; }
@@ -366,7 +374,8 @@ struct DiagWaveEngine {
     if (!(m_o & FORCED_BIT)) return 256;
     const int32_t df = N < M ? M - N : N - M;
     const int64_t span = band_w >= 0 ? (int64_t)df + 2 * (int64_t)band_w + 1 : (int64_t)N + M + 1;
-    return span + 5 <= 256 ? 256 : span + 5 <= 512 ? 512 : span + 5 <= 1024 ? 1024 : span + 5 <= 2048 ? 2048 : 0;
+    for (int w : {256, 384, 512, 768, 1024, 1536, 2048}) if (diag_window_holds(span + 5, w / 64)) return w;
+    return 0;
   }
   bool run(int32_t Astart, int32_t& Aend, int32_t Bstart, int32_t& Bend, unsigned m_o, int32_t band_w, int32_t& errors, int32_t& score) {
     const bool fwd = m_o & DIRECTION_BIT;
@@ -375,13 +384,17 @@ struct DiagWaveEngine {
     bool reached = false, done = false;
     switch (window_for(N, M, m_o, band_w)) {
       case 256: done = e4.run(Astart, a, Bstart, b, m_o, band_w, errors, score, reached); break;
+      case 384: done = e6.run(Astart, a, Bstart, b, m_o, band_w, errors, score, reached); break;
       case 512: done = e8.run(Astart, a, Bstart, b, m_o, band_w, errors, score, reached); break;
+      case 768: done = e12.run(Astart, a, Bstart, b, m_o, band_w, errors, score, reached); break;
       case 1024: done = e16.run(Astart, a, Bstart, b, m_o, band_w, errors, score, reached); break;
+      case 1536: done = e24.run(Astart, a, Bstart, b, m_o, band_w, errors, score, reached); break;
       case 2048: done = e32.run(Astart, a, Bstart, b, m_o, band_w, errors, score, reached); break;
       default: break;
     }
     if (done) { Aend = a; Bend = b; return reached; }
     ++fallbacks;
+    if (fallback_log) fallback_log(N, M, m_o, band_w);
     return slow.run(Astart, Aend, Bstart, Bend, m_o, band_w, errors, &score);
   }
   bool align(int32_t Astart, int32_t& Aend, int32_t Bstart, int32_t& Bend, unsigned m_o, int32_t& errors) {

@@ -173,6 +173,12 @@ int main(int argc, char** argv) {
       }
       // ANIM_DIAGWAVE: the diagonal-layout wave engines of the GPU (pg_nucmer_diag.h), emulated lane by lane, under the same walk
       pgd::DiagWaveEngine<SeqView, StrandView> weng(R, Q, d0.data(), d1.data(), d2.data(), cap);
+      if (getenv("ANIM_FALLBACK_LOG"))      // the runs no single-wave window holds (on the GPU: the group kernel / the column strips)
+        weng.fallback_log = [](int32_t N, int32_t M, unsigned m_o, int32_t band_w) {
+          if (m_o & pgn::FORCED_BIT) fprintf(stderr, "FALLBACK forced N %d M %d band %d span %lld\n", N, M, band_w,
+                                             band_w >= 0 ? (long long)(N > M ? N - M : M - N) + 2ll * band_w + 6 : (long long)N + M + 6);
+          else fprintf(stderr, "FALLBACK search N %d M %d\n", N, M);
+        };
       const int na = getenv("ANIM_DIAGWAVE") ? pgn::postnuc_unit(weng, chains.data(), cm.data(), co.data(), n_chains, bounds_of, fused.data(), al.data(), (int)al.size())
                    : getenv("ANIM_DIAG") ? pgn::postnuc_unit(deng, chains.data(), cm.data(), co.data(), n_chains, bounds_of, fused.data(), al.data(), (int)al.size())
                                          : pgn::postnuc_unit(eng, chains.data(), cm.data(), co.data(), n_chains,
