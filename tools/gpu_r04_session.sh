@@ -15,7 +15,8 @@ for w in "$@"; do
 case $w in
 tests)
   timeout 2400 python -m pytest tests -m gpu -q --timeout 1200 -x > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.log
-  tail -25 $O/pytest_gpu.log ;;
+  tail -25 $O/pytest_gpu.log
+  grep -q "pytest rc=0" $O/pytest_gpu.log || { echo "GPU tests failed: the remaining steps are skipped"; exit 1; } ;;
 new)
   timeout 1500 python -m pytest tests/test_anim_multirecord_gpu.py tests/test_anim_oracle_goldens_gpu.py -m gpu -q --timeout 900 > $O/pytest_new.log 2>&1
   echo "pytest rc=$?" >> $O/pytest_new.log; tail -30 $O/pytest_new.log ;;
