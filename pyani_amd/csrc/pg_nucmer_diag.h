@@ -51,10 +51,10 @@ PG_HD uint32_t spread16(uint32_t m) {      // bit t (t < 16) -> bit 2 t
 // from the neighbouring lane.  g0 = DPL * lane; slots in [glo, glo + gspan] are computed, the others of this parity are zeroed
 // ("not computed": what their later readers must see).  key / keyw: the lane's best cell as (score field | slot) and its word —
 // ties go to the larger slot = larger column, as MUMmer's ">=" scan does (TRACK = false: forced runs track nothing).  A slot
-// outside the range has a zero word, i.e. key = its slot number with score field 0: below every reachable cell's key.
-// rel = {~W_STATE, ST_INSERT, ST_MATCH} handed in as values: on the device the mask sits in a scalar register and the two labels
-// in vector registers, so that a re-labelling is ONE v_and_or_b32 (a VOP3 instruction of this ISA takes no literal and reads the
-// constant bus once; as literals the compiler needs v_and + v_or).
+// outside the range has score field 0, i.e. key = its slot number alone: below every reachable cell's key.
+// rel = {~W_STATE, ST_INSERT, ST_MATCH} handed in as values: on the device they sit in vector registers (the mask is selected per
+// slot: in range or 0), so that a re-labelling is ONE v_and_or_b32 (a VOP3 instruction of this ISA takes no literal and reads the
+// constant bus once; as literals the compiler needs v_and + v_or, and re-materialises the mask inside the loop).
 // The match bit of a slot's next cell is the TOP bit of its window (tested as a sign), the window moves up two bits per cell.
 struct DiagRelabel { uint32_t mask, st_insert, st_match; };
 template <int DPL, int PAR, bool TRACK>
@@ -70,17 +70,42 @@ PG_HD void diag_lane_step(DiagRegs<DPL>& T, uint32_t nbX, uint32_t nbG, uint32_t
     const uint32_t uX = s == DPL - 1 ? nbX : T.X[s == DPL - 1 ? s : s + 1], uI = s == DPL - 1 ? nbG : T.I[s == DPL - 1 ? s : s + 1];
     const uint32_t dc = w_gap(lD, CONT_GAP_SCORE), dx = w_gap(lX, OPEN_GAP_SCORE);
     const uint32_t ic = w_gap(uI, CONT_GAP_SCORE), ix = w_gap(uX, OPEN_GAP_SCORE);
-    const uint32_t d = (dc > dx ? dc : dx) & rel.mask /* | ST_DELETE = 0 */, i = ((ic > ix ? ic : ix) & rel.mask) | rel.st_insert;
-    const uint32_t m = (w_step(T.X[s], (int32_t)T.mw[s] < 0) & rel.mask) | rel.st_match;
-    T.mw[s] <<= 2;
-    const uint32_t x = w_max3(d, i, m);
+    // a slot outside the range keeps nothing but its state label: a word with score field 0 is unreachable whatever its low bits
+    // (gaps and mismatches saturate it to 0, a match step tests the field, trimming and the best-cell key look at the field), so
+    // ONE select — of the re-labelling mask — takes the place of three on the results
     const bool in = (uint32_t)(gofs + (uint32_t)s) <= gspan;
-    T.X[s] = in ? x : 0u; T.D[s] = in ? d : 0u; T.I[s] = in ? i : 0u;
+    const uint32_t mk = in ? rel.mask : 0u;
+    const uint32_t d = (dc > dx ? dc : dx) & mk /* | ST_DELETE = 0 */, i = ((ic > ix ? ic : ix) & mk) | rel.st_insert;
+    const uint32_t m = (w_step(T.X[s], (int32_t)T.mw[s] < 0) & mk) | rel.st_match;
+    T.mw[s] <<= 2;
+    T.X[s] = w_max3(d, i, m); T.D[s] = d; T.I[s] = i;
     if (TRACK) {
       const uint32_t k = (T.X[s] & ~(W_ONE - 1u)) | (g0 + (uint32_t)s);
       if (k >= key) { key = k; keyw = T.X[s]; }
     }
   }
+}
+// the lane's best cell of this parity, as diag_lane_step<TRACK = true> leaves it (for callers that look at it only on the
+// anti-diagonals where some cell reaches the running best); top: the largest X word of the parity (what decides that)
+template <int DPL, int PAR>
+PG_HD void diag_lane_key(const DiagRegs<DPL>& T, uint32_t g0, uint32_t& key, uint32_t& keyw) {
+  key = 0u; keyw = 0u;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+  for (int s = PAR; s < DPL; s += 2) {
+    const uint32_t k = (T.X[s] & ~(W_ONE - 1u)) | (g0 + (uint32_t)s);
+    if (k >= key) { key = k; keyw = T.X[s]; }
+  }
+}
+template <int DPL, int PAR>
+PG_HD uint32_t diag_lane_top(const DiagRegs<DPL>& T) {
+  uint32_t top = 0u;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+  for (int s = PAR; s < DPL; s += 2) top = T.X[s] > top ? T.X[s] : top;
+  return top;
 }
 // which of the lane's cells of this parity survive the trimming (bit s): X >= thr, thr = the word of score high - MAX_DIFF
 template <int DPL, int PAR>
@@ -141,7 +166,7 @@ struct DiagCtl {
   uint32_t high_f, high_w;          // best score so far as a score FIELD (score + SCORE_BIAS) and its word
   int32_t FinishCt, FinishG, FinishShift;
   uint32_t span_sum;                // sum of (hi - lo) over the steps: cells = span_sum / 2 + steps
-  int32_t steps, wmax;
+  int32_t wmax;
   int32_t next_refill;
   template <int DPL>
   PG_HD void init(int32_t N_, int32_t M_, unsigned m_o, int32_t band_w) {
@@ -153,7 +178,7 @@ struct DiagCtl {
     ga = HALF; gb = HALF; lo = HALF; hi = HALF; shiftk = 0;
     c1g = 1 - 2 * N + HALF; c2g = 2 * M - 1 + HALF;
     high_f = 0u; high_w = 0u; FinishCt = 0; FinishG = HALF; FinishShift = 0;
-    span_sum = 0u; steps = 0; wmax = 0; next_refill = 1;
+    span_sum = 0u; wmax = 0; next_refill = 1;
   }
   // 0: compute anti-diagonal Dct (lo / hi set); 1: the run is over (end of the matrix, break length, band trimmed away);
   // 2: the band is empty after clipping
@@ -191,10 +216,11 @@ struct DiagCtl {
   }
   template <bool WIDEST>
   PG_HD void note_cells() {
-    span_sum += (uint32_t)(hi - lo); ++steps;
+    span_sum += (uint32_t)(hi - lo);
     if (WIDEST) { const int32_t w = (hi - lo) / 2 + 1; if (w > wmax) wmax = w; }
   }
-  PG_HD unsigned long long cells_total() const { return (unsigned long long)(span_sum / 2u) + (unsigned long long)steps; }
+  PG_HD int32_t steps() const { return Dct - 1; }      // anti-diagonals computed (Dct starts at 1 and moves on after each)
+  PG_HD unsigned long long cells_total() const { return (unsigned long long)(span_sum / 2u) + (unsigned long long)steps(); }
   // the wave's best cell of this anti-diagonal: gk = (score field | slot), gw its word; ties move the finish forward (">=")
   PG_HD void update_best(uint32_t gk, uint32_t gw) {
     const uint32_t f = gk >> SCORE_SHIFT;
