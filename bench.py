@@ -515,14 +515,20 @@ def run_anim(args, rank, world, local, dist, torch):
         # rate at which the chip can issue the vector instructions those cells cost (instructions per cell: rocprofv3 SQ_INSTS_VALU of
         # the extension kernels / the engines' own cell count of the same command, profiles/pmc_anim.json)
         cells = int(cnt[2]) + int(cnt[5]) + int(cnt[8])
-        vpc = pmc.get("extension_valu_per_cell")
+        vpc, spc = pmc.get("extension_valu_per_cell"), pmc.get("extension_salu_per_cell")
         valu = None
         if vpc and ext_ms:
-            peak_cells = SIMDS * CLOCK_GHZ * 1e9 / 4.0 / vpc
-            valu = {"bound": "valu-issue", "kernels": "anim_postnuc_{gaplane,gapbig,fwd,rehearse,bwd,(walk),forced,forced_wide}_kernel",
+            # a CU issues one wave64 VALU instruction per cycle (4 SIMDs x 1 per 4 cycles) and one scalar instruction per cycle (ONE scalar
+            # unit per CU): the step loop of the engines spends about as many scalar as vector instructions, so whichever is larger binds
+            ipc = max(vpc, spc or 0.0)
+            peak_cells = SIMDS * CLOCK_GHZ * 1e9 / 4.0 / ipc
+            valu = {"bound": "valu-issue" if ipc == vpc else "salu-issue",
+                    "kernels": "anim_postnuc_{gaplane,gapbig,fwd,rehearse,bwd,(walk),forced,forced_wide,forced_huge}_kernel",
                     "achieved": cells / (ext_ms * 1e-3), "peak": peak_cells, "unit": "DP cells/s", "frac": cells / (ext_ms * 1e-3) / peak_cells,
                     "cells": cells, "anti_diagonals": int(cnt[1]), "extension_ms": ext_ms, "valu_instructions_per_cell": vpc,
-                    "peak_definition": f"{SIMDS} SIMDs x {CLOCK_GHZ} GHz / 4 cycles per wave64 VALU instruction / instructions per cell "
+                    "salu_instructions_per_cell": spc,
+                    "peak_definition": f"256 CUs x {CLOCK_GHZ} GHz x 1 wave64 VALU instruction per cycle ({SIMDS} SIMDs, 4 cycles each) or 1 scalar "
+                                       f"instruction per cycle (one scalar unit per CU) / instructions per cell of the binding kind "
                                        f"({pmc.get('extension_valu_source', 'profiles/pmc_anim.json')})"}
         # hash of one whole N x N result grid (the last occurrence of every cell among the timed steps), if the steps cover it
         dense = np.zeros((n, n, g.shape[1]), dtype=np.int64)

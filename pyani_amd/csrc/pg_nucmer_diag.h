@@ -164,6 +164,7 @@ struct DiagCtl {
   int32_t kming, kmaxg;             // a forced run's band (slots)
   int32_t shiftk;                   // diagonal of slot g: k = g - HALF + shiftk
   uint32_t high_f, high_w;          // best score so far as a score FIELD (score + SCORE_BIAS) and its word
+  uint32_t high_fw, thr_w;          // high_f << SCORE_SHIFT; the trimming threshold word (both change only when the best does)
   int32_t FinishCt, FinishG, FinishShift;
   uint32_t span_sum;                // sum of (hi - lo) over the steps: cells = span_sum / 2 + steps
   int32_t wmax;
@@ -178,6 +179,7 @@ struct DiagCtl {
     ga = HALF; gb = HALF; lo = HALF; hi = HALF; shiftk = 0;
     c1g = 1 - 2 * N + HALF; c2g = 2 * M - 1 + HALF;
     high_f = 0u; high_w = 0u; FinishCt = 0; FinishG = HALF; FinishShift = 0;
+    high_fw = 0u; thr_w = (0u - (uint32_t)MAX_DIFF) << SCORE_SHIFT;
     span_sum = 0u; wmax = 0; next_refill = 1;
   }
   // 0: compute anti-diagonal Dct (lo / hi set); 1: the run is over (end of the matrix, break length, band trimmed away);
@@ -185,9 +187,7 @@ struct DiagCtl {
   template <bool FORCED>
   PG_HD int begin_step() {
     if (Dct > Dend) return 1;
-    lo = ga - 1; hi = gb + 1;
-    if (lo < c1g) lo = c1g;
-    if (hi > c2g) hi = c2g;
+    lo = ga - 1 > c1g ? ga - 1 : c1g; hi = gb + 1 < c2g ? gb + 1 : c2g;
     if (FORCED && banded) {
       if (lo < kming) lo = kming;
       if (hi > kmaxg) hi = kmaxg;
@@ -225,14 +225,14 @@ struct DiagCtl {
   PG_HD void update_best(uint32_t gk, uint32_t gw) {
     const uint32_t f = gk >> SCORE_SHIFT;
     if (f >= high_f) {
-      high_f = f; high_w = gw; FinishCt = Dct; FinishG = (int32_t)(gk & (W_ONE - 1u)); FinishShift = shiftk;
+      high_f = f; high_w = gw; high_fw = f << SCORE_SHIFT; thr_w = (f - (uint32_t)MAX_DIFF) << SCORE_SHIFT; FinishCt = Dct; FinishG = (int32_t)(gk & (W_ONE - 1u)); FinishShift = shiftk;
       Dend = Dct + BREAK_LEN < NM ? Dct + BREAK_LEN : NM;
     }
   }
   // the word a cell must reach to survive the trimming (cells more than MAX_DIFF below the best score go).  high >= -10 after the
   // first anti-diagonal of a search (its cells are one step from the origin) and never falls: the threshold is a positive word, so
   // a zero word — a slot outside the computed range — never counts as a survivor.
-  PG_HD uint32_t trim_threshold() const { return (high_f - (uint32_t)MAX_DIFF) << SCORE_SHIFT; }
+  PG_HD uint32_t trim_threshold() const { return thr_w; }
   // survivors: the lowest / highest surviving slot (any = false: none)
   template <bool FORCED>
   PG_HD void end_step(bool any, uint32_t gmin, uint32_t gmax) {

@@ -42,7 +42,7 @@ fetch|write)
   python tools/summarize_pmc.py $O/pmc_$w $O/pmc_${w}_summary.csv 2>&1 | tail -30
   find $O/pmc_$w -name "*counter_collection.csv" -size +20M -delete ;;
 stats4)
-  PYANI_PN_STATS=1 PYANI_ANIM_WORKERS=1 timeout 900 python bench.py --gpus 1 --steps 1 --warmup 0 --no-tetra --no-cpu-baseline > $O/bench_c4_stats.log 2> $O/bench_c4_stats.err; echo "stats4 rc=$?"
+  PYANI_PN_STATS=1 PYANI_ANIM_WORKERS=1 timeout 900 $B1 > $O/bench_c4_stats.log 2> $O/bench_c4_stats.err; echo "stats4 rc=$?"
   grep '^{' $O/bench_c4_stats.log | cut -c1-1500; grep "pn-stats" $O/bench_c4_stats.err | tail -16 ;;
 c4)
   timeout 1200 python bench.py --gpus 1 --steps 4 --warmup 1 --no-tetra --no-cpu-baseline > $O/bench_c4.log 2> $O/bench_c4.err; echo "c4 rc=$?"
@@ -60,6 +60,8 @@ tetra)
   cd $R
   f=$(find $O/tetra_kt -name "*kernel_stats.csv" | head -1); cp $f $O/tetra_kernel_stats.csv; head -8 $f | cut -c1-200
   for d in tetra_fetch tetra_write tetra_sq; do python tools/summarize_pmc.py $O/$d $O/${d}_summary.csv 2>&1 | tail -6; done ;;
+summ)    # profiles/ on the box from what the steps before left (bench.py reads profiles/pmc_anim.json)
+  python tools/summarize_r04_profiles.py | tail -20 ;;
 cold)    # one cold end-to-end run of the whole C4 job from FASTA files on disk
   PYANI_BENCH_TMP=/tmp timeout 1200 python bench.py --gpus 1 --cold-e2e > $O/cold_e2e.json 2> $O/cold_e2e.err; echo "cold rc=$?"
   cut -c1-1200 $O/cold_e2e.json; tail -3 $O/cold_e2e.err ;;

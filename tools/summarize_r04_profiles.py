@@ -28,6 +28,7 @@ STAGE = {   # rocprofv3 kernel -> the stage name bench.py reports (pg_kernel_nam
     "anim_postnuc_rehearse_kernel": "anim_postnuc_rehearse_kernel+anim_postnuc_bwd_kernel", "anim_postnuc_bwd_kernel": "anim_postnuc_rehearse_kernel+anim_postnuc_bwd_kernel",
     "anim_postnuc_kernel": "anim_postnuc_kernel|anim_extend_kernels",
     "anim_postnuc_forced_kernel": "anim_postnuc_forced_kernels|anim_extdp_lane_kernel", "anim_postnuc_forced_wide_kernel": "anim_postnuc_forced_kernels|anim_extdp_lane_kernel",
+    "anim_postnuc_forced_huge_kernel": "anim_postnuc_forced_kernels|anim_extdp_lane_kernel",
     "anim_finish_kernel": "anim_finish_kernel",
 }
 EXT = [k for k in STAGE if k.startswith("anim_postnuc_")]
@@ -67,11 +68,15 @@ out.update(stage_bytes)
 stats = SRC / "bench_c4_stats.err"
 cells = None
 if stats.exists():
-    m = re.search(r"regs: calls \d+ steps (\d+) cells (\d+).*?lds: calls \d+ steps \d+ cells (\d+).*?global: calls \d+ steps \d+ cells (\d+)", stats.read_text())
-    if m:
-        cells = int(m.group(2)) + int(m.group(3)) + int(m.group(4))
+    # one "[pn-stats] units ..." line per launch of the SAME command as the PMC passes (3 launches: warm-up, timed, roofline step):
+    # averages per launch on both sides of the ratio
+    ms = re.findall(r"regs: calls \d+ steps (\d+) cells (\d+).*?lds: calls \d+ steps \d+ cells (\d+).*?global: calls \d+ steps \d+ cells (\d+)", stats.read_text())
+    if ms:
+        cells = sum(int(m[1]) + int(m[2]) + int(m[3]) for m in ms) / len(ms)
         out["extension_cells_per_launch"] = cells
-        out["extension_anti_diagonals_per_launch"] = int(m.group(1))
+        out["extension_anti_diagonals_per_launch"] = sum(int(m[0]) for m in ms) / len(ms)
+        out["extension_launches_counted"] = len(ms)
+        (DST / "r04_pn_stats_C4_step.txt").write_text("".join(l + "\n" for l in stats.read_text().splitlines() if "pn-stats" in l))
 if cells and sq:
     valu = sum(float(sq[k]["SQ_INSTS_VALU_sum"]) / max(1, int(sq[k]["launches"])) for k in EXT if k in sq)
     salu = sum(float(sq[k]["SQ_INSTS_SALU_sum"]) / max(1, int(sq[k]["launches"])) for k in EXT if k in sq)
