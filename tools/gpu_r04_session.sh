@@ -7,7 +7,7 @@
 #   fetch / write   FETCH_SIZE / WRITE_SIZE passes of the same command
 #   stats4   one C4 step with the engines' own counters (PYANI_PN_STATS)
 #   c4       short bench (4 steps)             bench    the driver's command
-#   tetra    rocprofv3 of the TETRA workload at HEAD (kernel trace + FETCH/WRITE)
+#   tetra    rocprofv3 of the TETRA workload at HEAD (kernel trace + FETCH/WRITE)     anib   C5 bench + kernel trace + SQ pass
 R=$(pwd); O=$R/gpurun_out/r04; mkdir -p $O; export TMPDIR=/tmp
 export PYANI_DEV_KNOBS=1
 B1="python $R/bench.py --gpus 1 --steps 1 --warmup 1 --no-cpu-baseline --no-tetra"
@@ -60,6 +60,17 @@ tetra)
   cd $R
   f=$(find $O/tetra_kt -name "*kernel_stats.csv" | head -1); cp $f $O/tetra_kernel_stats.csv; head -8 $f | cut -c1-200
   for d in tetra_fetch tetra_write tetra_sq; do python tools/summarize_pmc.py $O/$d $O/${d}_summary.csv 2>&1 | tail -6; done ;;
+anib)    # C5 fragment mode at HEAD: the bench record, a kernel trace and one SQ pass of its steps
+  timeout 900 python bench.py --gpus 1 --workload anib > $O/bench_anib.log 2> $O/bench_anib.err; echo "anib rc=$?"
+  grep '^{' $O/bench_anib.log > $O/bench_anib_C5_n1.json; cut -c1-1500 $O/bench_anib_C5_n1.json
+  cd /tmp; rm -rf $O/anib_kt $O/anib_sq
+  A="python $R/bench.py --gpus 1 --workload anib --steps 1 --warmup 1 --no-cpu-baseline"
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/anib_kt -o kt -- $A > $O/anib_kt.log 2>&1
+  timeout 900 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY --output-format csv -d $O/anib_sq -o pmc -- $A > $O/anib_sq.log 2>&1
+  cd $R
+  f=$(find $O/anib_kt -name "*kernel_stats.csv" | head -1); cp $f $O/anib_kernel_stats.csv; head -8 $f | cut -c1-200
+  python tools/summarize_pmc.py $O/anib_sq $O/anib_sq_summary.csv 2>&1 | tail -8
+  find $O/anib_kt $O/anib_sq -name "*.csv" -size +20M -delete ;;
 summ)    # profiles/ on the box from what the steps before left (bench.py reads profiles/pmc_anim.json)
   python tools/summarize_r04_profiles.py | tail -20 ;;
 cold)    # one cold end-to-end run of the whole C4 job from FASTA files on disk

@@ -24,9 +24,10 @@ for path in hits:
                 counters.append(c)
             acc[k][c] += float(r["Counter_Value"])
             launches[k].add(r.get("Dispatch_Id") or r.get("Correlation_Id"))
-with open(dst, "w") as fh:
-    fh.write("kernel,launches," + ",".join(f"{c}_sum,{c}_per_launch" for c in counters) + "\n")
+with open(dst, "w", newline="") as fh:      # (kernel names hold commas: tetra_count_kernel<3, 0, 512>)
+    wr = csv.writer(fh)
+    wr.writerow(["kernel", "launches"] + [x for c in counters for x in (f"{c}_sum", f"{c}_per_launch")])
     for k in sorted(acc, key=lambda k: -max(acc[k].values())):
         n = max(1, len(launches[k]))
-        fh.write(f"{k},{n}," + ",".join(f"{acc[k][c]:.0f},{acc[k][c] / n:.1f}" for c in counters) + "\n")
+        wr.writerow([k, n] + [x for c in counters for x in (f"{acc[k][c]:.0f}", f"{acc[k][c] / n:.1f}")])
 print(open(dst).read()[:6000])

@@ -91,6 +91,36 @@ if cold.exists():
     out["end_to_end_cold_breakdown_s"] = rec["config"]["seconds"]
     shutil.copyfile(cold, DST / "r04_cold_e2e_C4.json")
 (DST / "pmc_anim.json").write_text(json.dumps(out, indent=1) + "\n")
+bench = SRC / "bench_n1.json"
+if bench.exists() and bench.stat().st_size:
+    shutil.copyfile(bench, DST / "r04_bench_n1.json")
+# TETRA (C2) at HEAD: kernel trace + FETCH / WRITE / SQ passes of `bench.py --workload tetra --steps 20 --warmup 5 --no-cpu-baseline`
+tk = SRC / "tetra_kernel_stats.csv"
+if tk.exists():
+    shutil.copyfile(tk, DST / "r04_tetra_C2_rocprofv3_kernel_stats.csv")
+    for w in ("fetch", "write", "sq"):
+        if (SRC / f"tetra_{w}_summary.csv").exists():
+            shutil.copyfile(SRC / f"tetra_{w}_summary.csv", DST / f"r04_tetra_C2_pmc_{w}_summary.csv")
+    def count_row(path):
+        return next((r for k, r in rows(path).items() if k.startswith("tetra_count_kernel")), None)
+    f, w, q = count_row(SRC / "tetra_fetch_summary.csv"), count_row(SRC / "tetra_write_summary.csv"), count_row(SRC / "tetra_sq_summary.csv")
+    kt = next((r for r in csv.DictReader(open(tk)) if "tetra_count_kernel" in r["Name"]), None)
+    if f and w:
+        fk, wk = float(f["FETCH_SIZE_sum"]) / int(f["launches"]), float(w["WRITE_SIZE_sum"]) / int(w["launches"])
+        t = {"kernel": "tetra_count_kernel", "workload": "C2 (200 x 5 Mb synthetic genomes, seed 20250228)", "round": "r04",
+             "command": "python bench.py --gpus 1 --workload tetra --steps 20 --warmup 5 --no-cpu-baseline under rocprofv3 (--kernel-trace --stats; --pmc FETCH_SIZE; "
+                        "--pmc WRITE_SIZE; --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES: separate runs)",
+             "FETCH_SIZE_KiB_avg": fk, "WRITE_SIZE_KiB_avg": wk, "launches_sampled": int(f["launches"]),
+             "correction": "gfx950 rocprofv3 tallies 128-B read requests at 64 B: FETCH_SIZE reads exactly half the bytes of a wide coalesced stream "
+                           "(MI355X_MICROARCH.md §HBM) -> doubled. WRITE_SIZE taken as reported (uncalibrated, ~1 MB).",
+             "hbm_bytes_per_launch": int(2 * 1024 * fk + 1024 * wk)}
+        if kt:
+            t["rocprofv3_avg_launch_us"] = float(kt["AverageNs"]) / 1e3
+        if q:
+            t["lds_bank_conflict_cycles_per_lds_active_cycle"] = float(q["SQ_LDS_BANK_CONFLICT_sum"]) / max(1.0, float(q["SQ_LDS_IDX_ACTIVE_sum"]))
+            t["valu_instructions_per_launch"] = float(q["SQ_INSTS_VALU_sum"]) / int(q["launches"])
+        (DST / "pmc_tetra_count.json").write_text(json.dumps(t, indent=1) + "\n")
+        print("tetra:", json.dumps(t)[:600])
 print(json.dumps({k: v for k, v in out.items() if not isinstance(v, dict)}, indent=1))
 for st, v in stage_bytes.items():
     print(f"{st:60s} {v['hbm_bytes_per_launch'] / 1e9:9.2f} GB per launch")
