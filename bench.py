@@ -613,6 +613,8 @@ def run_anim(args, rank, world, local, dist, torch):
             if cb and cb.get("cpu_s_per_related_pair"):
                 # the two halves of the job priced separately: a genus-level job is all related pairs
                 cb["speedup_related_only"] = out["related_only"]["pairs_per_s"] / (cb["cores"] / cb["cpu_s_per_related_pair"])
+                if out["related_only"].get("steady"):
+                    cb["speedup_related_only_steady"] = out["related_only"]["steady"]["pairs_per_s"] / (cb["cores"] / cb["cpu_s_per_related_pair"])
                 if out["unrelated_only"] and cb.get("cpu_s_per_unrelated_pair"):
                     cb["speedup_unrelated_only"] = out["unrelated_only"]["pairs_per_s"] / (cb["cores"] / cb["cpu_s_per_unrelated_pair"])
                 cb["note_speedups"] = ("the GPU's all-related family job (related_only) and all-unrelated job (unrelated_only), each ONE call, against host "

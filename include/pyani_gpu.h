@@ -156,8 +156,9 @@ int pg_anim_set_workers(pg_ctx* ctx, int workers);
 /* Engine counters of the nucmer extender since the last reset, for measurement (bench.py's VALU-issue roofline: cells per second
  * against the instruction count per cell): out[64].  out[0..2] = calls / anti-diagonals / DP cells of all register engines;
  * out[32 + 4 k + {0, 1, 2}] = the same for the diagonal engine in kernel class k (0 match-to-match gaps, 1 forward extensions,
- * 2 backward searches run ahead, 3 the units' walks, 4 forced runs in the narrow kernel, 5 / 6 forced runs in 1024- / 2048-
- * diagonal windows); the rest: development counters.  Synchronises the context's streams. */
+ * 2 backward searches run ahead, 3 the units' walks, 4 forced runs in the narrow kernel, 5 / 6 forced runs in windows of up to 1024 /
+ * 2048 diagonals, 7 forced runs on a group of four waves: 3072 ... 8192 diagonals); the rest: development counters.
+ * Synchronises the context's streams. */
 int pg_anim_counters(pg_ctx* ctx, uint64_t* out, int reset);
 
 /* Work-memory budget of pg_anim_pairs: at most max_pairs ordered pairs and max_matches exact matches in flight (about 264 bytes

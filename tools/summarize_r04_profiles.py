@@ -94,6 +94,11 @@ if cold.exists():
 bench = SRC / "bench_n1.json"
 if bench.exists() and bench.stat().st_size:
     shutil.copyfile(bench, DST / "r04_bench_n1.json")
+# ANIb (C5) at HEAD: the bench record, kernel trace and SQ pass of its steps
+for src, dst in (("bench_anib_C5_n1.json", "r04_bench_anib_C5_n1.json"), ("anib_kernel_stats.csv", "r04_anib_C5_rocprofv3_kernel_stats.csv"),
+                 ("anib_sq_summary.csv", "r04_anib_C5_pmc_sq_summary.csv")):
+    if (SRC / src).exists() and (SRC / src).stat().st_size:
+        shutil.copyfile(SRC / src, DST / dst)
 # TETRA (C2) at HEAD: kernel trace + FETCH / WRITE / SQ passes of `bench.py --workload tetra --steps 20 --warmup 5 --no-cpu-baseline`
 tk = SRC / "tetra_kernel_stats.csv"
 if tk.exists():
