@@ -98,6 +98,58 @@ def test_pre_pass_forms_of_the_statement_give_the_same_records(programs, genome_
     assert n >= 16
 
 
+def test_diagonal_wave_engines_emulated_lane_by_lane_give_the_same_records(programs, genome_dir, tmp_path):
+    """The GPU's alignment engine (pg_nucmer_diag.h: cells laid out by diagonal, 4 ... 32 diagonals per lane, match windows, the
+    per-step control in slot coordinates, window moves, the smallest window that is sure to hold a forced band) is plain C++ shared
+    by device and host; ANIM_DIAGWAVE=1 runs the host statement on it, 64 emulated lanes at a time.  Every record of the
+    Blochmannia runs and of one 85 % Caulobacter pair must come out as MUMmer wrote it, and — real genomes at >= 85 % rarely need
+    more than 1024 diagonals — five pairs of C4's most divergent family at 800 kb (forced bands up to 2048 diagonals and beyond)
+    as the scalar engine computes them.  The emulated engines must have taken (nearly) all calls, in EVERY window size, and no
+    band may have missed the window chosen for it."""
+    import os
+    import re
+    from pyani_amd import synth
+    _, stmt = programs
+    env = dict(os.environ, ANIM_DIAGWAVE="1")
+    calls = [0] * 7
+    n = fits = fallbacks = total = 0
+
+    def tally(stderr):
+        nonlocal calls, fits, fallbacks, total
+        for m in re.finditer(r"diag-wave engines: calls ([\d /]+) \(.*?did not fit (\d+), fell back to the scalar engine (\d+)", stderr):
+            c = [int(x) for x in m.group(1).split(" / ")]
+            calls = [a + b for a, b in zip(calls, c)]
+            fits += int(m.group(2))
+            fallbacks += int(m.group(3))
+            total += sum(c)
+
+    for grp, f, pa, pb in _runs(genome_dir):
+        if grp == "group2" or (grp == "caulobacter" and "NC_014100" not in f.name):
+            continue
+        want = {(x.ref_id, x.qry_id, x.rs, x.re, x.qs, x.qe, x.errors) for x in anim_oracle.read_delta(f)[0]}
+        r = subprocess.run([str(stmt), str(pa), str(pb), "--dump", "--exact"], capture_output=True, text=True, check=True, env=env)
+        assert set(_records(r.stdout)) == want, f.name
+        tally(r.stderr)
+        n += 1
+    assert n >= 16
+    paths = {}
+    for g in (121, 321, 441, 681, 161):
+        seq, off = synth.genome(20250301, 1000, g, 800_000)
+        paths[g] = tmp_path / f"g{g}.fna"
+        synth.write_fasta(paths[g], seq, off, synth.genome_name(g))
+    for a, b in ((321, 681), (681, 321), (121, 161), (441, 121), (321, 441)):
+        # (against the statement on the scalar engine, which the oracle's goldens of the same family pin — tests/golden/anim_oracle_goldens:
+        # the oracle itself computes MUMmer's full rectangles and needs 40 s per such pair)
+        o = subprocess.run([str(stmt), str(paths[a]), str(paths[b]), "--dump", "--exact"], capture_output=True, text=True, check=True).stdout
+        r = subprocess.run([str(stmt), str(paths[a]), str(paths[b]), "--dump", "--exact"], capture_output=True, text=True, check=True, env=env)
+        assert set(_records(r.stdout)) == set(_records(o)) and len(_records(o)) >= 1, (a, b)
+        tally(r.stderr)
+    assert total > 20_000
+    assert all(c > 0 for c in calls), calls           # every window size was exercised
+    assert fits == 0, fits                            # a window is only chosen when the band is sure to fit it
+    assert fallbacks <= total // 200, (fallbacks, total)   # (bands beyond one wave's 2048 diagonals: the group kernel's on the GPU)
+
+
 def test_multirecord_genomes_statement_equals_oracle(programs, tmp_path):
     """Genomes whose RECORDS share content (repeats spread over contigs) and are cut at different places in reference and query:
     `mummer` tests query-side uniqueness per query SEQUENCE (reference-side over the whole file), and a cluster that mgaps builds
