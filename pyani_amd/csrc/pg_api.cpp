@@ -814,7 +814,9 @@ int pg_anim_pairs(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_ids, u
   }
   // launches: as many pairs as the scratch budget allows, at most MAX_REFS hubs; with W workers the launches are 1/W as
   // large and each worker gets 1/W of the match budget, so the memory in use is the same
-  const int W = n_pairs >= 128 ? ctx->anim_workers : 1;      // (a family of 25 genomes = 600 pairs already has two sequential tails worth overlapping)
+  // (measured, MI355X r04: one family of 25 genomes = 600 related pairs takes 0.58 s on one worker and 0.71 s split over two — each half
+  // keeps the launch's sequential tails and they contend; four families = 2 400 pairs: two workers win)
+  const int W = n_pairs >= 1024 ? ctx->anim_workers : 1;
   const uint32_t MAX_PAIRS = ctx->anim_batch_pairs / W, MAX_REFS = 256;
   const uint64_t max_matches = ctx->anim_batch_matches / W;
   // about equal launches, a multiple of W of them, none above the per-launch budget

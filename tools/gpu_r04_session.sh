@@ -71,6 +71,10 @@ anib)    # C5 fragment mode at HEAD: the bench record, a kernel trace and one SQ
   f=$(find $O/anib_kt -name "*kernel_stats.csv" | head -1); cp $f $O/anib_kernel_stats.csv; head -8 $f | cut -c1-200
   python tools/summarize_pmc.py $O/anib_sq $O/anib_sq_summary.csv 2>&1 | tail -8
   find $O/anib_kt $O/anib_sq -name "*.csv" -size +20M -delete ;;
+final)   # what the driver runs at round end: smoke() and the default bench command (no flags), timed
+  ( time timeout 900 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" ) > $O/smoke.log 2>&1; tail -5 $O/smoke.log
+  ( time timeout 1500 python bench.py > $O/bench_default.log 2> $O/bench_default.err ) 2> $O/bench_default.time; echo "default bench rc=$?"; cat $O/bench_default.time
+  grep '^{' $O/bench_default.log | cut -c1-600 ;;
 summ)    # profiles/ on the box from what the steps before left (bench.py reads profiles/pmc_anim.json)
   python tools/summarize_r04_profiles.py | tail -20 ;;
 cold)    # one cold end-to-end run of the whole C4 job from FASTA files on disk
