@@ -400,7 +400,7 @@ def run_anim(args, rank, world, local, dist, torch):
     # varies ~60 x and a static deal leaves the step waiting for its unluckiest rank); --static-deal: the fixed hash of round 3
     queue = None
     if dist is not None and not args.static_deal:
-        queue = parallel.RowQueue(rank, world, os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ.get("MASTER_PORT", "29500")) + 7)
+        queue = parallel.RowQueue(rank, world, os.environ.get("MASTER_ADDR", "127.0.0.1"))      # (the counter sits in the job's own rendezvous store)
 
     def rows_of(step, rows_per_step=None):
         r = rows_per_step or R
@@ -563,7 +563,7 @@ def run_anim(args, rank, world, local, dist, torch):
             "imbalance": None if not imbalance else {
                 "max_over_mean_rank_busy_time_per_step": [round(st["imbalance"], 4) for st in imbalance],
                 "mean": float(np.mean([st["imbalance"] for st in imbalance])), "worst": float(max(st["imbalance"] for st in imbalance)),
-                "chunks_per_rank_last_step": imbalance[-1]["chunks"], "dealing": "guided chunks from a cross-rank counter (pyani_amd.parallel.RowQueue)"},
+                "chunks_per_rank_last_step": imbalance[-1]["chunks"], "dealing": f"guided chunks from a cross-rank counter (pyani_amd.parallel.RowQueue, {queue.kind if queue else 'static'})"},
             "config": {
                 "workload": f"C4: ANIm N x N grid on {n} synthetic ~{args.length / 1e6:g} Mb genomes (SURVEY.md §8(d) generator, seed "
                             f"{args.seed}; {n * (n - 1)} ordered pairs, {n * (n // K - 1)} of them between descendants of one ancestor); "

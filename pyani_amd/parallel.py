@@ -171,14 +171,47 @@ def guided_chunks(n_rows: int, world: int, min_rows: int = 2) -> List[Tuple[int,
 
 
 class RowQueue:
-    """The cross-rank counter: `next_chunk(step)` returns the next unclaimed chunk number of that step (atomic over all ranks)."""
+    """The cross-rank counter: `next_chunk(step)` returns the next unclaimed chunk number of that step (atomic over all ranks).
+    The counter lives in a key-value store with an atomic add: by default THE JOB'S OWN rendezvous store (the TCPStore that
+    `init_process_group` already opened on MASTER_PORT: no second port to collide with another job on the node — the driver runs
+    N = 1, 2, 4, 8 back to back); `port` opens a store of its own instead (tests; a process group built without a store), and if that
+    port is taken rank 0 picks a free one and tells the others through the process group."""
 
-    def __init__(self, rank: int, world: int, host: str, port: int, timeout_s: float = 1800.0):
+    def __init__(self, rank: int, world: int, host: str = "127.0.0.1", port: int = 0, timeout_s: float = 1800.0, prefix: str = "pyani_rows"):
         import datetime
         self.world = world
-        self.store = dist.TCPStore(host, port, world, is_master=(rank == 0), timeout=datetime.timedelta(seconds=timeout_s),
-                                   wait_for_workers=True) if world > 1 else None
+        self.store = None
         self._local = {}
+        self._prefix = prefix
+        self.kind = "local"          # "job-store": the process group's rendezvous store; "own-store": a TCPStore of its own
+        if world <= 1:
+            return
+        if not port and dist.is_initialized():
+            try:
+                from torch.distributed.distributed_c10d import _get_default_store
+                self.store = dist.PrefixStore(prefix, _get_default_store())
+                self.store.add("probe", 0)      # (a store without `add` — a FileStore on some file systems — fails here, not mid-step)
+                self.kind = "job-store"
+                return
+            except Exception:
+                self.store = None
+        to = datetime.timedelta(seconds=timeout_s)
+        if dist.is_initialized():      # own store on a port rank 0 found free (the requested one if it is)
+            chosen = [0]
+            if rank == 0:
+                import socket
+                for cand in ([port] if port else []) + [0]:
+                    try:
+                        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+                            sk.bind((host if host not in ("localhost",) else "127.0.0.1", cand))
+                            chosen[0] = sk.getsockname()[1]
+                        break
+                    except OSError:
+                        continue
+            dist.broadcast_object_list(chosen, src=0)
+            port = int(chosen[0])
+        self.store = dist.TCPStore(host, port, world, is_master=(rank == 0), timeout=to, wait_for_workers=True)
+        self.kind = "own-store"
 
     def next_chunk(self, step_key: str) -> int:
         if self.store is None:

@@ -125,7 +125,7 @@ def test_anim_pair_grid_allgather(tmp_path, n):
                 assert a[q, s, 0] == 1000 * q + s and a[q, s, 3] == 7
 
 
-def _dyn_worker(rank, world, port, n, rows_per_step, out_dir):
+def _dyn_worker(rank, world, port, n, rows_per_step, out_dir, own_port=0):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -142,7 +142,16 @@ def _dyn_worker(rank, world, port, n, rows_per_step, out_dir):
             t[:, 0] = torch.from_numpy(pairs[:, 0] * 1000 + pairs[:, 1])
             return t
 
-        queue = parallel.RowQueue(rank, world, "127.0.0.1", port + 1)
+        # own_port = 0: the counter sits in the job's own rendezvous store (what bench.py does: no second port); else a store of
+        # its own on that port — which rank 0 has just occupied with a plain socket, so the queue must move to a free one
+        squat = None
+        if own_port and rank == 0:
+            import socket
+            squat = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+            squat.bind(("127.0.0.1", own_port))
+            squat.listen(1)
+        queue = parallel.RowQueue(rank, world, "127.0.0.1", own_port)
+        assert queue.kind == ("own-store" if own_port else "job-store")
         imb = []
         for step in range(2):
             rows = [(step * rows_per_step + i) % n for i in range(rows_per_step)]
@@ -168,6 +177,14 @@ def test_eight_ranks_pull_rows_from_a_shared_counter_and_stay_balanced_under_60x
     mp.spawn(_dyn_worker, args=(8, port, 1000, 800, str(tmp_path)), nprocs=8, join=True)
     imb = np.load(tmp_path / "imbalance.npy")
     assert (imb <= 1.15).all(), imb
+
+
+def test_row_queue_moves_off_a_port_that_is_taken(tmp_path):
+    """A RowQueue asked for a store of its own on a port another process holds (the driver runs N = 1, 2, 4, 8 back to back on one
+    node) must not fail the job: rank 0 picks a free port and tells the others through the process group."""
+    port, own = _free_port(), _free_port()
+    mp.spawn(_dyn_worker, args=(2, port, 200, 40, str(tmp_path), own), nprocs=2, join=True)
+    assert np.load(tmp_path / "imbalance.npy").shape == (2,)
 
 
 def test_guided_chunks_cover_the_rows():
