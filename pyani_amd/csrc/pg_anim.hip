@@ -903,7 +903,7 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
       PG_HIP(ctx, hipMemcpyAsync(A->pn_order, uorder.data(), (size_t)n_units * 4, hipMemcpyHostToDevice, cur_stream(ctx)));
       PG_HIP(ctx, hipStreamSynchronize(cur_stream(ctx)));     // (uorder is a local)
     }
-    if (!A->pn_cursor && (rc = regrow(ctx, A->pn_cursor, 16))) return rc;
+    if (!A->pn_cursor && (rc = regrow(ctx, A->pn_cursor, 24))) return rc;
     const uint32_t pn_waves = (uint32_t)ctx->num_cu * 12u;   // units / forced kernels: 12 KiB of LDS each: 12 per CU
     const uint32_t pn_waves_pre = (uint32_t)ctx->num_cu * 32u;   // gap / forward / backward pre-passes and the narrow forced kernel: no LDS, diagonal engine only, <= 64 registers: 8 per SIMD
     const uint32_t pn_waves_scr = ctx->anim_gap_lanes ? pn_waves : pn_waves_pre;      // (only the walks, the wide forced kernel and the all-gaps form of the gap kernel use the global scratch)
@@ -918,8 +918,8 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
     }
     const size_t req_cap = Mp + 16;      // one slot per match slot: a walk records at most one forced run per alignment it starts, and starts at most one per match
     A->pn_req_n = req_cap;
-    if (req_cap > A->pn_req_cap) { if ((rc = regrow(ctx, A->pn_reqs, req_cap + req_cap / 2))) return rc; if ((rc = regrow(ctx, A->pn_wide, 2 * (req_cap + req_cap / 2)))) return rc; A->pn_req_cap = req_cap + req_cap / 2; }
-    PG_HIP(ctx, hipMemsetAsync(A->pn_cursor, 0, 64, cur_stream(ctx)));   // [0] unit cursor, [1] forced runs recorded ([7]: the long ones), [2] forced-run cursor, [3] chain / big-gap cursor, [4..6] small gaps by class ([11]: gaps left to the wave engine), [8] cluster cursor of the forward extensions, [9] unit cursor of the rehearsal, [10] cluster cursor of the backward searches, [12] / [13] wide forced runs: count / cursor, [14] / [15] huge ones
+    if (req_cap > A->pn_req_cap) { if ((rc = regrow(ctx, A->pn_reqs, req_cap + req_cap / 2))) return rc; if ((rc = regrow(ctx, A->pn_wide, 3 * (req_cap + req_cap / 2)))) return rc; A->pn_req_cap = req_cap + req_cap / 2; }
+    PG_HIP(ctx, hipMemsetAsync(A->pn_cursor, 0, 96, cur_stream(ctx)));   // [0] unit cursor, [1] forced runs recorded ([7]: the long ones), [2] forced-run cursor, [3] chain / big-gap cursor, [4..6] small gaps by class ([11]: gaps left to the wave engine), [8] cluster cursor of the forward extensions, [9] unit cursor of the rehearsal, [10] cluster cursor of the backward searches, [12] / [13] wide forced runs: count / cursor, [14] / [15] huge ones, [16] / [17] the strips' list
     if (n_wl && trace) PG_HIP(ctx, hipMemcpyAsync(A->choff_d, choff.data(), choff.size() * 4, hipMemcpyHostToDevice, cur_stream(ctx)));
     if (n_wl && !trace) {     // the (unit, chain) work list, then every cluster's match-to-match alignments
       if (n_wl > A->wl) { if ((rc = regrow(ctx, A->wl_d, n_wl + n_wl / 2))) return rc; A->wl = n_wl + n_wl / 2; }
@@ -967,14 +967,19 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
     pg_prof_end(ctx);
     pg_prof_begin(ctx, PG_K_ANIM_EXTLANE);     // (the forced re-alignments, deferred: pga_postnuc.inc)
     if (n_wl) {      // narrow bands first (five waves per SIMD), then the runs that asked for a wide one (pga_postnuc.inc, pn_forced_wave)
+      const uint32_t win_max = (uint32_t)ctx->anim_pn_window_max, group_max = (uint32_t)ctx->anim_pn_group_max;
       hipLaunchKernelGGL(anim_postnuc_forced_kernel, dim3(pn_waves_pre), dim3(64), 0, cur_stream(ctx), A->refs_d, A->units_d, A->pn_reqs,
-                         A->pn_cursor + 1, (uint32_t)req_cap, A->pn_cursor + 2, A->pn_n, A->pn_wide, A->pn_cursor + 12);
+                         A->pn_cursor + 1, (uint32_t)req_cap, A->pn_cursor + 2, A->pn_n, A->pn_wide, A->pn_cursor + 12, win_max);
       hipLaunchKernelGGL(anim_postnuc_forced_wide_kernel, dim3(pn_waves), dim3(64), 0, cur_stream(ctx), A->refs_d, A->units_d, A->pn_reqs,
                          A->pn_cursor + 1, (uint32_t)req_cap, A->pn_cursor + 13, A->pn_n, A->pn_gscratch, A->pn_wide, A->pn_cursor + 12,
-                         A->pn_wide + req_cap, A->pn_cursor + 14);
-      // runs whose band spans more than one wave's 2048 diagonals: a workgroup of four waves each (2 workgroups per CU)
+                         A->pn_wide + req_cap, A->pn_cursor + 14, win_max);
+      // runs whose band spans more than one wave's 2048 diagonals: a workgroup of four waves each (2 workgroups per CU: the 8192-diagonal form holds 242 VGPRs); what the group
+      // cannot hold either: the column strips, one wave per run (a list that is empty on every workload seen so far)
       hipLaunchKernelGGL(anim_postnuc_forced_huge_kernel, dim3((uint32_t)ctx->num_cu * 2u), dim3(64 * PN_HUGE_WAVES), 0, cur_stream(ctx), A->refs_d,
-                         A->units_d, A->pn_reqs, A->pn_cursor + 15, A->pn_n, A->pn_gscratch, A->pn_wide + req_cap, A->pn_cursor + 14);
+                         A->units_d, A->pn_reqs, A->pn_cursor + 15, A->pn_n, A->pn_wide + req_cap, A->pn_cursor + 14, A->pn_wide + 2 * req_cap,
+                         A->pn_cursor + 16, group_max);
+      hipLaunchKernelGGL(anim_postnuc_forced_strips_kernel, dim3(pn_waves), dim3(64), 0, cur_stream(ctx), A->refs_d, A->units_d, A->pn_reqs,
+                         A->pn_cursor + 17, A->pn_n, A->pn_gscratch, A->pn_wide + 2 * req_cap, A->pn_cursor + 16);
     }
     pg_prof_end(ctx);
     if (pg_dev_env("PYANI_PN_STATS")) {   // development: what the engines did in this launch

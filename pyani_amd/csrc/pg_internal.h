@@ -96,6 +96,8 @@ struct pg_ctx {
   void* anim_lists = nullptr;      // per-genome seed lists, shared by the workers (guarded by anim_mu)
   std::mutex anim_mu, err_mu, prof_mu;
   int anib_word_tier = 1;      // fragment mode: search failed fragments again with blastn-sized (11-mer) seeds
+  int anim_pn_window_max = 2048;   // forced runs: the widest single-wave window (development: smaller values push runs on to the group kernel)
+  int anim_pn_group_max = 8184;    // ... and the widest band the group of four waves takes (development: 0 = everything beyond one wave on the strips)
   int anim_gap_lanes = 1;      // postnuc: small match-to-match gaps on one lane each (0: all gaps on the wave engine; tests compare the two)
   int anim_extender = 0;
   int anim_bwd_ahead = 1;      // backward searches ahead of the units' walks (pga_postnuc.inc); PYANI_ANIM_BWD_AHEAD=0 (development switch): inside them       // PG_EXTENDER_NUCMER (pg_anim_set_extender)

@@ -367,6 +367,7 @@ PG_HD bool diag_window_holds(int64_t span, int dpl) { return span <= 64 * (int64
 template <typename RefT, typename QryT>
 struct DiagWaveEngine {
   ScalarEngine<RefT, QryT> slow;
+  DiagWaveEmu<2, RefT, QryT> e2;      // (forced runs only)
   DiagWaveEmu<4, RefT, QryT> e4;
   DiagWaveEmu<6, RefT, QryT> e6;
   DiagWaveEmu<8, RefT, QryT> e8;
@@ -377,7 +378,7 @@ struct DiagWaveEngine {
   long fallbacks = 0;
   void (*fallback_log)(int32_t N, int32_t M, unsigned m_o, int32_t band_w) = nullptr;      // development: what did not fit
   DiagWaveEngine(const RefT& R, const QryT& Q, Cell* d0, Cell* d1, Cell* d2, int32_t cap)
-      : slow{R, Q, d0, d1, d2, cap}, e4{R, Q}, e6{R, Q}, e8{R, Q}, e12{R, Q}, e16{R, Q}, e24{R, Q}, e32{R, Q} {}
+      : slow{R, Q, d0, d1, d2, cap}, e2{R, Q}, e4{R, Q}, e6{R, Q}, e8{R, Q}, e12{R, Q}, e16{R, Q}, e24{R, Q}, e32{R, Q} {}
   bool gap_ready(int32_t, PnGap&) const { return false; }
   void piece(uint32_t, int32_t, int32_t, int32_t, int32_t, int32_t, int32_t, int32_t, unsigned) {}
   bool bwd_ready(int, PnBwd&) const { return false; }
@@ -400,7 +401,7 @@ struct DiagWaveEngine {
     if (!(m_o & FORCED_BIT)) return 256;
     const int32_t df = N < M ? M - N : N - M;
     const int64_t span = band_w >= 0 ? (int64_t)df + 2 * (int64_t)band_w + 1 : (int64_t)N + M + 1;
-    for (int w : {256, 384, 512, 768, 1024, 1536, 2048}) if (diag_window_holds(span + 5, w / 64)) return w;
+    for (int w : {128, 256, 384, 512, 768, 1024, 1536, 2048}) if (diag_window_holds(span + 5, w / 64)) return w;
     return 0;
   }
   bool run(int32_t Astart, int32_t& Aend, int32_t Bstart, int32_t& Bend, unsigned m_o, int32_t band_w, int32_t& errors, int32_t& score) {
@@ -409,6 +410,7 @@ struct DiagWaveEngine {
     int32_t a = Aend, b = Bend;
     bool reached = false, done = false;
     switch (window_for(N, M, m_o, band_w)) {
+      case 128: done = e2.run(Astart, a, Bstart, b, m_o, band_w, errors, score, reached); break;
       case 256: done = e4.run(Astart, a, Bstart, b, m_o, band_w, errors, score, reached); break;
       case 384: done = e6.run(Astart, a, Bstart, b, m_o, band_w, errors, score, reached); break;
       case 512: done = e8.run(Astart, a, Bstart, b, m_o, band_w, errors, score, reached); break;

@@ -315,6 +315,19 @@ def test_gap_forms_and_extenders_of_the_postnuc_stage_agree(monkeypatch):
         pairs = [(a, b) for a in ids for b in ids if a != b]
         inside = e.anim_pairs([a for a, _ in pairs], [b for _, b in pairs])
     assert inside.tobytes() == out["1"].tobytes()
+    # the forced re-alignments: every run on the window that just holds its certified band (default: one wave up to 2048 diagonals,
+    # a group of four waves up to 8192, column strips beyond — a list that is empty on every workload seen) — with the single-wave
+    # windows capped at 256 diagonals every wider run goes to the GROUP engine, and with the group switched off as well to the
+    # STRIPS: three ways through the same certified-band loop, not a single result may differ
+    monkeypatch.setenv("PYANI_ANIM_BWD_AHEAD", "1")
+    for window_max, group_max in (("256", "8184"), ("256", "0"), ("128", "3064")):
+        monkeypatch.setenv("PYANI_PN_WINDOW_MAX", window_max)
+        monkeypatch.setenv("PYANI_PN_GROUP_MAX", group_max)
+        with Engine(0) as e:
+            ids = [e.add_genome(*d) for d in data]
+            pairs = [(a, b) for a in ids for b in ids if a != b]
+            got = e.anim_pairs([a for a, _ in pairs], [b for _, b in pairs])
+        assert got.tobytes() == out["1"].tobytes(), (window_max, group_max)
 
 
 def test_cluster_stage_forms_do_not_change_results(eng, monkeypatch):

@@ -111,7 +111,7 @@ def test_diagonal_wave_engines_emulated_lane_by_lane_give_the_same_records(progr
     from pyani_amd import synth
     _, stmt = programs
     env = dict(os.environ, ANIM_DIAGWAVE="1")
-    calls = [0] * 7
+    calls = [0] * 8
     n = fits = fallbacks = total = 0
 
     def tally(stderr):

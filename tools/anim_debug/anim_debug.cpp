@@ -188,12 +188,12 @@ int main(int argc, char** argv) {
             if (strand) { const int32_t a = (int32_t)H.len - qh, b = (int32_t)H.len - ql; ql = a; qh = b; } },
           fused.data(), al.data(), (int)al.size());
       if (getenv("ANIM_DIAGWAVE"))
-        fprintf(stderr, "diag-wave engines: calls %ld / %ld / %ld / %ld / %ld / %ld / %ld (256 / 384 / 512 / 768 / 1024 / 1536 / 2048 diagonals), window moves %ld, did not fit %ld, "
+        fprintf(stderr, "diag-wave engines: calls %ld / %ld / %ld / %ld / %ld / %ld / %ld / %ld (128 / 256 / 384 / 512 / 768 / 1024 / 1536 / 2048 diagonals), window moves %ld, did not fit %ld, "
                         "fell back to the scalar engine %ld, cells %ld + %ld\n",
-                weng.e4.calls, weng.e6.calls, weng.e8.calls, weng.e12.calls, weng.e16.calls, weng.e24.calls, weng.e32.calls,
-                weng.e4.moves + weng.e6.moves + weng.e8.moves + weng.e12.moves + weng.e16.moves + weng.e24.moves + weng.e32.moves,
-                weng.e4.fails + weng.e6.fails + weng.e8.fails + weng.e12.fails + weng.e16.fails + weng.e24.fails + weng.e32.fails, weng.fallbacks,
-                weng.e4.cells + weng.e6.cells + weng.e8.cells + weng.e12.cells + weng.e16.cells + weng.e24.cells + weng.e32.cells, weng.slow.cells);
+                weng.e2.calls, weng.e4.calls, weng.e6.calls, weng.e8.calls, weng.e12.calls, weng.e16.calls, weng.e24.calls, weng.e32.calls,
+                weng.e2.moves + weng.e4.moves + weng.e6.moves + weng.e8.moves + weng.e12.moves + weng.e16.moves + weng.e24.moves + weng.e32.moves,
+                weng.e2.fails + weng.e4.fails + weng.e6.fails + weng.e8.fails + weng.e12.fails + weng.e16.fails + weng.e24.fails + weng.e32.fails, weng.fallbacks,
+                weng.e2.cells + weng.e4.cells + weng.e6.cells + weng.e8.cells + weng.e12.cells + weng.e16.cells + weng.e24.cells + weng.e32.cells, weng.slow.cells);
       if (na < 0 || eng.overflow || deng.slow.overflow || weng.slow.overflow) { fprintf(stderr, "postnuc statement: capacity exceeded\n"); return 3; }
       exact_cells += eng.cells + deng.fast.cells + deng.slow.cells;
       if (!bwd.empty()) fprintf(stderr, "the walk still ran %ld itself (%ld cells)\n", eng.searches, eng.search_cells);
