@@ -52,8 +52,8 @@ def parse_args():
     ap.add_argument("--workload", choices=["anim", "tetra", "anib"], default="anim",
                     help="anim = C4 (default: the N x N ANIm grid the metric is quoted on); tetra = C2 alone; "
                          "anib = C5 (mixed-length set, 1020-nt fragment mode)")
-    ap.add_argument("--steps", type=int, default=None, help="default 2 (anim: two passes over the grid) / 50 (tetra) / 3 (anib)")
-    ap.add_argument("--warmup", type=int, default=None, help="default 1 (anim, anib) / 5 (tetra)")
+    ap.add_argument("--steps", type=int, default=None, help="default 10 (anim: ten steps of a tenth of the grid = ONE whole C4 grid, so the result hash covers it and no tile is over-represented) / 50 (tetra) / 3 (anib)")
+    ap.add_argument("--warmup", type=int, default=None, help="default 2 (anim) / 1 (anib) / 5 (tetra)")
     ap.add_argument("--genomes", type=int, default=None, help="anim: genomes of the job (C4: 1000); tetra: genomes per GPU (C2: 200)")
     ap.add_argument("--length", type=int, default=5_000_000, help="ancestor length in bases (5 Mb)")
     ap.add_argument("--seed", type=int, default=None, help="default: the set's own seed (C4 20250301, C2 20250228)")
@@ -69,18 +69,18 @@ def parse_args():
     args = ap.parse_args()
     w = args.workload
     if args.steps is None:
-        args.steps = {"anim": 2, "tetra": 50, "anib": 3}[w]
+        args.steps = {"anim": 10, "tetra": 50, "anib": 3}[w]
     if args.warmup is None:
-        args.warmup = {"anim": 1, "tetra": 5, "anib": 1}[w]
+        args.warmup = {"anim": 2, "tetra": 5, "anib": 1}[w]
     if args.genomes is None:
         args.genomes = {"anim": 1000, "tetra": 200, "anib": 500}[w]
     if args.seed is None:
         args.seed = {"anim": 20250301, "tetra": 20250228, "anib": 20250302}[w]
     args.rows_default = args.rows_per_step is None
     if args.rows_per_step is None:
-        # anim: a tenth of the grid PER GPU per step (the exact extension stage makes a whole C4 grid a ~1 min step; the driver's 25
-        # steps must finish in minutes) — ~100 000 ordered pairs per GPU and step at C4, where launches still fill the GPU and a
-        # launch's sequential tail (its longest unit walk, ~2.4 s) stays a fraction of it.  Per-GPU work is fixed as N grows: the
+        # anim: a tenth of the grid PER GPU per step (a whole C4 grid is an 18 s step; the driver's 25 steps must finish in
+        # minutes) — ~100 000 ordered pairs per GPU and step at C4, where launches still fill the GPU and a launch's sequential tails
+        # (its longest unit walk, ~0.1 s) stay a fraction of it.  Per-GPU work is fixed as N grows: the
         # default series is WEAK scaling (8 GPUs: 800 rows per step, 10 steps = 8 grids); an explicit --rows-per-step R keeps R rows
         # per step whatever N is (strong scaling of that step).
         world = int(os.environ.get("WORLD_SIZE", "1")) if args.gpus > 1 else 1
