@@ -599,7 +599,10 @@ def run_anim(args, rank, world, local, dist, torch):
                               "(stage events un-overlapped; rank 0's share at N > 1) / the HIP-event time of the stage that took longest in it",
                 "one_worker_step": {"pairs": int(len(prof_pairs)), "seconds": prof_s,
                                     "stage_ms": {name: round(ms, 3) for name, (ms, _) in prof.items()},
-                                    "stage_launches": {name: int(c) for name, (_, c) in prof.items()}},
+                                    "stage_launches": {name: int(c) for name, (_, c) in prof.items()},
+                                    "note": "seconds = wall time of the call, which includes growing the single worker's scratch to the whole "
+                                            "launch budget (it held half of it while two workers ran) and the event synchronisations; the "
+                                            "kernels' own time is the sum of stage_ms"},
                 "pipeline_achieved": alg_bytes / elapsed / 1e9, "pipeline_frac": alg_bytes / elapsed / 1e9 / HBM_PEAK_GBS,
                 "timed_region_ms": round(elapsed * 1e3, 3),
                 "valu_issue": valu,
