@@ -185,3 +185,37 @@ def test_holdout_concordance_pair_equals_the_oracle(programs, genome_dir):
     o = subprocess.run([str(oracle), str(a), str(c)], capture_output=True, text=True, check=True).stdout
     s = subprocess.run([str(stmt), str(a), str(c), "--dump", "--exact", "--nofilter"], capture_output=True, text=True, check=True).stdout
     assert set(_records(s)) == set(_records(o)) and len(_records(o)) == 220
+
+
+def test_edge_case_inputs_statement_equals_oracle(programs, tmp_path):
+    """What the reference's nucmer jobs meet in real input directories: sequences shorter than a minimum match, records of N only,
+    empty records, identical genomes, an N run inside an alignment (MUMmer aligns THROUGH it: 50 errors), lower-case bases, a
+    reverse-complemented genome, IUPAC ambiguity symbols — the product's statement and the independent oracle must say the same,
+    including "no alignment at all"."""
+    import random
+    oracle, stmt = programs
+    rng = random.Random(7)
+    seq = lambda n: "".join(rng.choice("ACGT") for _ in range(n))
+    base = seq(3000)
+    rc = base[::-1].translate(str.maketrans("ACGT", "TGCA"))
+    cases = {
+        "short": (">a\n" + seq(15) + "\n", ">b\n" + seq(15) + "\n", 0),
+        "all_n": (">a\n" + "N" * 500 + "\n", ">b\n" + base + "\n", 0),
+        "empty_record": (">a0\n\n>a1\n" + base + "\n", ">b\n" + base[:1500] + "\n", 1),
+        "identical": (">a\n" + base + "\n", ">b\n" + base + "\n", 1),
+        "n_run": (">a\n" + base[:1000] + "N" * 50 + base[1000:] + "\n", ">b\n" + base + "\n", 1),
+        "lower_case": (">a\n" + base.lower() + "\n", ">b\n" + base + "\n", 1),
+        "reverse_complement": (">a\n" + base + "\n", ">b\n" + rc + "\n", 1),
+        "iupac": (">a\n" + base[:500] + "RYKM" + base[500:] + "\n", ">b\n" + base + "\n", 1),
+    }
+    for name, (fa, fb, n_want) in cases.items():
+        pa, pb = tmp_path / f"{name}_a.fna", tmp_path / f"{name}_b.fna"
+        pa.write_text(fa)
+        pb.write_text(fb)
+        o = subprocess.run([str(oracle), str(pa), str(pb)], capture_output=True, text=True, check=True).stdout
+        r = subprocess.run([str(stmt), str(pa), str(pb), "--dump", "--exact"], capture_output=True, text=True)
+        assert r.returncode in (0, 4), (name, r.returncode, r.stderr[-200:])      # (4: no alignment — the statement's ZeroDivisionError case)
+        assert set(_records(r.stdout)) == set(_records(o)), (name, _records(r.stdout), _records(o))
+        assert len(_records(o)) == n_want, (name, _records(o))
+    assert ("a", "b", 1, 3050, 1, 3000, 50) in _records(subprocess.run([str(stmt), str(tmp_path / "n_run_a.fna"), str(tmp_path / "n_run_b.fna"),
+                                                                         "--dump", "--exact"], capture_output=True, text=True).stdout)
