@@ -62,7 +62,7 @@ def parse_args():
     ap.add_argument("--cpu-pairs", type=int, default=0, help="anim: ordered pairs timed by the CPU leg (0 = one per host thread, <= 128)")
     ap.add_argument("--cpu-genomes", type=int, default=2, help="tetra: genomes timed by the CPU leg")
     ap.add_argument("--no-tetra", action="store_true", help="anim: skip the nested C2 TETRA sub-record")
-    ap.add_argument("--no-side-records", action="store_true", help="anim: skip related_only / banded64 / strong-step side records")
+    ap.add_argument("--no-side-records", action="store_true", help="anim: skip related_only / unrelated_only / strong-step side records")
     ap.add_argument("--static-deal", action="store_true", help="anim, N > 1: deal a step's rows by the fixed hash (round 3) instead of the cross-rank queue")
     ap.add_argument("--cold-e2e", action="store_true", help="anim, N = 1: measure ONE cold end-to-end run instead of the step loop: FASTA files on disk -> "
                     "parse + pack (pg_add_fasta_batch) -> upload -> seed lists -> the whole grid -> run matrices -> JSON, one wall clock")
@@ -630,18 +630,6 @@ def run_anim(args, rank, world, local, dist, torch):
                     cb["speedup_unrelated_only"] = out["unrelated_only"]["pairs_per_s"] / (cb["cores"] / cb["cpu_s_per_unrelated_pair"])
                 cb["note_speedups"] = ("the GPU's all-related family job (related_only) and all-unrelated job (unrelated_only), each ONE call, against host "
                                        "threads / CPU seconds per pair of that kind; speedup_gpu_over_cpu_job is the C4 mix (97.6 % unrelated)")
-            # the opt-in approximate extender of rounds 1-2 on one step of the same job, for scale (NOT exact: DESIGN.md §8b)
-            eng.anim_set_extender("banded64")
-            step(args.warmup)                     # its own scratch and lists are built here
-            fence()
-            tb = time.perf_counter()
-            pb = step(args.warmup + 1)
-            fence()
-            dt = time.perf_counter() - tb
-            eng.anim_set_extender("nucmer")
-            out["banded64_extender"] = {"pairs_per_s": len(pb) / dt, "ms_per_step": dt * 1e3,
-                                        "note": "PG_EXTENDER_BANDED64: fixed 64-diagonal band, fitted junction rules; 99.55 % of the hold-out MUMmer records, "
-                                                "identity up to 3.3e-4 off — not what `value` measures"}
         if world == 1 and not args.no_tetra:
             out["tetra"] = tetra_subrecord(eng, local, args.no_cpu_baseline)
         print(json.dumps(out), flush=True)

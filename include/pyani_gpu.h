@@ -134,19 +134,11 @@ typedef struct {
 int pg_anim_pairs(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_ids, uint64_t n_pairs, int maxmatch,
                   int filter_1to1, pg_anim_result* out);
 
-/* Which extension algorithm pg_anim_pairs / pg_anim_pair_alignments run after seeding and clustering.
- *   PG_EXTENDER_NUCMER (default)  MUMmer 3.23's own postnuc algorithm (extendClusters + its alignment engine: dynamic
- *                                 anti-diagonal band trimmed at breaklen * 3 below the best score, backward search + forced
- *                                 forward re-alignment, MUMmer's tie order).  Reproduces every alignment record (coordinates and
- *                                 error counts) of the nucmer output files the reference's tests hold; this is what replaces
- *                                 pyani's `nucmer` job (pyani/anim.py:240-289).
- *   PG_EXTENDER_BANDED64          the round-1/2 extender: fixed 64-diagonal band, per-chain searches on one LANE each, junction
- *                                 rules calibrated on fixtures.  ~3 x less DP work, NOT exact: 99.5 % of those records, identity
- *                                 within 4e-5 on them and up to 3.3e-4 on genomes it was not calibrated on.  Opt-in only. */
-#define PG_EXTENDER_NUCMER 0
-#define PG_EXTENDER_BANDED64 1
-int pg_anim_set_extender(pg_ctx* ctx, int extender);
-
+/* The extension algorithm after seeding and clustering is MUMmer 3.23's own postnuc (extendClusters + its alignment engine:
+ * dynamic anti-diagonal band trimmed at breaklen * 3 below the best score, backward search + forced forward re-alignment,
+ * MUMmer's tie order): it reproduces every alignment record (coordinates and error counts) of the nucmer output files the
+ * reference's tests hold and is what replaces pyani's `nucmer` job (pyani/anim.py:240-289).  There is no other extender: the
+ * approximate fixed-band one of rounds 1-2 (and its pg_anim_set_extender switch) was retired in round 5. */
 /* How many host worker threads (each with its own HIP stream and scratch) share one pg_anim_pairs / pg_anib_pairs call: 1 ... 4,
  * default 2 (the launches of two streams overlap: one worker's read-backs and sequential tails hide behind the other's kernels).
  * The counterpart of pyani's --workers inside ONE device (subcmd_anim.py:392-396 spreads jobs over CPU cores; over devices it is
@@ -188,7 +180,7 @@ int pg_anim_pair_alignments(pg_ctx* ctx, int32_t ref_id, int32_t qry_id, pg_anim
  * with_indels != 0 adds a traceback pass on the GPU (one thread per search / forced piece of the alignments' paths, scalar engine
  * with a backpointer store) and yields every record's .delta indel offset list (pyani/nucmer.py:170-290 parses them: positive =
  * a reference base facing a gap, negative = a query base facing a gap, distances between consecutive indels; the terminating 0
- * is not stored); *n_indels = how many numbers all lists hold together.  Needs the default extender (PG_EXTENDER_NUCMER).
+ * is not stored); *n_indels = how many numbers all lists hold together.
  * The result stays in the context until the next call; pg_anim_alignments_read copies it out: out[aln_offsets[n_pairs]],
  * indel_offsets[n_alignments + 1] and indels[*n_indels] (both may be NULL). */
 int pg_anim_alignments_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_ids, uint64_t n_pairs, int maxmatch, int with_indels,
@@ -259,9 +251,9 @@ int pg_profile_reset(pg_ctx* ctx);
 #define PG_K_ANIM_SEED 4     /* anim_seed_kernel: LDS-resident reference groups, streamed query lists */
 #define PG_K_ANIM_HIT 5      /* anim_hoff_kernel + anim_hit_scatter_kernel + anim_hit_kernel + anim_scatter_kernel */
 #define PG_K_ANIM_CLUSTER 6  /* anim_cluster_wave_kernel (one launch; + anim_cluster_prep_kernel when few units) */
-#define PG_K_ANIM_GAPS 7     /* nucmer extender: anim_postnuc_gaplist / gaplane<16,32,59> / gapbig kernels (match-to-match alignments); banded64: anim_gaps_kernel + anim_gapsort_kernel + the four anim_gapdp_lane_kernel launches */
-#define PG_K_ANIM_EXTLANE 8  /* nucmer extender: anim_postnuc_forced_kernel (narrow bands) + anim_postnuc_forced_wide_kernel; banded64: anim_extdp_lane_kernel */
-#define PG_K_ANIM_EXTEND 9   /* nucmer extender: anim_postnuc_kernel (the units' walks); banded64: anim_extreq_kernel / anim_extend_kernel / anim_gapreq_kernel / anim_gapdp_kernel */
+#define PG_K_ANIM_GAPS 7     /* anim_postnuc_gaplist / gaplane<16,32,59> / gapbig kernels (match-to-match alignments) */
+#define PG_K_ANIM_EXTLANE 8  /* anim_postnuc_forced_kernel (narrow bands) + anim_postnuc_forced_wide / _huge / _strips kernels */
+#define PG_K_ANIM_EXTEND 9   /* anim_postnuc_kernel (the units' walks) */
 #define PG_K_ANIM_FINISH 10  /* anim_finish_kernel */
 #define PG_K_ANIB_BUCKET 11  /* anib_bucket_kernel: seeds clipped to fragments, counting sort by fragment */
 #define PG_K_ANIB_FRAG 12    /* anib_frag_kernel: anchors + X-drop extensions, one wave per (pair, fragment) */

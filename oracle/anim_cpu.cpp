@@ -120,8 +120,8 @@ struct Result {   // = pg_anim_result (include/pyani_gpu.h)
   int32_t reserved;
 };
 
-// extender: 0 = the postnuc statement (pg_nucmer_core.h: MUMmer's own extension algorithm, scalar engine), 1 = banded64
-Result run_pair(const Genome& G, const Genome& H, int filter_1to1, int maxmatch, int extender) {
+// the extension stage is the postnuc statement (pg_nucmer_core.h: MUMmer's own extension algorithm, scalar engine)
+Result run_pair(const Genome& G, const Genome& H, int filter_1to1, int maxmatch) {
   const SeqView R = G.view();
   std::vector<Aln> alns;
   std::vector<int32_t> a_rrec, a_qrec;
@@ -151,7 +151,7 @@ Result run_pair(const Genome& G, const Genome& H, int filter_1to1, int maxmatch,
     std::vector<int32_t> co(n_chains);
     for (int i = 0; i < n_chains; ++i) co[i] = i;
     std::sort(co.begin(), co.end(), [&](int a, int b) { return chain_before(chains.data(), cm.data(), a, b); });
-    if (extender == 0) {
+    {
       const int cap = 1 << 14;   // widest anti-diagonal: MAX_ALIGNMENT_LENGTH + 1 cells
       std::vector<pgn::Cell> d0(cap), d1(cap), d2(cap);
       pgn::ScalarEngine<SeqView, StrandView> eng{R, Q, d0.data(), d1.data(), d2.data(), cap};
@@ -171,36 +171,6 @@ Result run_pair(const Genome& G, const Genome& H, int filter_1to1, int maxmatch,
         a_qrec.push_back(record_of(H.rec_start.data(), nq, a.qs));
         alns.push_back(a);
       }
-      continue;
-    }
-    std::vector<ChainFwd> fw(n_chains);
-    std::vector<ChainBwd> bw(n_chains);
-    std::vector<int32_t> prev_of(n_chains, -1), next_of(n_chains, -1), r_lo(n_chains), r_hi(n_chains), q_lo(n_chains), q_hi(n_chains);
-    chain_neighbours(chains.data(), cm.data(), co.data(), n_chains, prev_of.data(), next_of.data());
-    for (int c = 0; c < n_chains; ++c) {
-      r_lo[c] = G.rec_start[chains[c].rrec]; r_hi[c] = G.rec_start[chains[c].rrec + 1] - 1;
-      q_lo[c] = H.rec_start[chains[c].qrec]; q_hi[c] = H.rec_start[chains[c].qrec + 1] - 1;
-      if (strand) { const int32_t a = (int32_t)H.len - q_hi[c], b = (int32_t)H.len - q_lo[c]; q_lo[c] = a; q_hi[c] = b; }
-      fw[c] = extend_chain_fwd(R, Q, cm.data(), chains.data(), next_of.data(), c, r_hi[c], q_hi[c]);
-    }
-    for (int k = 0; k < n_chains; ++k) {
-      const int c = co[k];
-      const int p = prev_of[c];
-      bw[c] = extend_chain_bwd(R, Q, fw[c].first_r, fw[c].first_q, r_lo[c], q_lo[c], p >= 0 ? fw[p].re : -1, p >= 0 ? fw[p].qe : -1,
-                               p >= 0 ? fw[p].lr : -1, p >= 0 ? fw[p].lq : -1, p >= 0 ? fw[p].first_r : -1, p >= 0 ? fw[p].first_q : -1,
-                               fw[c].lr, fw[c].lq, p >= 0 && fw[p].reached && fw[p].target == c, p >= 0 ? fw[p].err_fwd : 0);
-    }
-    std::vector<int32_t> aln_of(n_chains + 1);
-    const int before = (int)alns.size();
-    alns.resize(before + n_chains);
-    const int after = stitch_chains(fw.data(), bw.data(), cm.data(), chains.data(), co.data(), prev_of.data(), next_of.data(), n_chains,
-                                    strand, aln_of.data(), alns.data(), before, (int)alns.size());
-    alns.resize(after);
-    for (int i = before; i < after; ++i) {
-      Aln& a = alns[i];
-      a_rrec.push_back(record_of(G.rec_start.data(), (int)G.rec_start.size() - 1, a.rs));
-      if (strand) { const int32_t qs = (int32_t)H.len - a.qe, qe = (int32_t)H.len - a.qs; a.qs = qs; a.qe = qe; }  // forward coords
-      a_qrec.push_back(record_of(H.rec_start.data(), nq, a.qs));
     }
   }
   const int n = (int)alns.size();
@@ -228,7 +198,7 @@ extern "C" {
 // pyani's runner does it, run_multiprocessing.py:130-144).  Returns 0.
 int anim_cpu_pairs(const uint8_t* const* seqs, const uint64_t* const* rec_offs, const uint32_t* n_recs, uint32_t n_genomes,
                    const int32_t* ref_ids, const int32_t* qry_ids, uint32_t n_pairs, int maxmatch, int filter_1to1, int threads,
-                   int extender, Result* out, double* seconds_out) {
+                   Result* out, double* seconds_out) {
   std::vector<Genome> G(n_genomes);
   std::vector<char> used(n_genomes, 0);
   for (uint32_t i = 0; i < n_pairs; ++i) { used[ref_ids[i]] = 1; used[qry_ids[i]] = 1; }
@@ -247,7 +217,7 @@ int anim_cpu_pairs(const uint8_t* const* seqs, const uint64_t* const* rec_offs, 
     pool.emplace_back([&]() {
       for (uint32_t i; (i = next++) < n_pairs;) {
         const auto t0 = std::chrono::steady_clock::now();
-        out[i] = run_pair(G[ref_ids[i]], G[qry_ids[i]], filter_1to1, maxmatch, extender);
+        out[i] = run_pair(G[ref_ids[i]], G[qry_ids[i]], filter_1to1, maxmatch);
         if (seconds_out) seconds_out[i] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
       }
     });

@@ -13,7 +13,7 @@ RESULT_DTYPE = np.dtype([("ref_aln_len", "<i8"), ("qry_aln_len", "<i8"), ("sim_e
                          ("identity", "<f8"), ("status", "<i4"), ("reserved", "<i4")])
 
 
-def anim_cpu_pairs(genomes, ref_ids, qry_ids, maxmatch=False, filter_1to1=True, threads=0, extender="nucmer"):
+def anim_cpu_pairs(genomes, ref_ids, qry_ids, maxmatch=False, filter_1to1=True, threads=0):
     """genomes: list of (uint8 sequence array, uint64 record offsets) as Engine.add_genome takes them (entries not named by
     any pair may be None).  Returns (structured result array like Engine.anim_pairs, per-pair CPU seconds)."""
     lib = ctypes.CDLL(str(_obuild.build_anim_cpu()))
@@ -35,6 +35,6 @@ def anim_cpu_pairs(genomes, ref_ids, qry_ids, maxmatch=False, filter_1to1=True, 
     secs = np.zeros(len(r), dtype=np.float64)
     rc = lib.anim_cpu_pairs(seqs, offs, ctypes.c_void_p(nrec.ctypes.data), ctypes.c_uint32(n), ctypes.c_void_p(r.ctypes.data),
                             ctypes.c_void_p(q.ctypes.data), ctypes.c_uint32(len(r)), int(bool(maxmatch)), int(bool(filter_1to1)),
-                            int(threads), {"nucmer": 0, "banded64": 1}[extender], ctypes.c_void_p(out.ctypes.data), ctypes.c_void_p(secs.ctypes.data))
+                            int(threads), ctypes.c_void_p(out.ctypes.data), ctypes.c_void_p(secs.ctypes.data))
     assert rc == 0
     return out, secs

@@ -12,7 +12,6 @@ K_TETRA_COUNT, K_TETRA_FINALIZE, K_TETRA_STATS, K_TETRA_PAIRS = 0, 1, 2, 3
 K_ANIB_BUCKET, K_ANIB_FRAG = 11, 12
 K_ANIM_FWD, K_ANIM_BWD = 13, 14
 K_COUNT = 15
-EXTENDER_NUCMER, EXTENDER_BANDED64 = 0, 1
 
 # every symbol declared in include/pyani_gpu.h: (name, restype, argtypes)
 _vp, _i32, _u32, _u64, _int = ctypes.c_void_p, ctypes.c_int32, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_int
@@ -42,7 +41,6 @@ SIGNATURES = {
     "pg_anim_pairs": (_int, [_vp, _vp, _vp, _u64, _int, _int, _vp]),
     "pg_anim_reduce": (_int, [_vp, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _vp]),
     "pg_anim_set_batch_budget": (_int, [_vp, _u32, ctypes.c_uint64]),
-    "pg_anim_set_extender": (_int, [_vp, _int]),
     "pg_anim_set_workers": (_int, [_vp, _int]),
     "pg_anim_counters": (_int, [_vp, _vp, _int]),
     "pg_anim_pair_alignments": (_int, [_vp, _i32, _i32, _vp, _u32, _P(_u32)]),

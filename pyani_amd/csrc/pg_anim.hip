@@ -9,20 +9,15 @@
 //                            sequential HBM reads; no random global access except to verify / extend actual hits)
 //   A3 anim_cluster_wave_kernel  one WAVE per (pair, strand): MUM filter (packed radix sorts + wave-scan containment
 //                            flags), mgaps clustering (lock-free union-find), chain extraction (register / LDS resident)
-//   A4 anim_gaps_kernel      one wave per chain: trims the chained matches, settles trivial gaps, emits GapTasks
-//      the banded affine DP (pga::extend_banded) in two forms with identical results:
-//      anim_gapdp_lane_kernel / anim_extdp_lane_kernel   one LANE per search, 64 per wave, the band in registers (small
-//                            gaps row by row; extensions and larger gaps by anti-diagonals in persistent waves)
-//      extend_wave           one WAVE per search (64 lanes = 64 diagonals, DPP neighbour exchange): takes over the
-//                            searches the lane waves hand over mid-way when they run thin, and the rare later calls
-//      anim_extreq_kernel    writes the DP calls of every chain down as requests for the lanes (policy code, no DP)
-//      anim_extend_kernel    one wave per chain: forward extension towards the next chain, then backward extension /
-//                            junction bridge, consuming the lanes' answers
-//   A5 anim_finish_kernel    one wave per pair: stitch/fuse chains, 1-to-1 filter, parse_delta reduction -> pg_anim_result
+//   A4x the extension stage  MUMmer's own postnuc / sw_align (pga_postnuc.inc, pga_postnuc_diag.inc; statement pg_nucmer_core.h,
+//                            pg_nucmer_diag.h): match-to-match gaps, forward extensions and backward searches as pre-passes
+//                            (one wave or one lane per call), the units' sequential cluster walks, the forced re-alignments
+//                            as certified bands on diagonal-window engines of 128 ... 8192 diagonals
+//   A5 anim_finish_kernel    one wave per pair: 1-to-1 filter (delta-filter -1), parse_delta reduction -> pg_anim_result
 //
-// The kernels live in five include files, in pipeline order: pga_seed.inc (A1/A2), pga_cluster.inc (A3), pga_dp_wave.inc and
-// pga_dp_lane.inc (the DP in its two forms, A4a-c), pga_finish.inc (A4d/A5); this file holds the shared descriptors and
-// the host driver.
+// The kernels live in include files, in pipeline order: pga_seed.inc (A1/A2), pga_cluster.inc (A3), pga_postnuc.inc +
+// pga_postnuc_diag.inc (A4x), pga_finish.inc (A5), pga_frag.inc (fragment mode); this file holds the shared descriptors and
+// the host driver.  (The fixed-band "banded64" extender of rounds 1-2 was retired in round 5: it was not exact.)
 //
 // Every kernel has a scalar statement in pg_anim_core.h that compiles for the host (tools/anim_debug); the two are kept
 // in lock-step and compared on the GPU by tests/test_anim_gpu.py.  Limits: genomes up to ~14 Mb (a reference k-mer
@@ -95,8 +90,6 @@ __device__ __forceinline__ void packed_window(const uint32_t* __restrict__ codes
 
 #include "pga_seed.inc"
 #include "pga_cluster.inc"
-#include "pga_dp_wave.inc"
-#include "pga_dp_lane.inc"
 #include "pga_postnuc.inc"
 #include "pga_finish.inc"
 #include "pga_frag.inc"
@@ -136,26 +129,13 @@ struct AnimScratch {
   pg_anim_result* out = nullptr;
   // per-match arrays (sliced by moff)
   Match *mem = nullptr, *cm = nullptr;
-  int32_t *iscratch = nullptr, *order = nullptr, *prev = nullptr, *next = nullptr, *alnof = nullptr;
+  int32_t *iscratch = nullptr, *order = nullptr;
   Chain* chains = nullptr;
-  ChainFwd* fw = nullptr;
-  ChainBwd* bw = nullptr;
   FinishScratch S{};
   uint2* wl_d = nullptr;
-  GapTask* tasks_d = nullptr; // gaps that need the DP (at most one per match)
-  size_t tasks = 0;
   Match* seedbuf = nullptr;   // batch-wide append buffer of the seed pass
   size_t seed_cap = 0;
   uint32_t* seed_total = nullptr;   // [0] matches appended, [1] hits recorded
-  uint32_t* gap_counts = nullptr;   // gap tasks per size class + the wave list
-  ExtReq* ext_reqs = nullptr;       // DP requests for the lanes: free searches, then (at n_wl) target searches
-  ExtPre* ext_pre = nullptr;        // [EXT_ROUNDS][n_wl] arguments of the chains' first DP calls and the delivered results
-  ExtDump* ext_dumps = nullptr;     // searches the lanes hand over to the wave kernel mid-way
-  uint32_t* ext_wave = nullptr;     // chains left for the wave kernel of a phase
-  uint32_t* ext_counts = nullptr;   // request list lengths, hand-out cursor, hand-over count of a lane launch
-  size_t ext_cap = 0;
-  uint8_t* task_cls = nullptr;      // size class of the GapTask in every match slot (0xFF = none)
-  uint32_t* task_lists = nullptr;   // [GAP_CLASSES + 1][slots] slot lists by class
   Match* hits_d = nullptr;          // hits recorded by the probe kernel for anim_hit_kernel
   Match* hits_sorted = nullptr;     // the same, dealt into per-unit slices (hoff)
   uint32_t *hit_count = nullptr, *hoff = nullptr, *hit_cursor = nullptr;   // per unit
@@ -324,9 +304,9 @@ void pg_anim_free_scratch(pg_ctx* ctx) {
 static void anim_free_one(pg_ctx* ctx, void*& slot) {
   AnimScratch* A = static_cast<AnimScratch*>(slot);
   if (!A) return;
-  void* ptrs[] = {A->mirror_d, A->big_d, A->ranges_d, A->range_out, A->ext_reqs, A->ext_pre, A->ext_dumps, A->ext_wave, A->ext_counts, A->gap_counts, A->task_cls, A->task_lists, A->hits_sorted, A->hit_count, A->hoff, A->hit_cursor, A->hits_d, A->slice_d, A->choff_d, A->list_cnt, A->srefs_d, A->sqry_d, A->recs_d, A->refs_d, A->units_d, A->mem_count, A->moff, A->nch, A->status, A->out, A->mem, A->cm,
-                  A->iscratch, A->order, A->prev, A->next, A->alnof, A->chains, A->fw, A->bw, A->S.alns, A->S.a_rrec,
-                  A->S.a_qrec, A->S.idx, A->S.from, A->S.sc, A->wl_d, A->seedbuf, A->seed_total, A->tasks_d, A->fr_tables, A->fr_pairs,
+  void* ptrs[] = {A->mirror_d, A->big_d, A->ranges_d, A->range_out, A->hits_sorted, A->hit_count, A->hoff, A->hit_cursor, A->hits_d, A->slice_d, A->choff_d, A->list_cnt, A->srefs_d, A->sqry_d, A->recs_d, A->refs_d, A->units_d, A->mem_count, A->moff, A->nch, A->status, A->out, A->mem, A->cm,
+                  A->iscratch, A->order, A->chains, A->S.alns, A->S.a_rrec,
+                  A->S.a_qrec, A->S.idx, A->S.from, A->S.sc, A->wl_d, A->seedbuf, A->seed_total, A->fr_tables, A->fr_pairs,
                   A->fr_slot_pair, A->fr_off, A->fr_nrows, A->fr_ebase, A->fr_entries, A->fr_rows, A->fr_out, A->fr_list, A->fr_nlist, A->fr_wtmp, A->fr_widx,
                   A->pn, A->pn_fused, A->pn_n, A->pn_cursor, A->pn_gscratch, A->pn_reqs, A->pn_wide, A->pn_gaps, A->pn_fwd, A->pn_bwd, A->pn_tasks, A->pn_order, A->pn_pieces, A->pn_npieces, A->tr_arena, A->tr_out, A->tr_jobs, A->tr_off, A->tr_cursor, A->tr_cnt};
   for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -347,7 +327,7 @@ static int anib_frag_stage(pg_ctx* ctx, AnimScratch* A, const int32_t* qry_ids, 
 // (pg_anim_trace.h).  Host work here is list management: sizing the jobs' slabs from the wave engine's own bookkeeping,
 // batching them into the arena, stitching the pieces' paths.
 static int anim_collect(pg_ctx* ctx, AnimScratch* A, const int32_t* ref_ids, const int32_t* qry_ids, uint32_t n_pairs, const pg_anim_result* res,
-                        const std::vector<uint32_t>& choff, bool postnuc, PgAlnSink& sink) {
+                        const std::vector<uint32_t>& choff, PgAlnSink& sink) {
   const uint32_t n_units = 2 * n_pairs;
   int rc;
   std::vector<uint32_t> moff((size_t)n_units + 1);
@@ -382,7 +362,6 @@ static int anim_collect(pg_ctx* ctx, AnimScratch* A, const int32_t* ref_ids, con
     sink.pair_count.push_back(n);
   }
   if (!sink.with_indels) return PG_OK;
-  if (!postnuc) return pg_fail(ctx, PG_E_ARG, "indel lists need the nucmer extender (pg_anim_set_extender)");
   sink.indels.resize(sink.alns.size());
   const size_t n_wl = choff[n_units];
   if (!total || !n_wl) return PG_OK;      // no clusters at all: no alignments, nothing to trace
@@ -711,7 +690,6 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
   const size_t budget = call_bound < max_matches ? call_bound : (size_t)max_matches;
   if (!A->seed_total) {
     if ((rc = regrow(ctx, A->seed_total, 2))) return rc;
-    if ((rc = regrow(ctx, A->gap_counts, GAP_CLASSES + 1))) return rc;
   }
   if (budget + 1024 > A->seed_cap) {
     A->seed_cap = budget + 1024;
@@ -793,11 +771,6 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
     if ((rc = regrow(ctx, A->iscratch, cap * 8))) return rc;
     if ((rc = regrow(ctx, A->chains, cap))) return rc;
     if ((rc = regrow(ctx, A->order, cap))) return rc;
-    if ((rc = regrow(ctx, A->prev, cap))) return rc;
-    if ((rc = regrow(ctx, A->next, cap))) return rc;
-    if ((rc = regrow(ctx, A->alnof, cap))) return rc;
-    if ((rc = regrow(ctx, A->fw, cap))) return rc;
-    if ((rc = regrow(ctx, A->bw, cap))) return rc;
     if ((rc = regrow(ctx, A->S.alns, cap))) return rc;
     if ((rc = regrow(ctx, A->S.a_rrec, cap))) return rc;
     if ((rc = regrow(ctx, A->S.a_qrec, cap))) return rc;
@@ -806,11 +779,10 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
     if ((rc = regrow(ctx, A->S.sc, cap))) return rc;
     A->matches = cap;
   }
-  A->S.aln_of = A->alnof;
   PG_HIP(ctx, hipMemcpyAsync(A->moff, moff.data(), ((size_t)n_units + 1) * 4, hipMemcpyHostToDevice, cur_stream(ctx)));
   PG_HIP(ctx, hipMemsetAsync(A->mem_count, 0, n_units * 4, cur_stream(ctx)));
   PG_HIP(ctx, hipMemsetAsync(A->status, 0, n_pairs * 4, cur_stream(ctx)));
-  ClusterOut O{A->moff, A->cm, A->chains, A->nch, A->order, A->prev, A->next, A->status};
+  ClusterOut O{A->moff, A->cm, A->chains, A->nch, A->order, A->status};
   pg_prof_begin(ctx, PG_K_ANIM_HIT);
   if (total)
     hipLaunchKernelGGL(anim_scatter_kernel, dim3((total + 255) / 256), dim3(256), 0, cur_stream(ctx), A->seedbuf, total, A->moff, n_units,
@@ -877,8 +849,7 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
   std::vector<uint32_t> choff((size_t)n_units + 1, 0);
   for (uint32_t u = 0; u < n_units; ++u) choff[u + 1] = choff[u] + (uint32_t)nch[u];
   const size_t n_wl = choff[n_units];
-  const bool postnuc = ctx->anim_extender == PG_EXTENDER_NUCMER;
-  if (postnuc) {
+  {
     // A4x: MUMmer's own extension algorithm, one wave per unit (persistent waves, units handed out longest first would be
     // better still: a unit's time is ~ its clusters; the cursor takes them in batch order)
     const size_t Mp = (M + 15) & ~(size_t)15;
@@ -1005,127 +976,14 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
                 st[k] / 1e5, st[k + 2] ? (st[k + 2] - ~st[k + 3]) / 1e5 : 0.0, (st[k + 1] >> 20) / 1e5, st[k + 1] & 0xFFFFFull);
     }
   }
-  if (n_wl && !postnuc) {
-    if (n_wl > A->wl) { if ((rc = regrow(ctx, A->wl_d, n_wl + n_wl / 2))) return rc; A->wl = n_wl + n_wl / 2; }
-    uint32_t* choff_d = A->choff_d;
-    PG_HIP(ctx, hipMemcpyAsync(choff_d, choff.data(), choff.size() * 4, hipMemcpyHostToDevice, cur_stream(ctx)));
-    hipLaunchKernelGGL(anim_wl_kernel, dim3(n_units), dim3(64), 0, cur_stream(ctx), choff_d, A->wl_d);
-    // gap tasks: one slot per match (sparse), a class byte per slot, and GAP_CLASSES + 1 slot lists
-    const size_t Mp = (M + 15) & ~(size_t)15;
-    if (Mp > A->tasks) {
-      if ((rc = regrow(ctx, A->tasks_d, Mp))) return rc;
-      if ((rc = regrow(ctx, A->task_cls, Mp))) return rc;
-      if ((rc = regrow(ctx, A->task_lists, (GAP_CLASSES + 1) * Mp))) return rc;
-      A->tasks = Mp;
-    }
-    PG_HIP(ctx, hipMemsetAsync(A->gap_counts, 0, (GAP_CLASSES + 1) * 4, cur_stream(ctx)));
-    PG_HIP(ctx, hipMemsetAsync(A->task_cls, 0xFF, Mp, cur_stream(ctx)));
-    pg_prof_begin(ctx, PG_K_ANIM_GAPS);
-    hipLaunchKernelGGL(anim_gaps_kernel, dim3((uint32_t)n_wl), dim3(64), 0, cur_stream(ctx), A->refs_d, A->units_d, O, A->wl_d,
-                       A->fw, A->tasks_d, A->task_cls);
-    hipLaunchKernelGGL(anim_gapsort_kernel, dim3((uint32_t)ctx->num_cu * 8u), dim3(GAPSORT_BLOCK), 0, cur_stream(ctx), A->task_cls,
-                       (uint32_t)Mp, A->task_lists, A->gap_counts);
-    const dim3 lane_grid((uint32_t)ctx->num_cu * 8u);
-    hipLaunchKernelGGL((anim_gapdp_lane_kernel<17, false>), lane_grid, dim3(64), 0, cur_stream(ctx), A->refs_d, A->units_d, O, A->tasks_d,
-                       A->task_lists, A->gap_counts, A->fw);
-    hipLaunchKernelGGL((anim_gapdp_lane_kernel<32, false>), lane_grid, dim3(64), 0, cur_stream(ctx), A->refs_d, A->units_d, O, A->tasks_d,
-                       A->task_lists + Mp, A->gap_counts + 1, A->fw);
-    hipLaunchKernelGGL((anim_gapdp_lane_kernel<48, true>), lane_grid, dim3(64), 0, cur_stream(ctx), A->refs_d, A->units_d, O, A->tasks_d,
-                       A->task_lists + 2 * Mp, A->gap_counts + 2, A->fw);
-    hipLaunchKernelGGL((anim_gapdp_lane_kernel<64, true>), lane_grid, dim3(64), 0, cur_stream(ctx), A->refs_d, A->units_d, O, A->tasks_d,
-                       A->task_lists + 3 * Mp, A->gap_counts + 3, A->fw);
-    pg_prof_end(ctx);
-    // the larger gaps go through the lanes of the extension DP (anim_gapreq_kernel); their number sizes the buffers
-    uint32_t gap_counts[GAP_CLASSES + 1];
-    PG_HIP(ctx, hipMemcpyAsync(gap_counts, A->gap_counts, sizeof(gap_counts), hipMemcpyDeviceToHost, cur_stream(ctx)));
-    PG_HIP(ctx, hipStreamSynchronize(cur_stream(ctx)));
-    const size_t n_big = gap_counts[GAP_CLASSES], n_ext = n_wl > n_big ? n_wl : n_big;
-    // development / test knobs of the hand-over rule (results do not depend on them: tests/test_anim_gpu.py)
-    const int tail_lanes = pg_dev_env("PYANI_EXT_TAIL_LANES") ? atoi(pg_dev_env("PYANI_EXT_TAIL_LANES")) : EXT_TAIL_LANES;
-    const int tail_blocks = pg_dev_env("PYANI_EXT_TAIL_BLOCKS") ? atoi(pg_dev_env("PYANI_EXT_TAIL_BLOCKS")) : EXT_TAIL_BLOCKS;
-    uint32_t dump_cap = EXT_DUMP_CAP;
-    if (pg_dev_env("PYANI_EXT_DUMP_CAP") && (uint32_t)atoi(pg_dev_env("PYANI_EXT_DUMP_CAP")) < dump_cap) dump_cap = (uint32_t)atoi(pg_dev_env("PYANI_EXT_DUMP_CAP"));
-    if (!A->ext_dumps && (rc = regrow(ctx, A->ext_dumps, EXT_DUMP_CAP))) return rc;
-    if (!A->ext_counts && (rc = regrow(ctx, A->ext_counts, 8))) return rc;
-    if (n_ext > A->ext_cap) {
-      const size_t cap = n_ext + n_ext / 2;
-      if ((rc = regrow(ctx, A->ext_reqs, 2 * cap))) return rc;
-      if ((rc = regrow(ctx, A->ext_pre, EXT_ROUNDS * cap))) return rc;
-      if ((rc = regrow(ctx, A->ext_wave, cap))) return rc;
-      A->ext_cap = cap;
-    }
-    // persistent lane-DP waves per CU: 4 = one per SIMD (the kernel holds its band in 256 VGPRs: two fit a SIMD)
-    const uint32_t ext_waves_per_cu = pg_dev_env("PYANI_EXT_WAVES_PER_CU") ? (uint32_t)atoi(pg_dev_env("PYANI_EXT_WAVES_PER_CU")) : 4u;
-    if (n_big) {
-      PG_HIP(ctx, hipMemsetAsync(A->ext_counts, 0, 20, cur_stream(ctx)));   // [0], [1] list lengths, [2] hand-out cursor, [4] handed over
-      pg_prof_begin(ctx, PG_K_ANIM_EXTEND);
-      hipLaunchKernelGGL(anim_gapreq_kernel, dim3((uint32_t)((n_big + 255) / 256)), dim3(256), 0, cur_stream(ctx), A->refs_d, A->units_d,
-                         A->tasks_d, A->task_lists + GAP_CLASSES * Mp, (uint32_t)n_big, A->ext_pre, A->ext_reqs, A->ext_counts);
-      pg_prof_end(ctx);
-      pg_prof_begin(ctx, PG_K_ANIM_EXTLANE);
-      hipLaunchKernelGGL(anim_extdp_lane_kernel, dim3((uint32_t)ctx->num_cu * ext_waves_per_cu), dim3(64), 0, cur_stream(ctx), A->ext_reqs, A->ext_reqs,
-                         A->ext_counts, A->ext_counts + 2, A->ext_pre, A->ext_dumps, dump_cap, A->ext_counts + 4, tail_lanes, tail_blocks);
-      pg_prof_end(ctx);
-      pg_prof_begin(ctx, PG_K_ANIM_EXTEND);
-      hipLaunchKernelGGL(anim_gapdp_kernel, dim3((uint32_t)ctx->num_cu * 32u), dim3(64), 0, cur_stream(ctx), A->refs_d, A->units_d, O,
-                         A->tasks_d, A->task_lists + GAP_CLASSES * Mp, (uint32_t)n_big, A->ext_pre, A->ext_dumps, A->fw);
-      pg_prof_end(ctx);
-    }
-    for (int phase = 0; phase < 2; ++phase) {
-      // the first DP calls of every chain: written down, solved one per LANE, then consumed by the wave kernel
-      PG_HIP(ctx, hipMemsetAsync(A->ext_counts + 4, 0, 4, cur_stream(ctx)));   // [4] searches handed over mid-way
-      for (int round = 0; round < EXT_ROUNDS; ++round) {
-        PG_HIP(ctx, hipMemsetAsync(A->ext_counts, 0, 16, cur_stream(ctx)));   // [0], [1] list lengths, [2] hand-out cursor
-        pg_prof_begin(ctx, PG_K_ANIM_EXTEND);
-        hipLaunchKernelGGL(anim_extreq_kernel, dim3((uint32_t)((n_wl + 255) / 256)), dim3(256), 0, cur_stream(ctx), A->refs_d, A->units_d, O,
-                           A->wl_d, (uint32_t)n_wl, A->fw, A->bw, phase, round, A->ext_pre, A->ext_reqs, A->ext_reqs + n_wl, A->ext_counts,
-                           A->ext_wave);
-        pg_prof_end(ctx);
-        pg_prof_begin(ctx, PG_K_ANIM_EXTLANE);
-        hipLaunchKernelGGL(anim_extdp_lane_kernel, dim3((uint32_t)ctx->num_cu * ext_waves_per_cu), dim3(64), 0, cur_stream(ctx), A->ext_reqs,
-                           A->ext_reqs + n_wl, A->ext_counts, A->ext_counts + 2, A->ext_pre + (size_t)round * n_wl, A->ext_dumps,
-                           dump_cap, A->ext_counts + 4, tail_lanes, tail_blocks);
-        pg_prof_end(ctx);
-      }
-      // final round: chains whose calls were all answered are finished by a thread each; the others (handed-over searches,
-      // third calls, junction rectangles) are listed for the wave kernel
-      PG_HIP(ctx, hipMemsetAsync(A->ext_counts, 0, 12, cur_stream(ctx)));   // [0] list length, [2] hand-out cursor
-      pg_prof_begin(ctx, PG_K_ANIM_EXTEND);
-      hipLaunchKernelGGL(anim_extreq_kernel, dim3((uint32_t)((n_wl + 255) / 256)), dim3(256), 0, cur_stream(ctx), A->refs_d, A->units_d, O,
-                         A->wl_d, (uint32_t)n_wl, A->fw, A->bw, phase, EXT_ROUNDS, A->ext_pre, A->ext_reqs, A->ext_reqs + n_wl,
-                         A->ext_counts, A->ext_wave);
-      hipLaunchKernelGGL(anim_extend_kernel, dim3((uint32_t)ctx->num_cu * 32u), dim3(64), 0, cur_stream(ctx), A->refs_d, A->units_d, O,
-                         A->wl_d, A->fw, A->bw, phase, A->ext_pre, (uint32_t)n_wl, A->ext_dumps, A->ext_wave, A->ext_counts,
-                         A->ext_counts + 2);
-      pg_prof_end(ctx);
-    }
-  }
   pg_prof_begin(ctx, PG_K_ANIM_FINISH);
   hipLaunchKernelGGL(anim_finish_kernel, dim3(n_pairs), dim3(64), 0, cur_stream(ctx), A->refs_d, A->units_d, n_pairs,
-                     O, A->fw, A->bw, postnuc ? A->pn : nullptr, A->pn_n, A->S, filter_1to1, A->out);
+                     O, A->pn, A->pn_n, A->S, filter_1to1, A->out);
   pg_prof_end(ctx);
   PG_HIP(ctx, hipGetLastError());
   PG_HIP(ctx, hipMemcpyAsync(out_host, A->out, n_pairs * sizeof(pg_anim_result), hipMemcpyDeviceToHost, cur_stream(ctx)));
   PG_HIP(ctx, hipStreamSynchronize(cur_stream(ctx)));
-  if (tls_sink && (rc = anim_collect(ctx, A, ref_ids, qry_ids, n_pairs, out_host, choff, postnuc, *tls_sink))) return rc;
-#ifdef PGA_DP_STATS
-  {
-    unsigned long long st[3][40];
-    PG_HIP(ctx, hipMemcpyFromSymbol(st, HIP_SYMBOL(g_dp_stats), sizeof(st)));
-    unsigned long long cl[16];
-    PG_HIP(ctx, hipMemcpyFromSymbol(cl, HIP_SYMBOL(g_cl_stats), sizeof(cl)));
-    fprintf(stderr, "[cluster-stats] phases mumfilter/unionfind/rootsort/chains/tail: sum cycles %llu %llu %llu %llu %llu  max %llu %llu %llu %llu %llu  max n_in %llu\n",
-            cl[0], cl[1], cl[2], cl[3], cl[4], cl[6], cl[7], cl[8], cl[9], cl[10], cl[12]);
-    fprintf(stderr, "[cluster-stats] general-path rounds %llu, sum of live entries over rounds %llu, cycles in the general path %llu\n", cl[13], cl[14], cl[15]);
-    const char* names[3] = {"gap", "fwd", "bwd"};
-    for (int k = 0; k < 3; ++k) {
-      fprintf(stderr, "[dp-stats] %s calls %llu steps %llu cycles %llu  first calls: delivered %llu, handed over %llu, not valid %llu, other arguments %llu  hist(log2 steps):",
-              names[k], st[k][0], st[k][1], st[k][2], st[k][3], st[k][6], st[k][4], st[k][5]);
-      for (int b = 0; b < 20; ++b) fprintf(stderr, " %llu", st[k][8 + b]);
-      fprintf(stderr, "\n");
-    }
-  }
-#endif
+  if (tls_sink && (rc = anim_collect(ctx, A, ref_ids, qry_ids, n_pairs, out_host, choff, *tls_sink))) return rc;
   return PG_OK;
 }
 

@@ -1,5 +1,6 @@
-// pg_anim_core.h — per-pair logic of the ANIm engine (MUM filter, mgaps-style clustering, banded affine extension,
-// 1-to-1 filter, parse_delta reduction) as plain C++ that compiles for the device (hipcc) AND for the host.
+// pg_anim_core.h — per-pair logic of the ANIm engine either side of the extension stage (MUM filter, mgaps clustering,
+// 1-to-1 filter, parse_delta reduction; the extension stage itself is pg_nucmer_core.h) as plain C++ that compiles for the
+// device (hipcc) AND for the host.
 // The host build exists only for tools/anim_debug (a development harness in the GPU-less build container); the
 // product runs these functions inside HIP kernels (pg_anim.hip).
 //
@@ -31,16 +32,7 @@ constexpr int BREAK_LEN = PGA_BREAK_LEN;
 #else
 constexpr int BREAK_LEN = 200;       // nucmer -b  (anti-diagonals without a new high score)
 #endif
-// A target search reaches its target only if the target's anti-diagonal lies fewer than BREAK_LEN - TARGET_SLACK steps past the
-// best cell: out of sample (round 2) MUMmer left every junction unfused whose target sat exactly 199 steps past the best cell
-// and fused the ones at 198 (host sweep over all 25 192 fixture records: slack 0 / 1 / 2 -> 25 006 / 25 022 / 25 014 exact).
-#ifdef PGA_TARGET_SLACK
-constexpr int TARGET_SLACK = PGA_TARGET_SLACK;
-#else
-constexpr int TARGET_SLACK = 1;
-#endif
-constexpr int SC_MATCH = 3, SC_MISMATCH = -7, SC_GAP_OPEN = -10, SC_GAP_EXT = -7;
-constexpr int BAND = 64;             // DP band: diagonal offsets -32 .. +31 around the start diagonal
+constexpr int32_t NEG_INF = -(1 << 28);
 
 // ---- packed genome view ------------------------------------------------------------------------------------------
 // Same layout as the TETRA arena (pg_internal.h): 2-bit codes, 1-bit clean mask, records separated by one dirty base.
@@ -72,184 +64,6 @@ struct Aln {     // alignment in ref / query-strand coordinates, half-open
   int32_t strand;
   int32_t keep;  // used by the 1-to-1 filter
 };
-
-// ---- banded affine extension -----------------------------------------------------------------------------------
-// Anti-diagonal order (d = i + j), band of BAND diagonals k = j - i in [-BAND/2, BAND/2).  This is the SCALAR statement
-// of the algorithm; pg_anim.hip holds the wave-cooperative version (one lane per diagonal, neighbours through DPP)
-// that computes exactly the same cells, checks and tie-breaks — the two must stay in lock-step.
-//   H: best score of a path ending at (i, j);  X: ending in a gap that consumed a ref base;  Y: ... a query base.
-//   X = max(H(i-1,j) + OPEN, X(i-1,j) + EXT)   (ties: open)      Y likewise from (i,j-1)
-//   H = max(diag + match/mismatch, X, Y)        (ties: diag, then X, then Y);  errors ride along.
-// Free search: the end is the best cell (ties: larger d, then larger k).  Every CHECK_EVERY anti-diagonals the search
-// stops once the best cell lies BREAK_LEN anti-diagonals back (nucmer -b; fitted: ">= 200", a tie at step 201 is too late) or no cell is alive.
-// Target search (tr >= 0): runs to d = tr + tq and reports whether the target cell was reached by a live path,
-// subject to the same break rule on the way (and to TARGET_SLACK at the target itself).
-struct ExtResult {
-  int32_t di, dj;      // bases consumed on ref / query at the chosen end
-  int32_t score, errors;
-  int32_t reached;     // target reached (only when a target was given)
-};
-
-constexpr int32_t NEG_INF = -(1 << 28);
-constexpr int CHECK_EVERY = 1;
-constexpr int TARGET_TRIM_MAX = 19;  // a following chain whose first match overlaps this one's end by < MIN_MATCH bases is still a target
-constexpr int GAP_DIAG_MAX = 64;  // same-diagonal gaps up to this length are first tried as pure substitutions
-
-struct DpCell { int32_t h, he, x, xe, y, ye; };
-
-// One cell update, shared by the scalar and the wave version.  up = cell (i-1, j), left = cell (i, j-1),
-// diag_h/diag_he = H of (i-1, j-1); ok = the two bases match.
-PG_HD DpCell dp_cell(bool has_up, int32_t up_h, int32_t up_he, int32_t up_x, int32_t up_xe, bool has_left, int32_t left_h,
-                     int32_t left_he, int32_t left_y, int32_t left_ye, bool has_diag, int32_t diag_h, int32_t diag_he, bool ok) {
-  // Every choice is the lexicographic maximum of (score, -errors): among equally scoring paths the one with fewer
-  // errors wins.  (This is what lets the device keep score and errors in one 32-bit key and use plain integer max.)
-  DpCell c{NEG_INF, 0, NEG_INF, 0, NEG_INF, 0};
-  if (has_up) {
-    const int32_t ho = up_h + SC_GAP_OPEN, xo = up_x + SC_GAP_EXT;
-    if (ho > xo || (ho == xo && up_he <= up_xe)) { c.x = ho; c.xe = up_he + 1; } else { c.x = xo; c.xe = up_xe + 1; }
-    if (c.x < NEG_INF / 2) c.x = NEG_INF;
-  }
-  if (has_left) {
-    const int32_t ho = left_h + SC_GAP_OPEN, yo = left_y + SC_GAP_EXT;
-    if (ho > yo || (ho == yo && left_he <= left_ye)) { c.y = ho; c.ye = left_he + 1; } else { c.y = yo; c.ye = left_ye + 1; }
-    if (c.y < NEG_INF / 2) c.y = NEG_INF;
-  }
-  if (has_diag && diag_h > NEG_INF / 2) { c.h = diag_h + (ok ? SC_MATCH : SC_MISMATCH); c.he = diag_he + (ok ? 0 : 1); }
-  if (c.x > c.h || (c.x == c.h && c.x > NEG_INF / 2 && c.xe < c.he)) { c.h = c.x; c.he = c.xe; }
-  if (c.y > c.h || (c.y == c.h && c.y > NEG_INF / 2 && c.ye < c.he)) { c.h = c.y; c.he = c.ye; }
-  return c;
-}
-
-template <typename RefT, typename QryT>
-PG_HD ExtResult extend_banded(const RefT& R, const QryT& Q, int64_t r0, int64_t q0, int dir, int32_t rmax, int32_t qmax,
-                              int32_t tr, int32_t tq) {
-  constexpr int W = BAND / 2;
-  DpCell cur[BAND];                 // latest cell of every diagonal (index l <-> k = l - W)
-  int32_t bs[BAND], bd[BAND], be[BAND];  // per-diagonal best: score, d, errors
-  for (int l = 0; l < BAND; ++l) { cur[l] = DpCell{NEG_INF, 0, NEG_INF, 0, NEG_INF, 0}; bs[l] = NEG_INF; bd[l] = 0; be[l] = 0; }
-  ExtResult res{0, 0, 0, 0, 0};
-  bool targeted = tr >= 0;
-  // band placement: diagonals k = l - W + koff.  A free search is centred on the start diagonal; a target search is
-  // centred between the start diagonal and the target's, so diagonal shifts of up to ~60 bases can be bridged.
-  int koff = 0;
-  if (targeted) {
-    koff = (tq - tr) / 2;
-    if (koff > W - 2) koff = W - 2;
-    if (koff < -(W - 2)) koff = -(W - 2);
-    const int lt = (tq - tr) - koff + W;
-    if (lt < 0 || lt >= BAND || tr > rmax || tq > qmax) { targeted = false; koff = 0; }   // unreachable: free search
-  }
-  if (targeted && tr == 0 && tq == 0) { res.reached = 1; return res; }
-  cur[W - koff].h = 0; bs[W - koff] = 0;   // cell (0, 0) lies on diagonal 0
-  const int32_t d_end = targeted ? tr + tq : rmax + qmax;
-  int32_t gbest = 0, gbest_d = 0;
-  for (int32_t d = 1; d <= d_end; ++d) {
-    DpCell nxt[BAND];
-    bool alive = false;
-    for (int l = 0; l < BAND; ++l) {
-      const int k = l - W + koff;
-      if ((d + k) & 1) { nxt[l] = cur[l]; continue; }        // this diagonal has no cell on anti-diagonal d
-      const int32_t i = (d - k) / 2, j = (d + k) / 2;
-      if (i < 0 || j < 0 || i > rmax || j > qmax) { nxt[l] = DpCell{NEG_INF, 0, NEG_INF, 0, NEG_INF, 0}; continue; }
-      const bool has_up = i >= 1 && l + 1 < BAND, has_left = j >= 1 && l >= 1, has_diag = i >= 1 && j >= 1;
-      bool ok = false;
-      if (has_diag) {
-        const int64_t rp = dir > 0 ? r0 + (i - 1) : r0 - i, qp = dir > 0 ? q0 + (j - 1) : q0 - j;
-        ok = R.clean(rp) && Q.clean(qp) && R.base(rp) == Q.base(qp);
-      }
-      const DpCell& U = cur[has_up ? l + 1 : l];
-      const DpCell& L = cur[has_left ? l - 1 : l];
-      nxt[l] = dp_cell(has_up, U.h, U.he, U.x, U.xe, has_left, L.h, L.he, L.y, L.ye, has_diag, cur[l].h, cur[l].he, ok);
-      if (nxt[l].h > NEG_INF / 2) {
-        alive = true;
-        if (nxt[l].h > bs[l] || (nxt[l].h == bs[l] && d >= bd[l])) { bs[l] = nxt[l].h; bd[l] = d; be[l] = nxt[l].he; }
-      }
-    }
-    for (int l = 0; l < BAND; ++l) cur[l] = nxt[l];
-    if ((d % CHECK_EVERY) == 0 || d == d_end) {
-      gbest = NEG_INF; gbest_d = 0;
-      for (int l = 0; l < BAND; ++l)
-        if (bs[l] > gbest || (bs[l] == gbest && bd[l] >= gbest_d)) { gbest = bs[l]; gbest_d = bd[l]; }
-      if (d - gbest_d >= BREAK_LEN) break;
-      // `alive` of the last anti-diagonal only; two dead anti-diagonals in a row cannot revive
-      bool any = alive;
-      for (int l = 0; l < BAND && !any; ++l) any = cur[l].h > NEG_INF / 2;
-      if (!any) break;
-    }
-    if (targeted && d == d_end) {
-      const int l = (tq - tr) - koff + W;
-      if (cur[l].h > NEG_INF / 2 && d - gbest_d < BREAK_LEN - TARGET_SLACK) { res.di = tr; res.dj = tq; res.score = cur[l].h; res.errors = cur[l].he; res.reached = 1; return res; }
-    }
-  }
-  // best cell: max score, ties -> larger d, then larger k
-  int bl = W; gbest = NEG_INF; gbest_d = -1;
-  for (int l = 0; l < BAND; ++l)
-    if (bs[l] > gbest || (bs[l] == gbest && bd[l] >= gbest_d)) { gbest = bs[l]; gbest_d = bd[l]; bl = l; }
-  const int k = bl - W + koff;
-  res.score = gbest; res.errors = be[bl]; res.di = (gbest_d - k) / 2; res.dj = (gbest_d + k) / 2;
-  return res;
-}
-
-// Full (un-banded) global alignment of a small rectangle: ref [r0, r0+n) x query [q0, q0+m), forward direction, same
-// recurrences and tie-breaks as dp_cell.  Used to bridge cluster junctions whose diagonal shift exceeds the band
-// (an indel of 60+ bases between two clusters that nucmer still fuses).  min(n, m) <= THIN_MAX; returns -1 otherwise.
-#ifdef PGA_THIN_LONG
-constexpr int THIN_MAX = 63, THIN_LONG = PGA_THIN_LONG;
-#else
-constexpr int THIN_MAX = 63, THIN_LONG = 511;
-#endif
-// THIN_WHOLE: the same DP with the shorter side up to two wave strips, for the ERROR COUNT of a bridged junction over the whole
-// junction (between the last match of one chain and the first match of the next); which junctions are bridged is still decided
-// on rectangles of at most THIN_MAX (host sweep, round 2: 63 / 126 / 189 -> 25 022 / 25 038 / 25 034 records exact).
-#ifdef PGA_THIN_WHOLE
-constexpr int THIN_WHOLE = PGA_THIN_WHOLE;
-#else
-constexpr int THIN_WHOLE = 2 * THIN_MAX;
-#endif
-struct RectResult { int32_t score, errors; };   // errors < 0: the rectangle is too large for the thin DP
-template <typename RefT, typename QryT>
-PG_HD RectResult thin_rect_errors(const RefT& R, const QryT& Q, int64_t r0, int32_t n, int64_t q0, int32_t m, int32_t max_short = THIN_MAX) {
-  if (n < 0 || m < 0 || n > THIN_LONG || m > THIN_LONG || (n > max_short && m > max_short)) return RectResult{NEG_INF, -1};
-  // rows = ref bases, columns = query bases (no transposition: both builds walk the same cells)
-  DpCell row[THIN_LONG + 1], nrow[THIN_LONG + 1];
-  row[0] = DpCell{0, 0, NEG_INF, 0, NEG_INF, 0};
-  for (int32_t j = 1; j <= m; ++j)
-    row[j] = dp_cell(false, 0, 0, 0, 0, true, row[j - 1].h, row[j - 1].he, row[j - 1].y, row[j - 1].ye, false, 0, 0, false);
-  for (int32_t i = 1; i <= n; ++i) {
-    nrow[0] = dp_cell(true, row[0].h, row[0].he, row[0].x, row[0].xe, false, 0, 0, 0, 0, false, 0, 0, false);
-    for (int32_t j = 1; j <= m; ++j) {
-      const bool ok = R.clean(r0 + i - 1) && Q.clean(q0 + j - 1) && R.base(r0 + i - 1) == Q.base(q0 + j - 1);
-      nrow[j] = dp_cell(true, row[j].h, row[j].he, row[j].x, row[j].xe, true, nrow[j - 1].h, nrow[j - 1].he, nrow[j - 1].y,
-                        nrow[j - 1].ye, true, row[j - 1].h, row[j - 1].he, ok);
-    }
-    for (int32_t j = 0; j <= m; ++j) row[j] = nrow[j];
-  }
-  return RectResult{row[m].h, row[m].he};
-}
-
-// Global alignment of the gap between two chained matches: ref gap n, query gap m (both small); returns errors.
-template <typename RefT, typename QryT>
-PG_HD int32_t gap_errors(const RefT& R, const QryT& Q, int64_t r0, int32_t n, int64_t q0, int32_t m) {
-  if (n == 0) return m;
-  if (m == 0) return n;
-  if (n == m && n <= GAP_DIAG_MAX) {
-    // A gap on one diagonal with e <= 2 mismatches: the straight path scores 3n - 10e >= 3n - 20, any path with an
-    // insertion/deletion pair at most 3(n-1) - 20 -> the diagonal is the unique optimum and the DP would return e.
-    int32_t err = 0;
-    for (int32_t t = 0; t < n; ++t)
-      err += (R.clean(r0 + t) && Q.clean(q0 + t) && R.base(r0 + t) == Q.base(q0 + t)) ? 0 : 1;
-    if (err <= 2) return err;
-  }
-  const ExtResult e = extend_banded(R, Q, r0, q0, +1, n, m, n, m);
-  if (e.reached) return e.errors;
-  // target outside the band (|n - m| >= BAND/2) or pruned: count the diagonal part + the length difference
-  int32_t k = n < m ? n : m, err = (n > m ? n - m : m - n);
-  for (int32_t t = 0; t < k; ++t) {
-    const bool ok = R.clean(r0 + t) && Q.clean(q0 + t) && R.base(r0 + t) == Q.base(q0 + t);
-    err += ok ? 0 : 1;
-  }
-  return err;
-}
 
 }  // namespace pga
 
@@ -447,296 +261,13 @@ PG_HD int split_chains_by_ref_record(Chain* chains, int n_chains, const Match* c
   return n_chains + extra;
 }
 
-// ---- chains -> alignments -------------------------------------------------------------------------------------------
-// postnuc semantics reconstructed from the fixtures: every chain is extended forward freely (stop = best-scoring
-// cell once BREAK_LEN anti-diagonals pass without a new high score); it is extended BACKWARD towards the end of the
-// preceding alignment as a target — if the target cell is reached before the break criterion fires, the two are
-// fused into one alignment (this is how nucmer bridges ~100-base junk between two clusters), otherwise the chain
-// starts a new alignment at its own best backward cell.
+// ---- chains in reference order (the extension stage that turns them into alignments is pg_nucmer_core.h) --------------------
 // Reference order of the chains: by the start of the first match; chains that start on the same reference base (only with
 // --maxmatch: one reference copy anchored by several query copies) in the order they were extracted — a TOTAL order, so
 // that every form of the cluster stage (radix sort of (r, chain), heapsort, std::sort) lists them identically.
 PG_HD bool chain_before(const Chain* chains, const Match* cm, int a, int b) {
   const int32_t ra = cm[chains[a].first].r, rb = cm[chains[b].first].r;
   return ra != rb ? ra < rb : a < b;
-}
-// nearest predecessor (chain_is_predecessor) / following chain of the same (ref record, query record) in ref order (looks 8
-// entries each way)
-// Chain p can be the predecessor of chain c (the alignment c's backward search aims at, may fuse with, and must not run into):
-// same records, and p's last match ends before c's first match starts in BOTH sequences, give or take the overlap a target may
-// have (TARGET_TRIM_MAX, as forward_target).  The chain before c in reference order may belong to another copy of a repeat,
-// far ahead in the query: with it as "predecessor" c never met the collinear chain one or two places further back that MUMmer
-// fuses it with (round 2, out of sample: +6 records; the bound itself is not sensitive, 0 / 19 / 100 / 10^5 -> +6 / +6 / +8 / +8).
-PG_HD bool chain_is_predecessor(const Chain* chains, const Match* cm, int p, int c) {
-  if (chains[p].rrec != chains[c].rrec || chains[p].qrec != chains[c].qrec) return false;
-  const Match& l = cm[chains[p].first + chains[p].count - 1];
-  const Match& f = cm[chains[c].first];
-  return l.r + l.len <= f.r + TARGET_TRIM_MAX && l.q + l.len <= f.q + TARGET_TRIM_MAX;
-}
-PG_HD void chain_neighbours(const Chain* chains, const Match* cm, const int32_t* order, int n, int32_t* prev_of, int32_t* next_of) {
-  for (int k = 0; k < n; ++k) {
-    const int c = order[k];
-    int p = -1, q = -1;
-    for (int kk = k - 1; kk >= 0 && kk >= k - 8 && p < 0; --kk)
-      if (chain_is_predecessor(chains, cm, order[kk], c)) p = order[kk];
-    for (int kk = k + 1; kk < n && kk <= k + 8 && q < 0; ++kk)
-      if (chains[order[kk]].rrec == chains[c].rrec && chains[order[kk]].qrec == chains[c].qrec) q = order[kk];
-    prev_of[c] = p;
-    next_of[c] = q;
-  }
-}
-
-struct ChainFwd {
-  int32_t first_r, first_q;     // first match start
-  int32_t inner_err;            // errors of the gaps between chained matches
-  int32_t lr, lq;               // end of the last chained match
-  int32_t re, qe, err_fwd;      // end after the forward extension (== next chain's first match when reached)
-  int32_t reached;              // forward extension landed exactly on chain `target`'s first match -> fuse
-  int32_t target;               // the first following chain that lies strictly ahead in both sequences (or -1)
-};
-struct ChainBwd {
-  int32_t rs, qs, err_back;     // start after the backward extension (== target cell when reached)
-  int32_t reached;              // landed exactly on the previous chain's forward end -> fuse
-                                // (2 = through the thin-rectangle bridge: err_back already includes the bridge)
-};
-
-// Gap fills between the chained matches; returns the end of the last match through er/eq.
-template <typename RefT, typename QryT>
-PG_HD int32_t chain_inner_errors(const RefT& R, const QryT& Q, const Match* cm, const Chain& c, int32_t& er, int32_t& eq) {
-  const Match& f = cm[c.first];
-  int32_t inner = 0;
-  er = f.r + f.len; eq = f.q + f.len;
-  for (int k = 1; k < c.count; ++k) {
-    Match t = cm[c.first + k];
-    int32_t trim = er - t.r;                 // chained matches may still overlap the running end
-    if (eq - t.q > trim) trim = eq - t.q;
-    if (trim > 0) { t.r += trim; t.q += trim; t.len -= trim; }
-    if (t.len <= 0) continue;
-    inner += gap_errors(R, Q, er, t.r - er, eq, t.q - eq);
-    er = t.r + t.len; eq = t.q + t.len;
-  }
-  return inner;
-}
-
-// Forward target of a chain that ends at (er, eq): the start of the following chain's first match.  If that match
-// overlaps this chain's end in ONE sequence by fewer than MIN_MATCH bases (a short tandem repeat at the edge of an
-// indel), the target is the match trimmed by the overlap, as between the matches of one cluster (fixture: Blochmannia
-// NC_007292 / NC_020075, one 791 kb alignment across a 46-base insertion flanked by an 11-mer repeat); if it overlaps in
-// BOTH sequences the two clusters stay two alignments (fixture: the Caulobacter pair around 3.73 Mb).
-PG_HD void forward_target(int32_t er, int32_t eq, int32_t nr, int32_t nq, int32_t nlen, int32_t& tr, int32_t& tq) {
-  tr = -1; tq = -1;
-  if (nr < 0 || (nr < er && nq < eq)) return;   // overlapping in BOTH sequences: the two clusters stay two alignments
-  int32_t trim = er - nr;
-  if (eq - nq > trim) trim = eq - nq;
-  if (trim < 0) trim = 0;
-  if (trim >= nlen || trim > TARGET_TRIM_MAX) return;
-  tr = nr + trim - er; tq = nq + trim - eq;
-}
-
-// MUMmer's DP works on at most MAX_ALIGNMENT_LENGTH = 10000 bases per call; an extension off a cluster end therefore
-// never exceeds 9999 bases in either direction — visible in the fixtures as alignments that stop exactly there.
-constexpr int32_t MAX_EXT_FWD = 9999, MAX_EXT_BWD = 9999;
-PG_HD int32_t cap_ext(int32_t v, int32_t cap) { return v < cap ? v : cap; }
-
-// Forward target: walk the following chains (same strand and records, ref order) and take the first whose first match
-// lies strictly ahead of (er, eq) in both sequences and within MUMmer's 10 kb DP limit; chains skipped on the way
-// overlap this one and end up shadowed.
-PG_HD int32_t pick_forward_target(const Chain* chains, const Match* cm, const int32_t* next_of, int c, int32_t er, int32_t eq,
-                                  int32_t& nr, int32_t& nq) {
-  nr = -1; nq = -1;
-  int t = next_of[c];
-  for (int hops = 0; t >= 0 && hops < 8; ++hops, t = next_of[t]) {
-    const Match& nf = cm[chains[t].first];
-    int32_t tr, tq;
-    forward_target(er, eq, nf.r, nf.q, nf.len, tr, tq);
-    if (tr >= 0) { nr = er + tr; nq = eq + tq; return t; }
-  }
-  return -1;
-}
-
-// Forward extension off the end (er, eq) of a chain towards the target match start (nr, nq) (or freely if nr < 0).
-// MUMmer's DP handles at most 10 kb per call: a farther target is approached in 10 kb free-search chunks, continuing
-// while a chunk runs into its length limit (the region is still alignable) and giving up as soon as one ends earlier.
-// EXT is the DP routine (scalar extend_banded on the host, the wave-cooperative one on the device).
-constexpr int MAX_FWD_CHUNKS = 64;
-template <typename EXT>
-PG_HD void forward_extension(EXT&& ext, int32_t er, int32_t eq, int32_t r_hi, int32_t q_hi, int32_t nr, int32_t nq, int32_t& re,
-                             int32_t& qe, int32_t& errors, int32_t& reached) {
-  int32_t cr = er, cq = eq, err = 0;
-  reached = 0;
-  for (int chunk = 0; chunk < MAX_FWD_CHUNKS; ++chunk) {
-    int32_t tr = -1, tq = -1;
-    if (nr >= 0) { tr = nr - cr; tq = nq - cq; }
-    const bool near = nr >= 0 && tr >= 0 && tq >= 0 && tr <= MAX_EXT_FWD && tq <= MAX_EXT_FWD;
-    ExtResult x = ext(cr, cq, cap_ext(r_hi - cr, MAX_EXT_FWD), cap_ext(q_hi - cq, MAX_EXT_FWD), near ? tr : -1, near ? tq : -1);
-    if (near && !x.reached && tr != tq)   // the band was shifted towards an unreachable target: search freely instead
-      x = ext(cr, cq, cap_ext(r_hi - cr, MAX_EXT_FWD), cap_ext(q_hi - cq, MAX_EXT_FWD), -1, -1);
-    err += x.errors; cr += x.di; cq += x.dj;
-    if (near) { reached = x.reached; break; }
-    const bool hit_cap = x.di >= MAX_EXT_FWD - 100 || x.dj >= MAX_EXT_FWD - 100;
-    if (nr < 0 || tr < 0 || tq < 0 || !hit_cap) break;   // no target, or the chunk ended on its own: stop here
-  }
-  re = cr; qe = cq; errors = err;
-}
-
-template <typename RefT, typename QryT>
-PG_HD ChainFwd extend_chain_fwd(const RefT& R, const QryT& Q, const Match* cm, const Chain* chains, const int32_t* next_of, int c,
-                                int32_t r_hi, int32_t q_hi) {
-  ChainFwd e;
-  e.first_r = cm[chains[c].first].r; e.first_q = cm[chains[c].first].q;
-  int32_t er, eq;
-  e.inner_err = chain_inner_errors(R, Q, cm, chains[c], er, eq);
-  e.lr = er; e.lq = eq;
-  int32_t nr, nq;
-  e.target = pick_forward_target(chains, cm, next_of, c, er, eq, nr, nq);
-  forward_extension([&](int32_t cr, int32_t cq, int32_t rmax, int32_t qmax, int32_t tr, int32_t tq) {
-                      return extend_banded(R, Q, cr, cq, +1, rmax, qmax, tr, tq); },
-                    er, eq, r_hi, q_hi, nr, nq, e.re, e.qe, e.err_fwd, e.reached);
-  return e;
-}
-
-// Junction with a diagonal shift beyond the band: the free backward search stopped at (e.rs, e.qs), its best cell.  nucmer's
-// DP band is dynamic: it widens by one diagonal per anti-diagonal and is trimmed from its edges where the score has fallen
-// more than  GOOD_SCORE * breaklen = 3 * 200 = 600  below the best cell, and the search ends breaklen anti-diagonals after the
-// best cell.  So the previous alignment's end (prev_re, prev_qe) is reached — and the two alignments fused — iff it lies
-// within the break length of the best cell (n + m <= 200) AND the optimal path over the residual rectangle between the two
-// costs no more than the X-drop.  Out of sample (the ten 85 % Caulobacter pairs, 101 such junctions): nucmer fused every
-// junction whose residual rectangle scores >= -612 and none below -623 (one exception at -605); 615 separates them, i.e.
-// indels up to ~87 bases between two clusters are bridged, longer ones end the alignment.  Round 1 had no score test (fitted
-// on the Blochmannia pairs, whose largest such indel is 80 bases) and fused 240 junctions nucmer does not.
-// RECT(r0, n, q0, m) -> {score, errors} of the optimal global path (errors < 0: too large for the thin DP).
-constexpr int32_t BRIDGE_XDROP =
-#ifdef PGA_BRIDGE_XDROP
-    PGA_BRIDGE_XDROP;
-#else
-    615;
-#endif
-template <typename RECT, typename RECTW>
-PG_HD void bridge_junction(ChainBwd& e, int32_t prev_re, int32_t prev_qe, int32_t tr, int32_t tq, int32_t first_r, int32_t first_q,
-                           int32_t prev_lr, int32_t prev_lq, int32_t prev_err_fwd, RECT&& rect, RECTW&& rect_whole) {
-  if (e.reached || prev_re < 0 || tr < 0) return;
-  int32_t shift = tq - tr;
-  if (shift < 0) shift = -shift;
-  if (shift < BAND - 2) return;                            // reachable shifts are decided by the (shifted-band) target search
-#ifdef PGA_BRIDGE_SHIFT_MAX
-  if (shift > PGA_BRIDGE_SHIFT_MAX) return;
-#endif
-  const int32_t n = e.rs - prev_re, m = e.qs - prev_qe;
-  if (n < 0 || m < 0 || n + m > BREAK_LEN) return;
-  const RectResult resid = rect(prev_re, n, prev_qe, m);
-  if (resid.errors < 0 || resid.score < -BRIDGE_XDROP) return;
-  // errors of the fused alignment: prefer the optimal path over the WHOLE junction, from the end of the previous chain's
-  // last match to this chain's first match (its free forward extension is then replaced: minus prev_err_fwd); then from the
-  // previous forward end; else the residual rectangle behind the free backward search
-  RectResult x = prev_lr >= 0 && prev_lr <= prev_re && prev_lq <= prev_qe ? rect_whole(prev_lr, first_r - prev_lr, prev_lq, first_q - prev_lq)
-                                                                           : RectResult{NEG_INF, -1};
-  if (x.errors >= 0) { e.err_back = x.errors - prev_err_fwd; }
-  else {
-    x = rect(prev_re, tr, prev_qe, tq);
-    if (x.errors >= 0) { e.err_back = x.errors; }
-    else { e.err_back += resid.errors; }
-  }
-  e.rs = prev_re; e.qs = prev_qe; e.reached = 2;
-}
-
-// The backward search of a chain never enters the matches of the chain before it — if that chain is its collinear
-// predecessor: its last match ends before this chain's first match in both sequences, on a diagonal the band can reach.  The
-// chain before it in reference order may just as well belong to another copy of a repeat, hundreds of kilobases away in the
-// query; stopping at ITS matches cut alignments short that MUMmer extends over them (round 2, out of sample: host sweep of
-// the shift bound over 25 192 records, none / 61 / 100 / 1000 / unbounded -> 25 057 / 25 057 / 25 056 / 25 044 / 25 022 exact).
-constexpr int PREV_LIMIT_SHIFT =
-#ifdef PGA_PREV_LIMIT_SHIFT
-    PGA_PREV_LIMIT_SHIFT;
-#else
-    BAND - 3;
-#endif
-PG_HD void limit_backward_by_prev(int32_t first_r, int32_t first_q, int32_t prev_lr, int32_t prev_lq, int32_t& r_lo, int32_t& q_lo) {
-  if (prev_lr > first_r || prev_lq > first_q) return;
-  int32_t sh = (first_q - prev_lq) - (first_r - prev_lr);
-  if (sh < 0) sh = -sh;
-  if (sh > PREV_LIMIT_SHIFT) return;
-  if (prev_lr > r_lo) r_lo = prev_lr;
-  if (prev_lq > q_lo) q_lo = prev_lq;
-}
-
-// prev_re/prev_qe: forward end of the preceding chain (same strand and records), or -1 if there is none;
-// prev_lr/prev_lq: end of its last match — the backward search never needs to enter the previous chain's matches;
-// prev_fr/prev_fq: its first match start; my_lr/my_lq: end of THIS chain's last match.  If the previous chain's span
-// already covers this chain entirely, the stitch will shadow it and no backward search is needed at all.
-template <typename RefT, typename QryT>
-PG_HD ChainBwd extend_chain_bwd(const RefT& R, const QryT& Q, int32_t first_r, int32_t first_q, int32_t r_lo, int32_t q_lo,
-                                int32_t prev_re, int32_t prev_qe, int32_t prev_lr, int32_t prev_lq, int32_t prev_fr,
-                                int32_t prev_fq, int32_t my_lr, int32_t my_lq, bool prev_reached_me, int32_t prev_err_fwd) {
-  // no search needed: the previous chain's forward extension already landed on this chain's first match (fusion),
-  // or its span covers this chain entirely (the stitch will shadow it)
-  if (prev_reached_me ||
-      (prev_re >= 0 && prev_fr <= first_r && prev_fq <= first_q && prev_re >= my_lr && prev_qe >= my_lq)) {
-    ChainBwd e;
-    e.rs = first_r; e.qs = first_q; e.err_back = 0; e.reached = 0;
-    return e;
-  }
-  int32_t tr = -1, tq = -1;
-  if (prev_re >= 0 && first_r >= prev_re && first_q >= prev_qe) { tr = first_r - prev_re; tq = first_q - prev_qe; }
-  if (prev_re >= 0) limit_backward_by_prev(first_r, first_q, prev_lr, prev_lq, r_lo, q_lo);
-  ExtResult b = extend_banded(R, Q, first_r, first_q, -1, cap_ext(first_r - r_lo, MAX_EXT_BWD),
-                              cap_ext(first_q - q_lo, MAX_EXT_BWD), tr, tq);
-  if (tr >= 0 && !b.reached && tr != tq)   // the band was shifted towards an unreachable target: search freely instead
-    b = extend_banded(R, Q, first_r, first_q, -1, cap_ext(first_r - r_lo, MAX_EXT_BWD), cap_ext(first_q - q_lo, MAX_EXT_BWD), -1, -1);
-  ChainBwd e;
-  e.rs = first_r - b.di; e.qs = first_q - b.dj; e.err_back = b.errors;
-  e.reached = (tr >= 0 && b.reached) ? 1 : 0;
-  bridge_junction(e, prev_re, prev_qe, tr, tq, first_r, first_q, prev_lr, prev_lq, prev_err_fwd,
-                  [&](int32_t r0, int32_t n, int32_t q0, int32_t m) { return thin_rect_errors(R, Q, r0, n, q0, m); },
-                  [&](int32_t r0, int32_t n, int32_t q0, int32_t m) { return thin_rect_errors(R, Q, r0, n, q0, m, THIN_WHOLE); });
-  return e;
-}
-
-// Sequential stitch of one strand's chains (order[] = sorted by first-match ref start).  prev_of / next_of: the
-// neighbouring chains of the same records in that order (or -1).  A chain is fused into the running alignment when
-// the previous chain's forward extension reached its first match, or when its own backward extension reached the
-// previous chain's forward end; chains lying inside an existing alignment are shadowed.
-PG_HD int stitch_chains(const ChainFwd* fw, const ChainBwd* bw, const Match* cm, const Chain* chains, const int32_t* order,
-                        const int32_t* prev_of, const int32_t* next_of, int n, int strand, int32_t* aln_of, Aln* out, int n_out,
-                        int max_out) {
-  const int out0 = n_out;
-  for (int k = 0; k < n; ++k) aln_of[order[k]] = -1;
-  for (int k = 0; k < n; ++k) {
-    const int c = order[k];
-    if (aln_of[c] >= 0) continue;                       // already fused forward into an earlier alignment
-    const Match& l = cm[chains[c].first + chains[c].count - 1];
-    const int p = prev_of[c];
-    int ai = -1;
-    if (p >= 0 && bw[c].reached && aln_of[p] >= 0 && out[aln_of[p]].re == fw[p].re && out[aln_of[p]].qe == fw[p].qe) {
-      ai = aln_of[p];                                    // bridge the junk between the two chains
-      out[ai].errors += bw[c].err_back + fw[c].inner_err;
-    } else {
-      bool shadow = false;
-      for (int t = out0; t < n_out && !shadow; ++t)
-        if (fw[c].first_r >= out[t].rs && l.r + l.len <= out[t].re && fw[c].first_q >= out[t].qs && l.q + l.len <= out[t].qe) {
-          shadow = true;
-          aln_of[c] = t;
-        }
-      if (shadow) continue;
-      if (n_out >= max_out) continue;
-      Aln a;
-      a.rs = bw[c].rs; a.qs = bw[c].qs; a.re = a.rs; a.qe = a.qs; a.strand = strand; a.keep = 0;
-      a.errors = bw[c].err_back + fw[c].inner_err;
-      ai = n_out;
-      out[n_out++] = a;
-    }
-    int cur = c;
-    for (;;) {
-      out[ai].errors += fw[cur].err_fwd;
-      out[ai].re = fw[cur].re; out[ai].qe = fw[cur].qe;
-      aln_of[cur] = ai;
-      if (!fw[cur].reached) break;
-      const int t = fw[cur].target;
-      if (t < 0 || aln_of[t] >= 0) break;
-      out[ai].errors += fw[t].inner_err;
-      cur = t;
-    }
-  }
-  return n_out;
 }
 
 // delta-filter -1 (1-to-1: intersection of the best alignment sets on the reference and on the query), restated from

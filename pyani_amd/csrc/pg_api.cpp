@@ -18,9 +18,8 @@ int pg_fail(pg_ctx* ctx, int code, const std::string& msg) {
 static const char* const KERNEL_NAMES[PG_K__COUNT] = {"tetra_count_kernel", "tetra_finalize_kernel", "tetra_stats_kernel",
                                                       "tetra_pairs_kernel", "anim_seed_kernel", "anim_hit_kernels",
                                                       "anim_cluster_wave_kernel",
-                                                      // the three extension-stage slots, by extender: nucmer (default) / banded64
-                                                      "anim_postnuc_gap_kernels|anim_gap_kernels", "anim_postnuc_forced_kernels|anim_extdp_lane_kernel",
-                                                      "anim_postnuc_kernel|anim_extend_kernels", "anim_finish_kernel", "anib_bucket_kernel",
+                                                      "anim_postnuc_gap_kernels", "anim_postnuc_forced_kernels",
+                                                      "anim_postnuc_kernel", "anim_finish_kernel", "anib_bucket_kernel",
                                                       "anib_frag_kernel", "anim_postnuc_fwd_kernel", "anim_postnuc_rehearse_kernel+anim_postnuc_bwd_kernel"};
 
 // ---- profiling ----------------------------------------------------------------------------------------------
@@ -744,12 +743,6 @@ int pg_anim_set_batch_budget(pg_ctx* ctx, uint32_t max_pairs, uint64_t max_match
   return PG_OK;
 }
 
-int pg_anim_set_extender(pg_ctx* ctx, int extender) {
-  if (!ctx || (extender != PG_EXTENDER_NUCMER && extender != PG_EXTENDER_BANDED64)) return pg_fail(ctx, PG_E_ARG, "bad argument");
-  ctx->anim_extender = extender;
-  return PG_OK;
-}
-
 int pg_anim_set_workers(pg_ctx* ctx, int workers) {
   if (!ctx || workers < 1 || workers > pg_ctx::MAX_WORKERS) return pg_fail(ctx, PG_E_ARG, "workers must be 1 ... 4");
   ctx->anim_workers = workers;
@@ -898,7 +891,6 @@ static int anim_alignments_batch_body(pg_ctx* ctx, const int32_t* ref_ids, const
   for (uint64_t i = 0; i < n_pairs; ++i)
     if (ref_ids[i] < 0 || (size_t)ref_ids[i] >= ctx->genomes.size() || qry_ids[i] < 0 || (size_t)qry_ids[i] >= ctx->genomes.size())
       return pg_fail(ctx, PG_E_ARG, "genome id out of range");
-  if (with_indels && ctx->anim_extender != PG_EXTENDER_NUCMER) return pg_fail(ctx, PG_E_ARG, "indel lists need the nucmer extender (pg_anim_set_extender)");
   PG_HIP(ctx, hipSetDevice(ctx->device));
   int rc;
   if ((rc = pg_upload(ctx))) return rc;

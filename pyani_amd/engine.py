@@ -172,11 +172,6 @@ class Engine:
                                            out.ctypes.data))
         return out
 
-    def anim_set_extender(self, extender: str = "nucmer") -> None:
-        """"nucmer" (default): MUMmer's own postnuc algorithm, exact; "banded64": the approximate fixed-band extender."""
-        which = {"nucmer": _lib.EXTENDER_NUCMER, "banded64": _lib.EXTENDER_BANDED64}[extender]
-        self._check(self.lib.pg_anim_set_extender(self._h, which))
-
     def anim_set_workers(self, workers: int = 2) -> None:
         """Host worker threads (streams) sharing one anim_pairs / anib_pairs call: 1 ... 4 (pyani's --workers inside one device)."""
         self._check(self.lib.pg_anim_set_workers(self._h, int(workers)))

@@ -115,9 +115,14 @@ class MultiEngine:
     def upload(self):
         self._all(lambda e: e.upload())
 
-    def anim_set_extender(self, extender: str = "nucmer"):
+    def anim_set_workers(self, workers: int = 2):
+        """Engine.anim_set_workers on every device (host worker threads / streams per device)."""
         for e in self.engines:
-            e.anim_set_extender(extender)
+            e.anim_set_workers(workers)
+
+    def anim_counters(self, reset: bool = False) -> np.ndarray:
+        """Engine.anim_counters summed over the devices."""
+        return np.sum([e.anim_counters(reset) for e in self.engines], axis=0).astype(np.uint64)
 
     # -- the work queue ----------------------------------------------------------------------------------------------------
     def _pull(self, chunks: List[np.ndarray], run_chunk, out: np.ndarray):
@@ -217,15 +222,9 @@ class MultiEngine:
 
     def tetra_counts(self, ids):
         shards = self._id_shards(ids)
-        res = [None] * len(shards)
-
-        def run(k):
-            res[k] = self.engines[k].tetra_counts(shards[k])
-        ts = [threading.Thread(target=run, args=(k,)) for k in range(len(shards))]
-        for t in ts:
-            t.start()
-        for t in ts:
-            t.join()
+        # one thread per engine through _all: an engine error (PG_E_NOMEM, a bad id) is re-raised here, not lost in a thread
+        res = self._all(lambda e: e.tetra_counts(shards[self.engines.index(e)]) if self.engines.index(e) < len(shards) else None)
+        res = [x for x in res if x is not None]
         return tuple(np.concatenate([x[j] for x in res]) for j in range(3))
 
     def tetra_matrix(self, ids, want_corr: bool = True):

@@ -321,16 +321,6 @@ def test_process_deltadir_walk_and_assembly(tmp_path):
         anim.process_deltadir(tmp_path, lengths, engine=OracleEngine())
 
 
-def test_lane_form_of_the_extension_dp_equals_the_scalar_statement():
-    """The one-LANE-per-search form of the banded DP (pga_dp_lane.inc: register parities, shared X / Y, H-only limit
-    kills, 64-bit sequence windows, best-cell tie order) restated for the host and compared with pga::extend_banded on
-    random searches (targets, tight limits, both directions, both strands, dirty bases): tools/anim_debug/lane_dp_check.cpp."""
-    exe = ROOT / "tools" / "anim_debug" / "lane_dp_check"
-    subprocess.run(["g++", "-O2", "-std=c++17", f"-I{ROOT / 'pyani_amd' / 'csrc'}", str(exe) + ".cpp", "-o", str(exe)], check=True)
-    out = subprocess.run([str(exe), "8000", "7"], capture_output=True, text=True)
-    assert out.returncode == 0 and out.stdout.strip().endswith(": 0 mismatches"), out.stdout[-2000:]
-
-
 def test_run_anim_recovery_mode_from_real_mummer_output(tmp_path, genome_dir):
     """pyani_amd.subcmd_anim.run_anim (the subcmd_anim.py:128-305 driver minus the database) in --recovery mode over the
     reference's own deltadir fixture: all 12 comparisons are recovered from MUMmer's .filter files, nothing is recomputed,

@@ -1,13 +1,11 @@
 """GPU tests of the ANIm path (through the C ABI).
 
   * the REDUCTION (parse_delta / delta-filter bookkeeping) has a pinned oracle -> integers equal, identity bit-equal;
-  * the ALIGNMENT SEARCH is MUMmer 3.23's own algorithm (default extender "nucmer": pga_postnuc.inc / pg_nucmer_core.h).
+  * the ALIGNMENT SEARCH is MUMmer 3.23's own algorithm (pga_postnuc.inc / pg_nucmer_core.h).
     MUMmer is absent from the reference tree, so it is pinned on the real nucmer / delta-filter output files the reference's
     tests hold: every alignment record (coordinates + error count), every delta-filter decision and every parse_delta tuple,
-    bit for bit, on all pairs whose genomes are available (tests/test_anim_oos_gpu.py has the pairs recovered in round 2);
-  * the round-1/2 extender ("banded64", opt-in, approximate) keeps its own self-consistency tests.
+    bit for bit, on all pairs whose genomes are available (tests/test_anim_oos_gpu.py has the pairs recovered in round 2).
 """
-import contextlib
 import json
 
 import numpy as np
@@ -21,15 +19,6 @@ import anim_oracle  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
-
-@contextlib.contextmanager
-def _extender(eng, name):
-    """Run a block with the given extension algorithm; the module's engine goes back to the default afterwards."""
-    eng.anim_set_extender(name)
-    try:
-        yield
-    finally:
-        eng.anim_set_extender("nucmer")
 
 # the genomes recovered in round 2 (tools/make_goldens.py) have their own module (tests/test_anim_oos_gpu.py: all 26 runs)
 OUT_OF_SAMPLE = {"NC_010338", "NC_014100"}
@@ -144,30 +133,27 @@ def test_unrelated_genomes_give_no_alignment(eng):
     assert int(r2["status"]) == 0 and float(r2["identity"]) > 0.99 and int(r2["ref_aln_len"]) > 50_000
 
 
-@pytest.mark.parametrize("extender", ["nucmer", "banded64"])
-def test_gpu_pipeline_equals_scalar_host_statement_on_synthetic_pairs(eng, extender):
+def test_gpu_pipeline_equals_scalar_host_statement_on_synthetic_pairs(eng):
     """Sampled-seed hashing + wave-cooperative clustering + the extension stage on the GPU give exactly what the
     exhaustive-seed scalar host build of the same statement gave (tools/make_anim_synth_host.py), for every divergence level of
-    the synthetic generator, with and without the 1-to-1 filter — for the default extender (MUMmer's postnuc algorithm:
-    wave engine == pgn::ScalarEngine) and for the opt-in banded64 one."""
+    the synthetic generator, with and without the 1-to-1 filter (MUMmer's postnuc algorithm: wave engine == pgn::ScalarEngine)."""
     from pyani_amd import synth
-    fx = json.loads((GOLD / ("anim_synth_host.json" if extender == "nucmer" else "anim_synth_host_banded64.json")).read_text())
+    fx = json.loads((GOLD / "anim_synth_host.json").read_text())
     n, L, seed = fx["n"], fx["length"], fx["seed"]
     eng.clear_genomes()
     ids = [eng.add_genome(*synth.genome(seed, n, g, L)) for g in range(n)]
     eng.upload()
     pairs = [(a, b) for a in range(n) for b in range(n) if a != b]
-    with _extender(eng, extender):
-        for mode, filt in (("filter", True), ("nofilter", False)):
-            res = eng.anim_pairs([ids[a] for a, _ in pairs], [ids[b] for _, b in pairs], filter_1to1=filt)
-            bad = []
-            for (a, b), r in zip(pairs, res):
-                want = fx["pairs"][f"{a},{b},{mode}"]
-                got = [int(r["ref_aln_len"]), int(r["qry_aln_len"]), float(r["identity"]).hex(), int(r["sim_errors"]),
-                       int(r["n_alignments"])]
-                if got != want:
-                    bad.append((a, b, got, want))
-            assert not bad, f"{extender} {mode}: {len(bad)} of {len(pairs)} pairs differ, first: {bad[0]}"
+    for mode, filt in (("filter", True), ("nofilter", False)):
+        res = eng.anim_pairs([ids[a] for a, _ in pairs], [ids[b] for _, b in pairs], filter_1to1=filt)
+        bad = []
+        for (a, b), r in zip(pairs, res):
+            want = fx["pairs"][f"{a},{b},{mode}"]
+            got = [int(r["ref_aln_len"]), int(r["qry_aln_len"]), float(r["identity"]).hex(), int(r["sim_errors"]),
+                   int(r["n_alignments"])]
+            if got != want:
+                bad.append((a, b, got, want))
+        assert not bad, f"{mode}: {len(bad)} of {len(pairs)} pairs differ, first: {bad[0]}"
 
 
 def _delta_data(path):
@@ -263,30 +249,6 @@ def test_batch_split_does_not_change_results_and_edge_inputs(eng):
     # --maxmatch (every maximal match, not only unique ones): on repeat-free synthetic genomes it must agree with --mum
     mm = eng.anim_pairs(ra[:30], qa[:30], maxmatch=True)
     assert mm.tobytes() == ref[:30].tobytes()
-
-
-def test_lane_to_wave_hand_over_does_not_change_results(eng, monkeypatch):
-    """The extension / gap DP runs one search per LANE and hands the tail of a launch over to the wave form mid-search
-    (pga_dp_lane.inc: anim_extdp_lane_kernel -> ExtDump -> extend_wave resume).  Where that happens must be invisible: hand
-    everything over at the first opportunity, never hand over, and run out of hand-over slots — same records."""
-    from pyani_amd import synth
-    eng.clear_genomes()
-    n, L = 8, 300_000
-    ids = [eng.add_genome(*synth.genome(11, n, g, L)) for g in range(n)]
-    eng.upload()
-    pairs = [(a, b) for a in ids for b in ids if a != b]
-    ra, qa = [a for a, _ in pairs], [b for _, b in pairs]
-    with _extender(eng, "banded64"):           # the lane / wave hand-over belongs to the banded64 extender
-        ref = eng.anim_pairs(ra, qa)
-        assert (ref["status"] == 0).sum() >= len(pairs) // 2
-        for lanes, blocks, cap in (("65", "0", None), ("0", "1000000", None), ("65", "0", "3"), ("65", "2", "100")):
-            monkeypatch.setenv("PYANI_EXT_TAIL_LANES", lanes)
-            monkeypatch.setenv("PYANI_EXT_TAIL_BLOCKS", blocks)
-            if cap is None:
-                monkeypatch.delenv("PYANI_EXT_DUMP_CAP", raising=False)
-            else:
-                monkeypatch.setenv("PYANI_EXT_DUMP_CAP", cap)
-            assert eng.anim_pairs(ra, qa).tobytes() == ref.tobytes(), (lanes, blocks, cap)
 
 
 def test_gap_forms_and_extenders_of_the_postnuc_stage_agree(monkeypatch):

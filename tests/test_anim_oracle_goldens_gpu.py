@@ -7,6 +7,8 @@ whole 5 Mb genomes of bench.py's own generator and seeds (tools/make_anim_oracle
   c4_divergent  the same set's most divergent family members (substitution rates 0.05 ... 0.15 + 0.15), N runs, 3 records; three
                 pairs with their .delta indel lists
   c3_family     BASELINE.json configs[2]: 8 ordered pairs of family 3
+  c4_filter_stress  (round 5) C4's family 2 with ten OVERLAPPING rearrangements per genome (tests/stress_genomes.py), 20 ordered pairs:
+                the set on which `delta-filter -1` has to choose (tests/test_anim_filter_oracle_gpu.py checks the filtered tuple)
 The GPU (pg_anim_alignments_batch through the C ABI) must return exactly these records — reference record, query record, the four
 coordinates, the error count — and, where listed, the indel offsets; pg_anim_pairs' tuple must equal pyani's parse_delta
 (anim.py:292-411, restated in oracle/anim_oracle.py) of the oracle's records."""
@@ -29,15 +31,23 @@ def gold():
         return json.load(fh)
 
 
+def golden_genome(S, g):
+    """genome g of a golden set, regenerated from its seeds (sets marked `rearranged`: tests/stress_genomes.py on top of the generator)"""
+    from pyani_amd import synth
+    if S.get("rearranged"):
+        from tests.stress_genomes import rearranged_benchmark_genome
+        return rearranged_benchmark_genome(S["seed"], S["n"], g, S["L"])
+    return synth.genome(S["seed"], S["n"], g, S["L"])
+
+
 def _check_set(S, name):
     import anim_oracle
-    from pyani_amd import synth
     from pyani_amd.engine import Engine
     pairs = S["pairs"]
     used = sorted({g for p in pairs for g in p[:2]})
     n_rec = 0
     with Engine(0) as eng:
-        ids = {g: eng.add_genome(*synth.genome(S["seed"], S["n"], g, S["L"])) for g in used}
+        ids = {g: eng.add_genome(*golden_genome(S, g)) for g in used}
         q, s = [ids[p[0]] for p in pairs], [ids[p[1]] for p in pairs]
         off, recs, _, _ = eng.anim_alignments_batch(q, s)                       # the production path (pre-passes on)
         tup = eng.anim_pairs(q, s, filter_1to1=False)
@@ -76,3 +86,7 @@ def test_c4_divergent_family_records_and_indel_lists_equal_the_nucmer_oracle(gol
 
 def test_c3_family_records_equal_the_nucmer_oracle(gold):
     assert _check_set(gold["c3_family"], "c3_family") > 300
+
+
+def test_c4_filter_stress_records_equal_the_nucmer_oracle(gold):
+    assert _check_set(gold["c4_filter_stress"], "c4_filter_stress") > 500

@@ -69,30 +69,10 @@ static void find_mems(const Genome& G, const QV& Q, int strand, std::vector<Matc
   }
 }
 
-// development aid: optimal global affine score of ref [r0, r0+n) x strand [q0, q0+m) (+3 / -7 / -10 / -7), plain O(nm)
-template <typename QV>
-static int rect_score(const SeqView& R, const QV& Q, int64_t r0, int n, int64_t q0, int m) {
-  const int NEG = -(1 << 28);
-  std::vector<int> H((n + 1) * (m + 1), NEG), X(H), Y(H);
-  auto at = [&](int i, int j) { return i * (m + 1) + j; };
-  H[0] = 0;
-  for (int i = 0; i <= n; ++i)
-    for (int j = 0; j <= m; ++j) {
-      if (!i && !j) continue;
-      int x = NEG, y = NEG, h = NEG;
-      if (i) x = std::max(H[at(i - 1, j)] + SC_GAP_OPEN, X[at(i - 1, j)] + SC_GAP_EXT);
-      if (j) y = std::max(H[at(i, j - 1)] + SC_GAP_OPEN, Y[at(i, j - 1)] + SC_GAP_EXT);
-      if (i && j) { const bool ok = R.clean(r0 + i - 1) && Q.clean(q0 + j - 1) && R.base(r0 + i - 1) == Q.base(q0 + j - 1); h = H[at(i - 1, j - 1)] + (ok ? SC_MATCH : SC_MISMATCH); }
-      X[at(i, j)] = x; Y[at(i, j)] = y; H[at(i, j)] = std::max(h, std::max(x, y));
-    }
-  return H[at(n, m)];
-}
-
 int main(int argc, char** argv) {
   if (argc < 3) { fprintf(stderr, "usage: anim_debug ref.fna qry.fna [--dump]\n"); return 2; }
   const bool dump = argc > 3 && !strcmp(argv[3], "--dump");
-  bool exact = getenv("ANIM_EXACT") != nullptr;   // the postnuc statement (pg_nucmer_core.h) instead of the banded64 extender
-  for (int i = 3; i < argc; ++i) if (!strcmp(argv[i], "--exact")) exact = true;
+  // (--exact is accepted and ignored: the postnuc statement, pg_nucmer_core.h, is the only extender since round 5)
   long exact_cells = 0;
   bool want_delta = false;        // --delta (with --exact): every alignment's .delta indel list after its ALN line
   for (int i = 3; i < argc; ++i) if (!strcmp(argv[i], "--delta")) want_delta = true;
@@ -131,7 +111,7 @@ int main(int argc, char** argv) {
     std::vector<int32_t> co(n_chains);
     for (int i = 0; i < n_chains; ++i) co[i] = i;
     std::sort(co.begin(), co.end(), [&](int a, int b) { return chain_before(chains.data(), cm.data(), a, b); });
-    if (exact) {
+    {
       const int cap = 1 << 15;
       std::vector<pgn::Cell> d0(cap), d1(cap), d2(cap);
       pgn::ScalarEngine<SeqView, StrandView> eng{R, Q, d0.data(), d1.data(), d2.data(), cap};
@@ -238,63 +218,6 @@ int main(int argc, char** argv) {
         alns.push_back(a);
       }
       fprintf(stderr, "strand %d: MEMs->MUMs %d, chains %d, alignments %d (postnuc statement, %ld cells so far)\n", strand, n, n_chains, na, exact_cells);
-      continue;
-    }
-    std::vector<ChainFwd> fw(n_chains);
-    std::vector<ChainBwd> bw(n_chains);
-    std::vector<int32_t> prev_of(n_chains, -1), next_of(n_chains, -1), r_lo(n_chains), r_hi(n_chains), q_lo(n_chains), q_hi(n_chains);
-    chain_neighbours(chains.data(), cm.data(), co.data(), n_chains, prev_of.data(), next_of.data());
-    for (int c = 0; c < n_chains; ++c) {
-      r_lo[c] = G.rec_start[chains[c].rrec]; r_hi[c] = G.rec_start[chains[c].rrec + 1] - 1;
-      q_lo[c] = H.rec_start[chains[c].qrec]; q_hi[c] = H.rec_start[chains[c].qrec + 1] - 1;
-      if (strand) { const int32_t a = (int32_t)H.len - q_hi[c], b = (int32_t)H.len - q_lo[c]; q_lo[c] = a; q_hi[c] = b; }
-      auto t0 = std::chrono::steady_clock::now();
-      fw[c] = extend_chain_fwd(R, Q, cm.data(), chains.data(), next_of.data(), c, r_hi[c], q_hi[c]);
-      const int t = fw[c].target;
-      double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-      if (ms > 20 && getenv("ANIM_TIMING")) fprintf(stderr, "FWD chain %d strand %d: %.0f ms, matches %d, first r %d q %d, last end r %d q %d -> re %d qe %d reached %d next %d\n", c, strand, ms, chains[c].count, fw[c].first_r, fw[c].first_q, fw[c].lr, fw[c].lq, fw[c].re, fw[c].qe, fw[c].reached, t);
-    }
-    for (int k = 0; k < n_chains; ++k) {
-      const int c = co[k];
-      const int p = prev_of[c];
-      auto t0 = std::chrono::steady_clock::now();
-      bw[c] = extend_chain_bwd(R, Q, fw[c].first_r, fw[c].first_q, r_lo[c], q_lo[c], p >= 0 ? fw[p].re : -1, p >= 0 ? fw[p].qe : -1, p >= 0 ? fw[p].lr : -1, p >= 0 ? fw[p].lq : -1,
-                               p >= 0 ? fw[p].first_r : -1, p >= 0 ? fw[p].first_q : -1, fw[c].lr, fw[c].lq,
-                               p >= 0 && fw[p].reached && fw[p].target == c, p >= 0 ? fw[p].err_fwd : 0);
-      if (getenv("ANIM_RECT") && p >= 0 && fw[c].first_r >= fw[p].re && fw[c].first_q >= fw[p].qe && !(fw[p].reached && fw[p].target == c)) {
-        // redo the free backward search (as extend_chain_bwd does) and score the residual rectangle up to the previous forward end
-        int32_t rl = r_lo[c], ql = q_lo[c];
-        if (fw[p].lr <= fw[c].first_r && fw[p].lq <= fw[c].first_q) { if (fw[p].lr > rl) rl = fw[p].lr; if (fw[p].lq > ql) ql = fw[p].lq; }
-        ExtResult b = extend_banded(R, Q, fw[c].first_r, fw[c].first_q, -1, cap_ext(fw[c].first_r - rl, MAX_EXT_BWD), cap_ext(fw[c].first_q - ql, MAX_EXT_BWD), -1, -1);
-        const int32_t rs = fw[c].first_r - b.di, qs = fw[c].first_q - b.dj, n = rs - fw[p].re, m = qs - fw[p].qe;
-        if (n >= 0 && m >= 0 && n + m <= 1000 && (long long)n * m < 4000000)
-          printf("RECT %d %d %d tr %d tq %d n %d m %d score %d bscore %d fscore_na 0 bw_reached %d\n", strand, fw[c].first_r, fw[c].first_q, fw[c].first_r - fw[p].re,
-                 fw[c].first_q - fw[p].qe, n, m, rect_score(R, Q, fw[p].re, n, fw[p].qe, m), b.score, bw[c].reached);
-      }
-      if (getenv("ANIM_JUNCTIONS") && p >= 0)
-        printf("JUNC %d %s %s %d %d %d %d %d %d %d %d %d %d %d %d %d %lld\n", strand, G.ids[chains[c].rrec].c_str(), H.ids[chains[c].qrec].c_str(),
-               fw[p].first_r, fw[p].first_q, fw[p].lr, fw[p].lq, fw[p].re, fw[p].qe, fw[p].reached && fw[p].target == c, fw[c].first_r, fw[c].first_q,
-               bw[c].rs, bw[c].qs, bw[c].reached, chains[p].count, (long long)H.len);
-      double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-      if (ms > 20 && getenv("ANIM_TIMING")) fprintf(stderr, "BWD chain %d strand %d: %.0f ms first r %d q %d -> rs %d qs %d reached %d prev %d (prev re %d qe %d lr %d lq %d)\n", c, strand, ms, fw[c].first_r, fw[c].first_q, bw[c].rs, bw[c].qs, bw[c].reached, p, p>=0?fw[p].re:-1, p>=0?fw[p].qe:-1, p>=0?fw[p].lr:-1, p>=0?fw[p].lq:-1);
-    }
-    if (getenv("ANIM_CHAINS")) {
-      const int lo = atoi(getenv("ANIM_CHAINS")), hi = getenv("ANIM_CHAINS_HI") ? atoi(getenv("ANIM_CHAINS_HI")) : lo + 4000;
-      for (int k = 0; k < n_chains; ++k) { const int c = co[k]; if (strand == (getenv("ANIM_CHAINS_STRAND") ? atoi(getenv("ANIM_CHAINS_STRAND")) : 0) && fw[c].first_r >= lo && fw[c].first_r <= hi)
-        fprintf(stderr, "chain %d: first %d %d last_end %d %d fwd_end %d %d (reached %d) bwd_start %d %d (reached %d) prev %d next %d count %d inner %d err_fwd %d err_back %d\n", c, fw[c].first_r, fw[c].first_q, fw[c].lr, fw[c].lq, fw[c].re, fw[c].qe, fw[c].reached, bw[c].rs, bw[c].qs, bw[c].reached, prev_of[c], next_of[c], chains[c].count, fw[c].inner_err, fw[c].err_fwd, bw[c].err_back); }
-    }
-    std::vector<int32_t> aln_of(n_chains + 1);
-    const int before = (int)alns.size();
-    alns.resize(before + n_chains);
-    const int after = stitch_chains(fw.data(), bw.data(), cm.data(), chains.data(), co.data(), prev_of.data(), next_of.data(), n_chains, strand,
-                                    aln_of.data(), alns.data(), before, (int)alns.size());
-    alns.resize(after);
-    fprintf(stderr, "strand %d: MEMs->MUMs %d, chains %d, alignments %d\n", strand, n, n_chains, after - before);
-    for (int i = before; i < after; ++i) {
-      Aln& a = alns[i];
-      a_rrec.push_back(record_of(G.rec_start.data(), (int)G.rec_start.size() - 1, a.rs));
-      if (strand) { const int32_t qs = (int32_t)H.len - a.qe, qe = (int32_t)H.len - a.qs; a.qs = qs; a.qe = qe; }  // forward coords
-      a_qrec.push_back(record_of(H.rec_start.data(), nq, a.qs));
     }
   }
   const int n = (int)alns.size();

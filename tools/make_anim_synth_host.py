@@ -1,8 +1,7 @@
 #!/usr/bin/env python3
 """Self-consistency fixture for the GPU ANIm pipeline: results of the HOST build of the same per-pair core
 (tools/anim_debug/anim_debug: exhaustive sorted-table seeding + pg_anim_core.h + pg_nucmer_core.h) on seeded synthetic genomes.
-Default: the postnuc statement (`--exact`, the product's default extender) -> tests/golden/anim_synth_host.json;
-`--banded64`: the approximate extender -> tests/golden/anim_synth_host_banded64.json.
+-> tests/golden/anim_synth_host.json.
 
 This does NOT pin parity with MUMmer (tests/golden/anim/ does that); it pins that the GPU seeding / clustering /
 wave-cooperative extension compute exactly what the scalar statement of the algorithm computes, on inputs with every
@@ -17,8 +16,7 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 from pyani_amd import synth  # noqa: E402
 
-BANDED = "--banded64" in sys.argv
-EXT = [] if BANDED else ["--exact"]
+EXT = []
 N, L, SEED = 6, 400_000, 20250228
 tmp = ROOT / "gpurun_out" / "_synth_host"
 tmp.mkdir(parents=True, exist_ok=True)
@@ -73,4 +71,4 @@ for a in range(3):
         f = r.stdout.split()
         out["contigs"]["pairs"][f"{a},{b}"] = [int(f[0]), int(f[1]), float(f[2]).hex(), int(f[3]), int(f[4])]
         print("contigs", a, b, out["contigs"]["pairs"][f"{a},{b}"], flush=True)
-(ROOT / "tests" / "golden" / ("anim_synth_host_banded64.json" if BANDED else "anim_synth_host.json")).write_text(json.dumps(out, indent=0, sort_keys=True))
+(ROOT / "tests" / "golden" / "anim_synth_host.json").write_text(json.dumps(out, indent=0, sort_keys=True))
