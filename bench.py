@@ -62,6 +62,7 @@ def parse_args():
     ap.add_argument("--cpu-pairs", type=int, default=0, help="anim: ordered pairs timed by the CPU leg (0 = one per host thread, <= 128)")
     ap.add_argument("--cpu-genomes", type=int, default=2, help="tetra: genomes timed by the CPU leg")
     ap.add_argument("--no-tetra", action="store_true", help="anim: skip the nested C2 TETRA sub-record")
+    ap.add_argument("--roofline-tiles", type=int, default=0, help="anim: how many tiles the one-worker roofline pass covers (0 = every tile of the grid)")
     ap.add_argument("--no-side-records", action="store_true", help="anim: skip related_only / unrelated_only / strong-step side records")
     ap.add_argument("--static-deal", action="store_true", help="anim, N > 1: deal a step's rows by the fixed hash (round 3) instead of the cross-rank queue")
     ap.add_argument("--cold-e2e", action="store_true", help="anim, N = 1: measure ONE cold end-to-end run instead of the step loop: FASTA files on disk -> "
@@ -460,25 +461,35 @@ def run_anim(args, rank, world, local, dist, torch):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # ---- the roofline step (untimed): ONE worker, so that the stages' HIP events are not timing the other worker's persistent waves
-    # (two streams made `anim_finish_kernel` look 379 ms long), engine counters read around it.  Each rank runs its
-    # static share of the next tile; rank 0 reports its own.
+    # ---- the roofline pass (untimed): ONE worker, so that the stages' HIP events are not timing the other worker's persistent waves
+    # (two streams made `anim_finish_kernel` look 379 ms long), over EVERY tile of the grid (one tile is
+    # not representative — the ten tiles of C4 hold 1.1 ... 2.5 x 10^12 DP cells), engine counters read around each.  At N > 1 each
+    # rank runs its static share of two tiles; rank 0 reports its own.
     k_prof = args.warmup + args.steps
-    my_rows = parallel.anim_row_shard(rows_of(k_prof), rank, world)
-    prof_pairs = parallel.anim_pair_array(n, my_rows, symmetric=True)
+    n_tiles = max(1, n // R)
+    prof_tiles = list(range(n_tiles)) if world == 1 else [k_prof % n_tiles, (k_prof + 1) % n_tiles]
+    if args.roofline_tiles:
+        prof_tiles = prof_tiles[:args.roofline_tiles]
     eng.anim_set_workers(1)
-    eng.anim_counters(reset=True)
-    eng.profile_reset()
     eng.profile_config(kernel_mask=sum(1 << s_ for s_ in stages), every_n=1)
-    eng.profile_enable(True)
-    t1 = time.perf_counter()
-    compute(prof_pairs)
-    eng.sync()
-    prof_s = time.perf_counter() - t1
-    eng.profile_enable(False)
-    prof = {eng.kernel_name(s_): eng.profile_get(s_) for s_ in stages}
-    ext_ms = sum(eng.profile_get(s_)[0] for s_ in ext_stages)
-    cnt = eng.anim_counters()
+    tile_recs = []
+    for tno in prof_tiles:
+        pp = parallel.anim_pair_array(n, parallel.anim_row_shard(rows_of(tno), rank, world), symmetric=True)
+        eng.anim_counters(reset=True)
+        eng.profile_reset()
+        eng.profile_enable(True)
+        t1 = time.perf_counter()
+        compute(pp)
+        eng.sync()
+        dt = time.perf_counter() - t1
+        eng.profile_enable(False)
+        tile_recs.append({"tile": tno, "pairs": pp, "seconds": dt, "prof": {eng.kernel_name(s_): eng.profile_get(s_) for s_ in stages},
+                          "ext_ms": sum(eng.profile_get(s_)[0] for s_ in ext_stages), "cnt": eng.anim_counters()})
+    prof_pairs = np.concatenate([t_["pairs"] for t_ in tile_recs])
+    prof_s = sum(t_["seconds"] for t_ in tile_recs)
+    prof = {name: (sum(t_["prof"][name][0] for t_ in tile_recs), sum(t_["prof"][name][1] for t_ in tile_recs)) for name in tile_recs[0]["prof"]}
+    ext_ms = sum(t_["ext_ms"] for t_ in tile_recs)
+    cnt = np.sum([t_["cnt"] for t_ in tile_recs], axis=0)
     eng.anim_set_workers(2)
     fence()
 
@@ -519,11 +530,44 @@ def run_anim(args, rank, world, local, dist, torch):
         achieved = alg_prof / (dom_ms * 1e-3) / 1e9 if dom_ms else 0.0
         pmc = _pmc_profile()
         traffic = pmc.get(dom, {}).get("hbm_bytes_per_launch")
+        # per tile: the dominant stage's time and byte rate (the tiles differ ~2 x in DP cells: the extremes are printed, `achieved` is the
+        # mean over all of them = total algorithmic bytes / total time of that stage)
+        def _alg(pp):
+            return float(((lens[pp[:, 0]] + 3) // 4 + (lens[pp[:, 1]] + 3) // 4 + 32).sum())
+        per_tile = [{"tile": t_["tile"], "pairs": int(len(t_["pairs"])), "ms": round(t_["prof"][dom][0], 3),
+                     "GBps": round(_alg(t_["pairs"]) / (t_["prof"][dom][0] * 1e-3) / 1e9, 2) if t_["prof"][dom][0] else None,
+                     "dp_cells": int(t_["cnt"][2]) + int(t_["cnt"][5]) + int(t_["cnt"][8]), "kernel_ms_sum": round(sum(v[0] for v in t_["prof"].values()), 1)}
+                    for t_ in tile_recs]
         # VALU-issue roofline of the extension stage (integer DP in registers: bytes are not its bound): DP cells per second against the
-        # rate at which the chip can issue the vector instructions those cells cost (instructions per cell: rocprofv3 SQ_INSTS_VALU of
-        # the extension kernels / the engines' own cell count of the same command, profiles/pmc_anim.json)
+        # rate at which the chip can issue the vector instructions those cells cost.  MEASURED IN THIS RUN: cells, anti-diagonals and calls
+        # per kernel class (the engines' own counters, pg_anim_counters) and the stages' HIP-event times of the roofline pass above.
+        # FROM THE COMMITTED PROFILE (profiles/pmc_anim.json: a rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU pass of the same command on
+        # MI355X, tools/summarize_r05_profiles.py): instructions per cell, per kernel class and for the stage as a whole.
         cells = int(cnt[2]) + int(cnt[5]) + int(cnt[8])
         vpc, spc = pmc.get("extension_valu_per_cell"), pmc.get("extension_salu_per_cell")
+        kclass = [("gaps", "anim_postnuc_gap_kernels", 128), ("forward", "anim_postnuc_fwd_kernel", 128), ("backward_ahead", "anim_postnuc_rehearse_kernel+anim_postnuc_bwd_kernel", 128),
+                  ("walks", "anim_postnuc_kernel", 128), ("forced_narrow", "anim_postnuc_forced_kernels", None), ("forced_512_1024", "anim_postnuc_forced_kernels", None),
+                  ("forced_2048", "anim_postnuc_forced_kernels", None), ("forced_group", "anim_postnuc_forced_kernels", None)]
+        per_kernel = {}
+        for kc, (kname, stage_name, slots) in enumerate(kclass):
+            calls, steps_k, cells_k = (int(cnt[32 + 4 * kc + j]) for j in range(3))
+            if not calls:
+                continue
+            rec = {"calls": calls, "anti_diagonals": steps_k, "cells": cells_k, "stage": stage_name, "stage_ms": round(prof.get(stage_name, (0.0, 0))[0], 3)}
+            if slots:      # a trimmed search runs on the 256-diagonal window: 64 lanes x 2 cell slots per anti-diagonal
+                rec["live_slot_fraction"] = round(cells_k / (steps_k * float(slots)), 4) if steps_k else None
+            ipc_k = (pmc.get("valu_per_cell_by_class") or {}).get(kname)
+            if ipc_k:
+                rec["valu_instructions_per_cell"] = ipc_k
+            per_kernel[kname] = rec
+        # instructions per CU and cycle of a stage = its cells (this run) x instructions per cell (committed profile) / its event time (this run)
+        for stage_name in {r_["stage"] for r_ in per_kernel.values()}:
+            ks = [r_ for r_ in per_kernel.values() if r_["stage"] == stage_name and r_.get("valu_instructions_per_cell")]
+            ms_ = prof.get(stage_name, (0.0, 0))[0]
+            if ks and ms_ and len(ks) == sum(1 for r_ in per_kernel.values() if r_["stage"] == stage_name):
+                instr = sum(r_["cells"] * r_["valu_instructions_per_cell"] for r_ in ks)
+                for r_ in ks:
+                    r_["stage_valu_per_cu_cycle"] = round(instr / 256.0 / (ms_ * 1e-3 * CLOCK_GHZ * 1e9), 3)
         valu = None
         if vpc and ext_ms:
             # a CU issues one wave64 VALU instruction per cycle (4 SIMDs x 1 per 4 cycles) and one scalar instruction per cycle (ONE scalar
@@ -535,9 +579,11 @@ def run_anim(args, rank, world, local, dist, torch):
                     "achieved": cells / (ext_ms * 1e-3), "peak": peak_cells, "unit": "DP cells/s", "frac": cells / (ext_ms * 1e-3) / peak_cells,
                     "cells": cells, "anti_diagonals": int(cnt[1]), "extension_ms": ext_ms, "valu_instructions_per_cell": vpc,
                     "salu_instructions_per_cell": spc,
+                    "measured_in_this_run": "cells, anti_diagonals, extension_ms, per_kernel.{calls, anti_diagonals, cells, stage_ms, live_slot_fraction} (engine counters + HIP events of the one-worker pass over all tiles)",
+                    "from_committed_profile": f"valu / salu instructions per cell, per_kernel.valu_instructions_per_cell ({pmc.get('extension_valu_source', 'profiles/pmc_anim.json')})",
+                    "per_kernel": per_kernel,
                     "peak_definition": f"256 CUs x {CLOCK_GHZ} GHz x 1 wave64 VALU instruction per cycle ({SIMDS} SIMDs, 4 cycles each) or 1 scalar "
-                                       f"instruction per cycle (one scalar unit per CU) / instructions per cell of the binding kind "
-                                       f"({pmc.get('extension_valu_source', 'profiles/pmc_anim.json')})"}
+                                       f"instruction per cycle (one scalar unit per CU) / instructions per cell of the binding kind"}
         # hash of one whole N x N result grid (the last occurrence of every cell among the timed steps), if the steps cover it
         dense = np.zeros((n, n, g.shape[1]), dtype=np.int64)
         covered = np.zeros((n, n), dtype=bool)
@@ -595,9 +641,13 @@ def run_anim(args, rank, world, local, dist, torch):
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "algorithmic_bytes_per_launch": alg_prof / max(dom_n, 1), "avg_launch_ms": dom_ms / max(dom_n, 1),
                 "launches": int(dom_n),
-                "definition": "SURVEY.md §8(d): ceil(Lq/4) + ceil(Ls/4) + 32 B per ordered pair of ONE untimed step run with a single worker "
-                              "(stage events un-overlapped; rank 0's share at N > 1) / the HIP-event time of the stage that took longest in it",
-                "one_worker_step": {"pairs": int(len(prof_pairs)), "seconds": prof_s,
+                "definition": "SURVEY.md §8(d): ceil(Lq/4) + ceil(Ls/4) + 32 B per ordered pair, summed over an untimed pass of EVERY tile of the grid "
+                              "run with a single worker (stage events un-overlapped; rank 0's share of two tiles at N > 1) / the summed HIP-event "
+                              "time of the stage that took longest in it; per_tile has each tile, tile_min / tile_max the extremes",
+                "tiles": len(tile_recs), "per_tile": per_tile,
+                "tile_min_GBps": min((t_["GBps"] for t_ in per_tile if t_["GBps"]), default=None),
+                "tile_max_GBps": max((t_["GBps"] for t_ in per_tile if t_["GBps"]), default=None),
+                "one_worker_step": {"pairs": int(len(prof_pairs)), "seconds": prof_s, "tiles": len(tile_recs),
                                     "stage_ms": {name: round(ms, 3) for name, (ms, _) in prof.items()},
                                     "stage_launches": {name: int(c) for name, (_, c) in prof.items()},
                                     "note": "seconds = wall time of the call, which includes growing the single worker's scratch to the whole "

@@ -15,6 +15,7 @@
 #include <cstdint>
 #include <cstring>
 #include <thread>
+#include <time.h>
 #include <vector>
 #include "pg_anim_core.h"
 #include "pg_nucmer_core.h"
@@ -121,20 +122,27 @@ struct Result {   // = pg_anim_result (include/pyani_gpu.h)
 };
 
 // the extension stage is the postnuc statement (pg_nucmer_core.h: MUMmer's own extension algorithm, scalar engine)
-Result run_pair(const Genome& G, const Genome& H, int filter_1to1, int maxmatch) {
+static double thread_cpu_seconds() { timespec t; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
+// helper_cpu_s: CPU seconds of the second walk's thread (the caller times its own thread)
+Result run_pair(const Genome& G, const Genome& H, int filter_1to1, int maxmatch, double* helper_cpu_s = nullptr) {
   const SeqView R = G.view();
   std::vector<Aln> alns;
   std::vector<int32_t> a_rrec, a_qrec;
   KmerTable tab;
   build_table(G, tab);
+  const int nq = (int)H.rec_start.size() - 1;
+  // seeding + MUM filter + mgaps per strand; then the two strands' walks side by side (pgn::PnPairSync: MUMmer walks the clusters of
+  // both strands of a record pair in ONE list — the walks consult each other where that matters)
+  struct Strand { std::vector<Chain> chains; std::vector<Match> cm; std::vector<int32_t> co; int n_chains = 0; std::vector<pgn::PnAln> al; int na = 0;
+                  std::vector<pgn::PnTurn> tlog; std::vector<int32_t> born; };
+  Strand S[2];
   for (int strand = 0; strand < 2; ++strand) {
     StrandView Q{H.view(), strand};
     std::vector<Match> mem;
     find_mems(G, tab, Q, strand, mem);
     int n = (int)mem.size();
-    const int nq = (int)H.rec_start.size() - 1;
     if (!maxmatch) n = mum_filter(mem.data(), n, strand, [&](int32_t q) { return record_of(H.rec_start.data(), nq, strand ? (int32_t)(H.len - 1 - q) : q); });
-    else std::sort(mem.begin(), mem.end(), [](const Match& a, const Match& b) { return a.q != b.q ? a.q < b.q : (a.len != b.len ? a.len > b.len : a.r < b.r); });   // the engine's total order: q, len desc, r
+    else std::sort(mem.begin(), mem.end(), [](const Match& a, const Match& b) { return a.q != b.q ? a.q < b.q : a.r < b.r; });      // mgaps' By_Start2: query start, then reference start
     mem.resize(n);
     std::vector<int32_t> rrec(n), qrec(n), parent(n), score(n), from(n), adj(n), order(n);
     for (int i = 0; i < n; ++i) {
@@ -142,35 +150,49 @@ Result run_pair(const Genome& G, const Genome& H, int filter_1to1, int maxmatch)
       const int32_t qf = strand ? (int32_t)(H.len - 1 - mem[i].q) : mem[i].q;
       qrec[i] = record_of(H.rec_start.data(), nq, qf);
     }
-    std::vector<Chain> chains(n + 1);
-    std::vector<Match> cm(n + 1);
-    int n_chains = 0, n_cm = 0;
+    Strand& T = S[strand];
+    T.chains.resize(n + 1); T.cm.resize(n + 1);
+    int n_cm = 0;
     mgaps_strand(mem.data(), n, strand, rrec.data(), qrec.data(), parent.data(), score.data(), from.data(), adj.data(),
-                 order.data(), chains.data(), n_chains, (int)chains.size(), cm.data(), n_cm, (int)cm.size());
-    n_chains = split_chains_by_ref_record(chains.data(), n_chains, cm.data(), [&](int32_t r) { return record_of(G.rec_start.data(), (int)G.rec_start.size() - 1, r); });
-    std::vector<int32_t> co(n_chains);
-    for (int i = 0; i < n_chains; ++i) co[i] = i;
-    std::sort(co.begin(), co.end(), [&](int a, int b) { return chain_before(chains.data(), cm.data(), a, b); });
-    {
-      const int cap = 1 << 14;   // widest anti-diagonal: MAX_ALIGNMENT_LENGTH + 1 cells
-      std::vector<pgn::Cell> d0(cap), d1(cap), d2(cap);
-      pgn::ScalarEngine<SeqView, StrandView> eng{R, Q, d0.data(), d1.data(), d2.data(), cap};
-      std::vector<uint8_t> fused(n_chains + 1);
-      std::vector<pgn::PnAln> al(n_chains + 1);
-      int na = pgn::postnuc_unit(eng, chains.data(), cm.data(), co.data(), n_chains,
-          [&](int c, int32_t& rl, int32_t& rh, int32_t& ql, int32_t& qh) {
-            rl = G.rec_start[chains[c].rrec]; rh = G.rec_start[chains[c].rrec + 1] - 1;
-            ql = H.rec_start[chains[c].qrec]; qh = H.rec_start[chains[c].qrec + 1] - 1;
-            if (strand) { const int32_t a = (int32_t)H.len - qh, b = (int32_t)H.len - ql; ql = a; qh = b; } },
-          fused.data(), al.data(), (int)al.size());
-      if (na < 0) na = -1 - na;
-      for (int i = 0; i < na; ++i) {
-        Aln a{al[i].sA, al[i].eA + 1, al[i].sB, al[i].eB + 1, al[i].errors, strand, 0};
-        a_rrec.push_back(record_of(G.rec_start.data(), (int)G.rec_start.size() - 1, a.rs));
-        if (strand) { const int32_t qs = (int32_t)H.len - a.qe, qe = (int32_t)H.len - a.qs; a.qs = qs; a.qe = qe; }
-        a_qrec.push_back(record_of(H.rec_start.data(), nq, a.qs));
-        alns.push_back(a);
-      }
+                 order.data(), T.chains.data(), T.n_chains, (int)T.chains.size(), T.cm.data(), n_cm, (int)T.cm.size());
+    T.n_chains = split_chains_by_ref_record(T.chains.data(), T.n_chains, T.cm.data(), [&](int32_t r) { return record_of(G.rec_start.data(), (int)G.rec_start.size() - 1, r); });
+    T.co.resize(T.n_chains);
+    for (int i = 0; i < T.n_chains; ++i) T.co[i] = i;
+    std::sort(T.co.begin(), T.co.end(), [&](int a, int b) { return chain_before(T.chains.data(), T.cm.data(), a, b); });
+    T.al.resize(T.n_chains + 1); T.tlog.resize(T.n_chains + 1); T.born.resize(T.n_chains + 1);
+  }
+  pgn::PnHostShared shared;
+  auto walk = [&](int strand) {
+    Strand& T = S[strand];
+    StrandView Q{H.view(), strand};
+    const int cap = 1 << 14;   // widest anti-diagonal: MAX_ALIGNMENT_LENGTH + 1 cells
+    std::vector<pgn::Cell> d0(cap), d1(cap), d2(cap);
+    pgn::ScalarEngine<SeqView, StrandView> eng{R, Q, d0.data(), d1.data(), d2.data(), cap};
+    std::vector<uint8_t> fused(T.n_chains + 1);
+    pgn::PnPairSync<pgn::PnHostPrim> sync{pgn::PnHostPrim{&shared, strand}, T.tlog.data(), S[1 - strand].tlog.data(), T.born.data()};
+    T.na = pgn::postnuc_unit(eng, T.chains.data(), T.cm.data(), T.co.data(), T.n_chains,
+        [&](int c, int32_t& rl, int32_t& rh, int32_t& ql, int32_t& qh) {
+          rl = G.rec_start[T.chains[c].rrec]; rh = G.rec_start[T.chains[c].rrec + 1] - 1;
+          ql = H.rec_start[T.chains[c].qrec]; qh = H.rec_start[T.chains[c].qrec + 1] - 1;
+          if (strand) { const int32_t a = (int32_t)H.len - qh, b = (int32_t)H.len - ql; ql = a; qh = b; } },
+        fused.data(), T.al.data(), (int)T.al.size(), sync, strand);
+    if (T.na < 0) T.na = -1 - T.na;
+  };
+  {
+    double other_cpu = 0.0;
+    std::thread other([&]() { const double t0 = thread_cpu_seconds(); walk(1); other_cpu = thread_cpu_seconds() - t0; });
+    walk(0);
+    other.join();
+    if (helper_cpu_s) *helper_cpu_s = other_cpu;
+  }
+  for (int strand = 0; strand < 2; ++strand) {
+    const Strand& T = S[strand];
+    for (int i = 0; i < T.na; ++i) {
+      Aln a{T.al[i].sA, T.al[i].eA + 1, T.al[i].sB, T.al[i].eB + 1, T.al[i].errors, strand, 0};
+      a_rrec.push_back(record_of(G.rec_start.data(), (int)G.rec_start.size() - 1, a.rs));
+      if (strand) { const int32_t qs = (int32_t)H.len - a.qe, qe = (int32_t)H.len - a.qs; a.qs = qs; a.qe = qe; }
+      a_qrec.push_back(record_of(H.rec_start.data(), nq, a.qs));
+      alns.push_back(a);
     }
   }
   const int n = (int)alns.size();
@@ -216,9 +238,12 @@ int anim_cpu_pairs(const uint8_t* const* seqs, const uint64_t* const* rec_offs, 
   for (unsigned t = 0; t < nt && t < n_pairs; ++t)
     pool.emplace_back([&]() {
       for (uint32_t i; (i = next++) < n_pairs;) {
-        const auto t0 = std::chrono::steady_clock::now();
-        out[i] = run_pair(G[ref_ids[i]], G[qry_ids[i]], filter_1to1, maxmatch);
-        if (seconds_out) seconds_out[i] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        // CPU seconds of the pair: this thread's + the second walk's thread's (the two strands' walks run side by side, so wall time
+        // would flatter the baseline whenever cores are idle)
+        const double t0 = thread_cpu_seconds();
+        double helper = 0.0;
+        out[i] = run_pair(G[ref_ids[i]], G[qry_ids[i]], filter_1to1, maxmatch, &helper);
+        if (seconds_out) seconds_out[i] = thread_cpu_seconds() - t0 + helper;
       }
     });
   for (auto& th : pool) th.join();

@@ -299,7 +299,16 @@ static bool extend_backward(std::vector<Alignment>& Al, long cur, long target, c
 }
 
 static void extend_clusters(std::vector<Cluster>& Cl, const Seq& A, const Seq& Bf, const Seq& Br, std::vector<Alignment>& Al) {
-  std::stable_sort(Cl.begin(), Cl.end(), [](const Cluster& x, const Cluster& y) { return x.matches.front().sA < y.matches.front().sA; });
+  // postnuc: sort (Clusters.begin(), Clusters.end(), by the reference start of the first match) — std::sort, NOT stable, over an
+  // input order that depends on mgaps' union-by-size roots: clusters that start on the same reference base (only --maxmatch makes
+  // them) come in an order MUMmer does not define.  This restatement makes itself a function of its input: forward strand first,
+  // then by the query-strand start of the first match (round 5; before: the order of this file's own mgaps output).
+  std::stable_sort(Cl.begin(), Cl.end(), [](const Cluster& x, const Cluster& y) {
+    const Match &a = x.matches.front(), &b = y.matches.front();
+    if (a.sA != b.sA) return a.sA < b.sA;
+    if (x.dirB != y.dirB) return x.dirB == '+';
+    return a.sB < b.sB;
+  });
   bool target_reached = false;
   long prev = 0, curc = 0, targetc = -1, cura = -1;
   long targetA = 0, targetB = 0;

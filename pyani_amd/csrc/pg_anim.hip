@@ -157,6 +157,9 @@ struct AnimScratch {
   pgn::PnGap* pn_gaps = nullptr;    // match-to-match alignments by match slot
   pgn::PnFwd* pn_fwd = nullptr;     // forward extensions by cluster (moff-relative position in the unit's order)
   pgn::PnBwd* pn_bwd = nullptr;      // backward searches run ahead of the walks, by cluster (as pn_fwd)
+  pgn::PnTurn* pn_tlog = nullptr;    // the walks' turn logs (pgn::PnPairSync), sliced by moff: at most one turn per cluster
+  int32_t* pn_born = nullptr;        // per alignment: the key of the turn that pushed it
+  uint32_t* pn_porder = nullptr;     // pairs by descending cluster count of their larger strand
   pgn::PnPiece* pn_pieces = nullptr; // traceback runs: the walks' pieces (pn_piece_base)
   uint32_t* pn_npieces = nullptr;    // per unit
   size_t pn_piece_cap = 0, pn_npieces_cap = 0;
@@ -308,7 +311,7 @@ static void anim_free_one(pg_ctx* ctx, void*& slot) {
                   A->iscratch, A->order, A->chains, A->S.alns, A->S.a_rrec,
                   A->S.a_qrec, A->S.idx, A->S.from, A->S.sc, A->wl_d, A->seedbuf, A->seed_total, A->fr_tables, A->fr_pairs,
                   A->fr_slot_pair, A->fr_off, A->fr_nrows, A->fr_ebase, A->fr_entries, A->fr_rows, A->fr_out, A->fr_list, A->fr_nlist, A->fr_wtmp, A->fr_widx,
-                  A->pn, A->pn_fused, A->pn_n, A->pn_cursor, A->pn_gscratch, A->pn_reqs, A->pn_wide, A->pn_gaps, A->pn_fwd, A->pn_bwd, A->pn_tasks, A->pn_order, A->pn_pieces, A->pn_npieces, A->tr_arena, A->tr_out, A->tr_jobs, A->tr_off, A->tr_cursor, A->tr_cnt};
+                  A->pn, A->pn_fused, A->pn_n, A->pn_cursor, A->pn_gscratch, A->pn_reqs, A->pn_wide, A->pn_gaps, A->pn_fwd, A->pn_bwd, A->pn_tlog, A->pn_born, A->pn_porder, A->pn_tasks, A->pn_order, A->pn_pieces, A->pn_npieces, A->tr_arena, A->tr_out, A->tr_jobs, A->tr_off, A->tr_cursor, A->tr_cnt};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   delete A;
   slot = nullptr;
@@ -859,12 +862,15 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
       if ((rc = regrow(ctx, A->pn_gaps, Mp))) return rc;
       if ((rc = regrow(ctx, A->pn_fwd, Mp))) return rc;
       if ((rc = regrow(ctx, A->pn_bwd, Mp))) return rc;
+      if ((rc = regrow(ctx, A->pn_tlog, Mp))) return rc;
+      if ((rc = regrow(ctx, A->pn_born, Mp))) return rc;
       if ((rc = regrow(ctx, A->pn_tasks, 4 * Mp))) return rc;      // three lane classes + the wave engine's list
       A->pn_cap = Mp;
     }
     if (n_units > A->pn_units) {
       if ((rc = regrow(ctx, A->pn_n, (size_t)n_units + n_units / 2))) return rc;
       if ((rc = regrow(ctx, A->pn_order, (size_t)n_units + n_units / 2))) return rc;
+      if ((rc = regrow(ctx, A->pn_porder, (size_t)n_units + n_units / 2))) return rc;
       A->pn_units = (size_t)n_units + n_units / 2;
     }
     {
@@ -872,7 +878,11 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
       for (uint32_t u = 0; u < n_units; ++u) uorder[u] = u;
       std::stable_sort(uorder.begin(), uorder.end(), [&](uint32_t a, uint32_t b) { return nch[a] > nch[b]; });
       PG_HIP(ctx, hipMemcpyAsync(A->pn_order, uorder.data(), (size_t)n_units * 4, hipMemcpyHostToDevice, cur_stream(ctx)));
-      PG_HIP(ctx, hipStreamSynchronize(cur_stream(ctx)));     // (uorder is a local)
+      std::vector<uint32_t> porder(n_pairs);      // the walk kernel takes PAIRS (one wave per strand): by the larger strand's cluster count
+      for (uint32_t p = 0; p < n_pairs; ++p) porder[p] = p;
+      std::stable_sort(porder.begin(), porder.end(), [&](uint32_t a, uint32_t b) { return std::max(nch[2 * a], nch[2 * a + 1]) > std::max(nch[2 * b], nch[2 * b + 1]); });
+      PG_HIP(ctx, hipMemcpyAsync(A->pn_porder, porder.data(), (size_t)n_pairs * 4, hipMemcpyHostToDevice, cur_stream(ctx)));
+      PG_HIP(ctx, hipStreamSynchronize(cur_stream(ctx)));     // (uorder / porder are locals)
     }
     if (!A->pn_cursor && (rc = regrow(ctx, A->pn_cursor, 24))) return rc;
     const uint32_t pn_waves = (uint32_t)ctx->num_cu * 12u;   // units / forced kernels: 12 KiB of LDS each: 12 per CU
@@ -929,10 +939,10 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
     }
     pg_prof_begin(ctx, PG_K_ANIM_EXTEND);
     if (n_wl)
-      hipLaunchKernelGGL(anim_postnuc_kernel, dim3(pn_waves < n_units ? pn_waves : n_units), dim3(64), 0, cur_stream(ctx), A->refs_d, A->units_d,
-                         n_units, O, A->pn_cursor, A->pn, A->pn_fused, A->pn_n, A->pn_gscratch, A->pn_reqs, A->pn_cursor + 1, (uint32_t)req_cap,
-                         trace ? nullptr : A->pn_gaps, trace ? nullptr : A->pn_fwd, A->pn_order, trace ? A->pn_pieces : nullptr, A->pn_npieces, A->choff_d,
-                         bwd_ahead && !trace ? A->pn_bwd : nullptr);
+      hipLaunchKernelGGL(anim_postnuc_kernel, dim3(pn_waves / 2 < n_pairs ? pn_waves / 2 : n_pairs), dim3(128), 0, cur_stream(ctx), A->refs_d, A->units_d,
+                         n_pairs, O, A->pn_cursor, A->pn, A->pn_fused, A->pn_n, A->pn_gscratch, A->pn_reqs, A->pn_cursor + 1, (uint32_t)req_cap,
+                         trace ? nullptr : A->pn_gaps, trace ? nullptr : A->pn_fwd, A->pn_porder, trace ? A->pn_pieces : nullptr, A->pn_npieces, A->choff_d,
+                         bwd_ahead && !trace ? A->pn_bwd : nullptr, A->pn_tlog, A->pn_born);
     else
       PG_HIP(ctx, hipMemsetAsync(A->pn_n, 0, (size_t)n_units * 4, cur_stream(ctx)));
     pg_prof_end(ctx);
@@ -960,7 +970,7 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
       PG_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_pn_stats), zero, sizeof(zero)));
       fprintf(stderr, "[pn-stats] units %llu clusters %llu | regs: calls %llu steps %llu cells %llu moves %llu overflows %llu | lds: calls %llu steps %llu cells %llu | "
                       "global: calls %llu steps %llu cells %llu\n", st[11], st[12], st[0], st[1], st[2], st[9], st[10], st[3], st[4], st[5], st[6], st[7], st[8]);
-      fprintf(stderr, "[pn-stats] searches of the gap + units kernels: %llu calls, %.1f ms inside the engine (summed over waves)\n", st[22], st[21] / 1e5);
+      fprintf(stderr, "[pn-stats] searches of the gap + units kernels: %llu calls, %.1f ms inside the engine (summed over waves); shadow tests that asked for the synteny's current alignment: %llu\n", st[22], st[21] / 1e5, st[31]);
       fprintf(stderr, "[pn-stats] forced passes by engine (127 / 255 / 511 cells / strips): %llu %llu %llu %llu passes, %.1f %.1f %.1f %.1f ms summed over waves\n",
               st[27], st[28], st[29], st[30], st[23] / 1e5, st[24] / 1e5, st[25] / 1e5, st[26] / 1e5);
       {

@@ -150,7 +150,16 @@ struct Chain {      // a cluster chain: matches cm[first .. first+count)
   int32_t rrec, qrec;  // record indices (ref, query-forward)
 };
 
-constexpr int CHAIN_LOOKBACK = 64;  // mgaps scans all earlier matches of the cluster; we bound the scan (documented)
+// mgaps scans ALL earlier matches of a cluster for a match's best predecessor.  The chain DP here looks at the latest CHAIN_WINDOW
+// live ones first (the wave form keeps exactly those in registers) and goes on to the rest only when they could matter: a
+// predecessor j outside the window yields at most score[j] + len_i, and being earlier it wins ties, so the window's answer stands
+// whenever  max(score of the entries that left the window) + len_i  <  the window's best candidate  — along a collinear run the
+// scores grow by a match length per entry and the test never fails; when it does (round 5: it used to be a documented
+// deviation, "the chain DP looks back 64 matches") the scan continues to the cluster's first entry.  Same answer as the full scan.
+constexpr int CHAIN_WINDOW = 64;
+#if !defined(__HIP_DEVICE_COMPILE__)
+static long g_chain_full_scans = 0, g_chain_full_wins = 0;      // host statement only (development / tests): certificate failures, and how many changed the predecessor
+#endif
 
 // mgaps: union-find clustering of one strand's MUMs (sorted by q) + best-chain extraction.
 // scratch: parent[n], score[n], from[n], adj[n], used[n] (int32 each).  Appends chains to chains[]/cm[].
@@ -191,16 +200,14 @@ PG_HD void mgaps_strand(const Match* m, int n, int strand, const int32_t* rrec_o
     for (int k = g0; k < g1; ++k) from[order[k]] = -1;
     while (remaining > 0) {
       int best = -1;
+      int win_tail = -1, win_n = 0;      // the window: the live entries at positions win_tail .. k - 1 (at most CHAIN_WINDOW of them)
+      int32_t win_out = NEG_INF;         // the largest score among the live entries that have left it
       for (int k = g0; k < g1; ++k) {
         const int i = order[k];
         if (from[i] == -2) continue;
         score[i] = m[i].len; from[i] = -1; adj[i] = 0;
-        int seen = 0;
         int32_t bc = NEG_INF, bj = -1, bol = 0;   // best predecessor; equal scores: the EARLIEST one (mgaps scans j = 0 .. i-1 with a strict >)
-        for (int kk = k - 1; kk >= g0 && seen < CHAIN_LOOKBACK; --kk) {
-          const int j = order[kk];
-          if (from[j] == -2) continue;
-          ++seen;
+        auto consider = [&](int j) {
           int32_t ol = m[j].r + m[j].len - m[i].r;
           if (ol < 0) ol = 0;
           const int32_t ol2 = m[j].q + m[j].len - m[i].q;
@@ -209,9 +216,26 @@ PG_HD void mgaps_strand(const Match* m, int n, int strand, const int32_t* rrec_o
           if (dd < 0) dd = -dd;
           const int32_t cand = score[j] + m[i].len - (ol + dd);
           if (cand >= bc) { bc = cand; bj = j; bol = ol; }
+        };
+        for (int kk = k - 1; kk >= win_tail && win_tail >= 0; --kk) if (from[order[kk]] != -2) consider(order[kk]);      // the window: near to far
+        if (win_out > NEG_INF / 2 && win_out + m[i].len >= bc) {      // an entry that left the window could reach the best candidate: the rest
+#if !defined(__HIP_DEVICE_COMPILE__)
+          ++g_chain_full_scans;
+          const int bj_w = bj;
+#endif
+          for (int kk = win_tail - 1; kk >= g0; --kk) if (from[order[kk]] != -2) consider(order[kk]);
+#if !defined(__HIP_DEVICE_COMPILE__)
+          if (bj != bj_w && bc > score[i]) ++g_chain_full_wins;
+#endif
         }
         if (bc > score[i]) { score[i] = bc; from[i] = bj; adj[i] = bol; }
         if (best < 0 || score[i] > score[best]) best = i;
+        if (win_n == 0) win_tail = k;
+        if (win_n < CHAIN_WINDOW) ++win_n;
+        else {      // the oldest entry leaves the window
+          if (score[order[win_tail]] > win_out) win_out = score[order[win_tail]];
+          do ++win_tail; while (from[order[win_tail]] == -2);
+        }
       }
       // walk the chain
       int32_t total = 0, cnt = 0;
@@ -262,12 +286,15 @@ PG_HD int split_chains_by_ref_record(Chain* chains, int n_chains, const Match* c
 }
 
 // ---- chains in reference order (the extension stage that turns them into alignments is pg_nucmer_core.h) --------------------
-// Reference order of the chains: by the start of the first match; chains that start on the same reference base (only with
-// --maxmatch: one reference copy anchored by several query copies) in the order they were extracted — a TOTAL order, so
-// that every form of the cluster stage (radix sort of (r, chain), heapsort, std::sort) lists them identically.
+// Reference order of the chains: by the reference start of the first match.  Chains that start on the same reference base (only
+// --maxmatch produces them: one reference copy anchored by several query copies) have NO defined order in MUMmer — postnuc sorts
+// its clusters with std::sort, which is not stable, over an input order that depends on mgaps' union-by-size roots — so the engine
+// and the tests' CPU checker of nucmer both put them in a canonical one: by the query-strand start of the first match (two chains of one strand
+// cannot share both starts), then by index.  A TOTAL order that does not depend on how a cluster stage numbers its components, so
+// every form of it (radix sorts on the GPU, heapsort, std::sort) lists the chains identically.
 PG_HD bool chain_before(const Chain* chains, const Match* cm, int a, int b) {
-  const int32_t ra = cm[chains[a].first].r, rb = cm[chains[b].first].r;
-  return ra != rb ? ra < rb : a < b;
+  const Match &ma = cm[chains[a].first], &mb = cm[chains[b].first];
+  return ma.r != mb.r ? ma.r < mb.r : (ma.q != mb.q ? ma.q < mb.q : a < b);
 }
 
 // delta-filter -1 (1-to-1: intersection of the best alignment sets on the reference and on the query), restated from

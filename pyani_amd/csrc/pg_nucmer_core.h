@@ -14,6 +14,9 @@
 #pragma once
 #include <stdint.h>
 #include "pg_anim_core.h"
+#if !defined(__HIP_DEVICE_COMPILE__)
+#include <thread>
+#endif
 
 namespace pgn {
 using pga::Chain;
@@ -54,11 +57,15 @@ struct PnBwd { int32_t sA, sB, tA, tB; uint32_t m_o; int32_t rA, rB, reached, st
 // state of ORIGIN in the two bits under the score, one unsigned max over the three candidates is exactly that rule — the three
 // candidates of a choice always come from three different states, so the error bits below never decide — and the errors of the
 // chosen path ride along for free.  After a choice the word is re-labelled with the state it now belongs to.
-// A word whose score field is 0 is UNREACHABLE (any low bits).  Fields: 15 bits of score, bias 1024: a trimmed search keeps its
-// live cells within MAX_DIFF + a few gap steps of the best score, which starts at 3, and an alignment of at most 10 001 x 10 001
-// bases cannot score above 30 003; a forced run may push cells below -1024, where they saturate to unreachable (they are
-// thousands of points under the optimum: never on its path).  15 bits of errors: one call aligns at most 20 002 bases.
-constexpr uint32_t SCORE_BIAS = 1024u, SCORE_SHIFT = 17u;
+// A word whose score field is 0 is UNREACHABLE (any low bits).  Fields: 15 bits of score, bias 2700: an alignment of at most
+// 10 001 x 10 001 bases cannot score above 30 003, so the field's 32 768 values cover [-2700, 30 067] (rounds 3-4 had the bias
+// at 1024 and wasted 1 700 values at the top).  A trimmed search keeps its live cells within MAX_DIFF + a few gap steps of the
+// best score, which starts at 3: it never comes near the floor.  A forced run may push cells below -2700, where they saturate to
+// unreachable: harmless off the optimal path (they are thousands of points under it), a deviation from MUMmer's plain integers
+// only if the OPTIMAL path of a forced rectangle has a prefix below -2700 (386 mismatches in a row) — and a rectangle whose corner
+// can then not be reached at all is reported (forced_verdict below), never counted as 0 errors.  tests/test_anim_cpu.py holds
+// both cases.  15 bits of errors: one call aligns at most 20 002 bases.
+constexpr uint32_t SCORE_BIAS = 2700u, SCORE_SHIFT = 17u;
 constexpr uint32_t W_ONE = 1u << SCORE_SHIFT;                 // one score point; also: the smallest live word
 constexpr uint32_t W_STATE = 3u << 15, W_ERR = 0x7FFFu;
 enum : uint32_t { ST_DELETE = 0u << 15, ST_INSERT = 1u << 15, ST_MATCH = 2u << 15 };   // DELETE consumes a B base, INSERT an A base
@@ -207,6 +214,11 @@ struct PnScalarScans {
     for (int t = from; t >= 0; --t) if (pn_shadow_hit(chains, al[t], c, sA, eA, sB, eB)) return true;
     return false;
   }
+  // the EARLIEST of the unit's alignments al[0 .. n_al) that contains the cluster, -1 if none does (whatever the walk may see of them)
+  PG_HD int shadow_first(const Chain* chains, const PnAln* al, int n_al, int c, int32_t sA, int32_t eA, int32_t sB, int32_t eB) const {
+    for (int t = 0; t < n_al; ++t) if (pn_shadow_hit(chains, al[t], c, sA, eA, sB, eB)) return t;
+    return -1;
+  }
   PG_HD int reverse_target(const Chain* chains, const PnAln* al, int cura, int c, int32_t sA, int32_t sB, int32_t dist) const {
     int tgt = -1;
     for (int t = cura - 1; t >= 0; --t) {
@@ -229,6 +241,98 @@ struct PnScalarScans {
     return targetk;
   }
 };
+
+// ---- one walk over BOTH strands (round 5) -----------------------------------------------------------------------------------
+// MUMmer's extendClusters walks the clusters of one (reference record, query record) pair — a "synteny" — of BOTH query strands in
+// one list sorted by reference start, and isShadowedCluster looks at that synteny's alignments from its CURRENT one (the alignment
+// the latest non-skipped cluster left the walk on: the one it pushed, or the one its backward search merged into) backwards.  The
+// engine walks each strand as a unit of its own (and all record pairs of a strand in one list), so "the current alignment" of the
+// synteny may belong to the OTHER strand's walk, and a cluster's shadow test must see exactly the alignments of its own strand
+// that were made before that one — rounds 3-4 scanned from the unit's own current alignment instead (deviation (1):
+// the answers differ when an alignment of the cluster's strand and synteny lies beyond the current one, which takes a backward
+// merge into an older alignment, or when a turn of the other strand moved the current alignment).
+// The two walks of a pair run side by side and meet only where it matters.  Every walk keeps a log of its non-skipped TURNS (a
+// turn = the cluster the walk's `prev` cursor stands on plus the chain of forward targets it fuses: MUMmer's while-loop from one
+// `curc = ++prev` to the next) keyed by the turn's place in the joint order, key = 2 * (reference start of the turn's first
+// cluster) + strand (equal starts: forward strand first, as a stable sort of MUMmer's cluster list — forward clusters are read
+// first — leaves them), and publishes the key of the turn it is in.  A shadow test first looks whether ANY alignment of the unit
+// contains the cluster; only then (rare) does it need the synteny's current alignment: the later of the latest entry of its own
+// log and the latest entry of the other walk's log below its own key — for the latter it waits until the other walk has passed
+// that key (the waits cannot deadlock: each walk waits only for keys below its own).  If the current alignment is the other
+// strand's, the test sees its own alignments born (turn key) before that one.
+struct PnTurn { int32_t key, rrec, qrec, aln, born, pad; };      // after the turn: the synteny's current alignment = this unit's al[aln], born in the turn `born`
+constexpr int32_t PN_KEY_DONE = 0x7FFFFFFF;
+PG_HD int32_t pn_turn_key(int32_t ref_start, int strand) { return 2 * ref_start + (strand ? 1 : 0); }
+// PRIM: how the two walks reach each other's words — the host (two threads, std::atomic) and the GPU (two waves of a workgroup:
+// progress words in LDS, logs in global memory read past the vector L1) supply
+//   int32_t ld(const int32_t* p)      a load that sees the other walk's latest store        void st(int32_t* p, int32_t v)   its store
+//   void publish(int32_t n_log, int32_t key)   make this walk's log (n_log entries) and position visible, in that order
+//   int32_t other_key() / other_nlog()         the other walk's position / log length (key first)         void pause()
+template <typename PRIM>
+struct PnPairSync {
+  PRIM prim;
+  PnTurn* log;                 // this walk's turns
+  const PnTurn* other_log;     // the other walk's (nullptr: there is none — a walk by itself, e.g. the rehearsal)
+  int32_t* born;               // per alignment of this unit: the key of the turn that pushed it
+  int32_t n_log = 0, key = 0;
+  long waits = 0, asked = 0, differs = 0;   // (development counters; differs: shadow tests that the unit's own current alignment would have answered otherwise)
+  PG_HD void begin_turn(int32_t k) { key = k; pushed_aln = -1; prim.publish(n_log, k); }
+  int32_t pushed_aln = -1;     // the alignment this turn pushed (its birth key is `key`: not read back through memory in the same turn)
+  PG_HD void pushed(int aln) { prim.st(born + aln, key); pushed_aln = aln; }
+  PG_HD void end_turn(int32_t rrec, int32_t qrec, int aln) {
+    PnTurn* e = log + n_log;
+    const int32_t b = aln == pushed_aln ? key : prim.ld(born + aln);      // (else: a merge target, born in an earlier turn — stored before that turn's publish)
+    prim.st(&e->key, key); prim.st(&e->rrec, rrec); prim.st(&e->qrec, qrec); prim.st(&e->aln, aln); prim.st(&e->born, b);
+    ++n_log;
+  }
+  PG_HD void finish() { prim.publish(n_log, PN_KEY_DONE); }
+  // isShadowedCluster's scan range for a cluster of synteny (rrec, qrec) at the current turn: the largest index of this unit's
+  // alignment list the test may look at (-1: none).  n_al: alignments of this unit so far.
+  PG_HD int visible(int32_t rrec, int32_t qrec, int n_al, int /* cura */) {
+    ++asked;
+    int32_t o_key = -1, o_aln = -1;
+    for (int t = n_log - 1; t >= 0; --t)
+      if (prim.ld(&log[t].rrec) == rrec && prim.ld(&log[t].qrec) == qrec) { o_key = prim.ld(&log[t].key); o_aln = prim.ld(&log[t].aln); break; }
+    int32_t x_key = -1, x_born = 0;
+    if (other_log) {
+      while (prim.other_key() <= key) { ++waits; prim.pause(); }
+      for (int t = prim.other_nlog() - 1; t >= 0; --t) {
+        const int32_t k = prim.ld(&other_log[t].key);
+        if (k > key) continue;      // (the other walk is ahead: turns that come after this one in the joint order)
+        if (prim.ld(&other_log[t].rrec) == rrec && prim.ld(&other_log[t].qrec) == qrec) { x_key = k; x_born = prim.ld(&other_log[t].born); break; }
+      }
+    }
+    if (x_key > o_key) {      // the synteny's current alignment is the other strand's: this strand's alignments born before it
+      int cnt = 0;
+      while (cnt < n_al && prim.ld(born + cnt) < x_born) ++cnt;
+      return cnt - 1;
+    }
+    return o_aln;      // this strand's (-1: the synteny has no alignment yet)
+  }
+};
+// a walk by itself (the DP-free rehearsal: a wrong guess costs time, never a result): sees its own list up to its current alignment
+struct PnNoSync {
+  long differs = 0;
+  PG_HD void begin_turn(int32_t) {}
+  PG_HD void pushed(int) {}
+  PG_HD void end_turn(int32_t, int32_t, int) {}
+  PG_HD void finish() {}
+  PG_HD int visible(int32_t, int32_t, int, int cura) const { return cura; }
+};
+#if !defined(__HIP_DEVICE_COMPILE__)
+// the host statement's two walks of a pair: one thread per strand (tools/anim_debug and the CPU baseline's host build), GCC / clang atomics
+struct PnHostShared { int32_t key[2] = {-1, -1}, nlog[2] = {0, 0}; };
+struct PnHostPrim {
+  PnHostShared* sh;
+  int me;
+  int32_t ld(const int32_t* p) const { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
+  void st(int32_t* p, int32_t v) const { __atomic_store_n(p, v, __ATOMIC_RELEASE); }
+  void publish(int32_t n_log, int32_t key) const { __atomic_store_n(&sh->nlog[me], n_log, __ATOMIC_RELEASE); __atomic_store_n(&sh->key[me], key, __ATOMIC_RELEASE); }
+  int32_t other_key() const { return __atomic_load_n(&sh->key[1 - me], __ATOMIC_ACQUIRE); }
+  int32_t other_nlog() const { return __atomic_load_n(&sh->nlog[1 - me], __ATOMIC_ACQUIRE); }
+  void pause() const { std::this_thread::yield(); }
+};
+#endif
 
 // ---- forced alignments: the whole rectangle, computed as a certified band ------------------------------------------------
 // A FORCED alignment (the forward re-alignment of a backward extension, up to 10 000 x 10 000) is the optimal global path of its
@@ -258,6 +362,13 @@ PG_HD int32_t forced_band_after(int32_t w, int32_t N, int32_t M, int32_t S) {
 PG_HD int64_t forced_outside_bound(int32_t N, int32_t M, int32_t w) {
   const int64_t mn = N < M ? N : M, df = N < M ? M - N : N - M;
   return (int64_t)GOOD_SCORE * (mn - (w + 1)) + (int64_t)CONT_GAP_SCORE * (df + 2 * (int64_t)(w + 1)) + 2 * (OPEN_GAP_SCORE - CONT_GAP_SCORE);
+}
+// What the band loop of a forced run does with the result of band w (score: of the corner's word):  0 = accept, 1 = grow the band,
+// 2 = give up: even the whole rectangle leaves the corner unreachable, i.e. every path to it fell out of the score field — the
+// caller flags the unit (PG_E_CAPACITY on the pair) instead of adding the error count of a word that holds none.
+PG_HD int forced_verdict(bool reached, int32_t score, bool whole, int32_t N, int32_t M, int32_t w) {
+  if (score <= -(int32_t)SCORE_BIAS) return whole ? 2 : 1;
+  return (whole || (reached && (int64_t)score > forced_outside_bound(N, M, w))) ? 0 : 1;
 }
 // band of a forced run in cell coordinates: diagonal k = j - i = 2 j - Dct within [kmin - w, kmax + w]
 PG_HD void forced_band_clip(int32_t Dct, int32_t N, int32_t M, int32_t w, int32_t& lo, int32_t& hi) {
@@ -302,6 +413,8 @@ struct ScalarEngine {
   // the scans of extendClusters in MUMmer's own order
   PG_HD bool shadowed(const Chain* chains, const PnAln* al, int from, int c, int32_t sA, int32_t eA, int32_t sB, int32_t eB) const {
     return PnScalarScans().shadowed(chains, al, from, c, sA, eA, sB, eB); }
+  PG_HD int shadow_first(const Chain* chains, const PnAln* al, int n_al, int c, int32_t sA, int32_t eA, int32_t sB, int32_t eB) const {
+    return PnScalarScans().shadow_first(chains, al, n_al, c, sA, eA, sB, eB); }
   PG_HD int reverse_target(const Chain* chains, const PnAln* al, int cura, int c, int32_t sA, int32_t sB, int32_t dist) const {
     return PnScalarScans().reverse_target(chains, al, cura, c, sA, sB, dist); }
   PG_HD int forward_target(const Chain* chains, const Match* cm, const int32_t* order, int n, int curk, int c, int32_t sA, int32_t sB,
@@ -324,7 +437,9 @@ struct ScalarEngine {
       int32_t a = Aend, b = Bend, score = 0;
       const bool whole = w >= (N > M ? N : M);
       const bool reached = run(Astart, a, Bstart, b, m_o, whole ? -1 : w, errors, &score);
-      if (overflow || whole || (reached && (int64_t)score > forced_outside_bound(N, M, w))) { Aend = a; Bend = b; return reached; }
+      const int v = overflow ? 0 : forced_verdict(reached, score, whole, N, M, w);
+      if (v == 2) { overflow = 1; Aend = a; Bend = b; errors = 0; return false; }
+      if (v == 0) { Aend = a; Bend = b; return reached; }
       w = forced_band_after(w, N, M, score);
     }
   }
@@ -525,6 +640,8 @@ struct DiagEngine {
   // the scans of extendClusters in MUMmer's own order
   PG_HD bool shadowed(const Chain* chains, const PnAln* al, int from, int c, int32_t sA, int32_t eA, int32_t sB, int32_t eB) const {
     return PnScalarScans().shadowed(chains, al, from, c, sA, eA, sB, eB); }
+  PG_HD int shadow_first(const Chain* chains, const PnAln* al, int n_al, int c, int32_t sA, int32_t eA, int32_t sB, int32_t eB) const {
+    return PnScalarScans().shadow_first(chains, al, n_al, c, sA, eA, sB, eB); }
   PG_HD int reverse_target(const Chain* chains, const PnAln* al, int cura, int c, int32_t sA, int32_t sB, int32_t dist) const {
     return PnScalarScans().reverse_target(chains, al, cura, c, sA, sB, dist); }
   PG_HD int forward_target(const Chain* chains, const Match* cm, const int32_t* order, int n, int curk, int c, int32_t sA, int32_t sB,
@@ -551,7 +668,9 @@ struct DiagEngine {
       int32_t a = Aend, b = Bend;
       const bool whole = w >= (N > M ? N : M);
       const bool reached = run(Astart, a, Bstart, b, m_o, whole ? -1 : w, errors, score);
-      if (slow.overflow || whole || (reached && (int64_t)score > forced_outside_bound(N, M, w))) { Aend = a; Bend = b; return reached; }
+      const int v = slow.overflow ? 0 : forced_verdict(reached, score, whole, N, M, w);
+      if (v == 2) { slow.overflow = 1; Aend = a; Bend = b; errors = 0; return false; }
+      if (v == 0) { Aend = a; Bend = b; return reached; }
       w = forced_band_after(w, N, M, score);
     }
   }
@@ -581,6 +700,8 @@ struct PnRehearsal {
   PG_HD int32_t forced_errors(int32_t, int32_t, int32_t, int32_t, PnAln*) { return 0; }
   PG_HD bool shadowed(const Chain* chains, const PnAln* al, int from, int c, int32_t sA, int32_t eA, int32_t sB, int32_t eB) const {
     return e.shadowed(chains, al, from, c, sA, eA, sB, eB); }
+  PG_HD int shadow_first(const Chain* chains, const PnAln* al, int n_al, int c, int32_t sA, int32_t eA, int32_t sB, int32_t eB) const {
+    return e.shadow_first(chains, al, n_al, c, sA, eA, sB, eB); }
   PG_HD int reverse_target(const Chain* chains, const PnAln* al, int cura, int c, int32_t sA, int32_t sB, int32_t dist) const {
     return e.reverse_target(chains, al, cura, c, sA, sB, dist); }
   PG_HD int forward_target(const Chain* chains, const Match* cm, const int32_t* order, int n, int curk, int c, int32_t sA, int32_t sB,
@@ -618,9 +739,9 @@ PG_HD PnFwd postnuc_forward(ENG& eng, const Chain* chains, const Match* cm, cons
   return PnFwd{targetA, targetB, err, targetk, reached ? 1 : 0};
 }
 
-template <typename ENG, typename BOUNDS>
+template <typename ENG, typename BOUNDS, typename SYNC>
 PG_HD int postnuc_unit(ENG& eng, const Chain* chains, const Match* cm, const int32_t* order, int n, BOUNDS&& bounds, uint8_t* fused,
-                       PnAln* al, int max_al) {
+                       PnAln* al, int max_al, SYNC& sync, int strand) {
   for (int k = 0; k < n; ++k) fused[k] = 0;
   int n_al = 0, cura = -1;
   // The current alignment lives in A (registers) and is written to al[cura] only when something is about to read al[] or the
@@ -630,6 +751,7 @@ PG_HD int postnuc_unit(ENG& eng, const Chain* chains, const Match* cm, const int
   bool target_reached = false, full = false;
   int prev = 0, curk = 0, targetk = -1;
   int32_t targetA = 0, targetB = 0;
+  int32_t turn_rrec = 0, turn_qrec = 0;
   while (curk < n) {
     const int c = order[curk];
     const Chain C = chains[c];
@@ -638,12 +760,15 @@ PG_HD int postnuc_unit(ENG& eng, const Chain* chains, const Match* cm, const int
     const Match ml = mm[C.count - 1];
     int32_t r_lo, r_hi, q_lo, q_hi;
     bounds(c, r_lo, r_hi, q_lo, q_hi);
-    if (!target_reached) {
+    if (!target_reached) {      // a new turn of the walk (see PnPairSync): the cluster `prev` stands on
       eng.piece(PIECE_VISIT, -1, mf.r, mf.q, 0, 0, 0, 0, 0u);
+      sync.begin_turn(pn_turn_key(mf.r, strand));
+      turn_rrec = C.rrec; turn_qrec = C.qrec;
       bool skip = fused[curk] != 0;
-      if (!skip) {   // isShadowedCluster: inside an alignment of the same records made so far (from the current one backwards)
+      if (!skip) {   // isShadowedCluster: inside an alignment of the same records and strand, from the synteny's CURRENT alignment backwards
         if (cura >= 0) al[cura] = A;
-        skip = eng.shadowed(chains, al, cura, c, mf.r, ml.r + ml.len - 1, mf.q, ml.q + ml.len - 1);
+        const int first = eng.shadow_first(chains, al, n_al, c, mf.r, ml.r + ml.len - 1, mf.q, ml.q + ml.len - 1);
+        if (first >= 0) { const int vis = sync.visible(C.rrec, C.qrec, n_al, cura); skip = first <= vis; if (skip != (first <= cura)) ++sync.differs; }
       }
       if (skip) { fused[curk] = 1; curk = ++prev; continue; }
     }
@@ -658,6 +783,7 @@ PG_HD int postnuc_unit(ENG& eng, const Chain* chains, const Match* cm, const int
         if (cura >= 0) al[cura] = A;      // (the one the walk leaves; the scan below reads the alignments made so far)
         A = PnAln{Mp.r, Mp.q, Mp.r + Mp.len - 1, Mp.q + Mp.len - 1, 0, c};
         cura = n_al++;
+        sync.pushed(cura);
         // getReverseTargetAlignment: the latest earlier alignment that ends at or before this start in both sequences and is
         // close enough; failing that, the one at the smallest distance if that beats the distance to the sequence starts
         const int32_t d0 = (A.sA - r_lo + 1) < (A.sB - q_lo + 1) ? (A.sA - r_lo + 1) : (A.sB - q_lo + 1);
@@ -736,9 +862,10 @@ PG_HD int postnuc_unit(ENG& eng, const Chain* chains, const Match* cm, const int
     if (full) break;
     if (targetk < 0) target_reached = false;
     fused[curk] = 1;
-    if (!target_reached) curk = ++prev; else curk = targetk;
+    if (!target_reached) { sync.end_turn(turn_rrec, turn_qrec, cura); curk = ++prev; } else curk = targetk;
   }
   if (cura >= 0) al[cura] = A;
+  sync.finish();
   return full ? -1 - n_al : n_al;
 }
 

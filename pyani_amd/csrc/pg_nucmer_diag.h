@@ -391,6 +391,8 @@ struct DiagWaveEngine {
   }
   bool shadowed(const Chain* chains, const PnAln* al, int from, int c, int32_t sA, int32_t eA, int32_t sB, int32_t eB) const {
     return PnScalarScans().shadowed(chains, al, from, c, sA, eA, sB, eB); }
+  int shadow_first(const Chain* chains, const PnAln* al, int n_al, int c, int32_t sA, int32_t eA, int32_t sB, int32_t eB) const {
+    return PnScalarScans().shadow_first(chains, al, n_al, c, sA, eA, sB, eB); }
   int reverse_target(const Chain* chains, const PnAln* al, int cura, int c, int32_t sA, int32_t sB, int32_t dist) const {
     return PnScalarScans().reverse_target(chains, al, cura, c, sA, sB, dist); }
   int forward_target(const Chain* chains, const Match* cm, const int32_t* order, int n, int curk, int c, int32_t sA, int32_t sB,
@@ -434,7 +436,9 @@ struct DiagWaveEngine {
       int32_t a = Aend, b = Bend;
       const bool whole = w >= (N > M ? N : M);
       const bool reached = run(Astart, a, Bstart, b, m_o, whole ? -1 : w, errors, score);
-      if (slow.overflow || whole || (reached && (int64_t)score > forced_outside_bound(N, M, w))) { Aend = a; Bend = b; return reached; }
+      const int v = slow.overflow ? 0 : forced_verdict(reached, score, whole, N, M, w);
+      if (v == 2) { slow.overflow = 1; Aend = a; Bend = b; errors = 0; return false; }
+      if (v == 0) { Aend = a; Bend = b; return reached; }
       w = forced_band_after(w, N, M, score);
     }
   }

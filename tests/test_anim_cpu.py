@@ -374,3 +374,17 @@ def test_run_anim_recovery_mode_from_real_mummer_output(tmp_path, genome_dir):
     subcmd_anim.outfile_path(outdir, "NC_014100", "NC_002696").unlink()
     with pytest.raises(AssertionError, match="must not recompute"):
         subcmd_anim.run_anim(indir, outdir, recovery=True, engine=RecoveryOnlyEngine())
+
+
+def test_forced_runs_whose_optimal_path_dips_far_below_zero():
+    """DESIGN §4, deviation (3), directed: MUMmer's sw_align scores on plain integers, the engine's packed state words hold 15 bits of
+    score above a floor (pg_nucmer_core.h: SCORE_BIAS, -2700 since round 5; -1024 before).  tools/anim_debug/forced_check.cpp runs
+    pgn::ScalarEngine and the host emulation of the GPU's diagonal-window engines on rectangles whose optimal path falls to -1 586
+    (equal to a plain-integer statement of the forced alignment: exact now, lost with the old floor) and to -3 471 (below the floor on
+    every path: the run must fail LOUDLY — engine overflow, PG_E_CAPACITY on the pair — and not return an unreachable word's error
+    count).  No walk can produce such a rectangle (a backward search breaks 200 anti-diagonals after its last best cell), so there
+    is no genome pair that reaches this through the C ABI: the engines are driven directly."""
+    exe = ROOT / "tools" / "anim_debug" / "forced_check"
+    subprocess.run(["g++", "-O2", "-std=c++17", f"-I{ROOT / 'pyani_amd' / 'csrc'}", str(exe) + ".cpp", "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.count(" ok") == 6 and "WRONG" not in out.stdout, out.stdout

@@ -72,3 +72,55 @@ def test_statement_filter_decisions_and_tuple_equal_oracle_on_rearranged_pairs(p
             n_pairs_with_drops += sum(keep) < len(keep)
     # the generator does what it is for: the filter drops records in most pairs
     assert n_records > 600 and n_dropped > 60 and n_pairs_with_drops >= 35, (n_records, n_dropped, n_pairs_with_drops)
+
+
+def test_chain_dp_beyond_the_64_entry_window_equals_oracle_on_tandem_repeats(programs, tmp_path):
+    """DESIGN §4's former deviation (2), directed: tandem repeats under --maxmatch put hundreds of overlapping matches into one mgaps
+    cluster, where a match's best predecessor lies more than 64 entries back.  The statement's chain DP (pga::mgaps_strand) keeps a
+    64-entry window and now goes on to the rest whenever an entry outside it could matter; it reports how often that happened and
+    how often it CHANGED the predecessor — so this test proves it is exercised — and the records equal the oracle's full scan."""
+    from tests.stress_genomes import make_tandem_pair
+    oracle, stmt = programs
+    changed = trials_changed = 0
+    for t in range(24):
+        rng = random.Random(7000001 + t)
+        ref, qry = make_tandem_pair(rng)
+        pa, pb = tmp_path / f"tr{t}.fna", tmp_path / f"tq{t}.fna"
+        write_fasta(pa, "r", [ref])
+        write_fasta(pb, "q", [qry])
+        want = set(oracle_records(oracle, pa, pb, ["--maxmatch"]))
+        r = subprocess.run([str(stmt), str(pa), str(pb), "--dump", "--maxmatch", "--nofilter"], capture_output=True, text=True)
+        got = {(x[1], x[2], int(x[3]), int(x[4]), int(x[5]), int(x[6]), int(x[7])) for x in (ln.split() for ln in r.stdout.splitlines()) if x and x[0] == "ALN"}
+        assert got == want, (t, sorted(got ^ want)[:4])
+        for ln in r.stderr.splitlines():
+            if ln.startswith("chain DP:"):
+                n = int(ln.split(",")[1].split()[0])
+                changed += n
+                trials_changed += n > 0
+    assert changed > 1000 and trials_changed >= 8, (changed, trials_changed)
+
+
+def test_two_strand_walk_equals_oracle_where_a_walk_per_strand_would_not(programs, tmp_path):
+    """DESIGN §4's former deviation (1), directed: MUMmer walks the clusters of BOTH strands of a record pair in one list and tests a
+    cluster for being shadowed from the pair's CURRENT alignment backwards; the engine walks the strands side by side and lets the
+    walks consult each other (pgn::PnPairSync).  On tandem arrays that match on both strands (tests/stress_genomes.py) the statement
+    reports how many shadow tests needed the record pair's current alignment and how many of those a walk per strand — what rounds 3-4
+    did — would have answered otherwise: some must, and every record equals the oracle's (which walks one list, as MUMmer does)."""
+    import re
+    from tests.stress_genomes import TWO_STRAND_TRIALS, make_two_strand_repeat_pair
+    oracle, stmt = programs
+    asked = differs = 0
+    for t in TWO_STRAND_TRIALS:
+        rng = random.Random(13000003 + t)
+        ref, qry = make_two_strand_repeat_pair(rng)
+        pa, pb = tmp_path / f"pr{t}.fna", tmp_path / f"pq{t}.fna"
+        write_fasta(pa, "r", ref)
+        write_fasta(pb, "q", qry)
+        extra = ["--maxmatch"] if t % 4 != 0 else []
+        want = set(oracle_records(oracle, pa, pb, extra))
+        r = subprocess.run([str(stmt), str(pa), str(pb), "--dump", "--nofilter"] + extra, capture_output=True, text=True)
+        got = {(x[1], x[2], int(x[3]), int(x[4]), int(x[5]), int(x[6]), int(x[7])) for x in (ln.split() for ln in r.stdout.splitlines()) if x and x[0] == "ALN"}
+        assert got == want, (t, extra, sorted(got ^ want)[:4])
+        asked += sum(int(x) for x in re.findall(r"current alignment: (\d+),", r.stderr))
+        differs += sum(int(x) for x in re.findall(r"own current alignment would: (\d+)", r.stderr))
+    assert asked > 5000 and differs >= 5, (asked, differs)

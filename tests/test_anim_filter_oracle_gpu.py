@@ -97,3 +97,79 @@ def test_rearranged_pairs_filtered_tuple_and_kept_flags_equal_the_independent_or
         dropped += d
         with_drops += d > 0
     assert dropped > 80 and with_drops >= 45, (dropped, with_drops)
+
+
+def test_chain_dp_beyond_the_64_entry_window_equals_oracle_on_tandem_repeats(tmp_path):
+    """DESIGN §4's former deviation (2), directed (CPU twin: tests/test_anim_filter_oracle_cpu.py): tandem repeats under --maxmatch give
+    mgaps clusters of hundreds of overlapping matches whose best predecessors lie more than 64 entries back in query order.  The
+    wave form of the chain DP (pga_cluster.inc, extract_chains: a 64-entry register window) now scans the entries outside the window
+    whenever one of them could matter; every record must equal the oracle's (full scan, as mgaps) — 25 of the first 60 pairs of this
+    generator did not in round 4."""
+    from pyani_amd.engine import Engine
+    from tests.fuzz_genomes import write_fasta
+    from tests.stress_genomes import make_tandem_pair
+    from tests.test_anim_filter_oracle_cpu import oracle_records
+    from tests.test_anim_multirecord_gpu import _oracle
+    exe = _oracle()
+    trials = []
+    for t in range(48):
+        rng = random.Random(7000001 + t)
+        ref, qry = make_tandem_pair(rng)
+        pa, pb = tmp_path / f"tr{t}.fna", tmp_path / f"tq{t}.fna"
+        write_fasta(pa, "r", [ref])
+        write_fasta(pb, "q", [qry])
+        trials.append((pa, pb))
+    with Engine(0) as eng:
+        ids = [(eng.add_fasta(pa)[0], eng.add_fasta(pb)[0]) for pa, pb in trials]
+        q = [i[0] for i in ids] + [i[1] for i in ids]
+        s = [i[1] for i in ids] + [i[0] for i in ids]
+        off, recs, _, _ = eng.anim_alignments_batch(q, s, maxmatch=True)
+    n = 0
+    for j in range(2 * len(trials)):
+        pa, pb = trials[j % len(trials)] if j < len(trials) else trials[j % len(trials)][::-1]
+        want = {r[2:] for r in oracle_records(exe, pa, pb, ["--maxmatch"])}
+        got = {(int(r["rs"]), int(r["re"]), int(r["qs"]), int(r["qe"]), int(r["errors"])) for r in recs[int(off[j]):int(off[j + 1])]}
+        assert got == want, (j, sorted(got ^ want)[:4])
+        n += len(want)
+    assert n >= 96
+
+
+def test_two_strand_walk_equals_oracle_where_a_walk_per_strand_would_not(tmp_path):
+    """DESIGN §4's former deviation (1), directed (CPU twin: tests/test_anim_filter_oracle_cpu.py, which also proves that the
+    inputs make the two rules differ): tandem arrays that match on both strands, --maxmatch and --mum, 1 - 2 records per genome.
+    The walk kernel runs the two strands of a pair as the two waves of a workgroup that consult each other (pga_postnuc.inc,
+    PnWavePrim / pgn::PnPairSync); every record must equal the oracle's, which walks both strands in one list as MUMmer does.  Also
+    the canonical order of clusters that start on the same reference base (pga::chain_before) and mgaps' (query start, reference
+    start) match order under --maxmatch: 34 of the first 120 pairs of this generator differed from the oracle before round 5."""
+    from pyani_amd import anim
+    from pyani_amd.engine import Engine
+    from tests.fuzz_genomes import write_fasta
+    from tests.stress_genomes import TWO_STRAND_TRIALS, make_two_strand_repeat_pair
+    from tests.test_anim_filter_oracle_cpu import oracle_records
+    from tests.test_anim_multirecord_gpu import _oracle
+    exe = _oracle()
+    trials = []
+    for t in list(range(0, 40)) + TWO_STRAND_TRIALS:
+        rng = random.Random(13000003 + t)
+        ref, qry = make_two_strand_repeat_pair(rng)
+        pa, pb = tmp_path / f"pr{t}.fna", tmp_path / f"pq{t}.fna"
+        write_fasta(pa, f"r{t}_", ref)
+        write_fasta(pb, f"q{t}_", qry)
+        trials.append((pa, pb, t % 4 != 0))
+    n = 0
+    with Engine(0) as eng:
+        ids = [(eng.add_fasta(pa)[0], eng.add_fasta(pb)[0]) for pa, pb, _ in trials]
+        for mm in (True, False):
+            sel = [k for k, tr in enumerate(trials) if tr[2] == mm]
+            q = [ids[k][0] for k in sel] + [ids[k][1] for k in sel]
+            s = [ids[k][1] for k in sel] + [ids[k][0] for k in sel]
+            off, recs, _, _ = eng.anim_alignments_batch(q, s, maxmatch=mm)
+            for j, k in enumerate(sel + sel):
+                pa, pb = trials[k][:2] if j < len(sel) else trials[k][:2][::-1]
+                na, nb = [x[0] for x in anim.fasta_records(pa)], [x[0] for x in anim.fasta_records(pb)]
+                want = set(oracle_records(exe, pa, pb, ["--maxmatch"] if mm else []))
+                got = {(na[int(r["ref_rec"])], nb[int(r["qry_rec"])], int(r["rs"]), int(r["re"]), int(r["qs"]), int(r["qe"]), int(r["errors"]))
+                       for r in recs[int(off[j]):int(off[j + 1])]}
+                assert got == want, (mm, k, j < len(sel), sorted(got ^ want)[:4])
+                n += len(want)
+    assert n > 3000

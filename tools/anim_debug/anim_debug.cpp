@@ -9,6 +9,7 @@
 #include <cstring>
 #include <fstream>
 #include <string>
+#include <thread>
 #include <vector>
 #include "pg_anim_core.h"
 #include "pg_nucmer_core.h"
@@ -82,18 +83,24 @@ int main(int argc, char** argv) {
   const SeqView R = G.view();
   std::vector<Aln> alns;
   std::vector<int32_t> a_rrec, a_qrec;
+  // per strand: what seeding and clustering leave for the walk, and what the walk leaves for the output
+  struct StrandState {
+    std::vector<Chain> chains; std::vector<Match> cm; std::vector<int32_t> co; int n = 0, n_chains = 0, n_cm = 0;
+    std::vector<pgn::PnTurn> tlog; std::vector<int32_t> born;
+    std::vector<Aln> alns; std::vector<int32_t> a_rrec, a_qrec; std::vector<std::vector<int64_t>> deltas; std::vector<int32_t> visit; long cells = 0;
+  } ST[2];
+  const int nq = (int)H.rec_start.size() - 1;
   for (int strand = 0; strand < 2; ++strand) {
     StrandView Q{H.view(), strand};
     std::vector<Match> mem;
     find_mems(G, Q, strand, mem);
-    const int nq = (int)H.rec_start.size() - 1;
     int n = (int)mem.size();
     bool maxmatch = false;
     for (int i = 3; i < argc; ++i) if (!strcmp(argv[i], "--maxmatch")) maxmatch = true;
     if (!maxmatch)
       n = mum_filter(mem.data(), n, strand, [&](int32_t q) { return record_of(H.rec_start.data(), nq, strand ? (int32_t)(H.len - 1 - q) : q); });
     else
-      std::sort(mem.begin(), mem.end(), [](const Match& a, const Match& b) { return a.q != b.q ? a.q < b.q : (a.len != b.len ? a.len > b.len : a.r < b.r); });
+      std::sort(mem.begin(), mem.end(), [](const Match& a, const Match& b) { return a.q != b.q ? a.q < b.q : a.r < b.r; });      // mgaps' By_Start2: query start, then reference start
     mem.resize(n);
     std::vector<int32_t> rrec(n), qrec(n), parent(n), score(n), from(n), adj(n), order(n);
     for (int i = 0; i < n; ++i) {
@@ -101,16 +108,38 @@ int main(int argc, char** argv) {
       const int32_t qf = strand ? (int32_t)(H.len - 1 - mem[i].q) : mem[i].q;
       qrec[i] = record_of(H.rec_start.data(), nq, qf);
     }
-    std::vector<Chain> chains(n + 1);
-    std::vector<Match> cm(n + 1);
-    int n_chains = 0, n_cm = 0;
+    StrandState& T = ST[strand];
+    T.n = n;
+    T.chains.resize(n + 1); T.cm.resize(n + 1);
+    std::vector<Chain>& chains = T.chains;
+    std::vector<Match>& cm = T.cm;
+    int& n_chains = T.n_chains; int& n_cm = T.n_cm;
     mgaps_strand(mem.data(), n, strand, rrec.data(), qrec.data(), parent.data(), score.data(), from.data(), adj.data(),
                  order.data(), chains.data(), n_chains, (int)chains.size(), cm.data(), n_cm, (int)cm.size());
     n_chains = split_chains_by_ref_record(chains.data(), n_chains, cm.data(), [&](int32_t r) { return record_of(G.rec_start.data(), (int)G.rec_start.size() - 1, r); });
     // order chains by first-match ref start; pick forward targets
-    std::vector<int32_t> co(n_chains);
+    std::vector<int32_t>& co = T.co;
+    co.resize(n_chains);
     for (int i = 0; i < n_chains; ++i) co[i] = i;
     std::sort(co.begin(), co.end(), [&](int a, int b) { return chain_before(chains.data(), cm.data(), a, b); });
+    T.tlog.resize(n_chains + 1); T.born.resize(n_chains + 1);
+  }
+  // the two strands' walks side by side (pgn::PnPairSync: MUMmer walks the clusters of both strands of a record pair in ONE list;
+  // the walks consult each other where that matters), one thread each
+  pgn::PnHostShared pair_shared;
+  auto walk_strand = [&](int strand) {
+    StrandState& T = ST[strand];
+    StrandView Q{H.view(), strand};
+    std::vector<Chain>& chains = T.chains;
+    std::vector<Match>& cm = T.cm;
+    std::vector<int32_t>& co = T.co;
+    const int n = T.n, n_chains = T.n_chains, n_cm = T.n_cm;
+    std::vector<Aln>& alns = T.alns;
+    std::vector<int32_t>&a_rrec = T.a_rrec, &a_qrec = T.a_qrec;
+    std::vector<std::vector<int64_t>>& deltas_all = T.deltas;
+    std::vector<int32_t>& visit_all = T.visit;
+    long& exact_cells = T.cells;
+    pgn::PnPairSync<pgn::PnHostPrim> sync{pgn::PnHostPrim{&pair_shared, strand}, T.tlog.data(), ST[1 - strand].tlog.data(), T.born.data()};
     {
       const int cap = 1 << 15;
       std::vector<pgn::Cell> d0(cap), d1(cap), d2(cap);
@@ -139,7 +168,7 @@ int main(int argc, char** argv) {
         std::vector<uint8_t> fused2(n_chains + 1);
         std::vector<pgn::PnAln> al2(n_chains + 1);
         pgn::PnRehearsal<pgn::ScalarEngine<SeqView, StrandView>> dry{eng, bwd.data()};
-        pgn::postnuc_unit(dry, chains.data(), cm.data(), co.data(), n_chains, bounds_of, fused2.data(), al2.data(), (int)al2.size());
+        { pgn::PnNoSync alone; pgn::postnuc_unit(dry, chains.data(), cm.data(), co.data(), n_chains, bounds_of, fused2.data(), al2.data(), (int)al2.size(), alone, strand); }
         long predicted = 0;
         for (auto& b : bwd) if (b.state == 1) {
           int32_t a = b.tA, q = b.tB, err = 0;
@@ -159,14 +188,14 @@ int main(int argc, char** argv) {
                                              band_w >= 0 ? (long long)(N > M ? N - M : M - N) + 2ll * band_w + 6 : (long long)N + M + 6);
           else fprintf(stderr, "FALLBACK search N %d M %d\n", N, M);
         };
-      const int na = getenv("ANIM_DIAGWAVE") ? pgn::postnuc_unit(weng, chains.data(), cm.data(), co.data(), n_chains, bounds_of, fused.data(), al.data(), (int)al.size())
-                   : getenv("ANIM_DIAG") ? pgn::postnuc_unit(deng, chains.data(), cm.data(), co.data(), n_chains, bounds_of, fused.data(), al.data(), (int)al.size())
+      const int na = getenv("ANIM_DIAGWAVE") ? pgn::postnuc_unit(weng, chains.data(), cm.data(), co.data(), n_chains, bounds_of, fused.data(), al.data(), (int)al.size(), sync, strand)
+                   : getenv("ANIM_DIAG") ? pgn::postnuc_unit(deng, chains.data(), cm.data(), co.data(), n_chains, bounds_of, fused.data(), al.data(), (int)al.size(), sync, strand)
                                          : pgn::postnuc_unit(eng, chains.data(), cm.data(), co.data(), n_chains,
           [&](int c, int32_t& rl, int32_t& rh, int32_t& ql, int32_t& qh) {
             rl = G.rec_start[chains[c].rrec]; rh = G.rec_start[chains[c].rrec + 1] - 1;
             ql = H.rec_start[chains[c].qrec]; qh = H.rec_start[chains[c].qrec + 1] - 1;
             if (strand) { const int32_t a = (int32_t)H.len - qh, b = (int32_t)H.len - ql; ql = a; qh = b; } },
-          fused.data(), al.data(), (int)al.size());
+          fused.data(), al.data(), (int)al.size(), sync, strand);
       if (getenv("ANIM_DIAGWAVE"))
         fprintf(stderr, "diag-wave engines: calls %ld / %ld / %ld / %ld / %ld / %ld / %ld / %ld (128 / 256 / 384 / 512 / 768 / 1024 / 1536 / 2048 diagonals), window moves %ld, did not fit %ld, "
                         "fell back to the scalar engine %ld, cells %ld + %ld\n",
@@ -174,12 +203,12 @@ int main(int argc, char** argv) {
                 weng.e2.moves + weng.e4.moves + weng.e6.moves + weng.e8.moves + weng.e12.moves + weng.e16.moves + weng.e24.moves + weng.e32.moves,
                 weng.e2.fails + weng.e4.fails + weng.e6.fails + weng.e8.fails + weng.e12.fails + weng.e16.fails + weng.e24.fails + weng.e32.fails, weng.fallbacks,
                 weng.e2.cells + weng.e4.cells + weng.e6.cells + weng.e8.cells + weng.e12.cells + weng.e16.cells + weng.e24.cells + weng.e32.cells, weng.slow.cells);
-      if (na < 0 || eng.overflow || deng.slow.overflow || weng.slow.overflow) { fprintf(stderr, "postnuc statement: capacity exceeded\n"); return 3; }
+      if (na < 0 || eng.overflow || deng.slow.overflow || weng.slow.overflow) { fprintf(stderr, "postnuc statement: capacity exceeded\n"); exit(3); }
       exact_cells += eng.cells + deng.fast.cells + deng.slow.cells;
       if (!bwd.empty()) fprintf(stderr, "the walk still ran %ld itself (%ld cells)\n", eng.searches, eng.search_cells);
       if (want_delta) {
         // the paths of the walk's search / forced pieces, by the scalar engine with its traceback store (on the GPU: anim_trace_kernel)
-        if (eng.n_pieces > eng.piece_cap) { fprintf(stderr, "piece list too small\n"); return 3; }
+        if (eng.n_pieces > eng.piece_cap) { fprintf(stderr, "piece list too small\n"); exit(3); }
         eng.pieces = nullptr;
         std::vector<std::vector<uint32_t>> rle((size_t)eng.n_pieces);
         for (int p = 0; p < eng.n_pieces; ++p) {
@@ -194,17 +223,17 @@ int main(int argc, char** argv) {
           int32_t a = P.kind == pgn::PIECE_FORCED ? P.A1 : P.tA, b = P.kind == pgn::PIECE_FORCED ? P.B1 : P.tB, err = 0;
           eng.align(P.A0, a, P.B0, b, P.m_o, err);
           eng.trace = nullptr;
-          if (tr.overflow || eng.overflow || a != P.A1 || b != P.B1) { fprintf(stderr, "trace: piece %d does not repeat (%d %d vs %d %d, overflow %d)\n", p, a, b, P.A1, P.B1, tr.overflow); return 3; }
+          if (tr.overflow || eng.overflow || a != P.A1 || b != P.B1) { fprintf(stderr, "trace: piece %d does not repeat (%d %d vs %d %d, overflow %d)\n", p, a, b, P.A1, P.B1, tr.overflow); exit(3); }
           rle[p].resize((size_t)N + M + 4);
           const int32_t cnt = pgn::pn_trace_back(tr, rle[p].data(), (int32_t)rle[p].size());
-          if (cnt < 0) { fprintf(stderr, "trace: broken path at piece %d\n", p); return 3; }
+          if (cnt < 0) { fprintf(stderr, "trace: broken path at piece %d\n", p); exit(3); }
           rle[p].resize((size_t)cnt);
         }
         std::vector<std::vector<int64_t>> deltas;
         std::vector<int32_t> visit;
         std::string why;
         if (!pgt::unit_deltas(pieces.data(), eng.n_pieces, al.data(), na, [&](int32_t p, int32_t& cnt) { cnt = (int32_t)rle[p].size(); return rle[p].data(); }, deltas, visit, &why)) {
-          fprintf(stderr, "trace: %s\n", why.c_str()); return 3; }
+          fprintf(stderr, "trace: %s\n", why.c_str()); exit(3); }
         for (auto& d : deltas) deltas_all.push_back(std::move(d));
         for (int i = 0; i < na; ++i) visit_all.push_back(visit[(size_t)i]);
       }
@@ -217,9 +246,24 @@ int main(int argc, char** argv) {
         a_qrec.push_back(record_of(H.rec_start.data(), nq, a.qs));
         alns.push_back(a);
       }
-      fprintf(stderr, "strand %d: MEMs->MUMs %d, chains %d, alignments %d (postnuc statement, %ld cells so far)\n", strand, n, n_chains, na, exact_cells);
+      fprintf(stderr, "strand %d: MEMs->MUMs %d, chains %d, alignments %d (postnuc statement, %ld cells); shadow tests that asked for the record pair's current alignment: %ld, answered otherwise than the strand's own current alignment would: %ld\n", strand, n, n_chains, na, exact_cells, sync.asked, sync.differs);
     }
+  };
+  {
+    std::thread other(walk_strand, 1);
+    walk_strand(0);
+    other.join();
   }
+  for (int strand = 0; strand < 2; ++strand) {
+    StrandState& T = ST[strand];
+    alns.insert(alns.end(), T.alns.begin(), T.alns.end());
+    a_rrec.insert(a_rrec.end(), T.a_rrec.begin(), T.a_rrec.end());
+    a_qrec.insert(a_qrec.end(), T.a_qrec.begin(), T.a_qrec.end());
+    for (auto& d : T.deltas) deltas_all.push_back(std::move(d));
+    visit_all.insert(visit_all.end(), T.visit.begin(), T.visit.end());
+    exact_cells += T.cells;
+  }
+  if (pga::g_chain_full_scans) fprintf(stderr, "chain DP: %ld scans beyond the 64-entry window, %ld of them changed the predecessor\n", pga::g_chain_full_scans, pga::g_chain_full_wins);
   const int n = (int)alns.size();
   std::vector<int32_t> idx(n + 1), from(n + 1);
   std::vector<double> sc(n + 1);
