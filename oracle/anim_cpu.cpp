@@ -200,8 +200,8 @@ Result run_pair(const Genome& G, const Genome& H, int filter_1to1, int maxmatch,
   std::vector<double> sc(n + 1);
   if (!filter_1to1) for (auto& a : alns) a.keep = 3;
   else {
-    lis_filter(alns.data(), n, 0, a_rrec.data(), idx.data(), sc.data(), from.data());
-    lis_filter(alns.data(), n, 1, a_qrec.data(), idx.data(), sc.data(), from.data());
+    lis_filter(alns.data(), n, 0, a_rrec.data(), a_qrec.data(), idx.data(), sc.data(), from.data());
+    lis_filter(alns.data(), n, 1, a_qrec.data(), a_rrec.data(), idx.data(), sc.data(), from.data());
   }
   const PairResult pr = reduce_pair(alns.data(), n, a_rrec.data(), a_qrec.data(), idx.data());
   Result out{};

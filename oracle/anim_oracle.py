@@ -97,6 +97,14 @@ def parse_delta_records(alns) -> Tuple[int, int, float, int]:
     return raln, qaln, identity, sim_error
 
 
+def _ordinal(seq_id):
+    """a sequence's place for tie-breaking: the number at the end of its id when there is one (the tests name records r0, r1, ... in
+    file order; the goldens store ordinals), else the id itself"""
+    import re
+    m = re.search(r"(\d+)$", str(seq_id))
+    return (0, int(m.group(1)), "") if m else (1, 0, str(seq_id))
+
+
 def delta_filter_1to1(alns) -> List[bool]:
     """`delta-filter -1` (what pyani's delta_filter_wrapper.py:80-90 runs on every nucmer output): MUMmer 3.23's published 1-to-1
     mapping — an alignment survives iff it lies on the best weighted chain of its REFERENCE sequence and on the best weighted
@@ -115,15 +123,20 @@ def delta_filter_1to1(alns) -> List[bool]:
             idy = 1.0 - 2.0 * a.errors / tot if tot > 0 else 0.0
             length = hi - lo + 1
             own = int(length * (idy * idy))
-            groups[a.ref_id if side == 0 else a.qry_id].append((lo, -own, i, hi, length, idy, own))
+            # equal start and equal score (two copies of a duplicated region): delta-filter's std::sort leaves them in an order MUMmer
+            # does not define — here by the other sequence (its ordinal among the file's sequences: first appearance), the start there,
+            # the strand, and only then the input order: a function of the alignments, not of how they were listed
+            other = a.qry_id if side == 0 else a.ref_id
+            o_lo = min(a.qs, a.qe) if side == 0 else min(a.rs, a.re)
+            groups[a.ref_id if side == 0 else a.qry_id].append((lo, -own, i, hi, length, idy, own, (_ordinal(other), o_lo, 1 if a.qs > a.qe else 0)))
         for items in groups.values():
-            items.sort(key=lambda t: (t[0], t[1], t[2]))
+            items.sort(key=lambda t: (t[0], t[1], t[7], t[2]))
             score, frm = [], []
             best = -1
-            for k, (lo, _, i, hi, length, idy, own) in enumerate(items):
+            for k, (lo, _, i, hi, length, idy, own, _) in enumerate(items):
                 sc, fr = own, -1
                 for kk in range(k):
-                    lo_j, _, _, hi_j, len_j, _, _ = items[kk]
+                    lo_j, _, _, hi_j, len_j, _, _, _ = items[kk]
                     olap = max(0, hi_j - lo + 1)
                     if olap > 0 and (olap / length * 100.0 > 100.0 or olap / len_j * 100.0 > 100.0):
                         continue

@@ -315,18 +315,24 @@ PG_HD int64_t lis_gain(int64_t len_i, int64_t len_j, int64_t olap, double idy_i,
   allowed = !(olap > 0 && ((double)olap / (double)len_i * 100.0 > LIS_MAX_OLAP || (double)olap / (double)len_j * 100.0 > LIS_MAX_OLAP));
   return (int64_t)((double)(len_i - olap) * (idy_i * idy_i));
 }
-PG_HD void lis_filter(Aln* a, int n, int side, const int32_t* grp, int32_t* idx, double* sc_, int32_t* from) {
+PG_HD void lis_filter(Aln* a, int n, int side, const int32_t* grp, const int32_t* ogrp, int32_t* idx, double* sc_, int32_t* from) {
   int64_t* sc = reinterpret_cast<int64_t*>(sc_);
   auto lo = [&](int i) { return side == 0 ? a[i].rs : a[i].qs; };   // a[] carries FORWARD query coordinates here
   auto hi = [&](int i) { return side == 0 ? a[i].re : a[i].qe; };
+  auto olo = [&](int i) { return side == 0 ? a[i].qs : a[i].rs; };   // the start on the OTHER sequence (ogrp: its record)
   bool ok;
   for (int i = 0; i < n; ++i) { idx[i] = i; sc[i] = lis_gain(hi(i) - lo(i), 1, 0, lis_idy(a[i]), ok); }   // own scores
-  // by start; equal starts: the higher-scoring alignment first (then input order) — with the fixtures' equal-start
-  // pairs this is the order that reproduces delta-filter's choices
+  // by start; equal starts: the higher-scoring alignment first — with the fixtures' equal-start pairs this is the order that
+  // reproduces delta-filter's choices.  Equal start AND equal score (two copies of a duplicated region): delta-filter's std::sort
+  // leaves them in an order MUMmer does not define; here, so that the result does not depend on how the alignments were listed
+  // (by strand on the GPU, by record pair in a .delta file): by the other sequence's record, then the start there, then strand
   heapsort(idx, n, [&](int x, int y) {
     if (grp[x] != grp[y]) return grp[x] < grp[y];
     if (lo(x) != lo(y)) return lo(x) < lo(y);
     if (sc[x] != sc[y]) return sc[x] > sc[y];
+    if (ogrp[x] != ogrp[y]) return ogrp[x] < ogrp[y];
+    if (olo(x) != olo(y)) return olo(x) < olo(y);
+    if (a[x].strand != a[y].strand) return a[x].strand < a[y].strand;
     return x < y; });
   int g0 = 0;
   while (g0 < n) {

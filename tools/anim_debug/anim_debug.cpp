@@ -270,7 +270,7 @@ int main(int argc, char** argv) {
   bool nofilter = false;
   for (int i = 3; i < argc; ++i) if (!strcmp(argv[i], "--nofilter")) nofilter = true;
   if (nofilter) for (auto& a : alns) a.keep = 3;
-  else { lis_filter(alns.data(), n, 0, a_rrec.data(), idx.data(), sc.data(), from.data()); lis_filter(alns.data(), n, 1, a_qrec.data(), idx.data(), sc.data(), from.data()); }
+  else { lis_filter(alns.data(), n, 0, a_rrec.data(), a_qrec.data(), idx.data(), sc.data(), from.data()); lis_filter(alns.data(), n, 1, a_qrec.data(), a_rrec.data(), idx.data(), sc.data(), from.data()); }
   PairResult pr = reduce_pair(alns.data(), n, a_rrec.data(), a_qrec.data(), idx.data());
   printf("%lld %lld %.16g %lld %lld\n", (long long)pr.ref_aln_len, (long long)pr.qry_aln_len, (double)pr.weighted / (double)pr.aligned,
          (long long)pr.sim_errors, (long long)pr.n_alignments);

@@ -16,8 +16,8 @@ int main() {
   }
   const int n = (int)a.size();
   std::vector<int32_t> idx(n + 1), from(n + 1); std::vector<double> sc(n + 1);
-  lis_filter(a.data(), n, 0, rg.data(), idx.data(), sc.data(), from.data());
-  lis_filter(a.data(), n, 1, qg.data(), idx.data(), sc.data(), from.data());
+  lis_filter(a.data(), n, 0, rg.data(), qg.data(), idx.data(), sc.data(), from.data());
+  lis_filter(a.data(), n, 1, qg.data(), rg.data(), idx.data(), sc.data(), from.data());
   for (int i = 0; i < n; ++i) if (a[i].keep == 3) printf("%d %d %d %d %d\n", a[i].rs + 1, a[i].re, a[i].strand ? a[i].qe : a[i].qs + 1, a[i].strand ? a[i].qs + 1 : a[i].qe, a[i].errors);
   return 0;
 }
