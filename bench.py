@@ -536,7 +536,8 @@ def run_anim(args, rank, world, local, dist, torch):
             return float(((lens[pp[:, 0]] + 3) // 4 + (lens[pp[:, 1]] + 3) // 4 + 32).sum())
         per_tile = [{"tile": t_["tile"], "pairs": int(len(t_["pairs"])), "ms": round(t_["prof"][dom][0], 3),
                      "GBps": round(_alg(t_["pairs"]) / (t_["prof"][dom][0] * 1e-3) / 1e9, 2) if t_["prof"][dom][0] else None,
-                     "dp_cells": int(t_["cnt"][2]) + int(t_["cnt"][5]) + int(t_["cnt"][8]), "kernel_ms_sum": round(sum(v[0] for v in t_["prof"].values()), 1)}
+                     "dp_cells": int(t_["cnt"][2]) + int(t_["cnt"][5]) + int(t_["cnt"][8]), "kernel_ms_sum": round(sum(v[0] for v in t_["prof"].values()), 1),
+                     "stage_ms": {name_: round(v[0], 1) for name_, v in t_["prof"].items()}}
                     for t_ in tile_recs]
         # VALU-issue roofline of the extension stage (integer DP in registers: bytes are not its bound): DP cells per second against the
         # rate at which the chip can issue the vector instructions those cells cost.  MEASURED IN THIS RUN: cells, anti-diagonals and calls

@@ -266,7 +266,7 @@ PG_HD int32_t pn_turn_key(int32_t ref_start, int strand) { return 2 * ref_start 
 // PRIM: how the two walks reach each other's words — the host (two threads, std::atomic) and the GPU (two waves of a workgroup:
 // progress words in LDS, logs in global memory read past the vector L1) supply
 //   int32_t ld(const int32_t* p)      a load that sees the other walk's latest store        void st(int32_t* p, int32_t v)   its store
-//   void publish(int32_t n_log, int32_t key)   make this walk's log (n_log entries) and position visible, in that order
+//   void publish_log(int32_t n_log)   make this walk's log (its stores so far) visible and announce its length;   void publish_key(int32_t key)   its position (after the log)
 //   int32_t other_key() / other_nlog()         the other walk's position / log length (key first)         void pause()
 template <typename PRIM>
 struct PnPairSync {
@@ -276,7 +276,7 @@ struct PnPairSync {
   int32_t* born;               // per alignment of this unit: the key of the turn that pushed it
   int32_t n_log = 0, key = 0;
   long waits = 0, asked = 0, differs = 0;   // (development counters; differs: shadow tests that the unit's own current alignment would have answered otherwise)
-  PG_HD void begin_turn(int32_t k) { key = k; pushed_aln = -1; prim.publish(n_log, k); }
+  PG_HD void begin_turn(int32_t k) { key = k; pushed_aln = -1; prim.publish_key(k); }
   int32_t pushed_aln = -1;     // the alignment this turn pushed (its birth key is `key`: not read back through memory in the same turn)
   PG_HD void pushed(int aln) { prim.st(born + aln, key); pushed_aln = aln; }
   PG_HD void end_turn(int32_t rrec, int32_t qrec, int aln) {
@@ -284,8 +284,9 @@ struct PnPairSync {
     const int32_t b = aln == pushed_aln ? key : prim.ld(born + aln);      // (else: a merge target, born in an earlier turn — stored before that turn's publish)
     prim.st(&e->key, key); prim.st(&e->rrec, rrec); prim.st(&e->qrec, qrec); prim.st(&e->aln, aln); prim.st(&e->born, b);
     ++n_log;
+    prim.publish_log(n_log);      // (only turns that were not skipped pay for the store fence)
   }
-  PG_HD void finish() { prim.publish(n_log, PN_KEY_DONE); }
+  PG_HD void finish() { prim.publish_key(PN_KEY_DONE); }
   // isShadowedCluster's scan range for a cluster of synteny (rrec, qrec) at the current turn: the largest index of this unit's
   // alignment list the test may look at (-1: none).  n_al: alignments of this unit so far.
   PG_HD int visible(int32_t rrec, int32_t qrec, int n_al, int /* cura */) {
@@ -327,7 +328,8 @@ struct PnHostPrim {
   int me;
   int32_t ld(const int32_t* p) const { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
   void st(int32_t* p, int32_t v) const { __atomic_store_n(p, v, __ATOMIC_RELEASE); }
-  void publish(int32_t n_log, int32_t key) const { __atomic_store_n(&sh->nlog[me], n_log, __ATOMIC_RELEASE); __atomic_store_n(&sh->key[me], key, __ATOMIC_RELEASE); }
+  void publish_log(int32_t n_log) const { __atomic_store_n(&sh->nlog[me], n_log, __ATOMIC_RELEASE); }
+  void publish_key(int32_t key) const { __atomic_store_n(&sh->key[me], key, __ATOMIC_RELEASE); }
   int32_t other_key() const { return __atomic_load_n(&sh->key[1 - me], __ATOMIC_ACQUIRE); }
   int32_t other_nlog() const { return __atomic_load_n(&sh->nlog[1 - me], __ATOMIC_ACQUIRE); }
   void pause() const { std::this_thread::yield(); }

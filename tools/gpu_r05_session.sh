@@ -44,6 +44,22 @@ fetch|write)
 stats4)
   PYANI_PN_STATS=1 PYANI_ANIM_WORKERS=1 timeout -k 10 600 $B1 > $O/bench_c4_stats.log 2> $O/bench_c4_stats.err; echo "stats4 rc=$?"
   grep '^{' $O/bench_c4_stats.log | cut -c1-1500; grep "pn-stats" $O/bench_c4_stats.err | tail -16 ;;
+grid)    # one whole grid timed (10 steps), no CPU leg: the quick comparison with the driver's value
+  timeout -k 10 900 python bench.py --gpus 1 --steps 10 --warmup 2 --no-tetra --no-cpu-baseline --no-side-records > $O/bench_grid.log 2> $O/bench_grid.err; echo "grid rc=$?"
+  grep '^{' $O/bench_grid.log > $O/bench_grid.json; python - <<'PY'
+import json
+d = json.loads(open("gpurun_out/r05/bench_grid.json").read())
+r = d["roofline"]
+print("value", round(d["value"]), "pairs/s, ms/step", round(d["ms_per_step"], 1), "sha", d["config"]["results_sha1_full_grid"])
+print("one-worker stage sums over", r["tiles"], "tiles:", r["one_worker_step"]["stage_ms"])
+for t in r["per_tile"]:
+    print(t["tile"], t["kernel_ms_sum"], t["stage_ms"])
+v = r["valu_issue"]
+print("valu_issue", v and {k: v[k] for k in ("frac", "achieved", "cells", "extension_ms")})
+for k, x in (v or {}).get("per_kernel", {}).items():
+    print(" ", k, x)
+PY
+  ;;
 c4)
   timeout -k 10 900 python bench.py --gpus 1 --steps 4 --warmup 1 --no-tetra --no-cpu-baseline > $O/bench_c4.log 2> $O/bench_c4.err; echo "c4 rc=$?"
   grep '^{' $O/bench_c4.log > $O/bench_c4.json; cut -c1-2500 $O/bench_c4.json; tail -5 $O/bench_c4.err ;;
