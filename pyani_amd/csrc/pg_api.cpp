@@ -328,6 +328,7 @@ int pg_create(pg_ctx** out, int device) {
   for (int w = 1; w < pg_ctx::MAX_WORKERS; ++w)
     if (hipStreamCreateWithFlags(&ctx->stream_w[w], hipStreamNonBlocking) != hipSuccess) { delete ctx; return PG_E_HIP; }
   if (const char* g = pg_dev_env("PYANI_ANIM_BWD_AHEAD")) ctx->anim_bwd_ahead = atoi(g) != 0;
+  if (const char* g = pg_dev_env("PYANI_PN_WALK_OCC")) ctx->anim_walk_occ = atoi(g);
   if (const char* g = pg_dev_env("PYANI_PN_WINDOW_MAX")) ctx->anim_pn_window_max = atoi(g);   // development switches of the forced kernels (tests: same results)
   if (const char* g = pg_dev_env("PYANI_PN_GROUP_MAX")) ctx->anim_pn_group_max = atoi(g);
   if (const char* g = pg_dev_env("PYANI_ANIM_GAP_LANES")) ctx->anim_gap_lanes = atoi(g) != 0;   // development switch (tests: both forms, same results)

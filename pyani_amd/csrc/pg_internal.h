@@ -99,6 +99,7 @@ struct pg_ctx {
   int anim_pn_window_max = 2048;   // forced runs: the widest single-wave window (development: smaller values push runs on to the group kernel)
   int anim_pn_group_max = 8184;    // ... and the widest band the group of four waves takes (development: 0 = everything beyond one wave on the strips)
   int anim_gap_lanes = 1;      // postnuc: small match-to-match gaps on one lane each (0: all gaps on the wave engine; tests compare the two)
+  int anim_walk_occ = 2;       // waves per SIMD the walk / rehearsal kernels are compiled for (2: the compiler's 219 VGPRs; 4: capped at 128); PYANI_PN_WALK_OCC
   int anim_bwd_ahead = 1;      // backward searches ahead of the units' walks (pga_postnuc.inc); PYANI_ANIM_BWD_AHEAD=0 (development switch): inside them       // PG_EXTENDER_NUCMER (pg_anim_set_extender)
   int anim_workers = 2;
   uint32_t anim_batch_pairs = 131072;         // ordered pairs in flight (split over the two workers: 65536 per launch; every launch pays its slowest unit once)
