@@ -235,6 +235,26 @@ typedef struct {
 } pg_anib_row;
 int pg_anib_pair_rows(pg_ctx* ctx, int32_t qry_id, int32_t sbj_id, uint32_t fragsize, pg_anib_row* out, uint32_t cap, uint32_t* n_out);
 
+/* ---- sketch mode: an opt-in ESTIMATE in the shape of pyani's fastANI wrapper -------------------------
+ * Replaces the `fastANI -q <query> -r <ref> --fragLen 3000 -k 16 --minFraction 0.2` job of pyani/fastani.py:193-229
+ * (construct_fastani_cmdline) and the line parse_fastani_file reads back (fastani.py:231-270): ANI estimate, matching fragments,
+ * query fragments.  Definition (pyani_amd/csrc/pg_sketch_core.h): canonical 16-mers sampled 1 in `scale` by a hash (FracMinHash);
+ * the query's records cut into non-overlapping fragments of `frag_len` bases; per fragment the share C of its sampled k-mers that
+ * occur anywhere in the reference, identity = C^(1/16); a fragment matches with >= 2 hits and identity >= 0.80; ani = mean identity
+ * of the matching fragments (a FRACTION, as ComparisonResult.ani), status PG_SKETCH_NO_RESULT when fewer than min_fraction of
+ * the fragments match (fastANI writes no line then).  Sketches are built on first use and cached per genome.  An estimate with
+ * its own columns: nothing of it enters the exact ANIm / ANIb results.  Limits: k = 16 only; <= 24 576 fragments per query. */
+typedef struct {
+  double ani;          /* mean identity estimate of the matching fragments, 0 ... 1 (0 when status != 0) */
+  int32_t matches;     /* fragments with an identity estimate >= 0.80 */
+  int32_t fragments;   /* fragments of the query genome */
+  int32_t status;      /* 0 = ok, PG_SKETCH_NO_RESULT */
+  int32_t reserved;
+} pg_sketch_result;
+#define PG_SKETCH_NO_RESULT 1
+int pg_sketch_pairs(pg_ctx* ctx, const int32_t* qry_ids, const int32_t* ref_ids, uint64_t n_pairs, int32_t frag_len, int32_t scale,
+                    double min_fraction, pg_sketch_result* out);
+
 /* ---- measurement ---------------------------------------------------------------------------------------- */
 /* When enabled, every kernel launch is bracketed by HIP events on the context's stream. */
 int pg_profile_enable(pg_ctx* ctx, int on);
@@ -259,7 +279,8 @@ int pg_profile_reset(pg_ctx* ctx);
 #define PG_K_ANIB_FRAG 12    /* anib_frag_kernel: anchors + X-drop extensions, one wave per (pair, fragment) */
 #define PG_K_ANIM_FWD 13     /* anim_postnuc_fwd_kernel: the forward extension off every cluster, ahead of the units' walks */
 #define PG_K_ANIM_BWD 14     /* anim_postnuc_rehearse_kernel + anim_postnuc_bwd_kernel: the walks rehearsed, their backward searches run ahead */
-#define PG_K__COUNT 15
+#define PG_K_SKETCH_PAIRS 15 /* sketch_pairs_kernel: the sketch mode's containment pass (pg_sketch_pairs) */
+#define PG_K__COUNT 16
 /* total milliseconds and number of launches of kernel `which` since the last reset (synchronises). */
 int pg_profile_get(pg_ctx* ctx, int which, double* total_ms_out, uint64_t* launches_out);
 const char* pg_kernel_name(int which);

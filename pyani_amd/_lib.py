@@ -11,7 +11,9 @@ K_TETRA_COUNT, K_TETRA_FINALIZE, K_TETRA_STATS, K_TETRA_PAIRS = 0, 1, 2, 3
 (K_ANIM_SEED, K_ANIM_HIT, K_ANIM_CLUSTER, K_ANIM_GAPS, K_ANIM_EXTLANE, K_ANIM_EXTEND, K_ANIM_FINISH) = 4, 5, 6, 7, 8, 9, 10
 K_ANIB_BUCKET, K_ANIB_FRAG = 11, 12
 K_ANIM_FWD, K_ANIM_BWD = 13, 14
-K_COUNT = 15
+K_SKETCH_PAIRS = 15
+K_COUNT = 16
+PG_SKETCH_NO_RESULT = 1
 
 # every symbol declared in include/pyani_gpu.h: (name, restype, argtypes)
 _vp, _i32, _u32, _u64, _int = ctypes.c_void_p, ctypes.c_int32, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_int
@@ -49,6 +51,7 @@ SIGNATURES = {
     "pg_anib_reduce": (_int, [_vp, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pg_anib_pairs": (_int, [_vp, _vp, _vp, _u64, _u32, _vp]),
     "pg_anib_pair_rows": (_int, [_vp, _i32, _i32, _u32, _vp, _u32, _P(_u32)]),
+    "pg_sketch_pairs": (_int, [_vp, _vp, _vp, _u64, _i32, _i32, ctypes.c_double, _vp]),
     "pg_profile_enable": (_int, [_vp, _int]),
     "pg_profile_config": (_int, [_vp, _u32, _u32]),
     "pg_profile_reset": (_int, [_vp]),

@@ -886,8 +886,7 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
     }
     if (!A->pn_cursor && (rc = regrow(ctx, A->pn_cursor, 24))) return rc;
     const uint32_t pn_waves = (uint32_t)ctx->num_cu * 12u;   // forced kernels with the LDS store: 12 KiB of LDS each: 12 per CU
-    const bool walk_occ4 = ctx->anim_walk_occ >= 4;          // the walk / rehearsal kernels capped at 128 VGPRs: four waves per SIMD
-    const uint32_t pn_walk_waves = (uint32_t)ctx->num_cu * (walk_occ4 ? 12u : 8u);   // (one persistent wave per resident slot)
+    const uint32_t pn_walk_waves = (uint32_t)ctx->num_cu * 8u;   // the walk / rehearsal kernels: 219 / 173 VGPRs, two waves per SIMD — one persistent wave per resident slot
     const uint32_t pn_waves_pre = (uint32_t)ctx->num_cu * 32u;   // gap / forward / backward pre-passes and the narrow forced kernel: no LDS, diagonal engine only, <= 64 registers: 8 per SIMD
     const uint32_t pn_waves_scr = ctx->anim_gap_lanes ? (pn_waves > pn_walk_waves ? pn_waves : pn_walk_waves) : pn_waves_pre;      // (only the walks, the wide forced kernel and the all-gaps form of the gap kernel use the global scratch)
     if (pn_waves_scr > A->pn_waves) { if ((rc = regrow(ctx, A->pn_gscratch, (size_t)pn_waves_scr * PN_GLOBAL_WORDS))) return rc; A->pn_waves = pn_waves_scr; }
@@ -932,7 +931,7 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
       pg_prof_begin(ctx, PG_K_ANIM_BWD);
       if (bwd_ahead) {     // the walks rehearsed without their backward searches, then the searches they predict, one wave each
         PG_HIP(ctx, hipMemsetAsync(A->pn_bwd, 0, (size_t)M * sizeof(pgn::PnBwd), cur_stream(ctx)));
-        hipLaunchKernelGGL(walk_occ4 ? anim_postnuc_rehearse_occ4_kernel : anim_postnuc_rehearse_kernel, dim3(pn_walk_waves < n_units ? pn_walk_waves : n_units), dim3(64), 0, cur_stream(ctx), A->refs_d,
+        hipLaunchKernelGGL(anim_postnuc_rehearse_kernel, dim3(pn_walk_waves < n_units ? pn_walk_waves : n_units), dim3(64), 0, cur_stream(ctx), A->refs_d,
                            A->units_d, n_units, O, A->pn_cursor + 9, A->pn, A->pn_fused, A->pn_gscratch, A->pn_gaps, A->pn_fwd, A->pn_order, A->pn_bwd);
         hipLaunchKernelGGL(anim_postnuc_bwd_kernel, dim3(pn_waves_pre), dim3(64), 0, cur_stream(ctx), A->refs_d, A->units_d, O, A->wl_d, (uint32_t)n_wl,
                            A->pn_cursor + 10, A->pn_bwd, A->pn_gscratch);
@@ -941,7 +940,7 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
     }
     pg_prof_begin(ctx, PG_K_ANIM_EXTEND);
     if (n_wl)
-      hipLaunchKernelGGL(walk_occ4 ? anim_postnuc_occ4_kernel : anim_postnuc_kernel, dim3(pn_walk_waves / 2 < n_pairs ? pn_walk_waves / 2 : n_pairs), dim3(128), 0, cur_stream(ctx), A->refs_d, A->units_d,
+      hipLaunchKernelGGL(anim_postnuc_kernel, dim3(pn_walk_waves / 2 < n_pairs ? pn_walk_waves / 2 : n_pairs), dim3(128), 0, cur_stream(ctx), A->refs_d, A->units_d,
                          n_pairs, O, A->pn_cursor, A->pn, A->pn_fused, A->pn_n, A->pn_gscratch, A->pn_reqs, A->pn_cursor + 1, (uint32_t)req_cap,
                          trace ? nullptr : A->pn_gaps, trace ? nullptr : A->pn_fwd, A->pn_porder, trace ? A->pn_pieces : nullptr, A->pn_npieces, A->choff_d,
                          bwd_ahead && !trace ? A->pn_bwd : nullptr, A->pn_tlog, A->pn_born);

@@ -20,7 +20,8 @@ static const char* const KERNEL_NAMES[PG_K__COUNT] = {"tetra_count_kernel", "tet
                                                       "anim_cluster_wave_kernel",
                                                       "anim_postnuc_gap_kernels", "anim_postnuc_forced_kernels",
                                                       "anim_postnuc_kernel", "anim_finish_kernel", "anib_bucket_kernel",
-                                                      "anib_frag_kernel", "anim_postnuc_fwd_kernel", "anim_postnuc_rehearse_kernel+anim_postnuc_bwd_kernel"};
+                                                      "anib_frag_kernel", "anim_postnuc_fwd_kernel", "anim_postnuc_rehearse_kernel+anim_postnuc_bwd_kernel",
+                                                      "sketch_pairs_kernel"};
 
 // ---- profiling ----------------------------------------------------------------------------------------------
 thread_local hipStream_t pg_tls_stream = nullptr;
@@ -328,7 +329,6 @@ int pg_create(pg_ctx** out, int device) {
   for (int w = 1; w < pg_ctx::MAX_WORKERS; ++w)
     if (hipStreamCreateWithFlags(&ctx->stream_w[w], hipStreamNonBlocking) != hipSuccess) { delete ctx; return PG_E_HIP; }
   if (const char* g = pg_dev_env("PYANI_ANIM_BWD_AHEAD")) ctx->anim_bwd_ahead = atoi(g) != 0;
-  if (const char* g = pg_dev_env("PYANI_PN_WALK_OCC")) ctx->anim_walk_occ = atoi(g);
   if (const char* g = pg_dev_env("PYANI_PN_WINDOW_MAX")) ctx->anim_pn_window_max = atoi(g);   // development switches of the forced kernels (tests: same results)
   if (const char* g = pg_dev_env("PYANI_PN_GROUP_MAX")) ctx->anim_pn_group_max = atoi(g);
   if (const char* g = pg_dev_env("PYANI_ANIM_GAP_LANES")) ctx->anim_gap_lanes = atoi(g) != 0;   // development switch (tests: both forms, same results)
@@ -351,6 +351,7 @@ void pg_destroy(pg_ctx* ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   for (int w = 1; w < pg_ctx::MAX_WORKERS; ++w) (void)hipStreamSynchronize(ctx->stream_w[w]);
   pg_anim_free_scratch(ctx);
+  pg_sketch_drop(ctx);
   prof_drain(ctx);
   void* dev[] = {ctx->d_codes, ctx->d_mask, ctx->d_quirk, ctx->d_seg_tile0, ctx->d_seg_prefix, ctx->d_batch_gid, ctx->d_acc,
                  ctx->d_counts, ctx->d_z, ctx->d_present, ctx->d_dev, ctx->d_ss, ctx->d_flags, ctx->d_corr};
@@ -464,6 +465,7 @@ int pg_clear_genomes(pg_ctx* ctx) {
   PG_HIP(ctx, hipSetDevice(ctx->device));
   PG_HIP(ctx, hipStreamSynchronize(ctx->stream));
   pg_anim_drop_lists(ctx);
+  pg_sketch_drop(ctx);
   ctx->genomes.clear();
   ctx->arena_used = 0;
   ctx->n_resident = 0;

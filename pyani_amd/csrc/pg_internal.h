@@ -94,12 +94,12 @@ struct pg_ctx {
   void* anim_scratch_w[MAX_WORKERS] = {nullptr, nullptr, nullptr, nullptr};   // workers 1.. (index 0 unused: worker 0 = anim_scratch)
   hipStream_t stream_w[MAX_WORKERS] = {nullptr, nullptr, nullptr, nullptr};   // workers 1.. (index 0 unused: worker 0 = stream)
   void* anim_lists = nullptr;      // per-genome seed lists, shared by the workers (guarded by anim_mu)
+  void* sketch_store = nullptr;    // per-genome k-mer sketches of the sketch mode (pg_sketch.hip), built on first use
   std::mutex anim_mu, err_mu, prof_mu;
   int anib_word_tier = 1;      // fragment mode: search failed fragments again with blastn-sized (11-mer) seeds
   int anim_pn_window_max = 2048;   // forced runs: the widest single-wave window (development: smaller values push runs on to the group kernel)
   int anim_pn_group_max = 8184;    // ... and the widest band the group of four waves takes (development: 0 = everything beyond one wave on the strips)
   int anim_gap_lanes = 1;      // postnuc: small match-to-match gaps on one lane each (0: all gaps on the wave engine; tests compare the two)
-  int anim_walk_occ = 2;       // waves per SIMD the walk / rehearsal kernels are compiled for (2: the compiler's 219 VGPRs; 4: capped at 128); PYANI_PN_WALK_OCC
   int anim_bwd_ahead = 1;      // backward searches ahead of the units' walks (pga_postnuc.inc); PYANI_ANIM_BWD_AHEAD=0 (development switch): inside them       // PG_EXTENDER_NUCMER (pg_anim_set_extender)
   int anim_workers = 2;
   uint32_t anim_batch_pairs = 131072;         // ordered pairs in flight (split over the two workers: 65536 per launch; every launch pays its slowest unit once)
@@ -165,6 +165,7 @@ struct PgAlnSink {
 int pg_anim_counters_read(pg_ctx* ctx, uint64_t* out /*[64]*/, int reset);
 void pg_anim_set_sink(PgAlnSink* sink);           // thread-local; nullptr = none
 void pg_anim_drop_lists(pg_ctx* ctx);   // per-genome seed lists: must go when the genome store is cleared
+void pg_sketch_drop(pg_ctx* ctx);       // ... and the sketches of the sketch mode (pg_sketch.hip)
 int pg_anib_reduce_run(pg_ctx* ctx, uint32_t n_pairs, const uint64_t* offsets, const uint32_t* n_frags, const int32_t* frag,
                        const int32_t* length, const int32_t* mismatch, const int32_t* gaps, const int32_t* qlen,
                        const double* pident, int64_t* aln_out, int64_t* err_out, double* pid_out);

@@ -279,6 +279,20 @@ class Engine:
         return out[:n.value].copy()
 
     # -- measurement ----------------------------------------------------------------------------------------------
+    # -- sketch mode (fastANI-shaped estimate; never mixed into the exact results) ----------------------------------------------
+    SKETCH_DTYPE = np.dtype([("ani", "<f8"), ("matches", "<i4"), ("fragments", "<i4"), ("status", "<i4"), ("reserved", "<i4")])
+
+    def sketch_pairs(self, qry_ids, ref_ids, frag_len: int = 3000, scale: int = 16, min_fraction: float = 0.2) -> np.ndarray:
+        """pg_sketch_pairs: one record per ORDERED pair (query fragmented, reference as a k-mer set): ani (a fraction), matches,
+        fragments, status (0 / 1 = fewer than min_fraction of the fragments matched: fastANI writes no line then)."""
+        q, r = self._ids(qry_ids), self._ids(ref_ids)
+        if len(q) != len(r):
+            raise ValueError("qry_ids and ref_ids must have the same length")
+        out = np.zeros(len(q), dtype=self.SKETCH_DTYPE)
+        self._check(self.lib.pg_sketch_pairs(self._h, q.ctypes.data, r.ctypes.data, len(q), int(frag_len), int(scale), float(min_fraction),
+                                             out.ctypes.data))
+        return out
+
     def profile_enable(self, on: bool = True):
         self._check(self.lib.pg_profile_enable(self._h, int(on)))
 

@@ -60,17 +60,6 @@ for k, x in (v or {}).get("per_kernel", {}).items():
     print(" ", k, x)
 PY
   ;;
-occ)     # A/B of the walk / rehearsal kernels' register cap: stage times of the three heavy tiles, one worker
-  for v in 2 4; do
-    PYANI_PN_WALK_OCC=$v timeout -k 10 300 python bench.py --gpus 1 --steps 1 --warmup 0 --roofline-tiles 3 --no-tetra --no-cpu-baseline --no-side-records > $O/occ$v.log 2> $O/occ$v.err
-    echo "walk occ $v:"; python - <<PY
-import json
-d = json.loads([l for l in open("gpurun_out/r05/occ$v.log") if l.startswith("{")][-1])
-for t in d["roofline"]["per_tile"]:
-    print(" tile", t["tile"], "sum", t["kernel_ms_sum"], {k: v_ for k, v_ in t["stage_ms"].items() if "postnuc_kernel" in k or "rehearse" in k or "forced" in k})
-PY
-  done
-  PYANI_PN_WALK_OCC=4 timeout -k 10 600 python -m pytest tests/test_anim_filter_oracle_gpu.py -m gpu -q --timeout 400 --timeout-method=thread -x 2>&1 | tail -3 ;;
 c4)
   timeout -k 10 900 python bench.py --gpus 1 --steps 4 --warmup 1 --no-tetra --no-cpu-baseline > $O/bench_c4.log 2> $O/bench_c4.err; echo "c4 rc=$?"
   grep '^{' $O/bench_c4.log > $O/bench_c4.json; cut -c1-2500 $O/bench_c4.json; tail -5 $O/bench_c4.err ;;
