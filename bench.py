@@ -315,6 +315,37 @@ def unrelated_only_record(eng, args, ids):
 SIMDS, CLOCK_GHZ = 1024, 2.4          # MI355X: 256 CUs x 4 SIMDs; a SIMD issues one wave64 VALU instruction per 4 cycles
 
 
+def sketch_record(eng, ids, n, K, dense, covered):
+    """The opt-in SKETCH mode (fastANI-shaped estimate, pg_sketch_pairs) on the WHOLE grid of the same job, for scale — an
+    estimate with its own columns, not what `value` measures: ordered pairs per second with the sketches resident, the one-off sketch
+    build, and its agreement with the exact engine's identity over the related pairs this run computed."""
+    ids = np.asarray(ids, dtype=np.int32)
+    q = np.repeat(np.arange(n), n)
+    r = np.tile(np.arange(n), n)
+    keep = q != r
+    q, r = q[keep], r[keep]
+    t0 = time.perf_counter()
+    eng.sketch_pairs(ids[:n], ids[:n])                  # builds every genome's sketch (cached), n pairs
+    t_build = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    res = eng.sketch_pairs(ids[q], ids[r])              # (query fragmented, reference as a k-mer set)
+    dt = time.perf_counter() - t0
+    related = (q % K) == (r % K)
+    got = res["status"] == 0
+    # exact identity of nucmer(reference = a, query = b) sits in dense[a, b]; the sketch's query is nucmer's query
+    ex_ok = covered[r, q] & (dense[r, q, 5] == 0)
+    both = related & got & ex_ok
+    err = np.abs(res["ani"][both] - dense[r, q, 4][both].view(np.float64)) if both.any() else np.zeros(0)
+    ex_id = dense[r, q, 4][both].view(np.float64) if both.any() else np.zeros(0)
+    return {"pairs": int(len(q)), "seconds": dt, "pairs_per_s": len(q) / dt, "sketch_build_s": t_build, "frag_len": 3000, "scale": 16, "min_fraction": 0.2,
+            "related_pairs_with_result": int((related & got).sum()), "unrelated_pairs_with_result": int((~related & got).sum()),
+            "vs_exact_identity": None if not len(err) else {
+                "pairs": int(len(err)), "mean_abs_error": float(err.mean()), "max_abs_error": float(err.max()),
+                "max_abs_error_identity_ge_0.90": float(err[ex_id >= 0.9].max()) if (ex_id >= 0.9).any() else None},
+            "note": "pg_sketch_pairs (FracMinHash containment per 3 kb query fragment, k = 16): an ESTIMATE in fastANI's output shape "
+                    "(pyani/fastani.py:193-270), never mixed into the exact matrices; not what `value` measures"}
+
+
 def _pmc_profile():
     f = ROOT / "profiles" / "pmc_anim.json"
     return json.loads(f.read_text()) if f.exists() else {}
@@ -380,12 +411,56 @@ def run_anim_cold(args, local):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+REHEARSAL = os.environ.get("PYANI_BENCH_REHEARSAL") == "1"
+
+
+class _RehearsalEngine:
+    """PYANI_BENCH_REHEARSAL=1 only (tests/test_parallel_gloo.py): a stand-in for pyani_amd.engine.Engine that COMPUTES NOTHING — it
+    sleeps what a call's pairs would cost (a related pair ~130 x an unrelated one, 4 x apart by family, as measured on C4) and returns records that are a function of the pair — so that the whole N > 1 control flow of this file (RowQueue dealing,
+    anim_allgather_dynamic, the strong-step series, the imbalance figures, the result hash) can be run with 8 gloo ranks on a box
+    without a GPU.  A rehearsal's line says so in `data` and carries no roofline; it is never what the driver measures."""
+
+    def __init__(self, n):
+        self.K = (n + 24) // 25
+
+    def add_genome(self, seq, off):
+        self._n = getattr(self, "_n", 0) + 1
+        return self._n - 1
+
+    def upload(self): pass
+    def sync(self): pass
+    def close(self): pass
+    def anim_set_workers(self, w): pass
+    def anim_set_batch_budget(self, a, b): pass
+    def profile_reset(self): pass
+    def profile_config(self, **kw): pass
+    def profile_enable(self, on=True): pass
+    def profile_get(self, which): return (0.0, 0)
+    def kernel_name(self, which): return f"stage{which}"
+    def anim_counters(self, reset=False): return np.zeros(64, dtype=np.uint64)
+
+    def anim_pairs(self, ref_ids, qry_ids, **kw):
+        from pyani_amd.engine import Engine
+        r, q = np.asarray(ref_ids, dtype=np.int64), np.asarray(qry_ids, dtype=np.int64)
+        rel = (r % self.K) == (q % self.K)
+        # C4 on MI355X: ~4.6 us per unrelated ordered pair, ~0.6 ms per related one on average, 0.3 - 1.2 ms by the divergence of the
+        # family members (a row = ~975 unrelated + 0 ... 48 related ordered pairs: 5 - 60 ms, a 100-row share ~1.8 s); here at 1/5 scale
+        fam_cost = 0.5 + 1.5 * ((np.minimum(r, q)[rel] // self.K) % 6) / 5.0
+        time.sleep(float(os.environ.get("PYANI_BENCH_REHEARSAL_SCALE", "1")) * (1.2e-4 * float(fam_cost.sum()) + 1e-6 * float((~rel).sum())))
+        out = np.zeros(len(r), dtype=Engine.ANIM_DTYPE)
+        out["ref_aln_len"], out["qry_aln_len"], out["sim_errors"] = r * 1000 + q, q * 1000 + r, (r * 7 + q * 13) % 1000
+        out["n_alignments"] = np.where(rel, 3, 0)
+        out["identity"] = np.where(rel, 0.9 + 1e-4 * ((r + q) % 100), 0.0)
+        out["status"] = np.where(rel, 0, 1)
+        return out
+
+
 def run_anim(args, rank, world, local, dist, torch):
     from pyani_amd import _lib, parallel
     from pyani_amd.engine import Engine
     if args.cold_e2e:
         return run_anim_cold(args, local)
-    eng = Engine(local)
+    eng = _RehearsalEngine(args.genomes) if REHEARSAL else Engine(local)
     n, R = args.genomes, max(1, min(args.rows_per_step, args.genomes))
     if os.environ.get("PYANI_BENCH_BATCH_PAIRS"):   # development: pairs / matches per internal launch of pg_anim_pairs
         eng.anim_set_batch_budget(int(os.environ["PYANI_BENCH_BATCH_PAIRS"]), int(os.environ.get("PYANI_BENCH_BATCH_MATCHES", 256 << 20)))
@@ -395,7 +470,7 @@ def run_anim(args, rank, world, local, dist, torch):
     ids = [eng.add_genome(s_, o_) for s_, o_ in data]
     eng.upload()
     t_prep = time.perf_counter() - t_prep
-    dev = torch.device("cuda", local)
+    dev = torch.device("cpu") if REHEARSAL else torch.device("cuda", local)
     lens = np.array([len(d[0]) for d in data], dtype=np.int64)
     # N > 1: the ranks PULL a step's rows in guided chunks from a cross-rank counter (pyani_amd.parallel.RowQueue: pair cost
     # varies ~60 x and a static deal leaves the step waiting for its unluckiest rank); --static-deal: the fixed hash of round 3
@@ -433,10 +508,12 @@ def run_anim(args, rank, world, local, dist, torch):
 
     def fence():
         eng.sync()
-        torch.cuda.synchronize()
+        if not REHEARSAL:
+            torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        if not REHEARSAL:
+            torch.cuda.synchronize()
 
     t_cold = time.perf_counter()
     for k in range(args.warmup):
@@ -457,7 +534,7 @@ def run_anim(args, rank, world, local, dist, torch):
     fence()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -496,7 +573,7 @@ def run_anim(args, rank, world, local, dist, torch):
     # ---- N > 1: the same tile size as N = 1's step, dealt over all ranks (strong scaling of ONE step: launches shrink with N)
     strong = None
     bare = args.no_cpu_baseline or args.no_side_records      # (tests and profiling runs: the step loop and the roofline step only)
-    if dist is not None and not bare:
+    if dist is not None and (not bare or REHEARSAL):
         r1 = max(1, n // 10)
         step(k_prof + 1, rows=rows_of(k_prof + 1, r1), key="strong_warm")
         fence()
@@ -506,7 +583,7 @@ def run_anim(args, rank, world, local, dist, torch):
             np_strong += len(step(k_prof + 2 + j, rows=rows_of(k_prof + 2 + j, r1), key=f"strong{j}"))
         fence()
         ts = time.perf_counter() - ts
-        tt = torch.tensor([ts], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([ts], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         strong = {"rows_per_step": r1, "steps": 2, "ms_per_step": float(tt.item()) / 2 * 1e3, "pairs_per_s": np_strong / float(tt.item()),
                   "note": f"the N = 1 step ({r1} rows, ~{r1 * (n - 1)} ordered pairs) dealt over {world} ranks: each rank's launches are 1/{world} the size"}
@@ -598,7 +675,8 @@ def run_anim(args, rank, world, local, dist, torch):
                       "parse_delta equivalent per ordered pair, genomes resident in HBM; vs the CPU path on this box's host cores",
             "value": pairs_done / elapsed, "unit": "genome-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": step_s * 1e3, "higher_is_better": True, "scaling": "weak" if args.rows_default else "strong", "vs_baseline": None,
-            "dtype": "u32 packed DP words (score << 17 | state << 15 | errors), i64 lengths, f64 identity", "data": "synthetic",
+            "dtype": "u32 packed DP words (score << 17 | state << 15 | errors), i64 lengths, f64 identity",
+            "data": "REHEARSAL: no engine, no GPU — a stub that sleeps a cost model (PYANI_BENCH_REHEARSAL=1; control-flow test only)" if REHEARSAL else "synthetic",
             "related_pairs_per_s": n_related / elapsed,
             "series": {
                 "weak": {"rows_per_step_per_gpu": R // world if args.rows_default else None, "pairs_per_s": pairs_done / elapsed, "ms_per_step": step_s * 1e3},
@@ -671,6 +749,7 @@ def run_anim(args, rank, world, local, dist, torch):
         if world == 1 and not bare:
             out["related_only"] = related_only_record(eng, args, stages)
             out["unrelated_only"] = unrelated_only_record(eng, args, ids)
+            out["sketch_mode"] = sketch_record(eng, ids, n, K, dense, covered)
             cb = out.get("cpu_baseline")
             if cb and cb.get("cpu_s_per_related_pair"):
                 # the two halves of the job priced separately: a genus-level job is all related pairs
@@ -734,10 +813,12 @@ def run_anib(args, rank, world, local, dist, torch):
 
     def fence():
         eng.sync()
-        torch.cuda.synchronize()
+        if not REHEARSAL:
+            torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        if not REHEARSAL:
+            torch.cuda.synchronize()
 
     t_cold = time.perf_counter()
     for k in range(args.warmup):
@@ -998,6 +1079,15 @@ def main():
             sys.exit("launch multi-GPU runs with torch.distributed.run (see module docstring)")
         args.gpus = world
     import torch
+    if REHEARSAL:      # (tests: the N > 1 control flow on CPU over gloo with a stub engine; never a measurement)
+        dist = None
+        if world > 1:
+            import torch.distributed as dist
+            dist.init_process_group("gloo")
+        if args.workload != "anim":
+            sys.exit("the rehearsal covers the anim workload")
+        args.no_cpu_baseline = args.no_tetra = True
+        return run_anim(args, rank, world, local, dist, torch)
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: the engine has no CPU fallback")
     # debugging aid for 1-GPU boxes: run the N>1 code path with every rank on GPU 0 over gloo (never the default)

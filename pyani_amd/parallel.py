@@ -171,54 +171,74 @@ def guided_chunks(n_rows: int, world: int, min_rows: int = 2) -> List[Tuple[int,
 
 
 class RowQueue:
-    """The cross-rank counter: `next_chunk(step)` returns the next unclaimed chunk number of that step (atomic over all ranks).
+    """The cross-rank counter: `next_chunk(token)` returns the next unclaimed chunk number of a step (atomic over all ranks).
     The counter lives in a key-value store with an atomic add: by default THE JOB'S OWN rendezvous store (the TCPStore that
     `init_process_group` already opened on MASTER_PORT: no second port to collide with another job on the node — the driver runs
-    N = 1, 2, 4, 8 back to back); `port` opens a store of its own instead (tests; a process group built without a store), and if that
-    port is taken rank 0 picks a free one and tells the others through the process group."""
+    N = 1, 2, 4, 8 back to back); `port` opens a store of its own instead (tests; a process group built without a store): rank 0
+    binds it (the requested port, or any free one if that is taken) and tells the others the port it got through the process group.
+    Which of the two it is, is AGREED between the ranks (a store that works on some ranks only would leave the others waiting in a
+    broadcast).  A step's counter is named by `step_token(step_key)`: the key plus how often this queue has begun that key, so a
+    caller that reuses a key (a rerun, two loops that both say "k0") gets a fresh counter each time — every rank calls step_token
+    once per collective step, in the same order."""
 
     def __init__(self, rank: int, world: int, host: str = "127.0.0.1", port: int = 0, timeout_s: float = 1800.0, prefix: str = "pyani_rows"):
         import datetime
         self.world = world
         self.store = None
         self._local = {}
+        self._uses = {}
         self._prefix = prefix
         self.kind = "local"          # "job-store": the process group's rendezvous store; "own-store": a TCPStore of its own
         if world <= 1:
             return
-        if not port and dist.is_initialized():
+        to = datetime.timedelta(seconds=timeout_s)
+        if not dist.is_initialized():      # no process group to talk through: everybody is given the same port (tests)
+            self.store = dist.TCPStore(host, port, world, is_master=(rank == 0), timeout=to, wait_for_workers=True)
+            self.kind = "own-store"
+            return
+        dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+        if not port:
+            store, ok = None, 1
             try:
                 from torch.distributed.distributed_c10d import _get_default_store
-                self.store = dist.PrefixStore(prefix, _get_default_store())
-                self.store.add("probe", 0)      # (a store without `add` — a FileStore on some file systems — fails here, not mid-step)
-                self.kind = "job-store"
-                return
+                store = dist.PrefixStore(prefix, _get_default_store())
+                store.add("probe", 0)      # (a store without `add` — a FileStore on some file systems — fails here, not mid-step)
             except Exception:
-                self.store = None
-        to = datetime.timedelta(seconds=timeout_s)
-        if dist.is_initialized():      # own store on a port rank 0 found free (the requested one if it is)
-            chosen = [0]
-            if rank == 0:
-                import socket
-                for cand in ([port] if port else []) + [0]:
-                    try:
-                        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
-                            sk.bind((host if host not in ("localhost",) else "127.0.0.1", cand))
-                            chosen[0] = sk.getsockname()[1]
-                        break
-                    except OSError:
-                        continue
-            dist.broadcast_object_list(chosen, src=0)
-            port = int(chosen[0])
-        self.store = dist.TCPStore(host, port, world, is_master=(rank == 0), timeout=to, wait_for_workers=True)
+                store, ok = None, 0
+            flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)      # every rank takes the same branch
+            if int(flag.item()) == 1:
+                self.store, self.kind = store, "job-store"
+                return
+        # a store of its own: rank 0 binds (no probe-then-bind window: the store itself takes the port), the others learn the port
+        chosen = [0]
+        if rank == 0:
+            for cand in ([port] if port else []) + [0]:
+                try:
+                    self.store = dist.TCPStore(host, cand, world, is_master=True, timeout=to, wait_for_workers=False)
+                    chosen[0] = int(self.store.port)
+                    break
+                except Exception:
+                    self.store = None
+        dist.broadcast_object_list(chosen, src=0)
+        if not chosen[0]:
+            raise RuntimeError("RowQueue: rank 0 could not open a TCPStore")
+        if rank != 0:
+            self.store = dist.TCPStore(host, int(chosen[0]), world, is_master=False, timeout=to)
         self.kind = "own-store"
 
-    def next_chunk(self, step_key: str) -> int:
+    def step_token(self, step_key: str) -> str:
+        """The counter name of the next collective step that uses `step_key` (call once per step on every rank)."""
+        n = self._uses.get(step_key, 0)
+        self._uses[step_key] = n + 1
+        return f"{step_key}#{n}"
+
+    def next_chunk(self, token: str) -> int:
         if self.store is None:
-            k = self._local.get(step_key, 0)
-            self._local[step_key] = k + 1
+            k = self._local.get(token, 0)
+            self._local[token] = k + 1
             return k
-        return int(self.store.add(f"rows/{step_key}", 1)) - 1
+        return int(self.store.add(f"rows/{token}", 1)) - 1
 
 
 def anim_allgather_dynamic(compute_pairs: Callable, n_genomes: int, device: torch.device, queue: RowQueue, step_key: str,
@@ -232,8 +252,9 @@ def anim_allgather_dynamic(compute_pairs: Callable, n_genomes: int, device: torc
     order = sorted(rows, key=lambda q: ((q * 0x9E3779B1) & 0xFFFFFFFF, q))      # related genomes sit side by side in sorted lists
     spans = guided_chunks(len(order), world, min_rows)
     mine_pairs, mine_vals, busy, taken = [], [], 0.0, 0
+    token = queue.step_token(step_key)      # (a key that is used again gets a counter of its own)
     while True:
-        k = queue.next_chunk(step_key)
+        k = queue.next_chunk(token)
         if k >= len(spans):
             break
         lo, hi = spans[k]

@@ -10,6 +10,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
+from tests.conftest import ROOT
+
 
 def _free_port():
     with socket.socket() as s:
@@ -156,7 +158,7 @@ def _dyn_worker(rank, world, port, n, rows_per_step, out_dir, own_port=0):
         for step in range(2):
             rows = [(step * rows_per_step + i) % n for i in range(rows_per_step)]
             dist.barrier()      # (bench.py's steps start together too: the previous step's all-gather is the last thing every rank did)
-            grid, st = parallel.anim_allgather_dynamic(fake_engine, n, torch.device("cpu"), queue, f"s{step}", rows)
+            grid, st = parallel.anim_allgather_dynamic(fake_engine, n, torch.device("cpu"), queue, "same_key_every_step", rows)      # (a reused key gets a fresh counter: RowQueue.step_token)
             imb.append(st["imbalance"])
             want = parallel.anim_pair_array(n, rows, symmetric=True)
             assert int((grid[:, :, 0] != 0).sum()) == len(want)
@@ -194,3 +196,40 @@ def test_guided_chunks_cover_the_rows():
         assert [a for a, _ in spans] == [0] + [b for _, b in spans[:-1]] if spans else n == 0
         assert (spans[-1][1] if spans else 0) == n
         assert all(b - a >= 1 for a, b in spans)
+
+
+def _rehearsal(n_ranks, extra, env_extra=None):
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, PYANI_BENCH_REHEARSAL="1", **(env_extra or {}))
+    bench = str(ROOT / "bench.py")
+    base = [sys.executable] if n_ranks == 1 else [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}", "--master-addr", "127.0.0.1",
+                                                  "--master-port", str(_free_port())]
+    r = subprocess.run(base + [bench, "--gpus", str(n_ranks), "--genomes", "1000", "--length", "2000"] + extra, capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+
+
+def test_eight_rank_dress_rehearsal_of_the_bench_control_flow():
+    """the REAL bench.py — its step loop, RowQueue in the job's own rendezvous store, anim_allgather_dynamic, the
+    weak / fixed-grid / strong-step series, the imbalance record, the result hash — launched exactly as the driver launches it
+    (torch.distributed.run, 8 ranks), on CPU over gloo with a stub engine that sleeps a C4-like cost model (PYANI_BENCH_REHEARSAL=1:
+    a related pair ~130 x an unrelated one, families 4 x apart: the proportions measured on C4).  The 8-rank grid must equal the 1-rank grid cell for cell (hash),
+    the line must carry what the driver's scaling run reads, and the dynamic dealing must keep the ranks within 25 % of each other."""
+    slow = {"PYANI_BENCH_REHEARSAL_SCALE": "2"}      # a step of ~0.8 s per rank: process wake-up skew (8 ranks on a few cores) must not be what is measured
+    one = _rehearsal(1, ["--steps", "10", "--warmup", "0"], slow)
+    eight = _rehearsal(8, ["--steps", "2", "--warmup", "1"], slow)
+    assert one["n_gpus"] == 1 and eight["n_gpus"] == 8 and eight["scaling"] == "weak" and "REHEARSAL" in eight["data"]
+    assert one["config"]["results_sha1_full_grid"] and one["config"]["results_sha1_full_grid"] == eight["config"]["results_sha1_full_grid"]
+    assert eight["config"]["rows_per_step"] == 800 and eight["series"]["weak"]["rows_per_step_per_gpu"] == 100
+    assert eight["series"]["strong_step"]["rows_per_step"] == 100 and eight["series"]["strong_step"]["pairs_per_s"] > 0
+    imb = eight["imbalance"]
+    assert imb["dealing"].startswith("guided chunks") and "job-store" in imb["dealing"] and len(imb["chunks_per_rank_last_step"]) == 8
+    assert imb["worst"] <= 1.25, imb
+    # the weak series scales: 8 ranks do 8 x the rows per step (not 8 x here: the step's all-gather and grid assembly run on the CPU
+    # over gloo in this rehearsal — 64 MB per step through loopback with 8 processes on a few cores; on the GPU box they are RCCL / HBM)
+    assert eight["value"] > 2.5 * one["value"], (one["value"], eight["value"])
+    # the fixed scrambled deal of round 3 (--static-deal) must give the same grid
+    static = _rehearsal(8, ["--steps", "2", "--warmup", "1", "--static-deal"])
+    assert static["config"]["results_sha1_full_grid"] == one["config"]["results_sha1_full_grid"]
