@@ -153,7 +153,7 @@ int pg_anim_set_workers(pg_ctx* ctx, int workers);
  * Synchronises the context's streams. */
 int pg_anim_counters(pg_ctx* ctx, uint64_t* out, int reset);
 
-/* Work-memory budget of pg_anim_pairs: at most max_pairs ordered pairs and max_matches exact matches in flight (about 264 bytes
+/* Work-memory budget of pg_anim_pairs: at most max_pairs ordered pairs and max_matches exact matches in flight (about 384 bytes
  * of device scratch per match, grown on demand; default 131072 pairs / 512 Mi matches, split over the context's two workers =
  * launches of up to 65536 pairs / 256 Mi matches, ~68 GB each).  Larger calls are split transparently; results do not depend on
  * the split. */

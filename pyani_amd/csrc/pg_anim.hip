@@ -303,6 +303,7 @@ void pg_anim_free_scratch(pg_ctx* ctx) {
   ctx->anim_lists = nullptr;
   anim_free_one(ctx, ctx->anim_scratch);
   for (int w = 1; w < pg_ctx::MAX_WORKERS; ++w) anim_free_one(ctx, ctx->anim_scratch_w[w]);
+  ctx->anim_scratch_matches_held = 0;
 }
 static void anim_free_one(pg_ctx* ctx, void*& slot) {
   AnimScratch* A = static_cast<AnimScratch*>(slot);
@@ -780,6 +781,7 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
     if ((rc = regrow(ctx, A->S.idx, cap))) return rc;
     if ((rc = regrow(ctx, A->S.from, cap))) return rc;
     if ((rc = regrow(ctx, A->S.sc, cap))) return rc;
+    __atomic_fetch_add(&ctx->anim_scratch_matches_held, (uint64_t)(cap - A->matches), __ATOMIC_RELAXED);      // (what pg_api.cpp's anim_match_budget may count as available)
     A->matches = cap;
   }
   PG_HIP(ctx, hipMemcpyAsync(A->moff, moff.data(), ((size_t)n_units + 1) * 4, hipMemcpyHostToDevice, cur_stream(ctx)));

@@ -739,6 +739,18 @@ static std::vector<std::pair<uint64_t, uint64_t>> anim_chunks(const int32_t* tab
   return chunks;
 }
 
+// The match budget of a call: the configured one, but never more than what the device has FREE right now can hold (~384 B of
+// scratch per exact match in flight: pg_anim.hip's per-match arrays) — several processes may share one GPU (ranks of a debugging
+// run, another job's context), and a budget sized for an empty 288 GB device would then over-commit it.  Scratch already held by
+// this context counts as available (it is reused).
+static uint64_t anim_match_budget(pg_ctx* ctx) {
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return ctx->anim_batch_matches; }
+  const uint64_t fit = (uint64_t)(0.7 * (double)free_b) / 384u;
+  const uint64_t floor_ = 4ull << 20;      // (always enough for a few related 5 Mb pairs; a launch that still does not fit reports PG_E_HIP / NOMEM)
+  return std::max<uint64_t>(floor_, std::min<uint64_t>(ctx->anim_batch_matches, fit + __atomic_load_n(&ctx->anim_scratch_matches_held, __ATOMIC_RELAXED)));
+}
+
 int pg_anim_set_batch_budget(pg_ctx* ctx, uint32_t max_pairs, uint64_t max_matches) {
   if (!ctx || max_pairs == 0 || max_matches < 1024) return pg_fail(ctx, PG_E_ARG, "bad argument");
   ctx->anim_batch_pairs = max_pairs;
@@ -816,7 +828,7 @@ int pg_anim_pairs(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_ids, u
   // keeps the launch's sequential tails and they contend; four families = 2 400 pairs: two workers win)
   const int W = n_pairs >= 1024 ? ctx->anim_workers : 1;
   const uint32_t MAX_PAIRS = ctx->anim_batch_pairs / W, MAX_REFS = 256;
-  const uint64_t max_matches = ctx->anim_batch_matches / W;
+  const uint64_t max_matches = anim_match_budget(ctx) / W;
   // about equal launches, a multiple of W of them, none above the per-launch budget
   const uint64_t cap = MAX_PAIRS ? MAX_PAIRS : 1;
   const uint64_t n_target = (uint64_t)W * ((n_pairs + (uint64_t)W * cap - 1) / ((uint64_t)W * cap));
@@ -867,7 +879,7 @@ int pg_anim_pair_alignments(pg_ctx* ctx, int32_t ref_id, int32_t qry_id, pg_anim
   if ((rc = pg_upload(ctx))) return rc;
   pg_anim_result res{};
   uint32_t done = 0;
-  if ((rc = pg_anim_run_batch(ctx, &ref_id, &qry_id, 1, 1, 0, ctx->anim_batch_matches, &res, &done))) return rc;
+  if ((rc = pg_anim_run_batch(ctx, &ref_id, &qry_id, 1, 1, 0, anim_match_budget(ctx), &res, &done))) return rc;
   if (res.status == PG_E_CAPACITY) return pg_fail(ctx, PG_E_CAPACITY, "anim: work buffers overflowed for this pair");
   *n_out = (uint32_t)res.reserved;
   const uint32_t n = *n_out < cap ? *n_out : cap;
@@ -915,7 +927,7 @@ static int anim_alignments_batch_body(pg_ctx* ctx, const int32_t* ref_ids, const
     for (uint64_t k = i; k < j; ++k) { r.push_back(ref_ids[order[k]]); q.push_back(qry_ids[order[k]]); }
     res.assign(j - i, pg_anim_result{});
     uint32_t done = 0;
-    rc = pg_anim_run_batch(ctx, r.data(), q.data(), (uint32_t)(j - i), 1, maxmatch != 0, ctx->anim_batch_matches, res.data(), &done);
+    rc = pg_anim_run_batch(ctx, r.data(), q.data(), (uint32_t)(j - i), 1, maxmatch != 0, anim_match_budget(ctx), res.data(), &done);
     i += done;
   }
   pg_anim_set_sink(nullptr);
@@ -1015,7 +1027,7 @@ int pg_anib_pairs(pg_ctx* ctx, const int32_t* qry_ids, const int32_t* sbj_ids, u
   std::stable_sort(order.begin(), order.end(), [&](uint64_t a, uint64_t b) { return sbj_ids[a] < sbj_ids[b]; });
   const int W = n_pairs >= 64 ? ctx->anim_workers : 1;
   const uint32_t MAX_PAIRS = ctx->anim_batch_pairs / W, MAX_REFS = 256;
-  const uint64_t max_matches = ctx->anim_batch_matches / W, max_slots = ANIB_MAX_SLOTS / W;
+  const uint64_t max_matches = anim_match_budget(ctx) / W, max_slots = ANIB_MAX_SLOTS / W;
   // (fragment launches are bounded by their (pair, fragment) slots: cut the chunks so that both workers get several)
   const auto chunks = anim_chunks(sbj_ids, order, std::max<uint64_t>(1, std::min<uint64_t>(MAX_PAIRS, W >= 2 ? (n_pairs + 4 * W - 1) / (4 * W) : n_pairs)), MAX_REFS);
   return anim_run_chunks(ctx, chunks, [&](uint64_t i, uint64_t j, int) -> int {
@@ -1046,7 +1058,7 @@ int pg_anib_pair_rows(pg_ctx* ctx, int32_t qry_id, int32_t sbj_id, uint32_t frag
   pg_anib_result res{};
   PgFragArgs F{(int32_t)fragsize, &res, out, cap, n_out, ANIB_MAX_SLOTS};
   uint32_t done = 0;
-  return pg_anim_run_batch(ctx, &sbj_id, &qry_id, 1, 0, 1, ctx->anim_batch_matches, nullptr, &done, &F);
+  return pg_anim_run_batch(ctx, &sbj_id, &qry_id, 1, 0, 1, anim_match_budget(ctx), nullptr, &done, &F);
 }
 
 // ---- measurement -----------------------------------------------------------------------------------------------

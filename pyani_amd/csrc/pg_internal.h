@@ -103,7 +103,8 @@ struct pg_ctx {
   int anim_bwd_ahead = 1;      // backward searches ahead of the units' walks (pga_postnuc.inc); PYANI_ANIM_BWD_AHEAD=0 (development switch): inside them       // PG_EXTENDER_NUCMER (pg_anim_set_extender)
   int anim_workers = 2;
   uint32_t anim_batch_pairs = 131072;         // ordered pairs in flight (split over the two workers: 65536 per launch; every launch pays its slowest unit once)
-  uint64_t anim_batch_matches = 512ull << 20; // exact matches in flight (~264 B of scratch each, grown on demand: at most ~136 GB of the 288 GB)
+  uint64_t anim_scratch_matches_held = 0;     // match slots the workers' scratch already holds (counts as available to anim_match_budget)
+  uint64_t anim_batch_matches = 512ull << 20; // exact matches in flight (~384 B of scratch each, grown on demand: at most ~136 GB of the 288 GB)
 };
 
 int pg_fail(pg_ctx* ctx, int code, const std::string& msg);
