@@ -314,3 +314,93 @@ def anim_records_to_tensor(recs, device: torch.device) -> torch.Tensor:
     a[:, 4] = recs["identity"].view(np.int64)
     a[:, 5] = recs["status"]
     return torch.from_numpy(a).to(device)
+
+
+# ---- the product's cross-process path: one engine per rank behind the Engine calls run_anim uses ------------------------------------
+class DistributedEngine:
+    """One process per GPU (torch.distributed: backend "nccl" = RCCL over xGMI on a node of MI355X, "gloo" in the CPU tests), every
+    rank holding a LOCAL engine with all genomes resident (they are small: 1.9 GB for 1000 x 5 Mb).  `anim_pairs` is a COLLECTIVE
+    call — every rank makes it with the same arguments, as every rank runs the same `run_anim` — that
+
+      * cuts the pair list into chunks by hub genome (a pair and its reverse stay together: they share their seeding), about
+        24 per rank, handed out through the cross-rank counter (RowQueue: the rank that drew cheap, unrelated pairs comes back
+        for more while another is still inside a family — pyani's own runner is such a pool, run_multiprocessing.py:113-152),
+      * computes the rank's chunks on its engine, and
+      * assembles the result with ONE all-gather per call (the 40-byte records + the pair's index, padded to the largest share),
+
+    so that every rank returns the complete array in the caller's order: the counterpart of pyani's `--workers` (subcmd_anim.py:
+    392-396) across the GPUs of a node, with the collective in the PRODUCT path (pyani_amd.subcmd_anim.run_anim wraps its engine in
+    one of these whenever a process group with more than one rank is initialised), not only in bench.py.  Everything else — the
+    genome store, reductions of existing files, alignment records for output files — is the local engine's call, made by every
+    rank alike.  Results do not depend on the number of ranks or on who computed what (tests/test_parallel_gloo.py, world size 2 on
+    CPU with a recording engine; tests/test_parallel_multi_gpu.py: two gloo ranks on GPU 0 and one RCCL rank == a plain engine)."""
+
+    def __init__(self, local_engine, group=None, queue: Optional["RowQueue"] = None, chunks_per_rank: int = 24):
+        self.local = local_engine
+        self.group = group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.queue = queue or RowQueue(self.rank, self.world)
+        self.chunks_per_rank = chunks_per_rank
+        self.device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+        self.last_stats = None
+
+    def __getattr__(self, name):      # genome store, reductions, single-pair calls: the local engine's
+        return getattr(self.local, name)
+
+    def anim_pairs(self, ref_ids, qry_ids, filter_1to1: bool = True, maxmatch: bool = False):
+        import time
+        import numpy as np
+        from .multi import _chunks_by_hub
+        r = np.ascontiguousarray(list(ref_ids), dtype=np.int32)
+        q = np.ascontiguousarray(list(qry_ids), dtype=np.int32)
+        if len(r) != len(q):
+            raise ValueError("ref_ids and qry_ids must have the same length")
+        n = len(r)
+        proto = self.local.anim_pairs(r[:0], q[:0], filter_1to1=filter_1to1, maxmatch=maxmatch)      # (dtype of the records)
+        if n == 0 or self.world == 1:
+            return self.local.anim_pairs(r, q, filter_1to1=filter_1to1, maxmatch=maxmatch)
+        chunks = _chunks_by_hub(r, q, max(64, n // (self.chunks_per_rank * self.world) + 1))
+        token = self.queue.step_token("anim_pairs")
+        mine_idx, mine_rec, busy = [], [], 0.0
+        while True:
+            k = self.queue.next_chunk(token)
+            if k >= len(chunks):
+                break
+            idx = chunks[k]
+            t0 = time.perf_counter()
+            mine_rec.append(self.local.anim_pairs(r[idx], q[idx], filter_1to1=filter_1to1, maxmatch=maxmatch))
+            busy += time.perf_counter() - t0
+            mine_idx.append(idx)
+        n_mine = sum(len(i) for i in mine_idx)
+        meta = torch.tensor([float(n_mine), busy], dtype=torch.float64, device=self.device)
+        metas = torch.zeros(self.world * 2, dtype=torch.float64, device=self.device)
+        dist.all_gather_into_tensor(metas, meta, group=self.group)
+        metas = metas.cpu().numpy().reshape(self.world, 2)
+        cap = max(1, int(metas[:, 0].max()))
+        words = proto.dtype.itemsize // 8      # (the record is 40 bytes = five 8-byte words; one more for the pair's index)
+        loc = np.zeros((cap, words + 1), dtype=np.int64)
+        loc[:, words] = -1
+        if n_mine:
+            loc[:n_mine, :words] = np.concatenate(mine_rec).view(np.int64).reshape(n_mine, words)
+            loc[:n_mine, words] = np.concatenate(mine_idx)
+        loc_t = torch.from_numpy(loc).to(self.device)
+        all_t = torch.zeros((self.world * cap, words + 1), dtype=torch.int64, device=self.device)
+        dist.all_gather_into_tensor(all_t, loc_t, group=self.group)      # THE collective of the call
+        allv = all_t.cpu().numpy()
+        valid = allv[:, words] >= 0
+        if int(valid.sum()) != n:
+            raise RuntimeError(f"DistributedEngine.anim_pairs: {int(valid.sum())} of {n} pairs came back")
+        out = np.zeros(n, dtype=proto.dtype)
+        out.view(np.int64).reshape(n, words)[allv[valid, words]] = allv[valid, :words]
+        mean = float(metas[:, 1].mean())
+        self.last_stats = {"busy_s": metas[:, 1].tolist(), "pairs": metas[:, 0].astype(int).tolist(), "chunks": len(chunks),
+                           "imbalance": float(metas[:, 1].max()) / mean if mean > 0 else 1.0}
+        return out
+
+
+def engine_for_process_group(local_engine, group=None):
+    """The engine run_anim should use: `local_engine` wrapped in a DistributedEngine when a process group with more than one rank is
+    initialised (one process per GPU, launched with torch.distributed.run), else `local_engine` itself."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        return DistributedEngine(local_engine, group)
+    return local_engine

@@ -50,7 +50,8 @@ def run_anim(indir, outdir=None, recovery: bool = False, nofilter: bool = False,
              devices: Optional[List[int]] = None, workers: Optional[int] = None) -> AnimRun:
     """ANIm over every FASTA file of `indir`.  outdir is needed for recovery / write_output only.
     devices / workers: run on several GPUs of this node (pyani's `--workers`, subcmd_anim.py:392-396, counts GPUs here): the
-    comparisons are pulled from a work queue by one engine per device (pyani_amd/multi.py); ignored when `engine` is given."""
+    comparisons are pulled from a work queue by one engine per device (pyani_amd/multi.py); ignored when `engine` is given.
+    Under torch.distributed (one process per GPU, world size > 1) the call is collective: see pyani_amd.parallel.DistributedEngine."""
     if write_output and outdir is None:
         raise ValueError("write_output needs an output directory")     # before any work is done
     own = None
@@ -59,7 +60,15 @@ def run_anim(indir, outdir=None, recovery: bool = False, nofilter: bool = False,
         engine = multi.engine_for(devices, workers)
         own = engine if isinstance(engine, multi.MultiEngine) else None
     try:
-        return _run_anim(indir, outdir, recovery, nofilter, maxmatch, write_output, skip_zero, engine or default_engine())
+        eng = engine or default_engine()
+        # one process per GPU (launched with torch.distributed.run): every rank runs this same call; the comparisons are dealt over
+        # the ranks and assembled with one RCCL all-gather (pyani_amd.parallel.DistributedEngine) — every rank returns the whole run.
+        # (output files and recovered files are handled by every rank alike: give the ranks their own outdir, or write on rank 0 only)
+        import sys
+        if "torch.distributed" in sys.modules:
+            from . import parallel
+            eng = parallel.engine_for_process_group(eng)
+        return _run_anim(indir, outdir, recovery, nofilter, maxmatch, write_output, skip_zero, eng)
     finally:
         if own is not None:
             own.close()

@@ -233,3 +233,63 @@ def test_eight_rank_dress_rehearsal_of_the_bench_control_flow():
     # the fixed scrambled deal of round 3 (--static-deal) must give the same grid
     static = _rehearsal(8, ["--steps", "2", "--warmup", "1", "--static-deal"])
     assert static["config"]["results_sha1_full_grid"] == one["config"]["results_sha1_full_grid"]
+
+
+def _dist_engine_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import time
+        from pyani_amd import parallel
+        from pyani_amd.engine import Engine
+
+        class Recording:      # a local engine that computes a function of the pair and remembers what it was asked
+            def __init__(self):
+                self.calls = []
+
+            def anim_pairs(self, r, q, filter_1to1=True, maxmatch=False):
+                r, q = np.asarray(r, dtype=np.int64), np.asarray(q, dtype=np.int64)
+                self.calls.append((r.copy(), q.copy()))
+                time.sleep(1e-4 * len(r))
+                out = np.zeros(len(r), dtype=Engine.ANIM_DTYPE)
+                out["ref_aln_len"], out["qry_aln_len"], out["sim_errors"], out["n_alignments"] = r * 1000 + q, q * 1000 + r, r + q, 1 + (r % 3)
+                out["identity"] = 0.9 + 1e-4 * q + (0.01 if filter_1to1 else 0.0)
+                out["status"] = (r + q) % 2
+                return out
+
+            def genome_count(self):
+                return 17
+
+        loc = Recording()
+        eng = parallel.engine_for_process_group(loc)
+        assert isinstance(eng, parallel.DistributedEngine) and eng.genome_count() == 17      # (everything else is the local engine's)
+        n = 29
+        pairs = [(a, b) for a in range(n) for b in range(n) if a != b]
+        r, q = [a for a, _ in pairs], [b for _, b in pairs]
+        got = eng.anim_pairs(r, q)
+        want = Recording().anim_pairs(r, q)
+        assert got.tobytes() == want.tobytes()
+        again = eng.anim_pairs(r[::-1], q[::-1], filter_1to1=False)      # a second collective call: a counter of its own
+        assert again.tobytes() == Recording().anim_pairs(r[::-1], q[::-1], filter_1to1=False).tobytes()
+        assert len(eng.anim_pairs([], [])) == 0
+        mine = sum(len(c[0]) for c in loc.calls)
+        t = torch.tensor([mine], dtype=torch.int64)
+        dist.all_reduce(t)
+        assert int(t.item()) == 2 * len(pairs) and 0 < mine < 2 * len(pairs)      # the ranks shared the work, nothing was computed twice
+        # a pair and its reverse were computed by the same rank in the same call (they share their seeding)
+        for cr, cq in loc.calls:
+            have = set(zip(cr.tolist(), cq.tolist()))
+            assert all((b, a) in have for a, b in have)
+        if rank == 0:
+            np.save(os.path.join(out_dir, "ok.npy"), np.array(eng.last_stats["pairs"]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_distributed_engine_is_a_collective_anim_pairs_with_one_all_gather(tmp_path):
+    """The product's cross-process path (pyani_amd.parallel.DistributedEngine: what run_anim wraps its engine in under
+    torch.distributed): world size 2 over gloo with a recording local engine — the complete result on every rank in the caller's
+    order, every pair computed exactly once, a pair and its reverse on the same rank."""
+    port = _free_port()
+    mp.spawn(_dist_engine_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert int(np.load(tmp_path / "ok.npy").sum()) == 29 * 28

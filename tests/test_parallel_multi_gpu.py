@@ -116,3 +116,45 @@ def test_alignment_records_and_tetra_over_two_engines_equal_one(genome_dir):
         a, b = int(want[0][k]), int(want[0][k + 1])
         assert got[1][a:b].tobytes() == want[1][a:b].tobytes()
     assert all(x.tobytes() == y.tobytes() for x, y in zip(got_t, want_t)) and all(x.tobytes() == y.tobytes() for x, y in zip(got_c, want_c))
+
+
+def _run_anim_rank(rank, world, port, indir, out_dir):
+    import json
+    import os
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)      # (two RCCL ranks cannot share one GPU)
+    try:
+        from pyani_amd import subcmd_anim
+        from pyani_amd.engine import Engine
+        with Engine(0) as eng:
+            run = subcmd_anim.run_anim(indir, engine=eng)
+        with open(os.path.join(out_dir, f"rank{rank}.json"), "w") as fh:
+            json.dump({"results": {f"{a}|{b}": list(v) for (a, b), v in run.results.items()}, "json": run.json}, fh)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_run_anim_under_a_process_group_equals_the_plain_run(genome_dir, tmp_path):
+    """run_anim as one process per GPU (here: two gloo ranks on GPU 0): the comparisons are dealt over the ranks through the
+    cross-rank counter and assembled with one all-gather (pyani_amd.parallel.DistributedEngine) — every rank returns the run a single
+    process computes, result for result."""
+    import json
+    import shutil
+    import socket
+    import torch.multiprocessing as mp
+    from pyani_amd import subcmd_anim
+    d = tmp_path / "in"
+    d.mkdir()
+    for p in list(genome_dir["blochmannia"].values())[:5]:
+        shutil.copy(p, d / p.name)
+    one = subcmd_anim.run_anim(d)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_run_anim_rank, args=(2, port, str(d), str(tmp_path)), nprocs=2, join=True)
+    want = {f"{a}|{b}": list(v) for (a, b), v in one.results.items()}
+    for rank in range(2):
+        got = json.loads((tmp_path / f"rank{rank}.json").read_text())
+        assert got["results"] == want and got["json"] == one.json, rank
