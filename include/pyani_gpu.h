@@ -218,8 +218,9 @@ int pg_anib_reduce(pg_ctx* ctx, uint32_t n_pairs, const uint64_t* offsets, const
  * blastn's 11-mer words for fragments those leave without a reportable hit), checked against the BLAST+ tables the reference's
  * tests hold (level of agreement per fixture).
  * Limits: fragsize <= 1020 (pyani's default and maximum in practice; larger values are rejected with PG_E_ARG — the fragment's
- * DP lives in LDS); a query genome of more than 15 872 fragments (16.1 Mb at 1020 nt) cannot be searched: its pairs come back
- * with status = PG_E_CAPACITY (n_frags set, everything else 0) and the call goes on with the others. */
+ * DP lives in LDS).  Query genomes of any bacterial or fungal size: up to 15 872 fragments (16.1 Mb at 1020 nt) the per-fragment
+ * counters sit in LDS, beyond that in HBM (round 5: there used to be a hard limit); only a query of more than ~10^6 fragments
+ * (1 Gb) comes back with status = PG_E_CAPACITY (n_frags set, everything else 0), the call going on with the others. */
 typedef struct {
   int64_t aln_length, sim_errors;
   double pid;

@@ -510,8 +510,6 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
       const PgGenome& Q = ctx->genomes[qry_ids[p]];
       uint64_t nf = 0;
       for (uint32_t r = 0; r < Q.n_rec; ++r) nf += ((uint64_t)(Q.rec_start[r + 1] - 1 - Q.rec_start[r]) + frag->fragsize - 1) / frag->fragsize;
-      if (nf > (uint64_t)FRAG_MAX_FRAGS)
-        return pg_fail(ctx, PG_E_CAPACITY, "fragment mode: a query genome has more fragments than the per-genome limit (15872)");
       if (p > 0 && slots + nf > frag->max_slots) break;
       slots += nf;
       fit = p + 1;

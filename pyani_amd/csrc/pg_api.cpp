@@ -1015,7 +1015,7 @@ int pg_anib_pairs(pg_ctx* ctx, const int32_t* qry_ids, const int32_t* sbj_ids, u
         nf = 0;
         for (uint32_t r = 0; r < Q.n_rec; ++r) nf += ((int64_t)(Q.rec_start[r + 1] - 1 - Q.rec_start[r]) + fragsize - 1) / fragsize;
       }
-      if (nf > (int64_t)PG_FRAG_MAX_FRAGS) {
+      if (nf > (int64_t)ANIB_MAX_SLOTS / pg_ctx::MAX_WORKERS) {      // (more fragments than one launch holds: a query genome beyond ~1 Gb)
         out[i] = pg_anib_result{};
         out[i].n_frags = (int32_t)nf;
         out[i].status = PG_E_CAPACITY;

@@ -163,3 +163,26 @@ def test_module_api_tables_and_matrices(eng, genome_dir, tmp_path):
     assert anib.write_blast_tab(out, table, [r[0] for r in recs], [r[1] for r in recs]) == len(table)
     aln, err, pid = anib_oracle.parse_blast_tab(out)
     assert (aln, err) == res[(q, s)][:2] and abs(pid - res[(q, s)][2]) < 1e-9
+
+
+def test_query_genome_beyond_the_lds_counters_equals_cpu_statement():
+    """A fragmented genome of more than 15 872 fragments (16.1 Mb at 1020 nt: the capacity of the bucket kernel's LDS counters; rounds
+    2-4 rejected such a genome with PG_E_CAPACITY — pyani's fragment_fasta_files, anib.py:164-203, has no such limit): 17 Mb of
+    random sequence carrying three diverged copies of the subject.  The counters move to HBM (pga_frag.inc, anib_bucket_kernel);
+    the table must equal the CPU statement's row for row."""
+    from pyani_amd import synth
+    from pyani_amd.engine import Engine
+    sbj = synth.genome(77, 4, 0, 200_000)
+    rng = np.random.default_rng(5)
+    big = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=17_000_000)]
+    for k, at in enumerate((1_000_000, 8_500_000, 16_200_000)):
+        cp, _ = synth.genome(77, 4, 1 + k, 200_000)      # descendants of the same ancestor: 0.5 %, 2 %, 5 % divergence
+        big[at:at + len(cp)] = cp
+    qry = (big, np.array([0, 9_000_000, len(big)], dtype=np.uint64))      # two records
+    with Engine(0) as e:
+        q, s = e.add_genome(*qry), e.add_genome(*sbj)
+        rec = e.anib_pairs([q], [s])[0]
+        assert int(rec["status"]) == 0 and int(rec["n_frags"]) > 15_872, rec
+        got = e.anib_pair_rows(q, s)
+    want = anib_cpu.anib_cpu_pair(qry, sbj)
+    assert _rows(got) == _rows(want) and len(want) > 400, (len(got), len(want))
