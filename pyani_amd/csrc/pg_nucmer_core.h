@@ -276,21 +276,28 @@ struct PnPairSync {
   int32_t* born;               // per alignment of this unit: the key of the turn that pushed it
   int32_t n_log = 0, key = 0;
   long waits = 0, asked = 0, differs = 0;   // (development counters; differs: shadow tests that the unit's own current alignment would have answered otherwise)
-  PG_HD void begin_turn(int32_t k) { key = k; pushed_aln = -1; prim.publish_key(k); }
+  // Publication is LAZY: the log's length and this walk's position go out (behind a store fence) every PUBLISH_EVERY-th logged turn,
+  // before this walk waits for the other one (else two waiting walks could each sit on news the other needs) and at the end — a
+  // fence per turn (10^7 turns per C4 launch) cost the walk kernel a third of its time, and the other walk only ever looks at
+  // this one's log inside the rare shadow test that found a containing alignment: it just waits a little longer there.
+  static constexpr int PUBLISH_EVERY = 16;
+  int32_t unpublished = 0;
+  PG_HD void publish() { prim.publish_log(n_log); prim.publish_key(key); unpublished = 0; }
+  PG_HD void begin_turn(int32_t k) { key = k; pushed_aln = -1; if (unpublished >= PUBLISH_EVERY) publish(); }
   int32_t pushed_aln = -1;     // the alignment this turn pushed (its birth key is `key`: not read back through memory in the same turn)
   PG_HD void pushed(int aln) { prim.st(born + aln, key); pushed_aln = aln; }
   PG_HD void end_turn(int32_t rrec, int32_t qrec, int aln) {
     PnTurn* e = log + n_log;
-    const int32_t b = aln == pushed_aln ? key : prim.ld(born + aln);      // (else: a merge target, born in an earlier turn — stored before that turn's publish)
+    const int32_t b = aln == pushed_aln ? key : prim.ld(born + aln);      // (else: a merge target, born in an earlier turn)
     prim.st(&e->key, key); prim.st(&e->rrec, rrec); prim.st(&e->qrec, qrec); prim.st(&e->aln, aln); prim.st(&e->born, b);
-    ++n_log;
-    prim.publish_log(n_log);      // (only turns that were not skipped pay for the store fence)
+    ++n_log; ++unpublished;
   }
-  PG_HD void finish() { prim.publish_key(PN_KEY_DONE); }
+  PG_HD void finish() { key = PN_KEY_DONE; publish(); }
   // isShadowedCluster's scan range for a cluster of synteny (rrec, qrec) at the current turn: the largest index of this unit's
   // alignment list the test may look at (-1: none).  n_al: alignments of this unit so far.
   PG_HD int visible(int32_t rrec, int32_t qrec, int n_al, int /* cura */) {
     ++asked;
+    publish();      // (this walk's own log entries are read back below, and the other walk may be waiting for this one's news)
     int32_t o_key = -1, o_aln = -1;
     for (int t = n_log - 1; t >= 0; --t)
       if (prim.ld(&log[t].rrec) == rrec && prim.ld(&log[t].qrec) == qrec) { o_key = prim.ld(&log[t].key); o_aln = prim.ld(&log[t].aln); break; }
