@@ -90,7 +90,8 @@ def test_edge_inputs(eng):
     b = eng.add_genome(*big)
     mixed = eng.anib_pairs([b, a, b], [a, a, b], fragsize=30)
     assert [int(r["status"]) for r in mixed] == [0, 0, 0] and int(mixed[0]["n_frags"]) > 15872
-    assert int(mixed[2]["n_kept"]) > 15000 and int(mixed[2]["sim_errors"]) == 0      # the big genome against itself: (nearly) every 30-nt piece, no error
+    # (a 30-nt piece cannot reach blastn's e-value of 1e-15, so nothing is KEPT at this fragment size: the rows of the HBM-counter path
+    # are checked against the CPU statement at pyani's own fragment size in test_query_genome_beyond_the_lds_counters_equals_cpu_statement)
     again = eng.anib_pairs([a], [a], fragsize=30)[0]
     assert tuple(mixed[1]) == tuple(again) and int(again["n_frags"]) >= 2000
     assert tuple(eng.anib_pairs([b], [a], fragsize=30)[0]) == tuple(mixed[0])
