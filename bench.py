@@ -315,6 +315,14 @@ def unrelated_only_record(eng, args, ids):
 SIMDS, CLOCK_GHZ = 1024, 2.4          # MI355X: 256 CUs x 4 SIMDs; a SIMD issues one wave64 VALU instruction per 4 cycles
 
 
+def _side_record(fn, *a):
+    """A side record (outside the timed region) must never cost the headline line: its failure is reported in its place."""
+    try:
+        return fn(*a)
+    except Exception as e:  # noqa: BLE001 - reported, not hidden
+        return {"error": f"{type(e).__name__}: {e}"}
+
+
 def sketch_record(eng, ids, n, K, dense, covered):
     """The opt-in SKETCH mode (fastANI-shaped estimate, pg_sketch_pairs) on the WHOLE grid of the same job, for scale — an
     estimate with its own columns, not what `value` measures: ordered pairs per second with the sketches resident, the one-off sketch
@@ -749,7 +757,7 @@ def run_anim(args, rank, world, local, dist, torch):
         if world == 1 and not bare:
             out["related_only"] = related_only_record(eng, args, stages)
             out["unrelated_only"] = unrelated_only_record(eng, args, ids)
-            out["sketch_mode"] = sketch_record(eng, ids, n, K, dense, covered)
+            out["sketch_mode"] = _side_record(sketch_record, eng, ids, n, K, dense, covered)
             cb = out.get("cpu_baseline")
             if cb and cb.get("cpu_s_per_related_pair"):
                 # the two halves of the job priced separately: a genus-level job is all related pairs

@@ -36,6 +36,18 @@ void free_genome(SketchGenome& S) {
   S = SketchGenome{};
 }
 
+// Device memory for a sketch.  The ANIm engine keeps its per-launch scratch and per-genome seed lists for reuse (after a 1000-genome
+// grid: ~200 GB of the 288); a sketch that does not fit beside them takes their place — they are rebuilt on the next ANIm call.
+template <typename T>
+int sk_malloc(pg_ctx* ctx, T*& p, size_t n) {
+  if (hipMalloc(reinterpret_cast<void**>(&p), n * sizeof(T)) == hipSuccess) return PG_OK;
+  (void)hipGetLastError();
+  p = nullptr;
+  pg_anim_free_scratch(ctx);
+  PG_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&p), n * sizeof(T)));
+  return PG_OK;
+}
+
 // record of stream position p (rec_start[r] <= p < rec_start[r + 1])
 __device__ __forceinline__ int rec_of(const int32_t* __restrict__ rec_start, int n_rec, int32_t p) {
   int lo = 0, hi = n_rec - 1;
@@ -167,9 +179,10 @@ int build_sketch(pg_ctx* ctx, SketchStore* ST, int32_t gid, int32_t frag_len, in
     rec_tab[G.n_rec + 1 + r] = (int32_t)nf;
     if (r < G.n_rec) nf += (uint32_t)((G.rec_start[r + 1] - 1 - G.rec_start[r]) / frag_len);
   }
-  PG_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&S.rec_tab), rec_tab.size() * 4));
+  int rc;
+  if ((rc = sk_malloc(ctx, S.rec_tab, rec_tab.size()))) return rc;
   PG_HIP(ctx, hipMemcpyAsync(S.rec_tab, rec_tab.data(), rec_tab.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-  if (!ST->counters) PG_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ST->counters), 8));
+  if (!ST->counters && (rc = sk_malloc(ctx, ST->counters, 2))) return rc;
   PG_HIP(ctx, hipMemsetAsync(ST->counters, 0, 8, ctx->stream));
   const uint32_t* codes = ctx->d_codes + G.arena_start / 16;
   const uint32_t* mask = ctx->d_mask + G.arena_start / 32;
@@ -182,10 +195,10 @@ int build_sketch(pg_ctx* ctx, SketchStore* ST, int32_t gid, int32_t frag_len, in
   uint32_t cap = 1024;
   while (cap < 2 * cnt[0]) cap <<= 1;
   S.cap_mask = cap - 1; S.n_occ = cnt[1]; S.n_frags = nf; S.frag_len = frag_len; S.scale = scale;
-  PG_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&S.tab), (size_t)cap * 4));
-  PG_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&S.occ_kmer), (size_t)(cnt[1] + 1) * 4));
-  PG_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&S.occ_frag), (size_t)(cnt[1] + 1) * 4));
-  PG_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&S.frag_n), (size_t)(nf + 1) * 4));
+  if ((rc = sk_malloc(ctx, S.tab, (size_t)cap))) return rc;
+  if ((rc = sk_malloc(ctx, S.occ_kmer, (size_t)cnt[1] + 1))) return rc;
+  if ((rc = sk_malloc(ctx, S.occ_frag, (size_t)cnt[1] + 1))) return rc;
+  if ((rc = sk_malloc(ctx, S.frag_n, (size_t)nf + 1))) return rc;
   PG_HIP(ctx, hipMemsetAsync(S.tab, 0xFF, (size_t)cap * 4, ctx->stream));
   PG_HIP(ctx, hipMemsetAsync(S.frag_n, 0, (size_t)(nf + 1) * 4, ctx->stream));
   PG_HIP(ctx, hipMemsetAsync(ST->counters, 0, 8, ctx->stream));
@@ -253,8 +266,8 @@ extern "C" int pg_sketch_pairs(pg_ctx* ctx, const int32_t* qry_ids, const int32_
   }
   SketchJob* d_jobs = nullptr;
   pg_sketch_result* d_out = nullptr;
-  PG_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&d_jobs), jobs.size() * sizeof(SketchJob)));
-  PG_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&d_out), n_pairs * sizeof(pg_sketch_result)));
+  if ((rc = sk_malloc(ctx, d_jobs, jobs.size()))) return rc;
+  if ((rc = sk_malloc(ctx, d_out, (size_t)n_pairs))) { (void)hipFree(d_jobs); return rc; }
   PG_HIP(ctx, hipMemcpyAsync(d_jobs, jobs.data(), jobs.size() * sizeof(SketchJob), hipMemcpyHostToDevice, ctx->stream));
   if (lds_max > 48 * 1024) PG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(sketch_pairs_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(96 * 1024)));
   pg_prof_begin(ctx, PG_K_SKETCH_PAIRS);
