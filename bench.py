@@ -107,7 +107,7 @@ def anim_cpu_baseline(args, data, n, related, gpu_lookup):
     delta-filter process per pair, run_multiprocessing.py:130-144).
       kind "reference": nucmer + delta-filter exist on this box -> exactly pyani's jobs, Pool(os.cpu_count()).
       kind "port"     : they do not (MUMmer is third-party, absent from the image) -> the repo's own CPU statement of the
-                        same search (oracle/anim_cpu.cpp: the scalar core of the engine on an exhaustive 20-mer table), one
+                        same search (oracle/anim_cpu.cpp: the engine's definitions in scalar form on a host k-mer index), one
                         pair per host thread ("own-cpu")."""
     threads = os.cpu_count() or 1
     k = args.cpu_pairs or min(threads, 128)     # bounded: ~2-10 CPU-s per pair, one pair per thread

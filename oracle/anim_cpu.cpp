@@ -3,8 +3,8 @@
 // What it is: the scalar functions of pyani_amd/csrc/pg_anim_core.h (MUM filter, mgaps clustering, banded affine extension,
 // 1-to-1 LIS filter, parse_delta reduction — the restatement of what `nucmer --mum` + `delta-filter -1` + pyani's
 // parse_delta (pyani/anim.py:240-289, 292-411; scripts/delta_filter_wrapper.py:70-93) compute, calibrated on the MUMmer
-// output files the reference's tests hold) compiled for the HOST, fed by an exhaustive sorted 20-mer table instead of the
-// GPU's sampled LDS seeding, one ordered pair per thread.  MUMmer itself is third-party and absent from /root/reference and
+// output files the reference's tests hold) compiled for the HOST, fed by a sparse host 16-mer index (below) instead of the
+// GPU's sampled LDS seeding, one ordered pair per thread (two walker threads while a pair is in its extension stage).  MUMmer itself is third-party and absent from /root/reference and
 // from this image, so this is the only same-box CPU comparison there is: bench.py's `cpu_baseline` leg times it on all
 // host cores ("own-cpu") and tests use it as the scalar statement the GPU pipeline must equal.
 // Nothing under pyani_amd/ loads this library.

@@ -14,8 +14,9 @@ reference's names, argument meaning, result containers and error behaviour for e
     update_comparison_matrices-equivalent `assemble_run_matrices(pair_results, lengths)` -> 5 DataFrames (v0.3 semantics)
 
 The alignment search emulates MUMmer 3.23 (`nucmer --mum`, `delta-filter -1`), which is NOT part of the reference
-tree: it is calibrated against the MUMmer output files the reference's tests hold (all 17 fixture pairs with
-FASTA inputs are reproduced bit for bit; beyond the fixtures parity is unpinned).  `program`/`version` strings for DB rows
+tree: it is pinned twice — against the MUMmer output files the reference's tests hold (all 43 fixture runs with FASTA inputs,
+25 192 records, bit for bit) and, beyond the fixtures, against an independent restatement of MUMmer 3.23's own algorithms
+(the benchmark-scale golden records under tests/golden/, filter ON and OFF).  `program`/`version` strings for DB rows
 must therefore differ from "nucmer" (SURVEY.md §5): use PROGRAM / VERSION below.
 """
 import gzip

@@ -140,11 +140,16 @@ class DeltaIterator:
                     yield comparison
                 comparison = DeltaComparison(DeltaHeader(*f[:4]), [])
                 alignment = None
-            elif len(f) == 7 and comparison is not None:
+            elif len(f) == 1:
+                if alignment is None:
+                    raise ValueError(f"delta file: indel line {line.strip()!r} before any alignment header")
+                alignment.indels.append(f[0])
+            else:
+                # (the reference unpacks the 7 fields and raises on anything else, pyani/nucmer.py DeltaIterator)
+                if len(f) != 7 or comparison is None:
+                    raise ValueError(f"delta file: malformed alignment line {line.strip()!r}")
                 alignment = DeltaAlignment(*f)
                 comparison.add_alignment(alignment)
-            elif len(f) == 1 and alignment is not None:
-                alignment.indels.append(f[0])
         if comparison is not None:
             yield comparison
 
@@ -199,4 +204,4 @@ class DeltaData:
         return len(self._comparisons)
 
     def __str__(self):
-        return os.linesep.join([str(self._metadata)] + [str(c) for c in self._comparisons]) + os.linesep
+        return os.linesep.join([str(self._metadata)] + [str(c) for c in self._comparisons])
