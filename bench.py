@@ -162,6 +162,10 @@ def anim_cpu_baseline(args, data, n, related, gpu_lookup):
                   f"{t_rel:.2f} s per related pair, {t_unrel:.2f} s per unrelated pair; extrapolated linearly to "
                   f"{n_rel_job} related + {n_unrel_job} unrelated pairs on {threads} threads",
         "job_seconds_extrapolated": job_wall, "cpu_seconds_extrapolated": job_cpu_s,
+        "seconds_definition": "CPU seconds of the pair's own threads (CLOCK_THREAD_CPUTIME_ID: the pair's thread + the second strand's walker) — what a "
+                              "pool of PROCESSES, pyani's runner, pays per pair.  Rounds 3-4 charged wall seconds inside a thread of one 128-thread "
+                              "process, which includes the time a thread sleeps on the process-wide address-space lock while 127 others fault in "
+                              "their 40 MB indexes (r04: 5.4 s per unrelated pair against 0.6 CPU-s) and made the baseline ~8 x slower than the box is",
         "gpu_parity_on_sample": f"{same}/{covered_n} sampled pairs (of {len(sample)}; the others were not among the timed cells) identical to the GPU's result",
     }
 
