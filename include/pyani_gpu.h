@@ -115,7 +115,7 @@ int pg_tetra_corr_rows_dev(pg_ctx* ctx, const double* d_z, const uint8_t* d_pres
  * file.  status: 0 = ok; PG_ANIM_NO_ALIGNMENT = no alignment survived (parse_delta would raise ZeroDivisionError,
  * anim.py:396); PG_E_CAPACITY = internal buffers overflowed for this pair.
  * MUMmer itself is third-party and absent from the reference tree: behaviour is reconstructed and calibrated against
- * the MUMmer output files the reference's tests hold (DESIGN.md §ANIm: every fixture reproduced exactly).
+ * the MUMmer output files the reference's tests hold (DESIGN.md §4: every fixture reproduced exactly).
  * reserved = number of alignments BEFORE the 1-to-1 filter (what nucmer's .delta would hold). */
 typedef struct {
   int64_t ref_aln_len, qry_aln_len, sim_errors, n_alignments;
@@ -216,7 +216,7 @@ int pg_anib_reduce(pg_ctx* ctx, uint32_t n_pairs, const uint64_t* offsets, const
  * returns.  BLAST+ is third-party and absent from the reference tree; the search is a restatement of its documented
  * behaviour for this command line (blastn scoring 2 / -3 / 5 / 2, X-drop 150 bits, e-value 1e-15; seeds: exact 16-mers, then
  * blastn's 11-mer words for fragments those leave without a reportable hit), checked against the BLAST+ tables the reference's
- * tests hold (DESIGN.md §9: level of agreement per fixture).
+ * tests hold (DESIGN.md §6: level of agreement per fixture).
  * Limits: fragsize <= 1020 (pyani's default and maximum in practice; larger values are rejected with PG_E_ARG — the fragment's
  * DP lives in LDS).  Query genomes of any bacterial or fungal size: up to 15 872 fragments (16.1 Mb at 1020 nt) the per-fragment
  * counters sit in LDS, beyond that in HBM (round 5: there used to be a hard limit); only a query of more than ~10^6 fragments

@@ -48,7 +48,7 @@ static double DIAG_FACTOR = 0.12;
 static const long MAX_ALIGNMENT_LENGTH = 10000;
 // SCORES: nucleotide matrix of sw_alignscore.hh
 static int GOOD_SCORE = 3, BAD_SCORE = -7, OPEN_GAP_SCORE = -10, CONT_GAP_SCORE = -7;
-// open questions of the restatement, settled on the fixtures (tools/anim_host_fixture_check.py --oracle; DESIGN.md §8):
+// open questions of the restatement, settled on the fixtures (tools/anim_host_fixture_check.py --oracle; DESIGN.md §4, §5a):
 static long MAX_DIFF = -1;        // trim threshold; -1 = GOOD_SCORE * BREAK_LEN
 static int TRIM_STRICT = 1;       // 1: trim when high - value > MAX_DIFF, 0: >=
 static int FORCED_TRIM = 0;       // forced alignments (FORCED_BIT) neither break nor trim: with trimming 4 of the 43 fixture runs lose their way

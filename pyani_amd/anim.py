@@ -16,7 +16,7 @@ reference's names, argument meaning, result containers and error behaviour for e
 The alignment search emulates MUMmer 3.23 (`nucmer --mum`, `delta-filter -1`), which is NOT part of the reference
 tree: it is pinned twice — against the MUMmer output files the reference's tests hold (all 43 fixture runs with FASTA inputs,
 25 192 records, bit for bit) and, beyond the fixtures, against an independent restatement of MUMmer 3.23's own algorithms
-(the benchmark-scale golden records under tests/golden/, filter ON and OFF; DESIGN.md §8).  `program`/`version` strings for DB rows
+(the benchmark-scale golden records under tests/golden/, filter ON and OFF; DESIGN.md §4).  `program`/`version` strings for DB rows
 must therefore differ from "nucmer" (SURVEY.md §5): use PROGRAM / VERSION below.
 """
 import gzip

@@ -9,7 +9,7 @@
 // behaviour below is reconstructed from its published defaults (-l 20 -c 65 -g 90 -d 0.12 -D 5 -b 200) and calibrated
 // at the alignment-record level against the real MUMmer output the reference's tests hold (tests/golden/anim/):
 // with the rules below all 505 alignment records of the 17 fixture pairs that have both genomes, and all 12 734
-// delta-filter decisions of the 27 .delta/.filter fixture pairs, are reproduced exactly (DESIGN.md §ANIm).
+// delta-filter decisions of the 27 .delta/.filter fixture pairs, are reproduced exactly (DESIGN.md §4, §5).
 #pragma once
 #include <stdint.h>
 

@@ -6,7 +6,7 @@ generate_fastani_commands / construct_fastani_cmdline, `--fragLen 3000 -k 16 --m
 in-process on the GPU from the packed genomes already resident in HBM (pg_sketch_pairs, pyani_amd/csrc/pg_sketch.hip), with the same
 parameters, the same result tuple, the same result-file line and the same failure for pairs without a result — but by an estimator
 of its own (FracMinHash containment per query fragment: pyani_amd/csrc/pg_sketch_core.h), NOT by fastANI's MashMap pipeline: the
-numbers are fastANI-SHAPED estimates with their own error bar (DESIGN.md §11), kept in their own columns and files and never
+numbers are fastANI-SHAPED estimates with their own error bar (DESIGN.md §7), kept in their own columns and files and never
 written into the exact ANIm / ANIb matrices.  No CPU fallback: the functions that compute need an Engine."""
 from pathlib import Path
 from typing import Dict, Iterable, List, NamedTuple, Optional, Sequence, Tuple

@@ -10,7 +10,7 @@ comes back for more.  No data-path collective: results are merged on the host in
 path (`pyani_amd/parallel.py`, `bench.py --gpus N`: one process per GPU, one all-gather per step) stays what the driver's scaling
 run measures; this class is what `run_anim(..., devices=[...])` and the module functions use.
 
-A chunk keeps a pair and its reverse together (they share their seeding inside one `pg_anim_pairs` call, DESIGN.md §8 "Roles") and
+A chunk keeps a pair and its reverse together (they share their seeding inside one `pg_anim_pairs` call, DESIGN.md §5c "Roles") and
 keeps the pairs of one reference genome together (its seed table is built once per call).  Results do not depend on the number of
 devices or on which device ran what (tests/test_parallel_multi_gpu.py: two engines on GPU 0 == one).
 """

@@ -5,7 +5,7 @@
   blochmannia  every fixture pair of the 7 Blochmannia genomes (the in-sample set of rounds 1-2): whole files equal
   caulobacter  two pairs at 85-87 % identity (~1200 alignments each, wide forced runs): every record with its indel list equal;
                the record ORDER equals MUMmer's except where a forward- and a reverse-strand cluster start on the same reference
-               base — MUMmer's unstable sort of the clusters decides those (DESIGN.md §8a "Traceback")
+               base — MUMmer's unstable sort of the clusters decides those (DESIGN.md §5b "Traceback")
 
 pyani/nucmer.py:170-290 reads these files (DeltaAlignment / DeltaComparison); anim.py:292-411 (parse_delta) reduces them.
 """

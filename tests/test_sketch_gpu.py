@@ -51,7 +51,7 @@ def test_sketch_pairs_equal_the_definition_bit_for_bit():
 
 
 def test_sketch_estimate_against_the_exact_engine():
-    """The estimate's error bar (DESIGN.md §11): on a family of one ancestor (substitution rates 0.1 % ... 15 %, indels, rearrangements:
+    """The estimate's error bar (DESIGN.md §7): on a family of one ancestor (substitution rates 0.1 % ... 15 %, indels, rearrangements:
     the benchmark generator) the sketch ANI runs HIGH by 0.07 ... 0.7 percentage points down to 90 % identity, stays within 2 points
     down to 80 % and within 4 below that (measured on MI355X: profiles/r05_sketch_vs_exact.json).  Why high: a k-mer estimator
     counts an indel EVENT as one change, nucmer's error count every indel BASE (~0.085 x the divergence on this generator's indel

@@ -5,7 +5,7 @@ against JSpecies' published tables (tests/golden/ref_targets/jspecies_output.tab
   TETRA  test_tetra_concordance  (:290-302)  correlation matrix within 0.1
   ANIb   test_anib_concordance   (:207-254)  cells >= 90 within 0.2, cells below within 5
 
-These genomes are the engine's HOLD-OUT: no constant of the search was chosen with them (DESIGN.md §8).  The ANIm tuples below
+These genomes are the engine's HOLD-OUT: no constant of the search was chosen with them (DESIGN.md §4).  The ANIm tuples below
 are those of the scalar host statement of MUMmer's algorithm (tools/anim_debug/anim_debug --exact), which the GPU has to
 reproduce exactly (round 4: the two 98 % cells moved by ONE error each — 49912 -> 49911, 49840 -> 49839 — when the chain extraction
 took mgaps' tie order, the earliest of equally scoring predecessors; the unfiltered records of both directions now equal the
