@@ -40,7 +40,9 @@ void free_genome(SketchGenome& S) {
 // grid: ~200 GB of the 288); a sketch that does not fit beside them takes their place — they are rebuilt on the next ANIm call.
 template <typename T>
 int sk_malloc(pg_ctx* ctx, T*& p, size_t n) {
-  if (hipMalloc(reinterpret_cast<void**>(&p), n * sizeof(T)) == hipSuccess) return PG_OK;
+  // (PYANI_SKETCH_ALLOC_FAIL under PYANI_DEV_KNOBS=1: every first attempt counts as failed, so that a test can walk the fallback)
+  static const bool fail_first = pg_dev_env("PYANI_SKETCH_ALLOC_FAIL") != nullptr;
+  if (!fail_first && hipMalloc(reinterpret_cast<void**>(&p), n * sizeof(T)) == hipSuccess) return PG_OK;
   (void)hipGetLastError();
   p = nullptr;
   pg_anim_free_scratch(ctx);

@@ -90,3 +90,39 @@ def test_sketch_estimate_against_the_exact_engine():
                                                                           "worst_abs_error_identity_ge_0.90": worst_hi, "worst_abs_error_identity_0.80_to_0.90": worst_mid,
                                                                           "worst_abs_error_identity_lt_0.80": worst_lo, "pairs": rows}, indent=1))
     assert n_cmp >= 20 and worst_hi < 0.01 and worst_mid < 0.02 and worst_lo < 0.04, (n_cmp, worst_hi, worst_mid, worst_lo)
+
+
+def test_sketch_allocation_that_does_not_fit_takes_the_anim_scratch_and_anim_recovers(tmp_path):
+    """After a 1000-genome ANIm grid ~200 GB of launch scratch and seed lists are held for reuse, and bench.py's sketch record ran out
+    of memory beside them (round 5).  A sketch allocation that fails now frees them (pg_anim_free_scratch) and tries again; the next
+    ANIm call rebuilds what it needs.  PYANI_SKETCH_ALLOC_FAIL (development knob) makes EVERY first attempt count as failed, so the
+    path runs without filling 288 GB: ANIm -> sketches -> ANIm must give the same ANIm records twice and the same sketch records as
+    a process without the knob."""
+    import os
+    import subprocess
+    script = r'''
+import hashlib, sys
+from pyani_amd import synth
+from pyani_amd.engine import Engine
+data = [synth.genome(20250228, 50, g, 150_000) for g in (0, 2, 4, 1)]
+with Engine(0) as eng:
+    ids = [eng.add_genome(s, o) for s, o in data]
+    r = [a for a in ids for b in ids if a != b]; q = [b for a in ids for b in ids if a != b]
+    first = eng.anim_pairs(r, q)
+    sk = eng.sketch_pairs(r, q)
+    again = eng.anim_pairs(r, q)
+    sk2 = eng.sketch_pairs(r, q)
+    assert first.tobytes() == again.tobytes() and sk.tobytes() == sk2.tobytes()
+    assert int((first["n_alignments"] > 0).sum()) >= 6
+    print("HASH", hashlib.sha1(first.tobytes()).hexdigest(), hashlib.sha1(sk.tobytes()).hexdigest())
+'''
+    outs = []
+    for knob in ("1", None):
+        env = dict(os.environ, PYANI_DEV_KNOBS="1", PYTHONPATH=str(ROOT))
+        env.pop("PYANI_SKETCH_ALLOC_FAIL", None)
+        if knob:
+            env["PYANI_SKETCH_ALLOC_FAIL"] = knob
+        r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0, r.stderr[-800:]
+        outs.append([ln for ln in r.stdout.splitlines() if ln.startswith("HASH")][0])
+    assert outs[0] == outs[1], outs
