@@ -54,3 +54,18 @@ def test_read_delta_with_indel_lists_equals_the_independent_reader():
         assert [r[2:] for r in recs] == [(a.rs, a.re, a.qs, a.qe, a.errors) for a in want]
         assert lists == [list(a.indels) for a in want]
         assert recs == anim.read_delta(f)
+
+
+def test_str_has_no_trailing_newline_and_malformed_lines_raise():
+    """As the reference's model (pyani/nucmer.py): str(DeltaData) is the joined lines without a final line separator, an alignment
+    header that does not have its 7 fields raises (the reference unpacks them), and so does an indel line before any alignment."""
+    import pytest
+    from pyani_amd.nucmer import DeltaData
+    good = "/a.fna /b.fna\nNUCMER\n>r q 100 90\n1 50 1 50 0 0 0\n5\n-3\n0\n"
+    d = DeltaData("x", io.StringIO(good))
+    assert str(d) == good.rstrip("\n").replace("\n", __import__("os").linesep) and not str(d).endswith("\n")
+    for bad in ("/a /b\nNUCMER\n>r q 100 90\n1 50 1 50 0 0\n0\n",           # six fields
+                "/a /b\nNUCMER\n>r q 100 90\n7\n1 50 1 50 0 0 0\n0\n",       # an indel offset before any alignment
+                "/a /b\nNUCMER\n1 50 1 50 0 0 0\n0\n"):                      # an alignment before any header
+        with pytest.raises(ValueError):
+            DeltaData("x", io.StringIO(bad))
