@@ -981,6 +981,8 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
         const char* kn[8] = {"gaps", "forward", "backward-ahead", "walks", "forced narrow", "forced 512-1024", "forced 2048", "forced group 8192"};
         for (int k = 0; k < 8; ++k)
           fprintf(stderr, "[pn-stats] diagonal engine in %-16s: %llu calls, %llu anti-diagonals, %llu cells\n", kn[k], ks[4 * k], ks[4 * k + 1], ks[4 * k + 2]);
+        fprintf(stderr, "[pn-stats] walk kernel scans: shadow test %.1f ms over %llu rows of 64 alignments, reverse-target search %.1f ms in %llu calls (summed over waves)\n",
+                ks[3] / 1e5, ks[7], ks[11] / 1e5, ks[15]);
       }
       for (int k = 13; k <= 17; k += 4)      // ticks of the 100 MHz wall clock -> ms
         fprintf(stderr, "[pn-stats] %s: busy %.1f ms summed over waves, span %.1f ms, longest item %.1f ms (size %llu)\n", k == 13 ? "units" : "forced",

@@ -160,6 +160,19 @@ int main(int argc, char** argv) {
         for (int k = 0; k < n_chains; ++k) fw[k] = pgn::postnuc_forward(eng, chains.data(), cm.data(), co.data(), n_chains, k, bounds_of);
         eng.fwd = fw.data();
       }
+      // ... and every match-to-match alignment (the GPU's gap pre-pass): the walk takes runs of them at once (ScalarEngine::gap_run)
+      std::vector<pgn::PnGap> gp;
+      if (getenv("ANIM_HOIST") && !want_delta) {
+        gp.assign(n_cm + 1, pgn::PnGap{0, 0, 0, -1});
+        for (int c = 0; c < n_chains; ++c)
+          for (int m = 0; m + 1 < chains[c].count; ++m) {
+            const Match a = cm[chains[c].first + m], b = cm[chains[c].first + m + 1];
+            int32_t tA = b.r, tB = b.q, err = 0;
+            const bool reached = eng.align(a.r + a.len - 1, tA, a.q + a.len - 1, tB, pgn::FORWARD_ALIGN, err);
+            gp[chains[c].first + m] = pgn::PnGap{tA, tB, err, (reached && !eng.overflow) ? 1 : 0};
+          }
+        eng.gaps = gp.data();
+      }
       // ANIM_BWD_AHEAD (with ANIM_HOIST): the walk rehearsed without its backward searches, the searches it predicts run ahead, the real
       // walk takes those whose arguments it repeats — what the GPU's backward pre-pass does (results must not change; the rate is printed)
       std::vector<pgn::PnBwd> bwd;
