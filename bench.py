@@ -64,7 +64,9 @@ def parse_args():
     ap.add_argument("--no-tetra", action="store_true", help="anim: skip the nested C2 TETRA sub-record")
     ap.add_argument("--roofline-tiles", type=int, default=0, help="anim: how many tiles the one-worker roofline pass covers (0 = every tile of the grid)")
     ap.add_argument("--no-side-records", action="store_true", help="anim: skip related_only / unrelated_only / strong-step side records")
-    ap.add_argument("--static-deal", action="store_true", help="anim, N > 1: deal a step's rows by the fixed hash (round 3) instead of the cross-rank queue")
+    ap.add_argument("--dynamic-deal", action="store_true", help="anim, N > 1: the ranks pull a step's rows in guided chunks from a cross-rank counter (round 4's default) "
+                                                               "instead of the fixed scrambled deal, one call per rank and step")
+    ap.add_argument("--static-deal", action="store_true", help="(the default since round 5; accepted for older command lines)")
     ap.add_argument("--cold-e2e", action="store_true", help="anim, N = 1: measure ONE cold end-to-end run instead of the step loop: FASTA files on disk -> "
                     "parse + pack (pg_add_fasta_batch) -> upload -> seed lists -> the whole grid -> run matrices -> JSON, one wall clock")
     args = ap.parse_args()
@@ -484,10 +486,13 @@ def run_anim(args, rank, world, local, dist, torch):
     t_prep = time.perf_counter() - t_prep
     dev = torch.device("cpu") if REHEARSAL else torch.device("cuda", local)
     lens = np.array([len(d[0]) for d in data], dtype=np.int64)
-    # N > 1: the ranks PULL a step's rows in guided chunks from a cross-rank counter (pyani_amd.parallel.RowQueue: pair cost
-    # varies ~60 x and a static deal leaves the step waiting for its unluckiest rank); --static-deal: the fixed hash of round 3
+    # N > 1: a step's rows are dealt over the ranks in a fixed scrambled order, ONE engine call per rank and step (measured on
+    # MI355X, profiles/r05_deal_probe.json: the 8 shares of a C4 step are within 2 - 5 % of each other, while a call of 6 rows costs
+    # 2.5 x as much per row as a call of 100 — every call pays the tails of its kernels — so round 4's dynamic deal ran at 48 % of
+    # the plain rate).  --dynamic-deal: the ranks PULL guided chunks from a cross-rank counter (pyani_amd.parallel.RowQueue), for
+    # jobs whose cost sits in a few rows.
     queue = None
-    if dist is not None and not args.static_deal:
+    if dist is not None and args.dynamic_deal:
         queue = parallel.RowQueue(rank, world, os.environ.get("MASTER_ADDR", "127.0.0.1"))      # (the counter sits in the job's own rendezvous store)
 
     def rows_of(step, rows_per_step=None):
@@ -512,7 +517,10 @@ def run_anim(args, rank, world, local, dist, torch):
                 if keep:
                     imbalance.append(st)
             else:
-                grid = parallel.anim_allgather(compute, n, dev, rows=rows, symmetric=True)
+                st = {}
+                grid = parallel.anim_allgather(compute, n, dev, rows=rows, symmetric=True, stats=st)
+                if keep:
+                    imbalance.append(st)
             vals = grid[torch.from_numpy(pairs[:, 0]).to(dev), torch.from_numpy(pairs[:, 1]).to(dev)]
         if keep:
             tiles[k] = (pairs, vals)
@@ -700,7 +708,8 @@ def run_anim(args, rank, world, local, dist, torch):
             "imbalance": None if not imbalance else {
                 "max_over_mean_rank_busy_time_per_step": [round(st["imbalance"], 4) for st in imbalance],
                 "mean": float(np.mean([st["imbalance"] for st in imbalance])), "worst": float(max(st["imbalance"] for st in imbalance)),
-                "chunks_per_rank_last_step": imbalance[-1]["chunks"], "dealing": f"guided chunks from a cross-rank counter (pyani_amd.parallel.RowQueue, {queue.kind if queue else 'static'})"},
+                "chunks_per_rank_last_step": imbalance[-1]["chunks"], "dealing": (f"guided chunks from a cross-rank counter (pyani_amd.parallel.RowQueue, {queue.kind})" if queue else
+                                                                        "fixed scrambled deal of the step's rows, one engine call per rank and step (pyani_amd.parallel.anim_row_shard)")},
             "config": {
                 "workload": f"C4: ANIm N x N grid on {n} synthetic ~{args.length / 1e6:g} Mb genomes (SURVEY.md §8(d) generator, seed "
                             f"{args.seed}; {n * (n - 1)} ordered pairs, {n * (n // K - 1)} of them between descendants of one ancestor); "

@@ -105,7 +105,7 @@ def anim_pair_array(n_genomes: int, rows: Sequence[int], symmetric: bool = False
 
 
 def anim_allgather(compute_pairs: Callable, n_genomes: int, device: torch.device, group=None,
-                   rows: Optional[Sequence[int]] = None, symmetric: bool = False) -> torch.Tensor:
+                   rows: Optional[Sequence[int]] = None, symmetric: bool = False, stats: Optional[dict] = None) -> torch.Tensor:
     """compute_pairs(pairs: int64 ndarray [m, 2] of (q, s)) -> int64 tensor [m, ANIM_FIELDS] on `device` (identity as its
     IEEE-754 bit pattern).
     rows = None: the whole grid -> [n, n, ANIM_FIELDS] on every rank (diagonal zero).  rows = a list of genomes (one step
@@ -132,11 +132,23 @@ def anim_allgather(compute_pairs: Callable, n_genomes: int, device: torch.device
         cap = rows_max * max(n_genomes - 1, 0)
     assert len(mine) <= cap
     loc = torch.zeros((cap, ANIM_FIELDS + 2), dtype=torch.int64, device=device)
+    busy = 0.0
     if len(mine):
+        import time
+        t0 = time.perf_counter()
         vals = compute_pairs(mine)
+        if vals.is_cuda:
+            torch.cuda.synchronize(vals.device)
+        busy = time.perf_counter() - t0
         loc[: len(mine), :ANIM_FIELDS] = vals
         loc[: len(mine), ANIM_FIELDS:] = torch.from_numpy(mine).to(device)
     loc[len(mine):, ANIM_FIELDS] = -1
+    if stats is not None:      # (a second, 8-byte collective: the ranks' busy seconds of this step)
+        allb = torch.zeros(world, dtype=torch.float64, device=device)
+        dist.all_gather_into_tensor(allb, torch.tensor([busy], dtype=torch.float64, device=device), group=group)
+        b = allb.cpu().tolist()
+        mean = sum(b) / len(b)
+        stats.update({"busy_s": b, "chunks": [1] * world, "imbalance": (max(b) / mean) if mean > 0 else 1.0})
     allv = torch.zeros((world * cap, ANIM_FIELDS + 2), dtype=torch.int64, device=device)
     dist.all_gather_into_tensor(allv, loc, group=group)
     valid = allv[:, ANIM_FIELDS] >= 0
@@ -322,10 +334,12 @@ class DistributedEngine:
     rank holding a LOCAL engine with all genomes resident (they are small: 1.9 GB for 1000 x 5 Mb).  `anim_pairs` is a COLLECTIVE
     call — every rank makes it with the same arguments, as every rank runs the same `run_anim` — that
 
-      * cuts the pair list into chunks by hub genome (a pair and its reverse stay together: they share their seeding), about
-        24 per rank, handed out through the cross-rank counter (RowQueue: the rank that drew cheap, unrelated pairs comes back
-        for more while another is still inside a family — pyani's own runner is such a pool, run_multiprocessing.py:113-152),
-      * computes the rank's chunks on its engine, and
+      * deals the pair list by hub genome (a pair and its reverse stay together: they share their seeding) into one scrambled share
+        per rank, ONE engine call each (pyani_amd.multi._static_parts_by_hub: measured on C4 the shares of 8 ranks are within 2 - 5 %
+        of each other, and every extra call pays its kernels' tails again); `dynamic=True`: chunks of 1 / chunks_per_rank of a
+        share handed out through the cross-rank counter (RowQueue: the rank that drew cheap pairs comes back for more — pyani's own
+        runner is such a pool, run_multiprocessing.py:113-152 — for jobs whose cost sits in a few genomes),
+      * computes the rank's share on its engine, and
       * assembles the result with ONE all-gather per call (the 40-byte records + the pair's index, padded to the largest share),
 
     so that every rank returns the complete array in the caller's order: the counterpart of pyani's `--workers` (subcmd_anim.py:
@@ -335,11 +349,12 @@ class DistributedEngine:
     rank alike.  Results do not depend on the number of ranks or on who computed what (tests/test_parallel_gloo.py, world size 2 on
     CPU with a recording engine; tests/test_parallel_multi_gpu.py: two gloo ranks on GPU 0 and one RCCL rank == a plain engine)."""
 
-    def __init__(self, local_engine, group=None, queue: Optional["RowQueue"] = None, chunks_per_rank: int = 24):
+    def __init__(self, local_engine, group=None, queue: Optional["RowQueue"] = None, chunks_per_rank: int = 24, dynamic: bool = False):
         self.local = local_engine
         self.group = group
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
-        self.queue = queue or RowQueue(self.rank, self.world)
+        self.dynamic = bool(dynamic) or queue is not None
+        self.queue = (queue or RowQueue(self.rank, self.world)) if self.dynamic else None
         self.chunks_per_rank = chunks_per_rank
         self.device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
         self.last_stats = None
@@ -350,7 +365,7 @@ class DistributedEngine:
     def anim_pairs(self, ref_ids, qry_ids, filter_1to1: bool = True, maxmatch: bool = False):
         import time
         import numpy as np
-        from .multi import _chunks_by_hub
+        from .multi import _chunks_by_hub, _static_parts_by_hub
         r = np.ascontiguousarray(list(ref_ids), dtype=np.int32)
         q = np.ascontiguousarray(list(qry_ids), dtype=np.int32)
         if len(r) != len(q):
@@ -359,11 +374,17 @@ class DistributedEngine:
         proto = self.local.anim_pairs(r[:0], q[:0], filter_1to1=filter_1to1, maxmatch=maxmatch)      # (dtype of the records)
         if n == 0 or self.world == 1:
             return self.local.anim_pairs(r, q, filter_1to1=filter_1to1, maxmatch=maxmatch)
-        chunks = _chunks_by_hub(r, q, max(64, n // (self.chunks_per_rank * self.world) + 1))
-        token = self.queue.step_token("anim_pairs")
+        if self.dynamic:
+            chunks = _chunks_by_hub(r, q, max(64, n // (self.chunks_per_rank * self.world) + 1))
+            token = self.queue.step_token("anim_pairs")
+            draw = lambda: self.queue.next_chunk(token)      # noqa: E731
+        else:
+            chunks = _static_parts_by_hub(r, q, self.world)
+            mine = iter([self.rank] if self.rank < len(chunks) else [])
+            draw = lambda: next(mine, len(chunks))           # noqa: E731
         mine_idx, mine_rec, busy = [], [], 0.0
         while True:
-            k = self.queue.next_chunk(token)
+            k = draw()
             if k >= len(chunks):
                 break
             idx = chunks[k]

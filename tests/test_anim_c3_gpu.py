@@ -89,17 +89,20 @@ def test_bench_two_ranks_on_one_gpu_equal_single_rank(tmp_path):
         assert rec["roofline"]["kernel"].startswith("anim_") and rec["roofline"]["achieved"] > 0
 
 
-def test_bench_four_ranks_on_one_gpu_with_dynamic_dealing_equal_single_rank(tmp_path):
+def test_bench_four_ranks_on_one_gpu_equal_single_rank_with_either_dealing(tmp_path):
     """FOUR ranks on GPU 0 over gloo, each with its own Engine (two host workers, its own scratch — sized
-    against the HBM that is free at the time: pg_api.cpp anim_match_budget), the step's rows PULLED from the cross-rank counter
-    (RowQueue in the job's rendezvous store, the default) — the configuration in which host threads, streams and scratch of several
-    processes contend for one device.  Same full-grid hash as one rank; every rank drew chunks."""
+    against the HBM that is free at the time: pg_api.cpp anim_match_budget) — the configuration in which host threads, streams and
+    scratch of several processes contend for one device.  With the default dealing (round 5: the fixed scrambled deal, one engine
+    call per rank and step) and with --dynamic-deal (the step's rows PULLED from the cross-rank counter, RowQueue in the job's
+    rendezvous store): the same full-grid hash as one rank."""
     args = ["--genomes", "48", "--length", "300000", "--seed", "11", "--rows-per-step", "24", "--steps", "2", "--warmup", "0", "--no-cpu-baseline", "--no-tetra"]
     one = _bench({}, 1, tmp_path, "one48", args)
     four = _bench({"PYANI_BENCH_DEBUG_ONE_GPU": "1"}, 4, tmp_path, "four48", args)
     assert one["config"]["results_sha1_full_grid"] and one["config"]["results_sha1_full_grid"] == four["config"]["results_sha1_full_grid"]
-    assert four["n_gpus"] == 4 and four["imbalance"] and len(four["imbalance"]["chunks_per_rank_last_step"]) == 4
-    assert "job-store" in four["imbalance"]["dealing"] and sum(four["imbalance"]["chunks_per_rank_last_step"]) >= 4
+    assert four["n_gpus"] == 4 and four["imbalance"]["chunks_per_rank_last_step"] == [1, 1, 1, 1] and four["imbalance"]["dealing"].startswith("fixed scrambled deal")
+    dyn = _bench({"PYANI_BENCH_DEBUG_ONE_GPU": "1"}, 4, tmp_path, "four48d", args + ["--dynamic-deal"])
+    assert dyn["config"]["results_sha1_full_grid"] == one["config"]["results_sha1_full_grid"]
+    assert "job-store" in dyn["imbalance"]["dealing"] and sum(dyn["imbalance"]["chunks_per_rank_last_step"]) >= 4
 
 
 def test_bench_fragment_mode_two_ranks_equal_single_rank(tmp_path):

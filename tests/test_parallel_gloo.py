@@ -216,10 +216,17 @@ def test_eight_rank_dress_rehearsal_of_the_bench_control_flow():
     weak / fixed-grid / strong-step series, the imbalance record, the result hash — launched exactly as the driver launches it
     (torch.distributed.run, 8 ranks), on CPU over gloo with a stub engine that sleeps a C4-like cost model (PYANI_BENCH_REHEARSAL=1:
     a related pair ~130 x an unrelated one, families 4 x apart: the proportions measured on C4).  The 8-rank grid must equal the 1-rank grid cell for cell (hash),
-    the line must carry what the driver's scaling run reads, and the dynamic dealing must keep the ranks within 25 % of each other."""
+    the line must carry what the driver's scaling run reads, and the dealing must keep the ranks within 25 % of each other — both the
+    default since round 5 (the fixed scrambled deal, one call per rank and step: measured on MI355X the better one, profiles/
+    r05_deal_probe.json) and --dynamic-deal (round 4's guided chunks from the cross-rank counter)."""
     slow = {"PYANI_BENCH_REHEARSAL_SCALE": "2"}      # a step of ~0.8 s per rank: process wake-up skew (8 ranks on a few cores) must not be what is measured
     one = _rehearsal(1, ["--steps", "10", "--warmup", "0"], slow)
-    eight = _rehearsal(8, ["--steps", "2", "--warmup", "1"], slow)
+    default = _rehearsal(8, ["--steps", "2", "--warmup", "1"], slow)
+    assert default["n_gpus"] == 8 and default["config"]["results_sha1_full_grid"] == one["config"]["results_sha1_full_grid"]
+    assert default["imbalance"]["dealing"].startswith("fixed scrambled deal") and default["imbalance"]["chunks_per_rank_last_step"] == [1] * 8
+    assert default["imbalance"]["worst"] <= 1.25, default["imbalance"]
+    assert default["value"] > 2.5 * one["value"], (one["value"], default["value"])
+    eight = _rehearsal(8, ["--steps", "2", "--warmup", "1", "--dynamic-deal"], slow)
     assert one["n_gpus"] == 1 and eight["n_gpus"] == 8 and eight["scaling"] == "weak" and "REHEARSAL" in eight["data"]
     assert one["config"]["results_sha1_full_grid"] and one["config"]["results_sha1_full_grid"] == eight["config"]["results_sha1_full_grid"]
     assert eight["config"]["rows_per_step"] == 800 and eight["series"]["weak"]["rows_per_step_per_gpu"] == 100
@@ -230,9 +237,9 @@ def test_eight_rank_dress_rehearsal_of_the_bench_control_flow():
     # the weak series scales: 8 ranks do 8 x the rows per step (not 8 x here: the step's all-gather and grid assembly run on the CPU
     # over gloo in this rehearsal — 64 MB per step through loopback with 8 processes on a few cores; on the GPU box they are RCCL / HBM)
     assert eight["value"] > 2.5 * one["value"], (one["value"], eight["value"])
-    # the fixed scrambled deal of round 3 (--static-deal) must give the same grid
-    static = _rehearsal(8, ["--steps", "2", "--warmup", "1", "--static-deal"])
-    assert static["config"]["results_sha1_full_grid"] == one["config"]["results_sha1_full_grid"]
+    # (--static-deal, the flag of older command lines, is still accepted)
+    static = _rehearsal(2, ["--steps", "1", "--warmup", "0", "--static-deal"])
+    assert static["imbalance"]["dealing"].startswith("fixed scrambled deal")
 
 
 def _dist_engine_worker(rank, world, port, out_dir):
@@ -263,6 +270,9 @@ def _dist_engine_worker(rank, world, port, out_dir):
         loc = Recording()
         eng = parallel.engine_for_process_group(loc)
         assert isinstance(eng, parallel.DistributedEngine) and eng.genome_count() == 17      # (everything else is the local engine's)
+        assert not eng.dynamic and eng.queue is None                                        # default: one scrambled share per rank, no counter
+        if os.environ.get("PYANI_TEST_DYNAMIC") == "1":
+            eng = parallel.DistributedEngine(loc, dynamic=True)
         n = 29
         pairs = [(a, b) for a in range(n) for b in range(n) if a != b]
         r, q = [a for a, _ in pairs], [b for _, b in pairs]
@@ -280,6 +290,8 @@ def _dist_engine_worker(rank, world, port, out_dir):
         for cr, cq in loc.calls:
             have = set(zip(cr.tolist(), cq.tolist()))
             assert all((b, a) in have for a, b in have)
+        if not eng.dynamic:
+            assert sum(1 for c in loc.calls if len(c[0])) == 2 and eng.last_stats["chunks"] == world      # ONE engine call per collective call
         if rank == 0:
             np.save(os.path.join(out_dir, "ok.npy"), np.array(eng.last_stats["pairs"]))
     finally:
@@ -290,6 +302,10 @@ def test_distributed_engine_is_a_collective_anim_pairs_with_one_all_gather(tmp_p
     """The product's cross-process path (pyani_amd.parallel.DistributedEngine: what run_anim wraps its engine in under
     torch.distributed): world size 2 over gloo with a recording local engine — the complete result on every rank in the caller's
     order, every pair computed exactly once, a pair and its reverse on the same rank."""
-    port = _free_port()
-    mp.spawn(_dist_engine_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
-    assert int(np.load(tmp_path / "ok.npy").sum()) == 29 * 28
+    for dynamic in ("0", "1"):
+        os.environ["PYANI_TEST_DYNAMIC"] = dynamic
+        try:
+            mp.spawn(_dist_engine_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+        finally:
+            os.environ.pop("PYANI_TEST_DYNAMIC", None)
+        assert int(np.load(tmp_path / "ok.npy").sum()) == 29 * 28

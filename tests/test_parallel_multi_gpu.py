@@ -23,6 +23,27 @@ def test_chunks_keep_a_pair_with_its_reverse_and_cover_the_list():
     assert all(len(ks) == 1 for ks in where.values())          # both directions (and repeats) of a pair share a chunk
 
 
+def test_static_shares_keep_a_pair_with_its_reverse_cover_the_list_and_are_even():
+    """The default deal of MultiEngine / DistributedEngine since round 5: one scrambled share per device, one engine call each
+    (pyani_amd.multi._static_parts_by_hub; measured on MI355X: profiles/r05_deal_probe.json)."""
+    from pyani_amd.multi import _static_parts_by_hub
+    n = 200
+    a, b = np.array([x for x in range(n) for y in range(n) if x != y]), np.array([y for x in range(n) for y in range(n) if x != y])
+    K = 8                                              # families at a fixed stride, as in the synthetic sets
+    for parts in (2, 3, 8):
+        shares = _static_parts_by_hub(a, b, parts)
+        assert len(shares) == parts and sorted(np.concatenate(shares).tolist()) == list(range(len(a)))
+        where = {}
+        for k, c in enumerate(shares):
+            for i in c:
+                where.setdefault(frozenset((int(a[i]), int(b[i]))), set()).add(k)
+        assert all(len(ks) == 1 for ks in where.values())
+        sizes = [len(c) for c in shares]
+        related = [int(((a[c] % K) == (b[c] % K)).sum()) for c in shares]      # the expensive pairs
+        assert max(sizes) <= 1.15 * min(sizes) and max(related) <= 1.35 * (sum(related) / parts), (parts, sizes, related)
+    assert len(_static_parts_by_hub(a[:6], b[:6], 8)) <= 6                    # fewer groups than parts: no empty share
+
+
 @pytest.mark.gpu
 def test_two_engines_on_one_gpu_equal_one_engine():
     from pyani_amd import synth
@@ -45,6 +66,9 @@ def test_two_engines_on_one_gpu_equal_one_engine():
     assert got.tobytes() == want.tobytes()
     assert got_b.tobytes() == want_b.tobytes()
     assert (want["status"] == 0).sum() >= len(pairs) // 3
+    with MultiEngine([0, 0]) as two:                   # the default deal: one scrambled share per device, one call each
+        assert [two.add_genome(*d) for d in data] == ids
+        assert two.anim_pairs(ra, qa).tobytes() == want.tobytes() and two.last_chunks_per_engine == [1, 1]
 
 
 @pytest.mark.gpu
