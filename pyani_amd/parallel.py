@@ -113,6 +113,14 @@ def anim_allgather(compute_pairs: Callable, n_genomes: int, device: torch.device
     symmetric = True a row is what anim_pair_array(symmetric=True) says and the result is [n, n, ANIM_FIELDS] with the
     computed cells filled.  Rows are dealt over the ranks by anim_row_shard either way.
     One collective of 64 B per pair (results + the pair's own (q, s), so the gathered block is self-describing)."""
+    import time as _time
+    _t = [_time.perf_counter()]
+
+    def _mark():      # (only when the caller asked for stats: the device is drained so that the sections do not bleed into each other)
+        if stats is not None:
+            if device.type == "cuda":
+                torch.cuda.synchronize(device)
+            _t.append(_time.perf_counter())
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     all_rows = list(range(n_genomes)) if rows is None else list(rows)
     shards = [anim_row_shard(all_rows, r, world) for r in range(world)]
@@ -132,6 +140,7 @@ def anim_allgather(compute_pairs: Callable, n_genomes: int, device: torch.device
         cap = rows_max * max(n_genomes - 1, 0)
     assert len(mine) <= cap
     loc = torch.zeros((cap, ANIM_FIELDS + 2), dtype=torch.int64, device=device)
+    _mark()
     busy = 0.0
     if len(mine):
         import time
@@ -143,6 +152,7 @@ def anim_allgather(compute_pairs: Callable, n_genomes: int, device: torch.device
         loc[: len(mine), :ANIM_FIELDS] = vals
         loc[: len(mine), ANIM_FIELDS:] = torch.from_numpy(mine).to(device)
     loc[len(mine):, ANIM_FIELDS] = -1
+    _mark()
     if stats is not None:      # (a second, 8-byte collective: the ranks' busy seconds of this step)
         allb = torch.zeros(world, dtype=torch.float64, device=device)
         dist.all_gather_into_tensor(allb, torch.tensor([busy], dtype=torch.float64, device=device), group=group)
@@ -151,11 +161,15 @@ def anim_allgather(compute_pairs: Callable, n_genomes: int, device: torch.device
         stats.update({"busy_s": b, "chunks": [1] * world, "imbalance": (max(b) / mean) if mean > 0 else 1.0})
     allv = torch.zeros((world * cap, ANIM_FIELDS + 2), dtype=torch.int64, device=device)
     dist.all_gather_into_tensor(allv, loc, group=group)
+    _mark()
     valid = allv[:, ANIM_FIELDS] >= 0
     q, s = allv[valid, ANIM_FIELDS], allv[valid, ANIM_FIELDS + 1]
     if symmetric:
         grid = torch.zeros((n_genomes, n_genomes, ANIM_FIELDS), dtype=torch.int64, device=device)
         grid[q, s] = allv[valid, :ANIM_FIELDS]
+        _mark()
+        if stats is not None and len(_t) == 5:
+            stats["host_ms"] = {k: round((b - a) * 1e3, 2) for k, a, b in zip(("deal", "compute", "gathers", "grid"), _t[:-1], _t[1:])}
         return grid
     row_slot = torch.full((n_genomes,), -1, dtype=torch.int64, device=device)
     row_slot[torch.tensor(all_rows, dtype=torch.int64, device=device)] = torch.arange(len(all_rows), dtype=torch.int64, device=device)
