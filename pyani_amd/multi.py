@@ -147,19 +147,21 @@ class MultiEngine:
     # -- the work queue ----------------------------------------------------------------------------------------------------
     def _pull(self, chunks: List[np.ndarray], run_chunk, out: np.ndarray):
         lock = threading.Lock()
-        nxt = [0]
+        first = {id(e): i for i, e in enumerate(self.engines)}      # engine i starts on chunk i (the static shares: one each) ...
+        nxt = [min(len(self.engines), len(chunks))]                 # ... and then pulls what is left
         taken = defaultdict(int)
 
         def worker(e):
+            k = first[id(e)]
             while True:
-                with lock:
-                    k = nxt[0]
-                    nxt[0] += 1
                 if k >= len(chunks):
                     return
                 idx = chunks[k]
                 out[idx] = run_chunk(e, idx)
                 taken[id(e)] += 1
+                with lock:
+                    k = nxt[0]
+                    nxt[0] += 1
         self._all(worker)
         self.last_chunks_per_engine = [taken[id(e)] for e in self.engines]
 
