@@ -365,6 +365,9 @@ PG_HD int32_t forced_band_after(int32_t w, int32_t N, int32_t M, int32_t S) {
   const int64_t need = ((int64_t)GOOD_SCORE * mn + (int64_t)CONT_GAP_SCORE * df + 2 * (OPEN_GAP_SCORE - CONT_GAP_SCORE) - S) / (GOOD_SCORE - 2 * CONT_GAP_SCORE);
   const int64_t mx = N > M ? N : M;
   int64_t nw = need > (int64_t)w + 1 ? need : (int64_t)w + 1;
+  // a corner word at the score floor says nothing about how far off the band is (S is a bound, not a score): double, so that a run
+  // that has to end as "give up" (forced_verdict) gets to the whole rectangle in a few passes instead of four diagonals at a time
+  if (S <= -(int32_t)SCORE_BIAS && nw < 2 * ((int64_t)w + 1)) nw = 2 * ((int64_t)w + 1);
   nw = (nw + 3) & ~(int64_t)3;
   return (int32_t)(nw < mx ? nw : mx);
 }

@@ -385,6 +385,6 @@ def test_forced_runs_whose_optimal_path_dips_far_below_zero():
     count).  No walk can produce such a rectangle (a backward search breaks 200 anti-diagonals after its last best cell), so there
     is no genome pair that reaches this through the C ABI: the engines are driven directly."""
     exe = ROOT / "tools" / "anim_debug" / "forced_check"
-    subprocess.run(["g++", "-O2", "-std=c++17", f"-I{ROOT / 'pyani_amd' / 'csrc'}", str(exe) + ".cpp", "-o", str(exe)], check=True)
+    subprocess.run(["g++", "-O2", "-std=c++17", "-pthread", f"-I{ROOT / 'pyani_amd' / 'csrc'}", str(exe) + ".cpp", "-o", str(exe)], check=True)
     out = subprocess.run([str(exe)], capture_output=True, text=True)
     assert out.returncode == 0 and out.stdout.count(" ok") == 6 and "WRONG" not in out.stdout, out.stdout

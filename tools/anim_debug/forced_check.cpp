@@ -15,6 +15,7 @@
 // Prints one line per case and engine; exit code 0 iff all are as stated.   g++ -O2 -std=c++17 -Ipyani_amd/csrc forced_check.cpp
 #include <cstdio>
 #include <string>
+#include <thread>
 #include <vector>
 #include "pg_nucmer_diag.h"
 using namespace pga;
@@ -98,15 +99,21 @@ int main() {
   for (int i = 0; i < 30; ++i) { scattered.push_back(49); scattered.push_back(-1); }
   Case cases[] = {{"A deep dip", {20, -700, 1200}, 0, false}, {"B below floor", {20, -1500, 2500}, 0, true}, {"C ordinary", scattered, 0, false}};
   int bad = 0;
-  for (Case& c : cases) {
+  // the cases are independent and the emulated window engines are slow (64 lanes in software): one thread per case
+  std::string report[3];
+  int bad_of[3] = {0, 0, 0};
+  auto run_case = [&](int ci) {
+    Case& c = cases[ci];
+    char line[512];
     std::string a, b;
     build(c.runs, a, b);
     long long ref_score, ref_min; int ref_err;
     // (the engine's rectangle includes the base pair the path already stands on: cell (1, 1) = a[0] / b[0])
     reference(a, b, ref_score, ref_err, ref_min);
     c.want_errors = ref_err;
-    printf("%-14s plain-integer statement: score %lld, errors %d, lowest prefix of the optimal path %lld\n", c.name, ref_score, ref_err, ref_min);
-    if (c.want_fail ? ref_min >= -(long long)pgn::SCORE_BIAS : (ref_min < -(long long)pgn::SCORE_BIAS || (c.name[0] == 'A' && ref_min > -1100))) { printf("  the case is not what it claims to be\n"); ++bad; }
+    snprintf(line, sizeof line, "%-14s plain-integer statement: score %lld, errors %d, lowest prefix of the optimal path %lld\n", c.name, ref_score, ref_err, ref_min);
+    report[ci] += line;
+    if (c.want_fail ? ref_min >= -(long long)pgn::SCORE_BIAS : (ref_min < -(long long)pgn::SCORE_BIAS || (c.name[0] == 'A' && ref_min > -1100))) { report[ci] += "  the case is not what it claims to be\n"; ++bad_of[ci]; }
     const Packed PA(a), PB(b);
     const SeqView R = PA.view();
     const StrandView Q{PB.view(), 0};
@@ -125,10 +132,16 @@ int main() {
         overflow = eng.slow.overflow != 0;
       }
       const bool ok = c.want_fail ? (overflow && !reached) : (!overflow && reached && err == c.want_errors && A1 == (int32_t)a.size() - 1 && B1 == (int32_t)b.size() - 1);
-      printf("%-14s %-16s reached %d overflow %d errors %d (want %s%d) %s\n", c.name, which ? "DiagWaveEngine" : "ScalarEngine", (int)reached, (int)overflow, err,
-             c.want_fail ? "failure, not " : "", c.want_errors, ok ? "ok" : "WRONG");
-      bad += !ok;
+      snprintf(line, sizeof line, "%-14s %-16s reached %d overflow %d errors %d (want %s%d) %s\n", c.name, which ? "DiagWaveEngine" : "ScalarEngine", (int)reached, (int)overflow, err,
+               c.want_fail ? "failure, not " : "", c.want_errors, ok ? "ok" : "WRONG");
+      report[ci] += line;
+      bad_of[ci] += !ok;
     }
+  };
+  {
+    std::thread t0(run_case, 0), t1(run_case, 1), t2(run_case, 2);
+    t0.join(); t1.join(); t2.join();
   }
+  for (int ci = 0; ci < 3; ++ci) { fputs(report[ci].c_str(), stdout); bad += bad_of[ci]; }
   return bad ? 1 : 0;
 }
