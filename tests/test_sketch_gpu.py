@@ -126,3 +126,41 @@ with Engine(0) as eng:
         assert r.returncode == 0, r.stderr[-800:]
         outs.append([ln for ln in r.stdout.splitlines() if ln.startswith("HASH")][0])
     assert outs[0] == outs[1], outs
+
+
+def test_sketch_edge_genomes_equal_the_definition():
+    """Genomes the fragmenting rule leaves with NO fragment (shorter than frag_len; fastANI drops a record's tail and maps nothing),
+    an all-N genome, a genome of many short records, a record of exactly frag_len and one with an N run across a fragment
+    boundary: matches / fragments / status and the ANI bits as the numpy definition gives them; a query without fragments has no
+    result against anything (status PG_SKETCH_NO_RESULT, 0 fragments), and is a valid REFERENCE."""
+    import sketch_oracle as so
+    from pyani_amd import synth
+    from pyani_amd.engine import Engine
+    base, off = synth.genome(77, 4, 0, 60_000)
+    rng = np.random.default_rng(3)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    tiny = (base[:2_500].copy(), np.array([0, 2_500], dtype=np.uint64))                                   # < frag_len: no fragment
+    all_n = (np.full(9_000, ord("N"), dtype=np.uint8), np.array([0, 9_000], dtype=np.uint64))
+    shorts = (base[:30_000].copy(), np.arange(0, 30_001, 1_500, dtype=np.uint64))                          # 20 records of 1 500: no fragment
+    exact = (base[10_000:13_000].copy(), np.array([0, 3_000], dtype=np.uint64))                            # exactly one fragment
+    holed = base[:24_000].copy()
+    holed[2_990:3_020] = ord("N")                                                                          # an N run across the first boundary
+    holed = (holed, np.array([0, 12_000, 24_000], dtype=np.uint64))
+    rand = (acgt[rng.integers(0, 4, size=20_000)], np.array([0, 20_000], dtype=np.uint64))
+    data = [(base, off), tiny, all_n, shorts, exact, holed, rand]
+    sk = [so.genome_sketch(s, o) for s, o in data]
+    pairs = [(a, b) for a in range(len(data)) for b in range(len(data))]
+    with Engine(0) as eng:
+        ids = [eng.add_genome(s, o) for s, o in data]
+        res = eng.sketch_pairs([ids[a] for a, _ in pairs], [ids[b] for _, b in pairs])
+    for k, (a, b) in enumerate(pairs):
+        ani, matches, frags, status = so.sketch_pair(sk[a], sk[b], 0.2)
+        r = res[k]
+        assert (int(r["matches"]), int(r["fragments"]), int(r["status"])) == (matches, frags, status), (a, b, r)
+        assert float(r["ani"]).hex() == float(ani).hex(), (a, b)
+    by = {p: res[k] for k, p in enumerate(pairs)}
+    for q in (1, 2, 3):                                   # no fragment (or nothing but N): never a result as the query
+        assert all(int(by[(q, b)]["status"]) == 1 for b in range(len(data)))
+    assert int(by[(1, 0)]["fragments"]) == 0 and int(by[(3, 0)]["fragments"]) == 0 and int(by[(2, 0)]["fragments"]) == 3
+    assert int(by[(4, 0)]["status"]) == 0 and int(by[(4, 0)]["fragments"]) == 1 and float(by[(4, 0)]["ani"]) == 1.0      # one fragment, contained
+    assert int(by[(0, 1)]["matches"]) >= 0 and int(by[(5, 0)]["status"]) == 0
