@@ -798,6 +798,16 @@ def c5_length(g):
     return 1_000_000 + (g * 22_045) % 11_000_001
 
 
+def anib_traffic(kernel, args, n):
+    """HBM bytes per launch of the dominant C5 kernel from the committed PMC passes (profiles/pmc_anib.json: rocprofv3 --pmc FETCH_SIZE and
+    --pmc WRITE_SIZE in separate runs of `--workload anib --steps 1 --warmup 1`, FETCH_SIZE doubled per the gfx950 note of
+    MI355X_MICROARCH.md) — only for the configuration they were taken on."""
+    pmc = ROOT / "profiles" / "pmc_anib.json"
+    if not pmc.exists() or (n, args.seed) != (500, 20250302):
+        return None
+    return json.loads(pmc.read_text()).get("kernels", {}).get(kernel, {}).get("hbm_bytes_per_launch")
+
+
 def run_anib(args, rank, world, local, dist, torch):
     """C5: N = 500 synthetic genomes of 1-12 Mb, pyani's ANIb on the engine's fragment mode: the 1020-nt fragments of every
     genome against every other genome.  A step = `--rows-per-step` (10) fragmented genomes x all N - 1 subjects; N > 1 = strong
@@ -902,7 +912,7 @@ def run_anib(args, rank, world, local, dist, torch):
             },
             "roofline": {
                 "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None, "launches": int(dom_n), "avg_launch_ms": dom_ms / max(dom_n, 1),
+                "traffic": anib_traffic(dom, args, n), "launches": int(dom_n), "avg_launch_ms": dom_ms / max(dom_n, 1),
                 "definition": "SURVEY.md §8(d): ceil(Lq/4) + ceil(Ls/4) + 32 B per ordered pair / the HIP-event time of the stage that took "
                               "longest; the fragment DP is LDS / VALU work, not an HBM stream: the fraction is small by construction",
                 "stage_ms": {name: round(ms, 3) for name, (ms, _) in prof.items()}, "timed_region_ms": round(elapsed * 1e3, 3),

@@ -87,6 +87,14 @@ anib)    # C5 fragment mode at HEAD: the bench record, a kernel trace and one SQ
   f=$(find $O/anib_kt -name "*kernel_stats.csv" | head -1); cp $f $O/anib_kernel_stats.csv; head -8 $f | cut -c1-200
   python tools/summarize_pmc.py $O/anib_sq $O/anib_sq_summary.csv 2>&1 | tail -8
   find $O/anib_kt $O/anib_sq -name "*.csv" -size +20M -delete ;;
+anibpmc)   # HBM traffic of the C5 steps: FETCH_SIZE / WRITE_SIZE passes of the anib step's command (separate runs)
+  cd /tmp; rm -rf $O/anib_fetch $O/anib_write
+  A="python $R/bench.py --gpus 1 --workload anib --steps 1 --warmup 1 --no-cpu-baseline"
+  timeout -k 10 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/anib_fetch -o pmc -- $A > $O/anib_fetch.log 2>&1
+  timeout -k 10 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/anib_write -o pmc -- $A > $O/anib_write.log 2>&1
+  cd $R
+  for d in anib_fetch anib_write; do python tools/summarize_pmc.py $O/$d $O/${d}_summary.csv 2>&1 | tail -6 | cut -c1-200; done
+  find $O/anib_fetch $O/anib_write -name "*.csv" -size +20M -delete ;;
 final)   # what the driver runs at round end: smoke() and the default bench command (no flags), timed
   ( time timeout 900 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" ) > $O/smoke.log 2>&1; tail -5 $O/smoke.log
   ( time timeout 1500 python bench.py > $O/bench_default.log 2> $O/bench_default.err ) 2> $O/bench_default.time; echo "default bench rc=$?"; cat $O/bench_default.time

@@ -122,6 +122,22 @@ for src, dst in (("bench_anib_C5_n1.json", "r05_bench_anib_C5_n1.json"), ("anib_
                  ("anib_sq_summary.csv", "r05_anib_C5_pmc_sq_summary.csv")):
     if (SRC / src).exists() and (SRC / src).stat().st_size:
         shutil.copyfile(SRC / src, DST / dst)
+# ... and the HBM traffic of its kernels (FETCH_SIZE / WRITE_SIZE passes of one warm-up + one timed step): profiles/pmc_anib.json, read by bench.py
+af, aw = rows(SRC / "anib_fetch_summary.csv"), rows(SRC / "anib_write_summary.csv")
+if af and aw:
+    for w in ("fetch", "write"):
+        shutil.copyfile(SRC / f"anib_{w}_summary.csv", DST / f"r05_anib_C5_pmc_{w}_summary.csv")
+    a = {"round": "r05", "workload": "C5 (500 synthetic genomes of 1-12 Mb, seed 20250302), fragment mode",
+         "command": "python bench.py --gpus 1 --workload anib --steps 1 --warmup 1 --no-cpu-baseline under rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate runs)",
+         "correction": "FETCH_SIZE doubled (gfx950 rocprofv3 tallies 128-B read requests at 64 B, MI355X_MICROARCH.md §HBM: exact for wide coalesced streams, an upper "
+                       "bound for narrower accesses); WRITE_SIZE as reported (uncalibrated)", "kernels": {}}
+    for k in af:
+        if k in aw and (k.startswith("anib_") or k.startswith("anim_")):
+            n = int(af[k]["launches"])
+            fk, wk = float(af[k]["FETCH_SIZE_sum"]) / n, float(aw[k]["WRITE_SIZE_sum"]) / max(1, int(aw[k]["launches"]))
+            a["kernels"][k] = {"launches": n, "FETCH_SIZE_KiB_per_launch": fk, "WRITE_SIZE_KiB_per_launch": wk, "hbm_bytes_per_launch": int(2 * 1024 * fk + 1024 * wk)}
+    (DST / "pmc_anib.json").write_text(json.dumps(a, indent=1) + "\n")
+    print("anib:", {k: round(v["hbm_bytes_per_launch"] / 1e9, 2) for k, v in a["kernels"].items()})
 # TETRA (C2) at HEAD: kernel trace + FETCH / WRITE / SQ passes of `bench.py --workload tetra --steps 20 --warmup 5 --no-cpu-baseline`
 tk = SRC / "tetra_kernel_stats.csv"
 if tk.exists():
