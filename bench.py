@@ -69,6 +69,9 @@ def parse_args():
     ap.add_argument("--static-deal", action="store_true", help="(the default since round 5; accepted for older command lines)")
     ap.add_argument("--cold-e2e", action="store_true", help="anim, N = 1: measure ONE cold end-to-end run instead of the step loop: FASTA files on disk -> "
                     "parse + pack (pg_add_fasta_batch) -> upload -> seed lists -> the whole grid -> run matrices -> JSON, one wall clock")
+    ap.add_argument("--expect-sha", default="auto", help="anim: sha1 the whole N x N result grid must have (checked whenever the timed steps cover the grid): "
+                    "'auto' = the committed hash of the default C4 job (tests/golden/anim_c4_grid_sha1.txt) when the job IS the default C4 job, 'none' = no check; "
+                    "a mismatch fails the run loudly (exit code 3) after the line is printed")
     args = ap.parse_args()
     w = args.workload
     if args.steps is None:
@@ -676,7 +679,7 @@ def run_anim(args, rank, world, local, dist, torch):
                     "kernels": "anim_postnuc_{gaplane,gapbig,fwd,rehearse,bwd,(walk),forced,forced_wide,forced_huge}_kernel",
                     "achieved": cells / (ext_ms * 1e-3), "peak": peak_cells, "unit": "DP cells/s", "frac": cells / (ext_ms * 1e-3) / peak_cells,
                     "cells": cells, "anti_diagonals": int(cnt[1]), "extension_ms": ext_ms, "valu_instructions_per_cell": vpc,
-                    "salu_instructions_per_cell": spc,
+                    "salu_instructions_per_cell": spc, "instructions_per_cell_replayed": True,
                     "measured_in_this_run": "cells, anti_diagonals, extension_ms, per_kernel.{calls, anti_diagonals, cells, stage_ms, live_slot_fraction} (engine counters + HIP events of the one-worker pass over all tiles)",
                     "from_committed_profile": f"valu / salu instructions per cell, per_kernel.valu_instructions_per_cell ({pmc.get('extension_valu_source', 'profiles/pmc_anim.json')})",
                     "per_kernel": per_kernel,
@@ -689,7 +692,42 @@ def run_anim(args, rank, world, local, dist, torch):
         covered[P[:, 0], P[:, 1]] = True
         sha = hashlib.sha1(dense.tobytes()).hexdigest() if int(covered.sum()) == n * (n - 1) else None
         grid_s = elapsed / pairs_done * n * (n - 1)
-        measured_cold = pmc.get("end_to_end_cold_s_measured")
+        # ---- the line checks itself: (1) the cells of the grid just computed that are ALSO pairs of the committed goldens of
+        # the INDEPENDENT oracle (tests/golden/anim_oracle_family_digests.json.gz: two whole C4 families = 1 200 ordered pairs, made by
+        # oracle/nucmer_oracle.cpp + oracle/anim_oracle.py, which share no header with the engine) must hold the oracle's tuple bit for bit;
+        # (2) the whole-grid hash must be the committed one.  Both only read committed DATA (no oracle code runs here).
+        parity_indep, sha_check = None, None
+        if not REHEARSAL:
+            try:
+                import gzip
+                with gzip.open(ROOT / "tests" / "golden" / "anim_oracle_family_digests.json.gz", "rt") as fh:
+                    fam = json.load(fh)
+                if (fam["n"], fam["L"], fam["seed"]) == (n, args.length, args.seed):
+                    same = checked = 0
+                    first_bad = None
+                    for a_, b_, _nrec, _nkept, _h1, _h2, tup in fam["pairs"]:
+                        if not covered[a_, b_]:
+                            continue
+                        checked += 1
+                        c = dense[a_, b_]
+                        got_t = None if int(c[3]) == 0 else [int(c[0]), int(c[1]), float(np.int64(c[4]).view(np.float64)).hex(), int(c[2]), int(c[3])]
+                        if got_t == tup:
+                            same += 1
+                        elif first_bad is None:
+                            first_bad = {"ref": a_, "qry": b_, "gpu": got_t, "oracle": tup}
+                    parity_indep = {"identical": same, "checked": checked, "golden_pairs": len(fam["pairs"]), "first_difference": first_bad,
+                                    "what": "(ref_aln_len, qry_aln_len, identity bits, sim_errors, n_alignments) of pg_anim_pairs, filter on, against the committed goldens of the "
+                                            "independent oracle (oracle/nucmer_oracle.cpp + oracle/anim_oracle.py; tools/make_anim_family_hashes.py)"}
+            except Exception as exc:  # noqa: BLE001
+                parity_indep = {"error": repr(exc)}
+            want_sha = args.expect_sha
+            if want_sha == "auto":
+                f_ = ROOT / "tests" / "golden" / "anim_c4_grid_sha1.txt"
+                default_job = (n, args.length, args.seed) == (1000, 5_000_000, 20250301)
+                want_sha = f_.read_text().split()[0] if (default_job and f_.exists()) else "none"
+            if want_sha != "none" and sha is not None:
+                sha_check = {"expected": want_sha, "ok": sha == want_sha}
+        measured_cold = None       # (never replayed: `bench.py --cold-e2e` measures it; profiles/ holds the last measurement)
         out = {
             "metric": "genome-pairs/sec (ordered pairs) + wall-clock for the N x N ANIm grid: nucmer --mum + delta-filter -1 + "
                       "parse_delta equivalent per ordered pair, genomes resident in HBM; vs the CPU path on this box's host cores",
@@ -722,7 +760,7 @@ def run_anim(args, rank, world, local, dist, torch):
                 "grid_pairs": n * (n - 1), "wall_s_grid": grid_s,
                 "identity_related_min_med_max": [float(x) for x in np.percentile(ident[(status == 0) & related_m], [0, 50, 100])]
                 if ok_rel else None,
-                "results_sha1_full_grid": sha,
+                "results_sha1_full_grid": sha, "results_sha1_check": sha_check, "parity_vs_independent_oracle": parity_indep,
                 "parallelism": (f"1 process/GPU x {world}; genomes replicated; each step's rows "
                                 + ("pulled in guided chunks from a cross-rank counter" if queue is not None else "dealt over the ranks by a fixed hash")
                                 + "; one RCCL all-gather of 64 B per pair per step") if world > 1 else "1 GPU",
@@ -738,7 +776,8 @@ def run_anim(args, rank, world, local, dist, torch):
             },
             "roofline": {
                 "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_replayed": True,
+                "traffic_source": "profiles/pmc_anim.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (counters cannot be read inside a timed run); replayed, not measured in this run",
                 "algorithmic_bytes_per_launch": alg_prof / max(dom_n, 1), "avg_launch_ms": dom_ms / max(dom_n, 1),
                 "launches": int(dom_n),
                 "definition": "SURVEY.md §8(d): ceil(Lq/4) + ceil(Ls/4) + 32 B per ordered pair, summed over an untimed pass of EVERY tile of the grid "
@@ -784,6 +823,15 @@ def run_anim(args, rank, world, local, dist, torch):
         if world == 1 and not args.no_tetra:
             out["tetra"] = tetra_subrecord(eng, local, args.no_cpu_baseline)
         print(json.dumps(out), flush=True)
+        failed = []
+        if sha_check and not sha_check["ok"]:
+            failed.append(f"result grid sha1 {sha} != expected {sha_check['expected']}")
+        if parity_indep and parity_indep.get("checked") and parity_indep["identical"] != parity_indep["checked"]:
+            failed.append(f"independent-oracle parity {parity_indep['identical']}/{parity_indep['checked']}: {parity_indep['first_difference']}")
+        if failed:
+            print("bench.py: RESULT CHECK FAILED: " + "; ".join(failed), file=sys.stderr, flush=True)
+            eng.close()
+            sys.exit(3)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -4,6 +4,7 @@
   libanimcpu.so   oracle/anim_cpu.cpp     g++ -pthread              host statement of the ANIm pair search (own-cpu baseline)
   libanibcpu.so   oracle/anib_cpu.cpp     g++ -pthread              host statement of fragment mode (ANIb)
   _build/nucmer_oracle   oracle/nucmer_oracle.cpp   g++               restatement of MUMmer 3.23's nucmer pipeline (the ANIm search oracle)
+  libblastnoracle.so     oracle/blastn_oracle.cpp   g++ -pthread      restatement of BLAST+'s blastn for pyani's ANIb command line (the ANIb search oracle)
 """
 import subprocess
 import sys
@@ -67,8 +68,21 @@ def build_nucmer_oracle(force=False) -> Path:
     return NUCMER_ORACLE
 
 
+BLASTN_ORACLE_LIB = HERE / "libblastnoracle.so"
+
+
+def build_blastn_oracle(force=False) -> Path:
+    """oracle/blastn_oracle.cpp -> oracle/libblastnoracle.so: the independent restatement of blastn for pyani's ANIb command line
+    (includes nothing from pyani_amd/csrc)."""
+    src = HERE / "blastn_oracle.cpp"
+    if force or not _newer(BLASTN_ORACLE_LIB, [src]):
+        _run(["g++", "-O2", "-std=c++17", "-pthread", "-fPIC", "-shared", "-Wall", "-o", BLASTN_ORACLE_LIB, src])
+    return BLASTN_ORACLE_LIB
+
+
 def build_all(force=False):
-    return build_oracle(force), build_anim_cpu(force), build_anib_cpu(force), build_nucmer_oracle(force)
+    return (build_oracle(force), build_anim_cpu(force), build_anib_cpu(force), build_nucmer_oracle(force),
+            build_blastn_oracle(force))
 
 
 if __name__ == "__main__":

@@ -370,7 +370,13 @@ class DistributedEngine:
         self.dynamic = bool(dynamic) or queue is not None
         self.queue = (queue or RowQueue(self.rank, self.world)) if self.dynamic else None
         self.chunks_per_rank = chunks_per_rank
-        self.device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+        # collective buffers live on the LOCAL ENGINE's device (torch.cuda.current_device() is GPU 0 for every rank of a
+        # caller that never called torch.cuda.set_device)
+        dev_index = getattr(local_engine, "device", None)
+        if dist.get_backend(group) == "nccl":
+            self.device = torch.device("cuda", int(dev_index) if dev_index is not None else torch.cuda.current_device())
+        else:
+            self.device = torch.device("cpu")
         self.last_stats = None
 
     def __getattr__(self, name):      # genome store, reductions, single-pair calls: the local engine's
@@ -397,20 +403,35 @@ class DistributedEngine:
             mine = iter([self.rank] if self.rank < len(chunks) else [])
             draw = lambda: next(mine, len(chunks))           # noqa: E731
         mine_idx, mine_rec, busy = [], [], 0.0
+        # error agreement: a rank whose engine call fails (PG_E_NOMEM, PG_E_CAPACITY, a bad id) must not leave the others
+        # waiting in the all-gathers until the backend's timeout — it keeps drawing (so a shared queue still drains), reports the failure
+        # in the `meta` all-gather, and EVERY rank raises
+        failure = None
         while True:
             k = draw()
             if k >= len(chunks):
                 break
+            if failure is not None:
+                continue
             idx = chunks[k]
             t0 = time.perf_counter()
-            mine_rec.append(self.local.anim_pairs(r[idx], q[idx], filter_1to1=filter_1to1, maxmatch=maxmatch))
+            try:
+                mine_rec.append(self.local.anim_pairs(r[idx], q[idx], filter_1to1=filter_1to1, maxmatch=maxmatch))
+            except Exception as exc:  # noqa: BLE001
+                failure = exc
+                continue
             busy += time.perf_counter() - t0
             mine_idx.append(idx)
         n_mine = sum(len(i) for i in mine_idx)
-        meta = torch.tensor([float(n_mine), busy], dtype=torch.float64, device=self.device)
-        metas = torch.zeros(self.world * 2, dtype=torch.float64, device=self.device)
+        meta = torch.tensor([float(n_mine), busy, 0.0 if failure is None else 1.0], dtype=torch.float64, device=self.device)
+        metas = torch.zeros(self.world * 3, dtype=torch.float64, device=self.device)
         dist.all_gather_into_tensor(metas, meta, group=self.group)
-        metas = metas.cpu().numpy().reshape(self.world, 2)
+        metas = metas.cpu().numpy().reshape(self.world, 3)
+        failed_ranks = [int(k) for k in np.nonzero(metas[:, 2])[0]]
+        if failed_ranks:
+            if failure is not None:
+                raise failure
+            raise RuntimeError(f"DistributedEngine.anim_pairs: the engine call failed on rank(s) {failed_ranks} (see their tracebacks); no rank returns a result")
         cap = max(1, int(metas[:, 0].max()))
         words = proto.dtype.itemsize // 8      # (the record is 40 bytes = five 8-byte words; one more for the pair's index)
         loc = np.zeros((cap, words + 1), dtype=np.int64)
@@ -434,8 +455,9 @@ class DistributedEngine:
 
 
 def engine_for_process_group(local_engine, group=None):
-    """The engine run_anim should use: `local_engine` wrapped in a DistributedEngine when a process group with more than one rank is
-    initialised (one process per GPU, launched with torch.distributed.run), else `local_engine` itself."""
+    """`local_engine` wrapped in a DistributedEngine when a process group with more than one rank is initialised (one process per
+    GPU, launched with torch.distributed.run), else `local_engine` itself.  run_anim calls this only when asked to
+    (`run_anim(..., distributed=True)` / `group=`): a collective must never start behind the caller's back."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         return DistributedEngine(local_engine, group)
     return local_engine

@@ -47,11 +47,16 @@ def outfile_path(outdir: Path, qstem: str, sstem: str, nofilter: bool = False) -
 
 def run_anim(indir, outdir=None, recovery: bool = False, nofilter: bool = False, maxmatch: bool = False,
              write_output: bool = False, skip_zero: bool = False, engine: Optional[Engine] = None,
-             devices: Optional[List[int]] = None, workers: Optional[int] = None) -> AnimRun:
+             devices: Optional[List[int]] = None, workers: Optional[int] = None, distributed: bool = False, group=None) -> AnimRun:
     """ANIm over every FASTA file of `indir`.  outdir is needed for recovery / write_output only.
     devices / workers: run on several GPUs of this node (pyani's `--workers`, subcmd_anim.py:392-396, counts GPUs here): the
     comparisons are pulled from a work queue by one engine per device (pyani_amd/multi.py); ignored when `engine` is given.
-    Under torch.distributed (one process per GPU, world size > 1) the call is collective: see pyani_amd.parallel.DistributedEngine."""
+    distributed=True (or group=<a torch.distributed process group>): one process per GPU — the call is COLLECTIVE: EVERY rank of
+    the group must make it with the same arguments (pyani_amd.parallel.DistributedEngine deals the comparisons over the ranks and
+    assembles them with one RCCL all-gather; every rank returns the whole run).  In that mode rank 0 alone reads recovery files and
+    writes output files, and the list of comparisons still to run is broadcast from rank 0, so every rank provably deals the same
+    list.  Never implied: an initialised process group alone changes nothing (a library user calling run_anim on rank 0 only must
+    not deadlock in a collective; passing a DistributedEngine as `engine` is the other explicit way in)."""
     if write_output and outdir is None:
         raise ValueError("write_output needs an output directory")     # before any work is done
     own = None
@@ -61,20 +66,28 @@ def run_anim(indir, outdir=None, recovery: bool = False, nofilter: bool = False,
         own = engine if isinstance(engine, multi.MultiEngine) else None
     try:
         eng = engine or default_engine()
-        # one process per GPU (launched with torch.distributed.run): every rank runs this same call; the comparisons are dealt over
-        # the ranks and assembled with one RCCL all-gather (pyani_amd.parallel.DistributedEngine) — every rank returns the whole run.
-        # (output files and recovered files are handled by every rank alike: give the ranks their own outdir, or write on rank 0 only)
-        import sys
-        if "torch.distributed" in sys.modules:
+        coll = None
+        if distributed or group is not None:
             from . import parallel
-            eng = parallel.engine_for_process_group(eng)
-        return _run_anim(indir, outdir, recovery, nofilter, maxmatch, write_output, skip_zero, eng)
+            eng = parallel.engine_for_process_group(eng, group)
+        if type(eng).__name__ == "DistributedEngine" and eng.world > 1:
+            coll = eng
+        return _run_anim(indir, outdir, recovery, nofilter, maxmatch, write_output, skip_zero, eng, coll)
     finally:
         if own is not None:
             own.close()
 
 
-def _run_anim(indir, outdir, recovery, nofilter, maxmatch, write_output, skip_zero, eng) -> AnimRun:
+def _bcast(coll, obj):
+    """rank 0's `obj` on every rank of the collective run (torch.distributed.broadcast_object_list)."""
+    import torch.distributed as dist
+    box = [obj if coll.rank == 0 else None]
+    dist.broadcast_object_list(box, src=dist.get_global_rank(coll.group, 0) if coll.group is not None else 0, group=coll.group)
+    return box[0]
+
+
+def _run_anim(indir, outdir, recovery, nofilter, maxmatch, write_output, skip_zero, eng, coll=None) -> AnimRun:
+    lead = coll is None or coll.rank == 0          # collective run: rank 0 alone touches the output directory
     paths = files.get_fasta_paths(Path(indir))
     stems = [p.stem for p in paths]
     if len(set(stems)) != len(stems):
@@ -88,19 +101,32 @@ def _run_anim(indir, outdir, recovery, nofilter, maxmatch, write_output, skip_ze
     if recovery:
         if outdir is None:
             raise ValueError("recovery mode needs the output directory of the earlier run")
-        existing = set(sorted((Path(outdir) / ALIGNDIR).glob("*/*.delta" if nofilter else "*/*.filter")))
-        old = [(q, s, outfile_path(outdir, q, s, nofilter)) for q, s in todo]
-        old = [(q, s, f) for q, s, f in old if f in existing]
-        if old:
-            recs = eng.anim_reduce([anim.read_delta(f) for _, _, f in old], apply_filter=False)
-            for (q, s, f), rec in zip(old, recs):
-                try:
-                    results[(q, s)] = anim._tuple(rec)
-                except ZeroDivisionError:
-                    if not skip_zero:
-                        raise
-                recovered.append(f)
-        done = {(q, s) for q, s, _ in old}
+        old, err = [], None
+        if lead:
+            try:
+                existing = set(sorted((Path(outdir) / ALIGNDIR).glob("*/*.delta" if nofilter else "*/*.filter")))
+                old = [(q, s, outfile_path(outdir, q, s, nofilter)) for q, s in todo]
+                old = [(q, s, f) for q, s, f in old if f in existing]
+                if old:
+                    recs = eng.anim_reduce([anim.read_delta(f) for _, _, f in old], apply_filter=False)
+                    for (q, s, f), rec in zip(old, recs):
+                        try:
+                            results[(q, s)] = anim._tuple(rec)
+                        except ZeroDivisionError:
+                            if not skip_zero:
+                                raise
+                        recovered.append(f)
+            except Exception as exc:  # noqa: BLE001
+                if coll is None:
+                    raise
+                err = exc
+        if coll is not None:      # every rank continues from rank 0's view of the output directory (or fails with it)
+            results, recovered, done_keys, err_text = _bcast(coll, (results, recovered, [(q, s) for q, s, _ in old], None if err is None else repr(err)))
+            if err_text is not None:
+                raise err if err is not None else RuntimeError(f"run_anim: recovery failed on rank 0: {err_text}")
+            done = set(done_keys)
+        else:
+            done = {(q, s) for q, s, _ in old}
         todo = [k for k in todo if k not in done]
     written: List[Path] = []
     scratch_store = eng.genome_count() == 0
@@ -117,7 +143,7 @@ def _run_anim(indir, outdir, recovery, nofilter, maxmatch, write_output, skip_ze
                 except ZeroDivisionError:
                     if not skip_zero:
                         raise
-            if write_output:
+            if write_output and lead:
                 # the files nucmer / delta-filter would have left, indel lists included: batched calls, a traceback pass on the GPU each
                 for c0 in range(0, len(todo), WRITE_CHUNK):
                     part = todo[c0:c0 + WRITE_CHUNK]
@@ -133,6 +159,8 @@ def _run_anim(indir, outdir, recovery, nofilter, maxmatch, write_output, skip_ze
     finally:
         if scratch_store:
             eng.clear_genomes()
+    if coll is not None and write_output:
+        written = _bcast(coll, written)      # (also the point where the other ranks wait for rank 0's files)
     mats = anim.assemble_run_matrices(results, lengths, genome_ids=genome_ids)
     return AnimRun(genome_ids, lengths, results, anim.comparison_rows(results, lengths, genome_ids, maxmatch=maxmatch), mats,
                    anim.run_matrices_to_json(mats), recovered, written)

@@ -151,8 +151,11 @@ def _run_anim_rank(rank, world, port, indir, out_dir):
     try:
         from pyani_amd import subcmd_anim
         from pyani_amd.engine import Engine
+        outdir = os.path.join(out_dir, "shared_out")      # ONE output directory for both ranks: rank 0 alone writes and recovers
         with Engine(0) as eng:
-            run = subcmd_anim.run_anim(indir, engine=eng)
+            run = subcmd_anim.run_anim(indir, outdir, write_output=True, engine=eng, distributed=True)
+            again = subcmd_anim.run_anim(indir, outdir, recovery=True, engine=eng, distributed=True)
+        assert again.results == run.results and len(again.recovered) == len(run.written) == len(run.results)
         with open(os.path.join(out_dir, f"rank{rank}.json"), "w") as fh:
             json.dump({"results": {f"{a}|{b}": list(v) for (a, b), v in run.results.items()}, "json": run.json}, fh)
     finally:
@@ -161,9 +164,10 @@ def _run_anim_rank(rank, world, port, indir, out_dir):
 
 @pytest.mark.gpu
 def test_run_anim_under_a_process_group_equals_the_plain_run(genome_dir, tmp_path):
-    """run_anim as one process per GPU (here: two gloo ranks on GPU 0): the comparisons are dealt over the ranks through the
-    cross-rank counter and assembled with one all-gather (pyani_amd.parallel.DistributedEngine) — every rank returns the run a single
-    process computes, result for result."""
+    """run_anim(distributed=True) as one process per GPU (here: two gloo ranks on GPU 0): the comparisons are dealt over the ranks and
+    assembled with one all-gather (pyani_amd.parallel.DistributedEngine) — every rank returns the run a single process computes,
+    result for result; both ranks share ONE output directory (rank 0 alone writes the .filter files, and a recovery run reads them
+    on rank 0 and broadcasts what is left to do)."""
     import json
     import shutil
     import socket
