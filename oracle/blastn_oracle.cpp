@@ -276,6 +276,7 @@ struct Hsp {
   int gq, gs;                         // the point the gapped alignment was grown from
   int length, mismatch, gaps, nident;
   double evalue;
+  std::vector<uint8_t> ops;           // edit script, one byte per column from (q0, s0) to (q1, s1): SCRIPT_SUB / SCRIPT_GAP_IN_A / SCRIPT_GAP_IN_B
 };
 struct Row { int32_t frag, length, mismatch, gaps, nident, qlen, qstart, qend, sstart, send, srec, score; };
 
@@ -292,13 +293,13 @@ bool hsp_contained(int ctx, int score, int q0, int q1, int s0, int s1, const Hsp
 // more than RUN_OK identities; otherwise it moves to the first run of more than 1.5 RUN_OK identities on the start point's diagonal
 // inside the preliminary HSP (to its middle), or to the middle of the longest run there.
 void nucl_gapped_start(const uint8_t* q, const uint8_t* sb, const Hsp& h, int* gq, int* gs) {
-  static const int RUN_OK = env_int("BLASTN_ORACLE_RUN_OK", 10);
+  static const int RUN_OK = env_int("BLASTN_ORACLE_RUN_OK", 20);
   int max_run = RUN_OK;
   int score = -1;
   for (int qi = *gq, si = *gs; qi < h.q1 && q[qi] < 4 && q[qi] == sb[si]; ++qi, ++si) { if (++score > max_run) return; }
   for (int qi = *gq, si = *gs; qi >= 0 && si >= 0 && q[qi] < 4 && q[qi] == sb[si]; --qi, --si) { if (++score > max_run) return; }
-  static const int RUN2 = env_int("BLASTN_ORACLE_RUN2", 0);
-  max_run = RUN2 ? RUN2 : (int)(max_run * 1.5);
+  static const int RUN2 = env_int("BLASTN_ORACLE_RUN2", 20);
+  max_run = RUN2;
   const int offset = std::min(*gs - h.s0, *gq - h.q0);
   const int q_start = *gq - offset, s_start = *gs - offset;
   const int q_len = std::min(h.s1 - s_start, h.q1 - q_start);
@@ -320,7 +321,89 @@ void nucl_gapped_start(const uint8_t* q, const uint8_t* sb, const Hsp& h, int* g
   if (max_score > 0) { *gq = max_offset; *gs = max_offset + s_start - q_start; }
 }
 
-struct Options { bool stale_gap_quirk = true; bool approx_prefilter = false; bool all_hsps = true; };
+struct Options { bool stale_gap_quirk = true; bool approx_prefilter = false; bool all_hsps = true; bool reevaluate = false; bool cut_common = true; bool recheck_contained = true; };
+
+void count_columns(Hsp& h, const uint8_t* q, const uint8_t* sb) {
+  h.length = h.mismatch = h.gaps = h.nident = 0;
+  int a = h.q0, b = h.s0;
+  for (uint8_t op : h.ops) {
+    if (op == SCRIPT_SUB) { if (q[a] < 4 && q[a] == sb[b]) ++h.nident; else ++h.mismatch; ++a; ++b; }
+    else if (op == SCRIPT_GAP_IN_A) { ++h.gaps; ++b; }
+    else { ++h.gaps; ++a; }
+    ++h.length;
+  }
+}
+
+// Blast_HSPReevaluateWithAmbiguitiesGapped (blast_hits.c), run on every blastn HSP after its traceback: one pass over the edit script
+// from the left, substitutions one at a time and a gap as a whole; when the running sum falls below zero the alignment restarts behind
+// that point (what was found before is forgotten unless it had reached the cut-off), the best-scoring stretch is kept and then grown
+// over exact matches at both ends.  false = the HSP is dropped (its score is below the cut-off).
+bool reevaluate(Hsp& h, const uint8_t* q, int qlen, const uint8_t* sb, int slen, int cutoff) {
+  int sum = 0, score = 0;
+  int qa = h.q0, sa = h.s0;                                  // running position
+  size_t cur_start = 0, best_start = 0, best_end = 0;        // indices into ops: [best_start, best_end)
+  int cur_q = qa, cur_s = sa, best_q0 = qa, best_s0 = sa, best_q1 = qa, best_s1 = sa;
+  size_t i = 0;
+  const size_t n = h.ops.size();
+  while (i < n) {
+    const uint8_t op = h.ops[i];
+    if (op == SCRIPT_SUB) { sum += sub_score(q[qa], sb[sa]); ++qa; ++sa; ++i; }
+    else {
+      size_t j = i;
+      while (j < n && h.ops[j] == op) ++j;
+      const int len = (int)(j - i);
+      sum -= GAP_OPEN + GAP_EXTEND * len;
+      if (op == SCRIPT_GAP_IN_A) sa += len; else qa += len;
+      i = j;
+    }
+    if (sum < 0) {
+      sum = 0;
+      cur_start = i; cur_q = qa; cur_s = sa;
+      if (score < cutoff) { best_start = best_end = i; best_q0 = best_q1 = qa; best_s0 = best_s1 = sa; score = 0; }
+    } else if (sum > score) {
+      score = sum;
+      best_start = cur_start; best_q0 = cur_q; best_s0 = cur_s;
+      best_end = i; best_q1 = qa; best_s1 = sa;
+    }
+  }
+  if (best_end <= best_start) return false;
+  std::vector<uint8_t> ops(h.ops.begin() + best_start, h.ops.begin() + best_end);
+  // "try to extend further": exact matches beyond both ends
+  int ext = 0;
+  while (best_q0 - ext > 0 && best_s0 - ext > 0 && q[best_q0 - ext - 1] < 4 && q[best_q0 - ext - 1] == sb[best_s0 - ext - 1]) ++ext;
+  if (ext) { ops.insert(ops.begin(), (size_t)ext, (uint8_t)SCRIPT_SUB); best_q0 -= ext; best_s0 -= ext; score += ext * REWARD; }
+  ext = 0;
+  while (best_q1 + ext < qlen && best_s1 + ext < slen && q[best_q1 + ext] < 4 && q[best_q1 + ext] == sb[best_s1 + ext]) ++ext;
+  if (ext) { ops.insert(ops.end(), (size_t)ext, (uint8_t)SCRIPT_SUB); best_q1 += ext; best_s1 += ext; score += ext * REWARD; }
+  h.ops.swap(ops);
+  h.q0 = best_q0; h.s0 = best_s0; h.q1 = best_q1; h.s1 = best_s1; h.score = score;
+  return score >= cutoff;
+}
+
+// s_CutOffGapEditScript (blast_hits.c): walk the script from the left, substitutions one at a time and a gap as a whole, to the
+// first point that has consumed q_cut query AND s_cut subject bases; cut_begin: the HSP starts there, else it ends there.
+bool cut_script(Hsp& h, int q_cut_abs, int s_cut_abs, bool cut_begin) {
+  const int q_cut = q_cut_abs - h.q0, s_cut = s_cut_abs - h.s0;
+  int qid = 0, sid = 0;
+  size_t i = 0;
+  const size_t n = h.ops.size();
+  bool found = false;
+  while (i < n) {
+    const uint8_t op = h.ops[i];
+    if (op == SCRIPT_SUB) { ++qid; ++sid; ++i; }
+    else {
+      size_t j = i;
+      while (j < n && h.ops[j] == op) ++j;
+      if (op == SCRIPT_GAP_IN_A) sid += (int)(j - i); else qid += (int)(j - i);
+      i = j;
+    }
+    if (qid >= q_cut && sid >= s_cut) { found = true; break; }
+  }
+  if (!found) return true;                 // (left as it is)
+  if (cut_begin) { h.ops.erase(h.ops.begin(), h.ops.begin() + i); h.q0 += qid; h.s0 += sid; }
+  else { h.ops.resize(i); h.q1 = h.q0 + qid; h.s1 = h.s0 + sid; }
+  return !h.ops.empty();
+}
 
 // HSPs of one fragment (both strands) against ONE subject record, in BLAST's output order
 void search_record(const uint8_t* frag_fwd, int qlen, const Subject& S, int rec, const std::vector<std::pair<int, int32_t>>* hits,
@@ -419,6 +502,10 @@ void search_record(const uint8_t* frag_fwd, int qlen, const Subject& S, int rec,
     const uint8_t* q = qctx[ih.ctx].data();
     const int adj = 4 - (ih.s_off % 4);
     int gq = ih.q_off + adj, gs = ih.s_off + adj;
+    static const int START_MODE = env_int("BLASTN_ORACLE_START_MODE", 0);
+    if (START_MODE == 1) { gq = ih.q_start + ih.length / 2; gs = ih.s_start + ih.length / 2; }
+    if (START_MODE == 2) { gq = ih.q_off; gs = ih.s_off; }
+    if (START_MODE == 3) { const int m = ih.length / 2; const int a2 = 4 - ((ih.s_start + m) % 4); gq = ih.q_start + m + a2; gs = ih.s_start + m + a2; }
     if (gq > qlen || gs > slen) { gq = ih.q_off; gs = ih.s_off; }
     int la = 0, lb = 0, ra = 0, rb = 0;
     const int sl = semi_gapped_align([&](int a) { return q[gq - a]; }, gq, [&](int b) { return sb[gs - b]; }, gs, P.x_prelim, &la, &lb, nullptr,
@@ -477,6 +564,31 @@ void search_record(const uint8_t* frag_fwd, int qlen, const Subject& S, int rec,
     const uint8_t* q = qctx[ph.ctx].data();
     int gq = ph.gq, gs = ph.gs;
     nucl_gapped_start(q, sb, ph, &gq, &gs);
+    if (debug && env_int("BLASTN_ORACLE_DEBUG_SCAN", 0) == 2 && ph.score > 300) {
+      const int off = std::min(ph.gs - ph.s0, ph.gq - ph.q0);
+      const int qs0 = ph.gq - off, ss0 = ph.gs - off, n = std::min(ph.s1 - ss0, ph.q1 - qs0);
+      fprintf(stderr, "SCAN prelim ctx %d q [%d,%d) score %d prelim start %d chosen %d; runs>=8 on the diagonal (q:len):", ph.ctx, ph.q0, ph.q1, ph.score, ph.gq, gq);
+      for (int i = 0; i < n;) { int j = i; while (j < n && q[qs0 + j] == sb[ss0 + j]) ++j; if (j - i >= 8) fprintf(stderr, " %d:%d", qs0 + i, j - i); i = j + 1; }
+      fprintf(stderr, "\n");
+      int last_mm = -1, last_gp = -1, last_len = -1, from = -1;
+      for (int i = 0; i <= n; ++i) {
+        int mm = -2, gp = -2, len = -2;
+        if (i < n && q[qs0 + i] == sb[ss0 + i]) {
+          const int tq = qs0 + i, ts = ss0 + i;
+          int la2 = 0, lb2 = 0, ra2 = 0, rb2 = 0;
+          std::vector<uint8_t> lo, ro;
+          semi_gapped_align([&](int a) { return q[tq - a]; }, tq, [&](int b) { return sb[ts - b]; }, ts, P.x_final, &la2, &lb2, &lo, opt.stale_gap_quirk);
+          semi_gapped_align([&](int a) { return q[tq + a - 1]; }, qlen - tq, [&](int b) { return sb[ts + b - 1]; }, slen - ts, P.x_final, &ra2, &rb2, &ro, opt.stale_gap_quirk);
+          Hsp t{}; t.q0 = tq - la2; t.s0 = ts - lb2; t.q1 = tq + ra2; t.s1 = ts + rb2; t.ops = lo; t.ops.insert(t.ops.end(), ro.rbegin(), ro.rend());
+          count_columns(t, q, sb);
+          mm = t.mismatch; gp = t.gaps; len = t.length;
+        } else if (i < n) continue;
+        if (mm != last_mm || gp != last_gp || len != last_len) {
+          if (from >= 0) fprintf(stderr, "   starts %d..%d -> len %d mm %d gaps %d\n", from, qs0 + i - 1, last_len, last_mm, last_gp);
+          from = qs0 + i; last_mm = mm; last_gp = gp; last_len = len;
+        }
+      }
+    }
     int la = 0, lb = 0, ra = 0, rb = 0;
     std::vector<uint8_t> lops, rops;
     const int sl = semi_gapped_align([&](int a) { return q[gq - a]; }, gq, [&](int b) { return sb[gs - b]; }, gs, P.x_final, &la, &lb, &lops,
@@ -489,29 +601,74 @@ void search_record(const uint8_t* frag_fwd, int qlen, const Subject& S, int rec,
     hs.ctx = ph.ctx; hs.score = sl + sr;
     hs.q0 = gq - la; hs.s0 = gs - lb; hs.q1 = gq + ra; hs.s1 = gs + rb;
     hs.gq = gq; hs.gs = gs;
-    // walk the path: left part (ops run from the far end towards the start point already: best cell -> start)
-    {
-      int a = la, b = lb;                       // distance from the start point
-      for (uint8_t op : lops) {
-        if (op == SCRIPT_SUB) { if (q[gq - a] < 4 && q[gq - a] == sb[gs - b]) ++hs.nident; else ++hs.mismatch; --a; --b; }
-        else if (op == SCRIPT_GAP_IN_A) { ++hs.gaps; --b; }
-        else { ++hs.gaps; --a; }
-        ++hs.length;
-      }
-      a = ra; b = rb;
-      for (uint8_t op : rops) {
-        if (op == SCRIPT_SUB) { if (q[gq + a - 1] < 4 && q[gq + a - 1] == sb[gs + b - 1]) ++hs.nident; else ++hs.mismatch; --a; --b; }
-        else if (op == SCRIPT_GAP_IN_A) { ++hs.gaps; --b; }
-        else { ++hs.gaps; --a; }
-        ++hs.length;
-      }
-    }
-    if (hs.score >= cutoff) fin.push_back(hs);
+    // the edit script from the left end to the right end: the left part's ops run from its far end to the start point already,
+    // the right part's from its far end back to the start point
+    hs.ops = lops;
+    hs.ops.insert(hs.ops.end(), rops.rbegin(), rops.rend());
+    if (debug) fprintf(stderr, "traceback ctx %d start (%d,%d) -> q [%d,%d) s [%d,%d) score %d\n", hs.ctx, gq, gs, hs.q0, hs.q1, hs.s0, hs.s1, hs.score);
+    if (opt.reevaluate && !reevaluate(hs, q, qlen, sb, slen, cutoff)) continue;
+    if (debug) fprintf(stderr, "   re-evaluated -> q [%d,%d) s [%d,%d) score %d\n", hs.q0, hs.q1, hs.s0, hs.s1, hs.score);
+    if (hs.score < cutoff) continue;
+    bool dup = false;      // (the tree is asked once more after the traceback)
+    for (const Hsp& t : fin)
+      if (hsp_contained(hs.ctx, hs.score, hs.q0, hs.q1, hs.s0, hs.s1, t)) { dup = true; break; }
+    if (!dup || !opt.recheck_contained) fin.push_back(std::move(hs));
   }
-  purge(fin);
-  for (Hsp& h : fin) h.evalue = evalue_of(h.score, searchsp);
+  // --- HSPs with a common start or a common end (same strand).  blastn does not simply drop the weaker one: when it reaches beyond
+  // the better one it is CUT where the better one ends (begins) and what is left is re-evaluated (blast_hits.c,
+  // Blast_HSPListPurgeHSPsWithCommonEndpoints with purge = FALSE, s_CutOffGapEditScript; blast_traceback.c re-evaluates the cut ones)
+  std::stable_sort(fin.begin(), fin.end(), score_order);
+  if (!opt.cut_common) {
+    purge(fin);
+  } else {
+    std::vector<Hsp> cut;                       // removed from the passes once cut
+    for (int pass = 0; pass < 2; ++pass) {
+      std::stable_sort(fin.begin(), fin.end(), [&](const Hsp& x, const Hsp& y) {
+        if (x.ctx != y.ctx) return x.ctx < y.ctx;
+        if (!pass) {
+          if (x.q0 != y.q0) return x.q0 < y.q0;
+          if (x.s0 != y.s0) return x.s0 < y.s0;
+          if (x.score != y.score) return x.score > y.score;
+          if (x.q1 != y.q1) return x.q1 > y.q1;
+          return x.s1 > y.s1;
+        }
+        if (x.q1 != y.q1) return x.q1 < y.q1;
+        if (x.s1 != y.s1) return x.s1 < y.s1;
+        if (x.score != y.score) return x.score > y.score;
+        if (x.q0 != y.q0) return x.q0 > y.q0;
+        return x.s0 > y.s0;
+      });
+      std::vector<Hsp> keep;
+      for (Hsp& h : fin) {
+        if (!keep.empty()) {
+          const Hsp& lead = keep.back();
+          const bool same = lead.ctx == h.ctx && (pass ? (lead.q1 == h.q1 && lead.s1 == h.s1) : (lead.q0 == h.q0 && lead.s0 == h.s0));
+          if (same) {
+            if (!pass && h.q1 > lead.q1) { if (cut_script(h, lead.q1, lead.s1, true)) cut.push_back(std::move(h)); }
+            else if (pass && h.q0 < lead.q0) { if (cut_script(h, lead.q0, lead.s0, false)) cut.push_back(std::move(h)); }
+            continue;
+          }
+        }
+        keep.push_back(std::move(h));
+      }
+      fin.swap(keep);
+    }
+    for (Hsp& h : cut) {
+      const uint8_t* q = qctx[h.ctx].data();
+      if (debug) fprintf(stderr, "cut hsp ctx %d q [%d,%d) s [%d,%d) ops %zu\n", h.ctx, h.q0, h.q1, h.s0, h.s1, h.ops.size());
+      const bool ok = reevaluate(h, q, qlen, sb, slen, cutoff);
+      if (debug) fprintf(stderr, "   re-evaluated -> q [%d,%d) s [%d,%d) score %d %s\n", h.q0, h.q1, h.s0, h.s1, h.score, ok ? "kept" : "dropped");
+      if (!ok) continue;
+      fin.push_back(std::move(h));
+    }
+  }
+  for (Hsp& h : fin) {
+    const uint8_t* q = qctx[h.ctx].data();
+    count_columns(h, q, sb);
+    h.evalue = evalue_of(h.score, searchsp);
+  }
   std::vector<Hsp> kept;
-  for (const Hsp& h : fin) if (h.evalue <= EVALUE) kept.push_back(h);
+  for (Hsp& h : fin) if (h.score >= cutoff && h.evalue <= EVALUE) kept.push_back(std::move(h));
   std::stable_sort(kept.begin(), kept.end(), score_order);
   out.swap(kept);
 }
@@ -585,6 +742,9 @@ int64_t blastn_oracle_pair(const uint8_t* qseq, const uint64_t* qrec_off, uint32
   Options opt;
   opt.all_hsps = !(flags & 1u);
   opt.stale_gap_quirk = env_int("BLASTN_ORACLE_STALE_GAP", 1) != 0;
+  opt.reevaluate = env_int("BLASTN_ORACLE_REEVALUATE", 0) != 0;
+  opt.cut_common = env_int("BLASTN_ORACLE_CUT", 1) != 0;
+  opt.recheck_contained = env_int("BLASTN_ORACLE_RECHECK", 1) != 0;
   std::vector<std::vector<Row>> per(frags.size());
   std::atomic<size_t> next{0};
   if (n_threads < 1) n_threads = 1;
