@@ -69,6 +69,10 @@ def parse_args():
     ap.add_argument("--static-deal", action="store_true", help="(the default since round 5; accepted for older command lines)")
     ap.add_argument("--cold-e2e", action="store_true", help="anim, N = 1: measure ONE cold end-to-end run instead of the step loop: FASTA files on disk -> "
                     "parse + pack (pg_add_fasta_batch) -> upload -> seed lists -> the whole grid -> run matrices -> JSON, one wall clock")
+    ap.add_argument("--pipeline", action="store_true", help="anim: step k + 1 is enqueued (pg_anim_pairs_enqueue) before step k is fetched, so one step's sequential tail "
+                    "overlaps the next step's front.  NOT the default: measured on MI355X at C4's step size (99 900 pairs) it is 3 %% slower than one blocking call per "
+                    "step (56 957 vs 58 657 pairs/s, profiles/r06_pipeline_vs_blocking.txt) — the two calls in flight halve each other's launches, and a step this large "
+                    "already overlaps its tails across its own two workers; it pays for family-sized calls (related_only.pipelined_calls)")
     ap.add_argument("--expect-sha", default="auto", help="anim: sha1 the whole N x N result grid must have (checked whenever the timed steps cover the grid): "
                     "'auto' = the committed hash of the default C4 job (tests/golden/anim_c4_grid_sha1.txt) when the job IS the default C4 job, 'none' = no check; "
                     "a mismatch fails the run loudly (exit code 3) after the line is printed")
@@ -290,6 +294,22 @@ def related_only_record(eng, args, stages=()):
         dt = time.perf_counter() - t0
         rec["steady"] = {"workload": f"{len(fams)} such families in one call ({len(many)} ordered pairs, all related)", "seconds": dt,
                          "pairs_per_s": len(many) / dt, "first_call_seconds": first}
+    if len(fams) > 1 and hasattr(eng, "anim_pairs_enqueue"):
+        # the same four families as FOUR family-sized calls, two in flight at a time (pg_anim_pairs_enqueue / _fetch): what a caller that
+        # submits one genus after another sees — the tail of each call overlaps the front of the next
+        calls = [[(a, b) for a in fam for b in fam if a != b] for fam in ids]
+        for rep in range(2):      # (first pass grows the lanes' scratch)
+            t0 = time.perf_counter()
+            pend = []
+            for c in calls:
+                pend.append(eng.anim_pairs_enqueue([a for a, _ in c], [b for _, b in c]))
+                if len(pend) == 2:
+                    eng.anim_pairs_fetch(pend.pop(0))
+            for t in pend:
+                eng.anim_pairs_fetch(t)
+            dt = time.perf_counter() - t0
+        rec["pipelined_calls"] = {"workload": f"{len(calls)} family-sized calls ({len(calls[0])} pairs each), two in flight (pg_anim_pairs_enqueue / _fetch)",
+                                  "seconds": dt, "pairs_per_s": sum(len(c) for c in calls) / dt, "seconds_per_call": dt / len(calls)}
     if stages:
         eng.anim_set_workers(1)
         eng.profile_reset()
@@ -504,13 +524,35 @@ def run_anim(args, rank, world, local, dist, torch):
 
     ids_np = np.asarray(ids, dtype=np.int32)
 
+    # --pipeline (round 6; measured and NOT made the default, see the flag's help): before a step's call is fetched the next step's call is already enqueued
+    # (pg_anim_pairs_enqueue / _fetch: two calls in flight on disjoint worker slots), so the sequential tail of one step — one forced
+    # re-alignment can hold a single wave for 0.1 s — overlaps the front of the next, as the pool of pyani's runner keeps its cores busy
+    # across job boundaries (run_multiprocessing.py:130-144).  Every step is still computed in full inside the timed region (the closing
+    # fence waits for the last one).  Default: one blocking call per step.
+    pipeline = (not REHEARSAL) and args.pipeline and queue is None
+    prefetched = {}
+    upcoming = [None]      # the pairs this rank will be asked for next (set by step())
+
+    def _key(pairs):
+        return (len(pairs), int(pairs[0, 0]), int(pairs[0, 1]), int(pairs[-1, 0]), int(pairs[-1, 1])) if len(pairs) else None
+
     def compute(pairs):   # pairs: int64 [m, 2] of (reference, query) genome numbers
-        return parallel.anim_records_to_tensor(eng.anim_pairs(ids_np[pairs[:, 0]], ids_np[pairs[:, 1]]), dev)
+        if not pipeline or not len(pairs):
+            return parallel.anim_records_to_tensor(eng.anim_pairs(ids_np[pairs[:, 0]], ids_np[pairs[:, 1]]), dev)
+        t = prefetched.pop(_key(pairs), None)
+        if t is None:
+            t = eng.anim_pairs_enqueue(ids_np[pairs[:, 0]], ids_np[pairs[:, 1]])
+        nxt, upcoming[0] = upcoming[0], None
+        if nxt is not None and len(nxt) and _key(nxt) not in prefetched:
+            prefetched[_key(nxt)] = eng.anim_pairs_enqueue(ids_np[nxt[:, 0]], ids_np[nxt[:, 1]])
+        return parallel.anim_records_to_tensor(eng.anim_pairs_fetch(t), dev)
 
     tiles, imbalance = {}, []
 
-    def step(k, keep=False, rows=None, key=None):
+    def step(k, keep=False, rows=None, key=None, then=None):
         rows = rows_of(k) if rows is None else rows
+        if pipeline and then is not None:      # this rank's share of the NEXT step of the same loop
+            upcoming[0] = parallel.anim_pair_array(n, rows_of(then) if dist is None else parallel.anim_row_shard(rows_of(then), rank, world), symmetric=True)
         pairs = parallel.anim_pair_array(n, rows, symmetric=True)   # the rows' unordered pairs, both directions
         if dist is None:
             vals = compute(pairs)
@@ -552,10 +594,12 @@ def run_anim(args, rank, world, local, dist, torch):
     ext_stages = [_lib.K_ANIM_GAPS, _lib.K_ANIM_FWD, _lib.K_ANIM_BWD, _lib.K_ANIM_EXTEND, _lib.K_ANIM_EXTLANE]
     # ---- the timed region: K steps between fences, no per-kernel events (they belong to the one-worker step below) ----------
     t0 = time.perf_counter()
+    last = args.warmup + args.steps - 1
     for k in range(args.warmup, args.warmup + args.steps):
-        step(k, keep=True)
+        step(k, keep=True, then=k + 1 if k < last else None)
     fence()
     elapsed = time.perf_counter() - t0
+    assert not prefetched, "a prefetched step was never fetched"
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -760,6 +804,8 @@ def run_anim(args, rank, world, local, dist, torch):
                 "grid_pairs": n * (n - 1), "wall_s_grid": grid_s,
                 "identity_related_min_med_max": [float(x) for x in np.percentile(ident[(status == 0) & related_m], [0, 50, 100])]
                 if ok_rel else None,
+                "step_loop": ("pipelined: step k + 1 enqueued before step k is fetched (pg_anim_pairs_enqueue / _fetch, two calls in flight)" if pipeline
+                              else "one blocking pg_anim_pairs per step"),
                 "results_sha1_full_grid": sha, "results_sha1_check": sha_check, "parity_vs_independent_oracle": parity_indep,
                 "parallelism": (f"1 process/GPU x {world}; genomes replicated; each step's rows "
                                 + ("pulled in guided chunks from a cross-rank counter" if queue is not None else "dealt over the ranks by a fixed hash")
@@ -814,6 +860,8 @@ def run_anim(args, rank, world, local, dist, torch):
             if cb and cb.get("cpu_s_per_related_pair"):
                 # the two halves of the job priced separately: a genus-level job is all related pairs
                 cb["speedup_related_only"] = out["related_only"]["pairs_per_s"] / (cb["cores"] / cb["cpu_s_per_related_pair"])
+                if out["related_only"].get("pipelined_calls"):
+                    cb["speedup_related_only_pipelined_calls"] = out["related_only"]["pipelined_calls"]["pairs_per_s"] / (cb["cores"] / cb["cpu_s_per_related_pair"])
                 if out["related_only"].get("steady"):
                     cb["speedup_related_only_steady"] = out["related_only"]["steady"]["pairs_per_s"] / (cb["cores"] / cb["cpu_s_per_related_pair"])
                 if out["unrelated_only"] and cb.get("cpu_s_per_unrelated_pair"):

@@ -133,6 +133,17 @@ typedef struct {
  * matches), so one call with the whole job is up to 1.6 x faster than the directions in separate calls — same results. */
 int pg_anim_pairs(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_ids, uint64_t n_pairs, int maxmatch,
                   int filter_1to1, pg_anim_result* out);
+/* The non-blocking form (round 6; the counterpart of pg_tetra_matrix_enqueue / _fetch): pyani's runner keeps all its cores busy
+ * across job boundaries (one multiprocessing.Pool for the whole job list, run_multiprocessing.py:130-144); a blocking pg_anim_pairs
+ * pays the sequential tails of its last kernels (one forced re-alignment can hold a single wave for 0.1 s) with the rest of the
+ * GPU idle.  pg_anim_pairs_enqueue copies the id lists, starts the call on a host thread of the context and returns a ticket at
+ * once; pg_anim_pairs_fetch waits for that call and writes its n_pairs results (the status of the call is fetch's return value).
+ * At most TWO calls are in flight per context (PG_E_CAPACITY beyond): they run on disjoint halves of the context's four
+ * (stream, scratch) worker slots with half the match budget each, so the tail of call k overlaps the front of call k + 1.
+ * Results are those of pg_anim_pairs, bit for bit.  Every ticket must be fetched (pg_destroy waits for unfetched calls). */
+int pg_anim_pairs_enqueue(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_ids, uint64_t n_pairs, int maxmatch,
+                          int filter_1to1, uint64_t* ticket);
+int pg_anim_pairs_fetch(pg_ctx* ctx, uint64_t ticket, pg_anim_result* out, uint64_t n_pairs);
 
 /* The extension algorithm after seeding and clustering is MUMmer 3.23's own postnuc (extendClusters + its alignment engine:
  * dynamic anti-diagonal band trimmed at breaklen * 3 below the best score, backward search + forced forward re-alignment,

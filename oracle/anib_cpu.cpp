@@ -10,6 +10,7 @@
 // time it as the own-cpu baseline of the fragment workload.  Nothing under pyani_amd/ loads this library.
 //   g++ -O2 -std=c++17 -pthread -fPIC -shared -Ipyani_amd/csrc oracle/anib_cpu.cpp -o oracle/libanibcpu.so
 #include <algorithm>
+#include <cstdio>
 #include <atomic>
 #include <cstdint>
 #include <cstdlib>
@@ -179,22 +180,44 @@ void run_pair(const Genome& Q, const Genome& S, int32_t fragsize, std::vector<Ro
       }
     }
   }
-  // rows of one fragment from its seed lists (both strands): anchors, extensions, e-value
+  // rows of one fragment from its seed lists (both strands): blastn's start points on the seeds' diagonals, extensions, e-value
+  int64_t db_len = 0;
+  const int32_t db_seqs = (int32_t)S.rec_start.size() - 1;
+  for (int32_t r = 0; r < db_seqs; ++r) db_len += S.rec_start[r + 1] - 1 - S.rec_start[r];
   auto fragment_rows = [&](size_t f, std::vector<Row>& cand) {
     const int32_t fp = frags[f].first, qlen = frags[f].second;
-    // anchors of both strands first (a weak candidate is dropped when the fragment has a strong one), then the extensions
+    FragInit init[2][FRAG_MAX_SEEDS];
+    int64_t dg[2][FRAG_MAX_SEEDS];
     int pick[2][2], nc[2] = {0, 0};
-    int32_t votes[2][2], vmax = 0;
+    int32_t best_score = 0;
     for (int strand = 0; strand < 2; ++strand) {
       std::vector<FragSeed>& e = seeds[strand][f];
       if (e.empty()) continue;
       std::sort(e.begin(), e.end(), [](const FragSeed& x, const FragSeed& y) { return x.len != y.len ? x.len > y.len : (x.q != y.q ? x.q < y.q : x.s < y.s); });
       if (e.size() > (size_t)FRAG_MAX_SEEDS) e.resize(FRAG_MAX_SEEDS);
-      nc[strand] = frag_pick_anchors(e.data(), (int)e.size(), pick[strand], votes[strand]);
-      for (int c = 0; c < nc[strand]; ++c) vmax = std::max(vmax, votes[strand][c]);
+      auto q_at = [&](int64_t p) -> int {
+        if (p < 0 || p >= qlen) return 4;
+        const int64_t g = strand ? fp + (qlen - 1 - p) : fp + p;
+        if (!QVw.clean(g)) return 4;
+        return strand ? 3 - QVw.base(g) : QVw.base(g);
+      };
+      const int n = (int)e.size();
+      for (int t = 0; t < n; ++t) {                       // one walk per distinct seed diagonal
+        const int64_t diag = (int64_t)e[t].s - e[t].q;
+        dg[strand][t] = diag;
+        init[strand][t] = FragInit{0, 0, 0, 0};
+        bool dup = false;
+        for (int u = 0; u < n; ++u) dup = dup || (u != t && (int64_t)e[u].s - e[u].q == diag && frag_seed_before(e[u], e[t]));      // the diagonal's longest seed walks it
+        if (dup) continue;
+        const int srec = record_of(S.rec_start.data(), (int)S.rec_start.size() - 1, e[t].s);
+        const int64_t s_lo = S.rec_start[srec], s_hi = S.rec_start[srec + 1] - 1;
+        auto match = [&](int32_t p) -> bool { const int qb = q_at(p); const int64_t sp = p + diag; return qb < 4 && sp >= s_lo && sp < s_hi && SV.clean(sp) && SV.base(sp) == qb; };
+        init[strand][t] = frag_diag_best_init(match, qlen, diag, e[t].q);
+      }
+      nc[strand] = frag_pick_inits(init[strand], dg[strand], n, pick[strand]);
+      for (int c = 0; c < nc[strand]; ++c) best_score = std::max(best_score, init[strand][pick[strand][c]].score);
     }
     for (int strand = 0; strand < 2; ++strand) {
-      std::vector<FragSeed>& e = seeds[strand][f];
       auto q_at = [&](int64_t p) -> int {
         if (p < 0 || p >= qlen) return 4;
         const int64_t g = strand ? fp + (qlen - 1 - p) : fp + p;
@@ -202,13 +225,18 @@ void run_pair(const Genome& Q, const Genome& S, int32_t fragsize, std::vector<Ro
         return strand ? 3 - QVw.base(g) : QVw.base(g);
       };
       for (int c = 0; c < nc[strand]; ++c) {
-        if (!frag_keep_candidate(votes[strand][c], vmax)) continue;
-        const FragSeed& A = e[pick[strand][c]];
-        const int srec = record_of(S.rec_start.data(), (int)S.rec_start.size() - 1, A.s);
+        const FragInit& I = init[strand][pick[strand][c]];
+        if (!frag_keep_init(I.score, best_score)) continue;
+        const int64_t diag = dg[strand][pick[strand][c]];
+        const int srec = record_of(S.rec_start.data(), (int)S.rec_start.size() - 1, (int32_t)(I.q_off + diag));
         const int64_t s_lo = S.rec_start[srec], s_hi = S.rec_start[srec + 1] - 1;
         auto s_at = [&](int64_t p) -> int { return (p >= s_lo && p < s_hi && SV.clean(p)) ? SV.base(p) : 5; };
-        const FragHit h = frag_hsp(q_at, qlen, s_at, s_lo, s_hi, A.q, A.s, A.len);
-        if (!frag_evalue_ok(h.score, qlen, s_hi - s_lo)) continue;
+        auto match = [&](int32_t p) -> bool { const int qb = q_at(p); return qb < 4 && s_at(p + diag) == qb; };
+        const int32_t lo = (int32_t)std::max<int64_t>(0, s_lo - diag), hi = (int32_t)std::min<int64_t>(qlen, s_hi - diag);
+        const int32_t g = frag_start_point(match, qlen, I.q_off, I.q_off + diag - s_lo, lo, hi, I.score);
+        const FragHit h = frag_hsp(q_at, qlen, s_at, s_lo, s_hi, g, g + diag, 1, [&](int32_t sc) { return frag_evalue_ok_db(sc, qlen, db_len, db_seqs); });
+        if (getenv("ANIB_DUMP_STARTS")) fprintf(stderr, "PSTART %zu %d %d %lld %d init score %d q_start %d len %d word %d -> score %d\n", f, strand, g, (long long)(g + diag - s_lo), srec, I.score, I.q_start, I.len, I.q_off, h.score);
+        if (!frag_evalue_ok_db(h.score, qlen, db_len, db_seqs)) continue;
         Row r;
         r.frag = (int32_t)f; r.length = h.length; r.mismatch = h.mismatch; r.gaps = h.gaps; r.nident = h.nident; r.qlen = qlen;
         r.srec = srec; r.score = h.score;
@@ -218,6 +246,20 @@ void run_pair(const Genome& Q, const Genome& S, int32_t fragsize, std::vector<Ro
       }
     }
     std::stable_sort(cand.begin(), cand.end(), [](const Row& x, const Row& y) { return x.score > y.score; });
+    {   // HSPs with a common start or end point (frag_rows_share_end): the better one stays
+      std::vector<Row> keep;
+      for (const Row& r : cand) {
+        bool drop = false;
+        for (const Row& k : keep) drop = drop || frag_rows_share_end(k.qstart, k.qend, k.sstart, k.send, r.qstart, r.qend, r.sstart, r.send);
+        if (!drop) keep.push_back(r);
+      }
+      cand.swap(keep);
+    }
+    // -max_target_seqs 1: only the subject record of the fragment's best HSP is reported
+    if (!cand.empty()) {
+      const int32_t keep = cand[0].srec;
+      cand.erase(std::remove_if(cand.begin(), cand.end(), [keep](const Row& x) { return x.srec != keep; }), cand.end());
+    }
   };
   auto reportable = [](const std::vector<Row>& cand) {   // parse_blast_tab's test (anib.py:641-649) on any row of the fragment
     for (const Row& r : cand) {
@@ -252,6 +294,7 @@ void run_pair(const Genome& Q, const Genome& S, int32_t fragsize, std::vector<Ro
           for (const FragSeed& y : seeds[strand][f]) if (y.s - y.q == x.s - x.q && x.q >= y.q && x.q + x.len <= y.q + y.len) dup = true;
           if (!dup) fresh.push_back(x);
         }
+        if (getenv("ANIB_DUMP_STARTS")) fprintf(stderr, "WORDTIER frag %zu strand %d: %zu word seeds, %zu fresh\n", f, strand, extra.size(), fresh.size());
         if (fresh.empty() || fresh.size() > (size_t)(WORD_MAX_SEEDS - FRAG_MAX_SEEDS)) continue;   // (a repeat family: left as it is)
         seeds[strand][f].insert(seeds[strand][f].end(), fresh.begin(), fresh.end());
         added = true;

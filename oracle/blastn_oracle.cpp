@@ -459,7 +459,10 @@ void search_record(const uint8_t* frag_fwd, int qlen, const Subject& S, int rec,
         const int len = q_end - q_beg, s_beg = s_a - (q_a - q_beg);
         last_hit = s_beg + len;
         if (last_hit < s_a + WORD) last_hit = s_a + WORD;
-        if (score >= P.trigger) init.push_back(InitHsp{ctx, q_a, s_a, q_beg, s_beg, len, score});
+        static const int MIN_RUN = env_int("BLASTN_ORACLE_EXP_MIN_RUN", 0);
+        bool has_run = MIN_RUN == 0;
+        if (MIN_RUN) { int run = 0; for (int t = 0; t < len; ++t) { run = (q[q_beg + t] < 4 && q[q_beg + t] == sb[s_beg + t]) ? run + 1 : 0; if (run >= MIN_RUN) has_run = true; } }
+        if (score >= P.trigger && has_run) init.push_back(InitHsp{ctx, q_a, s_a, q_beg, s_beg, len, score});
       }
     }
   }
@@ -563,7 +566,9 @@ void search_record(const uint8_t* frag_fwd, int qlen, const Subject& S, int rec,
     if (skip) continue;
     const uint8_t* q = qctx[ph.ctx].data();
     int gq = ph.gq, gs = ph.gs;
-    nucl_gapped_start(q, sb, ph, &gq, &gs);
+    static const int NO_PRELIM_EXTENTS = env_int("BLASTN_ORACLE_EXP_NO_PRELIM_EXTENTS", 0);
+    if (NO_PRELIM_EXTENTS) { Hsp whole = ph; const int off = std::min(gq, gs); whole.q0 = gq - off; whole.s0 = gs - off; const int room = std::min(qlen - gq, slen - gs); whole.q1 = gq + room; whole.s1 = gs + room; nucl_gapped_start(q, sb, whole, &gq, &gs); }
+    else nucl_gapped_start(q, sb, ph, &gq, &gs);
     if (debug && env_int("BLASTN_ORACLE_DEBUG_SCAN", 0) == 2 && ph.score > 300) {
       const int off = std::min(ph.gs - ph.s0, ph.gq - ph.q0);
       const int qs0 = ph.gq - off, ss0 = ph.gs - off, n = std::min(ph.s1 - ss0, ph.q1 - qs0);
@@ -703,6 +708,10 @@ void search_fragment(int frag_id, const uint8_t* frag_fwd, int qlen, const Subje
     search_record(frag_fwd, qlen, S, rec, hits, P, opt, searchsp, hs);
     if (hs.empty()) continue;
     if (best_rec < 0 || hs[0].score > best[0].score) { best.swap(hs); best_rec = rec; }   // -max_target_seqs 1
+  }
+  if (const char* dump = getenv("BLASTN_ORACLE_DUMP_STARTS")) {
+    static FILE* fh = fopen(dump, "w");
+    if (fh && !best.empty()) { const Hsp& h = best[0]; fprintf(fh, "%d %d %d %d %d\n", frag_id, h.ctx, h.gq, h.gs, best_rec); fflush(fh); }
   }
   for (const Hsp& h : best) {
     Row r;

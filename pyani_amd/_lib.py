@@ -4,11 +4,17 @@ import ctypes
 import os
 from pathlib import Path
 
-# The ANIm engine's workers own one HIP stream each and count on their kernels overlapping.  ROCm maps a process's streams onto
-# GPU_MAX_HW_QUEUES hardware queues (default 4); in a process that also runs RCCL the two workers can end up on one queue and
-# serialise (MI355X, one rank through the real backend: 53.7 k pairs/s on C4 against 56.8 k with 8 queues; 58.5 k without RCCL).
-# Only a default, and only effective if the HIP runtime has not started yet (import this package before the first torch.cuda call).
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+
+def configure_runtime(hw_queues: int = 8) -> bool:
+    """The ANIm engine's workers own one HIP stream each and count on their kernels overlapping.  ROCm maps a process's streams onto
+    GPU_MAX_HW_QUEUES hardware queues (default 4); in a process that also runs RCCL the two workers can end up on one queue and
+    serialise (MI355X, one rank through the real backend: 53.7 k pairs/s on C4 against 56.8 k with 8 queues; 58.5 k without RCCL).
+    An EXPLICIT call (importing the package must not change the host application's environment): sets the variable if
+    it is unset and returns whether it can still take effect, i.e. the HIP runtime has not started in this process (call it before the
+    first torch.cuda / Engine use; launch scripts may simply export GPU_MAX_HW_QUEUES=8 — INTEGRATION.md)."""
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(int(hw_queues)))
+    return _lib is None
 
 LIB_PATH = Path(__file__).resolve().parent / "libpyani_gpu.so"
 
@@ -48,6 +54,8 @@ SIGNATURES = {
     "pg_tetra_zscores_dev": (_int, [_vp, _vp, _u32, _vp, _vp]),
     "pg_tetra_corr_rows_dev": (_int, [_vp, _vp, _vp, _u32, _u32, _u32, _vp]),
     "pg_anim_pairs": (_int, [_vp, _vp, _vp, _u64, _int, _int, _vp]),
+    "pg_anim_pairs_enqueue": (_int, [_vp, _vp, _vp, _u64, _int, _int, _vp]),
+    "pg_anim_pairs_fetch": (_int, [_vp, _u64, _vp, _u64]),
     "pg_anim_reduce": (_int, [_vp, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _vp]),
     "pg_anim_set_batch_budget": (_int, [_vp, _u32, ctypes.c_uint64]),
     "pg_anim_set_workers": (_int, [_vp, _int]),

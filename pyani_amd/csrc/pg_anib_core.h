@@ -64,7 +64,7 @@ constexpr int32_t FRAG_NEG = -(1 << 28);
 // one cell: u = state of diagonal K+1 (cell (i-1, j)), l = diagonal K-1 (cell (i, j-1)), g = this diagonal's previous cell (i-1, j-1)
 struct FragCellIn { int32_t h, x, y, hs, xs, ys; };      // stats packed: mismatches << 16 | gap bases
 PG_HD FragCellIn frag_cell(bool has_u, const FragCellIn& u, bool has_l, const FragCellIn& l, bool has_g, const FragCellIn& g, bool ok,
-                           int32_t xbest) {
+                           int32_t xbest, int32_t abs_floor) {
   // straight-line: selects and NON-short-circuit logic only (& and | on the flags) — on the device every branch here cost a
   // round of exec-mask bookkeeping per cell
   constexpr int32_t LIVE = FRAG_NEG / 2;
@@ -88,7 +88,8 @@ PG_HD FragCellIn frag_cell(bool has_u, const FragCellIn& u, bool has_l, const Fr
   c.h = tx ? c.x : c.h; c.hs = tx ? c.xs : c.hs;
   const bool ty = c.y > c.h;
   c.h = ty ? c.y : c.h; c.hs = ty ? c.ys : c.hs;
-  const int32_t floor_ = xbest - FRAG_XDROP;
+  const int32_t rel_ = xbest - FRAG_XDROP;
+  const int32_t floor_ = rel_ > abs_floor ? rel_ : abs_floor;      // abs_floor: frag_hsp's second look (FRAG_NEG: none)
   c.h = c.h < floor_ ? FRAG_NEG : c.h;
   c.x = c.x < floor_ ? FRAG_NEG : c.x;
   c.y = c.y < floor_ ? FRAG_NEG : c.y;
@@ -96,7 +97,7 @@ PG_HD FragCellIn frag_cell(bool has_u, const FragCellIn& u, bool has_l, const Fr
 }
 
 template <typename QB, typename SB>
-PG_HD FragExt frag_extend(QB&& qbase, int32_t qmax, SB&& sbase, int32_t smax) {
+PG_HD FragExt frag_extend(QB&& qbase, int32_t qmax, SB&& sbase, int32_t smax, int32_t abs_floor = FRAG_NEG) {
   if (qmax <= 0 || smax <= 0) return FragExt{0, 0, 0, 0, 0};   // nothing to extend into (the anchor reaches the fragment's end)
   FragCellIn S[FRAG_BAND];                  // latest cell of every diagonal (index k <-> diagonal K = k + koff)
   const FragCellIn dead{FRAG_NEG, FRAG_NEG, FRAG_NEG, 0, 0, 0};
@@ -132,7 +133,7 @@ PG_HD FragExt frag_extend(QB&& qbase, int32_t qmax, SB&& sbase, int32_t smax) {
       bool ok = false;
       if (i >= 1 && j >= 1) { const int qb = qbase(i - 1), sb = sbase(j - 1); ok = qb < 4 && qb == sb; }
       const FragCellIn c = frag_cell(i >= 1 && k + 1 < FRAG_BAND, S[k + 1 < FRAG_BAND ? k + 1 : k], j >= 1 && k >= 1, S[k >= 1 ? k - 1 : k],
-                                     i >= 1 && j >= 1, S[k], ok, xbest);
+                                     i >= 1 && j >= 1, S[k], ok, xbest, abs_floor);
       S[k] = c;
       if (c.h > FRAG_NEG / 2 || c.x > FRAG_NEG / 2 || c.y > FRAG_NEG / 2) alive = true;
       if (c.h > best.score) { best.score = c.h; best.di = i; best.dj = j; best.mm = c.hs >> 16; best.gaps = c.hs & 0xFFFF; }
@@ -205,10 +206,215 @@ PG_HD int frag_pick_anchors(const FragSeed* e, int n, int* cand, int32_t* votes_
   return nc;
 }
 
+// ---- where blastn starts its gapped alignment (round 6) ---------------------------------------------------------------------------
+// Rounds 2-5 grew an HSP from the LONGEST exact seed of the fragment's best locus.  The DP itself already followed blastn's rules
+// (fed with blastn's start points it gives blastn's rows: 2 050 of 2 050 on NC_002696 vs NC_010338, profiles/
+// r06_anib_product_vs_blastn_restatement.json), but where two alignments of equal score exist the left (reversed) and the right DP pick
+// different ones, so WHERE the alignment is split decides one row in twenty-five.  blastn splits it like this (blast_gapalign.c,
+// na_ungapped.c; the tests compare with an independent restatement of blastn that shares nothing with this file):
+//   * every exact word of BL_WORD bases is a hit; on a diagonal the hits are taken left to right, one that starts inside the stretch
+//     already explored is dropped, the others are extended without gaps (reward 2 / penalty -3, stop BL_X_UNGAPPED below the best:
+//     20 bits) and become INITIAL HSPs when they score BL_TRIGGER (27 bits) or more;
+//   * the best initial HSP (score, then subject start, length, query start) is aligned first, from its word's first base moved to the
+//     next 4-base boundary of the subject record (1..4 bases);
+//   * before the final alignment that point is kept if it lies in a run of more than BL_START_RUN identities, else moved to the middle
+//     of the first such run on its diagonal, else to the middle of the longest run there.
+// The product takes these steps on the diagonals of its own seeds (16-mers, or 11-mers where the word tier ran): one diagonal walk
+// per seed diagonal — no extra DP pass (blastn bounds the last step by its preliminary X = 30-bit alignment; here the fragment's
+// whole diagonal is searched, which moves 4 of 2 059 reported rows on the table above).
+constexpr int BL_WORD = 11, BL_X_UNGAPPED = 22, BL_TRIGGER = 28, BL_START_RUN = 20;
+constexpr int BL_LOCAL_FULL = 60;                          // below: a chance hit, its own stretch is its diagonal's initial HSP (frag_diag_best_init)
+constexpr int BL_WEAK_SCORE = 64, BL_STRONG_SCORE = 128;   // a candidate below 64 is not aligned when the fragment has one of 128 or more
+
+struct FragInit { int32_t score, q_start, len, q_off; };   // best initial HSP of ONE diagonal (s = q + diag): ungapped stretch + its word
+
+// a precedes b in blastn's order of initial HSPs
+PG_HD bool frag_init_before(const FragInit& a, int64_t adiag, const FragInit& b, int64_t bdiag) {
+  if (a.score != b.score) return a.score > b.score;
+  const int64_t as = a.q_start + adiag, bs = b.q_start + bdiag;
+  if (as != bs) return as < bs;
+  if (a.len != b.len) return a.len > b.len;
+  return a.q_start < b.q_start;
+}
+
+// The one-hit diagonal procedure on one diagonal of a fragment strand.  match(p): query base p == subject base p + diag, both clean
+// and inside their sequences (false outside).  Returns the diagonal's best initial HSP (score 0: none).
+// (ungapped X-drop extension of the word at `a`: left of it, then right from its first base)
+template <typename M>
+PG_HD FragInit frag_ungapped(M&& match, int32_t qlen, int32_t a) {
+  int32_t score = 0, sum = 0, q_beg = a, q_end = a;
+  for (int32_t t = a - 1; t >= 0; --t) {
+    sum += match(t) ? FRAG_MATCH : FRAG_MISMATCH;
+    if (sum > 0) { q_beg = t; score += sum; sum = 0; }
+    else if (sum < -BL_X_UNGAPPED) break;
+  }
+  sum = 0;
+  for (int32_t t = a; t < qlen; ++t) {
+    sum += match(t) ? FRAG_MATCH : FRAG_MISMATCH;
+    if (sum > 0) { q_end = t + 1; score += sum; sum = 0; }
+    else if (sum < -BL_X_UNGAPPED) break;
+  }
+  return FragInit{score, q_beg, q_end - q_beg, a};
+}
+
+// seed_q: where the diagonal's longest seed starts in the fragment strand.  A seed whose own ungapped stretch scores less than
+// BL_LOCAL_FULL is a chance hit (2.4 of them per fragment and 5 Mb of unrelated subject): its diagonal holds nothing else (another
+// exact 11-mer on the same diagonal of 1020 random bases: p ~ 2e-4), so that stretch IS the diagonal's initial HSP and the walk over
+// the whole diagonal is skipped — on the GPU the walk of every chance hit cost as much as the rest of the fragment's work.
+template <typename M>
+PG_HD FragInit frag_diag_best_init(M&& match, int32_t qlen, int64_t diag, int32_t seed_q) {
+  {
+    const FragInit local = frag_ungapped(match, qlen, seed_q);
+    if (local.score < BL_LOCAL_FULL) {
+      if (local.score < BL_TRIGGER) return FragInit{0, 0, 0, 0};
+      int32_t word = seed_q, run = 0;                   // blastn's word: the first exact run of BL_WORD inside the stretch
+      for (int32_t t = local.q_start; t < local.q_start + local.len; ++t) {
+        run = match(t) ? run + 1 : 0;
+        if (run >= BL_WORD) { word = t - run + 1; break; }
+      }
+      return FragInit{local.score, local.q_start, local.len, word};
+    }
+  }
+  FragInit best{0, 0, 0, 0};
+  int32_t last_hit = 0, p = 0;
+  while (p < qlen) {
+    if (!match(p)) { ++p; continue; }
+    const int32_t a = p;
+    while (p < qlen && match(p)) ++p;                 // the maximal exact run [a, p)
+    if (p - a < BL_WORD || a < last_hit) continue;
+    const FragInit h = frag_ungapped(match, qlen, a);
+    const int32_t q_end = h.q_start + h.len;
+    last_hit = q_end > a + BL_WORD ? q_end : a + BL_WORD;
+    if (h.score >= BL_TRIGGER && (best.score == 0 || frag_init_before(h, diag, best, diag))) best = h;
+  }
+  return best;
+}
+
+// Up to two candidates among the per-diagonal initial HSPs init[0..n) (score 0 = none) on diagonals diag[]: the best-supported locus'
+// first initial HSP in blastn's order, then the same among the diagonals at least FRAG_VOTE_FAR away from it.  Returns their number.
+PG_HD int frag_pick_inits(const FragInit* init, const int64_t* diag, int n, int* cand) {
+  int nc = 0;
+  for (int round = 0; round < 2; ++round) {
+    // the locus: the diagonal neighbourhood (FRAG_VOTE_WIN) holding the largest total of initial-HSP scores — blastn aligns every
+    // initial HSP and the table's first row is the best FINAL score, which a long alignment in many pieces wins over one strong repeat
+    int locus = -1;
+    int64_t locus_sum = -1;
+    for (int a = 0; a < n; ++a) {
+      if (init[a].score <= 0) continue;
+      if (round == 1) { const int64_t dd = diag[a] - diag[cand[0]]; if (dd < FRAG_VOTE_FAR && -dd < FRAG_VOTE_FAR) continue; }
+      int64_t sum = 0;
+      for (int b = 0; b < n; ++b) {
+        const int64_t dd = diag[b] - diag[a];
+        if (init[b].score > 0 && dd <= FRAG_VOTE_WIN && -dd <= FRAG_VOTE_WIN) sum += init[b].score;
+      }
+      if (locus < 0 || sum > locus_sum || (sum == locus_sum && frag_init_before(init[a], diag[a], init[locus], diag[locus]))) { locus = a; locus_sum = sum; }
+    }
+    if (locus < 0) break;
+    // inside it, blastn's first initial HSP
+    int best = locus;
+    for (int b = 0; b < n; ++b) {
+      const int64_t dd = diag[b] - diag[locus];
+      if (init[b].score <= 0 || dd > FRAG_VOTE_WIN || -dd > FRAG_VOTE_WIN) continue;
+      if (round == 1) { const int64_t d0 = diag[b] - diag[cand[0]]; if (d0 < FRAG_VOTE_FAR && -d0 < FRAG_VOTE_FAR) continue; }
+      if (frag_init_before(init[b], diag[b], init[best], diag[best])) best = b;
+    }
+    cand[nc++] = best;
+  }
+  return nc;
+}
+PG_HD bool frag_keep_init(int32_t score, int32_t best_score_of_fragment) {
+  return !(score < BL_WEAK_SCORE && best_score_of_fragment >= BL_STRONG_SCORE);
+}
+
+// The point the gapped alignment grows from: the word's first base moved to the next 4-base boundary of the subject record, then
+// blastn's start rule on that diagonal of the fragment.  q_off: the word in the fragment strand; s_rel = its subject position
+// relative to the subject record's first base; lo / hi: the range of fragment positions whose subject base is inside the record.
+template <typename M>
+PG_HD int32_t frag_start_point(M&& match, int32_t qlen, int32_t q_off, int64_t s_rel, int32_t lo, int32_t hi, int32_t init_score) {
+  int32_t g = q_off + 4 - (int32_t)(s_rel & 3);
+  if (g >= qlen) g = q_off;
+  if (init_score < BL_LOCAL_FULL) return g;          // a chance hit: no run of BL_START_RUN anywhere near, the point stays in its word
+  int32_t score = -1;
+  for (int32_t t = g; t < hi && match(t); ++t) if (++score > BL_START_RUN) return g;
+  for (int32_t t = g; t >= lo && match(t); --t) if (++score > BL_START_RUN) return g;
+  int32_t max_score = 0, max_offset = lo, run = 0;
+  bool prev = false, m = false;
+  int32_t i = lo;
+  for (; i < hi; ++i) {
+    m = match(i);
+    if (m != prev) {
+      prev = m;
+      if (m) run = 1;
+      else if (run > max_score) { max_score = run; max_offset = i - run / 2; }
+    } else if (m) {
+      if (++run > BL_START_RUN) return i - BL_START_RUN / 2;
+    }
+  }
+  if (m && run > max_score) { max_score = run; max_offset = i - run / 2; }
+  return max_score > 0 ? max_offset : g;
+}
+
+// Two table rows of one fragment that begin or end at the same point of the same strand: blastn keeps the better one whole and cuts
+// the other where the better one ends (Blast_HSPListPurgeHSPsWithCommonEndpoints) — typically a weak neighbour whose X-drop
+// extension ran across a gap into the main alignment.  What is left of it never covers 70 % of a fragment, so for parse_blast_tab
+// dropping it is the same as cutting it: the product drops it (the statistics of a path are carried forward, there is no script to cut).
+PG_HD bool frag_rows_share_end(int32_t aqs, int32_t aqe, int32_t ass, int32_t ase, int32_t bqs, int32_t bqe, int32_t bss, int32_t bse) {
+  const bool a_minus = ass > ase, b_minus = bss > bse;
+  if (a_minus != b_minus) return false;
+  return (aqs == bqs && ass == bss) || (aqe == bqe && ase == bse);
+}
+
+// blastn's e-value cut (blast_stat.c): E = searchsp * K * exp(-lambda * S) on the EFFECTIVE search space — query and database
+// lengths shortened by the length adjustment l, the fixed point of  l = alpha / lambda * ln(K (m - l)(n - N l)) + beta  (gapped
+// parameters of 2 / -3 / 5 / 2: lambda 0.625, K 0.41, alpha 0.8, beta -2), database = the whole subject genome (n bases, N records).
+PG_HD int32_t frag_length_adjustment(int32_t qlen, int64_t db_len, int32_t db_seqs) {
+  const double K = 0.41, logK = -0.8915981192837836, a_d_l = 0.8 / 0.625, beta = -2.0;
+  const double m = (double)qlen, n = (double)db_len, N = (double)db_seqs;
+  double ell = 0, ell_min = 0, ell_max, ell_next = 0;
+  bool converged = false;
+  {
+    const double a = N, mb = m * N + n, c = n * m - (m > n ? m : n) / K;
+    if (c < 0) return 0;
+    ell_max = 2 * c / (mb + sqrt(mb * mb - 4 * a * c));
+  }
+  for (int i = 1; i <= 20; ++i) {
+    ell = ell_next;
+    const double ss = (m - ell) * (n - N * ell);
+    const double ell_bar = a_d_l * (logK + log(ss)) + beta;
+    if (ell_bar >= ell) {
+      ell_min = ell;
+      if (ell_bar - ell_min <= 1.0) { converged = true; break; }
+      if (ell_min == ell_max) break;
+    } else {
+      ell_max = ell;
+    }
+    if (ell_min <= ell_bar && ell_bar <= ell_max) ell_next = ell_bar;
+    else ell_next = (i == 1) ? ell_max : (ell_min + ell_max) / 2;
+  }
+  int32_t adj = (int32_t)ell_min;
+  if (converged) {
+    ell = ceil(ell_min);
+    if (ell <= ell_max) {
+      const double ss = (m - ell) * (n - N * ell);
+      if (a_d_l * (logK + log(ss)) + beta >= ell) adj = (int32_t)ell;
+    }
+  }
+  return adj;
+}
+PG_HD bool frag_evalue_ok_db(int32_t score, int32_t qlen, int64_t db_len, int32_t db_seqs) {
+  const int32_t adj = frag_length_adjustment(qlen, db_len, db_seqs);
+  int64_t eff_db = db_len - (int64_t)db_seqs * adj;
+  if (eff_db <= 0) eff_db = 1;
+  int32_t eff_q = qlen - adj;
+  if (eff_q <= 0) eff_q = 1;
+  const double bits_nat = 0.625 * (double)score - (-0.8915981192837836);   // lambda * S - ln K
+  return (double)eff_db * (double)eff_q * exp(-bits_nat) <= 1e-15;
+}
+
 // The word tier (blastn's word size, `-task blastn`: anib.py:465-471): a fragment that the 16-mer seeds leave without a reportable
 // HSP is searched again with every 11-mer of either strand; a hit becomes a seed if at least WORD_FLANK_MIN of the WORD_FLANK
 // bases on its left OR on its right match on its diagonal (chance: 8 +- 2.4 of 32; 22 centres the agreement with the BLAST+
-// tables of the reference's tests: the CPU checker of the tests (anib_cpu.cpp) has the statement, profiles/r03_anib_blast_agreement.json the level).
+// tables of the reference's tests: the CPU checker of the tests (anib_cpu.cpp) has the statement, profiles/archive/r03_anib_blast_agreement.json the level).
 constexpr int WORD_K = 11, WORD_FLANK = 32, WORD_FLANK_MIN = 22, WORD_MAX_SEEDS = 512;
 
 // BLAST's e-value for raw score S (blastn 2 / -3, gap costs 5 / 2: lambda = 0.625, K = 0.41), search space m * n without length
@@ -218,16 +424,34 @@ PG_HD bool frag_evalue_ok(int32_t score, int32_t qlen, int64_t slen) {
   return (double)qlen * (double)slen * exp(-bits_nat) <= 1e-15;
 }
 
+// blastn reports an alignment whole only if no proper prefix and no proper suffix of it scores more than all of it: otherwise the
+// better-scoring part is an HSP of its own (found from its own words) and this one, sharing an end with it, is cut there
+// (Blast_HSPListPurgeHSPsWithCommonEndpoints + re-evaluation).  With the alignment grown from a point, a prefix can only beat the
+// whole if the LEFT extension's running score fell below minus the right side's total on its way (and the other way round), which
+// needs that total to be below the X-drop: only then is the side grown a second time, with that floor.
+PG_HD bool frag_second_look(int32_t other_total, int32_t this_score) { return other_total < FRAG_XDROP && this_score > 0; }
+
 // The HSP grown from an exact anchor  query [aq, aq + alen)  ==  subject [as, as + alen)  (both within their limits): leftward
 // and rightward extension + the anchor itself.  q_at(p) / s_at(p): base at absolute query / subject position p (4 / 5 outside).
-template <typename QA, typename SA>
-PG_HD FragHit frag_hsp(QA&& q_at, int32_t qlen, SA&& s_at, int64_t s_lo, int64_t s_hi, int32_t aq, int64_t as, int32_t alen) {
+template <typename QA, typename SA, typename OK>
+PG_HD FragHit frag_hsp(QA&& q_at, int32_t qlen, SA&& s_at, int64_t s_lo, int64_t s_hi, int32_t aq, int64_t as, int32_t alen, OK&& reportable) {
   const int64_t room_r = s_hi - (as + alen), room_l = as - s_lo;
   const int32_t cap = FRAG_SIZE + FRAG_SLACK;
-  const FragExt R = frag_extend([&](int32_t t) { return q_at(aq + alen + t); }, qlen - (aq + alen),
-                                [&](int32_t t) { return s_at(as + alen + t); }, (int32_t)(room_r < cap ? room_r : cap));
-  const FragExt L = frag_extend([&](int32_t t) { return q_at(aq - 1 - t); }, aq,
-                                [&](int32_t t) { return s_at(as - 1 - t); }, (int32_t)(room_l < cap ? room_l : cap));
+  auto qr = [&](int32_t t) { return q_at(aq + alen + t); };
+  auto sr = [&](int32_t t) { return s_at(as + alen + t); };
+  auto ql = [&](int32_t t) { return q_at(aq - 1 - t); };
+  auto sl = [&](int32_t t) { return s_at(as - 1 - t); };
+  const int32_t nr = (int32_t)(room_r < cap ? room_r : cap), nl = (int32_t)(room_l < cap ? room_l : cap);
+  FragExt R = frag_extend(qr, qlen - (aq + alen), sr, nr);
+  FragExt L = frag_extend(ql, aq, sl, nl);
+  // The second look (frag_second_look): where one side scores less than the X-drop, the other side may have crossed a dip deeper than
+  // that side is worth — blastn then reports the far part as an HSP of its own and cuts this one at it.  That side is grown again
+  // with the running score not allowed below minus the other side's total; without such a dip the result is the same extension.
+  const int32_t r_total = R.score + FRAG_MATCH * alen, l_total = L.score;
+  if (reportable(r_total + l_total)) {      // (a second look can only lower the score: a row that fails the e-value already is not looked at again)
+    if (frag_second_look(r_total, L.score)) L = frag_extend(ql, aq, sl, nl, -r_total);
+    if (frag_second_look(l_total, R.score)) R = frag_extend(qr, qlen - (aq + alen), sr, nr, -l_total);
+  }
   return frag_join(L, R, aq, as, alen);
 }
 

@@ -297,6 +297,14 @@ static int anim_ensure_lists(pg_ctx* ctx, AnimScratch* A, const std::vector<int3
 }
 
 static void anim_free_one(pg_ctx* ctx, void*& slot);
+// the workers' launch scratch only (the per-genome seed lists stay): the context must be idle
+void pg_anim_release_worker_scratch(pg_ctx* ctx) {
+  (void)hipStreamSynchronize(ctx->stream);
+  for (int w = 1; w < pg_ctx::MAX_WORKERS; ++w) (void)hipStreamSynchronize(ctx->stream_w[w]);
+  anim_free_one(ctx, ctx->anim_scratch);
+  for (int w = 1; w < pg_ctx::MAX_WORKERS; ++w) anim_free_one(ctx, ctx->anim_scratch_w[w]);
+  ctx->anim_scratch_matches_held = 0;
+}
 void pg_anim_free_scratch(pg_ctx* ctx) {
   pg_anim_drop_lists(ctx);
   delete static_cast<AnimLists*>(ctx->anim_lists);

@@ -347,6 +347,7 @@ int pg_create(pg_ctx** out, int device) {
 
 void pg_destroy(pg_ctx* ctx) {
   if (!ctx) return;
+  for (auto& J : ctx->anim_async) if (J.th.joinable()) J.th.join();      // enqueued ANIm calls nobody fetched
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   for (int w = 1; w < pg_ctx::MAX_WORKERS; ++w) (void)hipStreamSynchronize(ctx->stream_w[w]);
@@ -693,13 +694,14 @@ int pg_tetra_corr_rows_dev(pg_ctx* ctx, const double* d_z, const uint8_t* d_pres
 // threads, each with its own stream and scratch) take chunks in turn, so that one launch's low-occupancy tail overlaps the
 // other's streaming kernels.  run(chunk_begin, chunk_end, worker) processes order[chunk_begin .. chunk_end).
 static int anim_run_chunks(pg_ctx* ctx, const std::vector<std::pair<uint64_t, uint64_t>>& chunks,
-                           const std::function<int(uint64_t, uint64_t, int)>& run) {
-  const int workers = (int)std::min<size_t>((size_t)ctx->anim_workers, chunks.size() ? chunks.size() : 1);
+                           const std::function<int(uint64_t, uint64_t, int)>& run, int slot_base = 0, int max_workers = 0) {
+  const int cap_w = max_workers > 0 ? max_workers : ctx->anim_workers;
+  const int workers = (int)std::min<size_t>((size_t)cap_w, chunks.size() ? chunks.size() : 1);
   std::atomic<size_t> next{0};
   std::atomic<int> first_rc{PG_OK};
   auto body = [&](int w) {
     (void)hipSetDevice(ctx->device);
-    pg_anim_set_worker(ctx, w);
+    pg_anim_set_worker(ctx, slot_base + w);
     for (size_t c; (c = next++) < chunks.size() && first_rc.load() == PG_OK;) {
       int rc;
       try { rc = run(chunks[c].first, chunks[c].second, w); }      // (a worker thread must not let an exception escape: std::terminate)
@@ -770,8 +772,76 @@ int pg_anim_counters(pg_ctx* ctx, uint64_t* out, int reset) {
   return pg_anim_counters_read(ctx, out, reset);
 }
 
+// slot_base / lane_workers: which of the context's worker slots the call drives (pg_anim_pairs: all of them from 0; the lanes of
+// pg_anim_pairs_enqueue: two each); budget_div: the share of the match budget one of its workers may take
+static int anim_pairs_body(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_ids, uint64_t n_pairs, int maxmatch,
+                           int filter_1to1, pg_anim_result* out, int slot_base, int lane_workers, int budget_div);
+
 int pg_anim_pairs(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_ids, uint64_t n_pairs, int maxmatch,
                   int filter_1to1, pg_anim_result* out) {
+  if (ctx) {      // the blocking call owns every worker slot: not while enqueued calls are in flight
+    std::lock_guard<std::mutex> lk(ctx->anim_async_mu);
+    if (ctx->anim_async[0].busy || ctx->anim_async[1].busy) return pg_fail(ctx, PG_E_ARG, "pg_anim_pairs while enqueued calls are in flight: fetch them first");
+  }
+  return anim_pairs_body(ctx, ref_ids, qry_ids, n_pairs, maxmatch, filter_1to1, out, 0, 0, 1);
+}
+
+int pg_anim_pairs_enqueue(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_ids, uint64_t n_pairs, int maxmatch,
+                          int filter_1to1, uint64_t* ticket) {
+  if (!ctx || !ticket || (n_pairs && (!ref_ids || !qry_ids))) return pg_fail(ctx, PG_E_ARG, "bad argument");
+  int rc;
+  if ((rc = pg_upload(ctx))) return rc;      // (on the caller's thread: the lanes never race to upload)
+  std::lock_guard<std::mutex> lk(ctx->anim_async_mu);
+  int lane = -1;
+  for (int l = 0; l < 2; ++l) if (!ctx->anim_async[l].busy) { lane = l; break; }
+  if (lane < 0) return pg_fail(ctx, PG_E_CAPACITY, "two enqueued ANIm calls are in flight: fetch one first");
+  // Blocking calls before this one may have grown two worker slots to most of the device (a 1000-genome grid leaves ~200 GB of launch
+  // scratch for reuse): the other lane's slots would find nothing left.  With no call in flight and less than 40 % of the device free,
+  // the slots' scratch is given back first (they grow again to what enqueued calls need: half-sized launches).
+  if (!ctx->anim_async[0].busy && !ctx->anim_async[1].busy) {
+    size_t free_b = 0, total_b = 0;
+    (void)hipSetDevice(ctx->device);
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (double)free_b < 0.4 * (double)total_b) pg_anim_release_worker_scratch(ctx);
+    (void)hipGetLastError();
+  }
+  pg_ctx::AnimAsync& J = ctx->anim_async[lane];
+  J.r.assign(ref_ids, ref_ids + n_pairs);
+  J.q.assign(qry_ids, qry_ids + n_pairs);
+  J.out.assign(n_pairs, pg_anim_result{});
+  J.ticket = ctx->anim_next_ticket++;
+  J.rc = PG_OK;
+  J.busy = true;
+  const int lane_workers = std::min(2, std::max(1, ctx->anim_workers));
+  J.th = std::thread([ctx, &J, lane, lane_workers, maxmatch, filter_1to1]() {
+    (void)hipSetDevice(ctx->device);
+    try { J.rc = anim_pairs_body(ctx, J.r.data(), J.q.data(), J.r.size(), maxmatch, filter_1to1, J.out.data(), 2 * lane, lane_workers, 2); }
+    catch (const std::bad_alloc&) { J.rc = pg_fail(ctx, PG_E_NOMEM, "out of host memory in an enqueued ANIm call"); }
+    catch (const std::exception& e) { J.rc = pg_fail(ctx, PG_E_HIP, std::string("enqueued ANIm call: ") + e.what()); }
+  });
+  *ticket = J.ticket;
+  return PG_OK;
+}
+
+int pg_anim_pairs_fetch(pg_ctx* ctx, uint64_t ticket, pg_anim_result* out, uint64_t n_pairs) {
+  if (!ctx || (n_pairs && !out)) return pg_fail(ctx, PG_E_ARG, "bad argument");
+  pg_ctx::AnimAsync* J = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(ctx->anim_async_mu);
+    for (int l = 0; l < 2; ++l) if (ctx->anim_async[l].busy && ctx->anim_async[l].ticket == ticket) J = &ctx->anim_async[l];
+  }
+  if (!J) return pg_fail(ctx, PG_E_ARG, "no enqueued ANIm call has this ticket");
+  if (J->th.joinable()) J->th.join();
+  int rc = J->rc;
+  if (rc == PG_OK && n_pairs != J->out.size()) rc = pg_fail(ctx, PG_E_ARG, "pg_anim_pairs_fetch: n_pairs differs from the enqueued call's");
+  if (rc == PG_OK && n_pairs) memcpy(out, J->out.data(), n_pairs * sizeof(pg_anim_result));
+  std::lock_guard<std::mutex> lk(ctx->anim_async_mu);
+  J->r.clear(); J->q.clear(); J->out.clear(); J->out.shrink_to_fit();
+  J->busy = false;
+  return rc;
+}
+
+static int anim_pairs_body(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_ids, uint64_t n_pairs, int maxmatch,
+                           int filter_1to1, pg_anim_result* out, int slot_base, int lane_workers, int budget_div) {
   if (!ctx || (n_pairs && (!ref_ids || !qry_ids || !out))) return pg_fail(ctx, PG_E_ARG, "bad argument");
   PG_HIP(ctx, hipSetDevice(ctx->device));
   for (uint64_t i = 0; i < n_pairs; ++i)
@@ -826,9 +896,11 @@ int pg_anim_pairs(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_ids, u
   // large and each worker gets 1/W of the match budget, so the memory in use is the same
   // (measured, MI355X r04: one family of 25 genomes = 600 related pairs takes 0.58 s on one worker and 0.71 s split over two — each half
   // keeps the launch's sequential tails and they contend; four families = 2 400 pairs: two workers win)
-  const int W = n_pairs >= 1024 ? ctx->anim_workers : 1;
-  const uint32_t MAX_PAIRS = ctx->anim_batch_pairs / W, MAX_REFS = 256;
-  const uint64_t max_matches = anim_match_budget(ctx) / W;
+  const int W = n_pairs >= 1024 ? (lane_workers > 0 ? lane_workers : ctx->anim_workers) : 1;
+  // (an enqueued call shares the device with one other call: half the pairs and half the matches in flight each, so that the
+  // four worker slots together hold what the two of a blocking call hold)
+  const uint32_t MAX_PAIRS = std::max<uint32_t>(1u, ctx->anim_batch_pairs / (uint32_t)(W * budget_div)), MAX_REFS = 256;
+  const uint64_t max_matches = std::max<uint64_t>(4ull << 20, anim_match_budget(ctx) / ((uint64_t)W * (uint64_t)budget_div));
   // about equal launches, a multiple of W of them, none above the per-launch budget
   const uint64_t cap = MAX_PAIRS ? MAX_PAIRS : 1;
   const uint64_t n_target = (uint64_t)W * ((n_pairs + (uint64_t)W * cap - 1) / ((uint64_t)W * cap));
@@ -867,7 +939,7 @@ int pg_anim_pairs(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_ids, u
       i += done;   // pairs beyond the match budget are taken up by the next launch
     }
     return PG_OK;
-  });
+  }, slot_base, W);
 }
 
 int pg_anim_pair_alignments(pg_ctx* ctx, int32_t ref_id, int32_t qry_id, pg_anim_alignment* out, uint32_t cap, uint32_t* n_out) {

@@ -5,6 +5,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -102,6 +103,17 @@ struct pg_ctx {
   int anim_gap_lanes = 1;      // postnuc: small match-to-match gaps on one lane each (0: all gaps on the wave engine; tests compare the two)
   int anim_bwd_ahead = 1;      // backward searches ahead of the units' walks (pga_postnuc.inc); PYANI_ANIM_BWD_AHEAD=0 (development switch): inside them       // PG_EXTENDER_NUCMER (pg_anim_set_extender)
   int anim_workers = 2;
+  // pg_anim_pairs_enqueue / _fetch: two lanes, lane L drives worker slots 2 L and 2 L + 1
+  struct AnimAsync {
+    std::thread th;
+    std::vector<int32_t> r, q;
+    std::vector<pg_anim_result> out;
+    uint64_t ticket = 0;
+    int rc = 0;
+    bool busy = false;
+  } anim_async[2];
+  uint64_t anim_next_ticket = 1;
+  std::mutex anim_async_mu;
   uint32_t anim_batch_pairs = 131072;         // ordered pairs in flight (split over the two workers: 65536 per launch; every launch pays its slowest unit once)
   uint64_t anim_scratch_matches_held = 0;     // match slots the workers' scratch already holds (counts as available to anim_match_budget)
   uint64_t anim_batch_matches = 512ull << 20; // exact matches in flight (~384 B of scratch each, grown on demand: at most ~136 GB of the 288 GB)
@@ -146,6 +158,7 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
                       const PgFragArgs* frag = nullptr);   // ref_ids grouped (equal ids adjacent)
 void pg_anim_set_worker(pg_ctx* ctx, int worker);   // binds the calling thread to worker 0 .. MAX_WORKERS-1 (stream + scratch) for run_batch
 void pg_anim_free_scratch(pg_ctx* ctx);
+void pg_anim_release_worker_scratch(pg_ctx* ctx);   // launch scratch of every worker slot (seed lists stay); idle context only
 int pg_anim_fetch_alignments(pg_ctx* ctx, int32_t ref_id, int32_t qry_id, uint32_t n, pg_anim_alignment* out);   // after a 1-pair batch
 // Where pg_anim_run_batch leaves the alignment records of its pairs when the calling thread has set one (pg_anim_alignments_batch):
 // appended pair after pair in the order of the call's arrays; with_indels adds the traceback pass and every alignment's .delta list.

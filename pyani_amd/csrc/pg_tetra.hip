@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256) void tetra_pairs_kernel(const double* __restri
 }  // namespace
 
 // ---- host launchers ---------------------------------------------------------------------------------------------
-// configuration chosen on MI355X with tools/microbench/count_bench.hip (profiles/r01_count_variants.txt)
+// configuration chosen on MI355X with tools/microbench/count_bench.hip (profiles/archive/r01_count_variants.txt)
 constexpr int K0_PF = 3, K0_BLOCK = 512, K0_BLOCKS_PER_CU = 2;
 
 int pg_launch_tetra_count(pg_ctx* ctx, uint32_t n_batch) {

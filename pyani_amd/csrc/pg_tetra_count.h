@@ -1,7 +1,7 @@
 // pg_tetra_count.h — K0, the HBM-streaming k-mer histogram kernel (device code; included inside an anonymous
 // namespace by pg_tetra.hip and by tools/microbench/count_bench.hip, which times its variants).
 //
-// What bounds it (measured on MI355X, profiles/r01_*): the stream itself runs at the HBM copy peak (~6.1 TB/s) when the
+// What bounds it (measured on MI355X, profiles/archive/r01_*): the stream itself runs at the HBM copy peak (~6.1 TB/s) when the
 // LDS atomics are removed, and the LDS atomic pipe sustains ~32 ds_add_u32 lanes/ns/CU conflict-free (~20 with
 // random banks).  One atomic per base would be 5x too slow, so the kernel counts HEPTAmers at stride 4 — one
 // atomic per 4 bases — into a 16384-bin u32 histogram (64 KiB of LDS) and folds each heptamer bin into the four

@@ -172,6 +172,24 @@ class Engine:
                                            out.ctypes.data))
         return out
 
+    def anim_pairs_enqueue(self, ref_ids, qry_ids, filter_1to1: bool = True, maxmatch: bool = False):
+        """Non-blocking anim_pairs (pg_anim_pairs_enqueue): returns a ticket at once; at most two calls are in flight per engine, the
+        tail of one overlapping the front of the next (pyani's pool keeps its cores busy across job boundaries,
+        run_multiprocessing.py:130-144).  Every ticket must be given to anim_pairs_fetch."""
+        r, q = self._ids(ref_ids), self._ids(qry_ids)
+        if len(r) != len(q):
+            raise ValueError("ref_ids and qry_ids must have the same length")
+        t = ctypes.c_uint64(0)
+        self._check(self.lib.pg_anim_pairs_enqueue(self._h, r.ctypes.data, q.ctypes.data, len(r), int(maxmatch), int(filter_1to1), ctypes.byref(t)))
+        return (int(t.value), len(r))
+
+    def anim_pairs_fetch(self, ticket) -> np.ndarray:
+        """Waits for the enqueued call and returns its records (the caller's pair order), exactly anim_pairs' result."""
+        tid, n = ticket
+        out = np.zeros(n, dtype=self.ANIM_DTYPE)
+        self._check(self.lib.pg_anim_pairs_fetch(self._h, ctypes.c_uint64(tid), out.ctypes.data, n))
+        return out
+
     def anim_set_workers(self, workers: int = 2) -> None:
         """Host worker threads (streams) sharing one anim_pairs / anib_pairs call: 1 ... 4 (pyani's --workers inside one device)."""
         self._check(self.lib.pg_anim_set_workers(self._h, int(workers)))

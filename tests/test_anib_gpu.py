@@ -1,12 +1,13 @@
 """Fragment mode (ANIb, BASELINE.json configs[4]) on the GPU, through the C ABI (pg_anib_pairs / pg_anib_pair_rows).
 
-Two bars, as for ANIm:
-  * GPU == the CPU statement of the same search (oracle/anib_cpu.cpp: same seeds, same anchor rule, same X-drop DP) ROW FOR ROW —
-    integers, so bit-exact — on synthetic pairs of every divergence level and on a real Caulobacter pair;
-  * the search emulates BLAST+ (third-party, absent): compared with the BLAST+ tables the reference's tests hold for the four
-    Caulobacter genomes (tests/golden/anib/*.blast_tab, all 12 ordered pairs) and with blastn_result.csv, at the level reached
-    (the reference's own concordance tolerances for ANIb are 0.2 percentage points above 90 % identity and 5 below,
-    tests/test_concordance.py:131-153).
+Three bars:
+  * against the INDEPENDENT oracle (oracle/blastn_oracle.cpp: blastn restated for pyani's command line, pyani/anib.py:451-471, sharing
+    no code with the product, pinned row by row on the 12 BLAST+ tables the reference's tests hold — tests/test_blastn_oracle.py):
+    the rows parse_blast_tab uses, row for row, on real and synthetic pairs, at the level the product's 16-mer seeding allows
+    (measured on all 12 tables: profiles/r06_anib_product_vs_blastn_restatement.json) — round 6, VERDICT r05 item 1;
+  * against BLAST+'s own tables (tests/golden/anib/*.blast_tab, all 12 ordered pairs) and blastn_result.csv: aggregated tuple;
+  * GPU == the host build of the product's own header (oracle/anib_cpu.cpp) ROW FOR ROW: an implementation check of the kernels
+    (same statement on two machines), NOT a parity claim — that is what the first two bars are.
 """
 import csv
 import json
@@ -18,8 +19,12 @@ import pytest
 from tests.conftest import GOLD, ROOT
 
 sys.path.insert(0, str(ROOT / "oracle"))
+sys.path.insert(0, str(ROOT / "tools"))
 import anib_cpu  # noqa: E402
 import anib_oracle  # noqa: E402
+import blastn_oracle  # noqa: E402
+import blastn_oracle_agreement as agreement  # noqa: E402
+from anib_product_vs_oracle import side_by_side, tuples  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
@@ -116,13 +121,68 @@ def test_real_pair_equals_cpu_statement(eng, caulobacter, genome_dir):
     assert _rows(eng.anib_pair_rows(ids["NC_014100"], ids["NC_002696"])) == _rows(anib_cpu.anib_cpu_pair(q, s))
 
 
+def test_rows_against_the_independent_blastn_oracle_on_real_genomes(eng, caulobacter, genome_dir):
+    """The GPU's table against oracle/blastn_oracle.cpp (nothing shared with the product), row for row over the rows parse_blast_tab
+    uses, on three ordered Caulobacter pairs: a 99.99 % pair (every used row but a handful identical, the tuple equal), an 84 % pair
+    with a two-record subject and a 79 % pair.  Bars = what the product's 16-mer seeding supports (all 12 pairs, measured:
+    profiles/r06_anib_product_vs_blastn_restatement.json: 97.6 - 98.8 % identical, 0 - 10 fragments used on one side only): >= 97 % of
+    the used rows identical, at most 0.5 % of the fragments used on one side only, tuple within 0.04 pp of identity / 0.3 % of aligned
+    length / 0.4 % of similarity errors.  Rows that differ are almost all the same alignment with one mismatch more or less: two
+    alignments of equal score, split at a different start point (blastn's lies on the best of ALL 11-mer diagonals, the product's on
+    the best of its 16-mer seeds' diagonals)."""
+    from tests import oracle_bind
+    ids, _ = caulobacter
+    arrays = {s: oracle_bind.read_fasta_arrays(genome_dir["caulobacter"][s]) for s in ("NC_002696", "NC_011916", "NC_014100", "NC_010338")}
+    report = {}
+    for q, s in (("NC_011916", "NC_002696"), ("NC_014100", "NC_002696"), ("NC_002696", "NC_010338")):
+        up = agreement.used_rows(tuples(eng.anib_pair_rows(ids[q], ids[s])))
+        uo = agreement.used_rows(tuples(blastn_oracle.blastn_pair(arrays[q], arrays[s])))
+        rep = side_by_side(up, uo)
+        report[f"{q}_vs_{s}"] = rep
+        assert rep["used_rows_other"] > 2000, rep
+        if rep["tuple_other"][2] > 99.0:
+            assert rep["identical_fraction"] >= 0.999 and rep["tuple_product"][:2] == rep["tuple_other"][:2] and abs(rep["identity_pp_diff"]) < 1e-9, (q, s, rep)
+        else:
+            assert rep["identical_fraction"] >= 0.97, (q, s, rep)
+            assert rep["only_product"] + rep["only_other"] <= 0.005 * rep["used_rows_other"], (q, s, rep)
+            assert abs(rep["identity_pp_diff"]) < 0.04 and abs(rep["aln_length_rel_diff"]) < 0.003 and abs(rep["sim_errors_rel_diff"]) < 0.004, (q, s, rep)
+    (ROOT / "gpurun_out").mkdir(exist_ok=True)
+    (ROOT / "gpurun_out" / "anib_gpu_vs_blastn_oracle.json").write_text(json.dumps(report, indent=1, sort_keys=True))
+
+
+def test_rows_against_the_independent_blastn_oracle_on_synthetic_pairs(eng):
+    """Synthetic descendants of one ancestor at every divergence of the generator (0.1 ... 15 % per genome, multi-record, inversions):
+    the used rows against the independent oracle.  Pairs above 87 % identity must be EQUAL row for row; over all 30 pairs (down to
+    74 %) >= 99 % of the used rows."""
+    from pyani_amd import synth
+    eng.clear_genomes()
+    n, L, seed = 6, 150_000, 20250302
+    data = [synth.genome(seed, n, g, L) for g in range(n)]
+    ids = [eng.add_genome(*d) for d in data]
+    eng.upload()
+    tot = same = 0
+    for a in range(n):
+        for b in range(n):
+            if a == b:
+                continue
+            up = agreement.used_rows(tuples(eng.anib_pair_rows(ids[a], ids[b])))
+            uo = agreement.used_rows(tuples(blastn_oracle.blastn_pair(data[a], data[b], threads=8)))
+            rep = side_by_side(up, uo)
+            tot += rep["used_rows_other"]
+            same += rep["identical"]
+            if rep["tuple_other"][2] > 87.0:      # (measured: 27 of 3 948 rows differ in all, every one on a pair below 87 %)
+                assert rep["identical"] == rep["used_rows_other"] == rep["used_rows_product"], (a, b, rep)
+            assert rep["identical_fraction"] >= 0.90 and abs(rep["identity_pp_diff"]) < 0.02, (a, b, rep)
+    assert tot > 3500 and same >= 0.99 * tot, (same, tot)
+
+
 def test_agreement_with_blast_plus_tables(eng, caulobacter):
     """All 12 ordered Caulobacter pairs against the BLAST+ tables and blastn_result.csv of the reference's tests.  The two
     99.99 % pairs: aligned length, similarity errors and mean identity EQUAL BLAST+'s (incl. the reference's known answer
     4 016 551 / 93 / 99.99769357705, tests/test_anib.py:387-391).  The ten 78-84 % pairs: mean identity within 0.04 percentage
     points and aligned length within 0.25 % (measured on MI355X, round 3, with the word tier — blastn's 11-mer seeds for the
     fragments the 16-mer seeds leave without a reportable HSP: identity -0.026 ... +0.026 pp, aligned length -0.15 ... +0.17 %,
-    profiles/r03_anib_blast_agreement.json; round 2 without it: +0.09 ... +0.16 pp and -0.8 ... -1.4 %).  BLAST+ itself is a
+    profiles/archive/r03_anib_blast_agreement.json; round 2 without it: +0.09 ... +0.16 pp and -0.8 ... -1.4 %).  BLAST+ itself is a
     heuristic whose tables cannot be reproduced row for row without restating all of blastn; the reference's own concordance
     tolerances for this mode are 0.2 / 5 points (tests/test_zz_concordance_gpu.py holds them on genomes not used here).
     Per pair the level reached goes to gpurun_out/anib_blast_agreement.json."""
@@ -136,14 +196,20 @@ def test_agreement_with_blast_plus_tables(eng, caulobacter):
         assert f"{0.01 * pid:.6f}" == f"{ident[(q, s)]:.6f}"            # the fixture table IS what blastn_result.csv was made from
         report[f"{q}_vs_{s}"] = {"blast": [aln, err, pid], "ours": [int(r["aln_length"]), int(r["sim_errors"]), float(r["pid"])],
                                  "identity_pp_diff": float(r["pid"]) - pid, "aln_length_rel_diff": (int(r["aln_length"]) - aln) / aln,
-                                 "fragments_kept": int(r["n_kept"])}
+                                 "sim_errors_rel_diff": (int(r["sim_errors"]) - err) / max(1, err), "fragments_kept": int(r["n_kept"])}
     (ROOT / "gpurun_out").mkdir(exist_ok=True)
     (ROOT / "gpurun_out" / "anib_blast_agreement.json").write_text(json.dumps(report, indent=1, sort_keys=True))
     for name, rep in report.items():
         if rep["blast"][2] > 99.0:
             assert rep["ours"][:2] == rep["blast"][:2] and abs(rep["identity_pp_diff"]) < 1e-9, (name, rep)
         else:
-            assert abs(rep["identity_pp_diff"]) < 0.04 and abs(rep["aln_length_rel_diff"]) < 0.0025, (name, rep)
+            # round 6 (blastn's start points, the second look, common end points; all 12 tables: profiles/
+            # r06_anib_product_vs_blastn_restatement.json, vs_blast_plus): mean identity -0.006 ... +0.034 pp, aligned length -0.24 ... 0.00 %,
+            # similarity errors -0.34 ... +0.03 % (now asserted too).  The rows agree better than in round 5 (97.5 - 98.8 % of the used rows
+            # identical, 95.7 % before) but the pair tuple does not: what is left is 1 - 6 fragments per pair that BLAST+ reports at 67 - 72 %
+            # identity and the product does not find at all — no exact 16-mer in them, and 11-mers whose 32-base flanks an indel breaks
+            # (the seeding floor); each missing low-identity fragment moves the mean by ~0.005 pp
+            assert abs(rep["identity_pp_diff"]) < 0.04 and abs(rep["aln_length_rel_diff"]) < 0.003 and abs(rep["sim_errors_rel_diff"]) < 0.004, (name, rep)
     near = report["NC_002696_vs_NC_011916"]
     assert near["ours"][:2] == [4016551, 93] and abs(near["ours"][2] - 99.997693577050029) < 1e-9   # the reference's known answer
 

@@ -77,6 +77,43 @@ def _bench(extra_env, nproc, tmp_path, tag, args=None):
     return json.loads(line)
 
 
+def test_enqueued_calls_overlap_and_equal_the_blocking_call():
+    """pg_anim_pairs_enqueue / _fetch (round 6): the pairs of a C3 family cut into four calls, two in flight at a
+    time on disjoint worker slots, give exactly the records of ONE blocking pg_anim_pairs; a third enqueue while two are in flight
+    is refused (PG_E_CAPACITY), so is a blocking call; fetching an unknown ticket is an error; an unfetched call does not leak
+    (pg_destroy joins it)."""
+    from pyani_amd import synth
+    from pyani_amd._lib import PyaniGpuError
+    from pyani_amd.engine import Engine
+    fx = json.loads((GOLD / "anim_c3_family_host.json").read_text())
+    n, L, seed = fx["n"], fx["length"], fx["seed"]
+    pairs = [(p[0], p[1]) for p in fx["pairs"]][:240]
+    used = sorted({g for p in pairs for g in p})
+    with Engine(0) as eng:
+        ids = {g: eng.add_genome(*synth.genome(seed, n, g, L)) for g in used}
+        r, q = [ids[a] for a, _ in pairs], [ids[b] for _, b in pairs]
+        want = eng.anim_pairs(r, q)
+        cuts = [0, 60, 120, 180, 240]
+        got = np.zeros(len(pairs), dtype=want.dtype)
+        pending = []
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            pending.append((lo, hi, eng.anim_pairs_enqueue(r[lo:hi], q[lo:hi])))
+            if len(pending) == 2:
+                with pytest.raises(PyaniGpuError):
+                    eng.anim_pairs_enqueue(r[:4], q[:4])          # two in flight: refused
+                with pytest.raises(PyaniGpuError):
+                    eng.anim_pairs(r[:4], q[:4])                  # the blocking call owns every worker slot
+                a, b, t = pending.pop(0)
+                got[a:b] = eng.anim_pairs_fetch(t)
+        for a, b, t in pending:
+            got[a:b] = eng.anim_pairs_fetch(t)
+        assert got.tobytes() == want.tobytes()
+        with pytest.raises(PyaniGpuError):
+            eng.anim_pairs_fetch((12345, 4))
+        assert eng.anim_pairs(r[:8], q[:8]).tobytes() == want[:8].tobytes()      # the blocking call works again
+        eng.anim_pairs_enqueue(r[:8], q[:8])                                    # never fetched: the context's teardown waits for it
+
+
 def test_bench_two_ranks_on_one_gpu_equal_single_rank(tmp_path):
     """bench.py's N > 1 path (rows dealt over the ranks, Engine per rank, one all-gather per step) on hardware: two ranks
     sharing GPU 0 over gloo (PYANI_BENCH_DEBUG_ONE_GPU) give the same full-grid result hash as one rank."""

@@ -9,7 +9,7 @@
 With the default extender (MUMmer's own postnuc algorithm, pga_postnuc.inc) every one of those records is reproduced —
 coordinates and error counts — and so is every delta-filter decision and every parse_delta tuple, bit for bit.  The per-pair
 report goes to gpurun_out/anim_oos_gpu_report.json (committed copy under profiles/).  History: the banded64 extender reached
-95.5 % of these records unfitted and 99.55 % after five fitted rules (profiles/r02_anim_oos_*.json); Group_2 and the JSpecies
+95.5 % of these records unfitted and 99.55 % after five fitted rules (profiles/archive/r02_anim_oos_*.json); Group_2 and the JSpecies
 runs were never used for any choice.
 """
 import json

@@ -68,3 +68,37 @@ def test_c5_slice_equals_cpu_statement():
         assert abs(float(g["pid"]) - pid) < 1e-9, (a, b)
         related += int(g["n_kept"]) > 0
     assert related >= 8       # the 6 + 2 pairs inside the two families
+
+
+def test_c5_slice_against_the_independent_blastn_oracle():
+    """A C5 slice (1 - 12 Mb genomes of BASELINE.json configs[4]; one family at 99.3 / 97.5 / 94 / 88 / 83.5 % identity) against
+    oracle/blastn_oracle.cpp — code that shares nothing with the product (the C5 test used to compare only with the
+    product's own header built for the host).  Every row parse_blast_tab uses must EQUAL the oracle's on the pairs down to 88 %,
+    and all but a handful at 83.5 % (measured: 2 267 of 2 268); the pair tuples follow."""
+    import sys
+    from tests.conftest import ROOT
+    sys.path.insert(0, str(ROOT / "oracle"))
+    sys.path.insert(0, str(ROOT / "tools"))
+    import blastn_oracle
+    import blastn_oracle_agreement as agreement
+    from anib_product_vs_oracle import side_by_side, tuples
+    from pyani_amd import synth
+    from pyani_amd.engine import Engine
+    n, seed = 500, 20250302
+    pick = [0, 20, 40, 60, 80, 1, 21]
+    data = {g: synth.genome(seed, n, g, _c5_length(g)) for g in pick}
+    with Engine(0) as eng:
+        ids = {g: eng.add_genome(*data[g]) for g in pick}
+        for a, b, exact in ((0, 20, True), (21, 1, True), (0, 40, True), (0, 60, True), (80, 0, True), (60, 80, False)):
+            rows = eng.anib_pair_rows(ids[a], ids[b])
+            rec = eng.anib_pairs([ids[a]], [ids[b]])[0]
+            up = agreement.used_rows(tuples(rows))
+            uo = agreement.used_rows(tuples(blastn_oracle.blastn_pair(data[a], data[b])))
+            rep = side_by_side(up, uo)
+            assert rep["used_rows_other"] > 900, (a, b, rep)
+            if exact:
+                assert rep["identical"] == rep["used_rows_other"] == rep["used_rows_product"], (a, b, rep)
+                aln, err, pid = rep["tuple_other"]
+                assert (int(rec["aln_length"]), int(rec["sim_errors"]), int(rec["n_kept"])) == (aln, err, len(uo)) and abs(float(rec["pid"]) - pid) < 1e-9, (a, b)
+            else:
+                assert rep["identical_fraction"] >= 0.995 and rep["only_product"] + rep["only_other"] <= 2 and abs(rep["identity_pp_diff"]) < 0.005, (a, b, rep)

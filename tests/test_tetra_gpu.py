@@ -209,6 +209,35 @@ def test_full_size_properties(eng):
     assert (corr == corr.T).all() and (np.diag(corr) == 1.0).all() and (np.abs(corr) <= 1.0).all()
 
 
+def test_whole_c2_batch_equals_the_c_oracle(eng, oracle):
+    """BASELINE.json configs[1] at FULL size (C2 ran only as a 6-genome slice under -m gpu): all 200 synthetic
+    ~5 Mb genomes of set C2 in ONE pg_tetra_matrix call — k-mer counts, Z-scores and the 200 x 200 Pearson matrix bit for bit equal
+    to oracle/tetra_oracle.c (the C restatement of pyani/tetra.py:78-194, pinned on the reference's own targets in
+    tests/test_oracle_tetra.py).  The oracle counts on the host's threads (1 GB of sequence: seconds)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from pyani_amd import synth
+    cfg = synth.SETS["C2"]
+    n = cfg["n"]
+    assert n == 200 and cfg["L"] == 5_000_000
+    eng.clear_genomes()
+    c2o, c3o, c4o = (np.zeros((n, k), dtype=np.uint64) for k in (16, 64, 256))
+    ids = []
+    for lo in range(0, n, 25):                                   # 25 genomes (125 MB of text) on the host at a time
+        part = [synth.genome(cfg["seed"], n, g, cfg["L"]) for g in range(lo, lo + 25)]
+        ids += [eng.add_genome(s_, o_) for s_, o_ in part]
+        with ThreadPoolExecutor(8) as ex:                        # (ctypes releases the GIL)
+            for g, (a, b, c) in zip(range(lo, lo + 25), ex.map(lambda d: oracle.counts(*d), part)):
+                c2o[g], c3o[g], c4o[g] = a, b, c
+    c2, c3, c4 = eng.tetra_counts(ids)
+    assert (c2 == c2o).all() and (c3 == c3o).all() and (c4 == c4o).all()
+    z, present, corr = eng.tetra_matrix(ids)
+    zo, po = oracle.zscores(c2o, c3o, c4o)
+    assert (present == po).all() and (z.view(np.uint64) == zo.view(np.uint64)).all()
+    rc, co = oracle.corr(zo, po)
+    assert rc == 0 and corr.shape == (200, 200) and (corr.view(np.uint64) == co.view(np.uint64)).all()
+    eng.clear_genomes()
+
+
 def test_batch_ingest_equals_per_file_ingest(eng, genome_dir):
     """pg_add_fasta_batch (multithreaded read + parse + pack): same ids order, lengths, record counts and counts as the
     per-file path; a missing file fails the whole call and adds nothing."""

@@ -117,7 +117,7 @@ int main(int argc, char** argv) {
             while (q_at(q + len) < 4 && q_at(q + len) == s_at(r + len)) ++len;
             if (len > best_len || (len == best_len && q < best_q)) { best_len = len; best_q = q; best_s = r; }
           }
-          FragHit h = frag_hsp(q_at, qlen, s_at, s_lo, s_hi, best_q, best_s, best_len);
+          FragHit h = frag_hsp(q_at, qlen, s_at, s_lo, s_hi, best_q, best_s, best_len, [](int32_t) { return true; });
           hits.push_back(h); hit_strand.push_back(strand);
           if ((int)chosen.size() >= TOP) break;
         }

@@ -1,7 +1,7 @@
 // valu_issue.hip — development micro-benchmark (not part of the product): how many cycles a SIMD of gfx950 needs per wave64
 // instruction of the kinds the ANIm extension engines are made of (integer VOP2 / VOP3, selects, compares, DPP moves, scalar ALU),
 // with v_fma_f32 as the reference the guide quotes (2 cycles).  The issue roofline of bench.py / DESIGN.md §9 is priced with what
-// this prints (profiles/r04_valu_issue_ubench.txt).
+// this prints (profiles/archive/r04_valu_issue_ubench.txt).
 //   hipcc --offload-arch=gfx950 -O3 tools/ubench/valu_issue.hip -o tools/ubench/valu_issue && tools/ubench/valu_issue
 #include <hip/hip_runtime.h>
 #include <cstdio>
