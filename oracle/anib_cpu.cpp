@@ -188,7 +188,7 @@ void run_pair(const Genome& Q, const Genome& S, int32_t fragsize, std::vector<Ro
     const int32_t fp = frags[f].first, qlen = frags[f].second;
     FragInit init[2][FRAG_MAX_SEEDS];
     int64_t dg[2][FRAG_MAX_SEEDS];
-    int pick[2][2], nc[2] = {0, 0};
+    int pick[2][2], members[2][2] = {{0, 0}, {0, 0}}, nc[2] = {0, 0};
     int32_t best_score = 0;
     for (int strand = 0; strand < 2; ++strand) {
       std::vector<FragSeed>& e = seeds[strand][f];
@@ -214,7 +214,7 @@ void run_pair(const Genome& Q, const Genome& S, int32_t fragsize, std::vector<Ro
         auto match = [&](int32_t p) -> bool { const int qb = q_at(p); const int64_t sp = p + diag; return qb < 4 && sp >= s_lo && sp < s_hi && SV.clean(sp) && SV.base(sp) == qb; };
         init[strand][t] = frag_diag_best_init(match, qlen, diag, e[t].q);
       }
-      nc[strand] = frag_pick_inits(init[strand], dg[strand], n, pick[strand]);
+      nc[strand] = frag_pick_inits(init[strand], dg[strand], n, pick[strand], members[strand]);
       for (int c = 0; c < nc[strand]; ++c) best_score = std::max(best_score, init[strand][pick[strand][c]].score);
     }
     for (int strand = 0; strand < 2; ++strand) {
@@ -234,7 +234,7 @@ void run_pair(const Genome& Q, const Genome& S, int32_t fragsize, std::vector<Ro
         auto match = [&](int32_t p) -> bool { const int qb = q_at(p); return qb < 4 && s_at(p + diag) == qb; };
         const int32_t lo = (int32_t)std::max<int64_t>(0, s_lo - diag), hi = (int32_t)std::min<int64_t>(qlen, s_hi - diag);
         const int32_t g = frag_start_point(match, qlen, I.q_off, I.q_off + diag - s_lo, lo, hi, I.score);
-        const FragHit h = frag_hsp(q_at, qlen, s_at, s_lo, s_hi, g, g + diag, 1, [&](int32_t sc) { return frag_evalue_ok_db(sc, qlen, db_len, db_seqs); });
+        const FragHit h = frag_hsp(q_at, qlen, s_at, s_lo, s_hi, g, g + diag, 1, [&](int32_t sc) { return frag_evalue_ok_db(sc, qlen, db_len, db_seqs); }, frag_init_is_lone_weak(I.score, members[strand][c]));
         if (getenv("ANIB_DUMP_STARTS")) fprintf(stderr, "PSTART %zu %d %d %lld %d init score %d q_start %d len %d word %d -> score %d\n", f, strand, g, (long long)(g + diag - s_lo), srec, I.score, I.q_start, I.len, I.q_off, h.score);
         if (!frag_evalue_ok_db(h.score, qlen, db_len, db_seqs)) continue;
         Row r;

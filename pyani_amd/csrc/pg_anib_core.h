@@ -59,12 +59,13 @@ struct FragHit {             // one HSP: the row of the BLAST table
 #define PGA_FRAG_XDROP 166
 #endif
 constexpr int FRAG_TRACK = 16, FRAG_SHIFT_MAX = 8, FRAG_XDROP = PGA_FRAG_XDROP, FRAG_XSYNC = 4;
+constexpr int FRAG_XDROP_PRELIM = 33;          // blastn's preliminary gapped extension: 30 bits in raw 2 / -3 scores (frag_hsp: chance hits only)
 constexpr int32_t FRAG_NEG = -(1 << 28);
 
 // one cell: u = state of diagonal K+1 (cell (i-1, j)), l = diagonal K-1 (cell (i, j-1)), g = this diagonal's previous cell (i-1, j-1)
 struct FragCellIn { int32_t h, x, y, hs, xs, ys; };      // stats packed: mismatches << 16 | gap bases
 PG_HD FragCellIn frag_cell(bool has_u, const FragCellIn& u, bool has_l, const FragCellIn& l, bool has_g, const FragCellIn& g, bool ok,
-                           int32_t xbest, int32_t abs_floor) {
+                           int32_t xbest, int32_t abs_floor, int32_t xdrop) {
   // straight-line: selects and NON-short-circuit logic only (& and | on the flags) — on the device every branch here cost a
   // round of exec-mask bookkeeping per cell
   constexpr int32_t LIVE = FRAG_NEG / 2;
@@ -88,7 +89,7 @@ PG_HD FragCellIn frag_cell(bool has_u, const FragCellIn& u, bool has_l, const Fr
   c.h = tx ? c.x : c.h; c.hs = tx ? c.xs : c.hs;
   const bool ty = c.y > c.h;
   c.h = ty ? c.y : c.h; c.hs = ty ? c.ys : c.hs;
-  const int32_t rel_ = xbest - FRAG_XDROP;
+  const int32_t rel_ = xbest - xdrop;                                 // xdrop: FRAG_XDROP, or FRAG_XDROP_PRELIM for the preliminary look at a chance hit
   const int32_t floor_ = rel_ > abs_floor ? rel_ : abs_floor;      // abs_floor: frag_hsp's second look (FRAG_NEG: none)
   c.h = c.h < floor_ ? FRAG_NEG : c.h;
   c.x = c.x < floor_ ? FRAG_NEG : c.x;
@@ -97,7 +98,7 @@ PG_HD FragCellIn frag_cell(bool has_u, const FragCellIn& u, bool has_l, const Fr
 }
 
 template <typename QB, typename SB>
-PG_HD FragExt frag_extend(QB&& qbase, int32_t qmax, SB&& sbase, int32_t smax, int32_t abs_floor = FRAG_NEG) {
+PG_HD FragExt frag_extend(QB&& qbase, int32_t qmax, SB&& sbase, int32_t smax, int32_t abs_floor = FRAG_NEG, int32_t xdrop = FRAG_XDROP) {
   if (qmax <= 0 || smax <= 0) return FragExt{0, 0, 0, 0, 0};   // nothing to extend into (the anchor reaches the fragment's end)
   FragCellIn S[FRAG_BAND];                  // latest cell of every diagonal (index k <-> diagonal K = k + koff)
   const FragCellIn dead{FRAG_NEG, FRAG_NEG, FRAG_NEG, 0, 0, 0};
@@ -133,7 +134,7 @@ PG_HD FragExt frag_extend(QB&& qbase, int32_t qmax, SB&& sbase, int32_t smax, in
       bool ok = false;
       if (i >= 1 && j >= 1) { const int qb = qbase(i - 1), sb = sbase(j - 1); ok = qb < 4 && qb == sb; }
       const FragCellIn c = frag_cell(i >= 1 && k + 1 < FRAG_BAND, S[k + 1 < FRAG_BAND ? k + 1 : k], j >= 1 && k >= 1, S[k >= 1 ? k - 1 : k],
-                                     i >= 1 && j >= 1, S[k], ok, xbest, abs_floor);
+                                     i >= 1 && j >= 1, S[k], ok, xbest, abs_floor, xdrop);
       S[k] = c;
       if (c.h > FRAG_NEG / 2 || c.x > FRAG_NEG / 2 || c.y > FRAG_NEG / 2) alive = true;
       if (c.h > best.score) { best.score = c.h; best.di = i; best.dj = j; best.mm = c.hs >> 16; best.gaps = c.hs & 0xFFFF; }
@@ -292,7 +293,9 @@ PG_HD FragInit frag_diag_best_init(M&& match, int32_t qlen, int64_t diag, int32_
 
 // Up to two candidates among the per-diagonal initial HSPs init[0..n) (score 0 = none) on diagonals diag[]: the best-supported locus'
 // first initial HSP in blastn's order, then the same among the diagonals at least FRAG_VOTE_FAR away from it.  Returns their number.
-PG_HD int frag_pick_inits(const FragInit* init, const int64_t* diag, int n, int* cand) {
+// locus_n[c] (optional): how many initial HSPs the candidate's locus holds — 1 = a LONE hit (what a chance match looks like; a weak
+// true alignment has neighbours on nearby diagonals), which is what frag_hsp's preliminary look is for.
+PG_HD int frag_pick_inits(const FragInit* init, const int64_t* diag, int n, int* cand, int* locus_n = nullptr) {
   int nc = 0;
   for (int round = 0; round < 2; ++round) {
     // the locus: the diagonal neighbourhood (FRAG_VOTE_WIN) holding the largest total of initial-HSP scores — blastn aligns every
@@ -311,13 +314,15 @@ PG_HD int frag_pick_inits(const FragInit* init, const int64_t* diag, int n, int*
     }
     if (locus < 0) break;
     // inside it, blastn's first initial HSP
-    int best = locus;
+    int best = locus, members = 0;
     for (int b = 0; b < n; ++b) {
       const int64_t dd = diag[b] - diag[locus];
       if (init[b].score <= 0 || dd > FRAG_VOTE_WIN || -dd > FRAG_VOTE_WIN) continue;
       if (round == 1) { const int64_t d0 = diag[b] - diag[cand[0]]; if (d0 < FRAG_VOTE_FAR && -d0 < FRAG_VOTE_FAR) continue; }
+      ++members;
       if (frag_init_before(init[b], diag[b], init[best], diag[best])) best = b;
     }
+    if (locus_n) locus_n[nc] = members;
     cand[nc++] = best;
   }
   return nc;
@@ -325,6 +330,8 @@ PG_HD int frag_pick_inits(const FragInit* init, const int64_t* diag, int n, int*
 PG_HD bool frag_keep_init(int32_t score, int32_t best_score_of_fragment) {
   return !(score < BL_WEAK_SCORE && best_score_of_fragment >= BL_STRONG_SCORE);
 }
+// A candidate that gets frag_hsp's preliminary look: a chance-sized initial HSP that stands alone in its locus.
+PG_HD bool frag_init_is_lone_weak(int32_t score, int locus_members) { return score < BL_LOCAL_FULL && locus_members <= 1; }
 
 // The point the gapped alignment grows from: the word's first base moved to the next 4-base boundary of the subject record, then
 // blastn's start rule on that diagonal of the fragment.  q_off: the word in the fragment strand; s_rel = its subject position
@@ -431,10 +438,24 @@ PG_HD bool frag_evalue_ok(int32_t score, int32_t qlen, int64_t slen) {
 // needs that total to be below the X-drop: only then is the side grown a second time, with that floor.
 PG_HD bool frag_second_look(int32_t other_total, int32_t this_score) { return other_total < FRAG_XDROP && this_score > 0; }
 
+// After the preliminary look at a lone chance-sized hit: the final alignment is made if the preliminary score passes the e-value
+// cut-off (blastn's rule) — or if it has grown to BL_PRELIM_RESCUE, which chance does not do (a lone 16-mer's stretch scores 32 - 45):
+// such a hit lies in a real, weak alignment, which blastn reaches from another of its 11-mer words that the 16-mer seeding does not
+// see (NC_002696 vs NC_010338, fragment 2494: the one seed's preliminary alignment stops at 56, BLAST+ reports 965 columns there).
+constexpr int BL_PRELIM_RESCUE = 50;
+template <typename OK>
+PG_HD bool frag_prelim_goes_on(int32_t prelim_score, OK&& reportable) { return prelim_score >= BL_PRELIM_RESCUE || reportable(prelim_score); }
+
 // The HSP grown from an exact anchor  query [aq, aq + alen)  ==  subject [as, as + alen)  (both within their limits): leftward
 // and rightward extension + the anchor itself.  q_at(p) / s_at(p): base at absolute query / subject position p (4 / 5 outside).
+// weak: the candidate is a chance hit (its initial HSP scores less than BL_LOCAL_FULL).  blastn aligns every initial HSP with a
+// PRELIMINARY X-drop of 30 bits first and drops those whose preliminary score misses the e-value cut-off before the final 150-bit
+// alignment is ever made; a chance hit dies there within ~20 bases.  The product takes that look for weak candidates only (a strong
+// one passes it anyway): the first version ran every chance hit — 2.4 per fragment and unrelated 5 Mb subject — under the final
+// X-drop, ~5 x the cells, which was most of what the fragment kernel did on a C5 grid.
 template <typename QA, typename SA, typename OK>
-PG_HD FragHit frag_hsp(QA&& q_at, int32_t qlen, SA&& s_at, int64_t s_lo, int64_t s_hi, int32_t aq, int64_t as, int32_t alen, OK&& reportable) {
+PG_HD FragHit frag_hsp(QA&& q_at, int32_t qlen, SA&& s_at, int64_t s_lo, int64_t s_hi, int32_t aq, int64_t as, int32_t alen, OK&& reportable,
+                       bool weak = false) {
   const int64_t room_r = s_hi - (as + alen), room_l = as - s_lo;
   const int32_t cap = FRAG_SIZE + FRAG_SLACK;
   auto qr = [&](int32_t t) { return q_at(aq + alen + t); };
@@ -442,6 +463,11 @@ PG_HD FragHit frag_hsp(QA&& q_at, int32_t qlen, SA&& s_at, int64_t s_lo, int64_t
   auto ql = [&](int32_t t) { return q_at(aq - 1 - t); };
   auto sl = [&](int32_t t) { return s_at(as - 1 - t); };
   const int32_t nr = (int32_t)(room_r < cap ? room_r : cap), nl = (int32_t)(room_l < cap ? room_l : cap);
+  if (weak) {
+    const FragExt Rp = frag_extend(qr, qlen - (aq + alen), sr, nr, FRAG_NEG, FRAG_XDROP_PRELIM);
+    const FragExt Lp = frag_extend(ql, aq, sl, nl, FRAG_NEG, FRAG_XDROP_PRELIM);
+    if (!frag_prelim_goes_on(Rp.score + Lp.score + FRAG_MATCH * alen, reportable)) return frag_join(Lp, Rp, aq, as, alen);      // (fails the cut-off: the caller drops it)
+  }
   FragExt R = frag_extend(qr, qlen - (aq + alen), sr, nr);
   FragExt L = frag_extend(ql, aq, sl, nl);
   // The second look (frag_second_look): where one side scores less than the X-drop, the other side may have crossed a dip deeper than
