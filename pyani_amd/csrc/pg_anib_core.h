@@ -258,12 +258,35 @@ PG_HD FragInit frag_ungapped(M&& match, int32_t qlen, int32_t a) {
   return FragInit{score, q_beg, q_end - q_beg, a};
 }
 
+// the whole diagonal, left to right: every exact run of BL_WORD or more that starts outside the stretch already explored is a hit
+// (second: the diagonal's second initial HSP in blastn's order, score 0 if none — the preliminary stage looks at both)
+template <typename M>
+PG_HD FragInit frag_diag_walk(M&& match, int32_t qlen, int64_t diag, FragInit* second = nullptr) {
+  FragInit best{0, 0, 0, 0}, next{0, 0, 0, 0};
+  int32_t last_hit = 0, p = 0;
+  while (p < qlen) {
+    if (!match(p)) { ++p; continue; }
+    const int32_t a = p;
+    while (p < qlen && match(p)) ++p;                 // the maximal exact run [a, p)
+    if (p - a < BL_WORD || a < last_hit) continue;
+    const FragInit h = frag_ungapped(match, qlen, a);
+    const int32_t q_end = h.q_start + h.len;
+    last_hit = q_end > a + BL_WORD ? q_end : a + BL_WORD;
+    if (h.score < BL_TRIGGER) continue;
+    if (best.score == 0 || frag_init_before(h, diag, best, diag)) { next = best; best = h; }
+    else if (next.score == 0 || frag_init_before(h, diag, next, diag)) next = h;
+  }
+  if (second) *second = next;
+  return best;
+}
+
 // seed_q: where the diagonal's longest seed starts in the fragment strand.  A seed whose own ungapped stretch scores less than
 // BL_LOCAL_FULL is a chance hit (2.4 of them per fragment and 5 Mb of unrelated subject): its diagonal holds nothing else (another
 // exact 11-mer on the same diagonal of 1020 random bases: p ~ 2e-4), so that stretch IS the diagonal's initial HSP and the walk over
 // the whole diagonal is skipped — on the GPU the walk of every chance hit cost as much as the rest of the fragment's work.
 template <typename M>
-PG_HD FragInit frag_diag_best_init(M&& match, int32_t qlen, int64_t diag, int32_t seed_q) {
+PG_HD FragInit frag_diag_best_init(M&& match, int32_t qlen, int64_t diag, int32_t seed_q, FragInit* second = nullptr) {
+  if (second) *second = FragInit{0, 0, 0, 0};
   {
     const FragInit local = frag_ungapped(match, qlen, seed_q);
     if (local.score < BL_LOCAL_FULL) {
@@ -276,19 +299,7 @@ PG_HD FragInit frag_diag_best_init(M&& match, int32_t qlen, int64_t diag, int32_
       return FragInit{local.score, local.q_start, local.len, word};
     }
   }
-  FragInit best{0, 0, 0, 0};
-  int32_t last_hit = 0, p = 0;
-  while (p < qlen) {
-    if (!match(p)) { ++p; continue; }
-    const int32_t a = p;
-    while (p < qlen && match(p)) ++p;                 // the maximal exact run [a, p)
-    if (p - a < BL_WORD || a < last_hit) continue;
-    const FragInit h = frag_ungapped(match, qlen, a);
-    const int32_t q_end = h.q_start + h.len;
-    last_hit = q_end > a + BL_WORD ? q_end : a + BL_WORD;
-    if (h.score >= BL_TRIGGER && (best.score == 0 || frag_init_before(h, diag, best, diag))) best = h;
-  }
-  return best;
+  return frag_diag_walk(match, qlen, diag, second);
 }
 
 // Up to two candidates among the per-diagonal initial HSPs init[0..n) (score 0 = none) on diagonals diag[]: the best-supported locus'
@@ -359,6 +370,69 @@ PG_HD int32_t frag_start_point(M&& match, int32_t qlen, int32_t q_off, int64_t s
   }
   if (m && run > max_score) { max_score = run; max_offset = i - run / 2; }
   return max_score > 0 ? max_offset : g;
+}
+
+// The same rule as blastn applies it (BlastGetStartForGappedAlignmentNucl): the search for a run is bounded by the PRELIMINARY
+// alignment's box — [q0, q1) x [s0, s1) in fragment / record-relative subject coordinates, grown from the point g (subject gs) under
+// the preliminary X-drop.  rec_lo: the first fragment position whose subject base on this diagonal is inside the record.
+template <typename M>
+PG_HD int32_t frag_start_point_boxed(M&& match, int32_t g, int64_t gs, int32_t q0, int32_t q1, int64_t s0, int64_t s1, int32_t rec_lo) {
+  int32_t score = -1;
+  for (int32_t t = g; t < q1 && match(t); ++t) if (++score > BL_START_RUN) return g;
+  for (int32_t t = g; t >= rec_lo && match(t); --t) if (++score > BL_START_RUN) return g;
+  const int64_t off64 = (gs - s0) < (int64_t)(g - q0) ? (gs - s0) : (int64_t)(g - q0);
+  const int32_t off = (int32_t)off64, lo = g - off;
+  const int64_t s_start = gs - off;
+  const int64_t len64 = (s1 - s_start) < (int64_t)(q1 - lo) ? (s1 - s_start) : (int64_t)(q1 - lo);
+  const int32_t hi = lo + (int32_t)len64;
+  int32_t max_score = 0, max_offset = lo, run = 0;
+  bool prev = false, m = false;
+  int32_t i = lo;
+  for (; i < hi; ++i) {
+    m = match(i);
+    if (m != prev) {
+      prev = m;
+      if (m) run = 1;
+      else if (run > max_score) { max_score = run; max_offset = i - run / 2; }
+    } else if (m) {
+      if (++run > BL_START_RUN) return i - BL_START_RUN / 2;
+    }
+  }
+  if (m && run > max_score) { max_score = run; max_offset = i - run / 2; }
+  return max_score > 0 ? max_offset : g;
+}
+
+// ---- blastn's preliminary stage (round 6, second half) ----------------------------------------------------------------------------
+// blastn does not align its best initial HSP once: EVERY initial HSP, best first, is grown under the preliminary X-drop (30 bits)
+// unless it lies inside the box of a better preliminary alignment on a nearby diagonal (blast_itree.c, s_HSPIsContained); of
+// preliminary alignments with a common end the better one stays, and the final alignment is grown from the start point OF THE BEST
+// PRELIMINARY ALIGNMENT — which need not be the best initial HSP's: a strong stretch walled in by a divergent patch loses to a weaker
+// one whose 30-bit alignment gets across (NC_002696 vs NC_010338, fragment 1618: initial HSPs of 787 and 437; the first one's
+// preliminary alignment stops at 462 of 1020 bases with 787, the second covers the fragment with 1 309 and gives the table's row).
+// The product takes these steps over the initial HSPs of a candidate's neighbourhood (FRAG_VOTE_FAR diagonals), at most
+// BL_MAX_PRELIMS preliminary alignments per candidate.
+struct FragPrelim { int32_t score, q0, q1, g; int64_t s0, s1, diag; };   // box [q0, q1] x [s0, s1], grown from (g, g + diag)
+constexpr int BL_MIN_DIAG_SEPARATION = 50, BL_MAX_PRELIMS = 4;
+PG_HD bool frag_init_contained(const FragInit& in, int64_t diag, const FragPrelim& t) {
+  if (in.score > t.score) return false;
+  const int64_t q0 = in.q_start, q1 = q0 + in.len, s0 = q0 + diag, s1 = s0 + in.len;
+  const bool inside = q0 >= t.q0 && q0 <= t.q1 && s0 >= t.s0 && s0 <= t.s1 && q1 >= t.q0 && q1 <= t.q1 && s1 >= t.s0 && s1 <= t.s1;
+  if (!inside) return false;
+  int64_t a = (t.q0 - t.s0) - (q0 - s0), b = (t.q1 - t.s1) - (q1 - s1);
+  a = a < 0 ? -a : a; b = b < 0 ? -b : b;
+  return a < BL_MIN_DIAG_SEPARATION || b < BL_MIN_DIAG_SEPARATION;
+}
+PG_HD bool frag_prelim_before(const FragPrelim& a, const FragPrelim& b) {
+  if (a.score != b.score) return a.score > b.score;
+  if (a.s0 != b.s0) return a.s0 < b.s0;
+  if (a.s1 != b.s1) return a.s1 > b.s1;
+  if (a.q0 != b.q0) return a.q0 < b.q0;
+  return a.q1 > b.q1;
+}
+// the word's first base moved to the next 4-base boundary of the subject record
+PG_HD int32_t frag_word_start(int32_t q_off, int64_t s_rel, int32_t qlen) {
+  const int32_t g = q_off + 4 - (int32_t)(s_rel & 3);
+  return g >= qlen ? q_off : g;
 }
 
 // Two table rows of one fragment that begin or end at the same point of the same strand: blastn keeps the better one whole and cuts
