@@ -188,7 +188,7 @@ void run_pair(const Genome& Q, const Genome& S, int32_t fragsize, std::vector<Ro
     const int32_t fp = frags[f].first, qlen = frags[f].second;
     FragInit init[2][FRAG_MAX_SEEDS], init2[2][FRAG_MAX_SEEDS];
     int64_t dg[2][FRAG_MAX_SEEDS];
-    int pick[2][2], members[2][2] = {{0, 0}, {0, 0}}, nc[2] = {0, 0};
+    int pick[2][FRAG_MAX_CAND], members[2][FRAG_MAX_CAND] = {}, nc[2] = {0, 0};
     int32_t best_score = 0;
     for (int strand = 0; strand < 2; ++strand) {
       std::vector<FragSeed>& e = seeds[strand][f];
@@ -214,7 +214,7 @@ void run_pair(const Genome& Q, const Genome& S, int32_t fragsize, std::vector<Ro
         auto match = [&](int32_t p) -> bool { const int qb = q_at(p); const int64_t sp = p + diag; return qb < 4 && sp >= s_lo && sp < s_hi && SV.clean(sp) && SV.base(sp) == qb; };
         init[strand][t] = frag_diag_best_init(match, qlen, diag, e[t].q, &init2[strand][t]);
       }
-      nc[strand] = frag_pick_inits(init[strand], dg[strand], n, pick[strand], members[strand]);
+      nc[strand] = frag_pick_inits(init[strand], dg[strand], n, pick[strand], members[strand], FRAG_MAX_CAND);
       for (int c = 0; c < nc[strand]; ++c) best_score = std::max(best_score, init[strand][pick[strand][c]].score);
     }
     for (int strand = 0; strand < 2; ++strand) {
@@ -224,68 +224,91 @@ void run_pair(const Genome& Q, const Genome& S, int32_t fragsize, std::vector<Ro
         if (!QVw.clean(g)) return 4;
         return strand ? 3 - QVw.base(g) : QVw.base(g);
       };
+      // phase A: the preliminary stage of every candidate that is not a lone chance-sized hit (pg_anib_core.h, FragPrelim)
+      FragPrelim pbest[FRAG_MAX_CAND];
+      bool have[FRAG_MAX_CAND] = {};
+      const int n_seeds = (int)seeds[strand][f].size() < FRAG_MAX_SEEDS ? (int)seeds[strand][f].size() : FRAG_MAX_SEEDS;
+      auto init_of = [&](int x) -> const FragInit& { return (x & 1) ? init2[strand][x >> 1] : init[strand][x >> 1]; };
       for (int c = 0; c < nc[strand]; ++c) {
         const FragInit& I = init[strand][pick[strand][c]];
-        if (!frag_keep_init(I.score, best_score)) continue;
+        if (!frag_keep_init(I.score, best_score) || frag_init_is_lone_weak(I.score, members[strand][c])) continue;
         const int64_t diag = dg[strand][pick[strand][c]];
         const int srec = record_of(S.rec_start.data(), (int)S.rec_start.size() - 1, (int32_t)(I.q_off + diag));
         const int64_t s_lo = S.rec_start[srec], s_hi = S.rec_start[srec + 1] - 1;
         auto s_at = [&](int64_t p) -> int { return (p >= s_lo && p < s_hi && SV.clean(p)) ? SV.base(p) : 5; };
-        auto match = [&](int32_t p) -> bool { const int qb = q_at(p); return qb < 4 && s_at(p + diag) == qb; };
-        const int32_t lo = (int32_t)std::max<int64_t>(0, s_lo - diag), hi = (int32_t)std::min<int64_t>(qlen, s_hi - diag);
+        std::vector<int> order;      // 2 t: the diagonal's best initial HSP, 2 t + 1: its second
+        for (int t = 0; t < n_seeds; ++t) {
+          if (init[strand][t].score <= 0) continue;
+          const int64_t dd = dg[strand][t] - diag;
+          if (dd >= FRAG_VOTE_FAR || -dd >= FRAG_VOTE_FAR) continue;
+          bool taken = false;      // (the neighbourhood of an earlier candidate)
+          for (int p = 0; p < c; ++p) { const int64_t d1 = dg[strand][t] - dg[strand][pick[strand][p]]; taken = taken || (d1 < FRAG_VOTE_FAR && -d1 < FRAG_VOTE_FAR); }
+          if (taken) continue;
+          if (record_of(S.rec_start.data(), (int)S.rec_start.size() - 1, (int32_t)(init[strand][t].q_off + dg[strand][t])) != srec) continue;
+          order.push_back(2 * t);
+          if (init2[strand][t].score > 0) order.push_back(2 * t + 1);
+        }
+        std::sort(order.begin(), order.end(), [&](int x, int y) { return frag_init_before(init_of(x), dg[strand][x >> 1], init_of(y), dg[strand][y >> 1]); });
+        FragPrelim pre[BL_MAX_PRELIMS];
+        int np = 0, tried = 0;
+        FragPrelim first{0, 0, 0, 0, 0, 0, 0};
+        for (int x : order) {
+          if (tried == BL_MAX_PRELIMS) break;
+          const FragInit& J = init_of(x);
+          const int64_t dj = dg[strand][x >> 1];
+          bool inside = false;
+          for (int u = 0; u < np; ++u) inside = inside || frag_init_contained(J, dj, pre[u]);
+          if (inside) continue;
+          const int32_t g0 = frag_word_start(J.q_off, J.q_off + dj - s_lo, qlen);
+          const int64_t as = g0 + dj;
+          auto qr = [&](int32_t x2) { return q_at(g0 + 1 + x2); };
+          auto sr = [&](int32_t x2) { return s_at(as + 1 + x2); };
+          auto ql = [&](int32_t x2) { return q_at(g0 - 1 - x2); };
+          auto sl = [&](int32_t x2) { return s_at(as - 1 - x2); };
+          const int32_t cap = FRAG_SIZE + FRAG_SLACK;
+          const FragExt Rp = frag_extend(qr, qlen - (g0 + 1), sr, (int32_t)std::min<int64_t>(s_hi - (as + 1), cap), FRAG_NEG, FRAG_XDROP_PRELIM);
+          const FragExt Lp = frag_extend(ql, g0, sl, (int32_t)std::min<int64_t>(as - s_lo, cap), FRAG_NEG, FRAG_XDROP_PRELIM);
+          const FragPrelim P{Rp.score + Lp.score + FRAG_MATCH, g0 - Lp.di, g0 + 1 + Rp.di, g0, as - Lp.dj, as + 1 + Rp.dj, dj};
+          if (tried++ == 0) first = P;
+          if (frag_evalue_ok_db(P.score, qlen, db_len, db_seqs)) pre[np++] = P;
+        }
+        const FragPrelim* best = nullptr;
+        for (int u = 0; u < np; ++u) if (!best || frag_prelim_before(pre[u], *best)) best = &pre[u];
+        if (!best && tried > 0 && first.score >= BL_PRELIM_RESCUE) best = &first;
+        if (best) { pbest[c] = *best; have[c] = true; }
+      }
+      // more than two: the final alignments of the two best preliminary ones only (frag_pick_inits)
+      {
+        int n_have = 0;
+        for (int c = 0; c < nc[strand]; ++c) n_have += have[c];
+        while (n_have > 2) {
+          int worst = -1;
+          for (int c = 0; c < nc[strand]; ++c) if (have[c] && (worst < 0 || !frag_prelim_before(pbest[c], pbest[worst]))) worst = c;
+          have[worst] = false; --n_have;
+        }
+      }
+      // phase B: the final alignments, in the candidates' order
+      for (int c = 0; c < nc[strand]; ++c) {
+        const FragInit& I = init[strand][pick[strand][c]];
+        if (!frag_keep_init(I.score, best_score)) continue;
         const bool lone_weak = frag_init_is_lone_weak(I.score, members[strand][c]);
-        int32_t g = frag_start_point(match, qlen, I.q_off, I.q_off + diag - s_lo, lo, hi, I.score);
+        if (!lone_weak && !have[c]) continue;
+        const int64_t diag = dg[strand][pick[strand][c]];
+        const int srec = record_of(S.rec_start.data(), (int)S.rec_start.size() - 1, (int32_t)(I.q_off + diag));
+        const int64_t s_lo = S.rec_start[srec], s_hi = S.rec_start[srec + 1] - 1;
+        auto s_at = [&](int64_t p) -> int { return (p >= s_lo && p < s_hi && SV.clean(p)) ? SV.base(p) : 5; };
+        int32_t g;
         int64_t gdiag = diag;
-        if (!lone_weak) {
-          // blastn's preliminary stage over the initial HSPs of the candidate's neighbourhood (pg_anib_core.h)
-          const int n = (int)seeds[strand][f].size() < FRAG_MAX_SEEDS ? (int)seeds[strand][f].size() : FRAG_MAX_SEEDS;
-          const int64_t d_other = nc[strand] > 1 ? dg[strand][pick[strand][1 - c]] : 0;
-          std::vector<int> order;      // 2 t: the diagonal's best initial HSP, 2 t + 1: its second
-          auto init_of = [&](int x) -> const FragInit& { return (x & 1) ? init2[strand][x >> 1] : init[strand][x >> 1]; };
-          for (int t = 0; t < n; ++t) {
-            if (init[strand][t].score <= 0) continue;
-            const int64_t dd = dg[strand][t] - diag;
-            if (dd >= FRAG_VOTE_FAR || -dd >= FRAG_VOTE_FAR) continue;
-            if (c == 1) { const int64_t d1 = dg[strand][t] - d_other; if (d1 < FRAG_VOTE_FAR && -d1 < FRAG_VOTE_FAR) continue; }
-            if (record_of(S.rec_start.data(), (int)S.rec_start.size() - 1, (int32_t)(init[strand][t].q_off + dg[strand][t])) != srec) continue;
-            order.push_back(2 * t);
-            if (init2[strand][t].score > 0) order.push_back(2 * t + 1);
-          }
-          struct Ent { FragInit in; int64_t d; };
-          std::vector<Ent> ents;
-          for (int x : order) ents.push_back(Ent{init_of(x), dg[strand][x >> 1]});
-          std::sort(ents.begin(), ents.end(), [&](const Ent& x, const Ent& y) { return frag_init_before(x.in, x.d, y.in, y.d); });
-          FragPrelim pre[BL_MAX_PRELIMS];
-          int np = 0, tried = 0;
-          FragPrelim first{0, 0, 0, 0, 0, 0, 0};
-          for (const Ent& en : ents) {
-            if (tried == BL_MAX_PRELIMS) break;
-            const FragInit& J = en.in;
-            const int64_t dj = en.d;
-            bool inside = false;
-            for (int u = 0; u < np; ++u) inside = inside || frag_init_contained(J, dj, pre[u]);
-            if (inside) continue;
-            const int32_t g0 = frag_word_start(J.q_off, J.q_off + dj - s_lo, qlen);
-            const int64_t as = g0 + dj;
-            auto qr = [&](int32_t x) { return q_at(g0 + 1 + x); };
-            auto sr = [&](int32_t x) { return s_at(as + 1 + x); };
-            auto ql = [&](int32_t x) { return q_at(g0 - 1 - x); };
-            auto sl = [&](int32_t x) { return s_at(as - 1 - x); };
-            const int32_t cap = FRAG_SIZE + FRAG_SLACK;
-            const FragExt Rp = frag_extend(qr, qlen - (g0 + 1), sr, (int32_t)std::min<int64_t>(s_hi - (as + 1), cap), FRAG_NEG, FRAG_XDROP_PRELIM);
-            const FragExt Lp = frag_extend(ql, g0, sl, (int32_t)std::min<int64_t>(as - s_lo, cap), FRAG_NEG, FRAG_XDROP_PRELIM);
-            const FragPrelim P{Rp.score + Lp.score + FRAG_MATCH, g0 - Lp.di, g0 + 1 + Rp.di, g0, as - Lp.dj, as + 1 + Rp.dj, dj};
-            if (tried++ == 0) first = P;
-            if (frag_evalue_ok_db(P.score, qlen, db_len, db_seqs)) pre[np++] = P;
-          }
-          const FragPrelim* best = nullptr;
-          for (int u = 0; u < np; ++u) if (!best || frag_prelim_before(pre[u], *best)) best = &pre[u];
-          if (!best && tried > 0 && first.score >= BL_PRELIM_RESCUE) best = &first;
-          if (!best) continue;
-          gdiag = best->diag;
+        if (lone_weak) {
+          auto match = [&](int32_t p) -> bool { const int qb = q_at(p); return qb < 4 && s_at(p + diag) == qb; };
+          const int32_t lo = (int32_t)std::max<int64_t>(0, s_lo - diag), hi = (int32_t)std::min<int64_t>(qlen, s_hi - diag);
+          g = frag_start_point(match, qlen, I.q_off, I.q_off + diag - s_lo, lo, hi, I.score);
+        } else {
+          const FragPrelim& best = pbest[c];
+          gdiag = best.diag;
           auto match_b = [&](int32_t p) -> bool { const int qb = q_at(p); return qb < 4 && s_at(p + gdiag) == qb; };
           const int32_t rec_lo = (int32_t)std::max<int64_t>(0, s_lo - gdiag);
-          g = frag_start_point_boxed(match_b, best->g, best->g + gdiag, best->q0, best->q1, best->s0, best->s1, rec_lo);
+          g = frag_start_point_boxed(match_b, best.g, best.g + gdiag, best.q0, best.q1, best.s0, best.s1, rec_lo);
         }
         const FragHit h = frag_hsp(q_at, qlen, s_at, s_lo, s_hi, g, g + gdiag, 1, [&](int32_t sc) { return frag_evalue_ok_db(sc, qlen, db_len, db_seqs); }, lone_weak);
         if (getenv("ANIB_DUMP_STARTS")) fprintf(stderr, "PSTART %zu %d %d %lld %d init score %d q_start %d len %d word %d -> score %d\n", f, strand, g, (long long)(g + gdiag - s_lo), srec, I.score, I.q_start, I.len, I.q_off, h.score);

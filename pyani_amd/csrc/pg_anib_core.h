@@ -306,16 +306,23 @@ PG_HD FragInit frag_diag_best_init(M&& match, int32_t qlen, int64_t diag, int32_
 // first initial HSP in blastn's order, then the same among the diagonals at least FRAG_VOTE_FAR away from it.  Returns their number.
 // locus_n[c] (optional): how many initial HSPs the candidate's locus holds — 1 = a LONE hit (what a chance match looks like; a weak
 // true alignment has neighbours on nearby diagonals), which is what frag_hsp's preliminary look is for.
-PG_HD int frag_pick_inits(const FragInit* init, const int64_t* diag, int n, int* cand, int* locus_n = nullptr) {
+// max_cand > 2 (FRAG_MAX_CAND): a repeat family (rRNA operons, insertion elements: a dozen copies with initial HSPs of a few hundred
+// each) — blastn aligns them all and the table's first row is the best FINAL score, which the two best-supported loci need not hold
+// (NC_002696 vs NC_010338, fragment 3015).  Candidates beyond the second must be strong (BL_STRONG_SCORE): chance hits never open
+// a third round.  The caller grows the preliminary alignments of all of them and the final ones of the two best (frag_prelim_before).
+constexpr int FRAG_MAX_CAND = 8;
+PG_HD int frag_pick_inits(const FragInit* init, const int64_t* diag, int n, int* cand, int* locus_n = nullptr, int max_cand = 2) {
   int nc = 0;
-  for (int round = 0; round < 2; ++round) {
+  for (int round = 0; round < max_cand; ++round) {
     // the locus: the diagonal neighbourhood (FRAG_VOTE_WIN) holding the largest total of initial-HSP scores — blastn aligns every
     // initial HSP and the table's first row is the best FINAL score, which a long alignment in many pieces wins over one strong repeat
     int locus = -1;
     int64_t locus_sum = -1;
     for (int a = 0; a < n; ++a) {
       if (init[a].score <= 0) continue;
-      if (round == 1) { const int64_t dd = diag[a] - diag[cand[0]]; if (dd < FRAG_VOTE_FAR && -dd < FRAG_VOTE_FAR) continue; }
+      bool taken = false;
+      for (int p = 0; p < round; ++p) { const int64_t dd = diag[a] - diag[cand[p]]; taken = taken || (dd < FRAG_VOTE_FAR && -dd < FRAG_VOTE_FAR); }
+      if (taken) continue;
       int64_t sum = 0;
       for (int b = 0; b < n; ++b) {
         const int64_t dd = diag[b] - diag[a];
@@ -329,10 +336,13 @@ PG_HD int frag_pick_inits(const FragInit* init, const int64_t* diag, int n, int*
     for (int b = 0; b < n; ++b) {
       const int64_t dd = diag[b] - diag[locus];
       if (init[b].score <= 0 || dd > FRAG_VOTE_WIN || -dd > FRAG_VOTE_WIN) continue;
-      if (round == 1) { const int64_t d0 = diag[b] - diag[cand[0]]; if (d0 < FRAG_VOTE_FAR && -d0 < FRAG_VOTE_FAR) continue; }
+      bool taken = false;
+      for (int p = 0; p < round; ++p) { const int64_t d0 = diag[b] - diag[cand[p]]; taken = taken || (d0 < FRAG_VOTE_FAR && -d0 < FRAG_VOTE_FAR); }
+      if (taken) continue;
       ++members;
       if (frag_init_before(init[b], diag[b], init[best], diag[best])) best = b;
     }
+    if (round >= 2 && init[best].score < BL_STRONG_SCORE) break;
     if (locus_n) locus_n[nc] = members;
     cand[nc++] = best;
   }
