@@ -149,7 +149,10 @@ int pg_anim_pairs_fetch(pg_ctx* ctx, uint64_t ticket, pg_anim_result* out, uint6
  * dynamic anti-diagonal band trimmed at breaklen * 3 below the best score, backward search + forced forward re-alignment,
  * MUMmer's tie order): it reproduces every alignment record (coordinates and error counts) of the nucmer output files the
  * reference's tests hold and is what replaces pyani's `nucmer` job (pyani/anim.py:240-289).  There is no other extender: the
- * approximate fixed-band one of rounds 1-2 (and its pg_anim_set_extender switch) was retired in round 5. */
+ * approximate fixed-band one of rounds 1-2 was retired in round 5.  pg_anim_set_extender stays in the ABI for callers built against the
+ * round-4 header: PG_EXTENDER_NUCMER is accepted (a no-op), every other value is PG_E_ARG. */
+#define PG_EXTENDER_NUCMER 0
+int pg_anim_set_extender(pg_ctx* ctx, int extender);
 /* How many host worker threads (each with its own HIP stream and scratch) share one pg_anim_pairs / pg_anib_pairs call: 1 ... 4,
  * default 2 (the launches of two streams overlap: one worker's read-backs and sequential tails hide behind the other's kernels).
  * The counterpart of pyani's --workers inside ONE device (subcmd_anim.py:392-396 spreads jobs over CPU cores; over devices it is

@@ -157,7 +157,7 @@ void run_pair(const Genome& Q, const Genome& S, int32_t fragsize, std::vector<Ro
     const int32_t r0 = Q.rec_start[rec], r1 = Q.rec_start[rec + 1] - 1;
     for (int32_t f0 = r0; f0 < r1; f0 += fragsize) frags.push_back({f0, std::min(fragsize, r1 - f0)});
   }
-  std::vector<std::vector<FragSeed>> seeds[2];
+  std::vector<std::vector<FragSeed>> seeds[2], wseeds[2];      // wseeds: what the word tier adds (fragment_rows merges them in)
   for (int strand = 0; strand < 2; ++strand) {
     seeds[strand].assign(frags.size(), {});
     StrandView QS{QVw, strand};
@@ -192,8 +192,19 @@ void run_pair(const Genome& Q, const Genome& S, int32_t fragsize, std::vector<Ro
     int32_t best_score = 0;
     for (int strand = 0; strand < 2; ++strand) {
       std::vector<FragSeed>& e = seeds[strand][f];
-      if (e.empty()) continue;
-      std::sort(e.begin(), e.end(), [](const FragSeed& x, const FragSeed& y) { return x.len != y.len ? x.len > y.len : (x.q != y.q ? x.q < y.q : x.s < y.s); });
+      if (e.empty() && (wseeds[strand].empty() || wseeds[strand][f].empty())) continue;      // (word seeds alone are a list too)
+      const auto by_len = [](const FragSeed& x, const FragSeed& y) { return x.len != y.len ? x.len > y.len : (x.q != y.q ? x.q < y.q : x.s < y.s); };
+      std::sort(e.begin(), e.end(), by_len);
+      if (!wseeds[strand].empty() && !wseeds[strand][f].empty()) {
+        // the word tier's seeds come FIRST: each passed the flank test (chance: ~1e-7 per hit), while a fragment with a low-complexity
+        // stretch can hold more than FRAG_MAX_SEEDS chance 16-mers, all longer than a real alignment's 11 ... 15-base words
+        std::vector<FragSeed> w = wseeds[strand][f];
+        std::sort(w.begin(), w.end(), by_len);
+        if (w.size() > (size_t)FRAG_WORD_FIRST) w.resize(FRAG_WORD_FIRST);      // (at most half of the list: the own seeds keep the other half)
+        w.insert(w.end(), e.begin(), e.end());
+        e.swap(w);
+        wseeds[strand][f].clear();
+      }
       if (e.size() > (size_t)FRAG_MAX_SEEDS) e.resize(FRAG_MAX_SEEDS);
       auto q_at = [&](int64_t p) -> int {
         if (p < 0 || p >= qlen) return 4;
@@ -215,6 +226,10 @@ void run_pair(const Genome& Q, const Genome& S, int32_t fragsize, std::vector<Ro
         init[strand][t] = frag_diag_best_init(match, qlen, diag, e[t].q, &init2[strand][t]);
       }
       nc[strand] = frag_pick_inits(init[strand], dg[strand], n, pick[strand], members[strand], FRAG_MAX_CAND);
+      if (getenv("ANIB_DEBUG_FRAG") && atoi(getenv("ANIB_DEBUG_FRAG")) == (int)f) {
+        for (int t = 0; t < n; ++t) fprintf(stderr, "DBG frag %zu strand %d seed %d: s %d q %d len %d diag %lld -> init score %d q_start %d len %d word %d | second %d\n", f, strand, t, e[t].s, e[t].q, e[t].len, (long long)dg[strand][t], init[strand][t].score, init[strand][t].q_start, init[strand][t].len, init[strand][t].q_off, init2[strand][t].score);
+        for (int c = 0; c < nc[strand]; ++c) fprintf(stderr, "DBG   cand %d: seed %d members %d\n", c, pick[strand][c], members[strand][c]);
+      }
       for (int c = 0; c < nc[strand]; ++c) best_score = std::max(best_score, init[strand][pick[strand][c]].score);
     }
     for (int strand = 0; strand < 2; ++strand) {
@@ -277,11 +292,11 @@ void run_pair(const Genome& Q, const Genome& S, int32_t fragsize, std::vector<Ro
         if (!best && tried > 0 && first.score >= BL_PRELIM_RESCUE) best = &first;
         if (best) { pbest[c] = *best; have[c] = true; }
       }
-      // more than two: the final alignments of the two best preliminary ones only (frag_pick_inits)
+      // a repeat family: the final alignments of the FRAG_MAX_FINALS best preliminary ones only (frag_pick_inits)
       {
         int n_have = 0;
         for (int c = 0; c < nc[strand]; ++c) n_have += have[c];
-        while (n_have > 2) {
+        while (n_have > FRAG_MAX_FINALS) {
           int worst = -1;
           for (int c = 0; c < nc[strand]; ++c) if (have[c] && (worst < 0 || !frag_prelim_before(pbest[c], pbest[worst]))) worst = c;
           have[worst] = false; --n_have;
@@ -322,6 +337,7 @@ void run_pair(const Genome& Q, const Genome& S, int32_t fragsize, std::vector<Ro
       }
     }
     std::stable_sort(cand.begin(), cand.end(), [](const Row& x, const Row& y) { return x.score > y.score; });
+    if (cand.size() > (size_t)FRAG_KEEP_ROWS) cand.resize(FRAG_KEEP_ROWS);
     {   // HSPs with a common start or end point (frag_rows_share_end): the better one stays
       std::vector<Row> keep;
       for (const Row& r : cand) {
@@ -372,7 +388,8 @@ void run_pair(const Genome& Q, const Genome& S, int32_t fragsize, std::vector<Ro
         }
         if (getenv("ANIB_DUMP_STARTS")) fprintf(stderr, "WORDTIER frag %zu strand %d: %zu word seeds, %zu fresh\n", f, strand, extra.size(), fresh.size());
         if (fresh.empty() || fresh.size() > (size_t)(WORD_MAX_SEEDS - FRAG_MAX_SEEDS)) continue;   // (a repeat family: left as it is)
-        seeds[strand][f].insert(seeds[strand][f].end(), fresh.begin(), fresh.end());
+        if (wseeds[strand].empty()) wseeds[strand].assign(frags.size(), {});
+        wseeds[strand][f] = fresh;
         added = true;
       }
       if (added) { per_frag[f].clear(); fragment_rows(f, per_frag[f]); }

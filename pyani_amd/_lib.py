@@ -59,6 +59,7 @@ SIGNATURES = {
     "pg_anim_reduce": (_int, [_vp, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _vp]),
     "pg_anim_set_batch_budget": (_int, [_vp, _u32, ctypes.c_uint64]),
     "pg_anim_set_workers": (_int, [_vp, _int]),
+    "pg_anim_set_extender": (_int, [_vp, _int]),
     "pg_anim_counters": (_int, [_vp, _vp, _int]),
     "pg_anim_pair_alignments": (_int, [_vp, _i32, _i32, _vp, _u32, _P(_u32)]),
     "pg_anim_alignments_batch": (_int, [_vp, _vp, _vp, _u64, _int, _int, _vp, _P(_u64)]),

@@ -309,8 +309,9 @@ PG_HD FragInit frag_diag_best_init(M&& match, int32_t qlen, int64_t diag, int32_
 // max_cand > 2 (FRAG_MAX_CAND): a repeat family (rRNA operons, insertion elements: a dozen copies with initial HSPs of a few hundred
 // each) — blastn aligns them all and the table's first row is the best FINAL score, which the two best-supported loci need not hold
 // (NC_002696 vs NC_010338, fragment 3015).  Candidates beyond the second must be strong (BL_STRONG_SCORE): chance hits never open
-// a third round.  The caller grows the preliminary alignments of all of them and the final ones of the two best (frag_prelim_before).
-constexpr int FRAG_MAX_CAND = 8;
+// a third round.  The caller grows the preliminary alignments of all of them and the final ones of the FRAG_MAX_FINALS best
+// (frag_prelim_before; a preliminary score orders copies of a repeat only roughly) and keeps the fragment's FRAG_KEEP_ROWS best rows.
+constexpr int FRAG_MAX_CAND = 8, FRAG_MAX_FINALS = 4, FRAG_KEEP_ROWS = 4;      // final alignments per strand; rows kept per fragment (the best)
 PG_HD int frag_pick_inits(const FragInit* init, const int64_t* diag, int n, int* cand, int* locus_n = nullptr, int max_cand = 2) {
   int nc = 0;
   for (int round = 0; round < max_cand; ++round) {
@@ -507,6 +508,11 @@ PG_HD bool frag_evalue_ok_db(int32_t score, int32_t qlen, int64_t db_len, int32_
 // bases on its left OR on its right match on its diagonal (chance: 8 +- 2.4 of 32; 22 centres the agreement with the BLAST+
 // tables of the reference's tests: the CPU checker of the tests (anib_cpu.cpp) has the statement, profiles/archive/r03_anib_blast_agreement.json the level).
 constexpr int WORD_K = 11, WORD_FLANK = 32, WORD_FLANK_MIN = 22, WORD_MAX_SEEDS = 512;
+// In the fragment's seed list (FRAG_MAX_SEEDS entries) the word tier's seeds come FIRST, up to FRAG_WORD_FIRST of them (longest first):
+// each passed the flank test (chance: ~1e-7 per hit), while a fragment with a low-complexity stretch can hold more than FRAG_MAX_SEEDS
+// chance 16-mers, all longer than the 11 ... 15-base words of a real 72 % alignment (NC_002696 vs NC_010338, fragments 1573, 2911, 2930:
+// found by the tier and cut from the list again by the length ranking of rounds 3-5).
+constexpr int FRAG_WORD_FIRST = 32;
 
 // BLAST's e-value for raw score S (blastn 2 / -3, gap costs 5 / 2: lambda = 0.625, K = 0.41), search space m * n without length
 // adjustment; pyani runs blastn with -evalue 1e-15 (anib.py:466).

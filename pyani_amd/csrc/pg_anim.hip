@@ -991,6 +991,8 @@ int pg_anim_run_batch(pg_ctx* ctx, const int32_t* ref_ids, const int32_t* qry_id
           fprintf(stderr, "[pn-stats] diagonal engine in %-16s: %llu calls, %llu anti-diagonals, %llu cells\n", kn[k], ks[4 * k], ks[4 * k + 1], ks[4 * k + 2]);
         fprintf(stderr, "[pn-stats] walk kernel scans: shadow test %.1f ms over %llu rows of 64 alignments, reverse-target search %.1f ms in %llu calls (summed over waves)\n",
                 ks[3] / 1e5, ks[7], ks[11] / 1e5, ks[15]);
+        fprintf(stderr, "[pn-stats] run-ahead results the walk took: forward %llu of %llu computed (%.4f), backward %llu found ready of %llu searches run ahead; %llu searches left to the walk itself\n",
+                ks[19], ks[4], ks[4] ? (double)ks[19] / (double)ks[4] : 0.0, ks[23], ks[8], ks[12]);
       }
       for (int k = 13; k <= 17; k += 4)      // ticks of the 100 MHz wall clock -> ms
         fprintf(stderr, "[pn-stats] %s: busy %.1f ms summed over waves, span %.1f ms, longest item %.1f ms (size %llu)\n", k == 13 ? "units" : "forced",

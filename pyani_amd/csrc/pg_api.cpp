@@ -760,6 +760,12 @@ int pg_anim_set_batch_budget(pg_ctx* ctx, uint32_t max_pairs, uint64_t max_match
   return PG_OK;
 }
 
+int pg_anim_set_extender(pg_ctx* ctx, int extender) {      // (deprecation stub: the one extender left is MUMmer's own)
+  if (!ctx) return PG_E_ARG;
+  if (extender != PG_EXTENDER_NUCMER) return pg_fail(ctx, PG_E_ARG, "pg_anim_set_extender: only PG_EXTENDER_NUCMER exists (the approximate banded64 extender was retired)");
+  return PG_OK;
+}
+
 int pg_anim_set_workers(pg_ctx* ctx, int workers) {
   if (!ctx || workers < 1 || workers > pg_ctx::MAX_WORKERS) return pg_fail(ctx, PG_E_ARG, "workers must be 1 ... 4");
   ctx->anim_workers = workers;

@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "pg_internal.h"
+#include <mutex>
 #include "pg_sketch_core.h"
 
 namespace {
@@ -45,6 +46,14 @@ int sk_malloc(pg_ctx* ctx, T*& p, size_t n) {
   if (!fail_first && hipMalloc(reinterpret_cast<void**>(&p), n * sizeof(T)) == hipSuccess) return PG_OK;
   (void)hipGetLastError();
   p = nullptr;
+  // The ANIm launch scratch takes the sketches' place — only on an IDLE context: never under an enqueued ANIm call (its thread is using
+  // that scratch), and only after everything the worker streams were given has finished.
+  {
+    std::lock_guard<std::mutex> lk(ctx->anim_async_mu);
+    if (ctx->anim_async[0].busy || ctx->anim_async[1].busy)
+      return pg_fail(ctx, PG_E_NOMEM, "sketch: device memory is short and enqueued ANIm calls are in flight (fetch them first: their launch scratch cannot be released under them)");
+  }
+  PG_HIP(ctx, hipDeviceSynchronize());
   pg_anim_free_scratch(ctx);
   PG_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&p), n * sizeof(T)));
   return PG_OK;
@@ -268,17 +277,22 @@ extern "C" int pg_sketch_pairs(pg_ctx* ctx, const int32_t* qry_ids, const int32_
   }
   SketchJob* d_jobs = nullptr;
   pg_sketch_result* d_out = nullptr;
+  struct Guard { SketchJob*& j; pg_sketch_result*& o; ~Guard() { if (j) (void)hipFree(j); if (o) (void)hipFree(o); } } guard{d_jobs, d_out};   // every exit path
   if ((rc = sk_malloc(ctx, d_jobs, jobs.size()))) return rc;
-  if ((rc = sk_malloc(ctx, d_out, (size_t)n_pairs))) { (void)hipFree(d_jobs); return rc; }
+  if ((rc = sk_malloc(ctx, d_out, (size_t)n_pairs))) return rc;
   PG_HIP(ctx, hipMemcpyAsync(d_jobs, jobs.data(), jobs.size() * sizeof(SketchJob), hipMemcpyHostToDevice, ctx->stream));
-  if (lds_max > 48 * 1024) PG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(sketch_pairs_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(96 * 1024)));
+  if (lds_max > 48 * 1024) {      // up to 96 KiB of dynamic LDS: fits gfx950's 160 KiB per workgroup; a part that refuses it gets a clear status, not a launch failure
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(sketch_pairs_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(96 * 1024)) != hipSuccess) {
+      (void)hipGetLastError();
+      return pg_fail(ctx, PG_E_CAPACITY, "sketch: the job's fragment counters need up to 96 KiB of LDS per workgroup, which this device does not grant");
+    }
+  }
   pg_prof_begin(ctx, PG_K_SKETCH_PAIRS);
   hipLaunchKernelGGL(sketch_pairs_kernel, dim3((uint32_t)jobs.size()), dim3(256), std::max<size_t>(lds_max, 16), ctx->stream, d_jobs, d_out);
   pg_prof_end(ctx);
   hipError_t e = hipGetLastError();
   if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, n_pairs * sizeof(pg_sketch_result), hipMemcpyDeviceToHost, ctx->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-  (void)hipFree(d_jobs); (void)hipFree(d_out);
   if (e != hipSuccess) return pg_fail(ctx, PG_E_HIP, std::string("sketch: ") + hipGetErrorString(e));
   return PG_OK;
 }

@@ -55,7 +55,10 @@ def comparison_results(engine, files: Sequence[Path], ids: Sequence[int], fragLe
     for fq in files:
         for fr in files:
             x = res[k]
-            out[(fq.stem, fr.stem)] = None if int(x["status"]) else ComparisonResult(fr, fq, float(x["ani"]), int(x["matches"]), int(x["fragments"]))
+            # field order = the reference's positional quirk (parse_fastani_file passes the file's columns through: the QUERY file
+            # lands in `.reference`, fastani.py:262-270; subcmd_fastani.py:447 unpacks it as `query, ref, ...`): results taken
+            # in-process equal results read back from write_fastani_file
+            out[(fq.stem, fr.stem)] = None if int(x["status"]) else ComparisonResult(fq, fr, float(x["ani"]), int(x["matches"]), int(x["fragments"]))
             k += 1
     return out
 
@@ -78,6 +81,18 @@ def parse_fastani_file(filename: Path) -> ComparisonResult:
     if not line:
         raise PyaniFastANIException(f"Input file {filename} is empty")
     return ComparisonResult(line[0], line[1], 0.01 * float(line[2]), int(line[3]), int(line[4]))
+
+
+def comparison_row(result: Optional[ComparisonResult], query: Path, reference: Path, fragLen: int, query_length: int) -> dict:
+    """The Comparison row the reference's driver makes of one result (subcmd_fastani.py:437-474): an empty result file becomes
+    (query, ref, 0, 0, 0); aln_length = matches * fragLen, sim_errs = (fragments - matches) * fragLen, cov_query = matches * fragLen /
+    query length, identity = the ANI fraction, cov_subject None."""
+    if result is None:
+        result = ComparisonResult(query, reference, 0, 0, 0)
+    q, r, ani, matches, num_frags = result
+    return {"query": q, "subject": r, "aln_length": int(matches * fragLen), "sim_errs": int(int(num_frags) * fragLen - matches * fragLen),
+            "identity": float(ani), "cov_query": float(matches) * fragLen / query_length, "cov_subject": None, "program": "fastANI",
+            "fragsize": fragLen, "maxmatch": False}
 
 
 def result_matrices(labels: Sequence[str], results: Dict[Tuple[str, str], Optional[ComparisonResult]]):

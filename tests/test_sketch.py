@@ -22,10 +22,15 @@ def test_parse_fastani_file_reads_the_reference_fixture(tmp_path):
     empty.write_text("")
     with pytest.raises(fastani.PyaniFastANIException):
         fastani.parse_fastani_file(empty)
-    res = fastani.ComparisonResult("r.fna", "q.fna", 0.987654321, 12, 20)
+    res = fastani.ComparisonResult("q.fna", "r.fna", 0.9876, 12, 20)      # in-process order = parse order (query file first: the reference's quirk)
     p = fastani.write_fastani_file(tmp_path / "q_vs_r.fastani", "q.fna", "r.fna", res)
     back = fastani.parse_fastani_file(p)
-    assert (back.matches, back.fragments) == (12, 20) and abs(back.ani - 0.987654321) < 5e-7
+    assert back[:2] == res[:2] and (back.matches, back.fragments) == (12, 20) and abs(back.ani - 0.9876) < 1e-12
+    # the Comparison row of the reference's driver (subcmd_fastani.py:437-474), also for an empty result file
+    row = fastani.comparison_row(back, "q.fna", "r.fna", 3000, 90_000)
+    assert (row["query"], row["subject"], row["aln_length"], row["sim_errs"]) == ("q.fna", "r.fna", 36_000, 24_000) and abs(row["cov_query"] - 0.4) < 1e-12
+    none = fastani.comparison_row(None, "q.fna", "r.fna", 3000, 90_000)
+    assert (none["aln_length"], none["sim_errs"], none["identity"], none["cov_query"]) == (0, 0, 0.0, 0.0)
     assert fastani.write_fastani_file(tmp_path / "none.fastani", "q.fna", "r.fna", None).read_text() == ""
 
 
