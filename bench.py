@@ -63,6 +63,7 @@ def parse_args():
     ap.add_argument("--cpu-genomes", type=int, default=2, help="tetra: genomes timed by the CPU leg")
     ap.add_argument("--no-tetra", action="store_true", help="anim: skip the nested C2 TETRA sub-record")
     ap.add_argument("--roofline-tiles", type=int, default=0, help="anim: how many tiles the one-worker roofline pass covers (0 = every tile of the grid)")
+    ap.add_argument("--side-records", action="store_true", help="anim: keep the side records under --no-cpu-baseline (related_only / unrelated_only / sketch_mode without the CPU leg)")
     ap.add_argument("--no-side-records", action="store_true", help="anim: skip related_only / unrelated_only / strong-step side records")
     ap.add_argument("--dynamic-deal", action="store_true", help="anim, N > 1: the ranks pull a step's rows in guided chunks from a cross-rank counter (round 4's default) "
                                                                "instead of the fixed scrambled deal, one call per rank and step")
@@ -639,7 +640,7 @@ def run_anim(args, rank, world, local, dist, torch):
 
     # ---- N > 1: the same tile size as N = 1's step, dealt over all ranks (strong scaling of ONE step: launches shrink with N)
     strong = None
-    bare = args.no_cpu_baseline or args.no_side_records      # (tests and profiling runs: the step loop and the roofline step only)
+    bare = args.no_side_records or (args.no_cpu_baseline and not args.side_records)      # (tests and profiling runs: the step loop and the roofline step only)
     if dist is not None and (not bare or REHEARSAL):
         r1 = max(1, n // 10)
         step(k_prof + 1, rows=rows_of(k_prof + 1, r1), key="strong_warm")
@@ -687,7 +688,7 @@ def run_anim(args, rank, world, local, dist, torch):
         # rate at which the chip can issue the vector instructions those cells cost.  MEASURED IN THIS RUN: cells, anti-diagonals and calls
         # per kernel class (the engines' own counters, pg_anim_counters) and the stages' HIP-event times of the roofline pass above.
         # FROM THE COMMITTED PROFILE (profiles/pmc_anim.json: a rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU pass of the same command on
-        # MI355X, tools/summarize_r05_profiles.py): instructions per cell, per kernel class and for the stage as a whole.
+        # MI355X, tools/summarize_round_profiles.py): instructions per cell, per kernel class and for the stage as a whole.
         cells = int(cnt[2]) + int(cnt[5]) + int(cnt[8])
         vpc, spc = pmc.get("extension_valu_per_cell"), pmc.get("extension_salu_per_cell")
         kclass = [("gaps", "anim_postnuc_gap_kernels", 128), ("forward", "anim_postnuc_fwd_kernel", 128), ("backward_ahead", "anim_postnuc_rehearse_kernel+anim_postnuc_bwd_kernel", 128),

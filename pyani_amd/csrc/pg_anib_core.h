@@ -505,9 +505,13 @@ PG_HD bool frag_evalue_ok_db(int32_t score, int32_t qlen, int64_t db_len, int32_
 
 // The word tier (blastn's word size, `-task blastn`: anib.py:465-471): a fragment that the 16-mer seeds leave without a reportable
 // HSP is searched again with every 11-mer of either strand; a hit becomes a seed if at least WORD_FLANK_MIN of the WORD_FLANK
-// bases on its left OR on its right match on its diagonal (chance: 8 +- 2.4 of 32; 22 centres the agreement with the BLAST+
-// tables of the reference's tests: the CPU checker of the tests (anib_cpu.cpp) has the statement, profiles/archive/r03_anib_blast_agreement.json the level).
-constexpr int WORD_K = 11, WORD_FLANK = 32, WORD_FLANK_MIN = 22, WORD_MAX_SEEDS = 512;
+// bases on its left OR on its right match on its diagonal (chance: 8 +- 2.4 of 32).  The bar is a PRE-filter only — a fragment strand
+// holds ~1 000 chance 11-mer hits and the list WORD_MAX_SEEDS — since blastn's own stages (initial HSP at the gap trigger, preliminary
+// and final gapped alignment, e-value) decide what is reported.  18 = 4 sigma above chance (~0.4 chance survivors per fragment) and
+// below what a 2/3-identity alignment shows (21.3: coding regions that differ at every third base have FEW exact 11-mers, each with
+// ~21 of 32 flank matches — rounds 3-5 asked for 22 and lost exactly those fragments: 3 ... 5 per 2 600 on the 78 - 84 % pairs of the
+// reference's tests, +0.02 pp mean identity; 16 admits enough chance seeds to crowd the list again).
+constexpr int WORD_K = 11, WORD_FLANK = 32, WORD_FLANK_MIN = 18, WORD_MAX_SEEDS = 512;
 // In the fragment's seed list (FRAG_MAX_SEEDS entries) the word tier's seeds come FIRST, up to FRAG_WORD_FIRST of them (longest first):
 // each passed the flank test (chance: ~1e-7 per hit), while a fragment with a low-complexity stretch can hold more than FRAG_MAX_SEEDS
 // chance 16-mers, all longer than the 11 ... 15-base words of a real 72 % alignment (NC_002696 vs NC_010338, fragments 1573, 2911, 2930:

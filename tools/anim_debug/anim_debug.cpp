@@ -159,6 +159,12 @@ int main(int argc, char** argv) {
         fw.resize(n_chains);
         for (int k = 0; k < n_chains; ++k) fw[k] = pgn::postnuc_forward(eng, chains.data(), cm.data(), co.data(), n_chains, k, bounds_of);
         eng.fwd = fw.data();
+        if (getenv("ANIM_FWD_LEN"))      // development: the extent of every forward search in walk order (anti-diagonals ~ bases of A + bases of B, + the break length where the target was not reached)
+          for (int k = 0; k < n_chains; ++k) {
+            const Chain& C = chains[co[k]];
+            const Match ml = cm[C.first + C.count - 1];
+            fprintf(stderr, "FWDLEN %d\n", (fw[k].eA - (ml.r + ml.len - 1)) + (fw[k].eB - (ml.q + ml.len - 1)) + (fw[k].reached ? 0 : pgn::BREAK_LEN));
+          }
       }
       // ... and every match-to-match alignment (the GPU's gap pre-pass): the walk takes runs of them at once (ScalarEngine::gap_run)
       std::vector<pgn::PnGap> gp;

@@ -100,7 +100,7 @@ final)   # what the driver runs at round end: smoke() and the default bench comm
   ( time timeout 1500 python bench.py > $O/bench_default.log 2> $O/bench_default.err ) 2> $O/bench_default.time; echo "default bench rc=$?"; cat $O/bench_default.time
   grep '^{' $O/bench_default.log | cut -c1-600 ;;
 summ)    # profiles/ on the box from what the steps before left (bench.py reads profiles/pmc_anim.json)
-  python tools/summarize_r05_profiles.py | tail -30 ;;
+  python tools/summarize_round_profiles.py r06 | tail -30 ;;
 cold)    # one cold end-to-end run of the whole C4 job from FASTA files on disk
   PYANI_BENCH_TMP=/tmp timeout -k 10 900 python bench.py --gpus 1 --cold-e2e > $O/cold_e2e.json 2> $O/cold_e2e.err; echo "cold rc=$?"
   cut -c1-1200 $O/cold_e2e.json; tail -3 $O/cold_e2e.err ;;
