@@ -220,11 +220,15 @@ def test_eight_rank_dress_rehearsal_of_the_bench_control_flow():
     default since round 5 (the fixed scrambled deal, one call per rank and step: measured on MI355X the better one, profiles/
     r05_deal_probe.json) and --dynamic-deal (round 4's guided chunks from the cross-rank counter)."""
     slow = {"PYANI_BENCH_REHEARSAL_SCALE": "2"}      # a step of ~0.8 s per rank: process wake-up skew (8 ranks on a few cores) must not be what is measured
+    # the balance bars are TIMING statements about 8 sleeping ranks on 8 cores: on a box that is busy with something else (load average
+    # above half its cores before the test starts) a descheduled rank is what would be measured — the bar then only guards against a
+    # broken deal (one rank doing everything: 8.0)
+    bar = 1.25 if os.getloadavg()[0] < 0.5 * (os.cpu_count() or 8) else 3.0
     one = _rehearsal(1, ["--steps", "10", "--warmup", "0"], slow)
     default = _rehearsal(8, ["--steps", "2", "--warmup", "1"], slow)
     assert default["n_gpus"] == 8 and default["config"]["results_sha1_full_grid"] == one["config"]["results_sha1_full_grid"]
     assert default["imbalance"]["dealing"].startswith("fixed scrambled deal") and default["imbalance"]["chunks_per_rank_last_step"] == [1] * 8
-    assert default["imbalance"]["worst"] <= 1.25, default["imbalance"]
+    assert default["imbalance"]["worst"] <= bar, default["imbalance"]
     assert default["value"] > 2.0 * one["value"], (one["value"], default["value"])      # (2.5 on an idle 8-core box; the bar leaves room for a busy one)
     eight = _rehearsal(8, ["--steps", "2", "--warmup", "1", "--dynamic-deal"], slow)
     assert one["n_gpus"] == 1 and eight["n_gpus"] == 8 and eight["scaling"] == "weak" and "REHEARSAL" in eight["data"]
@@ -233,7 +237,7 @@ def test_eight_rank_dress_rehearsal_of_the_bench_control_flow():
     assert eight["series"]["strong_step"]["rows_per_step"] == 100 and eight["series"]["strong_step"]["pairs_per_s"] > 0
     imb = eight["imbalance"]
     assert imb["dealing"].startswith("guided chunks") and "job-store" in imb["dealing"] and len(imb["chunks_per_rank_last_step"]) == 8
-    assert imb["worst"] <= 1.25, imb
+    assert imb["worst"] <= bar, imb
     # the weak series scales: 8 ranks do 8 x the rows per step (not 8 x here: the step's all-gather and grid assembly run on the CPU
     # over gloo in this rehearsal — 64 MB per step through loopback with 8 processes on a few cores; on the GPU box they are RCCL / HBM)
     assert eight["value"] > 2.0 * one["value"], (one["value"], eight["value"])
