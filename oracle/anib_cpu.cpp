@@ -251,7 +251,8 @@ void run_pair(const Genome& Q, const Genome& S, int32_t fragsize, std::vector<Ro
         const int srec = record_of(S.rec_start.data(), (int)S.rec_start.size() - 1, (int32_t)(I.q_off + diag));
         const int64_t s_lo = S.rec_start[srec], s_hi = S.rec_start[srec + 1] - 1;
         auto s_at = [&](int64_t p) -> int { return (p >= s_lo && p < s_hi && SV.clean(p)) ? SV.base(p) : 5; };
-        std::vector<int> order;      // 2 t: the diagonal's best initial HSP, 2 t + 1: its second
+        struct Ent { FragInit I; int64_t d; };
+        std::vector<Ent> order;      // the initial HSPs of the candidate's neighbourhood: per diagonal its best and its second
         for (int t = 0; t < n_seeds; ++t) {
           if (init[strand][t].score <= 0) continue;
           const int64_t dd = dg[strand][t] - diag;
@@ -260,17 +261,35 @@ void run_pair(const Genome& Q, const Genome& S, int32_t fragsize, std::vector<Ro
           for (int p = 0; p < c; ++p) { const int64_t d1 = dg[strand][t] - dg[strand][pick[strand][p]]; taken = taken || (d1 < FRAG_VOTE_FAR && -d1 < FRAG_VOTE_FAR); }
           if (taken) continue;
           if (record_of(S.rec_start.data(), (int)S.rec_start.size() - 1, (int32_t)(init[strand][t].q_off + dg[strand][t])) != srec) continue;
-          order.push_back(2 * t);
-          if (init2[strand][t].score > 0) order.push_back(2 * t + 1);
+          order.push_back(Ent{init[strand][t], dg[strand][t]});
+          if (init2[strand][t].score > 0) order.push_back(Ent{init2[strand][t], dg[strand][t]});
         }
-        std::sort(order.begin(), order.end(), [&](int x, int y) { return frag_init_before(init_of(x), dg[strand][x >> 1], init_of(y), dg[strand][y >> 1]); });
+        if (getenv("ANIB_ALL_DIAGS")) {
+          // EXPERIMENT: blastn's initial HSPs come from EVERY 11-mer diagonal, not only from the diagonals of the product's seeds: the
+          // neighbouring diagonals without a seed are walked too
+          for (int64_t dd = -(FRAG_VOTE_FAR - 1); dd < FRAG_VOTE_FAR; ++dd) {
+            const int64_t d2 = diag + dd;
+            bool has_seed = false, taken = false;
+            for (int t = 0; t < n_seeds; ++t) has_seed = has_seed || dg[strand][t] == d2;
+            for (int p = 0; p < c; ++p) { const int64_t d1 = d2 - dg[strand][pick[strand][p]]; taken = taken || (d1 < FRAG_VOTE_FAR && -d1 < FRAG_VOTE_FAR); }
+            if (has_seed || taken) continue;
+            auto match2 = [&](int32_t p) -> bool { const int qb = q_at(p); return qb < 4 && s_at(p + d2) == qb; };
+            FragInit second{0, 0, 0, 0};
+            const FragInit best = frag_diag_walk(match2, qlen, d2, &second);
+            if (best.score > 0 && record_of(S.rec_start.data(), (int)S.rec_start.size() - 1, (int32_t)(best.q_off + d2)) == srec) {
+              order.push_back(Ent{best, d2});
+              if (second.score > 0) order.push_back(Ent{second, d2});
+            }
+          }
+        }
+        std::sort(order.begin(), order.end(), [&](const Ent& x, const Ent& y) { return frag_init_before(x.I, x.d, y.I, y.d); });
         FragPrelim pre[BL_MAX_PRELIMS];
         int np = 0, tried = 0;
         FragPrelim first{0, 0, 0, 0, 0, 0, 0};
-        for (int x : order) {
+        for (const Ent& en : order) {
           if (tried == BL_MAX_PRELIMS) break;
-          const FragInit& J = init_of(x);
-          const int64_t dj = dg[strand][x >> 1];
+          const FragInit& J = en.I;
+          const int64_t dj = en.d;
           bool inside = false;
           for (int u = 0; u < np; ++u) inside = inside || frag_init_contained(J, dj, pre[u]);
           if (inside) continue;
