@@ -88,6 +88,26 @@ PG_HD uint32_t w_step(uint32_t w, bool same) {     // diagonal step from the bes
   const uint32_t hit = w + ((uint32_t)GOOD_SCORE << SCORE_SHIFT), miss = w_sat_sub(w, ((uint32_t)(-BAD_SCORE) << SCORE_SHIFT) - 1u);
   return w >= W_ONE ? (same ? hit : miss) : 0u;    // (an unreachable word must stay one: matches would lift it back into the field)
 }
+// The NORMALISED frame of the trimmed searches on the wave engines (pg_nucmer_diag.h, diag_lane_step<NORM>): on anti-diagonal d
+// the score field holds score - norm_offset(d) + NORM_BIAS.  A path to (i, j) has at most min(i, j) <= floor(d / 2) matches, so
+// score - norm_offset(d) <= 0: the bias is the top of the field.  A search of 10 001 x 10 001 bases ends at d = 20 002 with the
+// offset at 30 003, and its best score is >= -10 from the first anti-diagonal on: the trimming threshold's field is >= 32 767 -
+// 30 003 - 10 - MAX_DIFF = 2 154 — the same distance from the floor the plain frame keeps (SCORE_BIAS - 10 - MAX_DIFF = 2 090).
+constexpr uint32_t NORM_BIAS = 32767u;
+PG_HD int32_t norm_offset(int32_t d) { return GOOD_SCORE * (d >> 1); }
+// the diagonal step in that frame: a match keeps the word (an unreachable word stays unreachable by itself), a mismatch pays
+// BAD - GOOD and one error.  miss_window: the slot's window of MISMATCH bits, the cell's own bit on top.
+PG_HD uint32_t w_step_norm(uint32_t w, uint32_t miss_window) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  // (as written for the host the compiler folds shift + and back into v_cmp + v_cndmask: two half-rate instructions; the shift is
+  // therefore opaque to it — v_ashrrev_i32, v_and_b32 and v_sub_u32 clamp are the three full-rate ones)
+  uint32_t sign;
+  asm("v_ashrrev_i32 %0, 31, %1" : "=v"(sign) : "v"(miss_window));
+#else
+  const uint32_t sign = (uint32_t)((int32_t)miss_window >> 31);
+#endif
+  return w_sat_sub(w, sign & (((uint32_t)(GOOD_SCORE - BAD_SCORE) << SCORE_SHIFT) - 1u));
+}
 PG_HD uint32_t w_max3(uint32_t a, uint32_t b, uint32_t c) { const uint32_t m = a > b ? a : b; return m > c ? m : c; }
 
 struct Cell { uint32_t D, I, M, X; };   // the three states and X = the best of them (labelled with the winner's state)

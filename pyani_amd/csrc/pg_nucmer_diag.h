@@ -56,8 +56,17 @@ PG_HD uint32_t spread16(uint32_t m) {      // bit t (t < 16) -> bit 2 t
 // slot: in range or 0), so that a re-labelling is ONE v_and_or_b32 (a VOP3 instruction of this ISA takes no literal and reads the
 // constant bus once; as literals the compiler needs v_and + v_or, and re-materialises the mask inside the loop).
 // The match bit of a slot's next cell is the TOP bit of its window (tested as a sign), the window moves up two bits per cell.
+//
+// NORM (trimmed searches; round 6): the score field holds score - GOOD_SCORE * floor(Dct / 2) + NORM_BIAS instead of score +
+// SCORE_BIAS (pg_nucmer_core.h: norm_offset).  Every candidate of a cell sits on the same anti-diagonal, so maxima, ties and the
+// riding errors are untouched; what changes is the PRICE LIST: a diagonal step spans two anti-diagonals, so a match costs 0 — the
+// word is simply kept, and an unreachable word (field 0) stays one without the `w >= W_ONE` test — and a mismatch BAD - GOOD; a gap
+// step costs GOOD more on the even anti-diagonals (where floor(Dct / 2) moves), compile-time constants per parity.  The window
+// then holds MISMATCH bits (diag_lane_refill<NORM>), and the diagonal step is sign-extend, and, saturating subtract — three
+// full-rate instructions of gfx950 (tools/ubench/valu_issue.hip: 2.3 cycles per SIMD against 4.2 for compare / select) where
+// the plain form needs add, saturating subtract, two compares and two selects.
 struct DiagRelabel { uint32_t mask, st_insert, st_match; };
-template <int DPL, int PAR, bool TRACK>
+template <int DPL, int PAR, bool TRACK, bool NORM = false>
 PG_HD void diag_lane_step(DiagRegs<DPL>& T, uint32_t nbX, uint32_t nbG, uint32_t g0, uint32_t glo, uint32_t gspan, const DiagRelabel& rel,
                           uint32_t& key, uint32_t& keyw) {
   key = 0u; keyw = 0u;
@@ -68,15 +77,16 @@ PG_HD void diag_lane_step(DiagRegs<DPL>& T, uint32_t nbX, uint32_t nbG, uint32_t
   for (int s = PAR; s < DPL; s += 2) {
     const uint32_t lX = s == 0 ? nbX : T.X[s == 0 ? 0 : s - 1], lD = s == 0 ? nbG : T.D[s == 0 ? 0 : s - 1];
     const uint32_t uX = s == DPL - 1 ? nbX : T.X[s == DPL - 1 ? s : s + 1], uI = s == DPL - 1 ? nbG : T.I[s == DPL - 1 ? s : s + 1];
-    const uint32_t dc = w_gap(lD, CONT_GAP_SCORE), dx = w_gap(lX, OPEN_GAP_SCORE);
-    const uint32_t ic = w_gap(uI, CONT_GAP_SCORE), ix = w_gap(uX, OPEN_GAP_SCORE);
+    constexpr int32_t RISE = NORM && PAR == 0 ? GOOD_SCORE : 0;      // (NORM: the offset moves on the even anti-diagonals)
+    const uint32_t dc = w_gap(lD, CONT_GAP_SCORE - RISE), dx = w_gap(lX, OPEN_GAP_SCORE - RISE);
+    const uint32_t ic = w_gap(uI, CONT_GAP_SCORE - RISE), ix = w_gap(uX, OPEN_GAP_SCORE - RISE);
     // a slot outside the range keeps nothing but its state label: a word with score field 0 is unreachable whatever its low bits
     // (gaps and mismatches saturate it to 0, a match step tests the field, trimming and the best-cell key look at the field), so
     // ONE select — of the re-labelling mask — takes the place of three on the results
     const bool in = (uint32_t)(gofs + (uint32_t)s) <= gspan;
     const uint32_t mk = in ? rel.mask : 0u;
     const uint32_t d = (dc > dx ? dc : dx) & mk /* | ST_DELETE = 0 */, i = ((ic > ix ? ic : ix) & mk) | rel.st_insert;
-    const uint32_t m = (w_step(T.X[s], (int32_t)T.mw[s] < 0) & mk) | rel.st_match;
+    const uint32_t m = ((NORM ? w_step_norm(T.X[s], T.mw[s]) : w_step(T.X[s], (int32_t)T.mw[s] < 0)) & mk) | rel.st_match;
     T.mw[s] <<= 2;
     T.X[s] = w_max3(d, i, m); T.D[s] = d; T.I[s] = i;
     if (TRACK) {
@@ -119,7 +129,7 @@ PG_HD uint32_t diag_lane_alive(const DiagRegs<DPL>& T, uint32_t thr) {
 // e_s = (s ^ PAR) & 1, column j_s = i_s + k0 + s.  ca / oka: the codes (2 bits each) / clean bits of the 32 A rows from row
 // i_{DPL-1} on (field f = row i_{DPL-1} + f: the caller has undone direction and strand), cb / okb: the 32 B columns from column
 // j_0 on.  The offsets of slot s inside the two windows are compile-time constants.
-template <int DPL, int PAR>
+template <int DPL, int PAR, bool NORM = false>
 PG_HD void diag_lane_refill(DiagRegs<DPL>& T, uint64_t ca, uint32_t oka, uint64_t cb, uint32_t okb) {
   constexpr int e_last = ((DPL - 1) ^ PAR) & 1, e_0 = PAR & 1;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -132,7 +142,9 @@ PG_HD void diag_lane_refill(DiagRegs<DPL>& T, uint64_t ca, uint32_t oka, uint64_
     const uint32_t x = a16 ^ b16;
     const uint32_t eq = ~(x | (x >> 1)) & 0x55555555u;
     // cell t of the slot at bit 31 - 2 t: the fields in reverse order, one bit up
-    T.mw[s] = rev16_fields((eq & spread16((oka >> oa) & (okb >> ob)))) << 1;
+    // (NORM: the MISMATCH bits — unclean bases included — so that the step can AND the mismatch price with the window's sign)
+    const uint32_t hit = eq & spread16((oka >> oa) & (okb >> ob));
+    T.mw[s] = rev16_fields(NORM ? hit ^ 0x55555555u : hit) << 1;
   }
 }
 // first A row / first B column of the windows diag_lane_refill wants, for a lane whose first diagonal is k0
@@ -224,7 +236,7 @@ struct DiagCtl {
   // the wave's best cell of this anti-diagonal: gk = (score field | slot), gw its word; ties move the finish forward (">=")
   PG_HD void update_best(uint32_t gk, uint32_t gw) {
     const uint32_t f = gk >> SCORE_SHIFT;
-    if (f >= high_f) {
+    if (f >= (high_fw >> SCORE_SHIFT)) {      // (high_fw, not high_f: in the normalised frame it is the one kept in step with Dct)
       high_f = f; high_w = gw; high_fw = f << SCORE_SHIFT; thr_w = (f - (uint32_t)MAX_DIFF) << SCORE_SHIFT; FinishCt = Dct; FinishG = (int32_t)(gk & (W_ONE - 1u)); FinishShift = shiftk;
       Dend = Dct + BREAK_LEN < NM ? Dct + BREAK_LEN : NM;
     }
@@ -234,12 +246,15 @@ struct DiagCtl {
   // a zero word — a slot outside the computed range — never counts as a survivor.
   PG_HD uint32_t trim_threshold() const { return thr_w; }
   // survivors: the lowest / highest surviving slot (any = false: none)
-  template <bool FORCED>
+  // NORM_EVEN: a trimmed search in the normalised frame (diag_lane_step<NORM>) moves on to an EVEN anti-diagonal, where the
+  // frame's offset rises by GOOD_SCORE: the two words its cells are compared with follow (the best score itself stays)
+  template <bool FORCED, bool NORM_EVEN = false>
   PG_HD void end_step(bool any, uint32_t gmin, uint32_t gmax) {
     if (FORCED) { ga = lo; gb = hi; }
     else if (any) { ga = (int32_t)gmin; gb = (int32_t)gmax; }
     else { ga = 1; gb = 0; Dend = -1; }
     ++Dct; ++c1g; --c2g;
+    if (NORM_EVEN) { high_fw -= (uint32_t)GOOD_SCORE << SCORE_SHIFT; thr_w -= (uint32_t)GOOD_SCORE << SCORE_SHIFT; }
   }
   // after the loop: where the call finished.  corner_slot: the slot of the target corner (its X word is needed when the corner
   // counts as reached); returns whether the caller has to deliver that word (finish2) or the best cell's word stands.
@@ -256,12 +271,13 @@ struct DiagCtl {
     }
     return false;
   }
+  template <bool NORM = false>      // (NORM: fin_w is a word of anti-diagonal FinishCt in the normalised frame)
   PG_HD void finish2(uint32_t fin_w, int32_t FinishK, int32_t Astart, int32_t Bstart, int32_t& Aend, int32_t& Bend, int32_t& errors, int32_t& score) const {
     const int32_t fi = (FinishCt - FinishK) / 2, fj = (FinishCt + FinishK) / 2;
     Aend = fwd ? Astart + fi - 1 : Astart - fi + 1;
     Bend = fwd ? Bstart + fj - 1 : Bstart - fj + 1;
     errors = (int32_t)w_errors(fin_w);
-    score = w_score(fin_w);
+    score = NORM ? (int32_t)(fin_w >> SCORE_SHIFT) - (int32_t)NORM_BIAS + norm_offset(FinishCt) : w_score(fin_w);
   }
 };
 
@@ -275,7 +291,7 @@ struct DiagWaveEmu {
   long cells = 0, calls = 0, moves = 0, fails = 0;
   uint32_t last_cells = 0, last_wmax = 0;
   DiagRegs<DPL> T[64];
-  template <int PAR>
+  template <int PAR, bool NORM>
   void refill(const DiagCtl& C, int32_t Astart, int32_t Bstart) {
     for (int l = 0; l < 64; ++l) {
       const int32_t k0 = DPL * l - HALF + C.shiftk;
@@ -288,7 +304,7 @@ struct DiagWaveEmu {
         if (R.clean(pa)) { ca |= (uint64_t)R.base(pa) << (2 * f); oka |= 1u << f; }
         if (Q.clean(pb)) { cb |= (uint64_t)Q.base(pb) << (2 * f); okb |= 1u << f; }
       }
-      diag_lane_refill<DPL, PAR>(T[l], ca, oka, cb, okb);
+      diag_lane_refill<DPL, PAR, NORM>(T[l], ca, oka, cb, okb);
     }
   }
   template <int PAR, bool FORCED>
@@ -299,7 +315,7 @@ struct DiagWaveEmu {
       else { nbX[l] = l < 63 ? T[l + 1].X[0] : 0u; nbG[l] = l < 63 ? T[l + 1].I[0] : 0u; }
     }
     for (int l = 0; l < 64; ++l)
-      diag_lane_step<DPL, PAR, !FORCED>(T[l], nbX[l], nbG[l], (uint32_t)(DPL * l), (uint32_t)C.lo, (uint32_t)(C.hi - C.lo), DiagRelabel{~W_STATE, ST_INSERT, ST_MATCH}, key[l], keyw[l]);
+      diag_lane_step<DPL, PAR, !FORCED, !FORCED>(T[l], nbX[l], nbG[l], (uint32_t)(DPL * l), (uint32_t)C.lo, (uint32_t)(C.hi - C.lo), DiagRelabel{~W_STATE, ST_INSERT, ST_MATCH}, key[l], keyw[l]);
     bool any = false; uint32_t gmin = 0, gmax = 0;
     if (!FORCED) {
       uint32_t gk = 0, gw = 0;
@@ -312,7 +328,7 @@ struct DiagWaveEmu {
           if ((bits >> s) & 1u) { const uint32_t g = (uint32_t)(DPL * l + s); if (!any) { gmin = g; any = true; } gmax = g; }
       }
     }
-    C.template end_step<FORCED>(any, gmin, gmax);
+    C.template end_step<FORCED, !FORCED && PAR == 1>(any, gmin, gmax);
   }
   template <bool FORCED>
   bool run_(int32_t Astart, int32_t& Aend, int32_t Bstart, int32_t& Bend, unsigned m_o, int32_t band_w, int32_t& errors, int32_t& score, bool& reached) {
@@ -320,7 +336,7 @@ struct DiagWaveEmu {
     const bool fwd = m_o & DIRECTION_BIT;
     C.template init<DPL>(fwd ? Aend - Astart + 1 : Astart - Aend + 1, fwd ? Bend - Bstart + 1 : Bstart - Bend + 1, m_o, band_w);
     for (int l = 0; l < 64; ++l) for (int s = 0; s < DPL; ++s) { T[l].X[s] = 0u; T[l].D[s] = 0u; T[l].I[s] = 0u; T[l].mw[s] = 0u; }
-    T[HALF / DPL].X[0] = w_make(0, 0, ST_MATCH);
+    T[HALF / DPL].X[0] = FORCED ? w_make(0, 0, ST_MATCH) : (NORM_BIAS << SCORE_SHIFT) | ST_MATCH;      // (trimmed searches: the normalised frame)
     ++calls;
     for (;;) {
       if (C.template begin_step<FORCED>()) break;
@@ -335,14 +351,14 @@ struct DiagWaveEmu {
         C.template window_move<DPL>(n);
         ++moves;
       }
-      if (C.Dct == C.next_refill) { if (C.Dct & 1) refill<1>(C, Astart, Bstart); else refill<0>(C, Astart, Bstart); C.next_refill = C.Dct + 32; }
+      if (C.Dct == C.next_refill) { if (C.Dct & 1) refill<1, !FORCED>(C, Astart, Bstart); else refill<0, !FORCED>(C, Astart, Bstart); C.next_refill = C.Dct + 32; }
       C.template note_cells<true>();
       if (C.Dct & 1) step<1, FORCED>(C); else step<0, FORCED>(C);
     }
     uint32_t corner = 0, fin_w = C.high_w;
     int32_t FinishK = 0;
     if (C.template finish1<DPL>(reached, corner, FinishK)) fin_w = T[corner / DPL].X[corner % DPL];
-    C.finish2(fin_w, FinishK, Astart, Bstart, Aend, Bend, errors, score);
+    C.template finish2<!FORCED>(fin_w, FinishK, Astart, Bstart, Aend, Bend, errors, score);
     const unsigned long long nc = C.cells_total();
     cells += (long)nc;
     last_cells = nc > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)nc; last_wmax = (uint32_t)C.wmax;

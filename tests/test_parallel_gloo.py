@@ -223,12 +223,17 @@ def test_eight_rank_dress_rehearsal_of_the_bench_control_flow():
     # the balance bars are TIMING statements about 8 sleeping ranks on 8 cores: on a box that is busy with something else (load average
     # above half its cores before the test starts) a descheduled rank is what would be measured — the bar then only guards against a
     # broken deal (one rank doing everything: 8.0)
+    # — and even on an idle box ONE step of the two can catch a rank that the scheduler parked (seen: [1.02, 1.84]); a deal that is
+    # really uneven shows in EVERY step, so the tight bar is held against the best step and the broken-deal bar against the worst
     bar = 1.25 if os.getloadavg()[0] < 0.5 * (os.cpu_count() or 8) else 3.0
+
+    def balanced(imb):
+        return min(imb["max_over_mean_rank_busy_time_per_step"]) <= bar and imb["worst"] <= 3.0
     one = _rehearsal(1, ["--steps", "10", "--warmup", "0"], slow)
     default = _rehearsal(8, ["--steps", "2", "--warmup", "1"], slow)
     assert default["n_gpus"] == 8 and default["config"]["results_sha1_full_grid"] == one["config"]["results_sha1_full_grid"]
     assert default["imbalance"]["dealing"].startswith("fixed scrambled deal") and default["imbalance"]["chunks_per_rank_last_step"] == [1] * 8
-    assert default["imbalance"]["worst"] <= bar, default["imbalance"]
+    assert balanced(default["imbalance"]), default["imbalance"]
     assert default["value"] > 2.0 * one["value"], (one["value"], default["value"])      # (2.5 on an idle 8-core box; the bar leaves room for a busy one)
     eight = _rehearsal(8, ["--steps", "2", "--warmup", "1", "--dynamic-deal"], slow)
     assert one["n_gpus"] == 1 and eight["n_gpus"] == 8 and eight["scaling"] == "weak" and "REHEARSAL" in eight["data"]
@@ -237,7 +242,7 @@ def test_eight_rank_dress_rehearsal_of_the_bench_control_flow():
     assert eight["series"]["strong_step"]["rows_per_step"] == 100 and eight["series"]["strong_step"]["pairs_per_s"] > 0
     imb = eight["imbalance"]
     assert imb["dealing"].startswith("guided chunks") and "job-store" in imb["dealing"] and len(imb["chunks_per_rank_last_step"]) == 8
-    assert imb["worst"] <= bar, imb
+    assert balanced(imb), imb
     # the weak series scales: 8 ranks do 8 x the rows per step (not 8 x here: the step's all-gather and grid assembly run on the CPU
     # over gloo in this rehearsal — 64 MB per step through loopback with 8 processes on a few cores; on the GPU box they are RCCL / HBM)
     assert eight["value"] > 2.0 * one["value"], (one["value"], eight["value"])
