@@ -108,6 +108,20 @@ PG_HD uint32_t w_step_norm(uint32_t w, uint32_t miss_window) {
 #endif
   return w_sat_sub(w, sign & (((uint32_t)(GOOD_SCORE - BAD_SCORE) << SCORE_SHIFT) - 1u));
 }
+// w_step with the match bit as the SIGN of a window word (the wave engines' forced runs, which stay in the plain frame): the sign
+// spread over the word selects the price — add GOOD + |BAD| on a match, then pay |BAD| and one error either way (a match never
+// saturates: it ends above where it started) — in full-rate instructions; the reach test stays a compare and a select.
+PG_HD uint32_t w_step_window(uint32_t w, uint32_t match_window) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  uint32_t sign;
+  asm("v_ashrrev_i32 %0, 31, %1" : "=v"(sign) : "v"(match_window));
+  constexpr uint32_t MISS = ((uint32_t)(-BAD_SCORE) << SCORE_SHIFT) - 1u, LIFT = ((uint32_t)GOOD_SCORE << SCORE_SHIFT) + MISS;
+  const uint32_t t = w_sat_sub(w + (sign & LIFT), MISS);
+  return w >= W_ONE ? t : 0u;
+#else
+  return w_step(w, (int32_t)match_window < 0);
+#endif
+}
 PG_HD uint32_t w_max3(uint32_t a, uint32_t b, uint32_t c) { const uint32_t m = a > b ? a : b; return m > c ? m : c; }
 
 struct Cell { uint32_t D, I, M, X; };   // the three states and X = the best of them (labelled with the winner's state)

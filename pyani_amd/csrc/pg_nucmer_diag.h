@@ -86,7 +86,7 @@ PG_HD void diag_lane_step(DiagRegs<DPL>& T, uint32_t nbX, uint32_t nbG, uint32_t
     const bool in = (uint32_t)(gofs + (uint32_t)s) <= gspan;
     const uint32_t mk = in ? rel.mask : 0u;
     const uint32_t d = (dc > dx ? dc : dx) & mk /* | ST_DELETE = 0 */, i = ((ic > ix ? ic : ix) & mk) | rel.st_insert;
-    const uint32_t m = ((NORM ? w_step_norm(T.X[s], T.mw[s]) : w_step(T.X[s], (int32_t)T.mw[s] < 0)) & mk) | rel.st_match;
+    const uint32_t m = ((NORM ? w_step_norm(T.X[s], T.mw[s]) : w_step_window(T.X[s], T.mw[s])) & mk) | rel.st_match;
     T.mw[s] <<= 2;
     T.X[s] = w_max3(d, i, m); T.D[s] = d; T.I[s] = i;
     if (TRACK) {
@@ -129,7 +129,9 @@ PG_HD uint32_t diag_lane_alive(const DiagRegs<DPL>& T, uint32_t thr) {
 // e_s = (s ^ PAR) & 1, column j_s = i_s + k0 + s.  ca / oka: the codes (2 bits each) / clean bits of the 32 A rows from row
 // i_{DPL-1} on (field f = row i_{DPL-1} + f: the caller has undone direction and strand), cb / okb: the 32 B columns from column
 // j_0 on.  The offsets of slot s inside the two windows are compile-time constants.
-template <int DPL, int PAR, bool NORM = false>
+// CLEAN: every base of both windows is a clean one (oka & okb all ones — the caller's test, wave-wide on the device): the sixteen
+// clean bits per slot need not be spread over the 2-bit fields, which is half of a refill's instructions.
+template <int DPL, int PAR, bool NORM = false, bool CLEAN = false>
 PG_HD void diag_lane_refill(DiagRegs<DPL>& T, uint64_t ca, uint32_t oka, uint64_t cb, uint32_t okb) {
   constexpr int e_last = ((DPL - 1) ^ PAR) & 1, e_0 = PAR & 1;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -143,7 +145,7 @@ PG_HD void diag_lane_refill(DiagRegs<DPL>& T, uint64_t ca, uint32_t oka, uint64_
     const uint32_t eq = ~(x | (x >> 1)) & 0x55555555u;
     // cell t of the slot at bit 31 - 2 t: the fields in reverse order, one bit up
     // (NORM: the MISMATCH bits — unclean bases included — so that the step can AND the mismatch price with the window's sign)
-    const uint32_t hit = eq & spread16((oka >> oa) & (okb >> ob));
+    const uint32_t hit = CLEAN ? eq : eq & spread16((oka >> oa) & (okb >> ob));
     T.mw[s] = rev16_fields(NORM ? hit ^ 0x55555555u : hit) << 1;
   }
 }
@@ -304,7 +306,8 @@ struct DiagWaveEmu {
         if (R.clean(pa)) { ca |= (uint64_t)R.base(pa) << (2 * f); oka |= 1u << f; }
         if (Q.clean(pb)) { cb |= (uint64_t)Q.base(pb) << (2 * f); okb |= 1u << f; }
       }
-      diag_lane_refill<DPL, PAR, NORM>(T[l], ca, oka, cb, okb);
+      if ((oka & okb) == 0xFFFFFFFFu) diag_lane_refill<DPL, PAR, NORM, true>(T[l], ca, oka, cb, okb);      // (the device decides wave-wide; same words either way)
+      else diag_lane_refill<DPL, PAR, NORM, false>(T[l], ca, oka, cb, okb);
     }
   }
   template <int PAR, bool FORCED>
