@@ -46,9 +46,9 @@ PG_HD uint32_t spread16(uint32_t m) {      // bit t (t < 16) -> bit 2 t
 }
 
 // ---- per-lane code -------------------------------------------------------------------------------------------------------
-// The cells of one lane on an anti-diagonal of parity PAR: slots s = PAR, PAR + 2, ...  nbX / nbG: the X word and the D (PAR = 0:
-// left neighbour = slot DPL - 1 of the lane below) or I (PAR = 1: up neighbour = slot 0 of the lane above) word that slot needs
-// from the neighbouring lane.  g0 = DPL * lane; slots in [glo, glo + gspan] are computed, the others of this parity are zeroed
+// The cells of one lane on an anti-diagonal of parity PAR: slots s = PAR, PAR + 2, ...  nbM: the edge word of the neighbouring lane (diag_lane_edge
+// below — PAR = 0: the left neighbour of slot 0 is slot DPL - 1 of the lane below; PAR = 1: the up neighbour of slot DPL - 1 is
+// slot 0 of the lane above).  g0 = DPL * lane; slots in [glo, glo + gspan] are computed, the others of this parity are zeroed
 // ("not computed": what their later readers must see).  key / keyw: the lane's best cell as (score field | slot) and its word —
 // ties go to the larger slot = larger column, as MUMmer's ">=" scan does (TRACK = false: forced runs track nothing).  A slot
 // outside the range has score field 0, i.e. key = its slot number alone: below every reachable cell's key.
@@ -66,26 +66,41 @@ PG_HD uint32_t spread16(uint32_t m) {      // bit t (t < 16) -> bit 2 t
 // full-rate instructions of gfx950 (tools/ubench/valu_issue.hip: 2.3 cycles per SIMD against 4.2 for compare / select) where
 // the plain form needs add, saturating subtract, two compares and two selects.
 struct DiagRelabel { uint32_t mask, st_insert, st_match; };
+// What a lane's EDGE slot offers the neighbouring lane on an anti-diagonal of parity PAR: the better of its two gap candidates,
+// already priced (PAR = 0: slot DPL - 1 as the LEFT neighbour of the next lane's slot 0, i.e. its delete candidates; PAR = 1: slot
+// 0 as the UP neighbour of the lane below's slot DPL - 1, its insert candidates).  Priced on the sending side, ONE word crosses
+// the lanes per step instead of two, and the receiving side's first use of it is a plain `and` the DPP move folds into.
+template <int DPL, int PAR, bool NORM = false>
+PG_HD uint32_t diag_lane_edge(const DiagRegs<DPL>& T) {
+  constexpr int32_t RISE = NORM && PAR == 0 ? GOOD_SCORE : 0;
+  const uint32_t c = w_gap(PAR == 0 ? T.D[DPL - 1] : T.I[0], CONT_GAP_SCORE - RISE), x = w_gap(PAR == 0 ? T.X[DPL - 1] : T.X[0], OPEN_GAP_SCORE - RISE);
+  return c > x ? c : x;
+}
 template <int DPL, int PAR, bool TRACK, bool NORM = false>
-PG_HD void diag_lane_step(DiagRegs<DPL>& T, uint32_t nbX, uint32_t nbG, uint32_t g0, uint32_t glo, uint32_t gspan, const DiagRelabel& rel,
+PG_HD void diag_lane_step(DiagRegs<DPL>& T, uint32_t nbM, uint32_t g0, uint32_t glo, uint32_t gspan, const DiagRelabel& rel,
                           uint32_t& key, uint32_t& keyw) {
   key = 0u; keyw = 0u;
   const uint32_t gofs = g0 - glo;
+  constexpr int32_t RISE = NORM && PAR == 0 ? GOOD_SCORE : 0;      // (NORM: the offset moves on the even anti-diagonals)
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
   for (int s = PAR; s < DPL; s += 2) {
-    const uint32_t lX = s == 0 ? nbX : T.X[s == 0 ? 0 : s - 1], lD = s == 0 ? nbG : T.D[s == 0 ? 0 : s - 1];
-    const uint32_t uX = s == DPL - 1 ? nbX : T.X[s == DPL - 1 ? s : s + 1], uI = s == DPL - 1 ? nbG : T.I[s == DPL - 1 ? s : s + 1];
-    constexpr int32_t RISE = NORM && PAR == 0 ? GOOD_SCORE : 0;      // (NORM: the offset moves on the even anti-diagonals)
-    const uint32_t dc = w_gap(lD, CONT_GAP_SCORE - RISE), dx = w_gap(lX, OPEN_GAP_SCORE - RISE);
-    const uint32_t ic = w_gap(uI, CONT_GAP_SCORE - RISE), ix = w_gap(uX, OPEN_GAP_SCORE - RISE);
+    // the slot's delete candidates come from slot s - 1 (s = 0: the lane below's edge word nbM), its insert candidates from slot
+    // s + 1 (s = DPL - 1: the lane above's edge word)
+    uint32_t dm, im;
+    if (s == 0) dm = nbM;
+    else { const uint32_t dc = w_gap(T.D[s - 1], CONT_GAP_SCORE - RISE), dx = w_gap(T.X[s - 1], OPEN_GAP_SCORE - RISE); dm = dc > dx ? dc : dx; }
+    if (s == DPL - 1) im = nbM;
+    else { const uint32_t ic = w_gap(T.I[s + 1], CONT_GAP_SCORE - RISE), ix = w_gap(T.X[s + 1], OPEN_GAP_SCORE - RISE); im = ic > ix ? ic : ix; }
     // a slot outside the range keeps nothing but its state label: a word with score field 0 is unreachable whatever its low bits
     // (gaps and mismatches saturate it to 0, a match step tests the field, trimming and the best-cell key look at the field), so
     // ONE select — of the re-labelling mask — takes the place of three on the results
     const bool in = (uint32_t)(gofs + (uint32_t)s) <= gspan;
     const uint32_t mk = in ? rel.mask : 0u;
-    const uint32_t d = (dc > dx ? dc : dx) & mk /* | ST_DELETE = 0 */, i = ((ic > ix ? ic : ix) & mk) | rel.st_insert;
+    // (the edge word's insert label is ADDED — the mask has cleared those bits, so it is the same word — because `and` then `add`
+    // are two VOP2 instructions the DPP move folds into, where the fused and-or is a VOP3 one that needs the move in front)
+    const uint32_t d = dm & mk /* | ST_DELETE = 0 */, i = s == DPL - 1 ? (im & mk) + rel.st_insert : (im & mk) | rel.st_insert;
     const uint32_t m = ((NORM ? w_step_norm(T.X[s], T.mw[s]) : w_step_window(T.X[s], T.mw[s])) & mk) | rel.st_match;
     T.mw[s] <<= 2;
     T.X[s] = w_max3(d, i, m); T.D[s] = d; T.I[s] = i;
@@ -312,13 +327,13 @@ struct DiagWaveEmu {
   }
   template <int PAR, bool FORCED>
   void step(DiagCtl& C) {
-    uint32_t nbX[64], nbG[64], key[64], keyw[64];
+    uint32_t nbM[64], key[64], keyw[64];
     for (int l = 0; l < 64; ++l) {
-      if (PAR == 0) { nbX[l] = l > 0 ? T[l - 1].X[DPL - 1] : 0u; nbG[l] = l > 0 ? T[l - 1].D[DPL - 1] : 0u; }
-      else { nbX[l] = l < 63 ? T[l + 1].X[0] : 0u; nbG[l] = l < 63 ? T[l + 1].I[0] : 0u; }
+      if (PAR == 0) nbM[l] = l > 0 ? diag_lane_edge<DPL, PAR, !FORCED>(T[l - 1]) : 0u;
+      else nbM[l] = l < 63 ? diag_lane_edge<DPL, PAR, !FORCED>(T[l + 1]) : 0u;
     }
     for (int l = 0; l < 64; ++l)
-      diag_lane_step<DPL, PAR, !FORCED, !FORCED>(T[l], nbX[l], nbG[l], (uint32_t)(DPL * l), (uint32_t)C.lo, (uint32_t)(C.hi - C.lo), DiagRelabel{~W_STATE, ST_INSERT, ST_MATCH}, key[l], keyw[l]);
+      diag_lane_step<DPL, PAR, !FORCED, !FORCED>(T[l], nbM[l], (uint32_t)(DPL * l), (uint32_t)C.lo, (uint32_t)(C.hi - C.lo), DiagRelabel{~W_STATE, ST_INSERT, ST_MATCH}, key[l], keyw[l]);
     bool any = false; uint32_t gmin = 0, gmax = 0;
     if (!FORCED) {
       uint32_t gk = 0, gw = 0;
