@@ -225,6 +225,18 @@ struct DiagCtl {
     }
     return lo > hi ? 2 : 0;
   }
+  // begin_step as ONE decision (the device's step loop: a scalar compare + branch less per anti-diagonal): true = compute anti-diagonal Dct
+  template <bool FORCED>
+  PG_HD bool begin_step_go() {
+    lo = ga - 1 > c1g ? ga - 1 : c1g; hi = gb + 1 < c2g ? gb + 1 : c2g;
+    if (FORCED && banded) {
+      if (lo < kming) lo = kming;
+      if (hi > kmaxg) hi = kmaxg;
+      if ((lo + Dct) & 1) ++lo;
+      if ((hi + Dct) & 1) --hi;
+    }
+    return ((Dend - Dct) | (hi - lo)) >= 0;      // Dct <= Dend && lo <= hi (the misfit mark Dend = INT32_MIN is set when the loop is left)
+  }
   // How many LANES the window has to move before this step (0: fine; INT32_MIN: the band does not fit the window).  The slots
   // lo - 1 and hi + 1 are read, so two slots of margin are kept on either side.
   template <int DPL>
