@@ -111,15 +111,26 @@ PG_HD uint32_t w_step_norm(uint32_t w, uint32_t miss_window) {
 // w_step with the match bit as the SIGN of a window word (the wave engines' forced runs, which stay in the plain frame): the sign
 // spread over the word selects the price — add GOOD + |BAD| on a match, then pay |BAD| and one error either way (a match never
 // saturates: it ends above where it started) — in full-rate instructions; the reach test stays a compare and a select.
+PG_HD uint32_t w_step_mask(uint32_t w, uint32_t match_mask) {      // match_mask: all ones on a match, 0 otherwise
+  constexpr uint32_t MISS = ((uint32_t)(-BAD_SCORE) << SCORE_SHIFT) - 1u, LIFT = ((uint32_t)GOOD_SCORE << SCORE_SHIFT) + MISS;
+  const uint32_t t = w_sat_sub(w + (match_mask & LIFT), MISS);
+  return w >= W_ONE ? t : 0u;
+}
 PG_HD uint32_t w_step_window(uint32_t w, uint32_t match_window) {
 #if defined(__HIP_DEVICE_COMPILE__)
   uint32_t sign;
   asm("v_ashrrev_i32 %0, 31, %1" : "=v"(sign) : "v"(match_window));
-  constexpr uint32_t MISS = ((uint32_t)(-BAD_SCORE) << SCORE_SHIFT) - 1u, LIFT = ((uint32_t)GOOD_SCORE << SCORE_SHIFT) + MISS;
-  const uint32_t t = w_sat_sub(w + (sign & LIFT), MISS);
-  return w >= W_ONE ? t : 0u;
+  return w_step_mask(w, sign);
 #else
   return w_step(w, (int32_t)match_window < 0);
+#endif
+}
+// bit `bit` of `word` as a match mask (one v_bfe_i32 on the device)
+PG_HD uint32_t w_bit_mask(uint32_t word, int bit) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return (uint32_t)__builtin_amdgcn_sbfe((int)word, (unsigned)bit, 1u);
+#else
+  return 0u - ((word >> bit) & 1u);
 #endif
 }
 PG_HD uint32_t w_max3(uint32_t a, uint32_t b, uint32_t c) { const uint32_t m = a > b ? a : b; return m > c ? m : c; }
