@@ -15,6 +15,9 @@
 // tests/test_anim_cpu.py hold it against ScalarEngine on the MUMmer fixtures, so the layout is checked before it meets a GPU).
 // Results are those of pgn::ScalarEngine word for word: same cells (MUMmer's dynamic band: grows by one cell per side and
 // anti-diagonal, trimmed at MAX_DIFF below the best, trimmed cells stay readable), same tie order, same riding error counts.
+// Two score FRAMES (round 6): forced runs keep ScalarEngine's words (score + SCORE_BIAS: their floor is part of the definition);
+// trimmed searches hold score - GOOD_SCORE * floor(Dct / 2) + NORM_BIAS (diag_lane_step<NORM>), in which a match leaves the word as
+// it is — the same maxima, ties and errors, cheaper instructions; DiagCtl::finish2<NORM> hands back the plain score.
 #pragma once
 #include <stdint.h>
 #include "pg_nucmer_core.h"
