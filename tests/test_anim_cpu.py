@@ -388,3 +388,32 @@ def test_forced_runs_whose_optimal_path_dips_far_below_zero():
     subprocess.run(["g++", "-O2", "-std=c++17", "-pthread", f"-I{ROOT / 'pyani_amd' / 'csrc'}", str(exe) + ".cpp", "-o", str(exe)], check=True)
     out = subprocess.run([str(exe)], capture_output=True, text=True)
     assert out.returncode == 0 and out.stdout.count(" ok") == 6 and "WRONG" not in out.stdout, out.stdout
+
+
+def test_normalised_score_frame_of_the_trimmed_searches_equals_the_plain_one(tmp_path):
+    """the wave engines run MUMmer's trimmed searches in a NORMALISED frame (pg_nucmer_diag.h diag_lane_step<NORM>:
+    the score field holds score - 3 floor(d / 2) + 32 767, a match keeps the word, the best / threshold words slide with the frame);
+    pgn::ScalarEngine's plain words are the definition.  tools/anim_debug/norm_check.cpp drives both directly on searches built for the
+    corners of the frame's range — a 10 000 x 10 000 search whose score creeps while the offset runs to 30 000 (live words in the
+    bottom of the field), 10 000 matching bases (the top), indels on odd and even anti-diagonals, unclean bases, a band trimmed away, tiny
+    and one-row rectangles — forwards and backwards, to the target and to the best cell: end coordinates, errors, score and `reached`
+    must be equal in all 100.  A SABOTAGED frame (the offset rising by 2 instead of GOOD_SCORE = 3 per pair of anti-diagonals) must
+    be caught: the check is not vacuous."""
+    csrc = ROOT / "pyani_amd" / "csrc"
+    exe = ROOT / "tools" / "anim_debug" / "norm_check"
+    subprocess.run(["g++", "-O2", "-std=c++17", f"-I{csrc}", str(exe) + ".cpp", "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0 and "100 searches on both engines (100 on the emulated wave engine), 0 differ" in out.stdout and "WRONG" not in out.stdout, out.stdout
+    # the same program against a copy of the headers whose offset is wrong
+    bad = tmp_path / "csrc"
+    bad.mkdir()
+    for f in csrc.glob("*.h"):
+        text = f.read_text()
+        if f.name == "pg_nucmer_core.h":
+            assert "return GOOD_SCORE * (d >> 1);" in text
+            text = text.replace("return GOOD_SCORE * (d >> 1);", "return 2 * (d >> 1);")
+        (bad / f.name).write_text(text)
+    bexe = tmp_path / "norm_check_sabotaged"
+    subprocess.run(["g++", "-O2", "-std=c++17", f"-I{bad}", str(exe) + ".cpp", "-o", str(bexe)], check=True)
+    out = subprocess.run([str(bexe)], capture_output=True, text=True)
+    assert out.returncode == 1 and "WRONG" in out.stdout, out.stdout[-2000:]
