@@ -190,7 +190,8 @@ struct DiagCtl {
   int32_t N, M, NM;
   bool fwd, forced, optimal, banded;
   int32_t Dct, Dend;
-  int32_t ga, gb;                   // survivors of the latest anti-diagonal (slots)
+  int32_t ga, gb;                   // the latest anti-diagonal's lowest survivor - 1 / highest + 1 (slots): the next one's band before the clips —
+                                    // kept WITH the +-1 so that it folds into the constants the survivors are built from (two scalar adds per step)
   int32_t lo, hi;                   // range of the current one (slots)
   int32_t c1g, c2g;                 // the matrix's far sides on the current anti-diagonal: diagonals Dct - 2 N and 2 M - Dct, as slots
   int32_t kming, kmaxg;             // a forced run's band (slots)
@@ -208,7 +209,7 @@ struct DiagCtl {
     fwd = m_o & DIRECTION_BIT; forced = m_o & FORCED_BIT; optimal = m_o & OPTIMAL_BIT; banded = band_w >= 0;
     kming = (M - N < 0 ? M - N : 0) - band_w + HALF; kmaxg = (M - N > 0 ? M - N : 0) + band_w + HALF;
     Dct = 1; Dend = forced ? NM : (NM < BREAK_LEN ? NM : BREAK_LEN);      // (FinishCt = 0: the break rule allows BREAK_LEN steps)
-    ga = HALF; gb = HALF; lo = HALF; hi = HALF; shiftk = 0;
+    ga = HALF - 1; gb = HALF + 1; lo = HALF; hi = HALF; shiftk = 0;
     c1g = 1 - 2 * N + HALF; c2g = 2 * M - 1 + HALF;
     high_f = 0u; high_w = 0u; FinishCt = 0; FinishG = HALF; FinishShift = 0;
     high_fw = 0u; thr_w = (0u - (uint32_t)MAX_DIFF) << SCORE_SHIFT;
@@ -219,7 +220,7 @@ struct DiagCtl {
   template <bool FORCED>
   PG_HD int begin_step() {
     if (Dct > Dend) return 1;
-    lo = ga - 1 > c1g ? ga - 1 : c1g; hi = gb + 1 < c2g ? gb + 1 : c2g;
+    lo = ga > c1g ? ga : c1g; hi = gb < c2g ? gb : c2g;
     if (FORCED && banded) {
       if (lo < kming) lo = kming;
       if (hi > kmaxg) hi = kmaxg;
@@ -231,7 +232,7 @@ struct DiagCtl {
   // begin_step as ONE decision (the device's step loop: a scalar compare + branch less per anti-diagonal): true = compute anti-diagonal Dct
   template <bool FORCED>
   PG_HD bool begin_step_go() {
-    lo = ga - 1 > c1g ? ga - 1 : c1g; hi = gb + 1 < c2g ? gb + 1 : c2g;
+    lo = ga > c1g ? ga : c1g; hi = gb < c2g ? gb : c2g;
     if (FORCED && banded) {
       if (lo < kming) lo = kming;
       if (hi > kmaxg) hi = kmaxg;
@@ -282,9 +283,9 @@ struct DiagCtl {
   // frame's offset rises by GOOD_SCORE: the two words its cells are compared with follow (the best score itself stays)
   template <bool FORCED, bool NORM_EVEN = false>
   PG_HD void end_step(bool any, uint32_t gmin, uint32_t gmax) {
-    if (FORCED) { ga = lo; gb = hi; }
-    else if (any) { ga = (int32_t)gmin; gb = (int32_t)gmax; }
-    else { ga = 1; gb = 0; Dend = -1; }
+    if (FORCED) { ga = lo - 1; gb = hi + 1; }
+    else if (any) { ga = (int32_t)gmin - 1; gb = (int32_t)gmax + 1; }
+    else { ga = 0; gb = 1; Dend = -1; }
     ++Dct; ++c1g; --c2g;
     if (NORM_EVEN) { high_fw -= (uint32_t)GOOD_SCORE << SCORE_SHIFT; thr_w -= (uint32_t)GOOD_SCORE << SCORE_SHIFT; }
   }
